@@ -1,0 +1,331 @@
+/*
+ * opfx.h — C ABI of libopfx: MI355X-native batched AC power-flow + OPF-environment
+ * evaluation backend for opfgym.
+ *
+ * This is the drop-in boundary.  Every entry point replaces a
+ * piece of the reference's per-step Python path; citations are into
+ * /root/reference/opfgym/:
+ *
+ *   opfx_plan_create / opfx_ctx_create
+ *        one-time per grid; replaces the per-call structure work pandapower
+ *        redoes inside every `pp.runpp` (opf_env.py:703): bus typing, Ybus
+ *        assembly, Jacobian pattern, ordering and symbolic factorisation.
+ *   opfx_solve
+ *        replaces `self._run_power_flow(self.net)` (opf_env.py:657,
+ *        security_constrained.py:53) for B instances at once: Newton-Raphson
+ *        on given bus injections, returns V and branch loadings.
+ *   opfx_env_create
+ *        one-time; flattens what OpfEnv.__init__ wires up (opf_env.py:27-175):
+ *        action keys, observation keys, constraints (constraints.py:195-226),
+ *        cost tables (objective.py:6-87) and the reward function (reward.py).
+ *   opfx_step
+ *        replaces OpfEnv.step (opf_env.py:374-419) for B instances: apply
+ *        actions (:421-491), power flow (:646-662), objective (:493-500),
+ *        violations (:502-513), reward (:515-530), observation (:532-549).
+ *   opfx_reset
+ *        replaces OpfEnv.reset/_sampling/_set_simbench_state (opf_env.py:177-
+ *        372) and the benchmark envs' `_sampling` tails (voltage_control.py:
+ *        111-133, eco_dispatch.py:111-123, max_renewable.py:101-105).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary: every function returns
+ *     OPFX_OK (0) or a negative opfx_status; opfx_last_error() gives text.
+ *   - all `double*`/`int32_t*` data arguments of opfx_solve/opfx_step/
+ *     opfx_reset are DEVICE pointers (HIP), row-major, instance-major
+ *     ([B, n]); the caller owns them.  Plan/env descriptors are HOST pointers
+ *     and are copied during the call.
+ *   - work is enqueued on the caller's stream (`void* stream` = hipStream_t,
+ *     NULL = default stream) and is asynchronous; non-convergence is DATA
+ *     (converged[B], iterations[B], max_mismatch[B]), never an error code.
+ *   - one context per device; calls on one context are serialised by the
+ *     caller; no hidden global state.
+ */
+#ifndef OPFX_H
+#define OPFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPFX_VERSION_MAJOR 0
+#define OPFX_VERSION_MINOR 1
+#define OPFX_VERSION_PATCH 0
+
+typedef enum opfx_status {
+  OPFX_OK = 0,
+  OPFX_ERR_INVALID = -1,     /* bad argument / inconsistent descriptor   */
+  OPFX_ERR_HIP = -2,         /* a HIP runtime call failed                 */
+  OPFX_ERR_NO_DEVICE = -3,   /* no usable GPU                             */
+  OPFX_ERR_TOO_LARGE = -4,   /* grid does not fit the LDS-resident kernel */
+  OPFX_ERR_SINGULAR = -5     /* structurally singular case (no slack …)   */
+} opfx_status;
+
+enum { OPFX_PQ = 1, OPFX_PV = 2, OPFX_REF = 3 };
+
+/* ---- per-unit grid description (one topology, shared by the whole batch) ---
+ * Mirrors the pypower/pandapower `ppci` the reference builds inside runpp
+ * (SURVEY §8a rows P2/P3). */
+typedef struct opfx_case {
+  int32_t nb;                /* buses                                        */
+  int32_t nbr;               /* branches (lines + transformers), in service  */
+  double base_mva;
+  const int32_t* bus_type;   /* [nb] OPFX_PQ / OPFX_PV / OPFX_REF            */
+  const double* vm_set;      /* [nb] |V| set-point of PV/REF buses, start value else */
+  const double* va_set;      /* [nb] rad: REF angle; start angle for the others      */
+  const double* gs;          /* [nb] bus shunt conductance, p.u.             */
+  const double* bs;          /* [nb] bus shunt susceptance, p.u.             */
+  const int32_t* br_f;       /* [nbr] from bus                               */
+  const int32_t* br_t;       /* [nbr] to bus                                 */
+  const double* br_y;        /* [nbr*8] yff.re,yff.im,yft.re,yft.im,ytf.re,ytf.im,ytt.re,ytt.im */
+  const double* br_kf;       /* [nbr] loading_percent = max(|If|*kf, |It|*kt) */
+  const double* br_kt;       /* [nbr]                                        */
+} opfx_case;
+
+typedef struct opfx_plan opfx_plan;   /* host-side compiled structure        */
+typedef struct opfx_ctx opfx_ctx;     /* plan resident on one GPU            */
+typedef struct opfx_env opfx_env;     /* environment evaluator on a context  */
+
+typedef struct opfx_plan_info {
+  int32_t nb, nbr, nref, npv, npq;
+  int32_t nnz_y;             /* Ybus block entries (incl. diagonal)          */
+  int32_t nnz_j;             /* scalar Jacobian non-zeros, pypower layout    */
+  int32_t n_blk;             /* 2x2 LU blocks (Jacobian pattern + fill)      */
+  int32_t n_fill;            /* fill blocks                                  */
+  int32_t n_levels;          /* elimination levels                           */
+  int32_t n_targets;         /* forward update work items                    */
+  int32_t n_sources;         /* forward update terms                         */
+  int32_t n_uterms;          /* backward substitution terms                  */
+  int32_t max_level_width;   /* widest level in work items                   */
+  int32_t lds_doubles;       /* solver LDS footprint per instance (doubles)  */
+} opfx_plan_info;
+
+/* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
+ * CSR, level-scheduled fill-reducing ordering on the bus graph, symbolic block
+ * LU, elimination schedule. */
+int opfx_plan_create(const opfx_case* c, opfx_plan** out);
+void opfx_plan_destroy(opfx_plan* p);
+int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* out);
+
+/* Read-back of the compiled schedule for tests/tools.  `which` selects one of
+ * the OPFX_ARR_* int32 arrays; returns its length (or copies up to `cap`
+ * entries into `out` when out != NULL). */
+enum {
+  OPFX_ARR_Y_PTR = 0, OPFX_ARR_Y_COL, OPFX_ARR_Y_BLK, OPFX_ARR_DIAG_BLK,
+  OPFX_ARR_FILL_BLK, OPFX_ARR_LEV_TPTR, OPFX_ARR_TGT_BLK, OPFX_ARR_TGT_SPTR,
+  OPFX_ARR_SRC_IK, OPFX_ARR_SRC_KK, OPFX_ARR_SRC_KJ, OPFX_ARR_LEV_PPTR,
+  OPFX_ARR_PIV_BUS, OPFX_ARR_PIV_UPTR, OPFX_ARR_U_BLK, OPFX_ARR_U_COL,
+  OPFX_ARR_BLK_ROW, OPFX_ARR_BLK_COL
+};
+int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* out, int64_t cap);
+/* Ybus values in the plan's CSR order: out_g/out_b [nnz_y]. */
+int opfx_plan_get_ybus(const opfx_plan* p, double* out_g, double* out_b);
+
+/* Upload a plan to GPU `device` (hipSetDevice ordinal). */
+int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out);
+void opfx_ctx_destroy(opfx_ctx* ctx);
+const char* opfx_last_error(void);
+void opfx_version(int* major, int* minor, int* patch);
+
+/* ---- pure power flow ------------------------------------------------------
+ * p_inj/q_inj [B,nb]: net bus injections (generation - demand), p.u.; q_inj is
+ * ignored at PV buses.  Outputs (any may be NULL): vm [B,nb] p.u., va [B,nb]
+ * rad, loading [B,nbr] percent, s_ref [B,nref*2] slack-bus injection P,Q p.u.
+ * (interleaved, REF buses in increasing bus order), converged [B], iterations
+ * [B], max_mismatch [B] (final inf-norm of [dP;dQ], p.u.).
+ * q_inj at a PV bus is the reactive injection of everything EXCEPT the voltage-
+ * controlling generator there (so Qgen = Qcalc - q_inj); qg_min/qg_max [nb]
+ * p.u. (NULL = unlimited) are the generator capability used by enforce_q_lims.
+ * outage: NULL (all branches in service) or [B] int32: the one branch that is
+ * out of service in that instance, -1 = none — the N-1 axis of
+ * security_constrained.py:44-66. */
+typedef struct opfx_solve_opts {
+  double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
+  int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */
+  int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits */
+} opfx_solve_opts;
+
+int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
+               const double* qg_min, const double* qg_max,
+               const int32_t* outage, const opfx_solve_opts* opts,
+               double* vm, double* va, double* loading, double* s_ref,
+               uint8_t* converged, int32_t* iterations, double* max_mismatch,
+               void* stream);
+
+/* ---- environment evaluation ------------------------------------------------
+ * Per-instance state lives in one row-major column store x[B,nx] owned by the
+ * caller: every per-instance table column of the reference net that the hot
+ * path reads or writes (load/sgen/storage/gen p_mw,q_mvar as TABLE values,
+ * i.e. before `scaling`; per-reset limit columns such as max_q_mvar; sampled
+ * prices) has a slot in x.  Indices below are slots in x unless stated. */
+
+enum { OPFX_SRC_X = 0, OPFX_SRC_RESULT = 1 };
+/* result bank layout (per instance), index space of OPFX_SRC_RESULT sources
+ * and of constraint elements: [vm nb | va_degree nb | loading nbr |
+ * p_ext nref | q_ext nref | q_gen nb (Mvar generated at PV buses, 0 else)] */
+
+enum { OPFX_COST_UNIT = 0, OPFX_COST_EXT_GRID = 1, OPFX_COST_GEN = 2 };
+enum { OPFX_REWARD_SUMMATION = 0, OPFX_REWARD_REPLACEMENT = 1,
+       OPFX_REWARD_PARAMETERIZED = 2, OPFX_REWARD_ONLY_OBJECTIVE = 3 };
+
+typedef struct opfx_env_desc {
+  int32_t nx;                /* columns of the per-instance store           */
+  /* bus injections: P_i = sum coef*x[slot] over p-list of bus i (p.u.) */
+  const int32_t* pinj_ptr;   /* [nb+1] */
+  const int32_t* pinj_slot;  const double* pinj_coef;
+  const int32_t* qinj_ptr;   /* [nb+1] */
+  const int32_t* qinj_slot;  const double* qinj_coef;
+  /* reactive capability of PV buses for enforce_q_lims: Mvar → p.u. bounds  */
+  const double* qg_min;      /* [nb] p.u. (NaN/inf = unlimited) or NULL      */
+  const double* qg_max;      /* [nb] */
+  /* actions (opf_env.py:421-491) */
+  int32_t na;
+  const int32_t* act_slot;   /* [na] column written: x = setpoint/scaling    */
+  const double* act_scaling; /* [na] */
+  const int32_t* act_lo_slot;/* [na] range source column, or -1 → act_lo_const */
+  const int32_t* act_hi_slot;
+  const double* act_lo_const;/* [na] */
+  const double* act_hi_const;
+  const int32_t* clamp_lo_slot; /* [na] -2 none, -1 const, >=0 column (autoscale off / diff mode, :464-470) */
+  const int32_t* clamp_hi_slot;
+  const double* clamp_lo_const;
+  const double* clamp_hi_const;
+  int32_t clamp_enabled;
+  double diff_action_step_size;   /* 0 → absolute set-points (:451-461)     */
+  double clipped_action_penalty;  /* :403-404 */
+  /* costs (objective.py:34-77); coefficient table = [npoly*6 | npwl*nseg*3] */
+  int32_t npoly, npwl, nseg;
+  const int32_t* cost_kind;  /* [npoly+npwl] OPFX_COST_*                     */
+  const int32_t* cost_pidx;  /* UNIT: slot of p_mw; EXT_GRID: ref ordinal; GEN: bus */
+  const int32_t* cost_qidx;  /* UNIT: slot of q_mvar (or -1)                 */
+  const double* cost_scale;  /* UNIT: scaling; others 1                      */
+  const int32_t* pwl_is_q;   /* [npwl] */
+  const double* cost_coef;   /* [npoly*6 + npwl*nseg*3] cp0,cp1,cp2,cq0,cq1,cq2 | lo,hi,price */
+  int32_t nprice;            /* per-instance coefficient overrides           */
+  const int32_t* price_slot; /* [nprice] column of x holding the price       */
+  const int32_t* price_coef; /* [nprice] index into cost_coef it replaces    */
+  /* constraints (constraints.py:70-128): nc groups over result-bank elements */
+  int32_t nc;
+  const int32_t* con_ptr;    /* [nc+1] → elements                            */
+  const int32_t* con_src;    /* [ncel] result-bank index                     */
+  const double* con_min;     /* [ncel] NaN = no lower bound                  */
+  const double* con_max;     /* [ncel] NaN = no upper bound                  */
+  const double* con_autoscale;   /* [nc] multiplier (20, 1/30, … or 1)       */
+  const double* con_penalty_factor;
+  const double* con_penalty_power;
+  const double* con_count_penalty;
+  const int32_t* con_worst_case; /* [nc] only_worst_case_violations          */
+  /* reward (reward.py:61-98, 219-320) */
+  int32_t reward_kind;
+  double penalty_weight;     /* NaN → None (plain sum, reward.py:79-80)      */
+  double clip_lo, clip_hi;   /* NaN → no clipping                            */
+  double objective_factor, objective_bias, penalty_factor, penalty_bias;
+  double valid_reward, invalid_penalty, invalid_objective_share;
+  int32_t diff_objective;    /* opf_env.py:497-498                           */
+  /* observation (opf_env.py:532-549): obs[k] = bank(obs_kind[k])[obs_idx[k]] */
+  int32_t nobs;
+  const int32_t* obs_kind;   /* OPFX_SRC_X / OPFX_SRC_RESULT                 */
+  const int32_t* obs_idx;
+  int32_t steps_per_episode; /* opf_env.py:406-414                           */
+  /* N-1 security constraints (security_constrained.py:37-68): after the base
+   * case, every listed branch is taken out in turn, the case is re-solved and
+   * its violations are accumulated (valids &=, violations +=, penalties +=). */
+  int32_t n_cont;
+  const int32_t* cont_branch;     /* [n_cont] case branch index              */
+  double not_converged_penalty;   /* security_constrained.py:27,63-64        */
+} opfx_env_desc;
+
+int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);
+void opfx_env_destroy(opfx_env* env);
+
+typedef struct opfx_step_io {
+  /* inputs */
+  double* x;                 /* [B,nx] in/out: action set-points are written back */
+  const double* action;      /* [B,na] in [0,1] (clipped inside, opf_env.py:429)  */
+  const double* initial_obj; /* [B] or NULL (diff_objective)                 */
+  const int32_t* step_in_episode; /* [B] or NULL (→ 1)                       */
+  const int32_t* outage;     /* [B] or NULL: branch out of service in the base case, -1 none */
+  /* outputs, any may be NULL */
+  double* obs;               /* [B,nobs]                                     */
+  double* reward;            /* [B]                                          */
+  uint8_t* terminated;       /* [B]                                          */
+  uint8_t* truncated;        /* [B]                                          */
+  uint8_t* valids;           /* [B,nc]                                       */
+  double* violations;        /* [B,nc]                                       */
+  double* penalties;         /* [B,nc]  info['unscaled_penalties']           */
+  double* cost;              /* [B]     info['cost']                         */
+  double* objective;         /* [B]     sum of the (negated) cost vector     */
+  double* results;           /* [B,nres] result bank                         */
+  double* mean_correction;   /* [B]                                          */
+  uint8_t* converged;        /* [B]                                          */
+  int32_t* iterations;       /* [B]                                          */
+  double* max_mismatch;      /* [B]                                          */
+} opfx_step_io;
+
+/* One env.step() for B instances: apply actions → injections → NR → results →
+ * objective → violations → reward → observation, one kernel launch.
+ * mode: 0 = full step; 1 = power flow for reset (pf_for_obs, opf_env.py:209-
+ * 218: no action applied, writes obs/results/objective only). */
+int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
+              const opfx_solve_opts* opts, int32_t mode, void* stream);
+
+/* ---- reset: SimBench-state sampling on the device (opf_env.py:317-372) -----
+ * Profile tables are uploaded once in SimBench's factored form: column j of a
+ * table is rel[:, typ[j]] * peak[j]; per-column min/max are precomputed once
+ * (defect D10 of the reference recomputes them on every reset). */
+typedef struct opfx_profile_desc {
+  int32_t n_steps, n_types, n_cols;
+  const double* rel;         /* [n_steps, n_types] row-major                 */
+  const int32_t* typ;        /* [n_cols] */
+  const double* peak;        /* [n_cols] */
+  const int32_t* slot;       /* [n_cols] destination column in x             */
+  const double* col_min;     /* [n_cols] clip range (opf_env.py:364-369)     */
+  const double* col_max;
+} opfx_profile_desc;
+
+/* post-sampling column programme: the envs' `_sampling` tails as a short list
+ * of element-wise VECTOR ops executed in order on the instance's row of x; op k
+ * works on columns dst[k]+j, a[k]+j for j < n[k]; c0/c1/c2 are per-element
+ * constant vectors given as offsets into `consts` (-1 = not used):
+ *   OPFX_OP_SET_CONST   x[dst] = c0
+ *   OPFX_OP_AFFINE      x[dst] = x[a]*c0 + c1            (max_p = p*scaling + eps)
+ *   OPFX_OP_SQRT_DIFF   x[dst] = sqrt(c0^2 - x[a]^2)     (q_max = sqrt(S^2 - P^2))
+ *   OPFX_OP_NEG         x[dst] = -x[a]
+ *   OPFX_OP_UNIFORM     x[dst] = (c0 + u*(c1-c0)) / c2,  u = uniform[b, a+j]
+ *                       (opf_env.py:278-284; here `a` indexes the draw vector)
+ */
+enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
+       OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4 };
+typedef struct opfx_reset_desc {
+  int32_t n_tables;
+  const opfx_profile_desc* tables;
+  int32_t n_ops;
+  const int32_t* op_code; const int32_t* op_dst; const int32_t* op_a; const int32_t* op_n;
+  const int32_t* op_c0; const int32_t* op_c1; const int32_t* op_c2;   /* offsets into consts */
+  int32_t n_consts;
+  const double* consts;
+  int32_t n_uniform;         /* uniform draws consumed per instance          */
+} opfx_reset_desc;
+
+int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d);
+
+/* step_idx [B] int32: SimBench time step per instance; noise [B, n_noise] or
+ * NULL: multiplicative noise factors, one per profile column in table order
+ * (opf_env.py:352-356; the caller draws them so that runs are reproducible
+ * from the caller's RNG); uniform [B, n_uniform] or NULL: U[0,1) draws consumed
+ * by OPFX_OP_UNIFORM ops in order.  Fills x [B,nx]. */
+int opfx_reset(opfx_env* env, int64_t B, const int32_t* step_idx,
+               const double* noise, const double* uniform, double* x, void* stream);
+
+/* Timing helper for bench.py: runs `reps` back-to-back opfx_step launches on
+ * `stream` between two hipEvents recorded on that stream and returns the
+ * elapsed milliseconds (device time of the timed region). */
+int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
+                    const opfx_solve_opts* opts, int32_t reps, void* stream,
+                    float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPFX_H */

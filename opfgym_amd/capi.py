@@ -1,0 +1,282 @@
+"""ctypes binding of libopfx (include/opfx.h).
+
+The reference project is pure Python and reaches native solvers through
+third-party wheels; `cffi` is not available here, so the thin FFI layer is
+`ctypes` over the C ABI.  There is deliberately NO fallback: if the library is
+missing or a GPU entry point fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libopfx.so')
+
+OK = 0
+PQ, PV, REF = 1, 2, 3
+SRC_X, SRC_RESULT = 0, 1
+COST_UNIT, COST_EXT_GRID, COST_GEN = 0, 1, 2
+REWARD_SUMMATION, REWARD_REPLACEMENT, REWARD_PARAMETERIZED, REWARD_ONLY_OBJECTIVE = 0, 1, 2, 3
+OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM = 0, 1, 2, 3, 4
+
+ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
+          'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
+          'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL']
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class OpfxError(RuntimeError):
+    pass
+
+
+class CaseStruct(C.Structure):
+    _fields_ = [('nb', C.c_int32), ('nbr', C.c_int32), ('base_mva', C.c_double),
+                ('bus_type', _pi), ('vm_set', _pd), ('va_set', _pd), ('gs', _pd), ('bs', _pd),
+                ('br_f', _pi), ('br_t', _pi), ('br_y', _pd), ('br_kf', _pd), ('br_kt', _pd)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'nb', 'nbr', 'nref', 'npv', 'npq', 'nnz_y', 'nnz_j', 'n_blk', 'n_fill', 'n_levels',
+        'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles')]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32)]
+
+
+class EnvDesc(C.Structure):
+    _fields_ = [
+        ('nx', C.c_int32),
+        ('pinj_ptr', _pi), ('pinj_slot', _pi), ('pinj_coef', _pd),
+        ('qinj_ptr', _pi), ('qinj_slot', _pi), ('qinj_coef', _pd),
+        ('qg_min', _pd), ('qg_max', _pd),
+        ('na', C.c_int32),
+        ('act_slot', _pi), ('act_scaling', _pd), ('act_lo_slot', _pi), ('act_hi_slot', _pi),
+        ('act_lo_const', _pd), ('act_hi_const', _pd),
+        ('clamp_lo_slot', _pi), ('clamp_hi_slot', _pi), ('clamp_lo_const', _pd), ('clamp_hi_const', _pd),
+        ('clamp_enabled', C.c_int32),
+        ('diff_action_step_size', C.c_double), ('clipped_action_penalty', C.c_double),
+        ('npoly', C.c_int32), ('npwl', C.c_int32), ('nseg', C.c_int32),
+        ('cost_kind', _pi), ('cost_pidx', _pi), ('cost_qidx', _pi), ('cost_scale', _pd),
+        ('pwl_is_q', _pi), ('cost_coef', _pd),
+        ('nprice', C.c_int32), ('price_slot', _pi), ('price_coef', _pi),
+        ('nc', C.c_int32), ('con_ptr', _pi), ('con_src', _pi), ('con_min', _pd), ('con_max', _pd),
+        ('con_autoscale', _pd), ('con_penalty_factor', _pd), ('con_penalty_power', _pd),
+        ('con_count_penalty', _pd), ('con_worst_case', _pi),
+        ('reward_kind', C.c_int32), ('penalty_weight', C.c_double),
+        ('clip_lo', C.c_double), ('clip_hi', C.c_double),
+        ('objective_factor', C.c_double), ('objective_bias', C.c_double),
+        ('penalty_factor', C.c_double), ('penalty_bias', C.c_double),
+        ('valid_reward', C.c_double), ('invalid_penalty', C.c_double),
+        ('invalid_objective_share', C.c_double), ('diff_objective', C.c_int32),
+        ('nobs', C.c_int32), ('obs_kind', _pi), ('obs_idx', _pi),
+        ('steps_per_episode', C.c_int32),
+        ('n_cont', C.c_int32), ('cont_branch', _pi), ('not_converged_penalty', C.c_double)]
+
+
+class StepIO(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('action', C.c_void_p), ('initial_obj', C.c_void_p),
+                ('step_in_episode', C.c_void_p), ('outage', C.c_void_p),
+                ('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p),
+                ('truncated', C.c_void_p), ('valids', C.c_void_p), ('violations', C.c_void_p),
+                ('penalties', C.c_void_p), ('cost', C.c_void_p), ('objective', C.c_void_p),
+                ('results', C.c_void_p), ('mean_correction', C.c_void_p),
+                ('converged', C.c_void_p), ('iterations', C.c_void_p), ('max_mismatch', C.c_void_p)]
+
+
+class ProfileDesc(C.Structure):
+    _fields_ = [('n_steps', C.c_int32), ('n_types', C.c_int32), ('n_cols', C.c_int32),
+                ('rel', _pd), ('typ', _pi), ('peak', _pd), ('slot', _pi),
+                ('col_min', _pd), ('col_max', _pd)]
+
+
+class ResetDesc(C.Structure):
+    _fields_ = [('n_tables', C.c_int32), ('tables', C.POINTER(ProfileDesc)),
+                ('n_ops', C.c_int32), ('op_code', _pi), ('op_dst', _pi), ('op_a', _pi),
+                ('op_n', _pi), ('op_c0', _pi), ('op_c1', _pi), ('op_c2', _pi),
+                ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32)]
+
+
+_lib = None
+
+EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_plan_get_array',
+           'opfx_plan_get_ybus', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
+           'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
+           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps']
+
+
+def lib():
+    """Load libopfx.so (built in-tree by __graft_entry__.build()); fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OpfxError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
+                        f'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.opfx_last_error.restype = C.c_char_p
+    L.opfx_plan_create.argtypes = [C.POINTER(CaseStruct), C.POINTER(vp)]
+    L.opfx_plan_destroy.argtypes = [vp]
+    L.opfx_plan_destroy.restype = None
+    L.opfx_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.opfx_plan_get_array.argtypes = [vp, C.c_int, _pi, C.c_int64]
+    L.opfx_plan_get_array.restype = C.c_int64
+    L.opfx_plan_get_ybus.argtypes = [vp, _pd, _pd]
+    L.opfx_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.opfx_ctx_destroy.argtypes = [vp]
+    L.opfx_ctx_destroy.restype = None
+    L.opfx_version.argtypes = [C.POINTER(C.c_int)] * 3
+    L.opfx_version.restype = None
+    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 8
+    L.opfx_env_create.argtypes = [vp, C.POINTER(EnvDesc), C.POINTER(vp)]
+    L.opfx_env_destroy.argtypes = [vp]
+    L.opfx_env_destroy.restype = None
+    L.opfx_step.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32, vp]
+    L.opfx_env_set_reset.argtypes = [vp, C.POINTER(ResetDesc)]
+    L.opfx_reset.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.opfx_time_steps.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32,
+                                  vp, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = lib().opfx_last_error()
+        raise OpfxError(f'{what} failed with status {rc}: {msg.decode() if msg else ""}')
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_pd)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_pi)
+
+
+class Plan:
+    """Host-side compiled grid plan (opfx_plan)."""
+
+    def __init__(self, case):
+        self.case = case
+        keep = []
+        cs = CaseStruct()
+        cs.nb, cs.nbr, cs.base_mva = case.nb, case.nbr, float(case.base_mva)
+        for name, arr, conv in (('bus_type', case.bus_type, _i), ('vm_set', case.vm_set, _d),
+                                ('va_set', case.va_set, _d), ('gs', case.gs, _d), ('bs', case.bs, _d),
+                                ('br_f', case.f, _i), ('br_t', case.t, _i),
+                                ('br_kf', case.kf, _d), ('br_kt', case.kt, _d)):
+            a, p = conv(arr)
+            keep.append(a)
+            setattr(cs, name, p)
+        y = np.stack([case.yff.real, case.yff.imag, case.yft.real, case.yft.imag,
+                      case.ytf.real, case.ytf.imag, case.ytt.real, case.ytt.imag], axis=1)
+        ya, yp = _d(y)
+        keep.append(ya)
+        cs.br_y = yp
+        self.branch_y = ya
+        h = C.c_void_p()
+        check(lib().opfx_plan_create(C.byref(cs), C.byref(h)), 'opfx_plan_create')
+        self.handle = h
+        info = PlanInfo()
+        check(lib().opfx_plan_get_info(h, C.byref(info)), 'opfx_plan_get_info')
+        self.info = info.as_dict()
+
+    def array(self, name) -> np.ndarray:
+        which = ARRAYS.index(name.upper())
+        n = lib().opfx_plan_get_array(self.handle, which, None, 0)
+        if n < 0:
+            check(int(n), 'opfx_plan_get_array')
+        out = np.zeros(int(n), dtype=np.int32)
+        lib().opfx_plan_get_array(self.handle, which, out.ctypes.data_as(_pi), n)
+        return out
+
+    def ybus(self):
+        g = np.zeros(self.info['nnz_y'])
+        b = np.zeros(self.info['nnz_y'])
+        check(lib().opfx_plan_get_ybus(self.handle, g.ctypes.data_as(_pd), b.ctypes.data_as(_pd)))
+        return g, b
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                lib().opfx_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Context:
+    """Plan resident on one GPU (opfx_ctx)."""
+
+    def __init__(self, plan: Plan, device: int = 0):
+        self.plan = plan
+        self.device = device
+        h = C.c_void_p()
+        check(lib().opfx_ctx_create(plan.handle, int(device), C.byref(h)), 'opfx_ctx_create')
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                lib().opfx_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, tol=1e-8,
+          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref')):
+    """Batched power flow on torch CUDA tensors p_inj/q_inj [B, nb] (p.u.)."""
+    import torch
+    assert p_inj.is_cuda and p_inj.dtype == torch.float64 and p_inj.shape == q_inj.shape
+    B, nb = p_inj.shape
+    info = ctx.plan.info
+    assert nb == info['nb']
+    dev = p_inj.device
+    out = {}
+    if 'vm' in want:
+        out['vm'] = torch.empty(B, nb, dtype=torch.float64, device=dev)
+    if 'va' in want:
+        out['va'] = torch.empty(B, nb, dtype=torch.float64, device=dev)
+    if 'loading' in want:
+        out['loading'] = torch.empty(B, info['nbr'], dtype=torch.float64, device=dev)
+    if 's_ref' in want:
+        out['s_ref'] = torch.empty(B, info['nref'], 2, dtype=torch.float64, device=dev)
+    out['converged'] = torch.empty(B, dtype=torch.uint8, device=dev)
+    out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
+    out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
+    opts = SolveOpts(float(tol), int(max_iter), int(bool(enforce_q_lims)))
+    with torch.cuda.device(dev):
+        check(lib().opfx_solve(
+            ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),
+            _ptr(outage), C.byref(opts), _ptr(out.get('vm')), _ptr(out.get('va')),
+            _ptr(out.get('loading')), _ptr(out.get('s_ref')), _ptr(out['converged']),
+            _ptr(out['iterations']), _ptr(out['max_mismatch']), _stream()), 'opfx_solve')
+    return out

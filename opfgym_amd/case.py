@@ -1,0 +1,350 @@
+"""Per-unit power-flow case and the net→case conversion.
+
+A :class:`Case` is what crosses the C ABI (`include/opfx.h: opfx_case`): a
+MATPOWER/pypower-shaped per-unit description of one grid topology — buses with
+types and set-points, branches as their four admittance-matrix stamps, and the
+scale factors that turn per-unit branch currents into `loading_percent`.
+
+`net_to_case` restates the third-party pandapower `_pd2ppc` conversion
+ for the element types that occur in the SimBench
+benchmark grids: buses, lines, two-winding transformers, loads, sgens,
+storages, gens, ext_grids, shunts, bus-bus/line/trafo switches.  pandapower is
+not importable here, so the element formulas are restated from its published
+documentation ("Electric model" pages of line / trafo); parity of this
+conversion against pandapower itself is NOT verified in this repository (see
+DESIGN.md "parity unpinned").
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+PQ, PV, REF = 1, 2, 3
+KIND_LINE, KIND_TRAFO = 0, 1
+
+
+@dataclass
+class Case:
+    base_mva: float
+    # buses (internal consecutive numbering after switch fusing)
+    bus_type: np.ndarray          # int32 [nb]  PQ/PV/REF
+    vn_kv: np.ndarray             # f64 [nb]
+    vm_set: np.ndarray            # f64 [nb] set-point for PV/REF, 1.0 for PQ
+    va_set: np.ndarray            # f64 [nb] radians; REF angle, else start angle
+    gs: np.ndarray                # f64 [nb] shunt conductance p.u.
+    bs: np.ndarray                # f64 [nb] shunt susceptance p.u.
+    # branches: Ybus stamps  (makeYbus)
+    f: np.ndarray                 # int32 [nbr]
+    t: np.ndarray                 # int32 [nbr]
+    yff: np.ndarray               # c128 [nbr]
+    yft: np.ndarray
+    ytf: np.ndarray
+    ytt: np.ndarray
+    kf: np.ndarray                # f64 [nbr] loading% = max(|If|*kf, |It|*kt)
+    kt: np.ndarray
+    br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo
+    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo
+    # lookups back to the net
+    bus_lookup: dict = field(default_factory=dict)   # net bus index -> case bus
+    ref_elems: np.ndarray = None  # positional ext_grid rows per REF bus order
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def nb(self) -> int:
+        return len(self.bus_type)
+
+    @property
+    def nbr(self) -> int:
+        return len(self.f)
+
+    def ybus_dense(self) -> np.ndarray:
+        y = np.zeros((self.nb, self.nb), dtype=np.complex128)
+        np.add.at(y, (self.f, self.f), self.yff)
+        np.add.at(y, (self.f, self.t), self.yft)
+        np.add.at(y, (self.t, self.f), self.ytf)
+        np.add.at(y, (self.t, self.t), self.ytt)
+        y[np.arange(self.nb), np.arange(self.nb)] += self.gs + 1j * self.bs
+        return y
+
+
+def branch_stamps(r, x, bc, ratio, shift_rad):
+    """pypower makeYbus branch part: Ys = 1/(r+jx); Ytt = Ys + j*Bc/2;
+    Yff = Ytt/(tap*conj(tap)); Yft = -Ys/conj(tap); Ytf = -Ys/tap.
+    `bc` may be complex (pandapower stores transformer iron losses there)."""
+    ys = 1.0 / (np.asarray(r, dtype=float) + 1j * np.asarray(x, dtype=float))
+    tap = np.asarray(ratio, dtype=float) * np.exp(1j * np.asarray(shift_rad, dtype=float))
+    ytt = ys + 1j * np.asarray(bc, dtype=complex) / 2.0
+    yff = ytt / (tap * np.conj(tap))
+    yft = -ys / np.conj(tap)
+    ytf = -ys / tap
+    return yff, yft, ytf, ytt
+
+
+class _UnionFind:
+    def __init__(self, keys):
+        self.p = {k: k for k in keys}
+
+    def find(self, a):
+        while self.p[a] != a:
+            self.p[a] = self.p[self.p[a]]
+            a = self.p[a]
+        return a
+
+    def union(self, a, b):
+        ra, rb = self.find(a), self.find(b)
+        if ra != rb:
+            self.p[max(ra, rb)] = min(ra, rb)
+
+
+def _col(df, name, default):
+    if name in df.columns:
+        v = df[name].to_numpy()
+        try:
+            v = v.astype(float)
+            return np.where(np.isnan(v), default, v)
+        except (ValueError, TypeError):
+            return v
+    return np.full(len(df), default)
+
+
+def net_to_case(net, calculate_voltage_angles='auto') -> Case:
+    """Convert the element tables of `net` into a per-unit :class:`Case`.
+
+    Restates pandapower `_pd2ppc` (third party):
+      * closed bus-bus switches fuse buses; an open line/trafo switch takes
+        the element out of service (pandapower keeps an open-ended line
+        charged through an auxiliary bus; that residual charging current is
+        neglected here — documented deviation);
+      * line:  r,x [Ω/km]·len/parallel ÷ Zbase,  b = 2πf·C·len·parallel·Zbase,
+        Zbase = vn_kv(from bus)² / sn_mva;
+      * trafo: short-circuit impedance from vk/vkr referred to the LV side,
+        magnetising branch from pfe/i0, T-model converted to π by a wye-delta
+        transform (`trafo_model='t'`), off-nominal ratio from the tap changer,
+        phase shift when voltage angles are calculated;
+      * every in-service ext_grid bus is REF, every in-service gen bus PV.
+    """
+    base = float(net['sn_mva']) if 'sn_mva' in net else 1.0
+    f_hz = float(net['f_hz']) if 'f_hz' in net else 50.0
+    bus_df = net['bus']
+    in_service_bus = _col(bus_df, 'in_service', True).astype(bool)
+    bus_ids = list(bus_df.index)
+
+    # --- switches ---------------------------------------------------------
+    uf = _UnionFind(bus_ids)
+    line_off, trafo_off = set(), set()
+    sw = net['switch'] if 'switch' in net else None
+    if sw is not None and len(sw):
+        for b, e, et, closed in zip(sw['bus'], sw['element'], sw['et'], sw['closed']):
+            if et == 'b':
+                if closed:
+                    uf.union(int(b), int(e))
+            elif et == 'l':
+                if not closed:
+                    line_off.add(int(e))
+            elif et == 't':
+                if not closed:
+                    trafo_off.add(int(e))
+
+    # --- ext_grid / gen decide angle handling -------------------------------
+    eg = net['ext_grid']
+    eg_on = _col(eg, 'in_service', True).astype(bool) if len(eg) else np.zeros(0, bool)
+    if calculate_voltage_angles == 'auto':
+        # pandapower: angles are calculated iff an ext_grid sits above 70 kV
+        calc_angles = bool(len(eg)) and bool(
+            (bus_df.loc[eg['bus'].to_numpy()[eg_on], 'vn_kv'].to_numpy(float) > 70.0).any())
+    else:
+        calc_angles = bool(calculate_voltage_angles)
+
+    # --- branches -----------------------------------------------------------
+    ln = net['line']
+    tr = net['trafo']
+    rows = []  # (root_f, root_t, r, x, bc, ratio, shift, kind, elem_pos, kf_num, kt_num)
+    vn = bus_df['vn_kv'].astype(float)
+    if len(ln):
+        on = _col(ln, 'in_service', True).astype(bool)
+        par = _col(ln, 'parallel', 1.0)
+        dfac = _col(ln, 'df', 1.0)
+        g_us = _col(ln, 'g_us_per_km', 0.0)
+        for pos, idx in enumerate(ln.index):
+            if not on[pos] or int(idx) in line_off:
+                continue
+            fb, tb = int(ln.at[idx, 'from_bus']), int(ln.at[idx, 'to_bus'])
+            if not (in_service_bus[bus_ids.index(fb)] and in_service_bus[bus_ids.index(tb)]):
+                continue
+            length = float(ln.at[idx, 'length_km'])
+            zb = vn[fb] ** 2 / base
+            r = float(ln.at[idx, 'r_ohm_per_km']) * length / par[pos] / zb
+            x = float(ln.at[idx, 'x_ohm_per_km']) * length / par[pos] / zb
+            b = 2 * np.pi * f_hz * float(ln.at[idx, 'c_nf_per_km']) * 1e-9 * length * par[pos] * zb
+            g = g_us[pos] * 1e-6 * length * par[pos] * zb
+            bc = b - 1j * g                      # j*bc/2 = (g + jb)/2 per side
+            imax = float(ln.at[idx, 'max_i_ka']) * dfac[pos] * par[pos]
+            kf = base / (np.sqrt(3.0) * vn[fb] * imax) * 100.0
+            kt = base / (np.sqrt(3.0) * vn[tb] * imax) * 100.0
+            rows.append((fb, tb, r, x, bc, 1.0, 0.0, KIND_LINE, pos, kf, kt))
+    if len(tr):
+        on = _col(tr, 'in_service', True).astype(bool)
+        par = _col(tr, 'parallel', 1.0)
+        dfac = _col(tr, 'df', 1.0)
+        tap_pos = _col(tr, 'tap_pos', np.nan)
+        tap_neutral = _col(tr, 'tap_neutral', np.nan)
+        tap_step = _col(tr, 'tap_step_percent', np.nan)
+        shift = _col(tr, 'shift_degree', 0.0)
+        for pos, idx in enumerate(tr.index):
+            if not on[pos] or int(idx) in trafo_off:
+                continue
+            hb, lb = int(tr.at[idx, 'hv_bus']), int(tr.at[idx, 'lv_bus'])
+            if not (in_service_bus[bus_ids.index(hb)] and in_service_bus[bus_ids.index(lb)]):
+                continue
+            sn = float(tr.at[idx, 'sn_mva'])
+            vn_hv, vn_lv = float(tr.at[idx, 'vn_hv_kv']), float(tr.at[idx, 'vn_lv_kv'])
+            vt_hv, vt_lv = vn_hv, vn_lv
+            side = tr.at[idx, 'tap_side'] if 'tap_side' in tr.columns else None
+            if isinstance(side, str) and not np.isnan(tap_pos[pos]) \
+                    and not np.isnan(tap_step[pos]):
+                neutral = 0.0 if np.isnan(tap_neutral[pos]) else tap_neutral[pos]
+                fac = 1.0 + (tap_pos[pos] - neutral) * tap_step[pos] / 100.0
+                if side == 'hv':
+                    vt_hv = vn_hv * fac
+                elif side == 'lv':
+                    vt_lv = vn_lv * fac
+            vb_hv, vb_lv = vn[hb], vn[lb]
+            # short-circuit impedance referred to the LV side, system base
+            tap_lv = (vt_lv / vb_lv) ** 2 * base
+            z_sc = float(tr.at[idx, 'vk_percent']) / 100.0 / sn * tap_lv
+            r_sc = float(tr.at[idx, 'vkr_percent']) / 100.0 / sn * tap_lv
+            x_sc = np.sign(z_sc) * np.sqrt(max(z_sc ** 2 - r_sc ** 2, 0.0))
+            r_sc /= par[pos]
+            x_sc /= par[pos]
+            # magnetising admittance
+            base_r = vb_lv ** 2 / base
+            pfe = float(tr.at[idx, 'pfe_kw']) * 1e-3
+            vnl2 = vn_lv ** 2
+            b_real = pfe / vnl2 * base_r
+            i0 = float(tr.at[idx, 'i0_percent'])
+            b_img2 = (i0 / 100.0 * sn) ** 2 - pfe ** 2
+            b_img = np.sqrt(max(b_img2, 0.0)) * base_r / vnl2
+            y = (-1j * b_real - b_img * np.sign(i0)) / (vt_lv / vn_lv) ** 2 * par[pos]
+            # T -> pi (wye-delta), only when a magnetising branch exists
+            if y != 0:
+                za = zb_ = (r_sc + 1j * x_sc) / 2.0
+                zc = -1j / y
+                zsum = za * zb_ + za * zc + zb_ * zc
+                zab = zsum / zc
+                zac = zsum / zb_
+                r_pi, x_pi = zab.real, zab.imag
+                bc = -2j / zac
+            else:
+                r_pi, x_pi, bc = r_sc, x_sc, 0.0 + 0.0j
+            ratio = (vt_hv / vb_hv) / (vt_lv / vb_lv)
+            sh = np.deg2rad(shift[pos]) if calc_angles else 0.0
+            kf = base * (vn_hv / vb_hv) / sn * 100.0 / (par[pos] * dfac[pos])
+            kt = base * (vn_lv / vb_lv) / sn * 100.0 / (par[pos] * dfac[pos])
+            rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt))
+
+    # --- which fused buses are alive: connected to a REF through branches ----
+    roots = {b: uf.find(b) for b in bus_ids}
+    eg_bus = [int(b) for b, on_ in zip(eg['bus'], eg_on) if on_] if len(eg) else []
+    if not eg_bus:
+        raise ValueError('net has no in-service ext_grid (no slack bus)')
+    adj = {}
+    for row in rows:
+        a, b = roots[row[0]], roots[row[1]]
+        adj.setdefault(a, set()).add(b)
+        adj.setdefault(b, set()).add(a)
+    alive = set()
+    stack = [roots[b] for b in eg_bus]
+    while stack:
+        a = stack.pop()
+        if a in alive:
+            continue
+        alive.add(a)
+        stack.extend(adj.get(a, ()))
+    alive = {r for r in alive if any(
+        in_service_bus[i] for i, b in enumerate(bus_ids) if roots[b] == r)}
+    order = sorted(alive)
+    root_to_case = {r: i for i, r in enumerate(order)}
+    bus_lookup = {b: root_to_case[roots[b]] for i, b in enumerate(bus_ids)
+                  if roots[b] in root_to_case and in_service_bus[i]}
+    nb = len(order)
+
+    rows = [r for r in rows if roots[r[0]] in root_to_case and roots[r[1]] in root_to_case]
+    fcase = np.array([root_to_case[roots[r[0]]] for r in rows], dtype=np.int32)
+    tcase = np.array([root_to_case[roots[r[1]]] for r in rows], dtype=np.int32)
+    yff, yft, ytf, ytt = branch_stamps(
+        [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
+        [r[5] for r in rows], [r[6] for r in rows])
+
+    bus_type = np.full(nb, PQ, dtype=np.int32)
+    vm_set = np.ones(nb)
+    va_set = np.zeros(nb)
+    vn_case = np.array([float(vn[r]) for r in order])
+    gen = net['gen']
+    if len(gen):
+        g_on = _col(gen, 'in_service', True).astype(bool)
+        for b, vm, on_ in zip(gen['bus'], gen['vm_pu'], g_on):
+            if on_ and int(b) in bus_lookup:
+                bus_type[bus_lookup[int(b)]] = PV
+                vm_set[bus_lookup[int(b)]] = float(vm)
+    ref_elems = []
+    for pos, (b, on_) in enumerate(zip(eg['bus'], eg_on)):
+        if on_ and int(b) in bus_lookup:
+            i = bus_lookup[int(b)]
+            bus_type[i] = REF
+            vm_set[i] = float(eg['vm_pu'].iloc[pos])
+            va_deg = float(eg['va_degree'].iloc[pos]) if 'va_degree' in eg.columns else 0.0
+            va_set[i] = np.deg2rad(va_deg) if calc_angles else 0.0
+            ref_elems.append(pos)
+
+    gs = np.zeros(nb)
+    bs = np.zeros(nb)
+    sh_df = net['shunt'] if 'shunt' in net else None
+    if sh_df is not None and len(sh_df):
+        s_on = _col(sh_df, 'in_service', True).astype(bool)
+        step = _col(sh_df, 'step', 1.0)
+        for pos, b in enumerate(sh_df['bus']):
+            if s_on[pos] and int(b) in bus_lookup:
+                i = bus_lookup[int(b)]
+                v_ratio = (vn[int(b)] / float(sh_df['vn_kv'].iloc[pos])) ** 2
+                gs[i] += float(sh_df['p_mw'].iloc[pos]) * step[pos] * v_ratio / base
+                bs[i] -= float(sh_df['q_mvar'].iloc[pos]) * step[pos] * v_ratio / base
+
+    # start angles: propagate the REF angle through transformer phase shifts
+    # (equivalent in effect to pandapower's init='dc' for shifted MV grids:
+    # the converged solution does not depend on the start)
+    va0 = _propagate_angles(nb, fcase, tcase, [r[6] for r in rows], bus_type, va_set)
+    va_set = np.where(bus_type == REF, va_set, va0)
+
+    return Case(
+        base_mva=base, bus_type=bus_type, vn_kv=vn_case, vm_set=vm_set,
+        va_set=va_set, gs=gs, bs=bs, f=fcase, t=tcase, yff=yff, yft=yft,
+        ytf=ytf, ytt=ytt,
+        kf=np.array([r[9] for r in rows], dtype=float),
+        kt=np.array([r[10] for r in rows], dtype=float),
+        br_kind=np.array([r[7] for r in rows], dtype=np.int32),
+        br_elem=np.array([r[8] for r in rows], dtype=np.int32),
+        bus_lookup=bus_lookup, ref_elems=np.array(ref_elems, dtype=np.int32),
+        meta={'calc_angles': calc_angles})
+
+
+def _propagate_angles(nb, f, t, shift, bus_type, va_set):
+    va0 = np.zeros(nb)
+    seen = np.zeros(nb, bool)
+    nbrs = [[] for _ in range(nb)]
+    for k in range(len(f)):
+        nbrs[f[k]].append((t[k], -shift[k]))
+        nbrs[t[k]].append((f[k], +shift[k]))
+    stack = []
+    for i in np.flatnonzero(bus_type == REF):
+        va0[i] = va_set[i]
+        seen[i] = True
+        stack.append(i)
+    while stack:
+        a = stack.pop()
+        for b, d in nbrs[a]:
+            if not seen[b]:
+                seen[b] = True
+                va0[b] = va0[a] + d
+                stack.append(b)
+    return va0

@@ -1,0 +1,1119 @@
+// libopfx device side: batched Newton-Raphson AC power flow and fused OPF-
+// environment evaluation for gfx950 (MI355X).
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER GRID INSTANCE, instance state
+// resident in LDS, persistent waves striding over the batch.
+//   * all structure (Ybus CSR, Jacobian block pattern, level-scheduled block-LU
+//     elimination programme) is shared by the whole batch, read-only, and
+//     stays in L1/L2; per-instance HBM traffic is inputs + outputs only;
+//   * inside an instance the 64 lanes parallelise over buses (mismatch,
+//     Jacobian rows, voltage update, results), over the independent work items
+//     of an elimination level (numeric 2x2-block LU + forward substitution),
+//     over the pivots of a level (back substitution), and reduce the mismatch
+//     inf-norm / constraint sums with cross-lane shuffles;
+//   * no inter-workgroup communication, no atomics, deterministic results.
+//
+// Replaces: pypower `newtonpf` (P4), the q-limit outer loop
+// (P5), `pfsoln`/result extraction (P6) and, in MODE_ENV, OpfEnv._apply_actions
+// (opf_env.py:421-491), get_pandapower_costs (objective.py:6-87),
+// Constraint.get_violation_metrics (constraints.py:70-128),
+// RewardFunction.__call__ (reward.py:61-98) and OpfEnv._get_obs
+// (opf_env.py:532-549) — all inside one kernel launch per env.step().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "opfx.h"
+#include "plan.h"
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t err__ = (expr);                                                \
+    if (err__ != hipSuccess) {                                                \
+      opfx_set_error(std::string(#expr) + ": " + hipGetErrorString(err__));   \
+      return OPFX_ERR_HIP;                                                    \
+    }                                                                         \
+  } while (0)
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int MODE_SOLVE = 0;
+constexpr int MODE_ENV = 1;
+
+// ---------------------------------------------------------------------------
+// device-resident plan
+// ---------------------------------------------------------------------------
+struct DevPlan {
+  int nb, nbr, nref, nblk, nlev, nfill, npv;
+  double base_mva;
+  const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
+  const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
+  const int *lev_pptr, *piv_bus, *piv_uptr, *u_blk, *u_col;
+  const int *br_f, *br_t, *br_pos, *ref_bus, *ref_ord;
+  const double *vm_set, *va_set, *y_g, *y_b, *br_y, *br_kf, *br_kt;
+};
+
+struct DevEnv {
+  int nx, na, npoly, npwl, nseg, nprice, nc, nobs, nres, ncost;
+  int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
+  int n_cont;
+  double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
+  double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
+  double invalid_objective_share, diff_step, clipped_action_penalty;
+  double not_converged_penalty;
+  const int *pinj_ptr, *pinj_slot, *pinj_act, *qinj_ptr, *qinj_slot, *qinj_act;
+  const double *pinj_coef, *qinj_coef, *qg_min, *qg_max;
+  const int *act_slot, *act_lo_slot, *act_hi_slot, *clamp_lo_slot, *clamp_hi_slot;
+  const double *act_scaling, *act_lo_const, *act_hi_const, *clamp_lo_const, *clamp_hi_const;
+  const int *cost_kind, *cost_pidx, *cost_qidx, *cost_pact, *cost_qact, *pwl_is_q;
+  const double *cost_scale, *cost_coef;
+  const int *price_slot, *price_coef, *coef_price;   // coef_price: coef index -> price ordinal or -1
+  const int *con_ptr, *con_src, *con_worst;
+  const double *con_min, *con_max, *con_autoscale, *con_pfac, *con_ppow, *con_cpen;
+  const int *obs_kind, *obs_idx, *obs_act;
+  const int *cont_branch;
+};
+
+struct SolveIO {
+  const double *p_inj, *q_inj, *qg_min, *qg_max;
+  const int* outage;
+  double *vm, *va, *loading, *s_ref, *max_mismatch;
+  unsigned char* converged;
+  int* iterations;
+};
+
+struct StepIO {
+  double* x;
+  const double *action, *initial_obj;
+  const int* step_in_episode;
+  const int* outage;
+  double *obs, *reward, *violations, *penalties, *cost, *objective, *results;
+  double *mean_correction, *max_mismatch;
+  unsigned char *terminated, *truncated, *valids, *converged;
+  int* iterations;
+  int mode;
+};
+
+struct Opts {
+  double tol;
+  int max_iter;
+  int enforce_q_lims;
+};
+
+// ---------------------------------------------------------------------------
+// wave-level helpers (one wave == one workgroup == one instance)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+  // LDS operations of one wave execute in issue order; what is needed is that
+  // the compiler neither reorders across this point nor keeps LDS values in
+  // registers.  (blockDim.x == 64, so this is also a full workgroup barrier.)
+  __syncthreads();
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_any(int pred) { return __any(pred); }
+
+struct Blk { double a11, a12, a21, a22; };
+__device__ __forceinline__ Blk ld_blk(const double* blk, int id) {
+  const double2* p = reinterpret_cast<const double2*>(blk + 4 * id);
+  double2 r0 = p[0], r1 = p[1];
+  return Blk{r0.x, r0.y, r1.x, r1.y};
+}
+__device__ __forceinline__ void st_blk(double* blk, int id, const Blk& b) {
+  double2* p = reinterpret_cast<double2*>(blk + 4 * id);
+  p[0] = make_double2(b.a11, b.a12);
+  p[1] = make_double2(b.a21, b.a22);
+}
+
+constexpr int BT_PQ = 1, BT_PV = 2, BT_REF = 3, BT_PQ_HI = 4, BT_PQ_LO = 5;
+
+struct Lds {
+  double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp;
+  int* bt;
+};
+
+// Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
+__device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
+                       int out_br, int* iters_out, double* nrm_out) {
+  const int nb = P.nb;
+  // outaged branch: positions of its four Ybus stamps and their values
+  int op0 = -1, op1 = -1, op2 = -1, op3 = -1;
+  double oy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out_br >= 0) {
+    op0 = P.br_pos[out_br * 4 + 0]; op1 = P.br_pos[out_br * 4 + 1];
+    op2 = P.br_pos[out_br * 4 + 2]; op3 = P.br_pos[out_br * 4 + 3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
+  }
+  int it = 0;
+  double nrm = 0.0;
+  bool conv = false;
+  while (true) {
+    // ---- phase A: mismatch, inf-norm, Jacobian blocks (lane = bus row) -------
+    for (int f = lane; f < P.nfill; f += WAVE) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    double my = 0.0;
+    for (int i = lane; i < nb; i += WAVE) {
+      const int t = L.bt[i];
+      const double vri = L.vr[i], vii = L.vi[i], vmi = L.vm[i];
+      double ior = 0.0, ioi = 0.0, dr = 0.0, di = 0.0;   // off-diagonal sum, diagonal term
+      const int e0 = P.y_ptr[i], e1 = P.y_ptr[i + 1];
+      for (int e = e0; e < e1; ++e) {
+        const int j = P.y_col[e];
+        double g = P.y_g[e], b = P.y_b[e];
+        if (out_br >= 0) {
+          if (e == op0) { g -= oy[0]; b -= oy[1]; }
+          if (e == op1) { g -= oy[2]; b -= oy[3]; }
+          if (e == op2) { g -= oy[4]; b -= oy[5]; }
+          if (e == op3) { g -= oy[6]; b -= oy[7]; }
+        }
+        const double vrj = L.vr[j], vij = L.vi[j];
+        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;   // Y_ij V_j
+        if (j == i) { dr = tr; di = ti; continue; }
+        ior += tr; ioi += ti;
+        const int bid = P.y_blk[e];
+        if (bid >= 0 && t != BT_REF) {
+          // c = V_i conj(Y_ij V_j);  dS_i/dth_j = -j c;  dS_i/d|V_j| = c/|V_j|
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          const double inv = 1.0 / L.vm[j];
+          Blk jb{ci, cr * inv, -cr, ci * inv};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+          st_blk(L.blk, bid, jb);
+        }
+      }
+      if (t != BT_REF) {
+        const double ir = ior + dr, ii = ioi + di;              // I_i
+        const double pc = vri * ir + vii * ii, qc = vii * ir - vri * ii;   // S_i = V_i conj(I_i)
+        const double fp = pc - L.psp[i];
+        const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
+        L.rhs[2 * i] = -fp;
+        L.rhs[2 * i + 1] = -fq;
+        my = fmax(my, fmax(fabs(fp), fabs(fq)));
+        // dS_i/dth_i = j V_i conj(I_i - Y_ii V_i);  with e = V_i conj(Ioff): j e = -e.im + j e.re
+        const double er = vri * ior + vii * ioi, ei = vii * ior - vri * ioi;
+        // dS_i/d|V_i| = (V_i conj(Y_ii V_i) + S_i)/|V_i|
+        const double yr = vri * dr + vii * di, yi = vii * dr - vri * di;
+        Blk jb{-ei, (yr + pc) / vmi, er, (yi + qc) / vmi};
+        if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+        st_blk(L.blk, P.diag_blk[i], jb);
+      }
+    }
+    nrm = wave_max(my);
+    if (!(nrm == nrm)) { conv = false; break; }          // NaN: diverged
+    if (nrm < o.tol) { conv = true; break; }
+    if (it >= o.max_iter) { conv = false; break; }
+    ++it;
+    wave_sync();
+    // ---- phase B: block LU + forward substitution, level by level ------------
+    for (int lev = 0; lev < P.nlev; ++lev) {
+      const int t0 = P.lev_tptr[lev], t1 = P.lev_tptr[lev + 1];
+      for (int t = t0 + lane; t < t1; t += WAVE) {
+        const int tb = P.tgt_blk[t];
+        const int s0 = P.tgt_sptr[t], s1 = P.tgt_sptr[t + 1];
+        if (tb >= 0) {
+          Blk a = ld_blk(L.blk, tb);
+          for (int s = s0; s < s1; ++s) {
+            const Blk bi = ld_blk(L.blk, P.src_ik[s]);
+            const Blk bk = ld_blk(L.blk, P.src_kk[s]);
+            const Blk bj = ld_blk(L.blk, P.src_kj[s]);
+            const double r = 1.0 / (bk.a11 * bk.a22 - bk.a12 * bk.a21);
+            const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * r;
+            const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * r;
+            const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * r;
+            const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * r;
+            a.a11 -= w11 * bj.a11 + w12 * bj.a21;
+            a.a12 -= w11 * bj.a12 + w12 * bj.a22;
+            a.a21 -= w21 * bj.a11 + w22 * bj.a21;
+            a.a22 -= w21 * bj.a12 + w22 * bj.a22;
+          }
+          st_blk(L.blk, tb, a);
+        } else {
+          const int i = -1 - tb;
+          double y1 = L.rhs[2 * i], y2 = L.rhs[2 * i + 1];
+          for (int s = s0; s < s1; ++s) {
+            const Blk bi = ld_blk(L.blk, P.src_ik[s]);
+            const Blk bk = ld_blk(L.blk, P.src_kk[s]);
+            const int k = P.src_kj[s];
+            const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
+            const double r = 1.0 / (bk.a11 * bk.a22 - bk.a12 * bk.a21);
+            const double z1 = (bk.a22 * r1 - bk.a12 * r2) * r;
+            const double z2 = (bk.a11 * r2 - bk.a21 * r1) * r;
+            y1 -= bi.a11 * z1 + bi.a12 * z2;
+            y2 -= bi.a21 * z1 + bi.a22 * z2;
+          }
+          L.rhs[2 * i] = y1;
+          L.rhs[2 * i + 1] = y2;
+        }
+      }
+      wave_sync();
+    }
+    // ---- phase C: back substitution, levels in reverse ------------------------
+    for (int lev = P.nlev - 1; lev >= 0; --lev) {
+      const int p0 = P.lev_pptr[lev], p1 = P.lev_pptr[lev + 1];
+      for (int q = p0 + lane; q < p1; q += WAVE) {
+        const int k = P.piv_bus[q];
+        double y1 = L.rhs[2 * k], y2 = L.rhs[2 * k + 1];
+        const int u0 = P.piv_uptr[q], u1 = P.piv_uptr[q + 1];
+        for (int u = u0; u < u1; ++u) {
+          const Blk a = ld_blk(L.blk, P.u_blk[u]);
+          const int j = P.u_col[u];
+          const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+          y1 -= a.a11 * x1 + a.a12 * x2;
+          y2 -= a.a21 * x1 + a.a22 * x2;
+        }
+        const Blk bk = ld_blk(L.blk, P.diag_blk[k]);
+        const double r = 1.0 / (bk.a11 * bk.a22 - bk.a12 * bk.a21);
+        L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * r;
+        L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * r;
+      }
+      wave_sync();
+    }
+    // ---- phase D: update V (polar), lane = bus --------------------------------
+    for (int i = lane; i < nb; i += WAVE) {
+      if (L.bt[i] == BT_REF) continue;
+      double va = L.va[i] + L.rhs[2 * i];
+      double vm = L.vm[i] + L.rhs[2 * i + 1];
+      if (vm < 0.0) { vm = -vm; va += M_PI; }     // V = Vm e^{jVa}; Vm = |V| (newtonpf)
+      double s, c;
+      sincos(va, &s, &c);
+      L.va[i] = va; L.vm[i] = vm; L.vr[i] = vm * c; L.vi[i] = vm * s;
+    }
+    wave_sync();
+  }
+  *iters_out = it;
+  *nrm_out = nrm;
+  return conv;
+}
+
+// (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
+// A bus that an earlier solve of this instance pinned at a reactive limit gets
+// its generator share removed from q_sp again (L.bt must hold valid codes).
+__device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
+                             const double* qg_max) {
+  for (int i = lane; i < P.nb; i += WAVE) {
+    const int t = L.bt[i];
+    if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];
+    if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
+    const double vm = P.vm_set[i], va = P.va_set[i];
+    double s, c;
+    sincos(va, &s, &c);
+    L.vm[i] = vm; L.va[i] = va; L.vr[i] = vm * c; L.vi[i] = vm * s;
+    L.bt[i] = P.bus_type[i];
+  }
+}
+
+// Outer loop: NR + enforce_q_lims PV->PQ switching.
+__device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
+                               const double* qg_min, const double* qg_max, int* iters, double* nrm) {
+  int total = 0;
+  bool conv = false;
+  for (int outer = 0; outer <= P.npv; ++outer) {
+    int it;
+    conv = newton(P, L, o, lane, out_br, &it, nrm);
+    total += it;
+    if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
+    // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
+    int changed = 0;
+    wave_sync();
+    for (int i = lane; i < P.nb; i += WAVE) {
+      if (L.bt[i] != BT_PV) continue;
+      double ir = 0.0, ii = 0.0;
+      for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
+        const int j = P.y_col[e];
+        double g = P.y_g[e], b = P.y_b[e];
+        if (out_br >= 0) {
+          if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
+          if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
+          if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
+          if (e == P.br_pos[out_br * 4 + 3]) { g -= P.br_y[out_br * 8 + 6]; b -= P.br_y[out_br * 8 + 7]; }
+        }
+        ir += g * L.vr[j] - b * L.vi[j];
+        ii += g * L.vi[j] + b * L.vr[j];
+      }
+      const double qc = L.vi[i] * ir - L.vr[i] * ii;
+      const double qg = qc - L.qsp[i];
+      const double lo = qg_min[i], hi = qg_max[i];
+      if (qg > hi) { L.bt[i] = BT_PQ_HI; L.qsp[i] += hi; changed = 1; }
+      else if (qg < lo) { L.bt[i] = BT_PQ_LO; L.qsp[i] += lo; changed = 1; }
+    }
+    wave_sync();
+    if (!wave_any(changed)) break;
+  }
+  *iters = total;
+  return conv;
+}
+
+// after convergence: result bank in LDS region R (reuses the LU block storage)
+//   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
+__device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br,
+                                const double* qg_min, const double* qg_max, double* R, bool physical) {
+  const int nb = P.nb, nbr = P.nbr, nref = P.nref;
+  double* r_vm = R;
+  double* r_va = R + nb;
+  double* r_ld = R + 2 * nb;
+  double* r_pe = r_ld + nbr;
+  double* r_qe = r_pe + nref;
+  double* r_qg = r_qe + nref;
+  const double base = physical ? P.base_mva : 1.0;
+  for (int i = lane; i < nb; i += WAVE) {
+    r_vm[i] = L.vm[i];
+    const double ang = atan2(L.vi[i], L.vr[i]);
+    r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+    const int t = L.bt[i];
+    double qgen = 0.0;
+    if (t == BT_REF || t == BT_PV) {
+      double ir = 0.0, ii = 0.0;
+      for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
+        const int j = P.y_col[e];
+        double g = P.y_g[e], b = P.y_b[e];
+        if (out_br >= 0) {
+          if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
+          if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
+          if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
+          if (e == P.br_pos[out_br * 4 + 3]) { g -= P.br_y[out_br * 8 + 6]; b -= P.br_y[out_br * 8 + 7]; }
+        }
+        ir += g * L.vr[j] - b * L.vi[j];
+        ii += g * L.vi[j] + b * L.vr[j];
+      }
+      const double pc = L.vr[i] * ir + L.vi[i] * ii, qc = L.vi[i] * ir - L.vr[i] * ii;
+      if (t == BT_REF) {
+        const int ro = P.ref_ord[i];
+        r_pe[ro] = (pc - L.psp[i]) * base;
+        r_qe[ro] = (qc - L.qsp[i]) * base;
+      } else {
+        qgen = (qc - L.qsp[i]) * base;
+      }
+    } else if (t == BT_PQ_HI) {
+      qgen = qg_max[i] * base;
+    } else if (t == BT_PQ_LO) {
+      qgen = qg_min[i] * base;
+    }
+    r_qg[i] = qgen;
+  }
+  for (int k = lane; k < nbr; k += WAVE) {
+    double ld = 0.0;
+    if (k != out_br) {
+      const int f = P.br_f[k], t = P.br_t[k];
+      const double* y = P.br_y + 8 * k;
+      const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
+      const double ifr = y[0] * vfr - y[1] * vfi + y[2] * vtr - y[3] * vti;
+      const double ifi = y[0] * vfi + y[1] * vfr + y[2] * vti + y[3] * vtr;
+      const double itr = y[4] * vfr - y[5] * vfi + y[6] * vtr - y[7] * vti;
+      const double iti = y[4] * vfi + y[5] * vfr + y[6] * vti + y[7] * vtr;
+      ld = fmax(sqrt(ifr * ifr + ifi * ifi) * P.br_kf[k], sqrt(itr * itr + iti * iti) * P.br_kt[k]);
+    }
+    r_ld[k] = ld;
+  }
+}
+
+__device__ __forceinline__ Lds carve(const DevPlan& P, int na, double* base) {
+  Lds L;
+  const int nb = P.nb;
+  L.vr = base; L.vi = L.vr + nb; L.vm = L.vi + nb; L.va = L.vm + nb;
+  L.psp = L.va + nb; L.qsp = L.psp + nb; L.rhs = L.qsp + nb;
+  L.blk = L.rhs + 2 * nb;                      // 8*nb doubles so far: 16-B aligned
+  L.sp = L.blk + 4 * P.nblk;
+  L.bt = reinterpret_cast<int*>(L.sp + na);
+  return L;
+}
+
+// ---------------------------------------------------------------------------
+// pure power flow kernel (opfx_solve)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_solve(DevPlan P, SolveIO io, Opts o, long long B) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Lds L = carve(P, 0, smem);
+  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int i = lane; i < P.nb; i += WAVE) {
+      L.psp[i] = io.p_inj[b * P.nb + i];
+      L.qsp[i] = io.q_inj[b * P.nb + i];
+      L.bt[i] = BT_PQ;
+    }
+    init_voltage(P, L, lane, io.qg_min, io.qg_max);
+    wave_sync();
+    const int out_br = io.outage ? io.outage[b] : -1;
+    int iters; double nrm;
+    const bool conv = solve_instance(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
+    wave_sync();
+    double* R = L.blk;
+    compute_results(P, L, lane, out_br, io.qg_min, io.qg_max, R, false);
+    wave_sync();
+    const int nb = P.nb, nbr = P.nbr, nref = P.nref;
+    if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
+    if (io.va) for (int i = lane; i < nb; i += WAVE) io.va[b * nb + i] = R[nb + i];
+    if (io.loading) for (int k = lane; k < nbr; k += WAVE) io.loading[b * nbr + k] = R[2 * nb + k];
+    if (io.s_ref) for (int r = lane; r < nref; r += WAVE) {
+      io.s_ref[(b * nref + r) * 2] = R[2 * nb + nbr + r];
+      io.s_ref[(b * nref + r) * 2 + 1] = R[2 * nb + nbr + nref + r];
+    }
+    if (lane == 0) {
+      if (io.converged) io.converged[b] = conv ? 1 : 0;
+      if (io.iterations) io.iterations[b] = iters;
+      if (io.max_mismatch) io.max_mismatch[b] = nrm;
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused env.step kernel (opfx_step)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double xval(const double* xr, const double* sp, int slot, int act) {
+  return act >= 0 ? sp[act] : xr[slot];
+}
+
+__device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
+
+__global__ __launch_bounds__(WAVE) void k_step(DevPlan P, DevEnv E, StepIO io, Opts o, long long B) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const Lds L = carve(P, E.na, smem);
+  const int nb = P.nb;
+  const double NaN = __builtin_nan("");
+  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+    double* xr = io.x + b * E.nx;
+    // ---- apply actions (opf_env.py:421-491) -----------------------------------
+    double corr = 0.0;
+    for (int k = lane; k < E.na; k += WAVE) {
+      const int slot = E.act_slot[k];
+      double xv = xr[slot];
+      if (io.mode == 0) {
+        double a = io.action[b * E.na + k];
+        a = fmin(fmax(a, 0.0), 1.0);                                      // :429
+        const double lo = E.act_lo_slot[k] >= 0 ? xr[E.act_lo_slot[k]] : E.act_lo_const[k];
+        const double hi = E.act_hi_slot[k] >= 0 ? xr[E.act_hi_slot[k]] : E.act_hi_const[k];
+        const double delta = hi - lo;
+        const double sc = E.act_scaling[k];
+        double spt;
+        if (E.diff_step != 0.0) spt = (a * 2.0 - 1.0) * E.diff_step * delta + xv * sc;   // :453-458
+        else spt = a * delta + lo;                                                   // :461
+        if (E.clamp_enabled) {                                                       // :464-470
+          const int ch = E.clamp_hi_slot[k], cl = E.clamp_lo_slot[k];
+          if (ch > -2) { const double m = ch >= 0 ? xr[ch] : E.clamp_hi_const[k]; if (spt > m) spt = m; }
+          if (cl > -2) { const double m = cl >= 0 ? xr[cl] : E.clamp_lo_const[k]; if (spt < m) spt = m; }
+        }
+        xv = spt / sc;                                                               // :472-474
+        xr[slot] = xv;                                                               // :483
+        const double cur = (xv * sc - lo) / delta;                                   // :586
+        corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
+      }
+      L.sp[k] = xv;
+    }
+    corr = E.na > 0 ? wave_sum(corr) / E.na : 0.0;                                   // :488-489
+    wave_sync();
+    // ---- bus injections (makeSbus) ---------------------------------------------
+    for (int i = lane; i < nb; i += WAVE) {
+      double p = 0.0, q = 0.0;
+      for (int e = E.pinj_ptr[i]; e < E.pinj_ptr[i + 1]; ++e)
+        p += E.pinj_coef[e] * xval(xr, L.sp, E.pinj_slot[e], E.pinj_act[e]);
+      for (int e = E.qinj_ptr[i]; e < E.qinj_ptr[i + 1]; ++e)
+        q += E.qinj_coef[e] * xval(xr, L.sp, E.qinj_slot[e], E.qinj_act[e]);
+      L.psp[i] = p;
+      L.qsp[i] = q;
+      L.bt[i] = BT_PQ;
+    }
+    // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
+    double objective = 0.0, viol_acc = 0.0, pen_acc = 0.0;   // lane g < nc holds group g
+    int valid_acc = 1;
+    bool conv0 = false;
+    int iters0 = 0;
+    double nrm0 = 0.0;
+    const int base_out = io.outage ? io.outage[b] : -1;
+    for (int c = 0; c <= E.n_cont; ++c) {
+      const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
+      if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
+      init_voltage(P, L, lane, E.qg_min, E.qg_max);
+      wave_sync();
+      int iters; double nrm;
+      const bool conv = solve_instance(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
+      wave_sync();
+      if (c == 0) { conv0 = conv; iters0 = iters; nrm0 = nrm; if (!conv) break; }
+      if (!conv) {
+        // failed contingency: all invalid, +not_converged_penalty (sign as in the reference, D6)
+        valid_acc = 0;
+        viol_acc += E.not_converged_penalty;
+        pen_acc += E.not_converged_penalty;
+        continue;
+      }
+      double* R = L.blk;
+      compute_results(P, L, lane, out_br, E.qg_min, E.qg_max, R, true);
+      wave_sync();
+      // ---- constraints (constraints.py:70-128) ---------------------------------
+      for (int g = 0; g < E.nc; ++g) {
+        double smin = 0.0, smax = 0.0, wmin = 0.0, wmax = 0.0;
+        int cnt = 0;
+        for (int e = E.con_ptr[g] + lane; e < E.con_ptr[g + 1]; e += WAVE) {
+          const double v = R[E.con_src[e]];
+          const double lo = E.con_min[e], hi = E.con_max[e];
+          if (v < lo) { const double d = fabs(v - lo); smin += d; wmin = fmax(wmin, d); ++cnt; }
+          if (v > hi) { const double d = fabs(v - hi); smax += d; wmax = fmax(wmax, d); ++cnt; }
+        }
+        cnt = wave_sum_i(cnt);
+        double viol;
+        if (E.con_worst[g]) viol = wave_max(wmin) + wave_max(wmax);
+        else viol = wave_sum(smin) + wave_sum(smax);
+        const double as = E.con_autoscale[g];
+        if (as != 0.0) viol *= as;                                                   // :82-83
+        const double pw = E.con_ppow[g];
+        double pen = (pw == 1.0 ? viol : pow(viol, pw)) * E.con_pfac[g];
+        pen += cnt * E.con_cpen[g];                                                  // :124-128
+        if (lane == g) {
+          valid_acc = valid_acc && (cnt == 0);
+          viol_acc += viol;
+          pen_acc += -pen;
+        }
+      }
+      if (c == 0) {
+        // ---- objective (objective.py:6-87) --------------------------------------
+        double csum = 0.0;
+        const double* r_pe = R + 2 * nb + P.nbr;
+        const double* r_qe = r_pe + P.nref;
+        const double* r_qg = r_qe + P.nref;
+        for (int r = lane; r < E.ncost; r += WAVE) {
+          const int kind = E.cost_kind[r];
+          double pw_, qv_;
+          if (kind == OPFX_COST_UNIT) {
+            const double sc = E.cost_scale[r];
+            pw_ = E.cost_pidx[r] >= 0 ? xval(xr, L.sp, E.cost_pidx[r], E.cost_pact[r]) * sc : 0.0;
+            qv_ = E.cost_qidx[r] >= 0 ? xval(xr, L.sp, E.cost_qidx[r], E.cost_qact[r]) * sc : 0.0;
+          } else if (kind == OPFX_COST_EXT_GRID) {
+            pw_ = r_pe[E.cost_pidx[r]]; qv_ = r_qe[E.cost_pidx[r]];
+          } else {
+            const double sc = E.cost_scale[r];
+            pw_ = E.cost_qidx[r] >= 0 ? xval(xr, L.sp, E.cost_qidx[r], E.cost_qact[r]) * sc : 0.0;
+            qv_ = r_qg[E.cost_pidx[r]];
+          }
+          if (r < E.npoly) {
+            double cf[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              const int ci = r * 6 + q;
+              const int pr = E.coef_price[ci];
+              cf[q] = pr >= 0 ? xr[E.price_slot[pr]] : E.cost_coef[ci];
+            }
+            double pc = cf[0]; pc += cf[1] * pw_; pc += cf[2] * (pw_ * pw_);          // :38-40
+            double qc = cf[3]; qc += cf[4] * qv_; qc += cf[5] * (qv_ * qv_);          // :41-43
+            csum += pc + qc;
+          } else {
+            const int w = r - E.npoly;
+            const double pwr = E.pwl_is_q[w] ? qv_ : pw_;
+            const double s = sgn(pwr), pa = fabs(pwr);
+            double cst = 0.0;
+            for (int sg = 0; sg < E.nseg; ++sg) {                                     // :60-75
+              const int ci = E.npoly * 6 + (w * E.nseg + sg) * 3;
+              const double lo = E.cost_coef[ci], hi = E.cost_coef[ci + 1];
+              const int pr = E.coef_price[ci + 2];
+              const double price = pr >= 0 ? xr[E.price_slot[pr]] : E.cost_coef[ci + 2];
+              const double la = fabs(lo), ha = fabs(hi);
+              const double inside = fmin(la, ha);
+              const bool same = (s == sgn(lo + hi));
+              const bool in_f = (pa > inside) && same;
+              const bool out_f = pa > fmax(la, ha);
+              if (out_f) cst += s * (hi - lo) * price;
+              if (in_f && !out_f) cst += s * (pa - inside) * price;
+            }
+            csum += cst;
+          }
+        }
+        objective = -wave_sum(csum);                                                 // opf_env.py:500
+        if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
+        if (io.results) for (int q = lane; q < E.nres; q += WAVE) io.results[b * E.nres + q] = R[q];
+      }
+      // result observations reflect the LAST solved case (defect D7 of the reference)
+      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) {
+        const int idx = E.obs_idx[k];
+        if (E.obs_kind[k] == OPFX_SRC_X) { if (c == 0) io.obs[b * E.nobs + k] = xval(xr, L.sp, idx, E.obs_act[k]); }
+        else io.obs[b * E.nobs + k] = R[idx];
+      }
+      wave_sync();
+    }
+    // ---- reward (opf_env.py:515-530, reward.py:61-98) --------------------------
+    if (!conv0) {
+      // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
+      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
+      if (lane < E.nc) {
+        if (io.valids) io.valids[b * E.nc + lane] = 0;
+        if (io.violations) io.violations[b * E.nc + lane] = 1.0;
+        if (io.penalties) io.penalties[b * E.nc + lane] = 1.0;
+      }
+      if (lane == 0) {
+        if (io.reward) io.reward[b] = NaN;
+        if (io.cost) io.cost[b] = NaN;
+        if (io.objective) io.objective[b] = NaN;
+        if (io.terminated) io.terminated[b] = 1;
+        if (io.truncated) io.truncated[b] = 0;
+      }
+    } else {
+      double pen_l = lane < E.nc ? pen_acc : 0.0;
+      int inval_l = lane < E.nc ? !valid_acc : 0;
+      const double penalty = wave_sum(pen_l);
+      const bool valid = !wave_any(inval_l);
+      if (lane < E.nc) {
+        if (io.valids) io.valids[b * E.nc + lane] = valid_acc ? 1 : 0;
+        if (io.violations) io.violations[b * E.nc + lane] = viol_acc;
+        if (io.penalties) io.penalties[b * E.nc + lane] = pen_acc;
+      }
+      if (lane == 0) {
+        double obj = objective, pen = penalty;
+        double cost_extra = 0.0;
+        if (E.reward_kind == OPFX_REWARD_REPLACEMENT) {
+          obj = valid ? obj + E.valid_reward : 0.0;                                  // reward.py:247-252
+        } else if (E.reward_kind == OPFX_REWARD_PARAMETERIZED) {
+          pen = valid ? pen + E.valid_reward : pen - E.invalid_penalty;              // :288-291
+          if (!valid) obj *= E.invalid_objective_share;                              // :293-298
+          cost_extra = E.invalid_penalty;
+        } else if (E.reward_kind == OPFX_REWARD_ONLY_OBJECTIVE) {
+          pen = 0.0;                                                                 // :316-317
+        }
+        obj = obj * E.objective_factor + E.objective_bias;                           // :83-86
+        pen = pen * E.penalty_factor + E.penalty_bias;                               // :88-91
+        double rew;
+        if (E.penalty_weight != E.penalty_weight) rew = obj + pen;                   // :79-80
+        else rew = obj * (1.0 - E.penalty_weight) + pen * E.penalty_weight;          // :81
+        if (E.clip_lo == E.clip_lo) rew = fmin(fmax(rew, E.clip_lo), E.clip_hi);     // :70-71
+        if (E.clipped_action_penalty != 0.0 && io.mode == 0)
+          rew -= corr * E.clipped_action_penalty;                                    // opf_env.py:403-404
+        if (io.reward) io.reward[b] = rew;
+        if (io.cost) io.cost[b] = valid ? 0.0 : fabs(penalty * E.penalty_factor) + cost_extra;  // :93-98,301-305
+        if (io.objective) io.objective[b] = objective;
+        const int sie = io.step_in_episode ? io.step_in_episode[b] : 1;
+        unsigned char term = 0, trunc = 0;
+        if (E.steps_per_episode == 1) term = 1;                                      // opf_env.py:406-414
+        else if (sie >= E.steps_per_episode) trunc = 1;
+        if (io.terminated) io.terminated[b] = term;
+        if (io.truncated) io.truncated[b] = trunc;
+      }
+    }
+    if (lane == 0) {
+      if (io.converged) io.converged[b] = conv0 ? 1 : 0;
+      if (io.iterations) io.iterations[b] = iters0;
+      if (io.max_mismatch) io.max_mismatch[b] = nrm0;
+      if (io.mean_correction) io.mean_correction[b] = corr;
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reset kernel: SimBench state sampling (opf_env.py:317-372) + `_sampling` tails
+// ---------------------------------------------------------------------------
+struct DevTable {
+  int n_steps, n_types, n_cols, noise_off;
+  const double *rel, *peak, *col_min, *col_max;
+  const int *typ, *slot;
+};
+constexpr int MAX_TABLES = 8;
+struct DevReset {
+  int n_tables, n_ops, n_uniform, n_noise, nx;
+  DevTable tab[MAX_TABLES];
+  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2;
+  const double* consts;
+};
+
+__global__ __launch_bounds__(256) void k_reset(DevReset R, const int* step_idx, const double* noise,
+                                               const double* uniform, double* x, long long B) {
+  // one wave per instance, 4 instances per workgroup
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * 4;
+  for (long long b = w; b < B; b += nw) {
+    double* xr = x + b * R.nx;
+    const int step = step_idx[b];
+    for (int t = 0; t < R.n_tables; ++t) {
+      const DevTable& T = R.tab[t];
+      const double* row = T.rel + (long long)step * T.n_types;
+      for (int j = lane; j < T.n_cols; j += 64) {
+        double v = row[T.typ[j]] * T.peak[j];                                      // :343
+        if (noise) v = v * noise[b * R.n_noise + T.noise_off + j];                  // :354-356
+        v = fmin(fmax(v, T.col_min[j]), T.col_max[j]);                              // :364-369
+        xr[T.slot[j]] = v;                                                          // :371-372
+      }
+    }
+    // element j of every op is handled by lane j%64, so a value written by one op is
+    // read back by the same thread in a later op (program order suffices).
+    for (int k = 0; k < R.n_ops; ++k) {
+      const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
+      const double* c0 = R.op_c0[k] >= 0 ? R.consts + R.op_c0[k] : nullptr;
+      const double* c1 = R.op_c1[k] >= 0 ? R.consts + R.op_c1[k] : nullptr;
+      const double* c2 = R.op_c2[k] >= 0 ? R.consts + R.op_c2[k] : nullptr;
+      for (int j = lane; j < n; j += 64) {
+        double v;
+        if (code == OPFX_OP_SET_CONST) v = c0[j];
+        else if (code == OPFX_OP_AFFINE) v = xr[a + j] * c0[j] + c1[j];
+        else if (code == OPFX_OP_SQRT_DIFF) { const double s = c0[j], pz = xr[a + j]; v = sqrt(s * s - pz * pz); }
+        else if (code == OPFX_OP_NEG) v = -xr[a + j];
+        else { const double u = uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
+        xr[dst + j] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host objects
+// ---------------------------------------------------------------------------
+struct DevArena {
+  std::vector<void*> ptrs;
+  ~DevArena() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T>
+  int put(const T* host, size_t n, const T** dev) {
+    *dev = nullptr;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
+    ptrs.push_back(d);
+    if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T*>(d);
+    return OPFX_OK;
+  }
+  template <typename T>
+  int put(const std::vector<T>& v, const T** dev) { return put(v.data(), v.size(), dev); }
+};
+
+}  // namespace
+
+struct opfx_ctx {
+  int device = 0;
+  int n_cu = 0;
+  int solve_per_cu = 0;
+  opfx_plan plan;     // host copy
+  DevPlan dp{};
+  DevArena arena;
+};
+
+struct opfx_env {
+  opfx_ctx* ctx = nullptr;
+  DevEnv de{};
+  DevReset dr{};
+  bool has_reset = false;
+  DevArena arena;
+  size_t lds_bytes = 0;
+  int per_cu = 0;
+};
+
+namespace {
+
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres) {
+  size_t blk = std::max<size_t>((size_t)4 * p.n_blk, (size_t)nres);
+  size_t d = (size_t)8 * p.nb + blk + (size_t)na;
+  size_t bytes = d * sizeof(double) + (size_t)p.nb * sizeof(int);
+  return (bytes + 15) & ~(size_t)15;
+}
+
+template <typename K>
+int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int* per_cu_cache) {
+  if (*per_cu_cache > 0) {
+    *grid = (int)std::max<long long>(1, std::min<long long>((long long)*per_cu_cache * n_cu, B));
+    return OPFX_OK;
+  }
+  if (lds > 160 * 1024) {
+    opfx_set_error("grid too large for the LDS-resident kernel (needs " + std::to_string(lds) + " B of LDS per instance)");
+    return OPFX_ERR_TOO_LARGE;
+  }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
+  if (per_cu < 1) per_cu = 1;
+  *per_cu_cache = per_cu;
+  long long g = (long long)per_cu * n_cu;
+  *grid = (int)std::max<long long>(1, std::min<long long>(g, B));
+  return OPFX_OK;
+}
+
+}  // namespace
+
+extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
+  if (!p || !out) { opfx_set_error("opfx_ctx_create: null argument"); return OPFX_ERR_INVALID; }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+    opfx_set_error("opfx_ctx_create: no HIP device available");
+    return OPFX_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n_dev) { opfx_set_error("opfx_ctx_create: bad device ordinal"); return OPFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  auto* c = new opfx_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  c->plan = *p;
+  DevPlan& d = c->dp;
+  d.nb = p->nb; d.nbr = p->nbr; d.nref = p->nref; d.nblk = p->n_blk; d.nlev = p->n_levels();
+  d.nfill = (int)p->fill_blk.size(); d.npv = p->npv; d.base_mva = p->base_mva;
+  DevArena& A = c->arena;
+  int rc = OPFX_OK;
+#define PUT(field, vec) if (rc == OPFX_OK) rc = A.put(p->vec, &d.field)
+  PUT(bus_type, bus_type); PUT(y_ptr, y_ptr); PUT(y_col, y_col); PUT(y_blk, y_blk);
+  PUT(diag_blk, diag_blk); PUT(fill_blk, fill_blk); PUT(lev_tptr, lev_tptr); PUT(tgt_blk, tgt_blk);
+  PUT(tgt_sptr, tgt_sptr); PUT(src_ik, src_ik); PUT(src_kk, src_kk); PUT(src_kj, src_kj);
+  PUT(lev_pptr, lev_pptr); PUT(piv_bus, piv_bus); PUT(piv_uptr, piv_uptr); PUT(u_blk, u_blk);
+  PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(ref_bus, ref_bus);
+  PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
+  PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
+#undef PUT
+  if (rc != OPFX_OK) { delete c; return rc; }
+  *out = c;
+  return OPFX_OK;
+}
+
+extern "C" void opfx_ctx_destroy(opfx_ctx* ctx) { delete ctx; }
+
+extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
+                          const double* qg_min, const double* qg_max, const int32_t* outage,
+                          const opfx_solve_opts* opts, double* vm, double* va, double* loading,
+                          double* s_ref, uint8_t* converged, int32_t* iterations,
+                          double* max_mismatch, void* stream) {
+  if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
+  if (B == 0) return OPFX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
+  if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
+  const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
+  size_t lds = solver_lds_bytes(ctx->plan, 0, nres);
+  int grid = 0;
+  int rc = launch_geometry(k_solve, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu);
+  if (rc != OPFX_OK) return rc;
+  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, max_mismatch, converged, iterations};
+  hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
+                     (long long)B);
+  HIP_TRY(hipGetLastError());
+  return OPFX_OK;
+}
+
+extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out) {
+  if (!ctx || !d || !out) { opfx_set_error("opfx_env_create: null argument"); return OPFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const opfx_plan& p = ctx->plan;
+  const int nb = p.nb;
+  if (d->nx <= 0 || d->na < 0 || d->nc < 0 || d->nc > WAVE || d->nobs < 0 || !d->pinj_ptr || !d->qinj_ptr) {
+    opfx_set_error("opfx_env_create: inconsistent descriptor");
+    return OPFX_ERR_INVALID;
+  }
+  auto* e = new opfx_env();
+  e->ctx = ctx;
+  DevEnv& E = e->de;
+  E.nx = d->nx; E.na = d->na; E.npoly = d->npoly; E.npwl = d->npwl; E.nseg = d->nseg;
+  E.nprice = d->nprice; E.nc = d->nc; E.nobs = d->nobs; E.ncost = d->npoly + d->npwl;
+  E.nres = 3 * nb + p.nbr + 2 * p.nref;
+  E.reward_kind = d->reward_kind; E.diff_objective = d->diff_objective;
+  E.steps_per_episode = d->steps_per_episode; E.clamp_enabled = d->clamp_enabled;
+  E.penalty_weight = d->penalty_weight; E.clip_lo = d->clip_lo; E.clip_hi = d->clip_hi;
+  E.objective_factor = d->objective_factor; E.objective_bias = d->objective_bias;
+  E.penalty_factor = d->penalty_factor; E.penalty_bias = d->penalty_bias;
+  E.valid_reward = d->valid_reward; E.invalid_penalty = d->invalid_penalty;
+  E.invalid_objective_share = d->invalid_objective_share;
+  E.diff_step = d->diff_action_step_size; E.clipped_action_penalty = d->clipped_action_penalty;
+  E.n_cont = d->n_cont; E.not_converged_penalty = d->not_converged_penalty;
+  // slot -> action map: a column written by an action is read from the set-point, not from x
+  std::vector<int32_t> slot_act(d->nx, -1);
+  for (int k = 0; k < d->na; ++k) {
+    if (d->act_slot[k] < 0 || d->act_slot[k] >= d->nx) { delete e; opfx_set_error("opfx_env_create: act_slot out of range"); return OPFX_ERR_INVALID; }
+    slot_act[d->act_slot[k]] = k;
+  }
+  auto act_of = [&](const int32_t* slots, size_t n) {
+    std::vector<int32_t> v(n, -1);
+    for (size_t i = 0; i < n; ++i) if (slots[i] >= 0 && slots[i] < d->nx) v[i] = slot_act[slots[i]];
+    return v;
+  };
+  DevArena& A = e->arena;
+  int rc = OPFX_OK;
+  const size_t np_ = d->pinj_ptr[nb], nq_ = d->qinj_ptr[nb];
+#define PUTN(field, ptr, n) if (rc == OPFX_OK) rc = A.put(ptr, (size_t)(n), &E.field)
+  PUTN(pinj_ptr, d->pinj_ptr, nb + 1); PUTN(pinj_slot, d->pinj_slot, np_); PUTN(pinj_coef, d->pinj_coef, np_);
+  PUTN(qinj_ptr, d->qinj_ptr, nb + 1); PUTN(qinj_slot, d->qinj_slot, nq_); PUTN(qinj_coef, d->qinj_coef, nq_);
+  { auto v = act_of(d->pinj_slot, np_); if (rc == OPFX_OK) rc = A.put(v, &E.pinj_act); }
+  { auto v = act_of(d->qinj_slot, nq_); if (rc == OPFX_OK) rc = A.put(v, &E.qinj_act); }
+  if (d->qg_min && d->qg_max) { PUTN(qg_min, d->qg_min, nb); PUTN(qg_max, d->qg_max, nb); }
+  PUTN(act_slot, d->act_slot, d->na); PUTN(act_scaling, d->act_scaling, d->na);
+  PUTN(act_lo_slot, d->act_lo_slot, d->na); PUTN(act_hi_slot, d->act_hi_slot, d->na);
+  PUTN(act_lo_const, d->act_lo_const, d->na); PUTN(act_hi_const, d->act_hi_const, d->na);
+  if (d->clamp_enabled) {
+    PUTN(clamp_lo_slot, d->clamp_lo_slot, d->na); PUTN(clamp_hi_slot, d->clamp_hi_slot, d->na);
+    PUTN(clamp_lo_const, d->clamp_lo_const, d->na); PUTN(clamp_hi_const, d->clamp_hi_const, d->na);
+  }
+  const size_t ncost = (size_t)d->npoly + d->npwl;
+  const size_t ncoef = (size_t)d->npoly * 6 + (size_t)d->npwl * d->nseg * 3;
+  PUTN(cost_kind, d->cost_kind, ncost); PUTN(cost_pidx, d->cost_pidx, ncost); PUTN(cost_qidx, d->cost_qidx, ncost);
+  PUTN(cost_scale, d->cost_scale, ncost); PUTN(pwl_is_q, d->pwl_is_q, d->npwl); PUTN(cost_coef, d->cost_coef, ncoef);
+  {
+    std::vector<int32_t> pa(ncost, -1), qa(ncost, -1);
+    for (size_t r = 0; r < ncost; ++r) {
+      if (d->cost_kind[r] == OPFX_COST_UNIT) {
+        if (d->cost_pidx[r] >= 0) pa[r] = slot_act[d->cost_pidx[r]];
+        if (d->cost_qidx[r] >= 0) qa[r] = slot_act[d->cost_qidx[r]];
+      } else if (d->cost_kind[r] == OPFX_COST_GEN) {
+        if (d->cost_qidx[r] >= 0) qa[r] = slot_act[d->cost_qidx[r]];   // gen: qidx = slot of p_mw
+      }
+    }
+    if (rc == OPFX_OK) rc = A.put(pa, &E.cost_pact);
+    if (rc == OPFX_OK) rc = A.put(qa, &E.cost_qact);
+  }
+  PUTN(price_slot, d->price_slot, d->nprice); PUTN(price_coef, d->price_coef, d->nprice);
+  {
+    std::vector<int32_t> cp(ncoef, -1);
+    for (int k = 0; k < d->nprice; ++k) {
+      if (d->price_coef[k] < 0 || (size_t)d->price_coef[k] >= ncoef) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: price_coef out of range"); break; }
+      cp[d->price_coef[k]] = k;
+    }
+    if (rc == OPFX_OK) rc = A.put(cp, &E.coef_price);
+  }
+  const size_t ncel = d->nc ? d->con_ptr[d->nc] : 0;
+  PUTN(con_ptr, d->con_ptr, d->nc + 1); PUTN(con_src, d->con_src, ncel);
+  {
+    // NaN bound = absent boundary: comparisons against it must be false
+    std::vector<double> lo(d->con_min, d->con_min + ncel), hi(d->con_max, d->con_max + ncel);
+    for (auto& v : lo) if (v != v) v = -INFINITY;
+    for (auto& v : hi) if (v != v) v = INFINITY;
+    if (rc == OPFX_OK) rc = A.put(lo, &E.con_min);
+    if (rc == OPFX_OK) rc = A.put(hi, &E.con_max);
+  }
+  PUTN(con_autoscale, d->con_autoscale, d->nc); PUTN(con_pfac, d->con_penalty_factor, d->nc);
+  PUTN(con_ppow, d->con_penalty_power, d->nc); PUTN(con_cpen, d->con_count_penalty, d->nc);
+  PUTN(con_worst, d->con_worst_case, d->nc);
+  PUTN(obs_kind, d->obs_kind, d->nobs); PUTN(obs_idx, d->obs_idx, d->nobs);
+  {
+    std::vector<int32_t> oa(d->nobs, -1);
+    for (int k = 0; k < d->nobs; ++k)
+      if (d->obs_kind[k] == OPFX_SRC_X && d->obs_idx[k] >= 0 && d->obs_idx[k] < d->nx) oa[k] = slot_act[d->obs_idx[k]];
+    if (rc == OPFX_OK) rc = A.put(oa, &E.obs_act);
+  }
+  PUTN(cont_branch, d->cont_branch, d->n_cont);
+#undef PUTN
+  for (size_t i = 0; rc == OPFX_OK && i < ncel; ++i)
+    if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }
+  if (rc != OPFX_OK) { delete e; return rc; }
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres);
+  *out = e;
+  return OPFX_OK;
+}
+
+extern "C" void opfx_env_destroy(opfx_env* env) { delete env; }
+
+static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
+                   int32_t mode, void* stream) {
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1};
+  if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
+  int grid = 0;
+  int rc = launch_geometry(k_step, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu);
+  if (rc != OPFX_OK) return rc;
+  StepIO s{};
+  s.x = io->x; s.action = io->action; s.initial_obj = io->initial_obj;
+  s.step_in_episode = io->step_in_episode; s.outage = io->outage;
+  s.obs = io->obs; s.reward = io->reward; s.violations = io->violations; s.penalties = io->penalties;
+  s.cost = io->cost; s.objective = io->objective; s.results = io->results;
+  s.mean_correction = io->mean_correction; s.max_mismatch = io->max_mismatch;
+  s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
+  s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
+  hipLaunchKernelGGL(k_step, dim3(grid), dim3(WAVE), env->lds_bytes, static_cast<hipStream_t>(stream),
+                     env->ctx->dp, env->de, s, o, (long long)B);
+  HIP_TRY(hipGetLastError());
+  return OPFX_OK;
+}
+
+extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
+                         int32_t mode, void* stream) {
+  if (!env || !io || !io->x || B < 0 || (mode == 0 && env->de.na > 0 && !io->action)) {
+    opfx_set_error("opfx_step: bad argument");
+    return OPFX_ERR_INVALID;
+  }
+  if (B == 0) return OPFX_OK;
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  return do_step(env, B, io, opts, mode, stream);
+}
+
+extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
+                               int32_t reps, void* stream, float* elapsed_ms) {
+  if (!env || !io || !io->x || B <= 0 || reps <= 0 || !elapsed_ms) {
+    opfx_set_error("opfx_time_steps: bad argument");
+    return OPFX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, st));
+  int rc = OPFX_OK;
+  for (int r = 0; r < reps && rc == OPFX_OK; ++r) rc = do_step(env, B, io, opts, 0, stream);
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
+  if (!env || !d || d->n_tables < 0 || d->n_tables > MAX_TABLES) {
+    opfx_set_error("opfx_env_set_reset: bad argument (at most 8 profile tables)");
+    return OPFX_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  DevReset& R = env->dr;
+  DevArena& A = env->arena;
+  R = DevReset{};
+  R.n_tables = d->n_tables; R.n_ops = d->n_ops; R.n_uniform = d->n_uniform; R.nx = env->de.nx;
+  int rc = OPFX_OK, noise_off = 0;
+  for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
+    const opfx_profile_desc& T = d->tables[t];
+    DevTable& D = R.tab[t];
+    D.n_steps = T.n_steps; D.n_types = T.n_types; D.n_cols = T.n_cols; D.noise_off = noise_off;
+    noise_off += T.n_cols;
+    for (int j = 0; j < T.n_cols; ++j)
+      if (T.slot[j] < 0 || T.slot[j] >= R.nx || T.typ[j] < 0 || T.typ[j] >= T.n_types) {
+        opfx_set_error("opfx_env_set_reset: profile slot/type out of range");
+        return OPFX_ERR_INVALID;
+      }
+    rc = A.put(T.rel, (size_t)T.n_steps * T.n_types, &D.rel);
+    if (rc == OPFX_OK) rc = A.put(T.peak, (size_t)T.n_cols, &D.peak);
+    if (rc == OPFX_OK) rc = A.put(T.col_min, (size_t)T.n_cols, &D.col_min);
+    if (rc == OPFX_OK) rc = A.put(T.col_max, (size_t)T.n_cols, &D.col_max);
+    if (rc == OPFX_OK) rc = A.put(T.typ, (size_t)T.n_cols, &D.typ);
+    if (rc == OPFX_OK) rc = A.put(T.slot, (size_t)T.n_cols, &D.slot);
+  }
+  R.n_noise = noise_off;
+#define PUTN(field, ptr, n) if (rc == OPFX_OK) rc = A.put(ptr, (size_t)(n), &R.field)
+  PUTN(op_code, d->op_code, d->n_ops); PUTN(op_dst, d->op_dst, d->n_ops); PUTN(op_a, d->op_a, d->n_ops);
+  PUTN(op_n, d->op_n, d->n_ops); PUTN(op_c0, d->op_c0, d->n_ops); PUTN(op_c1, d->op_c1, d->n_ops);
+  PUTN(op_c2, d->op_c2, d->n_ops); PUTN(consts, d->consts, d->n_consts);
+#undef PUTN
+  if (rc != OPFX_OK) return rc;
+  env->has_reset = true;
+  return OPFX_OK;
+}
+
+extern "C" int opfx_reset(opfx_env* env, int64_t B, const int32_t* step_idx, const double* noise,
+                          const double* uniform, double* x, void* stream) {
+  if (!env || !env->has_reset || !step_idx || !x || B < 0) {
+    opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
+    return OPFX_ERR_INVALID;
+  }
+  if (env->dr.n_uniform > 0 && !uniform) { opfx_set_error("opfx_reset: uniform draws required"); return OPFX_ERR_INVALID; }
+  if (B == 0) return OPFX_OK;
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  const int grid = (int)std::min<long long>((B + 3) / 4, (long long)env->ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, step_idx,
+                     noise, uniform, x, (long long)B);
+  HIP_TRY(hipGetLastError());
+  return OPFX_OK;
+}

@@ -1,0 +1,274 @@
+// Host-side symbolic analysis: Ybus block CSR, level-scheduled multiple-minimum-
+// degree ordering on the bus graph, symbolic 2x2-block LU, elimination schedule.
+//
+// Replaces the per-call structure work inside pandapower.runpp (third party;
+// call site /root/reference/opfgym/opf_env.py:703): `_pd2ppc` bus typing,
+// `makeYbus`, and the symbolic half of the sparse factorisation that
+// `newtonpf` redoes in every Newton iteration.  In the benchmark environments
+// only injections change between instances and steps (voltage_control.py:56-57,
+// eco_dispatch.py:54-55), so all of it is compiled once per grid here.
+#include "plan.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+#include <unordered_map>
+
+static thread_local std::string g_last_error;
+void opfx_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* opfx_last_error(void) { return g_last_error.c_str(); }
+extern "C" void opfx_version(int* major, int* minor, int* patch) {
+  if (major) *major = OPFX_VERSION_MAJOR;
+  if (minor) *minor = OPFX_VERSION_MINOR;
+  if (patch) *patch = OPFX_VERSION_PATCH;
+}
+
+namespace {
+
+struct BlockMap {
+  int32_t nb;
+  std::unordered_map<int64_t, int32_t> ids;
+  std::vector<int32_t>* rows;
+  std::vector<int32_t>* cols;
+  int32_t get(int32_t i, int32_t j) const {
+    auto it = ids.find((int64_t)i * nb + j);
+    return it == ids.end() ? -1 : it->second;
+  }
+  int32_t get_or_add(int32_t i, int32_t j, bool* added) {
+    int64_t key = (int64_t)i * nb + j;
+    auto it = ids.find(key);
+    if (it != ids.end()) { if (added) *added = false; return it->second; }
+    int32_t id = (int32_t)rows->size();
+    ids.emplace(key, id);
+    rows->push_back(i);
+    cols->push_back(j);
+    if (added) *added = true;
+    return id;
+  }
+};
+
+}  // namespace
+
+extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
+  if (!c || !out) { opfx_set_error("opfx_plan_create: null argument"); return OPFX_ERR_INVALID; }
+  if (c->nb <= 0 || c->nbr < 0 || !c->bus_type || !c->vm_set || !c->va_set ||
+      (c->nbr > 0 && (!c->br_f || !c->br_t || !c->br_y))) {
+    opfx_set_error("opfx_plan_create: incomplete case descriptor");
+    return OPFX_ERR_INVALID;
+  }
+  const int32_t nb = c->nb, nbr = c->nbr;
+  auto* p = new opfx_plan();
+  p->nb = nb; p->nbr = nbr; p->base_mva = c->base_mva;
+  p->bus_type.assign(c->bus_type, c->bus_type + nb);
+  p->vm_set.assign(c->vm_set, c->vm_set + nb);
+  p->va_set.assign(c->va_set, c->va_set + nb);
+  p->br_f.assign(c->br_f, c->br_f + nbr);
+  p->br_t.assign(c->br_t, c->br_t + nbr);
+  p->br_y.assign(c->br_y, c->br_y + (size_t)nbr * 8);
+  p->br_kf.assign(nbr, 0.0); p->br_kt.assign(nbr, 0.0);
+  if (c->br_kf) p->br_kf.assign(c->br_kf, c->br_kf + nbr);
+  if (c->br_kt) p->br_kt.assign(c->br_kt, c->br_kt + nbr);
+  p->ref_ord.assign(nb, -1);
+  for (int32_t i = 0; i < nb; ++i) {
+    int32_t t = p->bus_type[i];
+    if (t == OPFX_REF) { p->ref_ord[i] = (int32_t)p->ref_bus.size(); p->ref_bus.push_back(i); }
+    else if (t == OPFX_PV) p->npv++;
+    else if (t == OPFX_PQ) p->npq++;
+    else { delete p; opfx_set_error("opfx_plan_create: bad bus_type"); return OPFX_ERR_INVALID; }
+  }
+  p->nref = (int32_t)p->ref_bus.size();
+  if (p->nref == 0) { delete p; opfx_set_error("opfx_plan_create: no REF bus"); return OPFX_ERR_SINGULAR; }
+  for (int32_t k = 0; k < nbr; ++k)
+    if (p->br_f[k] < 0 || p->br_f[k] >= nb || p->br_t[k] < 0 || p->br_t[k] >= nb ||
+        p->br_f[k] == p->br_t[k]) {
+      delete p; opfx_set_error("opfx_plan_create: bad branch end"); return OPFX_ERR_INVALID;
+    }
+
+  // ---- Ybus (makeYbus): block CSR with sorted columns -------------
+  std::vector<std::map<int32_t, std::pair<double, double>>> rows(nb);
+  for (int32_t i = 0; i < nb; ++i)
+    rows[i][i] = {c->gs ? c->gs[i] : 0.0, c->bs ? c->bs[i] : 0.0};
+  for (int32_t k = 0; k < nbr; ++k) {
+    const double* y = &p->br_y[(size_t)k * 8];
+    int32_t f = p->br_f[k], t = p->br_t[k];
+    auto add = [&](int32_t i, int32_t j, double g, double b) {
+      auto& e = rows[i][j]; e.first += g; e.second += b; };
+    add(f, f, y[0], y[1]); add(f, t, y[2], y[3]); add(t, f, y[4], y[5]); add(t, t, y[6], y[7]);
+  }
+  p->y_ptr.assign(nb + 1, 0);
+  p->y_diag.assign(nb, -1);
+  for (int32_t i = 0; i < nb; ++i) {
+    p->y_ptr[i] = (int32_t)p->y_col.size();
+    for (auto& kv : rows[i]) {
+      if (kv.first == i) p->y_diag[i] = (int32_t)p->y_col.size();
+      p->y_col.push_back(kv.first);
+      p->y_g.push_back(kv.second.first);
+      p->y_b.push_back(kv.second.second);
+    }
+  }
+  p->y_ptr[nb] = (int32_t)p->y_col.size();
+  auto ypos = [&](int32_t i, int32_t j) {
+    auto b = p->y_col.begin() + p->y_ptr[i], e = p->y_col.begin() + p->y_ptr[i + 1];
+    return (int32_t)(std::lower_bound(b, e, j) - p->y_col.begin());
+  };
+  p->br_pos.resize((size_t)nbr * 4);
+  for (int32_t k = 0; k < nbr; ++k) {
+    int32_t f = p->br_f[k], t = p->br_t[k];
+    p->br_pos[k * 4 + 0] = ypos(f, f); p->br_pos[k * 4 + 1] = ypos(f, t);
+    p->br_pos[k * 4 + 2] = ypos(t, f); p->br_pos[k * 4 + 3] = ypos(t, t);
+  }
+
+  // ---- Jacobian block pattern on non-REF buses -------------------------------
+  BlockMap bm{nb, {}, &p->blk_row, &p->blk_col};
+  std::vector<std::set<int32_t>> adj(nb);
+  auto is_ref = [&](int32_t i) { return p->bus_type[i] == OPFX_REF; };
+  p->y_blk.assign(p->y_col.size(), -1);
+  p->diag_blk.assign(nb, -1);
+  for (int32_t i = 0; i < nb; ++i) {
+    if (is_ref(i)) continue;
+    for (int32_t e = p->y_ptr[i]; e < p->y_ptr[i + 1]; ++e) {
+      int32_t j = p->y_col[e];
+      if (is_ref(j)) continue;
+      p->y_blk[e] = bm.get_or_add(i, j, nullptr);
+      if (i == j) p->diag_blk[i] = p->y_blk[e];
+      else { adj[i].insert(j); adj[j].insert(i); }
+      // pypower scalar Jacobian non-zeros (for the byte model)
+      bool ipq = p->bus_type[i] == OPFX_PQ, jpq = p->bus_type[j] == OPFX_PQ;
+      p->nnz_j += 1 + (jpq ? 1 : 0) + (ipq ? 1 : 0) + (ipq && jpq ? 1 : 0);
+    }
+  }
+  // symmetric pattern is required by the block elimination
+  for (int32_t i = 0; i < nb; ++i)
+    for (int32_t j : adj[i])
+      if (bm.get(i, j) < 0) {
+        bool added; int32_t id = bm.get_or_add(i, j, &added);
+        p->fill_blk.push_back(id);
+      }
+
+  // ---- level-scheduled multiple-minimum-degree elimination --------------------
+  std::vector<char> alive(nb, 0), blocked(nb, 0);
+  int32_t n_alive = 0;
+  for (int32_t i = 0; i < nb; ++i) if (!is_ref(i)) { alive[i] = 1; ++n_alive; }
+  p->lev_tptr.push_back(0);
+  p->lev_pptr.push_back(0);
+  p->tgt_sptr.push_back(0);
+  p->piv_uptr.push_back(0);
+  std::vector<int32_t> cand;
+  while (n_alive > 0) {
+    cand.clear();
+    size_t dmin = SIZE_MAX;
+    for (int32_t i = 0; i < nb; ++i) if (alive[i]) { cand.push_back(i); dmin = std::min(dmin, adj[i].size()); }
+    size_t dcap = std::max<size_t>(2, dmin);
+    std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) {
+      return adj[a].size() < adj[b].size(); });
+    std::fill(blocked.begin(), blocked.end(), 0);
+    std::vector<int32_t> piv;
+    for (int32_t k : cand) {
+      if (adj[k].size() > dcap) break;
+      if (blocked[k]) continue;
+      piv.push_back(k);
+      blocked[k] = 1;
+      for (int32_t j : adj[k]) blocked[j] = 1;
+    }
+    // targets of this level, grouped: key = block id (>=0) or -1-bus (rhs)
+    std::map<int32_t, std::vector<std::array<int32_t, 3>>> tg;
+    std::vector<std::pair<int32_t, int32_t>> new_edges;
+    for (int32_t k : piv) {
+      const int32_t kk = p->diag_blk[k];
+      std::vector<int32_t> nbrs(adj[k].begin(), adj[k].end());
+      p->piv_bus.push_back(k);
+      for (int32_t j : nbrs) { p->u_blk.push_back(bm.get(k, j)); p->u_col.push_back(j); }
+      p->piv_uptr.push_back((int32_t)p->u_blk.size());
+      for (int32_t i : nbrs) {
+        const int32_t ik = bm.get(i, k);
+        tg[-1 - i].push_back({ik, kk, k});
+        for (int32_t j : nbrs) {
+          bool added = false;
+          int32_t ij = bm.get_or_add(i, j, &added);
+          if (added) { p->fill_blk.push_back(ij); if (i < j) new_edges.push_back({i, j}); }
+          if (i == j && p->diag_blk[i] < 0) p->diag_blk[i] = ij;
+          tg[ij].push_back({ik, kk, bm.get(k, j)});
+        }
+      }
+    }
+    // heavy targets first so that a wave round holds similar trip counts
+    std::vector<std::pair<int32_t, const std::vector<std::array<int32_t, 3>>*>> order;
+    for (auto& kv : tg) order.push_back({kv.first, &kv.second});
+    std::stable_sort(order.begin(), order.end(), [](auto& a, auto& b) {
+      return a.second->size() > b.second->size(); });
+    for (auto& o : order) {
+      p->tgt_blk.push_back(o.first);
+      for (auto& s : *o.second) { p->src_ik.push_back(s[0]); p->src_kk.push_back(s[1]); p->src_kj.push_back(s[2]); }
+      p->tgt_sptr.push_back((int32_t)p->src_ik.size());
+    }
+    p->lev_tptr.push_back((int32_t)p->tgt_blk.size());
+    p->lev_pptr.push_back((int32_t)p->piv_bus.size());
+    p->max_level_width = std::max<int32_t>(p->max_level_width, (int32_t)order.size());
+    p->max_level_width = std::max<int32_t>(p->max_level_width, (int32_t)piv.size());
+    for (auto& e : new_edges) { adj[e.first].insert(e.second); adj[e.second].insert(e.first); }
+    for (int32_t k : piv) {
+      for (int32_t j : adj[k]) adj[j].erase(k);
+      adj[k].clear();
+      alive[k] = 0; --n_alive;
+    }
+  }
+  p->n_blk = (int32_t)p->blk_row.size();
+  *out = p;
+  return OPFX_OK;
+}
+
+extern "C" void opfx_plan_destroy(opfx_plan* p) { delete p; }
+
+extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
+  if (!p || !o) { opfx_set_error("opfx_plan_get_info: null argument"); return OPFX_ERR_INVALID; }
+  o->nb = p->nb; o->nbr = p->nbr; o->nref = p->nref; o->npv = p->npv; o->npq = p->npq;
+  o->nnz_y = (int32_t)p->y_col.size();
+  o->nnz_j = p->nnz_j;
+  o->n_blk = p->n_blk;
+  o->n_fill = (int32_t)p->fill_blk.size();
+  o->n_levels = p->n_levels();
+  o->n_targets = (int32_t)p->tgt_blk.size();
+  o->n_sources = (int32_t)p->src_ik.size();
+  o->n_uterms = (int32_t)p->u_blk.size();
+  o->max_level_width = p->max_level_width;
+  o->lds_doubles = 8 * p->nb + 4 * p->n_blk;
+  return OPFX_OK;
+}
+
+extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* out, int64_t cap) {
+  if (!p) { opfx_set_error("opfx_plan_get_array: null plan"); return OPFX_ERR_INVALID; }
+  const std::vector<int32_t>* v = nullptr;
+  switch (which) {
+    case OPFX_ARR_Y_PTR: v = &p->y_ptr; break;
+    case OPFX_ARR_Y_COL: v = &p->y_col; break;
+    case OPFX_ARR_Y_BLK: v = &p->y_blk; break;
+    case OPFX_ARR_DIAG_BLK: v = &p->diag_blk; break;
+    case OPFX_ARR_FILL_BLK: v = &p->fill_blk; break;
+    case OPFX_ARR_LEV_TPTR: v = &p->lev_tptr; break;
+    case OPFX_ARR_TGT_BLK: v = &p->tgt_blk; break;
+    case OPFX_ARR_TGT_SPTR: v = &p->tgt_sptr; break;
+    case OPFX_ARR_SRC_IK: v = &p->src_ik; break;
+    case OPFX_ARR_SRC_KK: v = &p->src_kk; break;
+    case OPFX_ARR_SRC_KJ: v = &p->src_kj; break;
+    case OPFX_ARR_LEV_PPTR: v = &p->lev_pptr; break;
+    case OPFX_ARR_PIV_BUS: v = &p->piv_bus; break;
+    case OPFX_ARR_PIV_UPTR: v = &p->piv_uptr; break;
+    case OPFX_ARR_U_BLK: v = &p->u_blk; break;
+    case OPFX_ARR_U_COL: v = &p->u_col; break;
+    case OPFX_ARR_BLK_ROW: v = &p->blk_row; break;
+    case OPFX_ARR_BLK_COL: v = &p->blk_col; break;
+    default: opfx_set_error("opfx_plan_get_array: unknown array id"); return OPFX_ERR_INVALID;
+  }
+  if (out) std::memcpy(out, v->data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
+}
+
+extern "C" int opfx_plan_get_ybus(const opfx_plan* p, double* out_g, double* out_b) {
+  if (!p) { opfx_set_error("opfx_plan_get_ybus: null plan"); return OPFX_ERR_INVALID; }
+  if (out_g) std::memcpy(out_g, p->y_g.data(), sizeof(double) * p->y_g.size());
+  if (out_b) std::memcpy(out_b, p->y_b.data(), sizeof(double) * p->y_b.size());
+  return OPFX_OK;
+}

@@ -1,0 +1,227 @@
+"""Minimal pandapower-shaped network container.
+
+The reference environment (`/root/reference/opfgym/opf_env.py:58`) mutates a
+``pandapowerNet``: an attribute-dict of pandas DataFrames (``net.load``,
+``net['load']``, ``net.res_bus`` ...).  pandapower itself is a third-party
+dependency that is not available here, so this module provides the same
+*shape* (table names and column names) with a handful of ``create_*`` helpers.
+A real pandapowerNet can be passed wherever a :class:`Net` is accepted: only
+the tables/columns listed in SURVEY.md Appendix B are touched.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pandas as pd
+
+_TABLES = {
+    'bus': ['name', 'vn_kv', 'type', 'in_service', 'min_vm_pu', 'max_vm_pu'],
+    'line': ['name', 'from_bus', 'to_bus', 'length_km', 'r_ohm_per_km',
+             'x_ohm_per_km', 'c_nf_per_km', 'g_us_per_km', 'max_i_ka', 'df',
+             'parallel', 'in_service', 'max_loading_percent'],
+    'trafo': ['name', 'hv_bus', 'lv_bus', 'sn_mva', 'vn_hv_kv', 'vn_lv_kv',
+              'vk_percent', 'vkr_percent', 'pfe_kw', 'i0_percent',
+              'shift_degree', 'tap_side', 'tap_neutral', 'tap_pos',
+              'tap_step_percent', 'parallel', 'df', 'in_service',
+              'max_loading_percent'],
+    'trafo3w': [],
+    'load': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
+             'controllable'],
+    'sgen': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
+             'controllable'],
+    'storage': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
+                'controllable'],
+    'gen': ['name', 'bus', 'p_mw', 'vm_pu', 'scaling', 'in_service',
+            'controllable', 'min_q_mvar', 'max_q_mvar'],
+    'ext_grid': ['name', 'bus', 'vm_pu', 'va_degree', 'in_service'],
+    'shunt': ['bus', 'p_mw', 'q_mvar', 'vn_kv', 'step', 'in_service'],
+    'switch': ['bus', 'element', 'et', 'closed'],
+    'poly_cost': ['element', 'et', 'cp0_eur', 'cp1_eur_per_mw',
+                  'cp2_eur_per_mw2', 'cq0_eur', 'cq1_eur_per_mvar',
+                  'cq2_eur_per_mvar2'],
+    'pwl_cost': ['power_type', 'element', 'et', 'points'],
+}
+
+
+class Net(dict):
+    """Attribute-dict of DataFrames, same access idioms as a pandapowerNet
+    (`net.load` and `net['load']`, both used by opf_env.py:105,267)."""
+
+    def __init__(self, name: str = '', f_hz: float = 50.0, sn_mva: float = 1.0):
+        super().__init__()
+        self['name'] = name
+        self['f_hz'] = float(f_hz)
+        self['sn_mva'] = float(sn_mva)
+        for tbl, cols in _TABLES.items():
+            self[tbl] = pd.DataFrame(columns=cols)
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError as exc:
+            raise AttributeError(key) from exc
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+    def __deepcopy__(self, memo):
+        new = Net.__new__(Net)
+        dict.__init__(new)
+        for k, v in self.items():
+            new[k] = copy.deepcopy(v, memo)
+        return new
+
+    def deepcopy(self) -> 'Net':
+        return copy.deepcopy(self)
+
+
+def _append(net, table: str, row: dict, index=None) -> int:
+    df = net[table]
+    if index is None:
+        index = 0 if len(df) == 0 else int(df.index.max()) + 1
+    for col in row:
+        if col not in df.columns:
+            df[col] = pd.Series(dtype=object if isinstance(row[col], (str, list)) else float)
+    df.loc[index] = pd.Series(row, dtype=object)
+    return index
+
+
+def _finalize_dtypes(net) -> None:
+    """Give numeric columns numeric dtypes (rows are appended as objects)."""
+    for tbl in _TABLES:
+        df = net[tbl]
+        if len(df) == 0:
+            continue
+        for col in df.columns:
+            if col in ('name', 'type', 'tap_side', 'et', 'points', 'power_type'):
+                continue
+            if col in ('in_service', 'controllable', 'closed'):
+                df[col] = df[col].astype(bool)
+                continue
+            try:
+                conv = pd.to_numeric(df[col])
+            except (ValueError, TypeError):
+                continue
+            if col in ('bus', 'from_bus', 'to_bus', 'hv_bus', 'lv_bus',
+                       'element', 'parallel') and not conv.isna().any():
+                conv = conv.astype(np.int64)
+            df[col] = conv
+
+
+def create_bus(net, vn_kv, name=None, index=None, in_service=True, **kw) -> int:
+    return _append(net, 'bus', dict(name=name, vn_kv=float(vn_kv), type='b',
+                                    in_service=bool(in_service), **kw), index)
+
+
+def create_line_from_parameters(net, from_bus, to_bus, length_km, r_ohm_per_km,
+                                x_ohm_per_km, c_nf_per_km, max_i_ka,
+                                g_us_per_km=0.0, df=1.0, parallel=1,
+                                in_service=True, name=None, index=None, **kw) -> int:
+    return _append(net, 'line', dict(
+        name=name, from_bus=int(from_bus), to_bus=int(to_bus),
+        length_km=float(length_km), r_ohm_per_km=float(r_ohm_per_km),
+        x_ohm_per_km=float(x_ohm_per_km), c_nf_per_km=float(c_nf_per_km),
+        g_us_per_km=float(g_us_per_km), max_i_ka=float(max_i_ka), df=float(df),
+        parallel=int(parallel), in_service=bool(in_service), **kw), index)
+
+
+def create_transformer_from_parameters(net, hv_bus, lv_bus, sn_mva, vn_hv_kv,
+                                       vn_lv_kv, vk_percent, vkr_percent,
+                                       pfe_kw, i0_percent, shift_degree=0.0,
+                                       tap_side=None, tap_neutral=0, tap_pos=0,
+                                       tap_step_percent=0.0, parallel=1, df=1.0,
+                                       in_service=True, name=None, index=None,
+                                       **kw) -> int:
+    return _append(net, 'trafo', dict(
+        name=name, hv_bus=int(hv_bus), lv_bus=int(lv_bus), sn_mva=float(sn_mva),
+        vn_hv_kv=float(vn_hv_kv), vn_lv_kv=float(vn_lv_kv),
+        vk_percent=float(vk_percent), vkr_percent=float(vkr_percent),
+        pfe_kw=float(pfe_kw), i0_percent=float(i0_percent),
+        shift_degree=float(shift_degree), tap_side=tap_side,
+        tap_neutral=float(tap_neutral), tap_pos=float(tap_pos),
+        tap_step_percent=float(tap_step_percent), parallel=int(parallel),
+        df=float(df), in_service=bool(in_service), **kw), index)
+
+
+def _create_unit(net, table, bus, p_mw, q_mvar, scaling, in_service, name,
+                 index, controllable, **kw) -> int:
+    return _append(net, table, dict(
+        name=name, bus=int(bus), p_mw=float(p_mw), q_mvar=float(q_mvar),
+        scaling=float(scaling), in_service=bool(in_service),
+        controllable=bool(controllable), **kw), index)
+
+
+def create_load(net, bus, p_mw, q_mvar=0.0, scaling=1.0, in_service=True,
+                name=None, index=None, controllable=False, **kw) -> int:
+    return _create_unit(net, 'load', bus, p_mw, q_mvar, scaling, in_service,
+                        name, index, controllable, **kw)
+
+
+def create_sgen(net, bus, p_mw, q_mvar=0.0, scaling=1.0, in_service=True,
+                name=None, index=None, controllable=False, **kw) -> int:
+    return _create_unit(net, 'sgen', bus, p_mw, q_mvar, scaling, in_service,
+                        name, index, controllable, **kw)
+
+
+def create_storage(net, bus, p_mw, q_mvar=0.0, scaling=1.0, in_service=True,
+                   name=None, index=None, controllable=False, **kw) -> int:
+    return _create_unit(net, 'storage', bus, p_mw, q_mvar, scaling, in_service,
+                        name, index, controllable, **kw)
+
+
+def create_gen(net, bus, p_mw, vm_pu=1.0, scaling=1.0, in_service=True,
+               min_q_mvar=np.nan, max_q_mvar=np.nan, name=None, index=None,
+               controllable=True, **kw) -> int:
+    return _append(net, 'gen', dict(
+        name=name, bus=int(bus), p_mw=float(p_mw), vm_pu=float(vm_pu),
+        scaling=float(scaling), in_service=bool(in_service),
+        controllable=bool(controllable), min_q_mvar=float(min_q_mvar),
+        max_q_mvar=float(max_q_mvar), **kw), index)
+
+
+def create_ext_grid(net, bus, vm_pu=1.0, va_degree=0.0, in_service=True,
+                    name=None, index=None, **kw) -> int:
+    return _append(net, 'ext_grid', dict(
+        name=name, bus=int(bus), vm_pu=float(vm_pu), va_degree=float(va_degree),
+        in_service=bool(in_service), **kw), index)
+
+
+def create_shunt(net, bus, q_mvar, p_mw=0.0, vn_kv=None, step=1,
+                 in_service=True, index=None) -> int:
+    if vn_kv is None:
+        vn_kv = float(net.bus.at[bus, 'vn_kv'])
+    return _append(net, 'shunt', dict(bus=int(bus), p_mw=float(p_mw),
+                                      q_mvar=float(q_mvar), vn_kv=float(vn_kv),
+                                      step=int(step),
+                                      in_service=bool(in_service)), index)
+
+
+def create_switch(net, bus, element, et, closed=True, index=None) -> int:
+    return _append(net, 'switch', dict(bus=int(bus), element=int(element),
+                                       et=et, closed=bool(closed)), index)
+
+
+def create_poly_cost(net, element, et, cp1_eur_per_mw, cp0_eur=0.0,
+                     cq1_eur_per_mvar=0.0, cq0_eur=0.0, cp2_eur_per_mw2=0.0,
+                     cq2_eur_per_mvar2=0.0, index=None) -> int:
+    """Same argument order as pandapower.create_poly_cost as it is called at
+    voltage_control.py:88-100, eco_dispatch.py:97-99, max_renewable.py:96."""
+    return _append(net, 'poly_cost', dict(
+        element=int(element), et=et, cp0_eur=float(cp0_eur),
+        cp1_eur_per_mw=float(cp1_eur_per_mw),
+        cp2_eur_per_mw2=float(cp2_eur_per_mw2), cq0_eur=float(cq0_eur),
+        cq1_eur_per_mvar=float(cq1_eur_per_mvar),
+        cq2_eur_per_mvar2=float(cq2_eur_per_mvar2)), index)
+
+
+def create_pwl_cost(net, element, et, points, power_type='p', index=None) -> int:
+    """Same shape as pandapower.create_pwl_cost (eco_dispatch.py:95)."""
+    return _append(net, 'pwl_cost', dict(
+        power_type=power_type, element=int(element), et=et,
+        points=[list(map(float, p)) for p in points]), index)
+
+
+def finalize(net) -> Net:
+    _finalize_dtypes(net)
+    return net

@@ -1,0 +1,126 @@
+"""Test helper: walks the elimination programme compiled by `opfx_plan_create`
+in plain numpy, statement by statement as the HIP kernel `newton()` in
+opfgym_amd/csrc/opfx.hip does.  Lets the CPU-only suite validate the symbolic
+schedule (pattern, fill, level independence, back-substitution lists) and the
+2x2-block formulas against the SciPy oracle without a GPU.  Test code only."""
+import numpy as np
+
+PQ, PV, REF = 1, 2, 3
+
+
+def load_plan(plan):
+    names = ['y_ptr', 'y_col', 'y_blk', 'diag_blk', 'fill_blk', 'lev_tptr', 'tgt_blk', 'tgt_sptr',
+             'src_ik', 'src_kk', 'src_kj', 'lev_pptr', 'piv_bus', 'piv_uptr', 'u_blk', 'u_col',
+             'blk_row', 'blk_col']
+    d = {n: plan.array(n) for n in names}
+    d['y_g'], d['y_b'] = plan.ybus()
+    return d
+
+
+def _inv2(b):
+    det = b[0, 0] * b[1, 1] - b[0, 1] * b[1, 0]
+    return np.array([[b[1, 1], -b[0, 1]], [-b[1, 0], b[0, 0]]]) / det
+
+
+def emulate_newton(plan, p_sp, q_sp, tol=1e-8, max_iter=10, check_levels=True):
+    """One instance.  Returns (V, converged, iterations, norm)."""
+    P = load_plan(plan)
+    case = plan.case
+    nb = case.nb
+    bt = case.bus_type
+    vm = case.vm_set.astype(float).copy()
+    va = case.va_set.astype(float).copy()
+    nblk = plan.info['n_blk']
+    it = 0
+    while True:
+        v = vm * np.exp(1j * va)
+        blk = np.full((nblk, 2, 2), np.nan)
+        blk[P['fill_blk']] = 0.0
+        rhs = np.zeros((nb, 2))
+        nrm = 0.0
+        for i in range(nb):
+            t = bt[i]
+            ioff = 0j
+            d = 0j
+            for e in range(P['y_ptr'][i], P['y_ptr'][i + 1]):
+                j = P['y_col'][e]
+                tt = (P['y_g'][e] + 1j * P['y_b'][e]) * v[j]
+                if j == i:
+                    d = tt
+                    continue
+                ioff += tt
+                bid = P['y_blk'][e]
+                if bid >= 0 and t != REF:
+                    c = v[i] * np.conj(tt)
+                    jb = np.array([[c.imag, c.real / vm[j]], [-c.real, c.imag / vm[j]]])
+                    if t == PV:
+                        jb[1] = 0.0
+                    blk[bid] = jb
+            if t != REF:
+                s = v[i] * np.conj(ioff + d)
+                fp = s.real - p_sp[i]
+                fq = 0.0 if t == PV else s.imag - q_sp[i]
+                rhs[i] = (-fp, -fq)
+                nrm = max(nrm, abs(fp), abs(fq))
+                e_ = v[i] * np.conj(ioff)
+                y_ = v[i] * np.conj(d)
+                jb = np.array([[-e_.imag, (y_.real + s.real) / vm[i]],
+                               [e_.real, (y_.imag + s.imag) / vm[i]]])
+                if t == PV:
+                    jb[1] = (0.0, 1.0)
+                blk[P['diag_blk'][i]] = jb
+        if not np.isfinite(nrm):
+            return v, False, it, nrm
+        if nrm < tol:
+            return v, True, it, nrm
+        if it >= max_iter:
+            return v, False, it, nrm
+        it += 1
+        assert not np.isnan(blk).any(), 'a block of the LU pattern was never initialised'
+        nlev = len(P['lev_tptr']) - 1
+        for lev in range(nlev):
+            t0, t1 = P['lev_tptr'][lev], P['lev_tptr'][lev + 1]
+            new_blk, new_rhs = {}, {}
+            written = set()
+            read = set()
+            for t in range(t0, t1):
+                tb = P['tgt_blk'][t]
+                s0, s1 = P['tgt_sptr'][t], P['tgt_sptr'][t + 1]
+                if tb >= 0:
+                    a = blk[tb].copy()
+                    for s in range(s0, s1):
+                        ik, kk, kj = P['src_ik'][s], P['src_kk'][s], P['src_kj'][s]
+                        read.update((ik, kk, kj))
+                        a -= blk[ik] @ _inv2(blk[kk]) @ blk[kj]
+                    new_blk[tb] = a
+                    written.add(tb)
+                else:
+                    i = -1 - tb
+                    y = rhs[i].copy()
+                    for s in range(s0, s1):
+                        ik, kk, k = P['src_ik'][s], P['src_kk'][s], P['src_kj'][s]
+                        read.update((ik, kk))
+                        y -= blk[ik] @ (_inv2(blk[kk]) @ rhs[k])
+                        assert ('r', k) not in new_rhs
+                    new_rhs[('r', i)] = y
+            if check_levels:
+                assert not (written & read), 'a level reads a block it also writes'
+            for tb, a in new_blk.items():
+                blk[tb] = a
+            for (_, i), y in new_rhs.items():
+                rhs[i] = y
+        for lev in range(nlev - 1, -1, -1):
+            for q in range(P['lev_pptr'][lev], P['lev_pptr'][lev + 1]):
+                k = P['piv_bus'][q]
+                y = rhs[k].copy()
+                for u in range(P['piv_uptr'][q], P['piv_uptr'][q + 1]):
+                    y -= blk[P['u_blk'][u]] @ rhs[P['u_col'][u]]
+                rhs[k] = _inv2(blk[P['diag_blk'][k]]) @ y
+        for i in range(nb):
+            if bt[i] == REF:
+                continue
+            va[i] += rhs[i, 0]
+            vm[i] += rhs[i, 1]
+            if vm[i] < 0:
+                vm[i] = -vm[i]
+                va[i] += np.pi
