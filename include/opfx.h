@@ -265,8 +265,10 @@ typedef struct opfx_step_io {
 
 /* One env.step() for B instances: apply actions → injections → NR → results →
  * objective → violations → reward → observation, one kernel launch.
- * mode: 0 = full step; 1 = power flow for reset (pf_for_obs, opf_env.py:209-
- * 218: no action applied, writes obs/results/objective only). */
+ * mode: 0 = full step; 1 = evaluate the current set-points without applying
+ * `action` (`apply_action=False`, opf_env.py:197,386); 2 = apply `action` and
+ * write the table observation only, no power flow (reset of an environment
+ * whose observation needs no results, opf_env.py:207,218). */
 int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
               const opfx_solve_opts* opts, int32_t mode, void* stream);
 
@@ -306,6 +308,8 @@ typedef struct opfx_reset_desc {
   int32_t n_consts;
   const double* consts;
   int32_t n_uniform;         /* uniform draws consumed per instance          */
+  int32_t init_off;          /* offset into consts of an nx-long row template copied
+                                into x before the tables are applied, or -1  */
 } opfx_reset_desc;
 
 int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d);

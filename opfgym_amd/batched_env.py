@@ -1,0 +1,772 @@
+"""Batched OPF environment: B independent instances of one grid per call.
+
+Host-side mirror of `/root/reference/opfgym/opf_env.py` (`OpfEnv`) and
+`security_constrained.py` (`SecurityConstrainedOpfEnv`): same constructor
+arguments and gymnasium-shaped `reset()/step()` API, but every call handles a
+whole batch and all numerics run on the GPU through libopfx (one kernel launch
+per `step`, one per `reset`).  This file only *compiles* the problem definition
+(action/observation keys, constraints, cost tables, reward, sampling programme)
+into the flat descriptors of `include/opfx.h` and moves tensors; it contains no
+power-flow or reward arithmetic and there is no CPU fallback.
+
+Per-instance state is a column store x[B, nx] (torch CUDA tensor): one slot per
+row of every per-instance table column the reference net would hold
+(`net.load.p_mw`, `net.sgen.max_q_mvar`, `net.poly_cost.cq2_eur_per_mvar2`, …),
+holding TABLE values exactly as the reference net does (i.e. before `scaling`).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from . import constraints as constraints_mod
+from . import reward as reward_mod
+from .case import KIND_LINE, KIND_TRAFO, PQ, PV, REF, net_to_case
+from .grids import factored_profile
+from .simbench_build import define_test_train_split, get_simbench_time_observation
+
+_POLY_COEF = {'cp0_eur': 0, 'cp1_eur_per_mw': 1, 'cp2_eur_per_mw2': 2,
+              'cq0_eur': 3, 'cq1_eur_per_mvar': 4, 'cq2_eur_per_mvar2': 5}
+
+
+class ColumnStore:
+    """Slot allocator for x: (table, column) -> contiguous range over the rows
+    of that table, with the net's current values as the row template."""
+
+    def __init__(self, net):
+        self.net = net
+        self.ranges = {}
+        self.template = []
+        self.n = 0
+        self.dynamic = set()
+
+    def slot(self, table, col, dynamic=False):
+        key = (table, col)
+        if key not in self.ranges:
+            tbl = self.net[table]
+            n = len(tbl)
+            if col in tbl.columns:
+                vals = np.array([float(v) if v is not None else np.nan
+                                 for v in tbl[col].to_numpy()], dtype=float) if n else np.zeros(0)
+            else:
+                vals = np.zeros(n)
+            self.ranges[key] = (self.n, n)
+            self.template.append(vals)
+            self.n += n
+        if dynamic:
+            self.dynamic.add(key)
+        return self.ranges[key][0]
+
+    def rows(self, table, idxs):
+        pos = self.net[table].index.get_indexer(np.asarray(idxs))
+        if (pos < 0).any():
+            raise KeyError(f'index not in net.{table}: {np.asarray(idxs)[pos < 0]}')
+        return pos
+
+    def slots(self, table, col, idxs, dynamic=False):
+        return self.slot(table, col, dynamic) + self.rows(table, idxs)
+
+    def row_template(self):
+        return np.concatenate(self.template) if self.template else np.zeros(0)
+
+
+class OpsBuilder:
+    """Collects the `_sampling` tail of an environment as vector ops on x
+    (see OPFX_OP_* in include/opfx.h)."""
+
+    def __init__(self, store: ColumnStore):
+        self.store = store
+        self.ops = []          # (code, dst, a, n, c0, c1, c2) with c* numpy vectors or None
+        self.n_uniform = 0
+
+    def _emit(self, code, dst, a, c0=None, c1=None, c2=None):
+        """dst/a: arrays of slots; split into runs where both are contiguous."""
+        dst = np.asarray(dst, dtype=np.int64)
+        a = np.asarray(a, dtype=np.int64)
+        n = len(dst)
+        if n == 0:
+            return
+        cut = np.flatnonzero((np.diff(dst) != 1) | (np.diff(a) != 1)) + 1
+        for s, e in zip(np.r_[0, cut], np.r_[cut, n]):
+            sl = slice(s, e)
+            self.ops.append((code, int(dst[s]), int(a[s]), int(e - s),
+                             None if c0 is None else np.broadcast_to(np.asarray(c0, float), (n,))[sl].copy(),
+                             None if c1 is None else np.broadcast_to(np.asarray(c1, float), (n,))[sl].copy(),
+                             None if c2 is None else np.broadcast_to(np.asarray(c2, float), (n,))[sl].copy()))
+
+    def _all(self, table, col, rows=None, dynamic=False):
+        base = self.store.slot(table, col, dynamic)
+        n = len(self.store.net[table])
+        rows = np.arange(n) if rows is None else np.asarray(rows)
+        return base + rows
+
+    def set_const(self, table, col, values, rows=None):
+        dst = self._all(table, col, rows, True)
+        self._emit(capi.OP_SET_CONST, dst, dst, c0=values)
+
+    def affine(self, table, col, src_col, c0, c1, rows=None):
+        dst = self._all(table, col, rows, True)
+        self._emit(capi.OP_AFFINE, dst, self._all(table, src_col, rows), c0=c0, c1=c1)
+
+    def sqrt_diff(self, table, col, src_col, c0, rows=None):
+        dst = self._all(table, col, rows, True)
+        self._emit(capi.OP_SQRT_DIFF, dst, self._all(table, src_col, rows), c0=c0)
+
+    def neg(self, table, col, src_col, rows=None):
+        dst = self._all(table, col, rows, True)
+        self._emit(capi.OP_NEG, dst, self._all(table, src_col, rows))
+
+    def uniform(self, table, col, idxs, lo, hi, scale=1.0):
+        """opf_env.py:266-284 `_sample_from_range`: one U[lo,hi] draw per row,
+        divided by `scale`; consumes len(idxs) draws of the instance's draw
+        vector, in order."""
+        rows = self.store.rows(table, idxs)
+        dst = self._all(table, col, rows, True)
+        src = self.n_uniform + np.arange(len(rows))
+        self.n_uniform += len(rows)
+        self._emit(capi.OP_UNIFORM, dst, src, c0=lo, c1=hi, c2=scale)
+
+
+def _keep(lst, arr, kind):
+    a = np.ascontiguousarray(arr, dtype=np.float64 if kind == 'd' else np.int32)
+    lst.append(a)
+    return a.ctypes.data_as(capi._pd if kind == 'd' else capi._pi)
+
+
+class BatchedOpfEnv:
+    """See module docstring.  Arguments as `OpfEnv.__init__` (opf_env.py:27-56)
+    plus `batch_size`, `device` and, for the N-1 variant
+    (security_constrained.py:21-35), `n_minus_one_keys` / `not_converged_penalty`."""
+
+    def __init__(self, net, action_keys, observation_keys, state_keys=None, profiles=None,
+                 evaluate_on='validation', steps_per_episode=1, bus_wise_obs=False,
+                 reward_function='summation', reward_function_params=None, diff_objective=False,
+                 add_res_obs=False, add_time_obs=False, add_act_obs=False, add_mean_obs=False,
+                 train_data='simbench', test_data='simbench', sampling_params=None,
+                 constraint_params=None, custom_constraints=None, autoscale_actions=True,
+                 diff_action_step_size=None, clipped_action_penalty=0.0, initial_action='center',
+                 objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
+                 seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
+                 not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
+                 defer_device=False, **kwargs):
+        if objective_function is not None or power_flow_solver is not None:
+            raise NotImplementedError('Python objective/solver callables cannot run inside the fused '
+                                      'GPU step; use the reference OpfEnv with opfgym_amd.power_flow_solver')
+        if bus_wise_obs:
+            raise NotImplementedError('bus_wise_obs is not supported by the batched backend yet')
+        self.net = net
+        self.device_spec = device
+        self.batch_size = int(batch_size)
+        self.obs_keys = list(observation_keys)
+        self.state_keys = list(state_keys) if state_keys else copy.copy(self.obs_keys)
+        self.act_keys = list(action_keys)
+        self.profiles = profiles
+        if not profiles:
+            assert 'simbench' not in test_data and 'simbench' not in train_data and not add_time_obs
+        self.evaluate_on = evaluate_on
+        self.train_data, self.test_data = train_data, test_data
+        self.sampling_params = sampling_params or {}
+        self.add_act_obs, self.add_time_obs, self.add_mean_obs = add_act_obs, add_time_obs, add_mean_obs
+        if add_act_obs:                                                    # opf_env.py:92-95
+            self.obs_keys.extend(self.act_keys)
+        if add_res_obs is True:                                            # opf_env.py:99-118
+            add_res_obs = ('voltage_magnitude', 'voltage_angle', 'line_loading', 'trafo_loading',
+                           'ext_grid_power')
+        if add_res_obs:
+            bus_idxs = (set(net.load.bus) | set(net.sgen.bus) | set(net.gen.bus) | set(net.storage.bus))
+            bus_idxs = np.sort(list(bus_idxs))
+            if 'voltage_magnitude' in add_res_obs:
+                self.obs_keys.append(('res_bus', 'vm_pu', bus_idxs))
+            if 'voltage_angle' in add_res_obs:
+                self.obs_keys.append(('res_bus', 'va_degree', bus_idxs))
+            if 'line_loading' in add_res_obs:
+                self.obs_keys.append(('res_line', 'loading_percent', net.line.index))
+            if 'trafo_loading' in add_res_obs:
+                self.obs_keys.append(('res_trafo', 'loading_percent', net.trafo.index))
+            if 'ext_grid_power' in add_res_obs:
+                self.obs_keys.append(('res_ext_grid', 'p_mw', net.ext_grid.index))
+                self.obs_keys.append(('res_ext_grid', 'q_mvar', net.ext_grid.index))
+        self.autoscale_actions = autoscale_actions
+        self.diff_action_step_size = diff_action_step_size
+        self.clipped_action_penalty = clipped_action_penalty
+        self.initial_action = initial_action
+        self.steps_per_episode = steps_per_episode
+        self.pf_for_obs = any('res_' in k[0] for k in self.obs_keys) or bool(diff_objective)   # :144-153
+        self.diff_objective = diff_objective
+        self.test_steps, self.validation_steps, self.train_steps = define_test_train_split(**kwargs)  # :156
+        if custom_constraints is None:                                     # :159-163
+            self.constraints = constraints_mod.create_default_constraints(net, constraint_params or {})
+        else:
+            self.constraints = list(custom_constraints)
+        self.n_minus_one_keys = n_minus_one_keys or ()
+        for _, column, _ in self.n_minus_one_keys:
+            assert column in ('in_service', 'closed')                      # security_constrained.py:34-35
+        self.not_converged_penalty = not_converged_penalty
+        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)))
+        self.np_random = np.random.default_rng(seed)
+
+        # ---- compile the grid --------------------------------------------------
+        self.case = net_to_case(net)
+        self.plan = capi.Plan(self.case)
+        self.store = ColumnStore(net)
+        for tbl in ('load', 'sgen', 'storage'):
+            self.store.slot(tbl, 'p_mw')
+            self.store.slot(tbl, 'q_mvar')
+        self.store.slot('gen', 'p_mw')
+        # sampling programme first: it decides which columns are per-instance
+        self._build_sampling()
+        self.n_actions = int(sum(len(idxs) for _, _, idxs in self.act_keys))
+        self._env_handle = None
+        self.ctx = None
+        self.current_simbench_step = None
+        self._reward_spec = (reward_function, reward_function_params or {})
+        self.reward_function = None
+        if not defer_device:
+            self.attach_device()
+
+    def attach_device(self):
+        """Upload the plan, create the device evaluator and allocate the batch
+        buffers.  Everything before this point is host-only problem compilation."""
+        import torch
+        self.torch = torch
+        self.device = torch.device(self.device_spec)
+        self.ctx = capi.Context(self.plan, self.device.index or 0)
+        self._resolve_reward(allow_estimate=True)
+        self._create_env()
+        self._alloc(self.batch_size)
+
+    def _resolve_reward(self, allow_estimate):
+        reward_function, params = self._reward_spec                        # opf_env.py:166-175
+        if not isinstance(reward_function, str):
+            self.reward_function = reward_function
+            return
+        cls = reward_mod.load_reward_class(reward_function)
+        sp = params.get('scaling_params') or {}
+        needs_env = isinstance(params.get('reward_scaling'), str) and not any(
+            k.startswith(('min_', 'std_')) for k in sp)
+        if needs_env:
+            if not allow_estimate:
+                raise RuntimeError('reward scaling needs a batched estimate on the device')
+            self.reward_function = reward_mod.Summation()
+            self._create_env()
+            self._alloc(1)
+        self.reward_function = cls(env=self, **params)
+
+    def host_definition(self):
+        """Problem definition without any device object (for tools and tests)."""
+        if self.reward_function is None:
+            self._resolve_reward(allow_estimate=False)
+        return dict(net=self.net, act_keys=self.act_keys, obs_keys=self.obs_keys,
+                    profiles=self.profiles, constraints=self.constraints,
+                    reward_function=self.reward_function)
+
+    # ------------------------------------------------------------------ sampling
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        """Hook for the benchmark environments' `_sampling` tails."""
+
+    def _build_sampling(self):
+        self.ops = OpsBuilder(self.store)
+        self.tables = []
+        modes = {self.train_data, self.test_data}
+        if modes - {'simbench', 'noisy_simbench', 'full_uniform'}:
+            raise NotImplementedError(f'data distributions {modes} are not supported yet')
+        self.noise_factor = float(self.sampling_params.get('noise_factor', 0.0))
+        if 'noisy_simbench' in modes and 'noise_factor' not in self.sampling_params:
+            self.noise_factor = 0.1                                        # opf_env.py:318 default
+        if self.sampling_params.get('noise_distribution', 'uniform') != 'uniform' or \
+                self.sampling_params.get('interpolate_steps'):
+            raise NotImplementedError('only uniform multiplicative noise is supported yet')
+        self.uses_profiles = bool(modes & {'simbench', 'noisy_simbench'})
+        if self.uses_profiles:
+            for key in self.profiles.keys():                               # opf_env.py:339-372
+                df = self.profiles[key]
+                if not df.shape[1]:
+                    continue
+                unit, col = key
+                rel, typ, peak = factored_profile(self.profiles, key)
+                slots = self.store.slots(unit, col, df.columns, dynamic=True)
+                self.tables.append(dict(rel=rel, typ=typ, peak=peak, slot=slots,
+                                        col_min=df.min().to_numpy(float), col_max=df.max().to_numpy(float)))
+        if 'full_uniform' in modes:
+            if len(modes) > 1:
+                raise NotImplementedError('mixing full_uniform with simbench data is not supported yet')
+            for unit, col, idxs in self.state_keys:                        # opf_env.py:253-284
+                if 'res_' in unit:
+                    continue
+                df = self.net[unit]
+                rows = self.store.rows(unit, idxs)
+                lo = df[f'min_min_{col}' if f'min_min_{col}' in df else f'min_{col}'].to_numpy(float)[rows]
+                hi = df[f'max_max_{col}' if f'max_max_{col}' in df else f'max_{col}'].to_numpy(float)[rows]
+                sc = df['scaling'].to_numpy(float)[rows] if 'scaling' in df else 1.0
+                self.ops.uniform(unit, col, idxs, lo, hi, sc)
+        self._sampling_ops(self.ops)
+
+    # ------------------------------------------------------------------ compile
+    def _range_source(self, unit, name, rows):
+        """(slots, consts) for a range/clamp column: per-instance slot if the
+        sampling programme writes it, the net's static value otherwise."""
+        if (unit, name) in self.store.dynamic:
+            return self.store.slot(unit, name) + rows, np.zeros(len(rows))
+        return np.full(len(rows), -1), self.net[unit][name].to_numpy(float)[rows]
+
+    def _result_index(self, unit, col, idxs):
+        c = self.case
+        nb, nbr = c.nb, c.nbr
+        ref_buses = np.flatnonzero(c.bus_type == REF)
+        nref = len(ref_buses)
+        zero = 2 * nb + nbr + 2 * nref + int(ref_buses[0])      # q_gen of a REF bus is always 0
+        out = []
+        if unit == 'bus':
+            off = {'vm_pu': 0, 'va_degree': nb}[col]
+            for b in idxs:
+                out.append(off + c.bus_lookup[int(b)] if int(b) in c.bus_lookup else -1)
+        elif unit in ('line', 'trafo'):
+            assert col == 'loading_percent'
+            kind = KIND_LINE if unit == 'line' else KIND_TRAFO
+            pos_to_br = {int(e): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem)) if kd == kind}
+            for pos in self.store.rows(unit, idxs):
+                out.append(2 * nb + pos_to_br[int(pos)] if int(pos) in pos_to_br else zero)
+        elif unit == 'ext_grid':
+            off = 2 * nb + nbr + (0 if col == 'p_mw' else nref)
+            ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+            for pos in self.store.rows(unit, idxs):
+                bus = int(self.net.ext_grid['bus'].iloc[pos])
+                out.append(off + ordinal[c.bus_lookup[bus]] if bus in c.bus_lookup else -1)
+        else:
+            raise NotImplementedError(f'result column res_{unit}.{col} is not in the device result bank')
+        return np.array(out, dtype=np.int64)
+
+    def _create_env(self):
+        net, c, st = self.net, self.case, self.store
+        nb, base = c.nb, c.base_mva
+        keep = []
+        d = capi.EnvDesc()
+        # ---- observation sources first (may register static columns) ------------
+        okind, oidx, self.obs_segments = [], [], []
+        for unit, col, idxs in self.obs_keys:
+            if unit.startswith('res_'):
+                ridx = self._result_index(unit[4:], col, idxs)
+                if (ridx < 0).any():
+                    raise ValueError(f'observation {unit}.{col} touches a de-energised element')
+                okind += [capi.SRC_RESULT] * len(ridx)
+                oidx += ridx.tolist()
+                self.obs_segments.append(len(ridx))
+            else:
+                sl = st.slots(unit, col, idxs)
+                okind += [capi.SRC_X] * len(sl)
+                oidx += sl.tolist()
+                self.obs_segments.append(len(sl))
+        # ---- actions (opf_env.py:421-491) ------------------------------------------
+        a_slot, a_sc, lo_s, hi_s, lo_c, hi_c = [], [], [], [], [], []
+        cl_s, ch_s, cl_c, ch_c = [], [], [], []
+        clamp = (not self.autoscale_actions) or bool(self.diff_action_step_size)
+        for unit, col, idxs in self.act_keys:
+            if len(idxs) == 0:
+                continue
+            if col in ('closed', 'in_service', 'tap_pos', 'step'):
+                raise NotImplementedError('topology/tap actions change Ybus per instance: not supported yet')
+            df = net[unit]
+            rows = st.rows(unit, idxs)
+            a_slot += (st.slot(unit, col) + rows).tolist()
+            a_sc += (df['scaling'].to_numpy(float)[rows] if 'scaling' in df.columns
+                     else np.ones(len(rows))).tolist()
+            pre_lo, pre_hi = ('min_', 'max_') if self.autoscale_actions else ('min_min_', 'max_max_')
+            s, v = self._range_source(unit, pre_lo + col, rows); lo_s += s.tolist(); lo_c += v.tolist()
+            s, v = self._range_source(unit, pre_hi + col, rows); hi_s += s.tolist(); hi_c += v.tolist()
+            for name, ss, cc in ((f'min_{col}', cl_s, cl_c), (f'max_{col}', ch_s, ch_c)):
+                if clamp and (name in df.columns or (unit, name) in st.dynamic):
+                    s, v = self._range_source(unit, name, rows)
+                    ss += s.tolist(); cc += v.tolist()
+                else:
+                    ss += [-2] * len(rows); cc += [0.0] * len(rows)
+        na = len(a_slot)
+        # ---- bus injections (makeSbus) -----------------------------------------------
+        plist = [[] for _ in range(nb)]
+        qlist = [[] for _ in range(nb)]
+        for tbl, sign, has_q in (('load', -1.0, True), ('sgen', 1.0, True), ('storage', -1.0, True),
+                                 ('gen', 1.0, False)):
+            df = net[tbl]
+            if not len(df):
+                continue
+            on = df['in_service'].to_numpy(bool) if 'in_service' in df.columns else np.ones(len(df), bool)
+            sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns else np.ones(len(df))
+            p0 = st.slot(tbl, 'p_mw')
+            q0 = st.slot(tbl, 'q_mvar') if has_q else None
+            for pos, b in enumerate(df['bus'].to_numpy()):
+                if on[pos] and int(b) in c.bus_lookup:
+                    i = c.bus_lookup[int(b)]
+                    plist[i].append((p0 + pos, sign * sc[pos] / base))
+                    if has_q:
+                        qlist[i].append((q0 + pos, sign * sc[pos] / base))
+
+        def csr(lists):
+            ptr = np.zeros(nb + 1, dtype=np.int32)
+            ptr[1:] = np.cumsum([len(l) for l in lists])
+            return ptr, [e[0] for l in lists for e in l], [e[1] for l in lists for e in l]
+        pp_, ps_, pc_ = csr(plist)
+        qp_, qs_, qc_ = csr(qlist)
+        qg_lo = np.full(nb, -np.inf)
+        qg_hi = np.full(nb, np.inf)
+        gen = net['gen']
+        if len(gen) and 'min_q_mvar' in gen.columns:
+            acc_lo, acc_hi, has = np.zeros(nb), np.zeros(nb), np.zeros(nb, bool)
+            on = gen['in_service'].to_numpy(bool)
+            for pos, b in enumerate(gen['bus'].to_numpy()):
+                if on[pos] and int(b) in c.bus_lookup:
+                    i = c.bus_lookup[int(b)]
+                    lo, hi = float(gen['min_q_mvar'].iloc[pos]), float(gen['max_q_mvar'].iloc[pos])
+                    acc_lo[i] += -np.inf if np.isnan(lo) else lo
+                    acc_hi[i] += np.inf if np.isnan(hi) else hi
+                    has[i] = True
+            qg_lo[has], qg_hi[has] = acc_lo[has] / base, acc_hi[has] / base
+        # ---- costs (objective.py:6-87) -----------------------------------------------
+        ref_buses = np.flatnonzero(c.bus_type == REF)
+        ref_ord = {int(b): k for k, b in enumerate(ref_buses)}
+
+        def cost_source(et, element):
+            pos = int(st.rows(et, [element])[0])
+            if et == 'ext_grid':
+                return capi.COST_EXT_GRID, ref_ord[c.bus_lookup[int(net.ext_grid['bus'].iloc[pos])]], -1, 1.0
+            sc = float(net[et]['scaling'].iloc[pos]) if 'scaling' in net[et].columns else 1.0
+            if et == 'gen':
+                return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc
+            return capi.COST_UNIT, st.slot(et, 'p_mw') + pos, st.slot(et, 'q_mvar') + pos, sc
+        poly, pwl = net['poly_cost'], net['pwl_cost']
+        ck, cp, cq, cs, coef, is_q = [], [], [], [], [], []
+        for _, row in poly.iterrows():
+            k, pi, qi, sc = cost_source(row['et'], row['element'])
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc)
+            coef += [float(row[n]) for n in _POLY_COEF]
+        nseg = min((len(p) for p in pwl['points']), default=0) if len(pwl) else 0      # defect D9
+        for _, row in pwl.iterrows():
+            k, pi, qi, sc = cost_source(row['et'], row['element'])
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc)
+            is_q.append(0 if row['power_type'] == 'p' else 1)
+            for sgm in row['points'][:nseg]:
+                coef += [float(v) for v in sgm]
+        price_slot, price_coef = [], []
+        for (tbl, col) in sorted(st.dynamic):
+            if tbl == 'poly_cost' and col in _POLY_COEF:
+                for r in range(len(poly)):
+                    price_slot.append(st.slot(tbl, col) + r); price_coef.append(r * 6 + _POLY_COEF[col])
+            elif tbl == 'pwl_cost' and col == 'cp1_eur_per_mw':                      # eco_dispatch.py:119-123
+                for r in range(len(pwl)):
+                    price_slot.append(st.slot(tbl, col) + r)
+                    price_coef.append(len(poly) * 6 + (r * nseg + 0) * 3 + 2)
+        # ---- constraints (constraints.py:70-128) ---------------------------------------
+        con_ptr, con_src, con_min, con_max = [0], [], [], []
+        c_as, c_pf, c_pp, c_cp, c_wc = [], [], [], [], []
+        for con in self.constraints:
+            lo, hi = con.boundaries(net)
+            ridx = self._result_index(con.unit_type, con.values_column, net[con.unit_type].index)
+            for r, l, h in zip(ridx, lo, hi):
+                if r >= 0 and not (np.isnan(l) and np.isnan(h)):
+                    con_src.append(int(r)); con_min.append(l); con_max.append(h)
+            con_ptr.append(len(con_src))
+            c_as.append(con.autoscale_factor(net)); c_pf.append(con.penalty_factor)
+            c_pp.append(con.penalty_power); c_cp.append(con.violation_count_penalty)
+            c_wc.append(int(bool(con.only_worst_case_violations)))
+        # ---- N-1 list (security_constrained.py:44-50) -------------------------------------
+        cont = []
+        for unit, column, idxs in self.n_minus_one_keys:
+            kind = {'line': KIND_LINE, 'trafo': KIND_TRAFO}[unit]
+            pos_to_br = {int(e): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem)) if kd == kind}
+            for pos in st.rows(unit, idxs):
+                if int(pos) in pos_to_br:          # already out of service -> skipped (:46-48)
+                    cont.append(pos_to_br[int(pos)])
+        self.contingencies = cont
+        # ---- fill the descriptor -------------------------------------------------------------
+        self.nx = st.n
+        d.nx = st.n
+        d.pinj_ptr, d.pinj_slot, d.pinj_coef = _keep(keep, pp_, 'i'), _keep(keep, ps_, 'i'), _keep(keep, pc_, 'd')
+        d.qinj_ptr, d.qinj_slot, d.qinj_coef = _keep(keep, qp_, 'i'), _keep(keep, qs_, 'i'), _keep(keep, qc_, 'd')
+        d.qg_min, d.qg_max = _keep(keep, qg_lo, 'd'), _keep(keep, qg_hi, 'd')
+        d.na = na
+        d.act_slot, d.act_scaling = _keep(keep, a_slot, 'i'), _keep(keep, a_sc, 'd')
+        d.act_lo_slot, d.act_hi_slot = _keep(keep, lo_s, 'i'), _keep(keep, hi_s, 'i')
+        d.act_lo_const, d.act_hi_const = _keep(keep, lo_c, 'd'), _keep(keep, hi_c, 'd')
+        d.clamp_lo_slot, d.clamp_hi_slot = _keep(keep, cl_s, 'i'), _keep(keep, ch_s, 'i')
+        d.clamp_lo_const, d.clamp_hi_const = _keep(keep, cl_c, 'd'), _keep(keep, ch_c, 'd')
+        d.clamp_enabled = int(clamp)
+        d.diff_action_step_size = float(self.diff_action_step_size or 0.0)
+        d.clipped_action_penalty = float(self.clipped_action_penalty or 0.0)
+        d.npoly, d.npwl, d.nseg = len(poly), len(pwl), nseg
+        d.cost_kind, d.cost_pidx, d.cost_qidx = _keep(keep, ck, 'i'), _keep(keep, cp, 'i'), _keep(keep, cq, 'i')
+        d.cost_scale, d.pwl_is_q, d.cost_coef = _keep(keep, cs, 'd'), _keep(keep, is_q, 'i'), _keep(keep, coef, 'd')
+        d.nprice = len(price_slot)
+        d.price_slot, d.price_coef = _keep(keep, price_slot, 'i'), _keep(keep, price_coef, 'i')
+        d.nc = len(self.constraints)
+        d.con_ptr, d.con_src = _keep(keep, con_ptr, 'i'), _keep(keep, con_src, 'i')
+        d.con_min, d.con_max = _keep(keep, con_min, 'd'), _keep(keep, con_max, 'd')
+        d.con_autoscale, d.con_penalty_factor = _keep(keep, c_as, 'd'), _keep(keep, c_pf, 'd')
+        d.con_penalty_power, d.con_count_penalty = _keep(keep, c_pp, 'd'), _keep(keep, c_cp, 'd')
+        d.con_worst_case = _keep(keep, c_wc, 'i')
+        rf = self.reward_function
+        d.reward_kind = rf.KIND
+        d.penalty_weight = np.nan if rf.penalty_weight is None else float(rf.penalty_weight)
+        d.clip_lo, d.clip_hi = (np.nan, np.nan) if not rf.clip_range else map(float, rf.clip_range)
+        sp = rf.scaling_params
+        d.objective_factor, d.objective_bias = float(sp['objective_factor']), float(sp['objective_bias'])
+        d.penalty_factor, d.penalty_bias = float(sp['penalty_factor']), float(sp['penalty_bias'])
+        d.valid_reward, d.invalid_penalty = float(rf.valid_reward), float(rf.invalid_penalty)
+        d.invalid_objective_share = float(rf.invalid_objective_share)
+        d.diff_objective = int(bool(self.diff_objective))
+        d.nobs = len(oidx)
+        d.obs_kind, d.obs_idx = _keep(keep, okind, 'i'), _keep(keep, oidx, 'i')
+        d.steps_per_episode = int(self.steps_per_episode)
+        d.n_cont = len(cont)
+        d.cont_branch = _keep(keep, cont, 'i')
+        d.not_converged_penalty = float(self.not_converged_penalty)
+        if self._env_handle is not None:
+            capi.lib().opfx_env_destroy(self._env_handle)
+            self._env_handle = None
+        h = C.c_void_p()
+        capi.check(capi.lib().opfx_env_create(self.ctx.handle, C.byref(d), C.byref(h)), 'opfx_env_create')
+        self._env_handle = h
+        self.n_obs_raw = len(oidx)
+        self.n_constraints = len(self.constraints)
+        self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses)
+        self.desc_arrays = dict(act_slot=np.array(a_slot, dtype=np.int64))
+        self._set_reset()
+
+    def _set_reset(self):
+        keep = []
+        st = self.store
+        template = st.row_template()
+        consts = [template]
+        off = len(template)
+        tabs = (capi.ProfileDesc * max(1, len(self.tables)))()
+        self.n_noise = 0
+        for k, t in enumerate(self.tables):
+            tabs[k].n_steps, tabs[k].n_types = t['rel'].shape
+            tabs[k].n_cols = len(t['typ'])
+            tabs[k].rel, tabs[k].typ = _keep(keep, t['rel'], 'd'), _keep(keep, t['typ'], 'i')
+            tabs[k].peak, tabs[k].slot = _keep(keep, t['peak'], 'd'), _keep(keep, t['slot'], 'i')
+            tabs[k].col_min, tabs[k].col_max = _keep(keep, t['col_min'], 'd'), _keep(keep, t['col_max'], 'd')
+            self.n_noise += len(t['typ'])
+        code, dst, a, n, c0, c1, c2 = [], [], [], [], [], [], []
+        for op in self.ops.ops:
+            code.append(op[0]); dst.append(op[1]); a.append(op[2]); n.append(op[3])
+            for vec, lst in ((op[4], c0), (op[5], c1), (op[6], c2)):
+                if vec is None:
+                    lst.append(-1)
+                else:
+                    lst.append(off); consts.append(vec); off += len(vec)
+        consts = np.concatenate(consts) if consts else np.zeros(0)
+        r = capi.ResetDesc()
+        r.n_tables, r.tables = len(self.tables), tabs
+        r.n_ops = len(code)
+        r.op_code, r.op_dst, r.op_a, r.op_n = (_keep(keep, v, 'i') for v in (code, dst, a, n))
+        r.op_c0, r.op_c1, r.op_c2 = (_keep(keep, v, 'i') for v in (c0, c1, c2))
+        r.n_consts, r.consts = len(consts), _keep(keep, consts, 'd')
+        r.n_uniform = self.ops.n_uniform
+        r.init_off = 0
+        capi.check(capi.lib().opfx_env_set_reset(self._env_handle, C.byref(r)), 'opfx_env_set_reset')
+        self.n_uniform = self.ops.n_uniform
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, B):
+        t, dev = self.torch, self.device
+        f64 = dict(dtype=t.float64, device=dev)
+        u8 = dict(dtype=t.uint8, device=dev)
+        nc = max(1, self.n_constraints)
+        self.B = B
+        self.x = t.zeros(B, self.nx, **f64)
+        self.buf = dict(
+            obs=t.zeros(B, max(1, self.n_obs_raw), **f64), reward=t.zeros(B, **f64),
+            terminated=t.zeros(B, **u8), truncated=t.zeros(B, **u8), valids=t.zeros(B, nc, **u8),
+            violations=t.zeros(B, nc, **f64), penalties=t.zeros(B, nc, **f64), cost=t.zeros(B, **f64),
+            objective=t.zeros(B, **f64), results=t.zeros(B, self.n_results, **f64),
+            mean_correction=t.zeros(B, **f64), converged=t.zeros(B, **u8),
+            iterations=t.zeros(B, dtype=t.int32, device=dev), max_mismatch=t.zeros(B, **f64))
+        self.initial_obj = t.zeros(B, **f64)
+        self.step_count = t.zeros(B, dtype=t.int32, device=dev)
+        self.steps_dev = t.zeros(B, dtype=t.int32, device=dev)
+
+    def _io(self, action, with_initial_obj):
+        io = capi.StepIO()
+        io.x = self.x.data_ptr()
+        io.action = action.data_ptr() if action is not None else None
+        io.initial_obj = self.initial_obj.data_ptr() if with_initial_obj else None
+        io.step_in_episode = self.step_count.data_ptr()
+        io.outage = None
+        for name, buf in self.buf.items():
+            setattr(io, name, buf.data_ptr())
+        return io
+
+    def _launch_step(self, action, mode=0, with_initial_obj=False):
+        io = self._io(action, with_initial_obj)
+        with self.torch.cuda.device(self.device):
+            capi.check(capi.lib().opfx_step(self._env_handle, self.B, C.byref(io), C.byref(self.solve_opts),
+                                            mode, capi._stream()), 'opfx_step')
+
+    def _as_action(self, action):
+        t = self.torch
+        if not t.is_tensor(action):
+            action = t.as_tensor(np.asarray(action, dtype=np.float64))
+        action = action.to(device=self.device, dtype=t.float64).reshape(self.B, self.n_actions).contiguous()
+        return action
+
+    # ------------------------------------------------------------------ gymnasium-shaped API
+    def reset(self, seed=None, options=None):
+        """opf_env.py:177-220 for the whole batch.  options: 'test' (bool),
+        'step' (int or [B] array), plus 'noise' [B,n_noise] / 'uniform'
+        [B,n_uniform] / 'initial_action' [B,na] to replay explicit draws."""
+        t = self.torch
+        if seed is not None:
+            self.np_random = np.random.default_rng(seed)
+        options = options or {}
+        B = self.B
+        self.test = bool(options.get('test', False))
+        step = options.get('step', None)
+        if step is None:                                                   # opf_env.py:327-333
+            if self.test and self.evaluate_on == 'test':
+                pool = self.test_steps
+            elif self.test and self.evaluate_on == 'validation':
+                pool = self.validation_steps
+            else:
+                pool = self.train_steps
+            step = self.np_random.choice(pool, size=B) if self.uses_profiles else np.zeros(B, int)
+        step = np.broadcast_to(np.asarray(step, dtype=np.int64), (B,))
+        if self.uses_profiles:
+            assert (step < len(self.profiles[('load', 'q_mvar')])).all()   # :335
+        self.current_simbench_step = step.copy()
+        self.steps_dev.copy_(t.as_tensor(step.astype(np.int32)))
+        noise = options.get('noise')
+        data_distr = self.test_data if self.test else self.train_data
+        if noise is None and self.n_noise and (data_distr == 'noisy_simbench' or self.noise_factor):
+            nf = self.noise_factor
+            noise = self.np_random.random((B, self.n_noise)) * nf * 2 + (1 - nf)   # :354-355
+        uniform = options.get('uniform')
+        if uniform is None and self.n_uniform:
+            uniform = self.np_random.random((B, self.n_uniform))
+        noise_t = t.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device) if noise is not None else None
+        uni_t = t.as_tensor(np.ascontiguousarray(uniform, dtype=np.float64)).to(self.device) if uniform is not None else None
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_reset(
+                self._env_handle, B, self.steps_dev.data_ptr(),
+                noise_t.data_ptr() if noise_t is not None else None,
+                uni_t.data_ptr() if uni_t is not None else None, self.x.data_ptr(), capi._stream()),
+                'opfx_reset')
+        self.step_count.zero_()
+        act = options.get('initial_action')
+        if act is None:
+            if self.initial_action == 'random':                            # :201-203
+                act = self.np_random.random((B, self.n_actions))
+            else:
+                act = np.full((B, self.n_actions), 0.5)                    # :206
+        act = self._as_action(act)
+        if self.pf_for_obs:                                                # :209-216
+            self._launch_step(act, mode=0, with_initial_obj=False)
+            if not bool(self.buf['converged'].all()):
+                raise RuntimeError('power flow failed in reset for some instances '
+                                   '(the reference re-samples recursively, opf_env.py:211-214)')
+            self.initial_obj.copy_(self.buf['objective'])
+        else:
+            self._launch_step(act, mode=2)
+        return self._finish_obs(), {}
+
+    def step(self, action):
+        """opf_env.py:374-419 for the whole batch: (obs, reward, terminated,
+        truncated, info) as torch tensors on the device."""
+        t = self.torch
+        action = self._as_action(action)
+        assert not bool(t.isnan(action).any())                             # :382
+        self.step_count += 1
+        self._launch_step(action, mode=0, with_initial_obj=self.diff_objective)
+        b = self.buf
+        info = {'valids': b['valids'].bool(), 'violations': b['violations'],
+                'unscaled_penalties': b['penalties'], 'cost': b['cost'],
+                'converged': b['converged'].bool(), 'iterations': b['iterations'],
+                'max_mismatch': b['max_mismatch'], 'objective': b['objective']}
+        return self._finish_obs(), b['reward'], b['terminated'].bool(), b['truncated'].bool(), info
+
+    def _finish_obs(self):
+        """add_mean_obs / add_time_obs post-processing (opf_env.py:539-547)."""
+        t = self.torch
+        obs = self.buf['obs'][:, :self.n_obs_raw]
+        parts = [obs]
+        if self.add_mean_obs:
+            off, means = 0, []
+            for n in self.obs_segments:
+                if n > 1:
+                    means.append(obs[:, off:off + n].mean(dim=1, keepdim=True))
+                off += n
+            parts += means
+        if self.add_time_obs and self.current_simbench_step is not None:
+            tobs = get_simbench_time_observation(self.current_simbench_step)   # intended semantics (defect D1)
+            parts = [t.as_tensor(tobs, dtype=t.float64, device=self.device)] + parts
+        return t.cat(parts, dim=1) if len(parts) > 1 else obs
+
+    # ------------------------------------------------------------------ helpers
+    def get_current_actions(self, from_results_table=True):
+        """opf_env.py:566-588: (set-point·scaling − min)/(max − min) per action."""
+        raise NotImplementedError
+
+    def results(self):
+        """Result bank of the last step as a dict of tensors (net.res_* columns)."""
+        c = self.case
+        nb, nbr = c.nb, c.nbr
+        nref = int((c.bus_type == REF).sum())
+        r = self.buf['results']
+        return dict(vm_pu=r[:, :nb], va_degree=r[:, nb:2 * nb], loading_percent=r[:, 2 * nb:2 * nb + nbr],
+                    p_ext_mw=r[:, 2 * nb + nbr:2 * nb + nbr + nref],
+                    q_ext_mvar=r[:, 2 * nb + nbr + nref:2 * nb + nbr + 2 * nref],
+                    q_gen_mvar=r[:, 2 * nb + nbr + 2 * nref:])
+
+    def result_table(self, unit, col):
+        """`net.res_<unit>.<col>` of the last step for all instances, [B, n_rows]
+        in the row order of `net.<unit>` (NaN for de-energised elements)."""
+        t = self.torch
+        idx = self._result_index(unit, col, self.net[unit].index)
+        gather = t.as_tensor(np.where(idx < 0, 0, idx), device=self.device)
+        out = self.buf['results'][:, gather]
+        if (idx < 0).any():
+            out = out.clone()
+            out[:, t.as_tensor(idx < 0, device=self.device)] = float('nan')
+        return out
+
+    def table_column(self, unit, col):
+        """Current per-instance values of a table column held in x, [B, n_rows]."""
+        off, n = self.store.ranges[(unit, col)]
+        return self.x[:, off:off + n]
+
+    def sample_objective_penalty(self, num_samples):
+        """One batched reset + random action + power flow (reward.py:181-196)."""
+        old = (self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev)
+        self._alloc(int(num_samples))
+        try:
+            self.reset()
+            self.step_count += 1
+            self._launch_step(self._as_action(self.np_random.random((self.B, self.n_actions))), mode=0)
+            conv = self.buf['converged'].bool().cpu().numpy()
+            obj = self.buf['objective'].cpu().numpy().copy()
+            pen = self.buf['penalties'][:, :self.n_constraints].sum(dim=1).cpu().numpy().copy()
+            obj[~conv] = np.nan
+            pen[~conv] = np.nan
+        finally:
+            self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev = old
+        return obj, pen
+
+    def close(self):
+        if self._env_handle is not None:
+            capi.lib().opfx_env_destroy(self._env_handle)
+            self._env_handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SecurityConstrainedOpfEnv(BatchedOpfEnv):
+    """security_constrained.py:7-35: same arguments; the K contingency solves of
+    every instance run inside the same kernel launch as its base case."""
+
+    def __init__(self, *args, n_minus_one_keys, not_converged_penalty=1, **kwargs):
+        super().__init__(*args, n_minus_one_keys=n_minus_one_keys,
+                         not_converged_penalty=not_converged_penalty, **kwargs)

@@ -104,7 +104,8 @@ class ResetDesc(C.Structure):
     _fields_ = [('n_tables', C.c_int32), ('tables', C.POINTER(ProfileDesc)),
                 ('n_ops', C.c_int32), ('op_code', _pi), ('op_dst', _pi), ('op_a', _pi),
                 ('op_n', _pi), ('op_c0', _pi), ('op_c1', _pi), ('op_c2', _pi),
-                ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32)]
+                ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32),
+                ('init_off', C.c_int32)]
 
 
 _lib = None
@@ -123,6 +124,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise OpfxError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
                         f'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It has to be
+    # in the process BEFORE libopfx.so so that the loader binds both to ONE runtime: device
+    # pointers and hipStream_t handles are then interchangeable between torch and libopfx.
+    # (The other order makes torch fail with "No HIP GPUs are available".)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.opfx_last_error.restype = C.c_char_p

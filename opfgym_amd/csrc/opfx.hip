@@ -116,9 +116,13 @@ __device__ __forceinline__ void wave_sync() {
   __syncthreads();
 }
 
+// NaN-propagating max: a NaN mismatch (e.g. NaN set-points) must reach the convergence test
+__device__ __forceinline__ double nan_max(double a, double b) {
+  return (a != a) ? a : ((b != b) ? b : fmax(a, b));
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+  for (int o = 32; o > 0; o >>= 1) v = nan_max(v, __shfl_xor(v, o, WAVE));
   return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -207,7 +211,7 @@ __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
         L.rhs[2 * i] = -fp;
         L.rhs[2 * i + 1] = -fq;
-        my = fmax(my, fmax(fabs(fp), fabs(fq)));
+        my = nan_max(my, nan_max(fabs(fp), fabs(fq)));
         // dS_i/dth_i = j V_i conj(I_i - Y_ii V_i);  with e = V_i conj(Ioff): j e = -e.im + j e.re
         const double er = vri * ior + vii * ioi, ei = vii * ior - vri * ioi;
         // dS_i/d|V_i| = (V_i conj(Y_ii V_i) + S_i)/|V_i|
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevPlan P, DevEnv E, StepIO io, O
     for (int k = lane; k < E.na; k += WAVE) {
       const int slot = E.act_slot[k];
       double xv = xr[slot];
-      if (io.mode == 0) {
+      if (io.mode != 1) {
         double a = io.action[b * E.na + k];
         a = fmin(fmax(a, 0.0), 1.0);                                      // :429
         const double lo = E.act_lo_slot[k] >= 0 ? xr[E.act_lo_slot[k]] : E.act_lo_const[k];
@@ -521,6 +525,14 @@ __global__ __launch_bounds__(WAVE) void k_step(DevPlan P, DevEnv E, StepIO io, O
     }
     corr = E.na > 0 ? wave_sum(corr) / E.na : 0.0;                                   // :488-489
     wave_sync();
+    if (io.mode == 2) {
+      // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
+      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE)
+        io.obs[b * E.nobs + k] = E.obs_kind[k] == OPFX_SRC_X ? xval(xr, L.sp, E.obs_idx[k], E.obs_act[k]) : NaN;
+      if (lane == 0 && io.mean_correction) io.mean_correction[b] = corr;
+      wave_sync();
+      continue;
+    }
     // ---- bus injections (makeSbus) ---------------------------------------------
     for (int i = lane; i < nb; i += WAVE) {
       double p = 0.0, q = 0.0;
@@ -724,7 +736,7 @@ struct DevTable {
 };
 constexpr int MAX_TABLES = 8;
 struct DevReset {
-  int n_tables, n_ops, n_uniform, n_noise, nx;
+  int n_tables, n_ops, n_uniform, n_noise, nx, init_off;
   DevTable tab[MAX_TABLES];
   const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2;
   const double* consts;
@@ -739,6 +751,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const int* step_idx, 
   for (long long b = w; b < B; b += nw) {
     double* xr = x + b * R.nx;
     const int step = step_idx[b];
+    if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) xr[j] = R.consts[R.init_off + j];
     for (int t = 0; t < R.n_tables; ++t) {
       const DevTable& T = R.tab[t];
       const double* row = T.rel + (long long)step * T.n_types;
@@ -1073,6 +1086,8 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   DevArena& A = env->arena;
   R = DevReset{};
   R.n_tables = d->n_tables; R.n_ops = d->n_ops; R.n_uniform = d->n_uniform; R.nx = env->de.nx;
+  R.init_off = d->init_off;
+  if (d->init_off >= 0 && d->init_off + R.nx > d->n_consts) { opfx_set_error("opfx_env_set_reset: init template out of range"); return OPFX_ERR_INVALID; }
   int rc = OPFX_OK, noise_off = 0;
   for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
     const opfx_profile_desc& T = d->tables[t];

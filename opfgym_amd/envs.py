@@ -1,0 +1,274 @@
+"""Benchmark environments on the batched GPU backend.
+
+Same problem definitions (grid preparation, action/observation keys, cost
+tables, per-reset sampling tails) as the reference's
+`opfgym/envs/{voltage_control,q_market,eco_dispatch,max_renewable}.py` and
+`opfgym/examples/security_constrained.py`, expressed against
+:class:`opfgym_amd.batched_env.BatchedOpfEnv`.  The `_sampling` tails become
+vector ops executed by the reset kernel (`_sampling_ops`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import net as ppn
+from .batched_env import BatchedOpfEnv, OpsBuilder, SecurityConstrainedOpfEnv
+from .simbench_build import build_simbench_net
+
+
+class VoltageControl(BatchedOpfEnv):
+    """voltage_control.py:8-133: reactive set-points of the bigger sgens and
+    storages; loss + (optional) reactive market costs; voltage band, line/trafo
+    loading and slack reactive exchange constraints."""
+
+    def __init__(self, simbench_network_name='1-MV-semiurb--1-sw', load_scaling=1.5, gen_scaling=1.3,
+                 cos_phi=0.95, max_q_exchange=0.5, min_sgen_power=0.5, min_storage_power=0.5,
+                 market_based=False, *args, **kwargs):
+        self.min_sgen_power, self.min_storage_power = min_sgen_power, min_storage_power
+        self.cos_phi, self.market_based, self.max_q_exchange = cos_phi, market_based, max_q_exchange
+        net, profiles = self._define_opf(simbench_network_name, gen_scaling=gen_scaling,
+                                         load_scaling=load_scaling, *args, **kwargs)
+        obs_keys = [('sgen', 'p_mw', net.sgen.index), ('storage', 'p_mw', net.storage.index),
+                    ('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]      # :42-47
+        if market_based:
+            obs_keys.append(('poly_cost', 'cq2_eur_per_mvar2', net.poly_cost.index))           # :49-53
+        act_keys = [('sgen', 'q_mvar', net.sgen.index[net.sgen.controllable]),
+                    ('storage', 'q_mvar', net.storage.index[net.storage.controllable])]        # :56-57
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.load['controllable'] = False
+        net.sgen['controllable'] = net.sgen.max_max_p_mw > self.min_sgen_power                 # :68
+        net.sgen['max_s_mva'] = net.sgen['max_max_p_mw'] / self.cos_phi                         # :70
+        net.sgen['max_max_q_mvar'] = net.sgen['max_s_mva']
+        net.sgen['min_min_q_mvar'] = -net.sgen['max_s_mva']
+        net.storage['controllable'] = net.storage.max_max_p_mw > self.min_storage_power if len(net.storage) \
+            else np.zeros(0, bool)
+        net.storage['max_s_mva'] = net.storage['max_max_p_mw'].abs() if len(net.storage) else np.zeros(0)
+        net.storage['max_max_q_mvar'] = net.storage['max_s_mva']
+        net.storage['min_min_q_mvar'] = -net.storage['max_s_mva']
+        net.ext_grid['max_q_mvar'] = self.max_q_exchange                                        # :80-81
+        net.ext_grid['min_q_mvar'] = -self.max_q_exchange
+        self.loss_costs = 0.03
+        for idx in net.sgen.index[net.sgen.controllable]:                                       # :87-100
+            ppn.create_poly_cost(net, idx, 'sgen', cp1_eur_per_mw=self.loss_costs, cq2_eur_per_mvar2=0)
+        for idx in net.storage.index[net.storage.controllable.astype(bool)]:
+            ppn.create_poly_cost(net, idx, 'storage', cp1_eur_per_mw=-self.loss_costs, cq2_eur_per_mvar2=0)
+        for idx in net.ext_grid.index:
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=self.loss_costs, cq2_eur_per_mvar2=0)
+        ppn.finalize(net)
+        assert len(net.gen) == 0                                                                # :102
+        self.max_price = 0.03
+        net.poly_cost['min_cq2_eur_per_mvar2'] = 0
+        net.poly_cost['max_cq2_eur_per_mvar2'] = self.max_price
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        net = self.net
+        if self.market_based:                                                                   # :115-119
+            pc = net.poly_cost
+            for unit_type in ('sgen', 'ext_grid', 'storage'):
+                idx = pc[pc.et == unit_type].index
+                rows = pc.index.get_indexer(idx)
+                ops.uniform('poly_cost', 'cq2_eur_per_mvar2', idx,
+                            pc['min_cq2_eur_per_mvar2'].to_numpy(float)[rows],
+                            pc['max_cq2_eur_per_mvar2'].to_numpy(float)[rows])
+        for unit_type in ('sgen', 'storage'):                                                   # :123-125
+            if not len(net[unit_type]):
+                continue
+            sc = net[unit_type].scaling.to_numpy(float)
+            ops.affine(unit_type, 'max_p_mw', 'p_mw', sc, 1e-9)
+            ops.affine(unit_type, 'min_p_mw', 'p_mw', sc, -1e-9)
+        for unit_type in ('sgen', 'storage'):                                                   # :128-133
+            if not len(net[unit_type]):
+                continue
+            ops.sqrt_diff(unit_type, 'max_q_mvar', 'max_p_mw', net[unit_type].max_s_mva.to_numpy(float))
+            ops.neg(unit_type, 'min_q_mvar', 'max_q_mvar')
+            ops.set_const(unit_type, 'q_mvar', 0.0)
+
+
+class QMarket(VoltageControl):
+    """q_market.py:22-35: market-based VoltageControl with other defaults."""
+
+    def __init__(self, simbench_network_name='1-MV-rural--0-sw', gen_scaling=1.0, load_scaling=1.5,
+                 min_sgen_power=0.2, cos_phi=0.95, max_q_exchange=0.1, market_based=True,
+                 *args, **kwargs):
+        super().__init__(simbench_network_name=simbench_network_name, load_scaling=load_scaling,
+                         gen_scaling=gen_scaling, cos_phi=cos_phi, max_q_exchange=max_q_exchange,
+                         market_based=market_based, min_sgen_power=min_sgen_power, *args, **kwargs)
+
+
+class EcoDispatch(BatchedOpfEnv):
+    """eco_dispatch.py:7-123: active power of sgens/gens at sampled prices."""
+
+    def __init__(self, simbench_network_name='1-HV-urban--0-sw', gen_scaling=1.0, load_scaling=1.5,
+                 max_price_eur_gwh=0.5, min_power=0, *args, **kwargs):
+        self.max_price_eur_gwh, self.min_power = max_price_eur_gwh, min_power
+        net, profiles = self._define_opf(simbench_network_name, gen_scaling=gen_scaling,
+                                         load_scaling=load_scaling, *args, **kwargs)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index),
+                    ('poly_cost', 'cp1_eur_per_mw', net.poly_cost.index),
+                    ('pwl_cost', 'cp1_eur_per_mw', net.pwl_cost.index),
+                    ('sgen', 'p_mw', net.sgen.index[~net.sgen.controllable]),
+                    ('storage', 'p_mw', net.storage.index), ('storage', 'q_mvar', net.storage.index)]  # :44-51
+        act_keys = [('sgen', 'p_mw', net.sgen.index[net.sgen.controllable]),
+                    ('gen', 'p_mw', net.gen.index[net.gen.controllable])]                       # :54-55
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.ext_grid['vm_pu'] = 1.0                                                             # :64-65
+        net.gen['vm_pu'] = 1.0
+        net.load['controllable'] = False
+        net.ext_grid['min_p_mw'] = 0                                                            # :70-72
+        net.ext_grid['max_p_mw'] = net.sgen.max_max_p_mw.max()
+        net.sgen['min_p_mw'] = 0                                                                # :75-78
+        net.sgen['max_p_mw'] = net.sgen['max_max_p_mw']
+        net.gen['min_p_mw'] = 0
+        net.gen['max_p_mw'] = net.gen['max_max_p_mw']
+        net.sgen['controllable'] = net.sgen.max_max_p_mw > self.min_power                       # :81-83
+        net.sgen['min_min_p_mw'] = 0
+        net.gen['controllable'] = True
+        for unit_type in ('gen', 'sgen'):                                                       # :86-88
+            net[unit_type]['max_q_mvar'] = 0.0
+            net[unit_type]['min_q_mvar'] = 0.0
+        for idx in net.ext_grid.index:                                                          # :95-99
+            ppn.create_pwl_cost(net, idx, 'ext_grid', points=[[0, 10000, 1]])
+        for idx in net.sgen.index[net.sgen.controllable]:
+            ppn.create_poly_cost(net, idx, 'sgen', cp1_eur_per_mw=0)
+        for idx in net.gen.index[net.gen.controllable]:
+            ppn.create_poly_cost(net, idx, 'gen', cp1_eur_per_mw=0)
+        ppn.finalize(net)
+        net.poly_cost['min_cp1_eur_per_mw'] = 0                                                 # :101-107
+        net.poly_cost['max_cp1_eur_per_mw'] = self.max_price_eur_gwh
+        net.pwl_cost['cp1_eur_per_mw'] = 0.0
+        net.pwl_cost['min_cp1_eur_per_mw'] = 0
+        net.pwl_cost['max_cp1_eur_per_mw'] = self.max_price_eur_gwh
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        net = self.net                                                                          # :115-123
+        for tbl in ('poly_cost', 'pwl_cost'):
+            df = net[tbl]
+            ops.uniform(tbl, 'cp1_eur_per_mw', df.index, df['min_cp1_eur_per_mw'].to_numpy(float),
+                        df['max_cp1_eur_per_mw'].to_numpy(float))
+
+
+class MaxRenewable(BatchedOpfEnv):
+    """max_renewable.py:7-105: maximise renewable feed-in."""
+
+    def __init__(self, simbench_network_name='1-HV-mixed--1-sw', gen_scaling=0.8, load_scaling=0.8,
+                 min_storage_power=10, min_sgen_power=24, *args, **kwargs):
+        self.min_sgen_power, self.min_storage_power = min_sgen_power, min_storage_power
+        net, profiles = self._define_opf(simbench_network_name, gen_scaling=gen_scaling,
+                                         load_scaling=load_scaling, *args, **kwargs)
+        nctrl_st = net.storage.index[~net.storage.controllable.astype(bool)]
+        obs_keys = [('sgen', 'max_p_mw', net.sgen.index), ('load', 'p_mw', net.load.index),
+                    ('load', 'q_mvar', net.load.index), ('storage', 'p_mw', nctrl_st)]          # :38-43
+        state_keys = [('sgen', 'p_mw', net.sgen.index), ('load', 'p_mw', net.load.index),
+                      ('load', 'q_mvar', net.load.index), ('storage', 'p_mw', nctrl_st)]        # :46-51
+        act_keys = [('sgen', 'p_mw', net.sgen.index[net.sgen.controllable]),
+                    ('storage', 'p_mw', net.storage.index[net.storage.controllable.astype(bool)])]  # :54-57
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, state_keys=state_keys, profiles=profiles,
+                         *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        if len(net.ext_grid) > 1:                                                               # :67-69
+            net.ext_grid = net.ext_grid.iloc[0:1]
+        net.trafo['max_loading_percent'] = 100                                                  # :72
+        net.load['controllable'] = False
+        net.ext_grid['vm_pu'] = 1.0
+        net.storage['controllable'] = net.storage.max_max_p_mw > self.min_storage_power if len(net.storage) \
+            else np.zeros(0, bool)                                                              # :78-86
+        net.storage['q_mvar'] = 0.0
+        net.storage['max_q_mvar'] = 0.0
+        net.storage['min_q_mvar'] = 0.0
+        net.storage['max_p_mw'] = net.storage['max_max_p_mw'] if len(net.storage) else np.zeros(0)
+        net.storage['min_p_mw'] = net.storage['min_min_p_mw'] if len(net.storage) else np.zeros(0)
+        net.sgen['controllable'] = net.sgen.max_max_p_mw > self.min_sgen_power                  # :88-92
+        net.sgen['min_p_mw'] = 0.0
+        net.sgen['q_mvar'] = 0.0
+        net.sgen['max_q_mvar'] = 0.0
+        net.sgen['min_q_mvar'] = 0.0
+        for idx in net.sgen.index:                                                              # :94-97
+            ppn.create_poly_cost(net, idx, 'sgen', cp1_eur_per_mw=-30 / 1000)
+        ppn.finalize(net)
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        ops.affine('sgen', 'max_p_mw', 'p_mw', self.net.sgen.scaling.to_numpy(float), 1e-6)     # :105
+
+
+class SecurityConstrained(SecurityConstrainedOpfEnv):
+    """examples/security_constrained.py:10-49: all sgen P as actions, loss cost at
+    the slack, N-1 security for the listed lines."""
+
+    def __init__(self, simbench_network_name='1-HV-urban--0-sw', n_minus_one_lines=(1, 3, 7),
+                 *args, **kwargs):
+        n_minus_one_keys = (('line', 'in_service', np.array(n_minus_one_lines)),)               # :13
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]       # :20-23
+        act_keys = [('sgen', 'p_mw', net.sgen.index)]                                           # :26
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, n_minus_one_keys=n_minus_one_keys, profiles=profiles,
+                         *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.sgen['controllable'] = True                                                         # :37-41
+        net.sgen['max_p_mw'] = net.sgen['max_max_p_mw']
+        net.sgen['min_p_mw'] = net.sgen['min_min_p_mw']
+        net.sgen['max_q_mvar'] = 0
+        net.sgen['min_q_mvar'] = 0
+        for unit_type in ('load', 'gen', 'storage'):
+            net[unit_type]['controllable'] = False
+        for idx in net.ext_grid.index:                                                          # :48-49
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=0.01)
+        ppn.finalize(net)
+        return net, profiles
+
+
+class SecurityConstrainedVoltageControl(VoltageControl):
+    """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
+    of security_constrained.py (no such class in the reference; composed as
+    SURVEY.md Appendix A.5 describes)."""
+
+    def __init__(self, simbench_network_name='1-HV-urban--0-sw', n_minus_one_lines=(1, 3, 7),
+                 not_converged_penalty=1, *args, **kwargs):
+        keys = (('line', 'in_service', np.array(n_minus_one_lines)),)
+        super().__init__(simbench_network_name, *args, n_minus_one_keys=keys,
+                         not_converged_penalty=not_converged_penalty, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        # VoltageControl asserts a grid without `gen` units (voltage_control.py:102):
+        # on the HV stand-in the PV generators become fixed sgens.
+        if len(net.gen):
+            g = net.gen
+            start = (int(net.sgen.index.max()) + 1) if len(net.sgen) else 0
+            for k, (idx, row) in enumerate(g.iterrows()):
+                net.sgen.loc[start + k] = {c: row[c] if c in row else np.nan for c in net.sgen.columns}
+                net.sgen.loc[start + k, 'q_mvar'] = 0.0
+            if ('gen', 'p_mw') in profiles:
+                df = profiles.pop(('gen', 'p_mw'))
+                df.columns = [start + k for k in range(df.shape[1])]
+                import pandas as pd
+                profiles[('sgen', 'p_mw')] = pd.concat([profiles[('sgen', 'p_mw')], df], axis=1)
+                if hasattr(profiles, 'rel'):
+                    profiles.rel.pop(('sgen', 'p_mw'), None)
+            net.gen = net.gen.iloc[0:0]
+            from .simbench_build import set_constraints_from_profiles
+            net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
+            net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
+            set_constraints_from_profiles(net, profiles)
+        saved = build_simbench_net
+        try:
+            globals()['build_simbench_net'] = lambda *a, **k: (net, profiles)
+            return super()._define_opf(simbench_network_name, *args, **kwargs)
+        finally:
+            globals()['build_simbench_net'] = saved

@@ -176,10 +176,11 @@ def _radial_grid(name, seed, *, vn_hv, vn_lv, n_trafos, trafo, n_lv_nodes,
                            in_service=True, controllable=False), n_sgens)
     if n_storage:
         stb = _units_on(rng, nodes, n_storage)
-        net['storage'] = _df(dict(name=None, bus=stb,
-                                  p_mw=rng.uniform(0.1, 0.8, n_storage),
+        p_st = rng.uniform(0.1, 0.8, n_storage)
+        net['storage'] = _df(dict(name=None, bus=stb, p_mw=p_st,
                                   q_mvar=0.0, scaling=1.0, in_service=True,
-                                  controllable=False), n_storage)
+                                  controllable=False, min_p_mw=-p_st, max_p_mw=p_st,
+                                  min_q_mvar=0.0, max_q_mvar=0.0), n_storage)
     profiles = synthetic_profiles(net, seed + 1)
     return net, profiles
 
@@ -348,7 +349,26 @@ class Profiles(dict):
 
     def add(self, key, rel, typ, peak, index):
         self.rel[key], self.typ[key], self.peak[key] = rel, np.asarray(typ), np.asarray(peak, float)
+        self._index = getattr(self, '_index', {})
+        self._index[key] = np.asarray(index)
         self[key] = pd.DataFrame(rel[:, typ] * self.peak[key][None, :], columns=index)
+
+
+def factored_profile(profiles, key):
+    """(rel [T,n_types], typ [n_cols], peak [n_cols]) such that column j of
+    profiles[key] equals rel[:, typ[j]] * peak[j] bit for bit.  Uses the
+    SimBench-style factored form when the dict carries it (and it still matches
+    after profile repair), otherwise one type per column with peak 1."""
+    df = profiles[key]
+    rel = getattr(profiles, 'rel', {}).get(key)
+    if rel is not None:
+        index = profiles._index[key]
+        pos = np.array([int(np.flatnonzero(index == c)[0]) for c in df.columns], dtype=int)
+        typ, peak = profiles.typ[key][pos], profiles.peak[key][pos]
+        if len(pos) == 0 or np.array_equal(rel[:, typ] * peak[None, :], df.to_numpy()):
+            return np.ascontiguousarray(rel), typ.astype(np.int32), peak.astype(float)
+    vals = np.ascontiguousarray(df.to_numpy(dtype=float))
+    return vals, np.arange(vals.shape[1], dtype=np.int32), np.ones(vals.shape[1])
 
 
 def synthetic_profiles(net, seed: int = 1, n_steps: int = N_STEPS) -> Profiles:
@@ -368,16 +388,28 @@ def synthetic_profiles(net, seed: int = 1, n_steps: int = N_STEPS) -> Profiles:
     big = p_s > np.quantile(p_s, 0.8) if n_sg else np.zeros(0, bool)
     typ_s = np.where(big, rng.integers(3, 5, n_sg), rng.integers(0, 3, n_sg))
     prof.add(('sgen', 'p_mw'), rel_s, typ_s, p_s, net.sgen.index)
+    # SimBench's get_absolute_values carries these keys even for grids without
+    # such units (empty tables), and build_simbench_net.py:67-81 relies on that
     if len(net.gen):
         rel_g = _relative_profiles(rng, 2, 'load', n_steps)
         prof.add(('gen', 'p_mw'), rel_g, rng.integers(0, 2, len(net.gen)),
                  net.gen.p_mw.to_numpy(float), net.gen.index)
+    else:
+        prof[('gen', 'p_mw')] = pd.DataFrame(index=np.arange(n_steps))
     if len(net.storage):
         n_st = len(net.storage)
         base = _relative_profiles(rng, 2, 'wind', n_steps) * 2.0 - 1.0   # charge/discharge
         prof.add(('storage', 'p_mw'), base, rng.integers(0, 2, n_st),
                  net.storage.p_mw.to_numpy(float), net.storage.index)
+    else:
+        prof[('storage', 'p_mw')] = pd.DataFrame(index=np.arange(n_steps))
     return prof
+
+
+def synthetic_hv_small(seed: int = 0):
+    """Small meshed HV grid with PV generators for fast tests (not a BASELINE config)."""
+    return synthetic_hv(seed, nb=40, n_ext=1, n_gen=4, name='syn-hv-small', trafos_per_ext=2,
+                        load_share=0.5, sgen_share=0.4)
 
 
 GRIDS = {
@@ -386,6 +418,7 @@ GRIDS = {
     '1-HV-mixed--0-sw': synthetic_hv_mixed,
     '1-HV-urban--0-sw': synthetic_hv_urban,
     'mv-small': synthetic_mv_small,
+    'hv-small': synthetic_hv_small,
 }
 
 

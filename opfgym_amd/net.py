@@ -31,7 +31,7 @@ _TABLES = {
     'sgen': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
              'controllable'],
     'storage': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
-                'controllable'],
+                'controllable', 'min_p_mw', 'max_p_mw', 'min_q_mvar', 'max_q_mvar'],
     'gen': ['name', 'bus', 'p_mw', 'vm_pu', 'scaling', 'in_service',
             'controllable', 'min_q_mvar', 'max_q_mvar'],
     'ext_grid': ['name', 'bus', 'vm_pu', 'va_degree', 'in_service'],
@@ -44,6 +44,21 @@ _TABLES = {
 }
 
 
+_OBJ_COLS = ('name', 'type', 'tap_side', 'et', 'points', 'power_type')
+_BOOL_COLS = ('in_service', 'controllable', 'closed')
+_INT_COLS = ('bus', 'from_bus', 'to_bus', 'hv_bus', 'lv_bus', 'element', 'parallel')
+
+
+def _dtype_of(col):
+    if col in _OBJ_COLS:
+        return object
+    if col in _BOOL_COLS:
+        return bool
+    if col in _INT_COLS:
+        return np.int64
+    return np.float64
+
+
 class Net(dict):
     """Attribute-dict of DataFrames, same access idioms as a pandapowerNet
     (`net.load` and `net['load']`, both used by opf_env.py:105,267)."""
@@ -54,7 +69,7 @@ class Net(dict):
         self['f_hz'] = float(f_hz)
         self['sn_mva'] = float(sn_mva)
         for tbl, cols in _TABLES.items():
-            self[tbl] = pd.DataFrame(columns=cols)
+            self[tbl] = pd.DataFrame({c: pd.Series(dtype=_dtype_of(c)) for c in cols})
 
     def __getattr__(self, key):
         try:

@@ -1,0 +1,354 @@
+"""CPU oracle for the environment half of the hot path (SURVEY.md §8a rows
+E2–E11): one instance at a time, plain numpy on the net's tables.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, `__graft_entry__.smoke()` and
+the `cpu_baseline` leg of bench.py, never by `opfgym_amd/`.
+
+Each function restates one piece of `/root/reference/opfgym/` (file:line cited
+per function).  The oracle is PINNED: tests/test_oracle_env.py replays the
+inputs stored in tests/golden/*.npz — produced by running the reference's own
+environment classes (tests/golden/make_golden.py) — and requires the outputs to
+match.  The power flow underneath is oracle/pf_oracle.py (parity unpinned
+against pandapower, see there).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from . import pf_oracle
+
+
+# ---------------------------------------------------------------------------
+# E2: OpfEnv._set_simbench_state  (opf_env.py:317-372)
+# ---------------------------------------------------------------------------
+def set_simbench_state(net, profiles, step, noise=None, col_range=None):
+    """Gather profile row `step` for every profile table, apply multiplicative
+    noise (one factor per column, tables in dict order, opf_env.py:352-356),
+    clip to the column's min/max over the whole profile (:364-369) and write
+    the unit table column (:371-372).  `noise` is the flat vector of factors."""
+    off = 0
+    for (unit, col), df in profiles.items():
+        n = df.shape[1]
+        if not n:
+            continue
+        idx = net[unit].index
+        data = df.loc[step, idx].to_numpy(float)
+        if noise is not None:
+            data = data * noise[off:off + n]
+        off += n
+        lo, hi = col_range[(unit, col)] if col_range else (df.min()[idx].to_numpy(float),
+                                                          df.max()[idx].to_numpy(float))
+        net[unit].loc[idx, col] = np.clip(data, lo, hi)
+
+
+def profile_ranges(profiles):
+    """Per-column min/max, computed once (the reference recomputes them on
+    every reset, opf_env.py:364-369 — defect D10, numerically identical)."""
+    return {k: (df.min().to_numpy(float), df.max().to_numpy(float))
+            for k, df in profiles.items() if df.shape[1]}
+
+
+# ---------------------------------------------------------------------------
+# E3: `_sample_from_range` and the benchmark envs' `_sampling` tails
+# ---------------------------------------------------------------------------
+def sample_from_range(net, unit, col, idxs, draws):
+    """opf_env.py:266-284: U[min_min|min, max_max|max] per row (`draws` are the
+    U[0,1) numbers, consumed in order), divided by `scaling` where it exists."""
+    df = net[unit]
+    lo = (df[f'min_min_{col}'] if f'min_min_{col}' in df else df[f'min_{col}']).loc[idxs].to_numpy(float)
+    hi = (df[f'max_max_{col}'] if f'max_max_{col}' in df else df[f'max_{col}']).loc[idxs].to_numpy(float)
+    u = np.array([next(draws) for _ in range(len(idxs))])
+    r = lo + (hi - lo) * u
+    if 'scaling' in df:
+        r = r / df['scaling'].loc[idxs].to_numpy(float)
+    net[unit].loc[idxs, col] = r
+
+
+def tail_voltage_control(net, draws, market_based):
+    """voltage_control.py:111-133."""
+    if market_based:
+        for unit in ('sgen', 'ext_grid', 'storage'):
+            idx = net.poly_cost[net.poly_cost.et == unit].index
+            sample_from_range(net, 'poly_cost', 'cq2_eur_per_mvar2', idx, draws)
+    for unit in ('sgen', 'storage'):
+        df = net[unit]
+        df['max_p_mw'] = df.p_mw * df.scaling + 1e-9
+        df['min_p_mw'] = df.p_mw * df.scaling - 1e-9
+    for unit in ('sgen', 'storage'):
+        df = net[unit]
+        q_max = (df.max_s_mva ** 2 - df.max_p_mw ** 2) ** 0.5
+        df['min_q_mvar'] = -q_max
+        df['max_q_mvar'] = q_max
+        df['q_mvar'] = 0.0
+
+
+def tail_eco_dispatch(net, draws):
+    """eco_dispatch.py:111-123."""
+    sample_from_range(net, 'poly_cost', 'cp1_eur_per_mw', net.poly_cost.index, draws)
+    sample_from_range(net, 'pwl_cost', 'cp1_eur_per_mw', net.pwl_cost.index, draws)
+    for idx in net.ext_grid.index:
+        net.pwl_cost.at[idx, 'points'] = [[0, 10000, net.pwl_cost.at[idx, 'cp1_eur_per_mw']]]
+
+
+def tail_max_renewable(net, draws):
+    """max_renewable.py:101-105."""
+    net.sgen['max_p_mw'] = net.sgen.p_mw * net.sgen.scaling + 1e-6
+
+
+TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
+         'QMarket': lambda net, d: tail_voltage_control(net, d, True),
+         'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
+         'SecurityConstrained': lambda net, d: None}
+
+
+# ---------------------------------------------------------------------------
+# E4: OpfEnv._apply_actions / get_current_actions  (opf_env.py:421-491, 566-588)
+# ---------------------------------------------------------------------------
+def apply_actions(net, act_keys, action, autoscale=True, diff_step=None):
+    action = np.clip(np.asarray(action, float), 0.0, 1.0)                # :429
+    k = 0
+    for unit, col, idxs in act_keys:
+        n = len(idxs)
+        if n == 0:
+            continue
+        df = net[unit]
+        a = action[k:k + n]
+        pre = ('min_', 'max_') if autoscale else ('min_min_', 'max_max_')   # :439-446
+        lo = df[pre[0] + col].loc[idxs].to_numpy(float)
+        hi = df[pre[1] + col].loc[idxs].to_numpy(float)
+        sc = df['scaling'].loc[idxs].to_numpy(float) if 'scaling' in df.columns else np.ones(n)
+        if diff_step:                                                       # :451-458
+            prev = df[col].loc[idxs].to_numpy(float) * sc
+            sp = (a * 2 - 1) * diff_step * (hi - lo) + prev
+        else:
+            sp = a * (hi - lo) + lo                                         # :461
+        if not autoscale or diff_step:                                      # :464-470
+            if f'max_{col}' in df.columns:
+                sp = np.minimum(sp, df[f'max_{col}'].loc[idxs].to_numpy(float))
+            if f'min_{col}' in df.columns:
+                sp = np.maximum(sp, df[f'min_{col}'].loc[idxs].to_numpy(float))
+        net[unit].loc[idxs, col] = sp / sc                                  # :472-483
+        k += n
+    cur = current_actions(net, act_keys, autoscale, from_results=False)
+    with np.errstate(invalid='ignore'):
+        return float(np.mean(np.abs(cur - action))) if len(action) else 0.0   # :488-489
+
+
+def current_actions(net, act_keys, autoscale=True, from_results=True):
+    out = []
+    for unit, col, idxs in act_keys:
+        df = net[unit]
+        if from_results:
+            sp = net['res_' + unit][col].loc[idxs].to_numpy(float)
+        else:
+            sp = df[col].loc[idxs].to_numpy(float)
+            if 'scaling' in df.columns:
+                sp = sp * df['scaling'].loc[idxs].to_numpy(float)
+        pre = ('min_', 'max_') if autoscale else ('min_min_', 'max_max_')
+        lo = df[pre[0] + col].loc[idxs].to_numpy(float)
+        hi = df[pre[1] + col].loc[idxs].to_numpy(float)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            out.append((sp - lo) / (hi - lo))
+    return np.concatenate(out) if out else np.zeros(0)
+
+
+# ---------------------------------------------------------------------------
+# E6: objective.get_pandapower_costs  (objective.py:6-87)
+# ---------------------------------------------------------------------------
+def cost_vector(net):
+    """[poly P costs…, poly Q costs…, pwl costs…] (objective.py:28,45)."""
+    parts = []
+    pc = net.poly_cost
+    if len(pc):
+        p = np.array([net['res_' + et][col].loc[el] for et, el, col in
+                      zip(pc.et, pc.element, ['p_mw'] * len(pc))], float)
+        q = np.array([net['res_' + et]['q_mvar'].loc[el] for et, el in zip(pc.et, pc.element)], float)
+        pcost = pc.cp0_eur.to_numpy(float) + pc.cp1_eur_per_mw.to_numpy(float) * p \
+            + pc.cp2_eur_per_mw2.to_numpy(float) * p ** 2
+        qcost = pc.cq0_eur.to_numpy(float) + pc.cq1_eur_per_mvar.to_numpy(float) * q \
+            + pc.cq2_eur_per_mvar2.to_numpy(float) * q ** 2
+        parts += [pcost, qcost]
+    pw = net.pwl_cost
+    if len(pw):
+        power = np.array([net['res_' + et]['p_mw' if pt == 'p' else 'q_mvar'].loc[el]
+                          for et, el, pt in zip(pw.et, pw.element, pw.power_type)], float)
+        costs = np.zeros(len(pw))
+        nseg = min(len(p) for p in pw.points)                # zip(*points) truncation, defect D9
+        for s in range(nseg):                                               # :60-75
+            lo = np.array([p[s][0] for p in pw.points], float)
+            hi = np.array([p[s][1] for p in pw.points], float)
+            price = np.array([p[s][2] for p in pw.points], float)
+            sign = np.sign(power)
+            same = sign == np.sign(lo + hi)
+            inside = np.minimum(np.abs(lo), np.abs(hi))
+            in_flag = (np.abs(power) > inside) & same
+            out_flag = np.abs(power) > np.maximum(np.abs(lo), np.abs(hi))
+            mid = in_flag & ~out_flag
+            costs[out_flag] += (sign * (hi - lo) * price)[out_flag]
+            costs[mid] += (sign * (np.abs(power) - inside) * price)[mid]
+        parts.append(costs)
+    return np.concatenate(parts) if parts else np.zeros(0)
+
+
+# ---------------------------------------------------------------------------
+# E7: Constraint.get_violation_metrics  (constraints.py:70-128)
+# ---------------------------------------------------------------------------
+def violation_metrics(net, con):
+    """`con`: any object with the reference Constraint's attributes
+    (unit_type, values_column, only_worst_case_violations, autoscale_violation,
+    scale_bounded_values, penalty_factor, penalty_power, violation_count_penalty)."""
+    values = net['res_' + con.unit_type][con.values_column].to_numpy(float)
+    tbl = net[con.unit_type]
+    violation, n_viol = 0.0, 0
+    for which in ('min', 'max'):                                            # :93-98
+        col = f'{which}_{con.values_column}'
+        if col not in tbl:
+            continue
+        bound = tbl[col].to_numpy(float)
+        if con.scale_bounded_values or ('scaling' in tbl and con.values_column in ('p_mw', 'q_mvar')):
+            bound = bound * tbl['scaling'].to_numpy(float)                  # :104-108
+        invalid = values > bound if which == 'max' else values < bound      # :110-111
+        n_viol += int(invalid.sum())
+        if invalid.any():                                                   # :113-122
+            absv = np.abs(values - bound)[invalid]
+            violation += absv.max() if con.only_worst_case_violations else absv.sum()
+    autoscale = con.autoscale_violation
+    if not autoscale and con.unit_type == 'ext_grid':                       # :179-182, 189-192
+        autoscale = 1 / abs(net.ext_grid['mean_' + con.values_column].sum())
+    if autoscale:
+        violation = violation * autoscale                                   # :82-83 (True -> ×1, defect D8)
+    penalty = -(violation ** con.penalty_power * con.penalty_factor
+                + n_viol * con.violation_count_penalty)                     # :124-128
+    return n_viol == 0, violation, penalty
+
+
+# ---------------------------------------------------------------------------
+# E8: reward  (reward.py:61-98, 219-320)
+# ---------------------------------------------------------------------------
+def reward_and_cost(rf, objective, penalty, valid):
+    """`rf`: dict(kind, penalty_weight, clip_range, scaling_params, valid_reward,
+    invalid_penalty, invalid_objective_share)."""
+    kind = rf.get('kind', 'summation')
+    obj, pen = objective, penalty
+    if kind == 'replacement':
+        obj = obj + rf['valid_reward'] if valid else 0.0                    # :247-252
+    elif kind == 'parameterized':
+        pen = pen + rf['valid_reward'] if valid else pen - rf['invalid_penalty']   # :288-291
+        if not valid:
+            obj = obj * rf['invalid_objective_share']                       # :293-298
+    elif kind == 'onlyobjective':
+        pen = 0.0                                                           # :316-317
+    sp = rf.get('scaling_params') or {'objective_factor': 1, 'objective_bias': 0,
+                                      'penalty_factor': 1, 'penalty_bias': 0}
+    obj = obj * sp['objective_factor'] + sp['objective_bias']               # :83-91
+    pen = pen * sp['penalty_factor'] + sp['penalty_bias']
+    w = rf.get('penalty_weight', 0.5)
+    reward = obj + pen if w is None else obj * (1 - w) + pen * w            # :78-81
+    if rf.get('clip_range'):
+        reward = float(np.clip(reward, *rf['clip_range']))                  # :70-71
+    cost = 0.0 if valid else abs(penalty * sp['penalty_factor'])            # :93-98
+    if kind == 'parameterized' and not valid:
+        cost += rf['invalid_penalty']                                       # :301-305
+    return reward, cost
+
+
+# ---------------------------------------------------------------------------
+# E9: OpfEnv._get_obs  (opf_env.py:532-549)
+# ---------------------------------------------------------------------------
+def observation(net, obs_keys, add_mean_obs=False, time_obs=None):
+    parts = [net[unit].loc[idxs, col].to_numpy(float) for unit, col, idxs in obs_keys]
+    if add_mean_obs:
+        parts.append(np.array([np.mean(p) for p in parts if len(p) > 1]))   # :539-542
+    if time_obs is not None:
+        parts = [np.asarray(time_obs, float)] + parts                       # :544-547
+    return np.concatenate(parts) if parts else np.zeros(0)
+
+
+# ---------------------------------------------------------------------------
+# E10/E11: step and the N-1 loop
+# ---------------------------------------------------------------------------
+class EnvOracle:
+    """One instance; mirrors reset()/step() of opf_env.py:177-220, 374-419 and
+    SecurityConstrainedOpfEnv.calculate_violations (security_constrained.py:37-68)."""
+
+    def __init__(self, net, act_keys, obs_keys, profiles, constraints, reward, tail, *,
+                 autoscale_actions=True, diff_action_step_size=None, clipped_action_penalty=0.0,
+                 diff_objective=False, add_mean_obs=False, pf_for_obs=False, steps_per_episode=1,
+                 n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True):
+        self.base_net = net
+        self.net = copy.deepcopy(net)
+        self.act_keys, self.obs_keys = act_keys, obs_keys
+        self.profiles, self.ranges = profiles, profile_ranges(profiles) if profiles else None
+        self.constraints, self.reward, self.tail = constraints, reward, tail
+        self.autoscale, self.diff_step = autoscale_actions, diff_action_step_size
+        self.cap = clipped_action_penalty
+        self.diff_objective, self.add_mean_obs, self.pf_for_obs = diff_objective, add_mean_obs, pf_for_obs
+        self.spe = steps_per_episode
+        self.n1, self.ncp = n_minus_one_keys, not_converged_penalty
+        self.enforce_q_lims = enforce_q_lims
+        self.initial_obj = 0.0
+
+    def solve(self):
+        try:
+            pf_oracle.runpp(self.net, enforce_q_lims=self.enforce_q_lims)
+            return True
+        except pf_oracle.LoadflowNotConverged:
+            return False
+
+    def reset(self, step, uniform=(), noise=None, initial_action=None):
+        self.net = copy.deepcopy(self.base_net)
+        self.step_in_episode = 0
+        set_simbench_state(self.net, self.profiles, step, noise, self.ranges)
+        self.tail(self.net, iter(np.asarray(uniform, float)))
+        n_act = sum(len(i) for _, _, i in self.act_keys)
+        act = np.full(n_act, 0.5) if initial_action is None else initial_action   # opf_env.py:201-207
+        apply_actions(self.net, self.act_keys, act, self.autoscale, None)
+        if self.pf_for_obs:                                                 # :209-216
+            assert self.solve()
+            self.initial_obj = float(np.sum(-cost_vector(self.net)))
+        return observation(self.net, self.obs_keys, self.add_mean_obs)
+
+    def violations(self):
+        res = [violation_metrics(self.net, c) for c in self.constraints]
+        return (np.array([r[0] for r in res], bool), np.array([r[1] for r in res], float),
+                np.array([r[2] for r in res], float))
+
+    def step(self, action):
+        self.step_in_episode += 1
+        corr = apply_actions(self.net, self.act_keys, action, self.autoscale, self.diff_step)
+        if not self.solve():
+            return dict(converged=False)
+        objective = float(np.sum(-cost_vector(self.net)))                   # :493-500, 517
+        if self.diff_objective:
+            objective -= self.initial_obj
+        valids, viol, pen = self.violations()
+        for unit, col, idxs in self.n1:                                     # security_constrained.py:44-66
+            for idx in idxs:
+                if not bool(self.net[unit].at[idx, col]):
+                    continue
+                self.net[unit].at[idx, col] = False
+                if self.solve():
+                    v2, vi2, p2 = self.violations()
+                    valids, viol, pen = valids & v2, viol + vi2, pen + p2
+                else:
+                    valids = np.zeros_like(valids)
+                    viol = viol + self.ncp
+                    pen = pen + self.ncp                                    # sign as in the reference (D6)
+                self.net[unit].at[idx, col] = True
+        valid = bool(valids.all())
+        reward, cost = reward_and_cost(self.reward, objective, float(np.sum(pen)), valid)
+        if self.cap:
+            reward -= corr * self.cap                                       # opf_env.py:403-404
+        term = self.spe == 1
+        trunc = (not term) and self.step_in_episode >= self.spe
+        return dict(converged=True, obs=observation(self.net, self.obs_keys, self.add_mean_obs),
+                    reward=reward, terminated=term, truncated=trunc, valids=valids, violations=viol,
+                    penalties=pen, cost=cost, objective=objective, mean_correction=corr,
+                    vm_pu=self.net.res_bus.vm_pu.to_numpy(float),
+                    va_degree=self.net.res_bus.va_degree.to_numpy(float),
+                    line_loading=self.net.res_line.loading_percent.to_numpy(float),
+                    trafo_loading=self.net.res_trafo.loading_percent.to_numpy(float),
+                    p_ext=self.net.res_ext_grid.p_mw.to_numpy(float),
+                    q_ext=self.net.res_ext_grid.q_mvar.to_numpy(float))

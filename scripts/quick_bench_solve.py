@@ -1,0 +1,31 @@
+"""Developer probe: time opfx_solve at a given batch size (not the bench contract)."""
+import sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from opfgym_amd import capi, grids
+from opfgym_amd.case import net_to_case
+from helpers import random_injections
+code = sys.argv[1] if len(sys.argv) > 1 else '1-MV-urban--0-sw'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+net, _ = grids.get_grid(code)
+case = net_to_case(net)
+plan = capi.Plan(case)
+print(plan.info)
+ctx = capi.Context(plan, 0)
+p, q = random_injections(net, case, B, 1)
+dev = torch.device('cuda:0')
+pt, qt = torch.tensor(p, device=dev), torch.tensor(q, device=dev)
+for _ in range(3):
+    out = capi.solve(ctx, pt, qt)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 20
+e0.record()
+for _ in range(reps):
+    out = capi.solve(ctx, pt, qt)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+it = out['iterations'].float().mean().item()
+print(f'{code} B={B}: {ms:.3f} ms/batch  -> {B/ms*1e3:.3e} solves/s, mean it {it:.2f}, conv {out["converged"].float().mean().item()}')

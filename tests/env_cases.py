@@ -1,0 +1,55 @@
+"""Builders shared by the environment parity tests (test code only)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from scenarios import SCENARIOS  # noqa: E402
+
+from opfgym_amd import envs as product_envs  # noqa: E402
+from oracle import env_oracle  # noqa: E402
+
+
+def golden(name):
+    return dict(np.load(os.path.join(HERE, 'golden', name + '.npz')))
+
+
+def product_env(name, batch_size=1, defer_device=False, **extra):
+    cls, kwargs, _, seed = SCENARIOS[name]
+    kw = dict(kwargs)
+    kw.update(extra)
+    return getattr(product_envs, cls)(seed=seed, batch_size=batch_size, defer_device=defer_device, **kw)
+
+
+def reward_dict(rf):
+    kind = type(rf).__name__.lower()
+    return dict(kind=kind, penalty_weight=rf.penalty_weight, clip_range=rf.clip_range,
+                scaling_params=rf.scaling_params, valid_reward=rf.valid_reward,
+                invalid_penalty=rf.invalid_penalty, invalid_objective_share=rf.invalid_objective_share)
+
+
+def oracle_env(name, env=None):
+    """EnvOracle for a scenario, built from the host-side problem definition."""
+    cls, kwargs, _, _ = SCENARIOS[name]
+    env = env or product_env(name, defer_device=True)
+    d = env.host_definition()
+    return env_oracle.EnvOracle(
+        d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
+        reward_dict(d['reward_function']), env_oracle.TAILS[cls],
+        autoscale_actions=env.autoscale_actions, diff_action_step_size=env.diff_action_step_size,
+        clipped_action_penalty=env.clipped_action_penalty, diff_objective=env.diff_objective,
+        add_mean_obs=env.add_mean_obs, pf_for_obs=env.pf_for_obs,
+        steps_per_episode=env.steps_per_episode, n_minus_one_keys=env.n_minus_one_keys,
+        not_converged_penalty=env.not_converged_penalty)
+
+
+def noise_factors(name, raw):
+    """Recorded raw U[0,1) draws -> multiplicative factors (opf_env.py:354-355);
+    None when the scenario samples without noise (factor exactly 1.0)."""
+    kwargs = SCENARIOS[name][1]
+    nf = (kwargs.get('sampling_params') or {}).get('noise_factor', 0.0)
+    if not nf or raw.size == 0:
+        return None
+    return raw * nf * 2 + (1 - nf)

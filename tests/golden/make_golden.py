@@ -1,0 +1,115 @@
+"""Generate tests/golden/*.npz from the REFERENCE's Python layer.
+
+Runs only in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden.py
+
+`opfgym` (the reference) is imported from /root/reference with the throw-away
+stub packages of tests/golden/_stubs standing in for gymnasium / pandapower /
+simbench: the grid comes from this repo's synthetic generator and every
+`pp.runpp` call is answered by the SciPy oracle (oracle/pf_oracle.py).  So the
+fixtures pin the reference's OWN environment logic — `_define_opf`, `_sampling`,
+`_set_simbench_state`, `_apply_actions`, objective, constraints, reward, info,
+observation, N-1 loop — on top of the oracle's power flow.  Only inputs/outputs
+are stored (no reference source text).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, '_stubs'), ROOT, '/root/reference', HERE]
+
+import numpy as np  # noqa: E402
+
+import opfgym.envs  # noqa: E402,F401  (reference)
+import opfgym.examples.security_constrained as ref_sc  # noqa: E402
+from scenarios import SCENARIOS, TRACKED  # noqa: E402
+
+REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
+       'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
+       'SecurityConstrained': ref_sc.SecurityConstrained}
+
+
+def snapshot(net):
+    out = {}
+    for tbl, col in TRACKED:
+        if tbl in net and col in net[tbl].columns and len(net[tbl]):
+            out[f'tab__{tbl}__{col}'] = np.array(net[tbl][col].to_numpy(dtype=float), copy=True)
+    return out
+
+
+def run(name):
+    cls, kwargs, n, seed = SCENARIOS[name]
+    env = REF[cls](seed=seed, **kwargs)
+    rng = np.random.default_rng(1000 + seed)
+    pool = env.train_steps
+    rec = {}
+
+    def push(key, val):
+        rec.setdefault(key, []).append(np.array(val, copy=True))
+    k = -1
+    done = 0
+    while done < n:
+        k += 1
+        step = int(rng.choice(pool))
+        obs0, _ = env.reset(seed=seed * 100 + k, options={'step': step})
+        log = env.np_random.log
+        uni = [u.ravel() for kind, u in log if kind == 'uniform']
+        noise = [u.ravel() for kind, u in log if kind == 'random']
+        action = rng.random(env.action_space.shape[0])
+        if k == 0:
+            action = np.clip(action * 1.6 - 0.3, -0.2, 1.2)        # exercise the [0,1] clipping
+        snap = snapshot(env.net)
+        init_obj = np.sum(env.initial_obj) if env.pf_for_obs else None
+        obs, reward, terminated, truncated, info = env.step(action)
+        if 'cost' not in info:
+            # power flow failed (opf_env.py:390-399): keep the inputs as a failure case
+            push('fail_step', step)
+            push('fail_action', action)
+            push('fail_uniform', np.concatenate(uni) if uni else np.zeros(0))
+            push('fail_noise', np.concatenate(noise) if noise else np.zeros(0))
+            continue
+        done += 1
+        push('step', step)
+        push('uniform', np.concatenate(uni) if uni else np.zeros(0))
+        push('noise', np.concatenate(noise) if noise else np.zeros(0))
+        push('obs_reset', obs0)
+        for key, val in snap.items():
+            push(key, val)
+        if init_obj is not None:
+            push('initial_obj', init_obj)
+        push('action', action)
+        push('obs_step', obs)
+        push('reward', reward)
+        push('terminated', terminated)
+        push('truncated', truncated)
+        push('valids', info['valids'])
+        push('violations', info['violations'])
+        push('penalties', info['unscaled_penalties'])
+        push('cost', info['cost'])
+        push('objective_vector', env.calculate_objective(diff_objective=False))
+        push('vm_pu', env.net.res_bus.vm_pu.to_numpy())
+        push('va_degree', env.net.res_bus.va_degree.to_numpy())
+        push('line_loading', env.net.res_line.loading_percent.to_numpy())
+        push('trafo_loading', env.net.res_trafo.loading_percent.to_numpy())
+        push('p_ext', env.net.res_ext_grid.p_mw.to_numpy())
+        push('q_ext', env.net.res_ext_grid.q_mvar.to_numpy())
+        push('current_actions', env.get_current_actions())
+        for tbl, col in (('sgen', 'q_mvar'), ('sgen', 'p_mw'), ('storage', 'q_mvar'), ('gen', 'p_mw')):
+            if len(env.net[tbl]):
+                push(f'post__{tbl}__{col}', np.array(env.net[tbl][col].to_numpy(dtype=float), copy=True))
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out['n_obs'] = np.array(env.observation_space.shape[0])
+    out['n_act'] = np.array(env.action_space.shape[0])
+    out['n_bus'] = np.array(len(env.net.bus))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: {n} samples, obs {out["obs_step"].shape}, reward {out["reward"].round(4)}, '
+          f'valid {out["valids"].all(axis=1)}')
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(SCENARIOS)
+    for nm in names:
+        run(nm)

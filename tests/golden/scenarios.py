@@ -1,0 +1,44 @@
+"""Scenario table shared by the golden-vector generator (runs the reference's
+environment classes under stubs, in the build container only) and by the parity
+tests (run this repo's oracle / GPU path on the same inputs)."""
+
+# name -> (environment class name, constructor kwargs, number of samples, seed)
+SCENARIOS = {
+    'vc_mv_small': ('VoltageControl', dict(simbench_network_name='mv-small'), 6, 1),
+    'vc_mv_urban': ('VoltageControl', dict(simbench_network_name='1-MV-urban--0-sw'), 4, 2),
+    'qm_mv_small': ('QMarket', dict(simbench_network_name='mv-small'), 6, 3),
+    'qm_mv_urban': ('QMarket', dict(simbench_network_name='1-MV-urban--0-sw'), 3, 4),
+    'eco_hv_small': ('EcoDispatch', dict(simbench_network_name='hv-small'), 6, 5),
+    'maxren_lv': ('MaxRenewable', dict(simbench_network_name='1-LV-rural1--0-sw',
+                                       min_sgen_power=0.005, min_storage_power=0.005), 6, 6),
+    'sc_hv_small': ('SecurityConstrained', dict(simbench_network_name='hv-small'), 5, 7),
+    # option coverage on the small MV grid
+    'vc_replacement': ('VoltageControl', dict(
+        simbench_network_name='mv-small', reward_function='replacement',
+        reward_function_params=dict(valid_reward=0.7, penalty_weight=0.3, clip_range=(-1.5, 1.0))), 4, 8),
+    'vc_parameterized': ('VoltageControl', dict(
+        simbench_network_name='mv-small', reward_function='parameterized',
+        reward_function_params=dict(valid_reward=0.4, invalid_penalty=0.2, invalid_objective_share=0.5,
+                                    penalty_weight=None),
+        constraint_params=dict(penalty_factor=2.0, penalty_power=1.5, violation_count_penalty=0.1,
+                               only_worst_case_violations=True)), 4, 9),
+    'vc_resobs_diff': ('VoltageControl', dict(
+        simbench_network_name='mv-small', add_res_obs=True, diff_objective=True, add_act_obs=True,
+        add_mean_obs=True, clipped_action_penalty=0.5), 4, 10),
+    'vc_noscale_scaled': ('VoltageControl', dict(
+        simbench_network_name='mv-small', autoscale_actions=False, voltage_band=0.02, max_loading=40,
+        reward_function='summation',
+        reward_function_params=dict(reward_scaling='minmax11', scaling_params=dict(
+            min_objective=-2.0, max_objective=0.5, min_penalty=-3.0, max_penalty=0.0))), 4, 11),
+    'vc_noisy': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='noisy_simbench',
+        sampling_params=dict(noise_factor=0.2)), 4, 12),
+}
+
+# table columns snapshotted after reset (when present in the reference net)
+TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_mvar'),
+           ('storage', 'p_mw'), ('storage', 'q_mvar'), ('gen', 'p_mw'),
+           ('sgen', 'max_p_mw'), ('sgen', 'min_p_mw'), ('sgen', 'max_q_mvar'), ('sgen', 'min_q_mvar'),
+           ('storage', 'max_q_mvar'), ('storage', 'min_q_mvar'),
+           ('poly_cost', 'cq2_eur_per_mvar2'), ('poly_cost', 'cp1_eur_per_mw'),
+           ('pwl_cost', 'cp1_eur_per_mw')]

@@ -55,3 +55,27 @@ def oracle_batch(case, p, q, **kw):
         sref[b, :, 0] = s.real[ref] - p[b, ref]
         sref[b, :, 1] = s.imag[ref] - q[b, ref]
     return dict(vm=vm, va=va, loading=load, s_ref=sref, converged=conv, iterations=its)
+
+
+def non_bridge_branches(case):
+    """Branches whose outage leaves every bus connected to a REF bus."""
+    out = []
+    ref = np.flatnonzero(case.bus_type == 3)
+    for k in range(case.nbr):
+        adj = [[] for _ in range(case.nb)]
+        for m in range(case.nbr):
+            if m != k:
+                adj[case.f[m]].append(case.t[m])
+                adj[case.t[m]].append(case.f[m])
+        seen = np.zeros(case.nb, bool)
+        stack = list(ref)
+        seen[ref] = True
+        while stack:
+            a = stack.pop()
+            for b in adj[a]:
+                if not seen[b]:
+                    seen[b] = True
+                    stack.append(b)
+        if seen.all():
+            out.append(k)
+    return np.array(out, dtype=np.int32)

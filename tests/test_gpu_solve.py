@@ -76,9 +76,11 @@ def test_outage_axis():
     ctx = capi.Context(plan, 0)
     B = 24
     p, q = random_injections(net, case, B, 3, lo=0.2, hi=0.8)
-    # choose lines on the ring backbone (their removal keeps the grid connected)
+    # only branches whose removal keeps the grid connected (no bridges)
+    from helpers import non_bridge_branches
+    cand = non_bridge_branches(case)
     outage = np.full(B, -1, dtype=np.int32)
-    outage[1::2] = np.arange(B // 2) * 3
+    outage[1::2] = cand[np.arange(B // 2) * 5 % len(cand)]
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev),
                      outage=torch.tensor(outage, device=dev))
