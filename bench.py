@@ -1,0 +1,166 @@
+"""Benchmark of the hot path: env.step()/s at batch 8192 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): VoltageControl on the synthetic stand-in
+for SimBench 1-MV-urban--0-sw (144 buses), B = 8192 instances per GPU, FP64.
+One "step" = one `env.step()` of the whole batch = ONE launch of the fused
+kernel (apply actions -> NR power flow -> results -> objective -> violations
+-> reward -> observation).  Inputs are resident in HBM when the timed region
+starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank steps its own 8192-instance shard (weak scaling) and the rewards are
+re-assembled on every rank with one RCCL all-gather per step.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
+
+import numpy as np  # noqa: E402
+
+BATCH = 8192
+GRID = '1-MV-urban--0-sw'
+
+
+def byte_model(env, mean_it):
+    """ALGORITHMIC bytes per instance-step:
+    B_step = 8*(n_in + n_out) + it*8*(2*nnzJ + 2*nnzLU + 4*nJ + 4*nb)."""
+    info = env.plan.info
+    net = env.net
+    n_price = sum(1 for k in env.store.dynamic if k[0] in ('poly_cost', 'pwl_cost'))
+    n_in = env.n_actions + 2 * len(net.load) + len(net.sgen) + len(net.gen) + len(net.storage) + n_price
+    n_out = 2 * info['nb'] + 2 * info['nbr'] + env.n_obs_raw + 3 * env.n_constraints + 4
+    n_j = info['npv'] + 2 * info['npq']
+    nnz_lu = 4 * info['n_blk']
+    per_it = 8 * (2 * info['nnz_j'] + 2 * nnz_lu + 4 * n_j + 4 * info['nb'])
+    b_step = 8 * (n_in + n_out) + mean_it * per_it
+    return dict(nb=info['nb'], nbr=info['nbr'], nJ=n_j, nnzJ=info['nnz_j'], nnzLU=nnz_lu,
+                n_in=n_in, n_out=n_out, it=mean_it, io_bytes=8 * (n_in + n_out),
+                bytes_per_iteration=per_it, B_step=b_step)
+
+
+def cpu_baseline(budget_s=15.0):
+    """The CPU oracle (numpy/SciPy restatement of the reference path: pandas
+    tables + SuperLU Newton) timed on this box, one core, on a bounded sample of
+    the same workload."""
+    from env_cases import oracle_env, product_env
+    orc = oracle_env('vc_mv_urban', product_env('vc_mv_urban', defer_device=True))
+    rng = np.random.default_rng(0)
+    pool = np.arange(2000, 30000)
+    n_act = sum(len(i) for _, _, i in orc.act_keys)
+    t_step, n = 0.0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        orc.reset(int(rng.choice(pool)))
+        a = rng.random(n_act)
+        t1 = time.perf_counter()
+        out = orc.step(a)
+        t_step += time.perf_counter() - t1
+        n += bool(out['converged'])
+    return dict(value=n / t_step, unit='env.step()/s', cores=1, kind='port',
+                sample=f'{n} instance-steps of VoltageControl/{GRID} with the numpy+SciPy oracle '
+                       f'(oracle/env_oracle.py + pf_oracle.py), step() only, {t_step:.1f} s of CPU work; '
+                       f'pandapower itself is not installed')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gather-obs', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from opfgym_amd import capi, dist as odist, envs
+    rank, world, local_rank = odist.init_from_env()
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N'
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    B = args.batch
+    env = envs.VoltageControl(simbench_network_name=GRID, batch_size=B, device=device, seed=rank)
+    rng = np.random.default_rng(1234 + rank)
+    env.reset(options={'step': rng.choice(env.train_steps, B)})
+    act_rng = np.random.default_rng(4321 + rank)
+    actions = torch.as_tensor(act_rng.random((B, env.n_actions)), device=device)
+    gather = ('reward', 'obs') if args.gather_obs else ('reward',)
+
+    def one_step():
+        obs, reward, term, trunc, info = env.step(actions)
+        if world > 1:
+            odist.all_gather_rows(reward, world)
+            if 'obs' in gather:
+                odist.all_gather_rows(obs, world)
+        return info
+
+    for _ in range(args.warmup):
+        info = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    conv = float(info['converged'].double().mean().item())
+    mean_it = float(info['iterations'].double().mean().item())
+
+    # kernel duration: HIP events on the launch stream around back-to-back launches
+    io = env._io(actions, False)
+    ms = capi.C.c_float()
+    with torch.cuda.device(device):
+        capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io),
+                                              capi.C.byref(env.solve_opts), max(5, args.steps),
+                                              capi._stream(), capi.C.byref(ms)), 'opfx_time_steps')
+    kernel_ms = ms.value / max(5, args.steps)
+
+    if rank == 0:
+        bm = byte_model(env, mean_it)
+        achieved = bm['B_step'] * B / (kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'env.step()/s (batched NR power-flow solves/s) at batch 8192',
+            'value': world * B * args.steps / elapsed,
+            'unit': 'env.step()/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'VoltageControl env, synthetic stand-in for SimBench {GRID} '
+                                   f'({bm["nb"]} buses), batch={B} per GPU, step() only',
+                       'batch_per_gpu': B, 'parallelism': f'shard{world}',
+                       'collective': 'all_gather(reward)' + ('+obs' if args.gather_obs else '') if world > 1 else 'none',
+                       'converged_fraction': conv, 'mean_nr_iterations': mean_it,
+                       'tolerance_pu': env.solve_opts.tol, 'byte_model': bm},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': None,
+                         'kernel': 'k_step', 'kernel_ms': kernel_ms,
+                         'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory '
+                                 'once per NR phase) x 8192 / kernel time; the kernel keeps that state in LDS, '
+                                 'so real HBM traffic is ~ io_bytes per instance (see DESIGN.md)'},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

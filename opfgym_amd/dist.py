@@ -1,0 +1,84 @@
+"""Multi-GPU: one process per GPU, the batch sharded over ranks.
+
+Instances are independent (the reference has no cross-environment state at
+all: one OpfEnv per net, opf_env.py:58), so the data path needs NO collective:
+every rank resets/steps its own contiguous shard.  The only exchange is the
+optional re-assembly of per-instance outputs (reward, flags, observations) for
+a learner that wants the full batch on every rank: one all-gather per tensor
+over `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1 or dist.is_initialized():
+        return int(os.environ.get('RANK', '0')), world, int(os.environ.get('LOCAL_RANK', '0'))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size(), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of `total` instances for `rank` (sizes differ by
+    at most one; whole instances only, so the N-1 reduction over the
+    contingencies of an instance never crosses ranks)."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(local, world: int, sizes=None):
+    """Concatenate per-rank [b_r, ...] tensors along dim 0 on every rank.
+    Equal shard sizes use one all_gather_into_tensor; ragged shards pad to the
+    largest shard and trim."""
+    import torch
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return local
+    if sizes is None or len(set(sizes)) == 1:
+        out = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype,
+                          device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((m * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], dim=0)
+
+
+class ShardedBatch:
+    """Wraps a per-rank environment factory: `total_batch` instances split over
+    the ranks; `step()` returns the local shard's outputs plus, for the names in
+    `gather`, full-batch tensors assembled with one all-gather each."""
+
+    def __init__(self, make_env, total_batch, rank, world, gather=('reward',)):
+        self.rank, self.world = rank, world
+        self.lo, self.hi = shard_bounds(total_batch, rank, world)
+        self.sizes = [shard_bounds(total_batch, r, world)[1] - shard_bounds(total_batch, r, world)[0]
+                      for r in range(world)]
+        self.env = make_env(self.hi - self.lo)
+        self.gather = tuple(gather)
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+    def step(self, local_actions):
+        obs, reward, term, trunc, info = self.env.step(local_actions)
+        full = {}
+        named = {'reward': reward, 'obs': obs, 'terminated': term.to(reward.dtype),
+                 'cost': info['cost']}
+        for name in self.gather:
+            full[name] = all_gather_rows(named[name], self.world, self.sizes)
+        return (obs, reward, term, trunc, info), full
