@@ -131,9 +131,11 @@ void opfx_version(int* major, int* minor, int* patch);
 /* ---- pure power flow ------------------------------------------------------
  * p_inj/q_inj [B,nb]: net bus injections (generation - demand), p.u.; q_inj is
  * ignored at PV buses.  Outputs (any may be NULL): vm [B,nb] p.u., va [B,nb]
- * rad, loading [B,nbr] percent, s_ref [B,nref*2] slack-bus injection P,Q p.u.
- * (interleaved, REF buses in increasing bus order), converged [B], iterations
- * [B], max_mismatch [B] (final inf-norm of [dP;dQ], p.u.).
+ * rad, loading [B,nbr] percent, s_ref [B,nref*2] power delivered by the slack
+ * source at each REF bus (calculated injection minus p_inj/q_inj there), P,Q
+ * p.u. interleaved, REF buses in increasing bus order; q_gen [B,nb] reactive
+ * output of the generator at each PV bus, p.u. (0 elsewhere); converged [B],
+ * iterations [B], max_mismatch [B] (final inf-norm of [dP;dQ], p.u.).
  * q_inj at a PV bus is the reactive injection of everything EXCEPT the voltage-
  * controlling generator there (so Qgen = Qcalc - q_inj); qg_min/qg_max [nb]
  * p.u. (NULL = unlimited) are the generator capability used by enforce_q_lims.
@@ -149,7 +151,7 @@ typedef struct opfx_solve_opts {
 int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
                const double* qg_min, const double* qg_max,
                const int32_t* outage, const opfx_solve_opts* opts,
-               double* vm, double* va, double* loading, double* s_ref,
+               double* vm, double* va, double* loading, double* s_ref, double* q_gen,
                uint8_t* converged, int32_t* iterations, double* max_mismatch,
                void* stream);
 

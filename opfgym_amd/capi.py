@@ -144,7 +144,7 @@ def lib():
     L.opfx_ctx_destroy.restype = None
     L.opfx_version.argtypes = [C.POINTER(C.c_int)] * 3
     L.opfx_version.restype = None
-    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 8
+    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 9
     L.opfx_env_create.argtypes = [vp, C.POINTER(EnvDesc), C.POINTER(vp)]
     L.opfx_env_destroy.argtypes = [vp]
     L.opfx_env_destroy.restype = None
@@ -258,7 +258,7 @@ def _stream():
 
 
 def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, tol=1e-8,
-          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref')):
+          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref', 'q_gen')):
     """Batched power flow on torch CUDA tensors p_inj/q_inj [B, nb] (p.u.)."""
     import torch
     assert p_inj.is_cuda and p_inj.dtype == torch.float64 and p_inj.shape == q_inj.shape
@@ -275,6 +275,8 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
         out['loading'] = torch.empty(B, info['nbr'], dtype=torch.float64, device=dev)
     if 's_ref' in want:
         out['s_ref'] = torch.empty(B, info['nref'], 2, dtype=torch.float64, device=dev)
+    if 'q_gen' in want:
+        out['q_gen'] = torch.empty(B, nb, dtype=torch.float64, device=dev)
     out['converged'] = torch.empty(B, dtype=torch.uint8, device=dev)
     out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
     out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
@@ -283,6 +285,6 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
         check(lib().opfx_solve(
             ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),
             _ptr(outage), C.byref(opts), _ptr(out.get('vm')), _ptr(out.get('va')),
-            _ptr(out.get('loading')), _ptr(out.get('s_ref')), _ptr(out['converged']),
+            _ptr(out.get('loading')), _ptr(out.get('s_ref')), _ptr(out.get('q_gen')), _ptr(out['converged']),
             _ptr(out['iterations']), _ptr(out['max_mismatch']), _stream()), 'opfx_solve')
     return out

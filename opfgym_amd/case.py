@@ -348,3 +348,44 @@ def _propagate_angles(nb, f, t, shift, bus_type, va_set):
                 va0[b] = va0[a] + d
                 stack.append(b)
     return va0
+
+
+def bus_injections(net, case: Case):
+    """makeSbus on the element tables: net injection per case
+    bus in MW/Mvar (generation − demand) from load/sgen/storage/gen rows
+    (`p_mw·scaling`, in service only), plus the summed reactive capability of
+    the generators per bus.  Returns (p, q, qg_min, qg_max); q excludes the
+    voltage-controlling generators (their Q is a result)."""
+    nb = case.nb
+    p = np.zeros(nb)
+    q = np.zeros(nb)
+    for tbl, sign in (('load', -1.0), ('sgen', 1.0), ('storage', -1.0)):
+        df = net[tbl]
+        if not len(df):
+            continue
+        on = _col(df, 'in_service', True).astype(bool)
+        sc = _col(df, 'scaling', 1.0)
+        pv, qv = df['p_mw'].to_numpy(float), df['q_mvar'].to_numpy(float)
+        for pos, b in enumerate(df['bus'].to_numpy()):
+            if on[pos] and int(b) in case.bus_lookup:
+                i = case.bus_lookup[int(b)]
+                p[i] += sign * pv[pos] * sc[pos]
+                q[i] += sign * qv[pos] * sc[pos]
+    qmin = np.full(nb, -np.inf)
+    qmax = np.full(nb, np.inf)
+    gen = net['gen']
+    if len(gen):
+        on = _col(gen, 'in_service', True).astype(bool)
+        sc = _col(gen, 'scaling', 1.0)
+        lo_c = _col(gen, 'min_q_mvar', -np.inf)
+        hi_c = _col(gen, 'max_q_mvar', np.inf)
+        acc_lo, acc_hi, has = np.zeros(nb), np.zeros(nb), np.zeros(nb, bool)
+        for pos, b in enumerate(gen['bus'].to_numpy()):
+            if on[pos] and int(b) in case.bus_lookup:
+                i = case.bus_lookup[int(b)]
+                p[i] += float(gen['p_mw'].iloc[pos]) * sc[pos]
+                acc_lo[i] += lo_c[pos]
+                acc_hi[i] += hi_c[pos]
+                has[i] = True
+        qmin[has], qmax[has] = acc_lo[has], acc_hi[has]
+    return p, q, qmin, qmax

@@ -83,7 +83,7 @@ struct DevEnv {
 struct SolveIO {
   const double *p_inj, *q_inj, *qg_min, *qg_max;
   const int* outage;
-  double *vm, *va, *loading, *s_ref, *max_mismatch;
+  double *vm, *va, *loading, *s_ref, *q_gen, *max_mismatch;
   unsigned char* converged;
   int* iterations;
 };
@@ -470,6 +470,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(DevPlan P, SolveIO io, Opts o, l
       io.s_ref[(b * nref + r) * 2] = R[2 * nb + nbr + r];
       io.s_ref[(b * nref + r) * 2 + 1] = R[2 * nb + nbr + nref + r];
     }
+    if (io.q_gen) for (int i = lane; i < nb; i += WAVE) io.q_gen[b * nb + i] = R[2 * nb + nbr + 2 * nref + i];
     if (lane == 0) {
       if (io.converged) io.converged[b] = conv ? 1 : 0;
       if (io.iterations) io.iterations[b] = iters;
@@ -894,7 +895,7 @@ extern "C" void opfx_ctx_destroy(opfx_ctx* ctx) { delete ctx; }
 extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
                           const double* qg_min, const double* qg_max, const int32_t* outage,
                           const opfx_solve_opts* opts, double* vm, double* va, double* loading,
-                          double* s_ref, uint8_t* converged, int32_t* iterations,
+                          double* s_ref, double* q_gen, uint8_t* converged, int32_t* iterations,
                           double* max_mismatch, void* stream) {
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
   if (B == 0) return OPFX_OK;
@@ -906,7 +907,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   int grid = 0;
   int rc = launch_geometry(k_solve, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu);
   if (rc != OPFX_OK) return rc;
-  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, max_mismatch, converged, iterations};
+  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations};
   hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());

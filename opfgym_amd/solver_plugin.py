@@ -1,0 +1,117 @@
+"""Drop-in for the reference's `power_flow_solver` seam (batch = 1 plumbing).
+
+`OpfEnv(..., power_flow_solver=opfgym_amd.power_flow_solver)` replaces the
+`pp.runpp(net, enforce_q_lims=True)` call of `OpfEnv.default_power_flow`
+(/root/reference/opfgym/opf_env.py:53,70,657,696-709; also reached from
+security_constrained.py:53 and reward.py:190).  Same contract: mutate the
+`net.res_*` tables in place, raise `LoadflowNotConverged` on failure.
+
+The solve itself is `opfx_solve` with B = 1 on the GPU (no CPU fallback); only
+the table <-> per-unit conversion and the writing of result columns happen on
+the host, as they do inside pandapower.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from . import capi
+from .case import KIND_LINE, KIND_TRAFO, REF, bus_injections, net_to_case
+
+
+class LoadflowNotConverged(Exception):
+    """Raised when the Newton-Raphson solve does not converge.  When pandapower is
+    importable its own `pp.powerflow.LoadflowNotConverged` is raised instead so
+    that `OpfEnv.run_power_flow` (opf_env.py:660) catches it."""
+
+
+def _not_converged_exception():
+    try:
+        import pandapower as pp
+        return pp.powerflow.LoadflowNotConverged
+    except Exception:
+        return LoadflowNotConverged
+
+
+class BatchedPowerFlowSolver:
+    def __init__(self, device='cuda:0', tolerance=1e-8, max_iteration=10):
+        self.device = device
+        self.tol, self.max_it = tolerance, max_iteration
+        self._cache = {}
+
+    def _context(self, case):
+        key = (case.nb, case.nbr, case.bus_type.tobytes(), case.f.tobytes(), case.t.tobytes(),
+               case.yff.tobytes(), case.yft.tobytes(), case.ytf.tobytes(), case.ytt.tobytes(),
+               case.vm_set.tobytes(), case.va_set.tobytes(), case.gs.tobytes(), case.bs.tobytes())
+        hit = self._cache.get('key')
+        if hit != key:
+            import torch
+            dev = torch.device(self.device)
+            self._cache = {'key': key, 'ctx': capi.Context(capi.Plan(case), dev.index or 0)}
+        return self._cache['ctx']
+
+    def __call__(self, net, enforce_q_lims=True, **kwargs):
+        import torch
+        case = net_to_case(net, kwargs.get('calculate_voltage_angles', 'auto'))
+        ctx = self._context(case)
+        base = case.base_mva
+        p, q, qmin, qmax = bus_injections(net, case)
+        dev = torch.device(self.device)
+        as_t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+        out = capi.solve(ctx, as_t(p[None] / base), as_t(q[None] / base), qg_min=as_t(qmin / base),
+                         qg_max=as_t(qmax / base), tol=self.tol, max_iter=self.max_it,
+                         enforce_q_lims=bool(enforce_q_lims) and case.bus_type.tolist().count(2) > 0)
+        if not bool(out['converged'][0]):
+            raise _not_converged_exception()('batched Newton-Raphson did not converge')
+        self._write_results(net, case, {k: v[0].cpu().numpy() for k, v in out.items()}, p, q)
+
+    @staticmethod
+    def _write_results(net, case, r, p_mw, q_mvar):
+        base = case.base_mva
+        nbus = len(net['bus'])
+        vm, va = np.full(nbus, np.nan), np.full(nbus, np.nan)
+        for pos, b in enumerate(net['bus'].index):
+            if int(b) in case.bus_lookup:
+                i = case.bus_lookup[int(b)]
+                vm[pos], va[pos] = r['vm'][i], np.degrees(r['va'][i])
+        net['res_bus'] = pd.DataFrame({'vm_pu': vm, 'va_degree': va}, index=net['bus'].index)
+        for tbl, kind in (('line', KIND_LINE), ('trafo', KIND_TRAFO)):
+            load = np.zeros(len(net[tbl]))
+            sel = case.br_kind == kind
+            load[case.br_elem[sel]] = r['loading'][sel]
+            net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
+        ref_buses = np.flatnonzero(case.bus_type == REF)
+        ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+        eg = net['ext_grid']
+        pe, qe = np.full(len(eg), np.nan), np.full(len(eg), np.nan)
+        for pos, b in enumerate(eg['bus'].to_numpy()):
+            if int(b) in case.bus_lookup:
+                k = ordinal[case.bus_lookup[int(b)]]
+                pe[pos], qe[pos] = r['s_ref'][k, 0] * base, r['s_ref'][k, 1] * base
+        net['res_ext_grid'] = pd.DataFrame({'p_mw': pe, 'q_mvar': qe}, index=eg.index)
+        for tbl in ('load', 'sgen', 'storage'):
+            df = net[tbl]
+            sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns and len(df) else 1.0
+            net['res_' + tbl] = pd.DataFrame({'p_mw': df['p_mw'].to_numpy(float) * sc,
+                                              'q_mvar': df['q_mvar'].to_numpy(float) * sc}, index=df.index)
+        gen = net['gen']
+        sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns and len(gen) else 1.0
+        qg, vg = np.full(len(gen), np.nan), np.full(len(gen), np.nan)
+        for pos, b in enumerate(gen['bus'].to_numpy() if len(gen) else []):
+            if int(b) in case.bus_lookup:
+                i = case.bus_lookup[int(b)]
+                qg[pos], vg[pos] = r['q_gen'][i] * base, r['vm'][i]
+        net['res_gen'] = pd.DataFrame({'p_mw': gen['p_mw'].to_numpy(float) * sc if len(gen) else [],
+                                       'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
+
+
+_default = None
+
+
+def power_flow_solver(net, **kwargs):
+    """Module-level callable with the reference's plug-in signature
+    `Callable[[pandapowerNet], None]` (opf_env.py:53)."""
+    global _default
+    if _default is None:
+        _default = BatchedPowerFlowSolver()
+    return _default(net, **kwargs)

@@ -1,0 +1,224 @@
+"""CPU: host-side logic and the known-answer tests the reference holds for the
+in-repo half of the path, restated against the oracle evaluators
+(reference tests/test_constraints.py:17-78, test_objective.py:17-88,
+test_reward.py:8-78, test_simbench.py:79-119)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from opfgym_amd import constraints as pc, grids, net as ppn, reward as pr
+from opfgym_amd.simbench_build import (build_simbench_net, define_test_train_split,
+                                       get_simbench_time_observation)
+from oracle import env_oracle as eo
+
+
+def _fake_net():
+    net = grids.case9()
+    for tbl, n in (('bus', 9), ('line', 9)):
+        pass
+    net['res_bus'] = pd.DataFrame({'vm_pu': np.ones(9), 'va_degree': np.zeros(9)})
+    net['res_line'] = pd.DataFrame({'loading_percent': np.full(9, 50.0)})
+    ppn.create_transformer_from_parameters(net, 0, 3, 100, 345, 345, 10, 0.5, 0, 0)
+    ppn.finalize(net)
+    net['res_trafo'] = pd.DataFrame({'loading_percent': [50.0]})
+    net['res_ext_grid'] = pd.DataFrame({'p_mw': [0.0], 'q_mvar': [0.0]})
+    for t in ('load', 'sgen', 'gen', 'storage'):
+        net['res_' + t] = pd.DataFrame({'p_mw': np.zeros(len(net[t])), 'q_mvar': np.zeros(len(net[t]))},
+                                       index=net[t].index)
+    ppn.create_sgen(net, 5, 1.0)
+    ppn.finalize(net)
+    net['res_sgen'] = pd.DataFrame({'p_mw': [0.0], 'q_mvar': [0.0]})
+    return net
+
+
+# ---- constraints: reference tests/test_constraints.py:17-78 -----------------------
+def test_voltage_constraint_kat():
+    net = _fake_net()
+    con = pc.VoltageConstraint(autoscale_violation=False, only_worst_case_violations=True)
+    net.bus['min_vm_pu'], net.bus['max_vm_pu'] = 0.95, 1.05
+    net.res_bus.at[0, 'vm_pu'] = 0.9
+    net.res_bus.at[1, 'vm_pu'] = 0.94
+    valid, viol, pen = eo.violation_metrics(net, con)
+    assert not valid and np.isclose(viol, 0.05) and np.isclose(pen, -0.05)
+
+
+def test_line_and_trafo_overload_kat():
+    net = _fake_net()
+    net.line['max_loading_percent'] = 100
+    net.res_line.at[0, 'loading_percent'] = 110
+    valid, viol, pen = eo.violation_metrics(net, pc.LineOverloadConstraint(autoscale_violation=False,
+                                                                           penalty_factor=2.0))
+    assert not valid and viol == 10 and pen == -20
+    net.trafo['max_loading_percent'] = 100
+    net.res_trafo.at[0, 'loading_percent'] = 110
+    valid, viol, pen = eo.violation_metrics(net, pc.TrafoOverloadConstraint(autoscale_violation=False,
+                                                                            penalty_power=2.0))
+    assert not valid and viol == 10 and pen == -100
+
+
+def test_ext_grid_constraints_kat():
+    net = _fake_net()
+    net.ext_grid['min_p_mw'] = 0
+    net.res_ext_grid.at[0, 'p_mw'] = -0.5
+    valid, viol, pen = eo.violation_metrics(net, pc.ExtGridActivePowerConstraint(autoscale_violation=0.5))
+    assert not valid and viol == 0.25 and pen == -0.25
+    net.ext_grid['min_q_mvar'] = 0
+    net.res_ext_grid.at[0, 'q_mvar'] = -0.5
+    valid, viol, pen = eo.violation_metrics(net, pc.ExtGridReactivePowerConstraint(autoscale_violation=0.5))
+    assert not valid and viol == 0.25 and pen == -0.25
+    # default autoscale=True multiplies by True (defect D8): 0.5 stays 0.5
+    valid, viol, pen = eo.violation_metrics(net, pc.ExtGridReactivePowerConstraint())
+    assert viol == 0.5
+
+
+def test_default_constraint_discovery():          # reference tests/test_constraints.py:80-128
+    net = _fake_net()
+    for col in ('min_vm_pu', 'max_vm_pu'):
+        net.bus[col] = np.nan
+    net.line['max_loading_percent'] = np.nan
+    assert pc.create_default_constraints(net, {}) == []
+    net.bus['min_vm_pu'], net.bus['max_vm_pu'] = 0.95, 1.05
+    net.line['max_loading_percent'] = 100
+    net.trafo['max_loading_percent'] = 100
+    net.ext_grid['min_p_mw'] = 0
+    net.ext_grid['min_q_mvar'] = 0
+    kinds = [type(c) for c in pc.create_default_constraints(net, {})]
+    assert kinds == [pc.VoltageConstraint, pc.LineOverloadConstraint, pc.TrafoOverloadConstraint,
+                     pc.ExtGridActivePowerConstraint, pc.ExtGridReactivePowerConstraint]
+    net.ext_grid['min_q_mvar'], net.ext_grid['max_q_mvar'] = -np.inf, np.inf
+    net.ext_grid['min_p_mw'], net.ext_grid['max_p_mw'] = np.nan, np.nan
+    net.bus['min_vm_pu'], net.bus['max_vm_pu'] = None, None
+    kinds = [type(c) for c in pc.create_default_constraints(net, {})]
+    assert kinds == [pc.LineOverloadConstraint, pc.TrafoOverloadConstraint]
+
+
+# ---- objective: reference tests/test_objective.py:30-88 -----------------------------
+def test_pwl_costs_kat():
+    net = _fake_net()
+    ppn.create_pwl_cost(net, 0, 'load', power_type='p', points=[[0, 1, 30], [1, 2, 50]])
+    net.res_load.loc[0, 'p_mw'] = 1.5
+    assert eo.cost_vector(net).sum() == 30 + 25
+    ppn.create_pwl_cost(net, 0, 'load', power_type='q', points=[[0, 1, 30], [1, 2, 50]])
+    net.res_load.loc[0, 'q_mvar'] = 2.0
+    assert eo.cost_vector(net).sum() == 30 + 25 + 30 + 50
+    ppn.create_pwl_cost(net, 0, 'gen', power_type='p', points=[[0, 1, 30], [1, 2, 50]])
+    net.res_gen.loc[0, 'p_mw'] = 0.5
+    assert eo.cost_vector(net).sum() == 30 + 25 + 30 + 50 + 15
+    ppn.create_pwl_cost(net, 0, 'gen', power_type='q', points=[[-1, 0, 40], [0, 1, 30], [1, 2, 50]])
+    net.res_gen.loc[0, 'q_mvar'] = -0.5
+    # zip(*points) truncates to the shortest list (defect D9): only 2 segments of the last row count
+    assert eo.cost_vector(net).sum() == -20 + 30 + 25 + 30 + 50 + 15
+    ppn.create_pwl_cost(net, 0, 'sgen', power_type='p', points=[[0, 1, 30], [1, 2, 50]])
+    net.res_sgen.loc[0, 'p_mw'] = -0.5
+    assert eo.cost_vector(net).sum() == -20 + 30 + 25 + 30 + 50 + 15
+
+
+def test_poly_costs_kat():
+    net = _fake_net()
+    ppn.create_poly_cost(net, 0, 'load', cp1_eur_per_mw=2)
+    net.res_load.loc[0, 'p_mw'] = 1.5
+    net.res_load.loc[0, 'q_mvar'] = 2.0
+    ppn.finalize(net)
+    assert eo.cost_vector(net).sum() == 3
+    ppn.create_poly_cost(net, 0, 'sgen', cp1_eur_per_mw=2, cq1_eur_per_mvar=2)
+    ppn.finalize(net)
+    net.res_sgen.loc[0, 'p_mw'] = 1.2
+    net.res_sgen.loc[0, 'q_mvar'] = 2.0
+    assert (eo.cost_vector(net) == np.array([3.0, 2.4, 0, 4.0])).all()
+    net.poly_cost.loc[0, 'cp0_eur'] = 1
+    net.poly_cost.loc[1, 'cq2_eur_per_mvar2'] = 2
+    assert (eo.cost_vector(net) == np.array([4.0, 2.4, 0, 12.0])).all()
+    ppn.create_pwl_cost(net, 0, 'load', power_type='p', points=[[0, 1, 30], [1, 2, 50]])
+    assert (eo.cost_vector(net)[-1] == 55) and len(eo.cost_vector(net)) == 5     # order: poly P, poly Q, pwl
+
+
+# ---- reward: reference tests/test_reward.py:8-78, host mirror and oracle ----------------
+def _rd(rf):
+    return dict(kind=type(rf).__name__.lower(), penalty_weight=rf.penalty_weight, clip_range=rf.clip_range,
+                scaling_params=rf.scaling_params, valid_reward=rf.valid_reward,
+                invalid_penalty=rf.invalid_penalty, invalid_objective_share=rf.invalid_objective_share)
+
+
+def test_reward_scaling_and_weights_kat():
+    rf = pr.Summation(clip_range=(0.0, 1.0))
+    assert rf.clip_reward(1.5) == 1.0 and rf.clip_reward(-1.5) == 0.0
+    rf = pr.Summation(penalty_weight=0.8)
+    assert rf.compute_total_reward(penalty=1.0, objective=0.0) == 0.8
+    assert np.isclose(rf.compute_total_reward(penalty=0.5, objective=1.0), 0.6)
+    sp = {'min_objective': 2.0, 'max_objective': 10.0, 'min_penalty': 0.0, 'max_penalty': 5.0}
+    rf = pr.Summation(reward_scaling='minmax11', scaling_params=dict(sp))
+    assert [rf.scale_objective(v) for v in (6.0, 2.0, 10.0)] == [0.0, -1.0, 1.0]
+    assert [rf.scale_penalty(v) for v in (2.5, 0.0, 5.0)] == [0.0, -1.0, 1.0]
+    rf = pr.Summation(reward_scaling='minmax01', scaling_params=dict(sp))
+    assert [rf.scale_objective(v) for v in (6.0, 2.0, 10.0)] == [0.5, 0.0, 1.0]
+    rf = pr.Summation(reward_scaling='normalization', scaling_params={
+        'std_objective': 2.0, 'mean_objective': 6.0, 'std_penalty': 1.0, 'mean_penalty': 2.5})
+    assert [rf.scale_objective(v) for v in (6.0, 2.0, 8.0)] == [0.0, -2.0, 1.0]
+    assert [rf.scale_penalty(v) for v in (2.5, 1.5, 4.5)] == [0.0, -1.0, 2.0]
+
+
+@pytest.mark.parametrize('rf,cases', [
+    (pr.Summation(penalty_weight=None), [(0.0, -1.0, True, -1.0), (1.0, -0.5, False, 0.5), (0.8, 0.0, True, 0.8)]),
+    (pr.Replacement(valid_reward=0.5, penalty_weight=None),
+     [(0.2, 0.0, True, 0.7), (0.2, -0.3, False, -0.3), (0.2, 0.0, False, 0.0)]),
+    (pr.Parameterized(valid_reward=0.7, invalid_penalty=0.3, invalid_objective_share=0.5, penalty_weight=None),
+     [(0.2, 0.0, True, 0.2 + 0.7), (0.2, -0.3, False, -0.3 - 0.3 + 0.2 / 2)]),
+])
+def test_reward_truth_tables(rf, cases):
+    for obj, pen, valid, want in cases:
+        assert np.isclose(rf(obj, pen, valid), want)
+        assert np.isclose(eo.reward_and_cost(_rd(rf), obj, pen, valid)[0], want)
+
+
+def test_unsupported_reference_defects_raise():
+    with pytest.raises(NotImplementedError):
+        pr.Replacement(valid_reward='worst')          # NameError in the reference (D2)
+    with pytest.raises(NotImplementedError):
+        pr.Parameterized(valid_reward='mean')         # UnboundLocalError in the reference (D3)
+
+
+# ---- data split / time observation: reference tests/test_simbench.py:79-119 -------------------
+def test_split_defaults_and_disjointness():
+    test, val, train = define_test_train_split()
+    assert len(test) == 6720 and len(val) == 6720 and len(train) == 21696
+    assert test[0] == 0 and val[0] == 672
+    assert not (set(test) & set(val)) and not (set(train) & set(test)) and not (set(train) & set(val))
+    # reference tests/test_simbench.py:79-119
+    test, val, train = define_test_train_split(test_share=0.1)
+    assert test[0] == 0 and val[0] == 672
+    assert 35136 / 10.5 <= len(test) <= 35136 / 9.5
+    test, val, train = define_test_train_split(test_share=0.1, random_validation_steps=True,
+                                               random_test_steps=True)
+    test2, val2, _ = define_test_train_split(test_share=0.1, random_validation_steps=True,
+                                             random_test_steps=True)
+    assert set(test) != set(test2) and set(val).isdisjoint(test) and set(val).isdisjoint(train)
+    test, val, train = define_test_train_split(test_share=0.5)
+    assert 35136 / 2.1 <= len(test) <= 35136 / 1.9
+    test, val, train = define_test_train_split(test_share=1.0, validation_share=0.0)
+    assert len(test) == 35136 and len(val) == 0 and len(train) == 0
+    assert len(define_test_train_split(validation_share=0.0)[1]) == 0
+    with pytest.raises(AssertionError):
+        define_test_train_split(test_share=0.6, validation_share=0.6)
+    a = define_test_train_split()
+    b = define_test_train_split()
+    assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_time_observation():
+    t = get_simbench_time_observation(0)
+    assert np.allclose(t, [0, 1, 0, 1, 0, 1])
+    t = get_simbench_time_observation(np.array([24, 96 * 7 // 4]))
+    assert t.shape == (2, 6) and np.isclose(t[0, 0], 1.0) and np.isclose(t[1, 2], 1.0)
+
+
+def test_build_simbench_net_columns():          # reference tests/test_simbench.py:15-76
+    net, prof = build_simbench_net('mv-small', gen_scaling=1.3, load_scaling=1.5, voltage_band=0.04,
+                                   max_loading=70)
+    assert (net.sgen.scaling == 1.3).all() and (net.load.scaling == 1.5).all()
+    assert (net.bus.max_vm_pu == 1.04).all() and (net.bus.min_vm_pu == 0.96).all()
+    assert (net.line.max_loading_percent == 70).all() and (net.trafo.max_loading_percent == 70).all()
+    assert np.allclose(net.load.max_max_p_mw, prof[('load', 'p_mw')].max() * 1.5)
+    assert np.allclose(net.sgen.min_min_p_mw, prof[('sgen', 'p_mw')].min() * 1.3)
+    assert (prof[('sgen', 'p_mw')].to_numpy() >= 0).all()
+    assert np.allclose(net.storage.min_min_p_mw, -net.storage.max_max_p_mw)
+    assert 'mean_q_mvar' in net.ext_grid and 'std_dev_p_mw' in net.load

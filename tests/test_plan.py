@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library loads, exports every symbol declared in
+include/opfx.h, and the host-side symbolic plan (ordering, block pattern,
+level schedule) is correct: walking the compiled programme in numpy
+(tests/plan_emulator.py) reproduces the SciPy oracle's Newton iterates."""
+import re
+import os
+
+import numpy as np
+import pytest
+
+from opfgym_amd import capi, grids
+from opfgym_amd.case import net_to_case
+from oracle import pf_oracle as po
+from plan_emulator import emulate_newton, load_plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'opfx.h')).read()
+    declared = set(re.findall(r'\b(opfx_[a-z_]+)\s*\(', header))
+    declared -= {'opfx_case', 'opfx_plan', 'opfx_ctx', 'opfx_env'}
+    assert declared == set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(built_lib, name), name
+    ver = [capi.C.c_int() for _ in range(3)]
+    built_lib.opfx_version(*[capi.C.byref(v) for v in ver])
+    assert (ver[0].value, ver[1].value) == (0, 1)
+
+
+def test_bad_arguments_return_status_not_exceptions(built_lib):
+    h = capi.C.c_void_p()
+    assert built_lib.opfx_plan_create(None, capi.C.byref(h)) == -1
+    assert b'null' in built_lib.opfx_last_error()
+    net = grids.two_bus()
+    case = net_to_case(net)
+    case.bus_type = np.array([1, 1], dtype=np.int32)           # no slack
+    with pytest.raises(capi.OpfxError, match='no REF'):
+        capi.Plan(case)
+
+
+@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', 'mv-small', '1-MV-urban--0-sw', 'hv-small'])
+def test_schedule_reproduces_oracle(built_lib, code):
+    net = grids.case9() if code == 'case9' else grids.get_grid(code)[0]
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    p, q, *_ = po.bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = po.solve_case(case, p, q)
+    v, conv, it, nrm = emulate_newton(plan, p, q)
+    assert conv and ref['converged'] and it == ref['iterations']
+    assert np.abs(v - ref['V']).max() < 1e-12
+
+
+def test_plan_structure_invariants(built_lib):
+    net, _ = grids.get_grid('1-HV-mixed--0-sw')
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    P = load_plan(plan)
+    info = plan.info
+    nb = info['nb']
+    # every non-REF bus is a pivot exactly once; REF buses never
+    piv = P['piv_bus']
+    assert sorted(piv.tolist()) == sorted(np.flatnonzero(case.bus_type != 3).tolist())
+    # pivots of one level are pairwise non-adjacent in the filled graph of that level
+    blocks = set(zip(P['blk_row'].tolist(), P['blk_col'].tolist()))
+    assert len(blocks) == info['n_blk']                      # no duplicate block
+    for lev in range(info['n_levels']):
+        ps = piv[P['lev_pptr'][lev]:P['lev_pptr'][lev + 1]]
+        for a in ps:
+            for u in range(P['piv_uptr'][np.flatnonzero(piv == a)[0]], P['piv_uptr'][np.flatnonzero(piv == a)[0] + 1]):
+                assert P['u_col'][u] not in ps
+    # symmetric pattern, diagonal present
+    for (i, j) in blocks:
+        assert (j, i) in blocks
+    assert all(P['diag_blk'][i] >= 0 for i in range(nb) if case.bus_type[i] != 3)
+    # Ybus of the plan equals the dense assembly of the case
+    g, b = plan.ybus()
+    y = np.zeros((nb, nb), complex)
+    for i in range(nb):
+        for e in range(P['y_ptr'][i], P['y_ptr'][i + 1]):
+            y[i, P['y_col'][e]] = g[e] + 1j * b[e]
+    assert np.abs(y - case.ybus_dense()).max() < 1e-12 * np.abs(y).max()   # summation order only
+    assert info['lds_doubles'] == 8 * nb + 4 * info['n_blk']
+
+
+def test_ctx_create_fails_loudly_without_gpu(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    plan = capi.Plan(net_to_case(grids.two_bus()))
+    with pytest.raises(capi.OpfxError):
+        capi.Context(plan, 0)
