@@ -99,6 +99,8 @@ typedef struct opfx_plan_info {
   int32_t n_uterms;          /* backward substitution terms                  */
   int32_t max_level_width;   /* widest level in work items                   */
   int32_t lds_doubles;       /* solver LDS footprint per instance (doubles)  */
+  /* register-resident lane programme (rounds of 64 work items); -1 = not built */
+  int32_t lp_rounds_a, lp_rounds_h, lp_rounds_b, lp_rounds_c;
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
@@ -116,8 +118,13 @@ enum {
   OPFX_ARR_FILL_BLK, OPFX_ARR_LEV_TPTR, OPFX_ARR_TGT_BLK, OPFX_ARR_TGT_SPTR,
   OPFX_ARR_SRC_IK, OPFX_ARR_SRC_KK, OPFX_ARR_SRC_KJ, OPFX_ARR_LEV_PPTR,
   OPFX_ARR_PIV_BUS, OPFX_ARR_PIV_UPTR, OPFX_ARR_U_BLK, OPFX_ARR_U_COL,
-  OPFX_ARR_BLK_ROW, OPFX_ARR_BLK_COL
+  OPFX_ARR_BLK_ROW, OPFX_ARR_BLK_COL,
+  OPFX_ARR_LP_A_ENT, OPFX_ARR_LP_A_DBLK, OPFX_ARR_LP_H_ENT, OPFX_ARR_LP_H_ROW,
+  OPFX_ARR_LP_B, OPFX_ARR_LP_C
 };
+/* double arrays of the lane programme: Ybus values per descriptor */
+enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };
+int64_t opfx_plan_get_darray(const opfx_plan* p, int which, double* out, int64_t cap);
 int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* out, int64_t cap);
 /* Ybus values in the plan's CSR order: out_g/out_b [nnz_y]. */
 int opfx_plan_get_ybus(const opfx_plan* p, double* out_g, double* out_b);

@@ -24,7 +24,9 @@ OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM = 0, 1, 2, 3, 4
 
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
-          'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL']
+          'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
+          'LP_B', 'LP_C']
+DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y']
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -44,7 +46,8 @@ class CaseStruct(C.Structure):
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'nb', 'nbr', 'nref', 'npv', 'npq', 'nnz_y', 'nnz_j', 'n_blk', 'n_fill', 'n_levels',
-        'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles')]
+        'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
+        'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -111,7 +114,7 @@ class ResetDesc(C.Structure):
 _lib = None
 
 EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_plan_get_array',
-           'opfx_plan_get_ybus', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
+           'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
            'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps']
 
@@ -139,6 +142,8 @@ def lib():
     L.opfx_plan_get_array.argtypes = [vp, C.c_int, _pi, C.c_int64]
     L.opfx_plan_get_array.restype = C.c_int64
     L.opfx_plan_get_ybus.argtypes = [vp, _pd, _pd]
+    L.opfx_plan_get_darray.argtypes = [vp, C.c_int, _pd, C.c_int64]
+    L.opfx_plan_get_darray.restype = C.c_int64
     L.opfx_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.opfx_ctx_destroy.argtypes = [vp]
     L.opfx_ctx_destroy.restype = None
@@ -208,6 +213,15 @@ class Plan:
             check(int(n), 'opfx_plan_get_array')
         out = np.zeros(int(n), dtype=np.int32)
         lib().opfx_plan_get_array(self.handle, which, out.ctypes.data_as(_pi), n)
+        return out
+
+    def darray(self, name) -> np.ndarray:
+        which = DARRAYS.index(name.upper())
+        n = lib().opfx_plan_get_darray(self.handle, which, None, 0)
+        if n < 0:
+            check(int(n), 'opfx_plan_get_darray')
+        out = np.zeros(int(n))
+        lib().opfx_plan_get_darray(self.handle, which, out.ctypes.data_as(_pd), n)
         return out
 
     def ybus(self):

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,10 @@ struct DevPlan {
   const int *lev_pptr, *piv_bus, *piv_uptr, *u_blk, *u_col;
   const int *br_f, *br_t, *br_pos, *ref_bus, *ref_ord;
   const double *vm_set, *va_set, *y_g, *y_b, *br_y, *br_kf, *br_kt;
+  // lane programme (plan.h)
+  int ra, rh, rb, rc;
+  int debug_skip;            // developer probe (OPFX_DEBUG_SKIP): bit mask of phases to skip
+  const unsigned *lp_bc, *lp_apk, *lp_hpk;
 };
 
 struct DevEnv {
@@ -130,6 +135,40 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
 }
+
+// ---- DPP wave reductions (no LDS traffic): quad xor-1, xor-2, half-row mirror, row
+// mirror give every lane its 16-lane row total; row_bcast:15 / row_bcast:31 fold the
+// rows so that lane 63 holds the wave total, which is then read back as a scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const long long ov = __double_as_longlong(old), sv = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp((int)ov, (int)sv, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(ov >> 32), (int)(sv >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double read_lane63(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1, 0xF>(0.0, v);        // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xF>(0.0, v);        // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xF>(0.0, v);       // row_half_mirror
+  v += dpp_f64<0x140, 0xF>(0.0, v);       // row_mirror
+  v += dpp_f64<0x142, 0xA>(0.0, v);       // row_bcast:15 -> rows 1,3
+  v += dpp_f64<0x143, 0xC>(0.0, v);       // row_bcast:31 -> rows 2,3
+  return read_lane63(v);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {   // NaN-propagating
+  v = nan_max(v, dpp_f64<0xB1, 0xF>(v, v));
+  v = nan_max(v, dpp_f64<0x4E, 0xF>(v, v));
+  v = nan_max(v, dpp_f64<0x141, 0xF>(v, v));
+  v = nan_max(v, dpp_f64<0x140, 0xF>(v, v));
+  v = nan_max(v, dpp_f64<0x142, 0xA>(v, v));
+  v = nan_max(v, dpp_f64<0x143, 0xC>(v, v));
+  return read_lane63(v);
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -151,9 +190,11 @@ __device__ __forceinline__ void st_blk(double* blk, int id, const Blk& b) {
 
 constexpr int BT_PQ = 1, BT_PV = 2, BT_REF = 3, BT_PQ_HI = 4, BT_PQ_LO = 5;
 
+// Per-instance LDS image.  The lane-programme kernel (V2) keeps the voltage in
+// rectangular form only (no |V|/angle arrays) to fit 6 instances per CU.
 struct Lds {
   double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp;
-  int* bt;
+  unsigned char* bt;
 };
 
 // Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
@@ -308,9 +349,273 @@ __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   return conv;
 }
 
+// ---------------------------------------------------------------------------
+// Newton-Raphson, second generation: driven by the plan's LANE PROGRAMME.
+// All structure a lane needs comes as fixed-size descriptors laid out
+// [round][lane] (coalesced, identical for every wave -> L1 resident) and is
+// prefetched one round ahead, so no phase chases index chains through memory;
+// update terms that share a target accumulate with LDS atomics (one wave, fixed
+// lane order -> deterministic); the unknown for |V| is the relative step
+// d|V|/|V|, which makes the Jacobian division-free.
+// ---------------------------------------------------------------------------
+// One wave per workgroup and the LDS executes a wave's operations in issue order, so
+// making one lane's LDS writes visible to the other lanes needs no hardware wait at all:
+// only the COMPILER must not move or cache LDS accesses across this point.  (A
+// __syncthreads()/fence here would also drain the prefetched global loads: s_waitcnt vmcnt(0).)
+__device__ __forceinline__ void wave_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+// 1/x by hardware estimate + two Newton steps (relative error ~1e-16; no denormal/overflow
+// special-casing: Jacobian pivots are O(1..1e4) in per-unit)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void lds_sub(double* p, double v) {
+  __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+struct ARound { uint4 ent; double2 y[4]; double2 yd; unsigned dw; };
+
+__device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane) {
+  const uint4* q = reinterpret_cast<const uint4*>(P.lp_apk) + (size_t)r * 7 * WAVE + lane;
+  ARound a;
+  a.ent = q[0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4 w = q[(1 + k) * WAVE];
+    a.y[k] = make_double2(__longlong_as_double(((long long)w.y << 32) | w.x),
+                          __longlong_as_double(((long long)w.w << 32) | w.z));
+  }
+  const uint4 w = q[5 * WAVE];
+  a.yd = make_double2(__longlong_as_double(((long long)w.y << 32) | w.x),
+                      __longlong_as_double(((long long)w.w << 32) | w.z));
+  a.dw = q[6 * WAVE].x;
+  return a;
+}
+
+__device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
+                        int* iters_out, double* nrm_out) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const int nb = P.nb;
+  int of = -1, ot = -1;
+  double oy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out_br >= 0) {
+    of = P.br_f[out_br]; ot = P.br_t[out_br];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
+  }
+  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc);
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
+  const int R = P.rb + P.rc;
+  const uint4 none4 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
+  auto ld_desc = [&](int r) { return r < R ? stream[(size_t)r * WAVE + lane] : none4; };
+  const bool skipB = P.debug_skip & 4, skipC = P.debug_skip & 8;
+
+  // one factor/forward item (r < rb) or one backward item (rb <= r < R)
+  auto do_round = [&](const uint4 d, int r) {
+    if (r >= R) return;
+    if (r < P.rb) {
+      const unsigned tb = d.x & 0xFFFF;
+      if (tb != NONE && !skipB) {
+        const Blk bi = ld_blk(L.blk, d.x >> 16);
+        const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
+        const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+        const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
+        const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
+        const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
+        const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
+        if (tb & 0x8000u) {
+          const int i = tb & 0x7FFF, k = d.y >> 16;
+          const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
+          lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
+          lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
+        } else {
+          const Blk bj = ld_blk(L.blk, d.y >> 16);
+          double* tp = L.blk + 4 * tb;
+          lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
+          lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
+          lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
+          lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
+        }
+      }
+    } else {
+      const unsigned k = d.x & 0xFFFF;
+      if (k != NONE && !skipC) {
+        double d1 = 0.0, d2 = 0.0;
+        if ((d.y & 0xFFFF) != NONE) {
+          const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
+          const unsigned j = d.y >> 16;
+          const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+          d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+        }
+        if ((d.z & 0xFFFF) != NONE) {
+          const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
+          const unsigned j = d.z >> 16;
+          const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+          d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+        }
+        const unsigned dblk = d.x >> 16;
+        if (dblk != NONE) {
+          const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
+          const Blk bk = ld_blk(L.blk, dblk);
+          const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+          L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
+          L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
+        } else {
+          lds_sub(&L.rhs[2 * k], d1);
+          lds_sub(&L.rhs[2 * k + 1], d2);
+        }
+      }
+    }
+    // Rounds of one level are independent; ordering is needed at level ends only, but on a
+    // single wave the fence is free (the LDS executes a wave's operations in order).
+    wave_fence();
+  };
+
+  int it = 0;
+  double nrm = 0.0;
+  bool conv = false;
+  ARound cur = load_around(P, 0, lane);
+  while (true) {
+    // descriptor stream of phases B and C: 4 rounds in flight while phase A runs
+    uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
+    // ---- phase A -----------------------------------------------------------------
+    if (!(P.debug_skip & 32)) for (int f = lane; f < P.nfill; f += WAVE) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    for (int h = 0; h < ((P.debug_skip & 1) ? 0 : P.rh); ++h) {          // overflow entries of rows longer than 4
+      const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
+      const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+      const unsigned row = __builtin_amdgcn_readfirstlane(he.y);
+      const int i = row & 0xFFFF;
+      const unsigned ent = he.x;
+      const unsigned j = ent & 0xFFFF;
+      double cr = 0.0, ci = 0.0;
+      if (j != NONE) {
+        double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
+        double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
+        if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+        if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+        const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
+        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+        cr = vri * tr + vii * ti; ci = vii * tr - vri * ti;
+        const unsigned bid = ent >> 16;
+        const int t = L.bt[i];
+        if (bid != NONE && t != BT_REF) {
+          Blk jb{ci, cr, -cr, ci};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+          st_blk(L.blk, bid, jb);
+        }
+      }
+      cr = wave_sum_dpp(cr); ci = wave_sum_dpp(ci);
+      if (lane == 0) {
+        if (row >> 16) { L.rhs[2 * i] += cr; L.rhs[2 * i + 1] += ci; }
+        else { L.rhs[2 * i] = cr; L.rhs[2 * i + 1] = ci; }
+      }
+    }
+    if (P.rh) wave_fence();
+    double my = 0.0;
+    for (int r = 0; r < ((P.debug_skip & 2) ? 0 : P.ra); ++r) {
+      const ARound a = cur;
+      cur = load_around(P, r + 1 < P.ra ? r + 1 : 0, lane);     // next round (or round 0 of the next iteration)
+      const int i = lane + WAVE * r;
+      if (i < nb) {
+        const int t = L.bt[i];
+        const double vri = L.vr[i], vii = L.vi[i];
+        double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
+        if (a.dw >> 16) { sr = L.rhs[2 * i]; si = L.rhs[2 * i + 1]; }
+        const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned j = ent[k] & 0xFFFF;
+          if (j != NONE) {
+            double g = a.y[k].x, b = a.y[k].y;
+            if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+            if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+            const double vrj = L.vr[j], vij = L.vi[j];
+            const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+            const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+            sr += cr; si += ci;
+            const unsigned bid = ent[k] >> 16;
+            if (bid != NONE && t != BT_REF) {
+              // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
+              Blk jb{ci, cr, -cr, ci};
+              if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+              st_blk(L.blk, bid, jb);
+            }
+          }
+        }
+        if (t != BT_REF) {
+          double g = a.yd.x, b = a.yd.y;
+          if (i == of) { g -= oy[0]; b -= oy[1]; }
+          if (i == ot) { g -= oy[6]; b -= oy[7]; }
+          const double v2 = vri * vri + vii * vii;
+          const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
+          const double pc = sr + yr, qc = si + yi;
+          const double fp = pc - L.psp[i];
+          const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
+          L.rhs[2 * i] = -fp;
+          L.rhs[2 * i + 1] = -fq;
+          my = nan_max(my, nan_max(fabs(fp), fabs(fq)));
+          // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
+          Blk jb{-si, yr + pc, sr, yi + qc};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          st_blk(L.blk, a.dw & 0xFFFF, jb);
+        }
+      }
+    }
+    nrm = wave_max_dpp(my);
+    if (!(nrm == nrm)) { conv = false; break; }
+    if (nrm < o.tol) { conv = true; break; }
+    if (it >= o.max_iter) { conv = false; break; }
+    ++it;
+    wave_fence();
+    // ---- phases B and C: block LU + forward substitution, then back substitution ----------
+    for (int r = 0; r < R; r += 4) {
+      do_round(q0, r);     q0 = ld_desc(r + 4);
+      do_round(q1, r + 1); q1 = ld_desc(r + 5);
+      do_round(q2, r + 2); q2 = ld_desc(r + 6);
+      do_round(q3, r + 3); q3 = ld_desc(r + 7);
+    }
+    // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
+    if (!(P.debug_skip & 16)) {
+      double big = 0.0;
+      for (int i = lane; i < nb; i += WAVE)
+        if (L.bt[i] != BT_REF) big = fmax(big, fabs(L.rhs[2 * i]));      // (rhs of REF rows is never written)
+      const bool small = !(wave_max_dpp(big) > 0.25);          // wave-uniform (false for NaN too)
+      for (int i = lane; i < nb; i += WAVE) {
+        if (L.bt[i] == BT_REF) continue;
+        const double dth = L.rhs[2 * i], sc = 1.0 + L.rhs[2 * i + 1];
+        double sn, cs;
+        if (small) {
+          // |dth| <= 0.25: Taylor series to x^15 / x^14, truncation error < 1e-21
+          const double z = dth * dth;
+          sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
+               + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+          cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
+               + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
+        } else {
+          sincos(dth, &sn, &cs);
+        }
+        const double vr = L.vr[i], vi = L.vi[i];
+        L.vr[i] = (vr * cs - vi * sn) * sc;
+        L.vi[i] = (vr * sn + vi * cs) * sc;
+      }
+    }
+    wave_fence();
+  }
+  *iters_out = it;
+  *nrm_out = nrm;
+  return conv;
+}
+
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
 // A bus that an earlier solve of this instance pinned at a reactive limit gets
 // its generator share removed from q_sp again (L.bt must hold valid codes).
+template <bool V2>
 __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
                              const double* qg_max) {
   for (int i = lane; i < P.nb; i += WAVE) {
@@ -320,19 +625,21 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
     const double vm = P.vm_set[i], va = P.va_set[i];
     double s, c;
     sincos(va, &s, &c);
-    L.vm[i] = vm; L.va[i] = va; L.vr[i] = vm * c; L.vi[i] = vm * s;
-    L.bt[i] = P.bus_type[i];
+    if (!V2) { L.vm[i] = vm; L.va[i] = va; }
+    L.vr[i] = vm * c; L.vi[i] = vm * s;
+    L.bt[i] = (unsigned char)P.bus_type[i];
   }
 }
 
 // Outer loop: NR + enforce_q_lims PV->PQ switching.
+template <bool V2>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm) {
   int total = 0;
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
-    conv = newton(P, L, o, lane, out_br, &it, nrm);
+    conv = V2 ? newton2(P, L, o, lane, out_br, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
@@ -379,7 +686,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   double* r_qg = r_qe + nref;
   const double base = physical ? P.base_mva : 1.0;
   for (int i = lane; i < nb; i += WAVE) {
-    r_vm[i] = L.vm[i];
+    r_vm[i] = sqrt(L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]);
     const double ang = atan2(L.vi[i], L.vr[i]);
     r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
     const int t = L.bt[i];
@@ -429,35 +736,42 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   }
 }
 
-__device__ __forceinline__ Lds carve(const DevPlan& P, int na, double* base) {
+template <bool V2>
+__device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base) {
   Lds L;
   const int nb = P.nb;
-  L.vr = base; L.vi = L.vr + nb; L.vm = L.vi + nb; L.va = L.vm + nb;
-  L.psp = L.va + nb; L.qsp = L.psp + nb; L.rhs = L.qsp + nb;
-  L.blk = L.rhs + 2 * nb;                      // 8*nb doubles so far: 16-B aligned
-  L.sp = L.blk + 4 * P.nblk;
-  L.bt = reinterpret_cast<int*>(L.sp + na);
+  const int nbe = (nb + 1) & ~1;               // even count keeps every array 16-byte aligned
+  L.vr = base; L.vi = L.vr + nbe;
+  double* nxt = L.vi + nbe;
+  if (V2) { L.vm = nullptr; L.va = nullptr; }
+  else { L.vm = nxt; L.va = L.vm + nbe; nxt = L.va + nbe; }
+  L.psp = nxt; L.qsp = L.psp + nbe; L.rhs = L.qsp + nbe;
+  L.blk = L.rhs + 2 * nbe;
+  const int nblk_d = 4 * P.nblk > nres ? 4 * P.nblk : nres;
+  L.sp = L.blk + ((nblk_d + 1) & ~1);
+  L.bt = reinterpret_cast<unsigned char*>(L.sp + na);
   return L;
 }
 
 // ---------------------------------------------------------------------------
 // pure power flow kernel (opfx_solve)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_solve(DevPlan P, SolveIO io, Opts o, long long B) {
+template <bool V2>
+__global__ __launch_bounds__(WAVE, 2) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
-  const Lds L = carve(P, 0, smem);
+  const Lds L = carve<V2>(P, 0, 3 * P.nb + P.nbr + 2 * P.nref, smem);
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     for (int i = lane; i < P.nb; i += WAVE) {
       L.psp[i] = io.p_inj[b * P.nb + i];
       L.qsp[i] = io.q_inj[b * P.nb + i];
       L.bt[i] = BT_PQ;
     }
-    init_voltage(P, L, lane, io.qg_min, io.qg_max);
+    init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max);
     wave_sync();
     const int out_br = io.outage ? io.outage[b] : -1;
     int iters; double nrm;
-    const bool conv = solve_instance(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
+    const bool conv = solve_instance<V2>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
     wave_sync();
     double* R = L.blk;
     compute_results(P, L, lane, out_br, io.qg_min, io.qg_max, R, false);
@@ -489,10 +803,11 @@ __device__ __forceinline__ double xval(const double* xr, const double* sp, int s
 
 __device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
 
-__global__ __launch_bounds__(WAVE) void k_step(DevPlan P, DevEnv E, StepIO io, Opts o, long long B) {
+template <bool V2>
+__global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv E, StepIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
-  const Lds L = carve(P, E.na, smem);
+  const Lds L = carve<V2>(P, E.na, E.nres, smem);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
@@ -555,10 +870,10 @@ __global__ __launch_bounds__(WAVE) void k_step(DevPlan P, DevEnv E, StepIO io, O
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
-      init_voltage(P, L, lane, E.qg_min, E.qg_max);
+      init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max);
       wave_sync();
       int iters; double nrm;
-      const bool conv = solve_instance(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
+      const bool conv = solve_instance<V2>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
       wave_sync();
       if (c == 0) { conv0 = conv; iters0 = iters; nrm0 = nrm; if (!conv) break; }
       if (!conv) {
@@ -811,12 +1126,15 @@ struct opfx_ctx {
   int solve_per_cu = 0;
   opfx_plan plan;     // host copy
   DevPlan dp{};
+  const DevPlan* d_dp = nullptr;   // device copy of dp (kernels take it by pointer)
+  bool v2 = true;
   DevArena arena;
 };
 
 struct opfx_env {
   opfx_ctx* ctx = nullptr;
   DevEnv de{};
+  const DevEnv* d_de = nullptr;
   DevReset dr{};
   bool has_reset = false;
   DevArena arena;
@@ -826,10 +1144,11 @@ struct opfx_env {
 
 namespace {
 
-size_t solver_lds_bytes(const opfx_plan& p, int na, int nres) {
-  size_t blk = std::max<size_t>((size_t)4 * p.n_blk, (size_t)nres);
-  size_t d = (size_t)8 * p.nb + blk + (size_t)na;
-  size_t bytes = d * sizeof(double) + (size_t)p.nb * sizeof(int);
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2) {
+  const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
+  size_t blk = (std::max<size_t>((size_t)4 * p.n_blk, (size_t)nres) + 1) & ~(size_t)1;
+  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na;
+  size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
 }
 
@@ -848,6 +1167,8 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
   if (per_cu < 1) per_cu = 1;
+  if (const char* ov = getenv("OPFX_WAVES_PER_CU")) per_cu = atoi(ov);     // developer override
+  if (getenv("OPFX_VERBOSE")) fprintf(stderr, "[opfx] lds=%zu B/instance, resident waves per CU=%d, CUs=%d\n", lds, per_cu, n_cu);
   *per_cu_cache = per_cu;
   long long g = (long long)per_cu * n_cu;
   *grid = (int)std::max<long long>(1, std::min<long long>(g, B));
@@ -884,7 +1205,12 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(ref_bus, ref_bus);
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
+  d.ra = p->ra; d.rh = p->rh; d.rb = p->rb; d.rc = p->rc;
+  d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
+  c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
+  PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk);
 #undef PUT
+  if (rc == OPFX_OK) rc = A.put(&c->dp, 1, &c->d_dp);
   if (rc != OPFX_OK) { delete c; return rc; }
   *out = c;
   return OPFX_OK;
@@ -903,12 +1229,13 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
-  size_t lds = solver_lds_bytes(ctx->plan, 0, nres);
+  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2);
   int grid = 0;
-  int rc = launch_geometry(k_solve, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu);
+  auto kern = ctx->v2 ? k_solve<true> : k_solve<false>;
+  int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu);
   if (rc != OPFX_OK) return rc;
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations};
-  hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
@@ -1015,8 +1342,9 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
 #undef PUTN
   for (size_t i = 0; rc == OPFX_OK && i < ncel; ++i)
     if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }
+  if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2);
   *out = e;
   return OPFX_OK;
 }
@@ -1028,7 +1356,8 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1};
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  int rc = launch_geometry(k_step, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu);
+  auto kern = env->ctx->v2 ? k_step<true> : k_step<false>;
+  int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu);
   if (rc != OPFX_OK) return rc;
   StepIO s{};
   s.x = io->x; s.action = io->action; s.initial_obj = io->initial_obj;
@@ -1038,7 +1367,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.mean_correction = io->mean_correction; s.max_mismatch = io->max_mismatch;
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
-  hipLaunchKernelGGL(k_step, dim3(grid), dim3(WAVE), env->lds_bytes, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), env->lds_bytes, static_cast<hipStream_t>(stream),
                      env->ctx->dp, env->de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;

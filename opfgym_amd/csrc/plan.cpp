@@ -50,6 +50,169 @@ struct BlockMap {
   }
 };
 
+// Lane programmes: the same schedule, re-expressed as fixed-size per-lane work
+// descriptors grouped in rounds of 64 so that the kernel keeps them in registers.
+//  A  bus rows in ELL form (KA off-diagonal entries per row; longer rows spill
+//     their remaining entries into "heavy" rounds reduced across the wave);
+//  B  per elimination level: one item per update term
+//     A_ij -= A_ik Kinv A_kj / y_i -= A_ik Kinv y_k (accumulated with LDS atomics);
+//  C  per level in reverse: extra U-term items (accumulated with LDS atomics), then
+//     solve items with up to two U-terms inline.
+void build_lane_programs(opfx_plan* p) {
+  constexpr int KA = opfx_plan::KA;
+  constexpr uint32_t NONE = 0xFFFFu;
+  const int nb = p->nb;
+  if (nb > 0x7FFF || p->n_blk > 0x7FFF) { p->ra = p->rb = p->rc = -1; return; }   // 16-bit descriptors
+  // ---- A ---------------------------------------------------------------------
+  p->ra = (nb + 63) / 64;
+  p->lp_a_ent.assign((size_t)p->ra * KA * 64, NONE | (NONE << 16));
+  p->lp_a_y.assign((size_t)p->ra * KA * 64 * 2, 0.0);
+  p->lp_a_ydiag.assign((size_t)p->ra * 64 * 2, 0.0);
+  p->lp_a_dblk.assign((size_t)p->ra * 64, NONE);
+  std::vector<std::array<double, 2>> hy;
+  for (int i = 0; i < nb; ++i) {
+    const int r = i / 64, lane = i % 64;
+    int k = 0;
+    std::vector<int> overflow;
+    for (int e = p->y_ptr[i]; e < p->y_ptr[i + 1]; ++e) {
+      const int j = p->y_col[e];
+      if (j == i) {
+        p->lp_a_ydiag[((size_t)r * 64 + lane) * 2] = p->y_g[e];
+        p->lp_a_ydiag[((size_t)r * 64 + lane) * 2 + 1] = p->y_b[e];
+        continue;
+      }
+      if (k < KA) {
+        const size_t o = ((size_t)r * KA + k) * 64 + lane;
+        const uint32_t blk = p->y_blk[e] >= 0 ? (uint32_t)p->y_blk[e] : NONE;
+        p->lp_a_ent[o] = (uint32_t)j | (blk << 16);
+        p->lp_a_y[o * 2] = p->y_g[e];
+        p->lp_a_y[o * 2 + 1] = p->y_b[e];
+        ++k;
+      } else {
+        overflow.push_back(e);
+      }
+    }
+    uint32_t d = p->diag_blk[i] >= 0 ? (uint32_t)p->diag_blk[i] : NONE;
+    if (!overflow.empty()) d |= 1u << 16;
+    p->lp_a_dblk[(size_t)r * 64 + lane] = d;
+    for (size_t o = 0; o < overflow.size(); o += 64) {            // one heavy round per 64 overflow entries
+      p->lp_h_row.push_back((uint32_t)i | (o == 0 ? 0u : 1u << 16));   // bit16: continue accumulating
+      for (int lane2 = 0; lane2 < 64; ++lane2) {
+        if (o + lane2 < overflow.size()) {
+          const int e = overflow[o + lane2];
+          const uint32_t blk = p->y_blk[e] >= 0 ? (uint32_t)p->y_blk[e] : NONE;
+          p->lp_h_ent.push_back((uint32_t)p->y_col[e] | (blk << 16));
+          p->lp_h_y.push_back(p->y_g[e]);
+          p->lp_h_y.push_back(p->y_b[e]);
+        } else {
+          p->lp_h_ent.push_back(NONE | (NONE << 16));
+          p->lp_h_y.push_back(0.0);
+          p->lp_h_y.push_back(0.0);
+        }
+      }
+    }
+  }
+  p->rh = (int32_t)p->lp_h_row.size();
+  // ---- B ---------------------------------------------------------------------
+  // per level: every (target, source) update term is one item; terms that share a
+  // target may sit in the same round (the kernel accumulates with LDS atomics);
+  // block targets first, rhs targets last, so that a round is mostly homogeneous.
+  const int nlev = p->n_levels();
+  std::vector<std::array<uint32_t, 2>> items;
+  auto flush = [&]() {
+    for (size_t o = 0; o < items.size(); o += 64) {
+      for (int lane = 0; lane < 64; ++lane) {
+        if (o + lane < items.size()) { p->lp_b.push_back(items[o + lane][0]); p->lp_b.push_back(items[o + lane][1]); }
+        else { p->lp_b.push_back(NONE | (NONE << 16)); p->lp_b.push_back(0); }
+      }
+    }
+    items.clear();
+  };
+  for (int lev = 0; lev < nlev; ++lev) {
+    const int t0 = p->lev_tptr[lev], t1 = p->lev_tptr[lev + 1];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int t = t0; t < t1; ++t) {
+        const int tb = p->tgt_blk[t];
+        if ((tb >= 0) != (pass == 0)) continue;
+        const uint32_t tgt = tb >= 0 ? (uint32_t)tb : (0x8000u | (uint32_t)(-1 - tb));
+        for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s)
+          items.push_back({tgt | ((uint32_t)p->src_ik[s] << 16),
+                           (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16)});
+      }
+    flush();
+  }
+  p->rb = (int32_t)(p->lp_b.size() / 128);
+  // ---- C ---------------------------------------------------------------------
+  auto flush_c = [&](std::vector<std::array<uint32_t, 3>>& its) {
+    for (size_t o = 0; o < its.size(); o += 64) {
+      for (int lane = 0; lane < 64; ++lane) {
+        if (o + lane < its.size()) for (int w = 0; w < 3; ++w) p->lp_c.push_back(its[o + lane][w]);
+        else { p->lp_c.push_back(NONE | (NONE << 16)); p->lp_c.push_back(NONE | (NONE << 16)); p->lp_c.push_back(NONE | (NONE << 16)); }
+      }
+    }
+    its.clear();
+  };
+  std::vector<std::array<uint32_t, 3>> citems;
+  for (int lev = nlev - 1; lev >= 0; --lev) {
+    const int p0 = p->lev_pptr[lev], p1 = p->lev_pptr[lev + 1];
+    // U-terms beyond the two carried by the solve item: packed two per item, any number of
+    // items per pivot in a round (the kernel accumulates into y_k with LDS atomics)
+    for (int q = p0; q < p1; ++q)
+      for (int u = p->piv_uptr[q] + 2; u < p->piv_uptr[q + 1]; u += 2) {
+        std::array<uint32_t, 3> it{(uint32_t)p->piv_bus[q] | (NONE << 16),
+                                   (uint32_t)p->u_blk[u] | ((uint32_t)p->u_col[u] << 16), NONE | (NONE << 16)};
+        if (u + 1 < p->piv_uptr[q + 1]) it[2] = (uint32_t)p->u_blk[u + 1] | ((uint32_t)p->u_col[u + 1] << 16);
+        citems.push_back(it);
+      }
+    flush_c(citems);
+    for (int q = p0; q < p1; ++q) {
+      const int u0 = p->piv_uptr[q], u1 = p->piv_uptr[q + 1];
+      std::array<uint32_t, 3> it{(uint32_t)p->piv_bus[q] | ((uint32_t)p->diag_blk[p->piv_bus[q]] << 16),
+                                 NONE | (NONE << 16), NONE | (NONE << 16)};
+      if (u0 < u1) it[1] = (uint32_t)p->u_blk[u0] | ((uint32_t)p->u_col[u0] << 16);
+      if (u0 + 1 < u1) it[2] = (uint32_t)p->u_blk[u0 + 1] | ((uint32_t)p->u_col[u0 + 1] << 16);
+      citems.push_back(it);
+    }
+    flush_c(citems);
+  }
+  p->rc = (int32_t)(p->lp_c.size() / 192);
+  // ---- packed device forms ---------------------------------------------------------
+  auto put_d = [](std::vector<uint32_t>& v, size_t at, double x) { std::memcpy(&v[at], &x, 8); };
+  p->lp_bc.assign((size_t)(p->rb + p->rc) * 64 * 4, 0u);
+  for (int r = 0; r < p->rb; ++r)
+    for (int l = 0; l < 64; ++l) {
+      p->lp_bc[((size_t)r * 64 + l) * 4 + 0] = p->lp_b[((size_t)r * 64 + l) * 2];
+      p->lp_bc[((size_t)r * 64 + l) * 4 + 1] = p->lp_b[((size_t)r * 64 + l) * 2 + 1];
+    }
+  for (int r = 0; r < p->rc; ++r)
+    for (int l = 0; l < 64; ++l)
+      for (int w = 0; w < 3; ++w)
+        p->lp_bc[((size_t)(p->rb + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 3 + w];
+  p->lp_apk.assign((size_t)p->ra * 7 * 64 * 4, 0u);
+  for (int r = 0; r < p->ra; ++r)
+    for (int l = 0; l < 64; ++l) {
+      auto at = [&](int v) { return (((size_t)r * 7 + v) * 64 + l) * 4; };
+      for (int k = 0; k < KA; ++k) {
+        const size_t o = ((size_t)r * KA + k) * 64 + l;
+        p->lp_apk[at(0) + k] = p->lp_a_ent[o];
+        put_d(p->lp_apk, at(1 + k), p->lp_a_y[o * 2]);
+        put_d(p->lp_apk, at(1 + k) + 2, p->lp_a_y[o * 2 + 1]);
+      }
+      put_d(p->lp_apk, at(5), p->lp_a_ydiag[((size_t)r * 64 + l) * 2]);
+      put_d(p->lp_apk, at(5) + 2, p->lp_a_ydiag[((size_t)r * 64 + l) * 2 + 1]);
+      p->lp_apk[at(6)] = p->lp_a_dblk[(size_t)r * 64 + l];
+    }
+  p->lp_hpk.assign((size_t)p->rh * 2 * 64 * 4, 0u);
+  for (int h = 0; h < p->rh; ++h)
+    for (int l = 0; l < 64; ++l) {
+      const size_t a0 = (((size_t)h * 2 + 0) * 64 + l) * 4, a1 = (((size_t)h * 2 + 1) * 64 + l) * 4;
+      put_d(p->lp_hpk, a0, p->lp_h_y[((size_t)h * 64 + l) * 2]);
+      put_d(p->lp_hpk, a0 + 2, p->lp_h_y[((size_t)h * 64 + l) * 2 + 1]);
+      p->lp_hpk[a1] = p->lp_h_ent[(size_t)h * 64 + l];
+      p->lp_hpk[a1 + 1] = p->lp_h_row[h];
+    }
+}
+
 }  // namespace
 
 extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
@@ -216,6 +379,7 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
     }
   }
   p->n_blk = (int32_t)p->blk_row.size();
+  build_lane_programs(p);
   *out = p;
   return OPFX_OK;
 }
@@ -235,13 +399,21 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->n_uterms = (int32_t)p->u_blk.size();
   o->max_level_width = p->max_level_width;
   o->lds_doubles = 8 * p->nb + 4 * p->n_blk;
+  o->lp_rounds_a = p->ra; o->lp_rounds_h = p->rh; o->lp_rounds_b = p->rb; o->lp_rounds_c = p->rc;
   return OPFX_OK;
 }
 
 extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* out, int64_t cap) {
   if (!p) { opfx_set_error("opfx_plan_get_array: null plan"); return OPFX_ERR_INVALID; }
   const std::vector<int32_t>* v = nullptr;
+  auto u32 = [](const std::vector<uint32_t>& x) { return reinterpret_cast<const std::vector<int32_t>*>(&x); };
   switch (which) {
+    case OPFX_ARR_LP_A_ENT: v = u32(p->lp_a_ent); break;
+    case OPFX_ARR_LP_A_DBLK: v = u32(p->lp_a_dblk); break;
+    case OPFX_ARR_LP_H_ENT: v = u32(p->lp_h_ent); break;
+    case OPFX_ARR_LP_H_ROW: v = u32(p->lp_h_row); break;
+    case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
+    case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
     case OPFX_ARR_Y_PTR: v = &p->y_ptr; break;
     case OPFX_ARR_Y_COL: v = &p->y_col; break;
     case OPFX_ARR_Y_BLK: v = &p->y_blk; break;
@@ -271,4 +443,17 @@ extern "C" int opfx_plan_get_ybus(const opfx_plan* p, double* out_g, double* out
   if (out_g) std::memcpy(out_g, p->y_g.data(), sizeof(double) * p->y_g.size());
   if (out_b) std::memcpy(out_b, p->y_b.data(), sizeof(double) * p->y_b.size());
   return OPFX_OK;
+}
+
+extern "C" int64_t opfx_plan_get_darray(const opfx_plan* p, int which, double* out, int64_t cap) {
+  if (!p) { opfx_set_error("opfx_plan_get_darray: null plan"); return OPFX_ERR_INVALID; }
+  const std::vector<double>* v = nullptr;
+  switch (which) {
+    case OPFX_DARR_LP_A_Y: v = &p->lp_a_y; break;
+    case OPFX_DARR_LP_A_YDIAG: v = &p->lp_a_ydiag; break;
+    case OPFX_DARR_LP_H_Y: v = &p->lp_h_y; break;
+    default: opfx_set_error("opfx_plan_get_darray: unknown array id"); return OPFX_ERR_INVALID;
+  }
+  if (out) std::memcpy(out, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
 }

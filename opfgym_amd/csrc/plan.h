@@ -34,6 +34,24 @@ struct opfx_plan {
   // backward substitution schedule (same level partition, walked in reverse)
   std::vector<int32_t> lev_pptr;           // [nlev+1] -> pivots
   std::vector<int32_t> piv_bus, piv_uptr, u_blk, u_col;
+  // ---- lane programmes for the register-resident kernel (k_*2) ------------------
+  // Every array is [round][lane] (64 lanes per round) so that a wave loads its
+  // descriptors with one coalesced access per round, once per kernel.
+  static constexpr int KA = 4;             // ELL width: off-diagonal Ybus entries per bus row
+  int32_t ra = 0, rh = 0, rb = 0, rc = 0;  // rounds: bus rows, heavy-row overflow, factor/forward, backward
+  std::vector<uint32_t> lp_a_ent;          // [ra][KA][64]  j | blk<<16   (0xFFFF = none)
+  std::vector<double> lp_a_y;              // [ra][KA][64][2] g,b
+  std::vector<double> lp_a_ydiag;          // [ra][64][2]
+  std::vector<uint32_t> lp_a_dblk;         // [ra][64]  diag blk | heavy flag<<16
+  std::vector<uint32_t> lp_h_ent;          // [rh][64]  j | blk<<16 ; row bus in lp_h_row
+  std::vector<uint32_t> lp_h_row;          // [rh]      bus whose overflow entries this round holds
+  std::vector<double> lp_h_y;              // [rh][64][2]
+  std::vector<uint32_t> lp_b;              // [rb][64][2]  tb|ik<<16 , kk|kj<<16
+  std::vector<uint32_t> lp_c;              // [rc][64][3]  k|dblk<<16 , blk1|j1<<16 , blk2|j2<<16
+  // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
+  std::vector<uint32_t> lp_bc;             // [rb+rc][64][4]  B: w0,w1,0,0   C: w0,w1,w2,0
+  std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
+  std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | ent,row,0,0
   int32_t nnz_j = 0;
   int32_t max_level_width = 0;
   int32_t n_levels() const { return (int32_t)lev_tptr.size() - 1; }

@@ -1,0 +1,28 @@
+"""Developer probe: kernel time vs forced Newton iteration count (tol=0 -> never converges)."""
+import sys, os
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+from opfgym_amd import capi, grids
+from opfgym_amd.case import net_to_case
+from helpers import random_injections
+code = sys.argv[1] if len(sys.argv) > 1 else '1-MV-urban--0-sw'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+net, _ = grids.get_grid(code)
+case = net_to_case(net)
+plan = capi.Plan(case)
+ctx = capi.Context(plan, 0)
+p, q = random_injections(net, case, B, 1)
+dev = torch.device('cuda:0')
+pt, qt = torch.tensor(p, device=dev), torch.tensor(q, device=dev)
+for mi in (0, 1, 2, 4, 8):
+    for _ in range(2):
+        capi.solve(ctx, pt, qt, tol=0.0, max_iter=mi)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        capi.solve(ctx, pt, qt, tol=0.0, max_iter=mi)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'max_iter={mi}: {e0.elapsed_time(e1)/10:.3f} ms')
