@@ -57,7 +57,7 @@ struct DevPlan {
   const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
   const int *lev_pptr, *piv_bus, *piv_uptr, *u_blk, *u_col;
   const int *br_f, *br_t, *br_pos, *ref_bus, *ref_ord;
-  const double *vm_set, *va_set, *y_g, *y_b, *br_y, *br_kf, *br_kt;
+  const double *vm_set, *va_set, *vr0, *vi0, *y_g, *y_b, *br_y, *br_kf, *br_kt;
   // lane programme (plan.h)
   int ra, rh, rb, rc;
   int debug_skip;            // developer probe (OPFX_DEBUG_SKIP): bit mask of phases to skip
@@ -67,13 +67,14 @@ struct DevPlan {
 struct DevEnv {
   int nx, na, npoly, npwl, nseg, nprice, nc, nobs, nres, ncost;
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
-  int n_cont;
+  int n_cont, n_inj, n_oseg, need_angle;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
   double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
   double invalid_objective_share, diff_step, clipped_action_penalty;
   double not_converged_penalty;
-  const int *pinj_ptr, *pinj_slot, *pinj_act, *qinj_ptr, *qinj_slot, *qinj_act;
-  const double *pinj_coef, *qinj_coef, *qg_min, *qg_max;
+  const int *inj_slot, *inj_bus, *inj_act;         // flat list: bus | isQ<<16, sorted by slot (coalesced x reads)
+  const double *inj_coef, *qg_min, *qg_max;
+  const int *oseg_kind, *oseg_src, *oseg_dst, *oseg_n;   // observation = list of contiguous copies
   const int *act_slot, *act_lo_slot, *act_hi_slot, *clamp_lo_slot, *clamp_hi_slot;
   const double *act_scaling, *act_lo_const, *act_hi_const, *clamp_lo_const, *clamp_hi_const;
   const int *cost_kind, *cost_pidx, *cost_qidx, *cost_pact, *cost_qact, *pwl_is_q;
@@ -622,11 +623,8 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
     const int t = L.bt[i];
     if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];
     if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
-    const double vm = P.vm_set[i], va = P.va_set[i];
-    double s, c;
-    sincos(va, &s, &c);
-    if (!V2) { L.vm[i] = vm; L.va[i] = va; }
-    L.vr[i] = vm * c; L.vi[i] = vm * s;
+    if (!V2) { L.vm[i] = P.vm_set[i]; L.va[i] = P.va_set[i]; }
+    L.vr[i] = P.vr0[i]; L.vi[i] = P.vi0[i];
     L.bt[i] = (unsigned char)P.bus_type[i];
   }
 }
@@ -676,7 +674,8 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
 // after convergence: result bank in LDS region R (reuses the LU block storage)
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br,
-                                const double* qg_min, const double* qg_max, double* R, bool physical) {
+                                const double* qg_min, const double* qg_max, double* R, bool physical,
+                                bool want_angle) {
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
   double* r_va = R + nb;
@@ -687,8 +686,10 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   const double base = physical ? P.base_mva : 1.0;
   for (int i = lane; i < nb; i += WAVE) {
     r_vm[i] = sqrt(L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]);
-    const double ang = atan2(L.vi[i], L.vr[i]);
-    r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+    if (want_angle) {
+      const double ang = atan2(L.vi[i], L.vr[i]);
+      r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+    }
     const int t = L.bt[i];
     double qgen = 0.0;
     if (t == BT_REF || t == BT_PV) {
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_solve(const DevPlan P, SolveIO io, 
     const bool conv = solve_instance<V2>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
     wave_sync();
     double* R = L.blk;
-    compute_results(P, L, lane, out_br, io.qg_min, io.qg_max, R, false);
+    compute_results(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
     wave_sync();
     const int nb = P.nb, nbr = P.nbr, nref = P.nref;
     if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
@@ -839,26 +840,26 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       }
       L.sp[k] = xv;
     }
-    corr = E.na > 0 ? wave_sum(corr) / E.na : 0.0;                                   // :488-489
+    corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
     wave_sync();
     if (io.mode == 2) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
-      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE)
-        io.obs[b * E.nobs + k] = E.obs_kind[k] == OPFX_SRC_X ? xval(xr, L.sp, E.obs_idx[k], E.obs_act[k]) : NaN;
+      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+        const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+        for (int j = lane; j < n; j += WAVE)
+          io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : NaN);
+      }
       if (lane == 0 && io.mean_correction) io.mean_correction[b] = corr;
       wave_sync();
       continue;
     }
-    // ---- bus injections (makeSbus) ---------------------------------------------
-    for (int i = lane; i < nb; i += WAVE) {
-      double p = 0.0, q = 0.0;
-      for (int e = E.pinj_ptr[i]; e < E.pinj_ptr[i + 1]; ++e)
-        p += E.pinj_coef[e] * xval(xr, L.sp, E.pinj_slot[e], E.pinj_act[e]);
-      for (int e = E.qinj_ptr[i]; e < E.qinj_ptr[i + 1]; ++e)
-        q += E.qinj_coef[e] * xval(xr, L.sp, E.qinj_slot[e], E.qinj_act[e]);
-      L.psp[i] = p;
-      L.qsp[i] = q;
-      L.bt[i] = BT_PQ;
+    // ---- bus injections (makeSbus): lane = unit column (coalesced x reads), LDS accumulate --
+    for (int i = lane; i < nb; i += WAVE) { L.psp[i] = 0.0; L.qsp[i] = 0.0; L.bt[i] = BT_PQ; }
+    wave_fence();
+    for (int e = lane; e < E.n_inj; e += WAVE) {
+      const int bq = E.inj_bus[e];
+      const double v = E.inj_coef[e] * xval(xr, L.sp, E.inj_slot[e], E.inj_act[e]);
+      lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
     }
     // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
     double objective = 0.0, viol_acc = 0.0, pen_acc = 0.0;   // lane g < nc holds group g
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
         continue;
       }
       double* R = L.blk;
-      compute_results(P, L, lane, out_br, E.qg_min, E.qg_max, R, true);
+      compute_results(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
       wave_sync();
       // ---- constraints (constraints.py:70-128) ---------------------------------
       for (int g = 0; g < E.nc; ++g) {
@@ -896,10 +897,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
           if (v < lo) { const double d = fabs(v - lo); smin += d; wmin = fmax(wmin, d); ++cnt; }
           if (v > hi) { const double d = fabs(v - hi); smax += d; wmax = fmax(wmax, d); ++cnt; }
         }
-        cnt = wave_sum_i(cnt);
+        cnt = (int)wave_sum_dpp((double)cnt);
         double viol;
-        if (E.con_worst[g]) viol = wave_max(wmin) + wave_max(wmax);
-        else viol = wave_sum(smin) + wave_sum(smax);
+        if (E.con_worst[g]) viol = wave_max_dpp(wmin) + wave_max_dpp(wmax);
+        else viol = wave_sum_dpp(smin) + wave_sum_dpp(smax);
         const double as = E.con_autoscale[g];
         if (as != 0.0) viol *= as;                                                   // :82-83
         const double pw = E.con_ppow[g];
@@ -963,15 +964,16 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
             csum += cst;
           }
         }
-        objective = -wave_sum(csum);                                                 // opf_env.py:500
+        objective = -wave_sum_dpp(csum);                                                 // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
         if (io.results) for (int q = lane; q < E.nres; q += WAVE) io.results[b * E.nres + q] = R[q];
       }
       // result observations reflect the LAST solved case (defect D7 of the reference)
-      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) {
-        const int idx = E.obs_idx[k];
-        if (E.obs_kind[k] == OPFX_SRC_X) { if (c == 0) io.obs[b * E.nobs + k] = xval(xr, L.sp, idx, E.obs_act[k]); }
-        else io.obs[b * E.nobs + k] = R[idx];
+      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+        const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+        if (kind != 1 && c != 0) continue;              // table values do not depend on the solved case
+        for (int j = lane; j < n; j += WAVE)
+          io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : R[src + j]);
       }
       wave_sync();
     }
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
     } else {
       double pen_l = lane < E.nc ? pen_acc : 0.0;
       int inval_l = lane < E.nc ? !valid_acc : 0;
-      const double penalty = wave_sum(pen_l);
+      const double penalty = wave_sum_dpp(pen_l);
       const bool valid = !wave_any(inval_l);
       if (lane < E.nc) {
         if (io.valids) io.valids[b * E.nc + lane] = valid_acc ? 1 : 0;
@@ -1209,6 +1211,12 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk);
+  {
+    std::vector<double> vr0(p->nb), vi0(p->nb);
+    for (int i = 0; i < p->nb; ++i) { vr0[i] = p->vm_set[i] * std::cos(p->va_set[i]); vi0[i] = p->vm_set[i] * std::sin(p->va_set[i]); }
+    if (rc == OPFX_OK) rc = A.put(vr0, &d.vr0);
+    if (rc == OPFX_OK) rc = A.put(vi0, &d.vi0);
+  }
 #undef PUT
   if (rc == OPFX_OK) rc = A.put(&c->dp, 1, &c->d_dp);
   if (rc != OPFX_OK) { delete c; return rc; }
@@ -1280,10 +1288,26 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   int rc = OPFX_OK;
   const size_t np_ = d->pinj_ptr[nb], nq_ = d->qinj_ptr[nb];
 #define PUTN(field, ptr, n) if (rc == OPFX_OK) rc = A.put(ptr, (size_t)(n), &E.field)
-  PUTN(pinj_ptr, d->pinj_ptr, nb + 1); PUTN(pinj_slot, d->pinj_slot, np_); PUTN(pinj_coef, d->pinj_coef, np_);
-  PUTN(qinj_ptr, d->qinj_ptr, nb + 1); PUTN(qinj_slot, d->qinj_slot, nq_); PUTN(qinj_coef, d->qinj_coef, nq_);
-  { auto v = act_of(d->pinj_slot, np_); if (rc == OPFX_OK) rc = A.put(v, &E.pinj_act); }
-  { auto v = act_of(d->qinj_slot, nq_); if (rc == OPFX_OK) rc = A.put(v, &E.qinj_act); }
+  {
+    // flat injection list sorted by column so that a wave reads x in coalesced runs
+    struct Inj { int32_t slot, bus, act; double coef; };
+    std::vector<Inj> inj;
+    for (int i = 0; i < nb; ++i) {
+      for (int e = d->pinj_ptr[i]; e < d->pinj_ptr[i + 1]; ++e)
+        inj.push_back({d->pinj_slot[e], i, slot_act[d->pinj_slot[e]], d->pinj_coef[e]});
+      for (int e = d->qinj_ptr[i]; e < d->qinj_ptr[i + 1]; ++e)
+        inj.push_back({d->qinj_slot[e], i | (1 << 16), slot_act[d->qinj_slot[e]], d->qinj_coef[e]});
+    }
+    std::stable_sort(inj.begin(), inj.end(), [](const Inj& a, const Inj& b) { return a.slot < b.slot; });
+    std::vector<int32_t> sl, bu, ac; std::vector<double> co;
+    for (auto& q : inj) { sl.push_back(q.slot); bu.push_back(q.bus); ac.push_back(q.act); co.push_back(q.coef); }
+    E.n_inj = (int)inj.size();
+    if (rc == OPFX_OK) rc = A.put(sl, &E.inj_slot);
+    if (rc == OPFX_OK) rc = A.put(bu, &E.inj_bus);
+    if (rc == OPFX_OK) rc = A.put(ac, &E.inj_act);
+    if (rc == OPFX_OK) rc = A.put(co, &E.inj_coef);
+    (void)np_; (void)nq_;
+  }
   if (d->qg_min && d->qg_max) { PUTN(qg_min, d->qg_min, nb); PUTN(qg_max, d->qg_max, nb); }
   PUTN(act_slot, d->act_slot, d->na); PUTN(act_scaling, d->act_scaling, d->na);
   PUTN(act_lo_slot, d->act_lo_slot, d->na); PUTN(act_hi_slot, d->act_hi_slot, d->na);
@@ -1333,10 +1357,22 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   PUTN(con_worst, d->con_worst_case, d->nc);
   PUTN(obs_kind, d->obs_kind, d->nobs); PUTN(obs_idx, d->obs_idx, d->nobs);
   {
-    std::vector<int32_t> oa(d->nobs, -1);
-    for (int k = 0; k < d->nobs; ++k)
-      if (d->obs_kind[k] == OPFX_SRC_X && d->obs_idx[k] >= 0 && d->obs_idx[k] < d->nx) oa[k] = slot_act[d->obs_idx[k]];
-    if (rc == OPFX_OK) rc = A.put(oa, &E.obs_act);
+    // observation as maximal contiguous runs: kind 0 = x[src..], 1 = result bank, 2 = action set-points
+    std::vector<int32_t> sk, ss, sd, sn;
+    E.need_angle = 0;
+    for (int k = 0; k < d->nobs; ++k) {
+      int kind = d->obs_kind[k] == OPFX_SRC_X ? 0 : 1, src = d->obs_idx[k];
+      if (kind == 0 && src >= 0 && src < d->nx && slot_act[src] >= 0) { kind = 2; src = slot_act[src]; }
+      if (kind == 1 && src >= nb && src < 2 * nb) E.need_angle = 1;
+      if (!sk.empty() && sk.back() == kind && ss.back() + sn.back() == src && sd.back() + sn.back() == k) sn.back()++;
+      else { sk.push_back(kind); ss.push_back(src); sd.push_back(k); sn.push_back(1); }
+    }
+    E.n_oseg = (int)sk.size();
+    if (rc == OPFX_OK) rc = A.put(sk, &E.oseg_kind);
+    if (rc == OPFX_OK) rc = A.put(ss, &E.oseg_src);
+    if (rc == OPFX_OK) rc = A.put(sd, &E.oseg_dst);
+    if (rc == OPFX_OK) rc = A.put(sn, &E.oseg_n);
+    for (size_t i = 0; i < ncel; ++i) if (d->con_src[i] >= nb && d->con_src[i] < 2 * nb) E.need_angle = 1;
   }
   PUTN(cont_branch, d->cont_branch, d->n_cont);
 #undef PUTN
