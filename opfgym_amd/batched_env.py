@@ -151,7 +151,7 @@ class BatchedOpfEnv:
                  objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
-                 defer_device=False, **kwargs):
+                 defer_device=False, validate_actions=False, **kwargs):
         if objective_function is not None or power_flow_solver is not None:
             raise NotImplementedError('Python objective/solver callables cannot run inside the fused '
                                       'GPU step; use the reference OpfEnv with opfgym_amd.power_flow_solver')
@@ -159,6 +159,9 @@ class BatchedOpfEnv:
             raise NotImplementedError('bus_wise_obs is not supported by the batched backend yet')
         self.net = net
         self.device_spec = device
+        # opf_env.py:382 asserts on NaN actions; checking that on the host costs a device sync per
+        # step, so it is opt-in here: by default a NaN action yields a failed (NaN) row instead
+        self.validate_actions = bool(validate_actions)
         self.batch_size = int(batch_size)
         self.obs_keys = list(observation_keys)
         self.state_keys = list(state_keys) if state_keys else copy.copy(self.obs_keys)
@@ -571,7 +574,7 @@ class BatchedOpfEnv:
     def _alloc(self, B):
         t, dev = self.torch, self.device
         f64 = dict(dtype=t.float64, device=dev)
-        u8 = dict(dtype=t.uint8, device=dev)
+        u8 = dict(dtype=t.bool, device=dev)          # one byte each; the kernel writes 0/1
         nc = max(1, self.n_constraints)
         self.B = B
         self.x = t.zeros(B, self.nx, **f64)
@@ -591,7 +594,7 @@ class BatchedOpfEnv:
         io.x = self.x.data_ptr()
         io.action = action.data_ptr() if action is not None else None
         io.initial_obj = self.initial_obj.data_ptr() if with_initial_obj else None
-        io.step_in_episode = self.step_count.data_ptr()
+        io.step_in_episode = self.step_count.data_ptr() if self.steps_per_episode != 1 else None
         io.outage = None
         for name, buf in self.buf.items():
             setattr(io, name, buf.data_ptr())
@@ -605,6 +608,9 @@ class BatchedOpfEnv:
 
     def _as_action(self, action):
         t = self.torch
+        if t.is_tensor(action) and action.dtype == t.float64 and action.device == self.device \
+                and action.is_contiguous() and action.shape == (self.B, self.n_actions):
+            return action
         if not t.is_tensor(action):
             action = t.as_tensor(np.asarray(action, dtype=np.float64))
         action = action.to(device=self.device, dtype=t.float64).reshape(self.B, self.n_actions).contiguous()
@@ -674,15 +680,17 @@ class BatchedOpfEnv:
         truncated, info) as torch tensors on the device."""
         t = self.torch
         action = self._as_action(action)
-        assert not bool(t.isnan(action).any())                             # :382
-        self.step_count += 1
+        if self.validate_actions:
+            assert not bool(t.isnan(action).any())                         # :382
+        if self.steps_per_episode != 1:
+            self.step_count += 1
         self._launch_step(action, mode=0, with_initial_obj=self.diff_objective)
         b = self.buf
-        info = {'valids': b['valids'].bool(), 'violations': b['violations'],
+        info = {'valids': b['valids'], 'violations': b['violations'],
                 'unscaled_penalties': b['penalties'], 'cost': b['cost'],
-                'converged': b['converged'].bool(), 'iterations': b['iterations'],
+                'converged': b['converged'], 'iterations': b['iterations'],
                 'max_mismatch': b['max_mismatch'], 'objective': b['objective']}
-        return self._finish_obs(), b['reward'], b['terminated'].bool(), b['truncated'].bool(), info
+        return self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info
 
     def _finish_obs(self):
         """add_mean_obs / add_time_obs post-processing (opf_env.py:539-547)."""
@@ -742,7 +750,7 @@ class BatchedOpfEnv:
             self.reset()
             self.step_count += 1
             self._launch_step(self._as_action(self.np_random.random((self.B, self.n_actions))), mode=0)
-            conv = self.buf['converged'].bool().cpu().numpy()
+            conv = self.buf['converged'].cpu().numpy()
             obj = self.buf['objective'].cpu().numpy().copy()
             pen = self.buf['penalties'][:, :self.n_constraints].sum(dim=1).cpu().numpy().copy()
             obj[~conv] = np.nan

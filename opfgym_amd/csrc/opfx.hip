@@ -820,7 +820,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       double xv = xr[slot];
       if (io.mode != 1) {
         double a = io.action[b * E.na + k];
-        a = fmin(fmax(a, 0.0), 1.0);                                      // :429
+        a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                         // :429 (a NaN action stays NaN -> failed row)
         const double lo = E.act_lo_slot[k] >= 0 ? xr[E.act_lo_slot[k]] : E.act_lo_const[k];
         const double hi = E.act_hi_slot[k] >= 0 ? xr[E.act_hi_slot[k]] : E.act_hi_const[k];
         const double delta = hi - lo;
@@ -1168,6 +1168,13 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
+  // The occupancy query can be one block high when the LDS request is not a multiple of the
+  // allocation granule; an oversubscribed persistent grid runs its surplus blocks as a tail.
+  {
+    const size_t granule = 1024;
+    const int by_lds = (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
+    if (by_lds >= 1 && per_cu > by_lds) per_cu = by_lds;
+  }
   if (per_cu < 1) per_cu = 1;
   if (const char* ov = getenv("OPFX_WAVES_PER_CU")) per_cu = atoi(ov);     // developer override
   if (getenv("OPFX_VERBOSE")) fprintf(stderr, "[opfx] lds=%zu B/instance, resident waves per CU=%d, CUs=%d\n", lds, per_cu, n_cu);
