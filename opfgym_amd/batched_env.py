@@ -532,7 +532,11 @@ class BatchedOpfEnv:
         self.n_obs_raw = len(oidx)
         self.n_constraints = len(self.constraints)
         self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses)
-        self.desc_arrays = dict(act_slot=np.array(a_slot, dtype=np.int64))
+        t = self.torch
+        as_i = lambda v: t.as_tensor(np.asarray(v, dtype=np.int64), device=self.device)
+        as_d = lambda v: t.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
+        self._act_desc = dict(slot=as_i(a_slot), scaling=as_d(a_sc), lo_slot=as_i(lo_s), hi_slot=as_i(hi_s),
+                              lo_const=as_d(lo_c), hi_const=as_d(hi_c))
         self._set_reset()
 
     def _set_reset(self):
@@ -711,8 +715,20 @@ class BatchedOpfEnv:
 
     # ------------------------------------------------------------------ helpers
     def get_current_actions(self, from_results_table=True):
-        """opf_env.py:566-588: (set-point·scaling − min)/(max − min) per action."""
-        raise NotImplementedError
+        """opf_env.py:566-588 for the batch: (set-point·scaling − min)/(max − min) per action,
+        [B, n_actions].  `res_<unit>.<col>` equals set-point·scaling (SURVEY §8b results
+        contract), so both variants read the same columns of x."""
+        t = self.torch
+        d = self._act_desc
+        x = self.x
+        sp = x[:, d['slot']] * d['scaling']
+        lo = t.where(d['lo_slot'] >= 0, x[:, d['lo_slot'].clamp(min=0)], d['lo_const'])
+        hi = t.where(d['hi_slot'] >= 0, x[:, d['hi_slot'].clamp(min=0)], d['hi_const'])
+        return (sp - lo) / (hi - lo)
+
+    def get_actions(self):
+        """opf_env.py:590-600."""
+        return self.get_current_actions()
 
     def results(self):
         """Result bank of the last step as a dict of tensors (net.res_* columns)."""

@@ -276,7 +276,8 @@ class EnvOracle:
     def __init__(self, net, act_keys, obs_keys, profiles, constraints, reward, tail, *,
                  autoscale_actions=True, diff_action_step_size=None, clipped_action_penalty=0.0,
                  diff_objective=False, add_mean_obs=False, pf_for_obs=False, steps_per_episode=1,
-                 n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True):
+                 n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True,
+                 data='simbench', state_keys=None):
         self.base_net = net
         self.net = copy.deepcopy(net)
         self.act_keys, self.obs_keys = act_keys, obs_keys
@@ -288,6 +289,7 @@ class EnvOracle:
         self.spe = steps_per_episode
         self.n1, self.ncp = n_minus_one_keys, not_converged_penalty
         self.enforce_q_lims = enforce_q_lims
+        self.data, self.state_keys = data, state_keys
         self.initial_obj = 0.0
 
     def solve(self):
@@ -300,8 +302,14 @@ class EnvOracle:
     def reset(self, step, uniform=(), noise=None, initial_action=None):
         self.net = copy.deepcopy(self.base_net)
         self.step_in_episode = 0
-        set_simbench_state(self.net, self.profiles, step, noise, self.ranges)
-        self.tail(self.net, iter(np.asarray(uniform, float)))
+        draws = iter(np.asarray(uniform, float))
+        if self.data == 'full_uniform':                                     # opf_env.py:238-239, 253-264
+            for unit, col, idxs in self.state_keys:
+                if 'res_' not in unit:
+                    sample_from_range(self.net, unit, col, idxs, draws)
+        else:
+            set_simbench_state(self.net, self.profiles, step, noise, self.ranges)
+        self.tail(self.net, draws)
         n_act = sum(len(i) for _, _, i in self.act_keys)
         act = np.full(n_act, 0.5) if initial_action is None else initial_action   # opf_env.py:201-207
         apply_actions(self.net, self.act_keys, act, self.autoscale, None)

@@ -6,7 +6,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
-from scenarios import SCENARIOS  # noqa: E402
+from scenarios import EPISODE_STEPS, SCENARIOS  # noqa: E402
+
+SINGLE_STEP = [n for n in SCENARIOS if n not in EPISODE_STEPS]
 
 from opfgym_amd import envs as product_envs  # noqa: E402
 from oracle import env_oracle  # noqa: E402
@@ -42,7 +44,7 @@ def oracle_env(name, env=None):
         clipped_action_penalty=env.clipped_action_penalty, diff_objective=env.diff_objective,
         add_mean_obs=env.add_mean_obs, pf_for_obs=env.pf_for_obs,
         steps_per_episode=env.steps_per_episode, n_minus_one_keys=env.n_minus_one_keys,
-        not_converged_penalty=env.not_converged_penalty)
+        not_converged_penalty=env.not_converged_penalty, data=env.train_data, state_keys=env.state_keys)
 
 
 def noise_factors(name, raw):

@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 
 import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc  # noqa: E402
-from scenarios import SCENARIOS, TRACKED  # noqa: E402
+from scenarios import EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
@@ -40,7 +40,50 @@ def snapshot(net):
     return out
 
 
+def run_episodes(name):
+    """Scenarios with several steps per episode: arrays get a step axis [n, S, ...]."""
+    cls, kwargs, n, seed = SCENARIOS[name]
+    S = EPISODE_STEPS[name]
+    env = REF[cls](seed=seed, **kwargs)
+    rng = np.random.default_rng(1000 + seed)
+    rec = {}
+
+    def push(key, val):
+        rec.setdefault(key, []).append(np.array(val, copy=True))
+    for k in range(n):
+        step = int(rng.choice(env.train_steps))
+        obs0, _ = env.reset(seed=seed * 100 + k, options={'step': step})
+        log = env.np_random.log
+        uni = [u.ravel() for kind, u in log if kind == 'uniform']
+        push('step', step)
+        push('uniform', np.concatenate(uni) if uni else np.zeros(0))
+        push('noise', np.zeros(0))
+        push('obs_reset', obs0)
+        ep = {}
+        for s_ in range(S):
+            action = rng.random(env.action_space.shape[0])
+            obs, reward, terminated, truncated, info = env.step(action)
+            assert 'cost' in info, 'multi-step golden episodes must converge'
+            for key, val in (('action', action), ('obs_step', obs), ('reward', reward),
+                             ('terminated', terminated), ('truncated', truncated), ('valids', info['valids']),
+                             ('violations', info['violations']), ('penalties', info['unscaled_penalties']),
+                             ('cost', info['cost']), ('vm_pu', env.net.res_bus.vm_pu.to_numpy()),
+                             ('current_actions', env.get_current_actions())):
+                ep.setdefault(key, []).append(np.array(val, copy=True))
+        for key, vals in ep.items():
+            push(key, np.stack(vals))
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out['n_obs'] = np.array(env.observation_space.shape[0])
+    out['n_act'] = np.array(env.action_space.shape[0])
+    out['n_bus'] = np.array(len(env.net.bus))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: {n} episodes x {S} steps, reward {out["reward"].round(4).tolist()}, '
+          f'term {out["terminated"].tolist()} trunc {out["truncated"].tolist()}')
+
+
 def run(name):
+    if name in EPISODE_STEPS:
+        return run_episodes(name)
     cls, kwargs, n, seed = SCENARIOS[name]
     env = REF[cls](seed=seed, **kwargs)
     rng = np.random.default_rng(1000 + seed)

@@ -33,7 +33,15 @@ SCENARIOS = {
     'vc_noisy': ('VoltageControl', dict(
         simbench_network_name='mv-small', train_data='noisy_simbench',
         sampling_params=dict(noise_factor=0.2)), 4, 12),
+    'vc_full_uniform': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='full_uniform', test_data='full_uniform'), 4, 13),
+    # multi-step episodes with incremental actions (opf_env.py:451-458, 406-414)
+    'vc_multistep_diff': ('VoltageControl', dict(
+        simbench_network_name='mv-small', steps_per_episode=3, diff_action_step_size=0.2), 3, 14),
 }
+
+# scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
+EPISODE_STEPS = {'vc_multistep_diff': 3}
 
 # table columns snapshotted after reset (when present in the reference net)
 TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_mvar'),

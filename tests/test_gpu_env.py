@@ -10,7 +10,7 @@ Jacobian times 1e-8 at most)."""
 import numpy as np
 import pytest
 
-from env_cases import SCENARIOS, golden, noise_factors, oracle_env, product_env
+from env_cases import EPISODE_STEPS, SINGLE_STEP, golden, noise_factors, oracle_env, product_env
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def _check_step(env, out, ref, k, n1=False):
         assert np.allclose(_np(env.result_table('ext_grid', 'q_mvar'))[k], ref['q_ext'], rtol=0, atol=R_TOL)
 
 
-@pytest.mark.parametrize('name', list(SCENARIOS))
+@pytest.mark.parametrize('name', SINGLE_STEP)
 def test_env_matches_reference_golden(name):
     g = golden(name)
     n = len(g['step'])
@@ -62,6 +62,7 @@ def test_env_matches_reference_golden(name):
     assert np.allclose(_np(obs0), g['obs_reset'], rtol=0, atol=R_TOL)
     out = env.step(g['action'])
     assert _np(out[4]['converged']).all()
+    assert np.allclose(_np(env.get_current_actions()), g['current_actions'], rtol=0, atol=1e-9, equal_nan=True)
     n1 = bool(env.n_minus_one_keys)
     for k in range(n):
         ref = {key: g[key][k] for key in g if g[key].ndim and len(g[key]) == n and not key.startswith('fail_')}
@@ -134,3 +135,41 @@ def test_full_batch_voltage_control_properties():
     r1 = _np(reward).copy()
     obs2, reward2, *_ = env.step(actions)
     assert np.array_equal(r1, _np(reward2), equal_nan=True)
+
+
+@pytest.mark.parametrize('name', list(EPISODE_STEPS))
+def test_env_multi_step_episodes(name):
+    """steps_per_episode > 1 with incremental actions: the column store x carries the
+    set-points from step to step (opf_env.py:451-458), truncation at the last step (:406-414)."""
+    g = golden(name)
+    n = len(g['step'])
+    env = product_env(name, batch_size=n)
+    obs0, _ = env.reset(options={'step': g['step']})
+    assert np.allclose(_np(obs0), g['obs_reset'], rtol=0, atol=R_TOL)
+    for s_ in range(EPISODE_STEPS[name]):
+        obs, reward, term, trunc, info = env.step(g['action'][:, s_])
+        assert _np(info['converged']).all()
+        assert np.allclose(_np(obs), g['obs_step'][:, s_], rtol=0, atol=R_TOL)
+        assert np.allclose(_np(reward), g['reward'][:, s_], rtol=1e-9, atol=R_TOL)
+        assert (_np(term) == g['terminated'][:, s_]).all() and (_np(trunc) == g['truncated'][:, s_]).all()
+        assert np.allclose(_np(info['unscaled_penalties'])[:, :g['penalties'].shape[2]], g['penalties'][:, s_],
+                           rtol=1e-9, atol=R_TOL)
+        assert np.allclose(_np(env.result_table('bus', 'vm_pu')), g['vm_pu'][:, s_], rtol=0, atol=V_TOL)
+        assert np.allclose(_np(env.get_current_actions()), g['current_actions'][:, s_], rtol=0, atol=1e-9)
+
+
+def test_reward_scaling_from_batched_estimate():
+    """reward_scaling without given statistics triggers estimate_reward_distribution
+    (reward.py:32-36, 181-216): here one batched reset+step of `num_samples` instances."""
+    env = product_env('vc_mv_small', batch_size=8, reward_function_params=dict(
+        reward_scaling='normalization', scaling_params=dict(num_samples=256)))
+    sp = env.reward_function.scaling_params
+    assert np.isfinite([sp['objective_factor'], sp['objective_bias'], sp['penalty_factor'], sp['penalty_bias']]).all()
+    assert sp['std_objective'] > 0 and sp['min_objective'] < sp['max_objective']
+    rng = np.random.default_rng(0)
+    env.reset(options={'step': rng.choice(env.train_steps, 8)})
+    obs, reward, *_ , info = env.step(rng.random((8, env.n_actions)))
+    obj, pen = _np(info['objective']), _np(info['unscaled_penalties']).sum(axis=1)
+    want = 0.5 * (obj * sp['objective_factor'] + sp['objective_bias']) + \
+        0.5 * (pen * sp['penalty_factor'] + sp['penalty_bias'])
+    assert np.allclose(_np(reward), want, rtol=1e-12, atol=1e-12)

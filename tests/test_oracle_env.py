@@ -7,12 +7,12 @@ penalties 1e-9, power-flow results 1e-9 (both sides use the same oracle solver).
 import numpy as np
 import pytest
 
-from env_cases import SCENARIOS, golden, noise_factors, oracle_env, product_env
+from env_cases import EPISODE_STEPS, SINGLE_STEP, golden, noise_factors, oracle_env, product_env
 
 TAB_TOL = 1e-12
 
 
-@pytest.mark.parametrize('name', list(SCENARIOS))
+@pytest.mark.parametrize('name', SINGLE_STEP)
 def test_oracle_matches_reference_golden(name):
     g = golden(name)
     env = product_env(name, defer_device=True)
@@ -50,3 +50,22 @@ def test_oracle_matches_reference_golden(name):
             noise = noise_factors(name, g['fail_noise'][k])
             orc.reset(int(g['fail_step'][k]), g['fail_uniform'][k], noise)
             assert not orc.step(g['fail_action'][k])['converged']
+
+
+@pytest.mark.parametrize('name', list(EPISODE_STEPS))
+def test_oracle_multi_step_episodes(name):
+    """steps_per_episode > 1 with incremental actions (opf_env.py:406-414, 451-458)."""
+    g = golden(name)
+    orc = oracle_env(name)
+    for k in range(len(g['step'])):
+        obs0 = orc.reset(int(g['step'][k]), g['uniform'][k])
+        assert np.allclose(obs0, g['obs_reset'][k], rtol=0, atol=1e-9)
+        for s_ in range(EPISODE_STEPS[name]):
+            out = orc.step(g['action'][k, s_])
+            assert out['converged']
+            assert np.allclose(out['obs'], g['obs_step'][k, s_], rtol=0, atol=1e-9)
+            assert np.isclose(out['reward'], g['reward'][k, s_], rtol=0, atol=1e-9)
+            assert bool(out['terminated']) == bool(g['terminated'][k, s_])
+            assert bool(out['truncated']) == bool(g['truncated'][k, s_])
+            assert np.allclose(out['penalties'], g['penalties'][k, s_], rtol=0, atol=1e-9)
+            assert np.allclose(out['vm_pu'], g['vm_pu'][k, s_], rtol=0, atol=1e-9)
