@@ -62,6 +62,8 @@ struct DevPlan {
   int ra, rh, rb, rc;
   int debug_skip;            // developer probe (OPFX_DEBUG_SKIP): bit mask of phases to skip
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
+  const int* lp_hrows;
+  int n_hrows;
 };
 
 struct DevEnv {
@@ -487,37 +489,38 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
     // ---- phase A -----------------------------------------------------------------
     if (!(P.debug_skip & 32)) for (int f = lane; f < P.nfill; f += WAVE) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
-    for (int h = 0; h < ((P.debug_skip & 1) ? 0 : P.rh); ++h) {          // overflow entries of rows longer than 4
-      const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
-      const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
-      const unsigned row = __builtin_amdgcn_readfirstlane(he.y);
-      const int i = row & 0xFFFF;
-      const unsigned ent = he.x;
-      const unsigned j = ent & 0xFFFF;
-      double cr = 0.0, ci = 0.0;
-      if (j != NONE) {
-        double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
-        double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
-        if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-        if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
-        const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
-        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-        cr = vri * tr + vii * ti; ci = vii * tr - vri * ti;
-        const unsigned bid = ent >> 16;
-        const int t = L.bt[i];
-        if (bid != NONE && t != BT_REF) {
-          Blk jb{ci, cr, -cr, ci};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-          st_blk(L.blk, bid, jb);
+    // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
+    // rhs slots of those rows (zeroed first) with LDS atomics
+    if (P.rh > 0 && !(P.debug_skip & 1)) {
+      for (int h = lane; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
+      wave_fence();
+      for (int h = 0; h < P.rh; ++h) {
+        const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
+        const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+        const unsigned ent = he.x;
+        const unsigned j = ent & 0xFFFF;
+        if (j != NONE) {
+          const int i = he.y;
+          double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
+          double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
+          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+          const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          const unsigned bid = ent >> 16;
+          const int t = L.bt[i];
+          if (bid != NONE && t != BT_REF) {
+            Blk jb{ci, cr, -cr, ci};
+            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+            st_blk(L.blk, bid, jb);
+          }
+          lds_sub(&L.rhs[2 * i], -cr);
+          lds_sub(&L.rhs[2 * i + 1], -ci);
         }
       }
-      cr = wave_sum_dpp(cr); ci = wave_sum_dpp(ci);
-      if (lane == 0) {
-        if (row >> 16) { L.rhs[2 * i] += cr; L.rhs[2 * i + 1] += ci; }
-        else { L.rhs[2 * i] = cr; L.rhs[2 * i + 1] = ci; }
-      }
+      wave_fence();
     }
-    if (P.rh) wave_fence();
     double my = 0.0;
     for (int r = 0; r < ((P.debug_skip & 2) ? 0 : P.ra); ++r) {
       const ARound a = cur;
@@ -1217,7 +1220,8 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb; d.rc = p->rc;
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
-  PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk);
+  PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
+  d.n_hrows = (int)p->lp_hrows.size();
   {
     std::vector<double> vr0(p->nb), vi0(p->nb);
     for (int i = 0; i < p->nb; ++i) { vr0[i] = p->vm_set[i] * std::cos(p->va_set[i]); vi0[i] = p->vm_set[i] * std::sin(p->va_set[i]); }

@@ -95,24 +95,22 @@ void build_lane_programs(opfx_plan* p) {
     uint32_t d = p->diag_blk[i] >= 0 ? (uint32_t)p->diag_blk[i] : NONE;
     if (!overflow.empty()) d |= 1u << 16;
     p->lp_a_dblk[(size_t)r * 64 + lane] = d;
-    for (size_t o = 0; o < overflow.size(); o += 64) {            // one heavy round per 64 overflow entries
-      p->lp_h_row.push_back((uint32_t)i | (o == 0 ? 0u : 1u << 16));   // bit16: continue accumulating
-      for (int lane2 = 0; lane2 < 64; ++lane2) {
-        if (o + lane2 < overflow.size()) {
-          const int e = overflow[o + lane2];
-          const uint32_t blk = p->y_blk[e] >= 0 ? (uint32_t)p->y_blk[e] : NONE;
-          p->lp_h_ent.push_back((uint32_t)p->y_col[e] | (blk << 16));
-          p->lp_h_y.push_back(p->y_g[e]);
-          p->lp_h_y.push_back(p->y_b[e]);
-        } else {
-          p->lp_h_ent.push_back(NONE | (NONE << 16));
-          p->lp_h_y.push_back(0.0);
-          p->lp_h_y.push_back(0.0);
-        }
-      }
+    if (!overflow.empty()) p->lp_hrows.push_back(i);
+    for (int e : overflow) {                     // flat list of overflow entries, any row per lane
+      const uint32_t blk = p->y_blk[e] >= 0 ? (uint32_t)p->y_blk[e] : NONE;
+      p->lp_h_ent.push_back((uint32_t)p->y_col[e] | (blk << 16));
+      p->lp_h_row.push_back((uint32_t)i);
+      p->lp_h_y.push_back(p->y_g[e]);
+      p->lp_h_y.push_back(p->y_b[e]);
     }
   }
-  p->rh = (int32_t)p->lp_h_row.size();
+  while (p->lp_h_ent.size() % 64) {
+    p->lp_h_ent.push_back(NONE | (NONE << 16));
+    p->lp_h_row.push_back(NONE);
+    p->lp_h_y.push_back(0.0);
+    p->lp_h_y.push_back(0.0);
+  }
+  p->rh = (int32_t)(p->lp_h_ent.size() / 64);
   // ---- B ---------------------------------------------------------------------
   // per level: every (target, source) update term is one item; terms that share a
   // target may sit in the same round (the kernel accumulates with LDS atomics);
@@ -209,7 +207,7 @@ void build_lane_programs(opfx_plan* p) {
       put_d(p->lp_hpk, a0, p->lp_h_y[((size_t)h * 64 + l) * 2]);
       put_d(p->lp_hpk, a0 + 2, p->lp_h_y[((size_t)h * 64 + l) * 2 + 1]);
       p->lp_hpk[a1] = p->lp_h_ent[(size_t)h * 64 + l];
-      p->lp_hpk[a1 + 1] = p->lp_h_row[h];
+      p->lp_hpk[a1 + 1] = p->lp_h_row[(size_t)h * 64 + l];
     }
 }
 

@@ -124,3 +124,130 @@ def emulate_newton(plan, p_sp, q_sp, tol=1e-8, max_iter=10, check_levels=True):
             if vm[i] < 0:
                 vm[i] = -vm[i]
                 va[i] += np.pi
+
+
+def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
+    """Walks the LANE PROGRAMME (plan.h lp_*: what kernel `newton2` executes) in
+    numpy: ELL bus rows + overflow entries, flat update items accumulated per
+    target, solve items with inline U-terms; relative-|V| unknowns and the
+    rectangular voltage update.  Returns (V, converged, iterations, norm)."""
+    NONE = 0xFFFF
+    case = plan.case
+    info = plan.info
+    nb = case.nb
+    bt = case.bus_type
+    ra, rh, rb, rc = (info[k] for k in ('lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c'))
+    a_ent = plan.array('lp_a_ent').view(np.uint32).reshape(ra, 4, 64)
+    a_dblk = plan.array('lp_a_dblk').view(np.uint32).reshape(ra, 64)
+    a_y = plan.darray('lp_a_y').reshape(ra, 4, 64, 2)
+    a_yd = plan.darray('lp_a_ydiag').reshape(ra, 64, 2)
+    h_ent = plan.array('lp_h_ent').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
+    h_row = plan.array('lp_h_row').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
+    h_y = plan.darray('lp_h_y').reshape(rh, 64, 2) if rh else np.zeros((0, 64, 2))
+    lp_b = plan.array('lp_b').view(np.uint32).reshape(rb, 64, 2)
+    lp_c = plan.array('lp_c').view(np.uint32).reshape(rc, 64, 3)
+    fill = plan.array('fill_blk')
+    v = case.vm_set * np.exp(1j * case.va_set)
+    nblk = info['n_blk']
+    it = 0
+
+    def inv2(b):
+        det = b[0, 0] * b[1, 1] - b[0, 1] * b[1, 0]
+        return np.array([[b[1, 1], -b[0, 1]], [-b[1, 0], b[0, 0]]]) / det
+    while True:
+        blk = np.full((nblk, 2, 2), np.nan)
+        blk[fill] = 0.0
+        rhs = np.zeros((nb, 2))
+        soff = np.zeros(nb, complex)
+        for h in range(rh):
+            for lane in range(64):
+                j = int(h_ent[h, lane] & 0xFFFF)
+                if j == NONE:
+                    continue
+                i = int(h_row[h, lane])
+                c = v[i] * np.conj((h_y[h, lane, 0] + 1j * h_y[h, lane, 1]) * v[j])
+                bid = int(h_ent[h, lane] >> 16)
+                if bid != NONE and bt[i] != REF:
+                    jb = np.array([[c.imag, c.real], [-c.real, c.imag]])
+                    if bt[i] == PV:
+                        jb[1] = 0.0
+                    blk[bid] = jb
+                soff[i] += c
+        nrm = 0.0
+        for r in range(ra):
+            for lane in range(64):
+                i = lane + 64 * r
+                if i >= nb:
+                    continue
+                t = bt[i]
+                s = soff[i] if (a_dblk[r, lane] >> 16) else 0j
+                for k in range(4):
+                    j = int(a_ent[r, k, lane] & 0xFFFF)
+                    if j == NONE:
+                        continue
+                    c = v[i] * np.conj((a_y[r, k, lane, 0] + 1j * a_y[r, k, lane, 1]) * v[j])
+                    s += c
+                    bid = int(a_ent[r, k, lane] >> 16)
+                    if bid != NONE and t != REF:
+                        jb = np.array([[c.imag, c.real], [-c.real, c.imag]])
+                        if t == PV:
+                            jb[1] = 0.0
+                        blk[bid] = jb
+                if t != REF:
+                    yv = np.conj(a_yd[r, lane, 0] + 1j * a_yd[r, lane, 1]) * abs(v[i]) ** 2
+                    sc = s + yv
+                    fp = sc.real - p_sp[i]
+                    fq = 0.0 if t == PV else sc.imag - q_sp[i]
+                    rhs[i] = (-fp, -fq)
+                    nrm = max(nrm, abs(fp), abs(fq))
+                    jb = np.array([[-s.imag, yv.real + sc.real], [s.real, yv.imag + sc.imag]])
+                    if t == PV:
+                        jb[1] = (0.0, 1.0)
+                    blk[int(a_dblk[r, lane] & 0xFFFF)] = jb
+        if not np.isfinite(nrm):
+            return v, False, it, nrm
+        if nrm < tol:
+            return v, True, it, nrm
+        if it >= max_iter:
+            return v, False, it, nrm
+        it += 1
+        assert not np.isnan(blk).any()
+        for r in range(rb):
+            dblk_upd, drhs = {}, {}
+            for lane in range(64):
+                w0, w1 = int(lp_b[r, lane, 0]), int(lp_b[r, lane, 1])
+                tb = w0 & 0xFFFF
+                if tb == NONE:
+                    continue
+                w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
+                if tb & 0x8000:
+                    i = tb & 0x7FFF
+                    drhs[i] = drhs.get(i, 0) + w @ rhs[w1 >> 16]
+                else:
+                    dblk_upd[tb] = dblk_upd.get(tb, 0) + w @ blk[w1 >> 16]
+            for tb, d in dblk_upd.items():
+                blk[tb] -= d
+            for i, d in drhs.items():
+                rhs[i] -= d
+        for r in range(rc):
+            upd = {}
+            for lane in range(64):
+                w0, w1, w2 = (int(x) for x in lp_c[r, lane])
+                k = w0 & 0xFFFF
+                if k == NONE:
+                    continue
+                d = np.zeros(2)
+                for w in (w1, w2):
+                    if (w & 0xFFFF) != NONE:
+                        d += blk[w & 0xFFFF] @ rhs[w >> 16]
+                dblk = w0 >> 16
+                if dblk != NONE:
+                    upd[k] = ('set', inv2(blk[dblk]) @ (rhs[k] - d))
+                else:
+                    prev = upd.get(k, ('sub', np.zeros(2)))[1]
+                    upd[k] = ('sub', prev + d)
+            for k, (kind, val) in upd.items():
+                rhs[k] = val if kind == 'set' else rhs[k] - val
+        for i in range(nb):
+            if bt[i] != REF:
+                v[i] = v[i] * (1.0 + rhs[i, 1]) * np.exp(1j * rhs[i, 0])

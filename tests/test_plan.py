@@ -11,7 +11,7 @@ import pytest
 from opfgym_amd import capi, grids
 from opfgym_amd.case import net_to_case
 from oracle import pf_oracle as po
-from plan_emulator import emulate_newton, load_plan
+from plan_emulator import emulate_newton, emulate_newton_lane_program, load_plan
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -50,6 +50,23 @@ def test_schedule_reproduces_oracle(built_lib, code):
     v, conv, it, nrm = emulate_newton(plan, p, q)
     assert conv and ref['converged'] and it == ref['iterations']
     assert np.abs(v - ref['V']).max() < 1e-12
+
+
+@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', '1-MV-urban--0-sw', 'hv-small'])
+def test_lane_programme_reproduces_oracle(built_lib, code):
+    """The register/stream form of the schedule that kernel `newton2` executes
+    (ELL rows + overflow entries, flat update items, solve items with inline
+    U-terms, relative-|V| unknowns) converges to the oracle's solution in the
+    same number of iterations."""
+    net = grids.case9() if code == 'case9' else grids.get_grid(code)[0]
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    p, q, *_ = po.bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = po.solve_case(case, p, q)
+    v, conv, it, nrm = emulate_newton_lane_program(plan, p, q)
+    assert conv and it == ref['iterations']
+    assert np.abs(v - ref['V']).max() < 1e-9          # both stop at ||F|| < 1e-8
 
 
 def test_plan_structure_invariants(built_lib):
