@@ -82,7 +82,8 @@ struct DevEnv {
   const int *cost_kind, *cost_pidx, *cost_qidx, *cost_pact, *cost_qact, *pwl_is_q;
   const double *cost_scale, *cost_coef;
   const int *price_slot, *price_coef, *coef_price;   // coef_price: coef index -> price ordinal or -1
-  const int *con_ptr, *con_src, *con_worst;
+  const int *con_ptr, *con_src, *con_worst, *con_grp;
+  int ncel;
   const double *con_min, *con_max, *con_autoscale, *con_pfac, *con_ppow, *con_cpen;
   const int *obs_kind, *obs_idx, *obs_act;
   const int *cont_branch;
@@ -196,7 +197,7 @@ constexpr int BT_PQ = 1, BT_PV = 2, BT_REF = 3, BT_PQ_HI = 4, BT_PQ_LO = 5;
 // Per-instance LDS image.  The lane-programme kernel (V2) keeps the voltage in
 // rectangular form only (no |V|/angle arrays) to fit 6 instances per CU.
 struct Lds {
-  double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp;
+  double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp, *acc;
   unsigned char* bt;
 };
 
@@ -568,6 +569,15 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
           st_blk(L.blk, a.dw & 0xFFFF, jb);
+        } else {
+          // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
+          // in its rhs slots so that the result pass needs no second walk over the row
+          double g = a.yd.x, b = a.yd.y;
+          if (i == of) { g -= oy[0]; b -= oy[1]; }
+          if (i == ot) { g -= oy[6]; b -= oy[7]; }
+          const double v2 = vri * vri + vii * vii;
+          L.rhs[2 * i] = sr + g * v2;
+          L.rhs[2 * i + 1] = si - b * v2;
         }
       }
     }
@@ -676,6 +686,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
 
 // after convergence: result bank in LDS region R (reuses the LU block storage)
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
+template <bool V2>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle) {
@@ -695,7 +706,11 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     const int t = L.bt[i];
     double qgen = 0.0;
-    if (t == BT_REF || t == BT_PV) {
+    if (V2 && t == BT_REF) {
+      const int ro = P.ref_ord[i];
+      r_pe[ro] = (L.rhs[2 * i] - L.psp[i]) * base;
+      r_qe[ro] = (L.rhs[2 * i + 1] - L.qsp[i]) * base;
+    } else if (t == BT_REF || t == BT_PV) {
       double ir = 0.0, ii = 0.0;
       for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
         const int j = P.y_col[e];
@@ -741,7 +756,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
 }
 
 template <bool V2>
-__device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base) {
+__device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc = 0) {
   Lds L;
   const int nb = P.nb;
   const int nbe = (nb + 1) & ~1;               // even count keeps every array 16-byte aligned
@@ -753,7 +768,8 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   L.blk = L.rhs + 2 * nbe;
   const int nblk_d = 4 * P.nblk > nres ? 4 * P.nblk : nres;
   L.sp = L.blk + ((nblk_d + 1) & ~1);
-  L.bt = reinterpret_cast<unsigned char*>(L.sp + na);
+  L.acc = L.sp + na;
+  L.bt = reinterpret_cast<unsigned char*>(L.acc + nacc);
   return L;
 }
 
@@ -778,7 +794,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_solve(const DevPlan P, SolveIO io, 
     const bool conv = solve_instance<V2>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
     wave_sync();
     double* R = L.blk;
-    compute_results(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
+    compute_results<V2>(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
     wave_sync();
     const int nb = P.nb, nbr = P.nbr, nref = P.nref;
     if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
@@ -811,7 +827,7 @@ template <bool V2>
 __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv E, StepIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
-  const Lds L = carve<V2>(P, E.na, E.nres, smem);
+  const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
@@ -888,29 +904,42 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
         continue;
       }
       double* R = L.blk;
-      compute_results(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
+      compute_results<V2>(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
       wave_sync();
-      // ---- constraints (constraints.py:70-128) ---------------------------------
-      for (int g = 0; g < E.nc; ++g) {
-        double smin = 0.0, smax = 0.0, wmin = 0.0, wmax = 0.0;
-        int cnt = 0;
-        for (int e = E.con_ptr[g] + lane; e < E.con_ptr[g + 1]; e += WAVE) {
+      // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
+      // violating lanes accumulate per-constraint sum / worst case / count in LDS
+      {
+        for (int q = lane; q < 5 * E.nc; q += WAVE) L.acc[q] = 0.0;
+        wave_fence();
+        for (int e = lane; e < E.ncel; e += WAVE) {
           const double v = R[E.con_src[e]];
           const double lo = E.con_min[e], hi = E.con_max[e];
-          if (v < lo) { const double d = fabs(v - lo); smin += d; wmin = fmax(wmin, d); ++cnt; }
-          if (v > hi) { const double d = fabs(v - hi); smax += d; wmax = fmax(wmax, d); ++cnt; }
+          double* a = L.acc + 5 * E.con_grp[e];
+          if (v < lo) {
+            const double d = fabs(v - lo);
+            lds_sub(a + 0, -d); lds_sub(a + 4, -1.0);
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 2), (unsigned long long)__double_as_longlong(d),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          if (v > hi) {
+            const double d = fabs(v - hi);
+            lds_sub(a + 1, -d); lds_sub(a + 4, -1.0);
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 3), (unsigned long long)__double_as_longlong(d),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
         }
-        cnt = (int)wave_sum_dpp((double)cnt);
-        double viol;
-        if (E.con_worst[g]) viol = wave_max_dpp(wmin) + wave_max_dpp(wmax);
-        else viol = wave_sum_dpp(smin) + wave_sum_dpp(smax);
-        const double as = E.con_autoscale[g];
-        if (as != 0.0) viol *= as;                                                   // :82-83
-        const double pw = E.con_ppow[g];
-        double pen = (pw == 1.0 ? viol : pow(viol, pw)) * E.con_pfac[g];
-        pen += cnt * E.con_cpen[g];                                                  // :124-128
-        if (lane == g) {
-          valid_acc = valid_acc && (cnt == 0);
+        wave_fence();
+        if (lane < E.nc) {
+          const int g = lane;
+          const double* a = L.acc + 5 * g;
+          const double cnt = a[4];
+          double viol = E.con_worst[g] ? a[2] + a[3] : a[0] + a[1];                  // :113-122, :93-98
+          const double as = E.con_autoscale[g];
+          if (as != 0.0) viol *= as;                                                 // :82-83
+          const double pw = E.con_ppow[g];
+          double pen = (pw == 1.0 ? viol : pow(viol, pw)) * E.con_pfac[g];
+          pen += cnt * E.con_cpen[g];                                                // :124-128
+          valid_acc = valid_acc && (cnt == 0.0);
           viol_acc += viol;
           pen_acc += -pen;
         }
@@ -1149,10 +1178,10 @@ struct opfx_env {
 
 namespace {
 
-size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2) {
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc = 0) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>((size_t)4 * p.n_blk, (size_t)nres) + 1) & ~(size_t)1;
-  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na;
+  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
 }
@@ -1356,6 +1385,12 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   const size_t ncel = d->nc ? d->con_ptr[d->nc] : 0;
   PUTN(con_ptr, d->con_ptr, d->nc + 1); PUTN(con_src, d->con_src, ncel);
   {
+    std::vector<int32_t> grp(ncel);
+    for (int g = 0; g < d->nc; ++g) for (int e = d->con_ptr[g]; e < d->con_ptr[g + 1]; ++e) grp[e] = g;
+    E.ncel = (int)ncel;
+    if (rc == OPFX_OK) rc = A.put(grp, &E.con_grp);
+  }
+  {
     // NaN bound = absent boundary: comparisons against it must be false
     std::vector<double> lo(d->con_min, d->con_min + ncel), hi(d->con_max, d->con_max + ncel);
     for (auto& v : lo) if (v != v) v = -INFINITY;
@@ -1391,7 +1426,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2, 5 * d->nc);
   *out = e;
   return OPFX_OK;
 }
