@@ -61,6 +61,7 @@ struct DevPlan {
   // lane programme (plan.h)
   int ra, rh, rb, rc;
   int debug_skip;            // developer probe (OPFX_DEBUG_SKIP): bit mask of phases to skip
+  unsigned long long* stamps; // developer probe (OPFX_STAMPS): per-phase cycle sums of workgroup 0
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
   const int* lp_hrows;
   int n_hrows;
@@ -383,6 +384,15 @@ __device__ __forceinline__ void lds_sub(double* p, double v) {
   __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+#define OPFX_STAMP(slot)                                                                   \
+  do {                                                                                      \
+    if (P.stamps && blockIdx.x == 0) {                                                       \
+      const unsigned long long now__ = __builtin_readcyclecounter();                          \
+      if (lane == 0) P.stamps[slot] += now__ - t_last__;                                      \
+      t_last__ = __builtin_readcyclecounter();                                                \
+    }                                                                                       \
+  } while (0)
+
 struct ARound { uint4 ent; double2 y[4]; double2 yd; unsigned dw; };
 
 __device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane) {
@@ -484,12 +494,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
+  unsigned long long t_last__ = __builtin_readcyclecounter();
   ARound cur = load_around(P, 0, lane);
   while (true) {
     // descriptor stream of phases B and C: 4 rounds in flight while phase A runs
     uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
     // ---- phase A -----------------------------------------------------------------
     if (!(P.debug_skip & 32)) for (int f = lane; f < P.nfill; f += WAVE) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    OPFX_STAMP(10);
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
     if (P.rh > 0 && !(P.debug_skip & 1)) {
@@ -522,6 +534,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       }
       wave_fence();
     }
+    OPFX_STAMP(11);
     double my = 0.0;
     for (int r = 0; r < ((P.debug_skip & 2) ? 0 : P.ra); ++r) {
       const ARound a = cur;
@@ -533,24 +546,25 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
         if (a.dw >> 16) { sr = L.rhs[2 * i]; si = L.rhs[2 * i + 1]; }
         const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+        // branch-free over the 4 ELL slots (padding slots carry Y = 0 and read V_i): the four
+        // dependency chains interleave instead of being serialised by exec-mask branches
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned j = ent[k] & 0xFFFF;
-          if (j != NONE) {
-            double g = a.y[k].x, b = a.y[k].y;
-            if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-            if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
-            const double vrj = L.vr[j], vij = L.vi[j];
-            const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-            const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
-            sr += cr; si += ci;
-            const unsigned bid = ent[k] >> 16;
-            if (bid != NONE && t != BT_REF) {
-              // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
-              Blk jb{ci, cr, -cr, ci};
-              if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-              st_blk(L.blk, bid, jb);
-            }
+          const unsigned jr = ent[k] & 0xFFFF;
+          const unsigned j = jr != NONE ? jr : (unsigned)i;
+          double g = a.y[k].x, b = a.y[k].y;
+          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+          const double vrj = L.vr[j], vij = L.vi[j];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          sr += cr; si += ci;
+          const unsigned bid = ent[k] >> 16;
+          if (bid != NONE && t != BT_REF) {
+            // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
+            Blk jb{ci, cr, -cr, ci};
+            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+            st_blk(L.blk, bid, jb);
           }
         }
         if (t != BT_REF) {
@@ -581,7 +595,9 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         }
       }
     }
+    OPFX_STAMP(12);
     nrm = wave_max_dpp(my);
+    OPFX_STAMP(1);
     if (!(nrm == nrm)) { conv = false; break; }
     if (nrm < o.tol) { conv = true; break; }
     if (it >= o.max_iter) { conv = false; break; }
@@ -593,7 +609,9 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       do_round(q1, r + 1); q1 = ld_desc(r + 5);
       do_round(q2, r + 2); q2 = ld_desc(r + 6);
       do_round(q3, r + 3); q3 = ld_desc(r + 7);
+      if (r + 4 >= P.rb && r < P.rb) OPFX_STAMP(2);
     }
+    OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
     if (!(P.debug_skip & 16)) {
       double big = 0.0;
@@ -620,6 +638,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       }
     }
     wave_fence();
+    OPFX_STAMP(4);
   }
   *iters_out = it;
   *nrm_out = nrm;
@@ -830,8 +849,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
   const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
+  unsigned long long t_last__ = __builtin_readcyclecounter();
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     double* xr = io.x + b * E.nx;
+    OPFX_STAMP(15);
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
     for (int k = lane; k < E.na; k += WAVE) {
@@ -880,6 +901,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       const double v = E.inj_coef[e] * xval(xr, L.sp, E.inj_slot[e], E.inj_act[e]);
       lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
     }
+    OPFX_STAMP(0);
     // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
     double objective = 0.0, viol_acc = 0.0, pen_acc = 0.0;   // lane g < nc holds group g
     int valid_acc = 1;
@@ -893,8 +915,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max);
       wave_sync();
       int iters; double nrm;
+      t_last__ = __builtin_readcyclecounter();
       const bool conv = solve_instance<V2>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
       wave_sync();
+      OPFX_STAMP(5);
       if (c == 0) { conv0 = conv; iters0 = iters; nrm0 = nrm; if (!conv) break; }
       if (!conv) {
         // failed contingency: all invalid, +not_converged_penalty (sign as in the reference, D6)
@@ -906,6 +930,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       double* R = L.blk;
       compute_results<V2>(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
       wave_sync();
+      OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
       // violating lanes accumulate per-constraint sum / worst case / count in LDS
       {
@@ -944,6 +969,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
           pen_acc += -pen;
         }
       }
+      OPFX_STAMP(7);
       if (c == 0) {
         // ---- objective (objective.py:6-87) --------------------------------------
         double csum = 0.0;
@@ -1000,6 +1026,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
         if (io.results) for (int q = lane; q < E.nres; q += WAVE) io.results[b * E.nres + q] = R[q];
       }
+      OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
@@ -1009,6 +1036,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
       }
       wave_sync();
     }
+    OPFX_STAMP(9);
     // ---- reward (opf_env.py:515-530, reward.py:61-98) --------------------------
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
@@ -1248,6 +1276,11 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb; d.rc = p->rc;
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
+  d.stamps = nullptr;
+  if (getenv("OPFX_STAMPS")) {
+    void* st = nullptr;
+    if (hipMalloc(&st, 32 * sizeof(unsigned long long)) == hipSuccess) { (void)hipMemset(st, 0, 32 * sizeof(unsigned long long)); A.ptrs.push_back(st); d.stamps = static_cast<unsigned long long*>(st); }
+  }
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   d.n_hrows = (int)p->lp_hrows.size();
@@ -1542,5 +1575,14 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const int32_t* step_idx, con
   hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, step_idx,
                      noise, uniform, x, (long long)B);
   HIP_TRY(hipGetLastError());
+  return OPFX_OK;
+}
+
+// developer probe (not part of the ABI header): copies and clears the OPFX_STAMPS cycle sums
+extern "C" int opfx_debug_read_stamps(opfx_ctx* ctx, unsigned long long* out32) {
+  if (!ctx || !ctx->dp.stamps) return OPFX_ERR_INVALID;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out32, ctx->dp.stamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(ctx->dp.stamps, 0, 32 * sizeof(unsigned long long)));
   return OPFX_OK;
 }

@@ -16,3 +16,18 @@ ms = capi.C.c_float()
 capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io), capi.C.byref(env.solve_opts), 20,
                                       capi._stream(), capi.C.byref(ms)))
 print(f'k_step {ms.value/20:.4f} ms  it={env.buf["iterations"].double().mean().item():.2f}')
+if os.environ.get('OPFX_STAMPS'):
+    import ctypes
+    out = (ctypes.c_ulonglong * 32)()
+    capi.lib().opfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    capi.lib().opfx_debug_read_stamps(env.ctx.handle, out)      # clear warm-up sums
+    env.step(actions)
+    capi.lib().opfx_debug_read_stamps(env.ctx.handle, out)
+    names = {0: 'prologue(actions+inject)', 1: ' A: norm reduction', 2: 'NR phase B', 3: 'NR phase C', 4: 'NR phase D',
+             5: 'solve_instance total(excl.)', 6: 'compute_results', 7: 'constraints', 8: 'objective+results out',
+             9: 'obs out', 10: ' A: desc prefetch + fill zero', 11: ' A: overflow entries', 12: ' A: bus rounds', 15: 'loop top/reward/outputs'}
+    tot = sum(out)
+    n_inst = (B + 1535) // 1536
+    for k in sorted(names):
+        print(f'  {names[k]:34s} {out[k]:10d} cyc  {100*out[k]/tot:5.1f}%')
+    print(f'  total {tot} cycles for ~{n_inst} instances of workgroup 0 (100 MHz ticks? see s_memtime)')
