@@ -650,14 +650,22 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // its generator share removed from q_sp again (L.bt must hold valid codes).
 template <bool V2>
 __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
-                             const double* qg_max) {
+                             const double* qg_max, bool enforce_q_lims) {
   for (int i = lane; i < P.nb; i += WAVE) {
     const int t = L.bt[i];
     if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];
     if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
     if (!V2) { L.vm[i] = P.vm_set[i]; L.va[i] = P.va_set[i]; }
     L.vr[i] = P.vr0[i]; L.vi[i] = P.vi0[i];
-    L.bt[i] = (unsigned char)P.bus_type[i];
+    int bt0 = P.bus_type[i];
+    // A generator whose reactive range is a single point (eco_dispatch.py:86-88 sets
+    // min_q = max_q = 0) always ends at that limit after the first enforce_q_lims pass
+    // (unless its free Q happens to equal it exactly): start it there, one solve saved.
+    if (bt0 == BT_PV && enforce_q_lims && qg_min != nullptr && qg_min[i] == qg_max[i]) {
+      bt0 = BT_PQ_HI;
+      L.qsp[i] += qg_max[i];
+    }
+    L.bt[i] = (unsigned char)bt0;
   }
 }
 
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_solve(const DevPlan P, SolveIO io, 
       L.qsp[i] = io.q_inj[b * P.nb + i];
       L.bt[i] = BT_PQ;
     }
-    init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max);
+    init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims != 0);
     wave_sync();
     const int out_br = io.outage ? io.outage[b] : -1;
     int iters; double nrm;
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
-      init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max);
+      init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
       wave_sync();
       int iters; double nrm;
       t_last__ = __builtin_readcyclecounter();
