@@ -83,6 +83,8 @@ def main():
     from opfgym_amd import capi, dist as odist, envs
     rank, world, local_rank = odist.init_from_env()
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N'
+    if os.environ.get('OPFX_BENCH_SHARE_GPU'):       # debugging aid: all ranks on GPU 0 (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     B = args.batch
@@ -114,7 +116,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     conv = float(info['converged'].double().mean().item())
@@ -132,6 +135,12 @@ def main():
     if rank == 0:
         bm = byte_model(env, mean_it)
         achieved = bm['B_step'] * B / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
+        # separate runs of this same script, see profiles/README.md) — not measurable in-process
+        traffic = None
+        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+        if B == BATCH and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file))['hbm_bytes_per_launch_fetch_x2']
         out = {
             'metric': 'env.step()/s (batched NR power-flow solves/s) at batch 8192',
             'value': world * B * args.steps / elapsed,
@@ -147,7 +156,8 @@ def main():
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it,
                        'tolerance_pu': env.solve_opts.tol, 'byte_model': bm},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': None,
+                         'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                         'algorithmic_bytes_per_launch': bm['B_step'] * B,
                          'kernel': 'k_step', 'kernel_ms': kernel_ms,
                          'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory '
                                  'once per NR phase) x 8192 / kernel time; the kernel keeps that state in LDS, '

@@ -20,12 +20,18 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world == 1 or dist.is_initialized():
         return int(os.environ.get('RANK', '0')), world, int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('OPFX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
-    dist.init_process_group(backend=backend)
-    return dist.get_rank(), dist.get_world_size(), int(os.environ.get('LOCAL_RANK', '0'))
+    if backend == 'nccl':
+        # one process per GPU: bind the device before the communicator is created
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, device_id=torch.device('cuda', local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist.get_rank(), dist.get_world_size(), local_rank
 
 
 def shard_bounds(total: int, rank: int, world: int):
@@ -45,6 +51,9 @@ def all_gather_rows(local, world: int, sizes=None):
     import torch.distributed as dist
     if world == 1 or not dist.is_initialized():
         return local
+    if local.is_cuda and dist.get_backend() == 'gloo':
+        # debugging aid (several ranks sharing one GPU): stage through the host
+        return all_gather_rows(local.cpu(), world, sizes).to(local.device)
     if sizes is None or len(set(sizes)) == 1:
         out = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype,
                           device=local.device)
