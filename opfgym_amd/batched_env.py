@@ -592,6 +592,13 @@ class BatchedOpfEnv:
         self.initial_obj = t.zeros(B, **f64)
         self.step_count = t.zeros(B, dtype=t.int32, device=dev)
         self.steps_dev = t.zeros(B, dtype=t.int32, device=dev)
+        self._center_action = t.full((B, self.n_actions), 0.5, **f64)
+        if not hasattr(self, '_gen'):
+            self._gen = t.Generator(device=dev)
+            self._gen.manual_seed(int(self.np_random.integers(0, 2 ** 31 - 1)))
+            as_i32 = lambda a: t.as_tensor(np.asarray(a, dtype=np.int32), device=dev)
+            self._pools = {'train': as_i32(self.train_steps), 'validation': as_i32(self.validation_steps),
+                           'test': as_i32(self.test_steps)}
 
     def _io(self, action, with_initial_obj):
         io = capi.StepIO()
@@ -628,33 +635,46 @@ class BatchedOpfEnv:
         t = self.torch
         if seed is not None:
             self.np_random = np.random.default_rng(seed)
+            self._gen.manual_seed(int(seed))
         options = options or {}
         B = self.B
+        dev = self.device
         self.test = bool(options.get('test', False))
         step = options.get('step', None)
         if step is None:                                                   # opf_env.py:327-333
-            if self.test and self.evaluate_on == 'test':
-                pool = self.test_steps
-            elif self.test and self.evaluate_on == 'validation':
-                pool = self.validation_steps
+            key = 'test' if (self.test and self.evaluate_on == 'test') else \
+                ('validation' if (self.test and self.evaluate_on == 'validation') else 'train')
+            if self.uses_profiles:
+                # random draws are made on the device (torch generator): no host round trip per reset
+                pool = self._pools[key]
+                self.steps_dev.copy_(pool[t.randint(len(pool), (B,), generator=self._gen, device=dev)])
             else:
-                pool = self.train_steps
-            step = self.np_random.choice(pool, size=B) if self.uses_profiles else np.zeros(B, int)
-        step = np.broadcast_to(np.asarray(step, dtype=np.int64), (B,))
-        if self.uses_profiles:
-            assert (step < len(self.profiles[('load', 'q_mvar')])).all()   # :335
-        self.current_simbench_step = step.copy()
-        self.steps_dev.copy_(t.as_tensor(step.astype(np.int32)))
-        noise = options.get('noise')
+                self.steps_dev.zero_()
+            self.current_simbench_step = None
+        else:
+            step = np.broadcast_to(np.asarray(step, dtype=np.int64), (B,))
+            if self.uses_profiles:
+                assert (step < len(self.profiles[('load', 'q_mvar')])).all()   # :335
+            self.current_simbench_step = step.copy()
+            self.steps_dev.copy_(t.as_tensor(step.astype(np.int32)))
+
+        def as_dev(a):
+            if t.is_tensor(a):
+                return a.to(device=dev, dtype=t.float64).contiguous()
+            return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        noise_t = options.get('noise')
         data_distr = self.test_data if self.test else self.train_data
-        if noise is None and self.n_noise and (data_distr == 'noisy_simbench' or self.noise_factor):
+        if noise_t is None and self.n_noise and (data_distr == 'noisy_simbench' or self.noise_factor):
             nf = self.noise_factor
-            noise = self.np_random.random((B, self.n_noise)) * nf * 2 + (1 - nf)   # :354-355
-        uniform = options.get('uniform')
-        if uniform is None and self.n_uniform:
-            uniform = self.np_random.random((B, self.n_uniform))
-        noise_t = t.as_tensor(np.ascontiguousarray(noise, dtype=np.float64)).to(self.device) if noise is not None else None
-        uni_t = t.as_tensor(np.ascontiguousarray(uniform, dtype=np.float64)).to(self.device) if uniform is not None else None
+            noise_t = t.rand(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64) * (nf * 2) \
+                + (1 - nf)                                                     # :354-355
+        elif noise_t is not None:
+            noise_t = as_dev(noise_t)
+        uni_t = options.get('uniform')
+        if uni_t is None and self.n_uniform:
+            uni_t = t.rand(B, self.n_uniform, generator=self._gen, device=dev, dtype=t.float64)
+        elif uni_t is not None:
+            uni_t = as_dev(uni_t)
         with t.cuda.device(self.device):
             capi.check(capi.lib().opfx_reset(
                 self._env_handle, B, self.steps_dev.data_ptr(),
@@ -665,9 +685,9 @@ class BatchedOpfEnv:
         act = options.get('initial_action')
         if act is None:
             if self.initial_action == 'random':                            # :201-203
-                act = self.np_random.random((B, self.n_actions))
+                act = t.rand(B, self.n_actions, generator=self._gen, device=dev, dtype=t.float64)
             else:
-                act = np.full((B, self.n_actions), 0.5)                    # :206
+                act = self._center_action                                  # :206
         act = self._as_action(act)
         if self.pf_for_obs:                                                # :209-216
             self._launch_step(act, mode=0, with_initial_obj=False)
@@ -708,8 +728,10 @@ class BatchedOpfEnv:
                     means.append(obs[:, off:off + n].mean(dim=1, keepdim=True))
                 off += n
             parts += means
-        if self.add_time_obs and self.current_simbench_step is not None:
-            tobs = get_simbench_time_observation(self.current_simbench_step)   # intended semantics (defect D1)
+        if self.add_time_obs:
+            step = self.current_simbench_step if self.current_simbench_step is not None \
+                else self.steps_dev.cpu().numpy()
+            tobs = get_simbench_time_observation(step)                     # intended semantics (defect D1)
             parts = [t.as_tensor(tobs, dtype=t.float64, device=self.device)] + parts
         return t.cat(parts, dim=1) if len(parts) > 1 else obs
 
@@ -760,19 +782,20 @@ class BatchedOpfEnv:
 
     def sample_objective_penalty(self, num_samples):
         """One batched reset + random action + power flow (reward.py:181-196)."""
-        old = (self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev)
+        old = (self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev, self._center_action)
         self._alloc(int(num_samples))
         try:
             self.reset()
             self.step_count += 1
-            self._launch_step(self._as_action(self.np_random.random((self.B, self.n_actions))), mode=0)
+            self._launch_step(self.torch.rand(self.B, self.n_actions, generator=self._gen, device=self.device,
+                                              dtype=self.torch.float64), mode=0)
             conv = self.buf['converged'].cpu().numpy()
             obj = self.buf['objective'].cpu().numpy().copy()
             pen = self.buf['penalties'][:, :self.n_constraints].sum(dim=1).cpu().numpy().copy()
             obj[~conv] = np.nan
             pen[~conv] = np.nan
         finally:
-            self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev = old
+            self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev, self._center_action = old
         return obj, pen
 
     def close(self):

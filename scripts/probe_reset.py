@@ -1,0 +1,22 @@
+"""Developer probe: reset()+step() episode throughput and the share of each part."""
+import sys, os, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+from opfgym_amd import envs
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+cls = getattr(envs, sys.argv[2]) if len(sys.argv) > 2 else envs.VoltageControl
+env = cls(simbench_network_name='1-MV-urban--0-sw', batch_size=B, device='cuda:0', seed=0)
+actions = torch.rand(B, env.n_actions, device='cuda:0', dtype=torch.float64)
+for _ in range(3):
+    env.reset(); env.step(actions)
+torch.cuda.synchronize()
+def timeit(fn, n=20):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+t_reset = timeit(lambda: env.reset())
+t_step = timeit(lambda: env.step(actions))
+t_both = timeit(lambda: (env.reset(), env.step(actions)))
+print(f'{cls.__name__} B={B}: reset {t_reset:.3f} ms, step {t_step:.3f} ms, reset+step {t_both:.3f} ms '
+      f'-> {B/t_both*1e3:.3e} episodes/s  (nx={env.nx}, n_uniform={env.n_uniform})')
