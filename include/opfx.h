@@ -305,9 +305,11 @@ typedef struct opfx_profile_desc {
  *   OPFX_OP_NEG         x[dst] = -x[a]
  *   OPFX_OP_UNIFORM     x[dst] = (c0 + u*(c1-c0)) / c2,  u = uniform[b, a+j]
  *                       (opf_env.py:278-284; here `a` indexes the draw vector)
+ *   OPFX_OP_NORMAL      x[dst] = c0 + c1*z,  z = normal[b, a+j]   (opf_env.py:311-312)
+ *   OPFX_OP_CLIP        x[dst] = min(max(x[a], c0), c1)           (opf_env.py:313-314)
  */
 enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
-       OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4 };
+       OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6 };
 typedef struct opfx_reset_desc {
   int32_t n_tables;
   const opfx_profile_desc* tables;
@@ -319,17 +321,33 @@ typedef struct opfx_reset_desc {
   int32_t n_uniform;         /* uniform draws consumed per instance          */
   int32_t init_off;          /* offset into consts of an nx-long row template copied
                                 into x before the tables are applied, or -1  */
+  int32_t n_normal;          /* standard-normal draws consumed per instance  */
 } opfx_reset_desc;
 
 int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d);
 
-/* step_idx [B] int32: SimBench time step per instance; noise [B, n_noise] or
- * NULL: multiplicative noise factors, one per profile column in table order
- * (opf_env.py:352-356; the caller draws them so that runs are reproducible
- * from the caller's RNG); uniform [B, n_uniform] or NULL: U[0,1) draws consumed
- * by OPFX_OP_UNIFORM ops in order.  Fills x [B,nx]. */
-int opfx_reset(opfx_env* env, int64_t B, const int32_t* step_idx,
-               const double* noise, const double* uniform, double* x, void* stream);
+/* Random numbers are INPUTS (the caller draws them, on the device or from a seeded host
+ * generator, so that runs are reproducible from the caller's RNG):
+ *   step_idx [B] int32   SimBench time step per instance;
+ *   noise [B,n_noise] or NULL, one value per profile column in table order:
+ *       normal_noise_factor == 0: multiplicative factors (opf_env.py:354-356);
+ *       normal_noise_factor  > 0: standard-normal draws z, value += |value|*factor*z (:359-360);
+ *   interp [B,n_tables] or NULL: r in [0,1) per table, value = row(step)*r + row(step+1)*(1-r)
+ *       for step < n_steps-1 (`interpolate_steps`, opf_env.py:345-349);
+ *   uniform [B,n_uniform], normal [B,n_normal]: draws consumed by the OPFX_OP_UNIFORM /
+ *       OPFX_OP_NORMAL ops in order.
+ * Fills x [B,nx]. */
+typedef struct opfx_reset_io {
+  const int32_t* step_idx;
+  const double* noise;
+  const double* interp;
+  const double* uniform;
+  const double* normal;
+  double normal_noise_factor;
+  double* x;
+} opfx_reset_io;
+
+int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);
 
 /* Timing helper for bench.py: runs `reps` back-to-back opfx_step launches on
  * `stream` between two hipEvents recorded on that stream and returns the

@@ -81,6 +81,7 @@ class OpsBuilder:
         self.store = store
         self.ops = []          # (code, dst, a, n, c0, c1, c2) with c* numpy vectors or None
         self.n_uniform = 0
+        self.n_normal = 0
 
     def _emit(self, code, dst, a, c0=None, c1=None, c2=None):
         """dst/a: arrays of slots; split into runs where both are contiguous."""
@@ -128,6 +129,17 @@ class OpsBuilder:
         src = self.n_uniform + np.arange(len(rows))
         self.n_uniform += len(rows)
         self._emit(capi.OP_UNIFORM, dst, src, c0=lo, c1=hi, c2=scale)
+
+
+def _normal_and_clip(ops, table, col, idxs, mean, std, lo, hi):
+    """opf_env.py:311-315: N(mean, std) per row clipped to [lo, hi]; consumes len(idxs)
+    standard-normal draws of the instance's draw vector, in order."""
+    rows = ops.store.rows(table, idxs)
+    dst = ops._all(table, col, rows, True)
+    src = ops.n_normal + np.arange(len(rows))
+    ops.n_normal += len(rows)
+    ops._emit(capi.OP_NORMAL, dst, src, c0=mean, c1=std)
+    ops._emit(capi.OP_CLIP, dst, dst, c0=lo, c1=hi)
 
 
 def _keep(lst, arr, kind):
@@ -274,14 +286,15 @@ class BatchedOpfEnv:
         self.ops = OpsBuilder(self.store)
         self.tables = []
         modes = {self.train_data, self.test_data}
-        if modes - {'simbench', 'noisy_simbench', 'full_uniform'}:
-            raise NotImplementedError(f'data distributions {modes} are not supported yet')
+        if modes - {'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean'}:
+            raise NotImplementedError(f'data distributions {modes} are not supported yet ("mixed" draws a '
+                                      f'different distribution per reset)')
         self.noise_factor = float(self.sampling_params.get('noise_factor', 0.0))
         if 'noisy_simbench' in modes and 'noise_factor' not in self.sampling_params:
             self.noise_factor = 0.1                                        # opf_env.py:318 default
-        if self.sampling_params.get('noise_distribution', 'uniform') != 'uniform' or \
-                self.sampling_params.get('interpolate_steps'):
-            raise NotImplementedError('only uniform multiplicative noise is supported yet')
+        self.noise_distribution = self.sampling_params.get('noise_distribution', 'uniform')
+        assert self.noise_distribution in ('uniform', 'normal')
+        self.interpolate_steps = bool(self.sampling_params.get('interpolate_steps', False))
         self.uses_profiles = bool(modes & {'simbench', 'noisy_simbench'})
         if self.uses_profiles:
             for key in self.profiles.keys():                               # opf_env.py:339-372
@@ -293,9 +306,26 @@ class BatchedOpfEnv:
                 slots = self.store.slots(unit, col, df.columns, dynamic=True)
                 self.tables.append(dict(rel=rel, typ=typ, peak=peak, slot=slots,
                                         col_min=df.min().to_numpy(float), col_max=df.max().to_numpy(float)))
+        if len(modes) > 1 and modes & {'full_uniform', 'normal_around_mean'}:
+            raise NotImplementedError('different train/test distributions are only supported among the '
+                                      'simbench variants')
+        if 'normal_around_mean' in modes:                                  # opf_env.py:286-315
+            if self.sampling_params.get('truncated'):
+                raise NotImplementedError('truncated normal sampling (scipy.stats.truncnorm) is not supported')
+            rel = self.sampling_params.get('relative_std')
+            for unit, col, idxs in self.state_keys:
+                if 'res_' in unit or 'poly_cost' in unit:
+                    continue
+                df = self.net[unit]
+                rows = self.store.rows(unit, idxs)
+                sc = df['scaling'].to_numpy(float)[rows]
+                hi = df[f'max_max_{col}'].to_numpy(float)[rows] / sc
+                lo = df[f'min_min_{col}'].to_numpy(float)[rows] / sc
+                diff = hi - lo
+                std = rel * diff if rel else df[f'std_dev_{col}'].to_numpy(float)[rows]
+                _normal_and_clip(self.ops, unit, col, idxs, df[f'mean_{col}'].to_numpy(float)[rows],
+                                 std * diff, lo, hi)                         # (std * diff as at :312)
         if 'full_uniform' in modes:
-            if len(modes) > 1:
-                raise NotImplementedError('mixing full_uniform with simbench data is not supported yet')
             for unit, col, idxs in self.state_keys:                        # opf_env.py:253-284
                 if 'res_' in unit:
                     continue
@@ -570,9 +600,11 @@ class BatchedOpfEnv:
         r.op_c0, r.op_c1, r.op_c2 = (_keep(keep, v, 'i') for v in (c0, c1, c2))
         r.n_consts, r.consts = len(consts), _keep(keep, consts, 'd')
         r.n_uniform = self.ops.n_uniform
+        r.n_normal = self.ops.n_normal
         r.init_off = 0
         capi.check(capi.lib().opfx_env_set_reset(self._env_handle, C.byref(r)), 'opfx_env_set_reset')
         self.n_uniform = self.ops.n_uniform
+        self.n_normal = self.ops.n_normal
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, B):
@@ -662,25 +694,43 @@ class BatchedOpfEnv:
             if t.is_tensor(a):
                 return a.to(device=dev, dtype=t.float64).contiguous()
             return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
-        noise_t = options.get('noise')
         data_distr = self.test_data if self.test else self.train_data
-        if noise_t is None and self.n_noise and (data_distr == 'noisy_simbench' or self.noise_factor):
-            nf = self.noise_factor
+        noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params)
+        nf = self.noise_factor if noisy else 0.0
+        normal_noise = noisy and self.noise_distribution == 'normal'
+        noise_t = options.get('noise')
+        if noise_t is not None:
+            noise_t = as_dev(noise_t)          # uniform mode: factors; normal mode: standard-normal draws
+        elif noisy and normal_noise:
+            noise_t = t.randn(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64)   # :359-360
+        elif noisy and nf:
             noise_t = t.rand(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64) * (nf * 2) \
                 + (1 - nf)                                                     # :354-355
-        elif noise_t is not None:
-            noise_t = as_dev(noise_t)
+        interp_t = options.get('interp')
+        if interp_t is not None:
+            interp_t = as_dev(interp_t)
+        elif self.interpolate_steps and self.uses_profiles:
+            interp_t = t.rand(B, len(self.tables), generator=self._gen, device=dev, dtype=t.float64)   # :348
         uni_t = options.get('uniform')
         if uni_t is None and self.n_uniform:
             uni_t = t.rand(B, self.n_uniform, generator=self._gen, device=dev, dtype=t.float64)
         elif uni_t is not None:
             uni_t = as_dev(uni_t)
+        nrm_t = options.get('normal')
+        if nrm_t is None and self.n_normal:
+            nrm_t = t.randn(B, self.n_normal, generator=self._gen, device=dev, dtype=t.float64)
+        elif nrm_t is not None:
+            nrm_t = as_dev(nrm_t)
+        rio = capi.ResetIO()
+        rio.step_idx = self.steps_dev.data_ptr()
+        rio.noise = noise_t.data_ptr() if noise_t is not None else None
+        rio.interp = interp_t.data_ptr() if interp_t is not None else None
+        rio.uniform = uni_t.data_ptr() if uni_t is not None else None
+        rio.normal = nrm_t.data_ptr() if nrm_t is not None else None
+        rio.normal_noise_factor = float(nf) if normal_noise else 0.0
+        rio.x = self.x.data_ptr()
         with t.cuda.device(self.device):
-            capi.check(capi.lib().opfx_reset(
-                self._env_handle, B, self.steps_dev.data_ptr(),
-                noise_t.data_ptr() if noise_t is not None else None,
-                uni_t.data_ptr() if uni_t is not None else None, self.x.data_ptr(), capi._stream()),
-                'opfx_reset')
+            capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
         self.step_count.zero_()
         act = options.get('initial_action')
         if act is None:

@@ -20,7 +20,7 @@ PQ, PV, REF = 1, 2, 3
 SRC_X, SRC_RESULT = 0, 1
 COST_UNIT, COST_EXT_GRID, COST_GEN = 0, 1, 2
 REWARD_SUMMATION, REWARD_REPLACEMENT, REWARD_PARAMETERIZED, REWARD_ONLY_OBJECTIVE = 0, 1, 2, 3
-OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM = 0, 1, 2, 3, 4
+OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP = 0, 1, 2, 3, 4, 5, 6
 
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
@@ -108,7 +108,13 @@ class ResetDesc(C.Structure):
                 ('n_ops', C.c_int32), ('op_code', _pi), ('op_dst', _pi), ('op_a', _pi),
                 ('op_n', _pi), ('op_c0', _pi), ('op_c1', _pi), ('op_c2', _pi),
                 ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32),
-                ('init_off', C.c_int32)]
+                ('init_off', C.c_int32), ('n_normal', C.c_int32)]
+
+
+class ResetIO(C.Structure):
+    _fields_ = [('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
+                ('uniform', C.c_void_p), ('normal', C.c_void_p), ('normal_noise_factor', C.c_double),
+                ('x', C.c_void_p)]
 
 
 _lib = None
@@ -155,7 +161,7 @@ def lib():
     L.opfx_env_destroy.restype = None
     L.opfx_step.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32, vp]
     L.opfx_env_set_reset.argtypes = [vp, C.POINTER(ResetDesc)]
-    L.opfx_reset.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    L.opfx_reset.argtypes = [vp, C.c_int64, C.POINTER(ResetIO), vp]
     L.opfx_time_steps.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32,
                                   vp, C.POINTER(C.c_float)]
     _lib = L

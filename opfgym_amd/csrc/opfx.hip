@@ -1122,28 +1122,41 @@ struct DevTable {
 };
 constexpr int MAX_TABLES = 8;
 struct DevReset {
-  int n_tables, n_ops, n_uniform, n_noise, nx, init_off;
+  int n_tables, n_ops, n_uniform, n_normal, n_noise, nx, init_off;
   DevTable tab[MAX_TABLES];
   const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2;
   const double* consts;
 };
 
-__global__ __launch_bounds__(256) void k_reset(DevReset R, const int* step_idx, const double* noise,
-                                               const double* uniform, double* x, long long B) {
+struct ResetIO {
+  const int* step_idx;
+  const double *noise, *interp, *uniform, *normal;
+  double normal_noise_factor;
+  double* x;
+};
+
+__global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long B) {
   // one wave per instance, 4 instances per workgroup
   const int lane = threadIdx.x & 63;
   const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nw = (long long)gridDim.x * 4;
   for (long long b = w; b < B; b += nw) {
-    double* xr = x + b * R.nx;
-    const int step = step_idx[b];
+    double* xr = io.x + b * R.nx;
+    const int step = io.step_idx[b];
     if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) xr[j] = R.consts[R.init_off + j];
     for (int t = 0; t < R.n_tables; ++t) {
       const DevTable& T = R.tab[t];
       const double* row = T.rel + (long long)step * T.n_types;
+      const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
+      const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
       for (int j = lane; j < T.n_cols; j += 64) {
         double v = row[T.typ[j]] * T.peak[j];                                      // :343
-        if (noise) v = v * noise[b * R.n_noise + T.noise_off + j];                  // :354-356
+        if (interp) v = v * rr + (row[T.n_types + T.typ[j]] * T.peak[j]) * (1.0 - rr);   // :347-349
+        if (io.noise) {
+          const double nz = io.noise[b * R.n_noise + T.noise_off + j];
+          if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz;   // :359-360
+          else v = v * nz;                                                          // :354-356
+        }
         v = fmin(fmax(v, T.col_min[j]), T.col_max[j]);                              // :364-369
         xr[T.slot[j]] = v;                                                          // :371-372
       }
@@ -1161,7 +1174,9 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const int* step_idx, 
         else if (code == OPFX_OP_AFFINE) v = xr[a + j] * c0[j] + c1[j];
         else if (code == OPFX_OP_SQRT_DIFF) { const double s = c0[j], pz = xr[a + j]; v = sqrt(s * s - pz * pz); }
         else if (code == OPFX_OP_NEG) v = -xr[a + j];
-        else { const double u = uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
+        else if (code == OPFX_OP_UNIFORM) { const double u = io.uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
+        else if (code == OPFX_OP_NORMAL) v = c0[j] + c1[j] * io.normal[b * R.n_normal + a + j];
+        else v = fmin(fmax(xr[a + j], c0[j]), c1[j]);
         xr[dst + j] = v;
       }
     }
@@ -1540,6 +1555,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   R = DevReset{};
   R.n_tables = d->n_tables; R.n_ops = d->n_ops; R.n_uniform = d->n_uniform; R.nx = env->de.nx;
   R.init_off = d->init_off;
+  R.n_normal = d->n_normal;
   if (d->init_off >= 0 && d->init_off + R.nx > d->n_consts) { opfx_set_error("opfx_env_set_reset: init template out of range"); return OPFX_ERR_INVALID; }
   int rc = OPFX_OK, noise_off = 0;
   for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
@@ -1570,18 +1586,18 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   return OPFX_OK;
 }
 
-extern "C" int opfx_reset(opfx_env* env, int64_t B, const int32_t* step_idx, const double* noise,
-                          const double* uniform, double* x, void* stream) {
-  if (!env || !env->has_reset || !step_idx || !x || B < 0) {
+extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream) {
+  if (!env || !env->has_reset || !io || !io->step_idx || !io->x || B < 0) {
     opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
     return OPFX_ERR_INVALID;
   }
-  if (env->dr.n_uniform > 0 && !uniform) { opfx_set_error("opfx_reset: uniform draws required"); return OPFX_ERR_INVALID; }
+  if (env->dr.n_uniform > 0 && !io->uniform) { opfx_set_error("opfx_reset: uniform draws required"); return OPFX_ERR_INVALID; }
+  if (env->dr.n_normal > 0 && !io->normal) { opfx_set_error("opfx_reset: normal draws required"); return OPFX_ERR_INVALID; }
   if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(env->ctx->device));
   const int grid = (int)std::min<long long>((B + 3) / 4, (long long)env->ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, step_idx,
-                     noise, uniform, x, (long long)B);
+  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x};
+  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, r, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }

@@ -23,20 +23,32 @@ from . import pf_oracle
 # ---------------------------------------------------------------------------
 # E2: OpfEnv._set_simbench_state  (opf_env.py:317-372)
 # ---------------------------------------------------------------------------
-def set_simbench_state(net, profiles, step, noise=None, col_range=None):
-    """Gather profile row `step` for every profile table, apply multiplicative
-    noise (one factor per column, tables in dict order, opf_env.py:352-356),
-    clip to the column's min/max over the whole profile (:364-369) and write
-    the unit table column (:371-372).  `noise` is the flat vector of factors."""
+def set_simbench_state(net, profiles, step, noise=None, col_range=None, interp=None,
+                       normal_noise_factor=0.0):
+    """Gather profile row `step` for every profile table, optionally interpolate
+    towards the next step (`interp`: one r per non-empty table, opf_env.py:345-349),
+    apply noise — `noise` is the flat vector of multiplicative factors (:352-356),
+    or of standard-normal draws z when `normal_noise_factor` > 0 (value +
+    |value|·factor·z, :357-360) — clip to the column's min/max over the whole
+    profile (:364-369) and write the unit table column (:371-372)."""
     off = 0
+    k_tab = 0
+    total = len(profiles[('load', 'q_mvar')])
     for (unit, col), df in profiles.items():
         n = df.shape[1]
         if not n:
             continue
         idx = net[unit].index
         data = df.loc[step, idx].to_numpy(float)
+        if interp is not None and step < total - 1:
+            r = interp[k_tab]
+            data = data * r + df.loc[step + 1, idx].to_numpy(float) * (1 - r)
+        k_tab += 1
         if noise is not None:
-            data = data * noise[off:off + n]
+            if normal_noise_factor > 0:
+                data = data + np.abs(data) * normal_noise_factor * noise[off:off + n]
+            else:
+                data = data * noise[off:off + n]
         off += n
         lo, hi = col_range[(unit, col)] if col_range else (df.min()[idx].to_numpy(float),
                                                           df.max()[idx].to_numpy(float))
@@ -64,6 +76,22 @@ def sample_from_range(net, unit, col, idxs, draws):
     if 'scaling' in df:
         r = r / df['scaling'].loc[idxs].to_numpy(float)
     net[unit].loc[idxs, col] = r
+
+
+def sample_normal(net, state_keys, zdraws, relative_std=None):
+    """opf_env.py:286-315 (`truncated=False`): N(mean, std·diff) clipped to the scaled
+    min_min/max_max range; `zdraws` are standard-normal numbers consumed in order."""
+    for unit, col, idxs in state_keys:
+        if 'res_' in unit or 'poly_cost' in unit:
+            continue
+        df = net[unit].loc[idxs]
+        hi = (df[f'max_max_{col}'] / df.scaling).to_numpy(float)
+        lo = (df[f'min_min_{col}'] / df.scaling).to_numpy(float)
+        diff = hi - lo
+        std = relative_std * diff if relative_std else df[f'std_dev_{col}'].to_numpy(float)
+        z = np.array([next(zdraws) for _ in range(len(idxs))])
+        vals = df[f'mean_{col}'].to_numpy(float) + (std * diff) * z
+        net[unit].loc[idxs, col] = np.clip(vals, lo, hi)
 
 
 def tail_voltage_control(net, draws, market_based):
@@ -277,7 +305,7 @@ class EnvOracle:
                  autoscale_actions=True, diff_action_step_size=None, clipped_action_penalty=0.0,
                  diff_objective=False, add_mean_obs=False, pf_for_obs=False, steps_per_episode=1,
                  n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True,
-                 data='simbench', state_keys=None):
+                 data='simbench', state_keys=None, sampling_params=None):
         self.base_net = net
         self.net = copy.deepcopy(net)
         self.act_keys, self.obs_keys = act_keys, obs_keys
@@ -290,6 +318,7 @@ class EnvOracle:
         self.n1, self.ncp = n_minus_one_keys, not_converged_penalty
         self.enforce_q_lims = enforce_q_lims
         self.data, self.state_keys = data, state_keys
+        self.sampling_params = sampling_params or {}
         self.initial_obj = 0.0
 
     def solve(self):
@@ -299,7 +328,7 @@ class EnvOracle:
         except pf_oracle.LoadflowNotConverged:
             return False
 
-    def reset(self, step, uniform=(), noise=None, initial_action=None):
+    def reset(self, step, uniform=(), noise=None, initial_action=None, interp=None, normal=()):
         self.net = copy.deepcopy(self.base_net)
         self.step_in_episode = 0
         draws = iter(np.asarray(uniform, float))
@@ -307,8 +336,13 @@ class EnvOracle:
             for unit, col, idxs in self.state_keys:
                 if 'res_' not in unit:
                     sample_from_range(self.net, unit, col, idxs, draws)
+        elif self.data == 'normal_around_mean':                             # :240-241
+            sample_normal(self.net, self.state_keys, iter(np.asarray(normal, float)),
+                          self.sampling_params.get('relative_std'))
         else:
-            set_simbench_state(self.net, self.profiles, step, noise, self.ranges)
+            nnf = self.sampling_params.get('noise_factor', 0.1) \
+                if self.sampling_params.get('noise_distribution') == 'normal' else 0.0
+            set_simbench_state(self.net, self.profiles, step, noise, self.ranges, interp, nnf)
         self.tail(self.net, draws)
         n_act = sum(len(i) for _, _, i in self.act_keys)
         act = np.full(n_act, 0.5) if initial_action is None else initial_action   # opf_env.py:201-207

@@ -44,14 +44,27 @@ def oracle_env(name, env=None):
         clipped_action_penalty=env.clipped_action_penalty, diff_objective=env.diff_objective,
         add_mean_obs=env.add_mean_obs, pf_for_obs=env.pf_for_obs,
         steps_per_episode=env.steps_per_episode, n_minus_one_keys=env.n_minus_one_keys,
-        not_converged_penalty=env.not_converged_penalty, data=env.train_data, state_keys=env.state_keys)
+        not_converged_penalty=env.not_converged_penalty, data=env.train_data, state_keys=env.state_keys,
+        sampling_params=env.sampling_params)
 
 
 def noise_factors(name, raw):
     """Recorded raw U[0,1) draws -> multiplicative factors (opf_env.py:354-355);
     None when the scenario samples without noise (factor exactly 1.0)."""
     kwargs = SCENARIOS[name][1]
-    nf = (kwargs.get('sampling_params') or {}).get('noise_factor', 0.0)
+    sp = kwargs.get('sampling_params') or {}
+    nf = sp.get('noise_factor', 0.0)
     if not nf or raw.size == 0:
         return None
+    if sp.get('noise_distribution') == 'normal':
+        return raw                       # standard-normal draws; the factor is applied by the sampler
     return raw * nf * 2 + (1 - nf)
+
+
+def draws(g, k, prefix=''):
+    """interp / normal draw vectors of sample k (absent in older fixtures)."""
+    out = {}
+    for key in ('interp', 'normal'):
+        arr = g.get(prefix + key)
+        out[key] = arr[k] if arr is not None and arr.shape[1] else None
+    return out

@@ -19,7 +19,7 @@ class RecordingRNG:
 
     def random(self, size=None):
         u = self._rng.random(size)
-        self.log.append(('random', np.array(u, copy=True)))
+        self.log.append(('random' if size is not None else 'random_scalar', np.array(u, copy=True)))
         return u
 
     def uniform(self, low=0.0, high=1.0, size=None):
@@ -34,7 +34,15 @@ class RecordingRNG:
         return self._rng.choice(a, size=size)
 
     def normal(self, loc=0.0, scale=1.0, size=None):
-        return self._rng.normal(loc, scale, size)
+        # numpy: normal(loc, scale) = loc + scale * standard_normal()
+        loc, scale = np.asarray(loc, dtype=float), np.asarray(scale, dtype=float)
+        if size is None:
+            size = np.broadcast(loc, scale).shape
+        elif np.isscalar(size):
+            size = (int(size),)
+        z = self._rng.standard_normal(size)
+        self.log.append(('normal', np.array(z, copy=True)))
+        return loc + scale * z
 
 
 class Env:

@@ -101,6 +101,11 @@ def run(name):
         log = env.np_random.log
         uni = [u.ravel() for kind, u in log if kind == 'uniform']
         noise = [u.ravel() for kind, u in log if kind == 'random']
+        interp = [u.ravel() for kind, u in log if kind == 'random_scalar']
+        normal = [u.ravel() for kind, u in log if kind == 'normal']
+        normal_noise = (kwargs.get('sampling_params') or {}).get('noise_distribution') == 'normal'
+        if normal_noise:                # the noise of _set_simbench_state is drawn with normal()
+            noise, normal = normal, []
         action = rng.random(env.action_space.shape[0])
         if k == 0:
             action = np.clip(action * 1.6 - 0.3, -0.2, 1.2)        # exercise the [0,1] clipping
@@ -113,11 +118,15 @@ def run(name):
             push('fail_action', action)
             push('fail_uniform', np.concatenate(uni) if uni else np.zeros(0))
             push('fail_noise', np.concatenate(noise) if noise else np.zeros(0))
+            push('fail_interp', np.concatenate(interp) if interp else np.zeros(0))
+            push('fail_normal', np.concatenate(normal) if normal else np.zeros(0))
             continue
         done += 1
         push('step', step)
         push('uniform', np.concatenate(uni) if uni else np.zeros(0))
         push('noise', np.concatenate(noise) if noise else np.zeros(0))
+        push('interp', np.concatenate(interp) if interp else np.zeros(0))
+        push('normal', np.concatenate(normal) if normal else np.zeros(0))
         push('obs_reset', obs0)
         for key, val in snap.items():
             push(key, val)

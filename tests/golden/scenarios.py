@@ -35,6 +35,14 @@ SCENARIOS = {
         sampling_params=dict(noise_factor=0.2)), 4, 12),
     'vc_full_uniform': ('VoltageControl', dict(
         simbench_network_name='mv-small', train_data='full_uniform', test_data='full_uniform'), 4, 13),
+    'vc_normal_noise': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='noisy_simbench',
+        sampling_params=dict(noise_factor=0.15, noise_distribution='normal')), 4, 15),
+    'vc_interpolate': ('VoltageControl', dict(
+        simbench_network_name='mv-small', sampling_params=dict(interpolate_steps=True)), 4, 16),
+    'vc_normal_mean': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='normal_around_mean', test_data='normal_around_mean',
+        sampling_params=dict(relative_std=0.3)), 4, 17),
     # multi-step episodes with incremental actions (opf_env.py:451-458, 406-414)
     'vc_multistep_diff': ('VoltageControl', dict(
         simbench_network_name='mv-small', steps_per_episode=3, diff_action_step_size=0.2), 3, 14),

@@ -51,8 +51,9 @@ def test_env_matches_reference_golden(name):
     noise = None
     if noise_factors(name, g['noise'][0]) is not None:
         noise = np.stack([noise_factors(name, g['noise'][k]) for k in range(n)])
+    extra = {k: g[k] for k in ('interp', 'normal') if k in g and g[k].shape[1]}
     obs0, _ = env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None,
-                                 'noise': noise})
+                                 'noise': noise, **extra})
     for key in g:
         if key.startswith('tab__'):
             _, tbl, col = key.split('__')
@@ -73,7 +74,8 @@ def test_env_matches_reference_golden(name):
         noise2 = None
         if noise_factors(name, g['fail_noise'][0]) is not None:
             noise2 = np.stack([noise_factors(name, g['fail_noise'][k]) for k in range(m)])
-        env2.reset(options={'step': g['fail_step'], 'noise': noise2,
+        extra2 = {k: g['fail_' + k] for k in ('interp', 'normal') if 'fail_' + k in g and g['fail_' + k].shape[1]}
+        env2.reset(options={'step': g['fail_step'], 'noise': noise2, **extra2,
                             'uniform': g['fail_uniform'] if g['fail_uniform'].shape[1] else None})
         obs, reward, term, trunc, info = env2.step(g['fail_action'])
         assert not _np(info['converged']).any()

@@ -7,7 +7,7 @@ penalties 1e-9, power-flow results 1e-9 (both sides use the same oracle solver).
 import numpy as np
 import pytest
 
-from env_cases import EPISODE_STEPS, SINGLE_STEP, golden, noise_factors, oracle_env, product_env
+from env_cases import EPISODE_STEPS, SINGLE_STEP, draws, golden, noise_factors, oracle_env, product_env
 
 TAB_TOL = 1e-12
 
@@ -22,7 +22,9 @@ def test_oracle_matches_reference_golden(name):
     n = len(g['step'])
     for k in range(n):
         noise = noise_factors(name, g['noise'][k])
-        obs0 = orc.reset(int(g['step'][k]), g['uniform'][k], noise)
+        d = draws(g, k)
+        obs0 = orc.reset(int(g['step'][k]), g['uniform'][k], noise, interp=d['interp'],
+                         normal=d['normal'] if d['normal'] is not None else ())
         for key in g:
             if key.startswith('tab__'):
                 _, tbl, col = key.split('__')
@@ -48,7 +50,9 @@ def test_oracle_matches_reference_golden(name):
     if 'fail_step' in g:
         for k in range(len(g['fail_step'])):
             noise = noise_factors(name, g['fail_noise'][k])
-            orc.reset(int(g['fail_step'][k]), g['fail_uniform'][k], noise)
+            d = draws(g, k, 'fail_')
+            orc.reset(int(g['fail_step'][k]), g['fail_uniform'][k], noise, interp=d['interp'],
+                      normal=d['normal'] if d['normal'] is not None else ())
             assert not orc.step(g['fail_action'][k])['converged']
 
 
