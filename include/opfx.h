@@ -307,9 +307,11 @@ typedef struct opfx_profile_desc {
  *                       (opf_env.py:278-284; here `a` indexes the draw vector)
  *   OPFX_OP_NORMAL      x[dst] = c0 + c1*z,  z = normal[b, a+j]   (opf_env.py:311-312)
  *   OPFX_OP_CLIP        x[dst] = min(max(x[a], c0), c1)           (opf_env.py:313-314)
+ *   OPFX_OP_DIV         x[dst] = x[a] / c0                        (load_shedding.py:137)
  */
 enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
-       OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6 };
+       OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6,
+       OPFX_OP_DIV = 7 };
 typedef struct opfx_reset_desc {
   int32_t n_tables;
   const opfx_profile_desc* tables;

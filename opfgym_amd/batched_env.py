@@ -116,6 +116,10 @@ class OpsBuilder:
         dst = self._all(table, col, rows, True)
         self._emit(capi.OP_SQRT_DIFF, dst, self._all(table, src_col, rows), c0=c0)
 
+    def div(self, table, col, src_col, c0, rows=None):
+        dst = self._all(table, col, rows, True)
+        self._emit(capi.OP_DIV, dst, self._all(table, src_col, rows), c0=c0)
+
     def neg(self, table, col, src_col, rows=None):
         dst = self._all(table, col, rows, True)
         self._emit(capi.OP_NEG, dst, self._all(table, src_col, rows))
@@ -485,10 +489,14 @@ class BatchedOpfEnv:
             if tbl == 'poly_cost' and col in _POLY_COEF:
                 for r in range(len(poly)):
                     price_slot.append(st.slot(tbl, col) + r); price_coef.append(r * 6 + _POLY_COEF[col])
-            elif tbl == 'pwl_cost' and col == 'cp1_eur_per_mw':                      # eco_dispatch.py:119-123
+            elif tbl == 'pwl_cost' and (col in getattr(self, 'pwl_price_columns', {}) or
+                                        (col == 'cp1_eur_per_mw' and not getattr(self, 'pwl_price_columns', None))):
+                # per-instance segment prices: by default the sampled price is the price of
+                # segment 0 (eco_dispatch.py:119-123); environments may name one column per segment
+                seg = getattr(self, 'pwl_price_columns', {}).get(col, 0)
                 for r in range(len(pwl)):
                     price_slot.append(st.slot(tbl, col) + r)
-                    price_coef.append(len(poly) * 6 + (r * nseg + 0) * 3 + 2)
+                    price_coef.append(len(poly) * 6 + (r * nseg + seg) * 3 + 2)
         # ---- constraints (constraints.py:70-128) ---------------------------------------
         con_ptr, con_src, con_min, con_max = [0], [], [], []
         c_as, c_pf, c_pp, c_cp, c_wc = [], [], [], [], []

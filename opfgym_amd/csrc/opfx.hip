@@ -1176,7 +1176,8 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long
         else if (code == OPFX_OP_NEG) v = -xr[a + j];
         else if (code == OPFX_OP_UNIFORM) { const double u = io.uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
         else if (code == OPFX_OP_NORMAL) v = c0[j] + c1[j] * io.normal[b * R.n_normal + a + j];
-        else v = fmin(fmax(xr[a + j], c0[j]), c1[j]);
+        else if (code == OPFX_OP_CLIP) v = fmin(fmax(xr[a + j], c0[j]), c1[j]);
+        else v = xr[a + j] / c0[j];
         xr[dst + j] = v;
       }
     }

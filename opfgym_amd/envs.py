@@ -204,6 +204,75 @@ class MaxRenewable(BatchedOpfEnv):
         ops.affine('sgen', 'max_p_mw', 'p_mw', self.net.sgen.scaling.to_numpy(float), 1e-6)     # :105
 
 
+class LoadShedding(BatchedOpfEnv):
+    """load_shedding.py:15-145: active power of the bigger loads and storages at sampled
+    shedding / storage prices; storage costs are piece-wise linear (efficiency)."""
+
+    def __init__(self, simbench_network_name='1-MV-comm--2-sw', gen_scaling=1.6, load_scaling=2.2,
+                 min_load_power=0.6, min_storage_power=1.0, max_p_exchange=8.0, storage_efficiency=0.95,
+                 *args, **kwargs):
+        self.min_load_power, self.min_storage_power = min_load_power, min_storage_power
+        self.max_p_exchange, self.storage_efficiency = max_p_exchange, storage_efficiency
+        net, profiles = self._define_opf(simbench_network_name, gen_scaling=gen_scaling,
+                                         load_scaling=load_scaling, *args, **kwargs)
+        nctrl_st = net.storage.index[~net.storage.controllable.astype(bool)]
+        obs_keys = [('sgen', 'p_mw', net.sgen.index), ('load', 'max_p_mw', net.load.index),
+                    ('load', 'q_mvar', net.load.index), ('storage', 'p_mw', nctrl_st),
+                    ('poly_cost', 'cp1_eur_per_mw', net.poly_cost.index),
+                    ('pwl_cost', 'cp1_eur_per_mw', net.pwl_cost.index)]                         # :46-53
+        state_keys = [('sgen', 'p_mw', net.sgen.index), ('load', 'p_mw', net.load.index),
+                      ('load', 'q_mvar', net.load.index), ('storage', 'p_mw', nctrl_st)]        # :56-63
+        act_keys = [('load', 'p_mw', net.load.index[net.load.controllable]),
+                    ('storage', 'p_mw', net.storage.index[net.storage.controllable.astype(bool)])]  # :66-67
+        # sampled price -> the two segment prices (points updated per reset, :134-141)
+        self.pwl_price_columns = {'neg_price_eur_per_mw': 0, 'pos_price_eur_per_mw': 1}
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, state_keys=state_keys, profiles=profiles, *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.load['controllable'] = net.load.max_max_p_mw > self.min_load_power                  # :79-82
+        net.load['min_min_p_mw'] = 0
+        net.load['min_p_mw'] = 0
+        max_storage_power = np.maximum(net.storage['min_min_p_mw'].abs(), net.storage['max_max_p_mw'].abs())
+        net.storage['min_p_mw'] = -max_storage_power                                            # :85-91
+        net.storage['max_p_mw'] = max_storage_power
+        net.storage['min_min_p_mw'] = -max_storage_power
+        net.storage['max_max_p_mw'] = max_storage_power
+        net.storage['controllable'] = net.storage.max_max_p_mw > self.min_storage_power
+        net.sgen['controllable'] = False
+        net.ext_grid['max_p_mw'] = self.max_p_exchange                                          # :96-97
+        net.ext_grid['min_p_mw'] = -np.inf
+        for idx in net.load.index[net.load.controllable]:                                       # :99-105
+            ppn.create_poly_cost(net, idx, 'load', cp1_eur_per_mw=0)
+        for idx in net.storage.index[net.storage.controllable.astype(bool)]:
+            ppn.create_pwl_cost(net, idx, 'storage', points=[[-1000, 0, 1], [0, 1000, 1]])
+        ppn.finalize(net)
+        net.poly_cost['min_cp1_eur_per_mw'] = -10                                               # :109-117
+        net.poly_cost['max_cp1_eur_per_mw'] = 0
+        net.pwl_cost['cp1_eur_per_mw'] = 0.0
+        net.pwl_cost['min_cp1_eur_per_mw'] = 0
+        net.pwl_cost['max_cp1_eur_per_mw'] = 2
+        net.ext_grid['vm_pu'] = 1.0
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        net = self.net
+        for tbl in ('poly_cost', 'pwl_cost'):                                                   # :127-130
+            df = net[tbl]
+            ops.uniform(tbl, 'cp1_eur_per_mw', df.index, df['min_cp1_eur_per_mw'].to_numpy(float),
+                        df['max_cp1_eur_per_mw'].to_numpy(float))
+        if len(net.pwl_cost):                                                                   # :133-141
+            ops.div('pwl_cost', 'pos_price_eur_per_mw', 'cp1_eur_per_mw', self.storage_efficiency)
+            ops.affine('pwl_cost', 'neg_price_eur_per_mw', 'cp1_eur_per_mw', self.storage_efficiency, 0.0)
+        ops.affine('load', 'max_p_mw', 'p_mw', net.load.scaling.to_numpy(float), 1e-9)           # :144
+        for unit_type in ('load', 'storage'):                                                   # :147-149
+            if len(net[unit_type]):
+                sc = net[unit_type].scaling.to_numpy(float)
+                ops.affine(unit_type, 'max_q_mvar', 'q_mvar', sc, 1e-9)
+                ops.affine(unit_type, 'min_q_mvar', 'q_mvar', sc, -1e-9)
+
+
 class SecurityConstrained(SecurityConstrainedOpfEnv):
     """examples/security_constrained.py:10-49: all sgen P as actions, loss cost at
     the slack, N-1 security for the listed lines."""

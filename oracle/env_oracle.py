@@ -125,10 +125,23 @@ def tail_max_renewable(net, draws):
     net.sgen['max_p_mw'] = net.sgen.p_mw * net.sgen.scaling + 1e-6
 
 
+def tail_load_shedding(net, draws, efficiency=0.95):
+    """load_shedding.py:122-149."""
+    sample_from_range(net, 'poly_cost', 'cp1_eur_per_mw', net.poly_cost.index, draws)
+    sample_from_range(net, 'pwl_cost', 'cp1_eur_per_mw', net.pwl_cost.index, draws)
+    for idx in net.pwl_cost.index:
+        price = net.pwl_cost.at[idx, 'cp1_eur_per_mw']
+        net.pwl_cost.at[idx, 'points'] = [[-1000, 0, price * efficiency], [0, 1000, price / efficiency]]
+    net.load['max_p_mw'] = net.load['p_mw'] * net.load.scaling + 1e-9
+    for unit in ('load', 'storage'):
+        net[unit]['max_q_mvar'] = net[unit].q_mvar * net[unit].scaling + 1e-9
+        net[unit]['min_q_mvar'] = net[unit].q_mvar * net[unit].scaling - 1e-9
+
+
 TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'QMarket': lambda net, d: tail_voltage_control(net, d, True),
          'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
-         'SecurityConstrained': lambda net, d: None}
+         'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding}
 
 
 # ---------------------------------------------------------------------------

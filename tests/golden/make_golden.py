@@ -29,7 +29,7 @@ from scenarios import EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
-       'SecurityConstrained': ref_sc.SecurityConstrained}
+       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding}
 
 
 def snapshot(net):

@@ -12,6 +12,8 @@ SCENARIOS = {
     'maxren_lv': ('MaxRenewable', dict(simbench_network_name='1-LV-rural1--0-sw',
                                        min_sgen_power=0.005, min_storage_power=0.005), 6, 6),
     'sc_hv_small': ('SecurityConstrained', dict(simbench_network_name='hv-small'), 5, 7),
+    'loadshed_mv_small': ('LoadShedding', dict(simbench_network_name='mv-small', min_load_power=0.8,
+                                               min_storage_power=0.3, max_p_exchange=6.0), 5, 18),
     # option coverage on the small MV grid
     'vc_replacement': ('VoltageControl', dict(
         simbench_network_name='mv-small', reward_function='replacement',
@@ -57,4 +59,4 @@ TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_m
            ('sgen', 'max_p_mw'), ('sgen', 'min_p_mw'), ('sgen', 'max_q_mvar'), ('sgen', 'min_q_mvar'),
            ('storage', 'max_q_mvar'), ('storage', 'min_q_mvar'),
            ('poly_cost', 'cq2_eur_per_mvar2'), ('poly_cost', 'cp1_eur_per_mw'),
-           ('pwl_cost', 'cp1_eur_per_mw')]
+           ('pwl_cost', 'cp1_eur_per_mw'), ('load', 'max_p_mw')]
