@@ -277,7 +277,8 @@ typedef struct opfx_step_io {
  * mode: 0 = full step; 1 = evaluate the current set-points without applying
  * `action` (`apply_action=False`, opf_env.py:197,386); 2 = apply `action` and
  * write the table observation only, no power flow (reset of an environment
- * whose observation needs no results, opf_env.py:207,218). */
+ * whose observation needs no results, opf_env.py:207,218); 3 = table observation of the
+ * current x only (no action, no power flow; multi_stage.py:56). */
 int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
               const opfx_solve_opts* opts, int32_t mode, void* stream);
 

@@ -146,6 +146,74 @@ def _normal_and_clip(ops, table, col, idxs, mean, std, lo, hi):
     ops._emit(capi.OP_CLIP, dst, dst, c0=lo, c1=hi)
 
 
+class Box:
+    """Minimal stand-in for gymnasium.spaces.Box (gymnasium is optional): bounds as
+    float64 arrays, `shape`, and `sample()`.  `BatchedOpfEnv` exposes the per-instance
+    spaces; a batch of actions is [B, *shape]."""
+
+    def __init__(self, low, high, shape=None, seed=None):
+        low, high = np.asarray(low, dtype=float), np.asarray(high, dtype=float)
+        if shape is None:
+            shape = np.broadcast(low, high).shape
+        self.low = np.broadcast_to(low, shape).copy()
+        self.high = np.broadcast_to(high, shape).copy()
+        self.shape = tuple(shape)
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self, batch=None):
+        shape = self.shape if batch is None else (batch,) + self.shape
+        return self.low + (self.high - self.low) * self._rng.random(shape)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape[-len(self.shape):] == self.shape and bool(((x >= self.low) & (x <= self.high)).all())
+
+
+def get_obs_and_state_space(net, obs_or_state_keys, add_time_obs=False, add_mean_obs=False, seed=None,
+                            bus_wise_obs=False):
+    """opf_env.py:720-803: observation/state bounds from the constraint columns of the net."""
+    lows, highs = [], []
+    if add_time_obs:                                                       # :728-732
+        lows.append(-np.ones(6)); highs.append(np.ones(6))
+    for unit_type, column, idxs in obs_or_state_keys:
+        if 'res_' in unit_type:
+            unit_type = unit_type[4:]                                      # :735-737
+        elif 'max_' in column or 'min_' in column:
+            column = column[4:]                                            # :738-740
+        df = net[unit_type]
+        if column == 'va_degree':                                          # :742-746
+            lo, hi = np.full(len(idxs), -30.0), np.full(len(idxs), 30.0)
+        else:
+            try:
+                lo = df[f'min_min_{column}' if f'min_min_{column}' in df.columns else f'min_{column}'] \
+                    .loc[idxs].to_numpy(float)
+                hi = df[f'max_max_{column}' if f'max_max_{column}' in df.columns else f'max_{column}'] \
+                    .loc[idxs].to_numpy(float)
+            except KeyError:                                               # :757-761 lines / trafos
+                lo = np.zeros(len(idxs))
+                hi = df[f'max_{column}'].loc[idxs].to_numpy(float) * 1.5
+            if column == 'vm_pu' or unit_type == 'ext_grid':               # :764-768
+                diff = hi - lo
+                lo, hi = lo - diff * 0.75, hi + diff * 0.75
+        if not ('min' in column or 'max' in column) and 'scaling' in df.columns:   # :770-778
+            sc = df['scaling'].loc[idxs].to_numpy(float)
+            lo, hi = lo / sc, hi / sc
+        if bus_wise_obs and unit_type == 'load':                           # :780-784
+            buses = sorted(set(df.bus))
+            bus_col = df.bus.loc[idxs].to_numpy() if len(idxs) == len(df) else df.bus.to_numpy()
+            lo = np.array([lo[bus_col == b].sum() for b in buses])
+            hi = np.array([hi[bus_col == b].sum() for b in buses])
+        if len(lo) > 0 and len(lo) == len(hi):
+            lows.append(lo); highs.append(hi)
+    if add_mean_obs:                                                       # :791-797
+        start = 1 if add_time_obs else 0
+        lows.append(np.array([np.mean(l) for l in lows[start:] if len(l) > 1]))
+        highs.append(np.array([np.mean(h) for h in highs[start:] if len(h) > 1]))
+    assert not any(np.isnan(l).any() for l in lows) and not any(np.isnan(h).any() for h in highs)
+    return Box(np.concatenate(lows) if lows else np.zeros(0), np.concatenate(highs) if highs else np.zeros(0),
+               seed=seed)
+
+
 def _keep(lst, arr, kind):
     a = np.ascontiguousarray(arr, dtype=np.float64 if kind == 'd' else np.int32)
     lst.append(a)
@@ -171,8 +239,7 @@ class BatchedOpfEnv:
         if objective_function is not None or power_flow_solver is not None:
             raise NotImplementedError('Python objective/solver callables cannot run inside the fused '
                                       'GPU step; use the reference OpfEnv with opfgym_amd.power_flow_solver')
-        if bus_wise_obs:
-            raise NotImplementedError('bus_wise_obs is not supported by the batched backend yet')
+        self.bus_wise_obs = bool(bus_wise_obs)
         self.net = net
         self.device_spec = device
         # opf_env.py:382 asserts on NaN actions; checking that on the host costs a device sync per
@@ -238,6 +305,11 @@ class BatchedOpfEnv:
         # sampling programme first: it decides which columns are per-instance
         self._build_sampling()
         self.n_actions = int(sum(len(idxs) for _, _, idxs in self.act_keys))
+        # spaces of ONE instance (opf_env.py:124-130)
+        self.observation_space = get_obs_and_state_space(net, self.obs_keys, add_time_obs, add_mean_obs,
+                                                         seed=seed, bus_wise_obs=self.bus_wise_obs)
+        self.state_space = get_obs_and_state_space(net, self.state_keys, seed=seed)
+        self.action_space = Box(0.0, 1.0, shape=(self.n_actions,), seed=seed)
         self._env_handle = None
         self.ctx = None
         self.current_simbench_step = None
@@ -778,20 +850,29 @@ class BatchedOpfEnv:
         """add_mean_obs / add_time_obs post-processing (opf_env.py:539-547)."""
         t = self.torch
         obs = self.buf['obs'][:, :self.n_obs_raw]
-        parts = [obs]
-        if self.add_mean_obs:
-            off, means = 0, []
-            for n in self.obs_segments:
-                if n > 1:
-                    means.append(obs[:, off:off + n].mean(dim=1, keepdim=True))
+        if self.bus_wise_obs or self.add_mean_obs:
+            segs, off = [], 0
+            for (unit, col, idxs), n in zip(self.obs_keys, self.obs_segments):
+                seg = obs[:, off:off + n]
                 off += n
-            parts += means
+                if self.bus_wise_obs and unit == 'load':                   # opf_env.py:535-536, 806-810
+                    buses = self.net.load.iloc[np.asarray(idxs)].bus.to_numpy()
+                    uniq, inv = np.unique(buses, return_inverse=True)
+                    agg = t.zeros(seg.shape[0], len(uniq), dtype=seg.dtype, device=seg.device)
+                    agg.index_add_(1, t.as_tensor(inv, device=seg.device), seg)
+                    seg = agg
+                segs.append(seg)
+            parts = list(segs)
+            if self.add_mean_obs:                                          # :539-542
+                parts += [sg.mean(dim=1, keepdim=True) for sg in segs if sg.shape[1] > 1]
+        else:
+            parts = [obs]
         if self.add_time_obs:
             step = self.current_simbench_step if self.current_simbench_step is not None \
                 else self.steps_dev.cpu().numpy()
             tobs = get_simbench_time_observation(step)                     # intended semantics (defect D1)
             parts = [t.as_tensor(tobs, dtype=t.float64, device=self.device)] + parts
-        return t.cat(parts, dim=1) if len(parts) > 1 else obs
+        return t.cat(parts, dim=1) if len(parts) > 1 else parts[0]
 
     # ------------------------------------------------------------------ helpers
     def get_current_actions(self, from_results_table=True):
@@ -875,3 +956,102 @@ class SecurityConstrainedOpfEnv(BatchedOpfEnv):
     def __init__(self, *args, n_minus_one_keys, not_converged_penalty=1, **kwargs):
         super().__init__(*args, n_minus_one_keys=n_minus_one_keys,
                          not_converged_penalty=not_converged_penalty, **kwargs)
+
+
+class MultiStageOpfEnv(BatchedOpfEnv):
+    """multi_stage.py:4-58 for the batch: after every step the instances that continue their
+    episode move on to the next SimBench time step (state re-sampled by the reset kernel at
+    step+1, `_sampling` tail included); crossing the train/test split truncates the episode."""
+
+    def __init__(self, *args, steps_per_episode: int = 4, **kwargs):
+        assert steps_per_episode > 1, 'At least two steps required for a multi-stage OPF.'
+        super().__init__(*args, steps_per_episode=steps_per_episode, **kwargs)
+        if self.pf_for_obs:
+            raise NotImplementedError('result observations are not supported by the multi-stage variant yet')
+
+    def attach_device(self):
+        super().attach_device()
+        t = self.torch
+        horizon = len(self.profiles[('load', 'q_mvar')])
+        kind = np.zeros(horizon + 1, dtype=np.int8)            # 0 train, 1 validation, 2 test
+        kind[np.asarray(self.validation_steps, dtype=int)] = 1
+        kind[np.asarray(self.test_steps, dtype=int)] = 2
+        self._step_kind = t.as_tensor(kind, device=self.device)
+        self._x_next = t.zeros_like(self.x)
+
+    def step(self, action):
+        t = self.torch
+        obs, reward, terminated, truncated, info = super().step(action)
+        new_step = (self.steps_dev + 1).long()
+        kind = self._step_kind[new_step.clamp(max=len(self._step_kind) - 1)]
+        crossing = (kind == 0) if self.test else (kind != 0)             # multi_stage.py:32-39
+        truncated = truncated | crossing
+        terminated = terminated | (self.step_count >= self.steps_per_episode)   # :42-43
+        cont = ~(terminated | truncated)
+        if bool(cont.any()):
+            # re-sample every row at step+1 into a scratch store, keep it for the continuing rows
+            obs = obs.clone()          # (the observation buffer is about to be overwritten)
+            steps_old, x_old = self.steps_dev, self.x
+            self.steps_dev = (self.steps_dev + 1).clamp(max=len(self._step_kind) - 2).int()
+            self.x = self._x_next
+            self._resample_current()
+            new_obs = self._finish_obs()
+            self.x = t.where(cont[:, None], self._x_next, x_old)
+            self._x_next = x_old
+            self.steps_dev = t.where(cont, self.steps_dev, steps_old)
+            obs = t.where(cont[:, None], new_obs, obs)
+        return obs, reward, terminated, truncated, info
+
+    def _resample_current(self):
+        """reset kernel at self.steps_dev into self.x, then the table observation (mode 2 step
+        with the centre action, as `_sampling` + `_get_obs` do at multi_stage.py:49-56)."""
+        B, t = self.B, self.torch
+        rio = capi.ResetIO()
+        rio.step_idx = self.steps_dev.data_ptr()
+        uni = t.rand(B, self.n_uniform, generator=self._gen, device=self.device, dtype=t.float64) \
+            if self.n_uniform else None
+        rio.uniform = uni.data_ptr() if uni is not None else None
+        rio.x = self.x.data_ptr()
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
+        io = self._io(None, False)
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_step(self._env_handle, B, C.byref(io), C.byref(self.solve_opts), 3,
+                                            capi._stream()), 'opfx_step')
+
+
+class StochasticObservation:
+    """wrappers/stochastic_obs.py:10-52 for the batch: uniform noise of
+    `noise_relative_range` × (observation range) added to every observation, optionally
+    clipped to the observation space."""
+
+    def __init__(self, env, noise_relative_range: float = 0.1, maintain_original_range: bool = True):
+        self.env = env
+        self.maintain_original_range = maintain_original_range
+        rng_ = env.observation_space.high - env.observation_space.low
+        self.abs_noise_range = noise_relative_range * rng_
+        self.observation_space = env.observation_space if maintain_original_range else \
+            Box(env.observation_space.low - self.abs_noise_range, env.observation_space.high + self.abs_noise_range)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def observation(self, obs):
+        t = self.env.torch
+        dev = obs.device
+        rng_ = t.as_tensor(self.abs_noise_range, device=dev, dtype=obs.dtype)
+        noise = (t.rand(obs.shape, generator=self.env._gen, device=dev, dtype=obs.dtype) * 2 - 1) * rng_
+        obs = obs + noise
+        if self.maintain_original_range:
+            lo = t.as_tensor(self.observation_space.low, device=dev, dtype=obs.dtype)
+            hi = t.as_tensor(self.observation_space.high, device=dev, dtype=obs.dtype)
+            obs = t.minimum(t.maximum(obs, lo), hi)
+        return obs
+
+    def reset(self, **kw):
+        obs, info = self.env.reset(**kw)
+        return self.observation(obs), info
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        return self.observation(obs), reward, terminated, truncated, info

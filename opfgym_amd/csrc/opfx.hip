@@ -866,7 +866,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
     for (int k = lane; k < E.na; k += WAVE) {
       const int slot = E.act_slot[k];
       double xv = xr[slot];
-      if (io.mode != 1) {
+      if (io.mode != 1 && io.mode != 3) {
         double a = io.action[b * E.na + k];
         a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                         // :429 (a NaN action stays NaN -> failed row)
         const double lo = E.act_lo_slot[k] >= 0 ? xr[E.act_lo_slot[k]] : E.act_lo_const[k];
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv 
     }
     corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
     wave_sync();
-    if (io.mode == 2) {
+    if (io.mode == 2 || io.mode == 3) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
@@ -1514,7 +1514,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
 
 extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                          int32_t mode, void* stream) {
-  if (!env || !io || !io->x || B < 0 || (mode == 0 && env->de.na > 0 && !io->action)) {
+  if (!env || !io || !io->x || B < 0 || ((mode == 0 || mode == 2) && env->de.na > 0 && !io->action)) {
     opfx_set_error("opfx_step: bad argument");
     return OPFX_ERR_INVALID;
   }

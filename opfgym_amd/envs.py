@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import net as ppn
-from .batched_env import BatchedOpfEnv, OpsBuilder, SecurityConstrainedOpfEnv
+from .batched_env import BatchedOpfEnv, MultiStageOpfEnv, OpsBuilder, SecurityConstrainedOpfEnv
 from .simbench_build import build_simbench_net
 
 
@@ -298,6 +298,33 @@ class SecurityConstrained(SecurityConstrainedOpfEnv):
             net[unit_type]['controllable'] = False
         for idx in net.ext_grid.index:                                                          # :48-49
             ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=0.01)
+        ppn.finalize(net)
+        return net, profiles
+
+
+class MultiStageOpf(MultiStageOpfEnv):
+    """examples/multi_stage.py:19-63: all sgen P as actions over several consecutive
+    SimBench time steps, cost of the power drawn from the external grid."""
+
+    def __init__(self, simbench_network_name='1-LV-urban6--0-sw', steps_per_episode=4, *args, **kwargs):
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]       # :33-36
+        act_keys = [('sgen', 'p_mw', net.sgen.index)]                                           # :39
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, steps_per_episode=steps_per_episode,
+                         *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.sgen['controllable'] = True                                                         # :50-54
+        net.sgen['min_p_mw'] = net.sgen['min_min_p_mw']
+        net.sgen['max_p_mw'] = net.sgen['max_max_p_mw']
+        net.sgen['min_q_mvar'] = 0
+        net.sgen['max_q_mvar'] = 0
+        for unit_type in ('load', 'gen', 'storage'):
+            net[unit_type]['controllable'] = False
+        for idx in net.ext_grid.index:                                                          # :61-62
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=1)
         ppn.finalize(net)
         return net, profiles
 

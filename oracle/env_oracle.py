@@ -141,7 +141,8 @@ def tail_load_shedding(net, draws, efficiency=0.95):
 TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'QMarket': lambda net, d: tail_voltage_control(net, d, True),
          'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
-         'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding}
+         'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding,
+         'MultiStageOpf': lambda net, d: None}
 
 
 # ---------------------------------------------------------------------------
@@ -298,8 +299,14 @@ def reward_and_cost(rf, objective, penalty, valid):
 # ---------------------------------------------------------------------------
 # E9: OpfEnv._get_obs  (opf_env.py:532-549)
 # ---------------------------------------------------------------------------
-def observation(net, obs_keys, add_mean_obs=False, time_obs=None):
-    parts = [net[unit].loc[idxs, col].to_numpy(float) for unit, col, idxs in obs_keys]
+def observation(net, obs_keys, add_mean_obs=False, time_obs=None, bus_wise_obs=False):
+    parts = []
+    for unit, col, idxs in obs_keys:
+        if unit == 'load' and bus_wise_obs:                                 # :535-536, 806-810
+            df = net[unit].iloc[np.asarray(idxs)]
+            parts.append(df.groupby(['bus'])[col].sum().to_numpy(float))
+        else:
+            parts.append(net[unit].loc[idxs, col].to_numpy(float))
     if add_mean_obs:
         parts.append(np.array([np.mean(p) for p in parts if len(p) > 1]))   # :539-542
     if time_obs is not None:
@@ -318,7 +325,8 @@ class EnvOracle:
                  autoscale_actions=True, diff_action_step_size=None, clipped_action_penalty=0.0,
                  diff_objective=False, add_mean_obs=False, pf_for_obs=False, steps_per_episode=1,
                  n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True,
-                 data='simbench', state_keys=None, sampling_params=None):
+                 data='simbench', state_keys=None, sampling_params=None, bus_wise_obs=False,
+                 multi_stage=False, split=None):
         self.base_net = net
         self.net = copy.deepcopy(net)
         self.act_keys, self.obs_keys = act_keys, obs_keys
@@ -332,6 +340,7 @@ class EnvOracle:
         self.enforce_q_lims = enforce_q_lims
         self.data, self.state_keys = data, state_keys
         self.sampling_params = sampling_params or {}
+        self.bus_wise_obs, self.multi_stage, self.split = bus_wise_obs, multi_stage, split
         self.initial_obj = 0.0
 
     def solve(self):
@@ -344,6 +353,7 @@ class EnvOracle:
     def reset(self, step, uniform=(), noise=None, initial_action=None, interp=None, normal=()):
         self.net = copy.deepcopy(self.base_net)
         self.step_in_episode = 0
+        self.current_step = step
         draws = iter(np.asarray(uniform, float))
         if self.data == 'full_uniform':                                     # opf_env.py:238-239, 253-264
             for unit, col, idxs in self.state_keys:
@@ -363,7 +373,7 @@ class EnvOracle:
         if self.pf_for_obs:                                                 # :209-216
             assert self.solve()
             self.initial_obj = float(np.sum(-cost_vector(self.net)))
-        return observation(self.net, self.obs_keys, self.add_mean_obs)
+        return observation(self.net, self.obs_keys, self.add_mean_obs, bus_wise_obs=self.bus_wise_obs)
 
     def violations(self):
         res = [violation_metrics(self.net, c) for c in self.constraints]
@@ -398,7 +408,20 @@ class EnvOracle:
             reward -= corr * self.cap                                       # opf_env.py:403-404
         term = self.spe == 1
         trunc = (not term) and self.step_in_episode >= self.spe
-        return dict(converged=True, obs=observation(self.net, self.obs_keys, self.add_mean_obs),
+        obs = observation(self.net, self.obs_keys, self.add_mean_obs, bus_wise_obs=self.bus_wise_obs)
+        if self.multi_stage:                                                # multi_stage.py:26-58
+            test_steps, val_steps, _ = self.split
+            new_step = self.current_step + 1
+            if new_step in set(val_steps.tolist()) or new_step in set(test_steps.tolist()):
+                trunc = True                                                # training mode (:36-39)
+            if self.step_in_episode >= self.spe:
+                term = True                                                 # :42-43
+            if not (term or trunc):
+                self.current_step = new_step
+                set_simbench_state(self.net, self.profiles, new_step, None, self.ranges)   # :50
+                self.tail(self.net, iter(()))
+                obs = observation(self.net, self.obs_keys, False)           # :56 (no mean obs there)
+        return dict(converged=True, obs=obs,
                     reward=reward, terminated=term, truncated=trunc, valids=valids, violations=viol,
                     penalties=pen, cost=cost, objective=objective, mean_correction=corr,
                     vm_pu=self.net.res_bus.vm_pu.to_numpy(float),

@@ -45,7 +45,8 @@ def oracle_env(name, env=None):
         add_mean_obs=env.add_mean_obs, pf_for_obs=env.pf_for_obs,
         steps_per_episode=env.steps_per_episode, n_minus_one_keys=env.n_minus_one_keys,
         not_converged_penalty=env.not_converged_penalty, data=env.train_data, state_keys=env.state_keys,
-        sampling_params=env.sampling_params)
+        sampling_params=env.sampling_params, bus_wise_obs=env.bus_wise_obs,
+        multi_stage=cls == 'MultiStageOpf', split=(env.test_steps, env.validation_steps, env.train_steps))
 
 
 def noise_factors(name, raw):

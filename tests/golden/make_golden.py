@@ -25,11 +25,12 @@ import numpy as np  # noqa: E402
 
 import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc  # noqa: E402
-from scenarios import EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
+from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
+import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
-       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding}
+       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf}
 
 
 def snapshot(net):
@@ -50,8 +51,9 @@ def run_episodes(name):
 
     def push(key, val):
         rec.setdefault(key, []).append(np.array(val, copy=True))
+    starts = EPISODE_START_STEPS.get(name)
     for k in range(n):
-        step = int(rng.choice(env.train_steps))
+        step = int(starts[k]) if starts else int(rng.choice(env.train_steps))
         obs0, _ = env.reset(seed=seed * 100 + k, options={'step': step})
         log = env.np_random.log
         uni = [u.ravel() for kind, u in log if kind == 'uniform']
@@ -60,8 +62,13 @@ def run_episodes(name):
         push('noise', np.zeros(0))
         push('obs_reset', obs0)
         ep = {}
+        done_at = S
         for s_ in range(S):
             action = rng.random(env.action_space.shape[0])
+            if s_ >= done_at:                      # episode over: pad with NaN rows of the right shape
+                for key in ep:
+                    ep[key].append(np.full_like(np.asarray(ep[key][0], dtype=float), np.nan))
+                continue
             obs, reward, terminated, truncated, info = env.step(action)
             assert 'cost' in info, 'multi-step golden episodes must converge'
             for key, val in (('action', action), ('obs_step', obs), ('reward', reward),
@@ -69,7 +76,10 @@ def run_episodes(name):
                              ('violations', info['violations']), ('penalties', info['unscaled_penalties']),
                              ('cost', info['cost']), ('vm_pu', env.net.res_bus.vm_pu.to_numpy()),
                              ('current_actions', env.get_current_actions())):
-                ep.setdefault(key, []).append(np.array(val, copy=True))
+                ep.setdefault(key, []).append(np.array(val, dtype=float, copy=True))
+            if terminated or truncated:
+                done_at = s_ + 1
+        push('n_done', done_at)
         for key, vals in ep.items():
             push(key, np.stack(vals))
     out = {k: np.stack(v) for k, v in rec.items()}
@@ -154,6 +164,7 @@ def run(name):
                 push(f'post__{tbl}__{col}', np.array(env.net[tbl][col].to_numpy(dtype=float), copy=True))
     out = {k: np.stack(v) for k, v in rec.items()}
     out['n_obs'] = np.array(env.observation_space.shape[0])
+    out['obs_low'], out['obs_high'] = env.observation_space.low, env.observation_space.high
     out['n_act'] = np.array(env.action_space.shape[0])
     out['n_bus'] = np.array(len(env.net.bus))
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)

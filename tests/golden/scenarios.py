@@ -50,8 +50,18 @@ SCENARIOS = {
         simbench_network_name='mv-small', steps_per_episode=3, diff_action_step_size=0.2), 3, 14),
 }
 
+SCENARIOS.update({
+    # observation variants (opf_env.py:535-536, 806-810)
+    'vc_bus_wise': ('VoltageControl', dict(simbench_network_name='mv-small', bus_wise_obs=True,
+                                           add_mean_obs=True), 3, 19),
+    # multi-stage episodes over consecutive time steps (multi_stage.py, examples/multi_stage.py)
+    'multistage_lv': ('MultiStageOpf', dict(simbench_network_name='1-LV-rural1--0-sw', steps_per_episode=4), 4, 20),
+})
+
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
-EPISODE_STEPS = {'vc_multistep_diff': 3}
+EPISODE_STEPS = {'vc_multistep_diff': 3, 'multistage_lv': 4}
+# explicit start steps (else drawn from the training steps): 670 runs into the first validation week at 672
+EPISODE_START_STEPS = {'multistage_lv': [5000, 20000, 670, 33000]}
 
 # table columns snapshotted after reset (when present in the reference net)
 TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_mvar'),

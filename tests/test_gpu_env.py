@@ -141,23 +141,52 @@ def test_full_batch_voltage_control_properties():
 
 @pytest.mark.parametrize('name', list(EPISODE_STEPS))
 def test_env_multi_step_episodes(name):
-    """steps_per_episode > 1 with incremental actions: the column store x carries the
-    set-points from step to step (opf_env.py:451-458), truncation at the last step (:406-414)."""
+    """steps_per_episode > 1: the column store x carries the set-points from step to step
+    (incremental actions, opf_env.py:451-458); multi-stage episodes re-sample the next time step
+    for the rows that continue (multi_stage.py:26-58); truncation/termination flags per row."""
     g = golden(name)
     n = len(g['step'])
     env = product_env(name, batch_size=n)
     obs0, _ = env.reset(options={'step': g['step']})
     assert np.allclose(_np(obs0), g['obs_reset'], rtol=0, atol=R_TOL)
+    n_done = g['n_done'] if 'n_done' in g else np.full(n, EPISODE_STEPS[name])
     for s_ in range(EPISODE_STEPS[name]):
-        obs, reward, term, trunc, info = env.step(g['action'][:, s_])
-        assert _np(info['converged']).all()
-        assert np.allclose(_np(obs), g['obs_step'][:, s_], rtol=0, atol=R_TOL)
-        assert np.allclose(_np(reward), g['reward'][:, s_], rtol=1e-9, atol=R_TOL)
-        assert (_np(term) == g['terminated'][:, s_]).all() and (_np(trunc) == g['truncated'][:, s_]).all()
-        assert np.allclose(_np(info['unscaled_penalties'])[:, :g['penalties'].shape[2]], g['penalties'][:, s_],
-                           rtol=1e-9, atol=R_TOL)
-        assert np.allclose(_np(env.result_table('bus', 'vm_pu')), g['vm_pu'][:, s_], rtol=0, atol=V_TOL)
-        assert np.allclose(_np(env.get_current_actions()), g['current_actions'][:, s_], rtol=0, atol=1e-9)
+        live = n_done > s_                      # rows whose reference episode is still running
+        act = np.where(np.isnan(g['action'][:, s_]), 0.5, g['action'][:, s_])
+        obs, reward, term, trunc, info = env.step(act)
+        assert _np(info['converged'])[live].all()
+        assert np.allclose(_np(obs)[live], g['obs_step'][live, s_], rtol=0, atol=R_TOL)
+        assert np.allclose(_np(reward)[live], g['reward'][live, s_], rtol=1e-9, atol=R_TOL)
+        assert (_np(term)[live] == g['terminated'][live, s_].astype(bool)).all()
+        assert (_np(trunc)[live] == g['truncated'][live, s_].astype(bool)).all()
+        assert np.allclose(_np(info['unscaled_penalties'])[live][:, :g['penalties'].shape[2]],
+                           g['penalties'][live, s_], rtol=1e-9, atol=R_TOL)
+        assert np.allclose(_np(env.result_table('bus', 'vm_pu'))[live], g['vm_pu'][live, s_], rtol=0, atol=V_TOL)
+        if name != 'multistage_lv':             # (after a multi-stage step x already holds the next state)
+            assert np.allclose(_np(env.get_current_actions())[live], g['current_actions'][live, s_],
+                               rtol=0, atol=1e-9)
+
+
+def test_time_observation_and_stochastic_wrapper():
+    """add_time_obs with the intended semantics of time_observation.py:4-22 (the reference
+    call site passes the wrong argument, defect D1) and the StochasticObservation wrapper
+    (wrappers/stochastic_obs.py:10-52)."""
+    from opfgym_amd import StochasticObservation
+    from opfgym_amd.simbench_build import get_simbench_time_observation
+    B = 8
+    env = product_env('vc_mv_small', batch_size=B, add_time_obs=True)
+    steps = np.array([0, 24, 96, 672, 5000, 20000, 33333, 35135])
+    obs, _ = env.reset(options={'step': steps})
+    assert obs.shape[1] == env.observation_space.shape[0] == 6 + env.n_obs_raw
+    assert np.allclose(_np(obs)[:, :6], get_simbench_time_observation(steps), rtol=0, atol=1e-15)
+    base = product_env('vc_mv_small', batch_size=B)
+    clean, _ = base.reset(options={'step': steps})
+    wrapped = StochasticObservation(base, noise_relative_range=0.05)
+    noisy, _ = wrapped.reset(options={'step': steps})
+    lo, hi = base.observation_space.low, base.observation_space.high
+    d = _np(noisy) - _np(clean)
+    assert (np.abs(d) <= 0.05 * (hi - lo) + 1e-12).all() and np.abs(d).max() > 0
+    assert (_np(noisy) >= lo - 1e-12).all() and (_np(noisy) <= hi + 1e-12).all()
 
 
 def test_reward_scaling_from_batched_estimate():

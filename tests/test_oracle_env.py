@@ -58,13 +58,15 @@ def test_oracle_matches_reference_golden(name):
 
 @pytest.mark.parametrize('name', list(EPISODE_STEPS))
 def test_oracle_multi_step_episodes(name):
-    """steps_per_episode > 1 with incremental actions (opf_env.py:406-414, 451-458)."""
+    """steps_per_episode > 1: incremental actions (opf_env.py:406-414, 451-458) and
+    multi-stage episodes over consecutive time steps (multi_stage.py:26-58)."""
     g = golden(name)
     orc = oracle_env(name)
     for k in range(len(g['step'])):
         obs0 = orc.reset(int(g['step'][k]), g['uniform'][k])
         assert np.allclose(obs0, g['obs_reset'][k], rtol=0, atol=1e-9)
-        for s_ in range(EPISODE_STEPS[name]):
+        n_done = int(g['n_done'][k]) if 'n_done' in g else EPISODE_STEPS[name]
+        for s_ in range(n_done):
             out = orc.step(g['action'][k, s_])
             assert out['converged']
             assert np.allclose(out['obs'], g['obs_step'][k, s_], rtol=0, atol=1e-9)
@@ -73,3 +75,16 @@ def test_oracle_multi_step_episodes(name):
             assert bool(out['truncated']) == bool(g['truncated'][k, s_])
             assert np.allclose(out['penalties'], g['penalties'][k, s_], rtol=0, atol=1e-9)
             assert np.allclose(out['vm_pu'], g['vm_pu'][k, s_], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', SINGLE_STEP + list(EPISODE_STEPS))
+def test_observation_space_matches_reference(name):
+    """get_obs_and_state_space (opf_env.py:720-803) of the host mirror vs the reference's."""
+    g = golden(name)
+    if 'obs_low' not in g:
+        pytest.skip('fixture without space bounds')
+    env = product_env(name, defer_device=True)
+    assert env.observation_space.shape == g['obs_low'].shape
+    assert np.allclose(env.observation_space.low, g['obs_low'], rtol=0, atol=1e-12)
+    assert np.allclose(env.observation_space.high, g['obs_high'], rtol=0, atol=1e-12)
+    assert env.action_space.shape == (int(g['n_act']),)
