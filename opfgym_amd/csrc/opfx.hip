@@ -851,7 +851,11 @@ __device__ __forceinline__ double xval(const double* xr, const double* sp, int s
 __device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
 
 template <bool V2>
-__global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv E, StepIO io, Opts o, long long B) {
+__global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
+                                                  long long B) {
+  // The environment descriptor (about 50 pointers) stays in memory and is read where it is
+  // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
+  const DevEnv& E = *Ep;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc);
@@ -1507,7 +1511,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), env->lds_bytes, static_cast<hipStream_t>(stream),
-                     env->ctx->dp, env->de, s, o, (long long)B);
+                     env->ctx->dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }
