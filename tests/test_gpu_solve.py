@@ -120,3 +120,17 @@ def test_enforce_q_lims():
     # the limits must actually bind in some instances for the test to mean something
     assert (np.abs(ref['vm'][:, 1] - 1.025) > 1e-4).any()
     assert np.abs(out['vm'] - ref['vm']).max() < TOL_V
+
+
+def test_first_generation_kernel_still_correct():
+    """The fallback kernel (plan walked through index arrays; used when a plan does not fit the
+    16-bit lane-programme descriptors) is selected with OPFX_KERNEL_V1=1 in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, OPFX_KERNEL_V1='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_solve.py'), '-m', 'gpu',
+                        '-q', '-x', '-k', 'matches_oracle or q_lims or outage'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
