@@ -65,6 +65,8 @@ struct DevPlan {
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
   const int* lp_hrows;
   int n_hrows;
+  const int* lp_groups;      // [n_groups+1] round offsets: independent groups of the B/C stream
+  int n_groups;
 };
 
 struct DevEnv {
@@ -180,6 +182,14 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 __device__ __forceinline__ int wave_any(int pred) { return __any(pred); }
+
+// NW = wavefronts per instance.  Sections that only wavefront 0 executes use sec_sync
+// (never a workgroup barrier); hand-overs between wavefront 0 and the team use blk_sync.
+template <int NW> __device__ __forceinline__ void blk_sync() { __syncthreads(); }
+template <int NW> __device__ __forceinline__ void sec_sync() {
+  if (NW == 1) { __syncthreads(); }
+  else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+}
 
 struct Blk { double a11, a12, a21, a22; };
 __device__ __forceinline__ Blk ld_blk(const double* blk, int id) {
@@ -388,7 +398,7 @@ __device__ __forceinline__ void lds_sub(double* p, double v) {
   do {                                                                                      \
     if (P.stamps && blockIdx.x == 0) {                                                       \
       const unsigned long long now__ = __builtin_readcyclecounter();                          \
-      if (lane == 0) P.stamps[slot] += now__ - t_last__;                                      \
+      if (threadIdx.x == 0) P.stamps[slot] += now__ - t_last__;                                \
       t_last__ = __builtin_readcyclecounter();                                                \
     }                                                                                       \
   } while (0)
@@ -645,6 +655,211 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   return conv;
 }
 
+// ---------------------------------------------------------------------------
+// Cooperative variant for LARGE grids: NW wavefronts (one workgroup) share ONE
+// instance.  Meshed HV grids need 70-90 KB of LDS per instance, i.e. only one
+// or two instances fit a CU; with one wave each, three of the four SIMDs would
+// idle.  Here the independent rounds of a group (an elimination level, its U
+// pre-items, its solves), the bus rows and the voltage update are dealt round-
+// robin to the NW waves and groups are separated by workgroup barriers.  Update
+// terms of different waves meet in LDS atomics, so the summation order — and the
+// last bits of the result — may differ between runs (the single-wave kernel is
+// bit-reproducible).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const unsigned tb = d.x & 0xFFFF;
+  if (tb == NONE) return;
+  const Blk bi = ld_blk(L.blk, d.x >> 16);
+  const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
+  const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+  const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
+  const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
+  const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
+  const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
+  if (tb & 0x8000u) {
+    const int i = tb & 0x7FFF, k = d.y >> 16;
+    const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
+    lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
+    lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
+  } else {
+    const Blk bj = ld_blk(L.blk, d.y >> 16);
+    double* tp = L.blk + 4 * tb;
+    lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
+    lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
+    lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
+    lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
+  }
+}
+
+__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const unsigned k = d.x & 0xFFFF;
+  if (k == NONE) return;
+  double d1 = 0.0, d2 = 0.0;
+  if ((d.y & 0xFFFF) != NONE) {
+    const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
+    const unsigned j = d.y >> 16;
+    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+  }
+  if ((d.z & 0xFFFF) != NONE) {
+    const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
+    const unsigned j = d.z >> 16;
+    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+  }
+  const unsigned dblk = d.x >> 16;
+  if (dblk != NONE) {
+    const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
+    const Blk bk = ld_blk(L.blk, dblk);
+    const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+    L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
+    L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
+  } else {
+    lds_sub(&L.rhs[2 * k], d1);
+    lds_sub(&L.rhs[2 * k + 1], d2);
+  }
+}
+
+template <int NW>
+__device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int out_br,
+                             int* iters_out, double* nrm_out) {
+  constexpr unsigned NONE = 0xFFFFu;
+  constexpr int NT = WAVE * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = P.nb;
+  int of = -1, ot = -1;
+  double oy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out_br >= 0) {
+    of = P.br_f[out_br]; ot = P.br_t[out_br];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
+  }
+  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc);
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
+  double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
+  int it = 0;
+  double nrm = 0.0;
+  bool conv = false;
+  while (true) {
+    // ---- phase A ------------------------------------------------------------------
+    for (int f = tid; f < P.nfill; f += NT) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
+    __syncthreads();
+    for (int h = wave; h < P.rh; h += NW) {
+      const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
+      const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+      const unsigned ent = he.x;
+      const unsigned j = ent & 0xFFFF;
+      if (j != NONE) {
+        const int i = he.y;
+        double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
+        double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
+        if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+        if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+        const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
+        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+        const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+        const unsigned bid = ent >> 16;
+        const int t = L.bt[i];
+        if (bid != NONE && t != BT_REF) {
+          Blk jb{ci, cr, -cr, ci};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+          st_blk(L.blk, bid, jb);
+        }
+        lds_sub(&L.rhs[2 * i], -cr);
+        lds_sub(&L.rhs[2 * i + 1], -ci);
+      }
+    }
+    __syncthreads();
+    double my = 0.0;
+    for (int r = wave; r < P.ra; r += NW) {
+      const ARound a = load_around(P, r, lane);
+      const int i = lane + WAVE * r;
+      if (i < nb) {
+        const int t = L.bt[i];
+        const double vri = L.vr[i], vii = L.vi[i];
+        double sr = 0.0, si = 0.0;
+        if (a.dw >> 16) { sr = L.rhs[2 * i]; si = L.rhs[2 * i + 1]; }
+        const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned jr = ent[k] & 0xFFFF;
+          const unsigned j = jr != NONE ? jr : (unsigned)i;
+          double g = a.y[k].x, b = a.y[k].y;
+          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
+          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+          const double vrj = L.vr[j], vij = L.vi[j];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          sr += cr; si += ci;
+          const unsigned bid = ent[k] >> 16;
+          if (bid != NONE && t != BT_REF) {
+            Blk jb{ci, cr, -cr, ci};
+            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+            st_blk(L.blk, bid, jb);
+          }
+        }
+        double g = a.yd.x, b = a.yd.y;
+        if (i == of) { g -= oy[0]; b -= oy[1]; }
+        if (i == ot) { g -= oy[6]; b -= oy[7]; }
+        const double v2 = vri * vri + vii * vii;
+        const double yr = g * v2, yi = -b * v2;
+        if (t != BT_REF) {
+          const double pc = sr + yr, qc = si + yi;
+          const double fp = pc - L.psp[i];
+          const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
+          L.rhs[2 * i] = -fp;
+          L.rhs[2 * i + 1] = -fq;
+          my = nan_max(my, nan_max(fabs(fp), fabs(fq)));
+          Blk jb{-si, yr + pc, sr, yi + qc};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          st_blk(L.blk, a.dw & 0xFFFF, jb);
+        } else {
+          L.rhs[2 * i] = sr + yr;
+          L.rhs[2 * i + 1] = si + yi;
+        }
+      }
+    }
+    my = wave_max_dpp(my);
+    if (lane == 0) xw[wave] = my;
+    __syncthreads();
+    nrm = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) nrm = nan_max(nrm, xw[w]);
+    if (!(nrm == nrm)) { conv = false; break; }
+    if (nrm < o.tol) { conv = true; break; }
+    if (it >= o.max_iter) { conv = false; break; }
+    ++it;
+    // ---- phases B and C: independent groups of rounds, one barrier per group ------------------
+    for (int g = 0; g < P.n_groups; ++g) {
+      const int r0 = P.lp_groups[g], r1 = P.lp_groups[g + 1];
+      if (r0 == r1) continue;
+      for (int r = r0 + wave; r < r1; r += NW) {
+        const uint4 d = stream[(size_t)r * WAVE + lane];
+        if (r < P.rb) item_factor(L, d); else item_solve(L, d);
+      }
+      __syncthreads();
+    }
+    // ---- phase D ---------------------------------------------------------------------------------
+    for (int i = tid; i < nb; i += NT) {
+      if (L.bt[i] == BT_REF) continue;
+      const double dth = L.rhs[2 * i], sc = 1.0 + L.rhs[2 * i + 1];
+      double sn, cs;
+      sincos(dth, &sn, &cs);
+      const double vr = L.vr[i], vi = L.vi[i];
+      L.vr[i] = (vr * cs - vi * sn) * sc;
+      L.vi[i] = (vr * sn + vi * cs) * sc;
+    }
+    __syncthreads();
+  }
+  __syncthreads();          // xw (aliases the constraint accumulators) is free again
+  *iters_out = it;
+  *nrm_out = nrm;
+  return conv;
+}
+
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
 // A bus that an earlier solve of this instance pinned at a reactive limit gets
 // its generator share removed from q_sp again (L.bt must hold valid codes).
@@ -670,42 +885,54 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
 }
 
 // Outer loop: NR + enforce_q_lims PV->PQ switching.
-template <bool V2>
+template <bool V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm) {
+  const int wave = threadIdx.x >> 6;
   int total = 0;
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
-    conv = V2 ? newton2(P, L, o, lane, out_br, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
+    if (NW > 1) conv = newton2_coop<NW>(P, L, o, out_br, &it, nrm);
+    else conv = V2 ? newton2(P, L, o, lane, out_br, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
     int changed = 0;
-    wave_sync();
-    for (int i = lane; i < P.nb; i += WAVE) {
-      if (L.bt[i] != BT_PV) continue;
-      double ir = 0.0, ii = 0.0;
-      for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
-        const int j = P.y_col[e];
-        double g = P.y_g[e], b = P.y_b[e];
-        if (out_br >= 0) {
-          if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
-          if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
-          if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
-          if (e == P.br_pos[out_br * 4 + 3]) { g -= P.br_y[out_br * 8 + 6]; b -= P.br_y[out_br * 8 + 7]; }
+    sec_sync<NW>();
+    if (wave == 0) {
+      for (int i = lane; i < P.nb; i += WAVE) {
+        if (L.bt[i] != BT_PV) continue;
+        double ir = 0.0, ii = 0.0;
+        for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
+          const int j = P.y_col[e];
+          double g = P.y_g[e], b = P.y_b[e];
+          if (out_br >= 0) {
+            if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
+            if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
+            if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
+            if (e == P.br_pos[out_br * 4 + 3]) { g -= P.br_y[out_br * 8 + 6]; b -= P.br_y[out_br * 8 + 7]; }
+          }
+          ir += g * L.vr[j] - b * L.vi[j];
+          ii += g * L.vi[j] + b * L.vr[j];
         }
-        ir += g * L.vr[j] - b * L.vi[j];
-        ii += g * L.vi[j] + b * L.vr[j];
+        const double qc = L.vi[i] * ir - L.vr[i] * ii;
+        const double qg = qc - L.qsp[i];
+        const double lo = qg_min[i], hi = qg_max[i];
+        if (qg > hi) { L.bt[i] = BT_PQ_HI; L.qsp[i] += hi; changed = 1; }
+        else if (qg < lo) { L.bt[i] = BT_PQ_LO; L.qsp[i] += lo; changed = 1; }
       }
-      const double qc = L.vi[i] * ir - L.vr[i] * ii;
-      const double qg = qc - L.qsp[i];
-      const double lo = qg_min[i], hi = qg_max[i];
-      if (qg > hi) { L.bt[i] = BT_PQ_HI; L.qsp[i] += hi; changed = 1; }
-      else if (qg < lo) { L.bt[i] = BT_PQ_LO; L.qsp[i] += lo; changed = 1; }
+      changed = wave_any(changed);
+      if (NW > 1 && lane == 0) L.acc[0] = changed ? 1.0 : 0.0;
     }
-    wave_sync();
-    if (!wave_any(changed)) break;
+    if (NW > 1) {
+      __syncthreads();
+      changed = L.acc[0] != 0.0;
+      __syncthreads();
+    } else {
+      sec_sync<NW>();
+    }
+    if (!changed) break;
   }
   *iters = total;
   return conv;
@@ -803,41 +1030,46 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
 // ---------------------------------------------------------------------------
 // pure power flow kernel (opfx_solve)
 // ---------------------------------------------------------------------------
-template <bool V2>
-__global__ __launch_bounds__(WAVE, 2) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
+template <bool V2, int NW>
+__global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
-  const Lds L = carve<V2>(P, 0, 3 * P.nb + P.nbr + 2 * P.nref, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
+  const Lds L = carve<V2>(P, 0, nres_, smem, 8);
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
-    for (int i = lane; i < P.nb; i += WAVE) {
-      L.psp[i] = io.p_inj[b * P.nb + i];
-      L.qsp[i] = io.q_inj[b * P.nb + i];
-      L.bt[i] = BT_PQ;
+    if (wave == 0) {
+      for (int i = lane; i < P.nb; i += WAVE) {
+        L.psp[i] = io.p_inj[b * P.nb + i];
+        L.qsp[i] = io.q_inj[b * P.nb + i];
+        L.bt[i] = BT_PQ;
+      }
+      init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims != 0);
     }
-    init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims != 0);
-    wave_sync();
+    blk_sync<NW>();
     const int out_br = io.outage ? io.outage[b] : -1;
     int iters; double nrm;
-    const bool conv = solve_instance<V2>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
-    wave_sync();
-    double* R = L.blk;
-    compute_results<V2>(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
-    wave_sync();
-    const int nb = P.nb, nbr = P.nbr, nref = P.nref;
-    if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
-    if (io.va) for (int i = lane; i < nb; i += WAVE) io.va[b * nb + i] = R[nb + i];
-    if (io.loading) for (int k = lane; k < nbr; k += WAVE) io.loading[b * nbr + k] = R[2 * nb + k];
-    if (io.s_ref) for (int r = lane; r < nref; r += WAVE) {
-      io.s_ref[(b * nref + r) * 2] = R[2 * nb + nbr + r];
-      io.s_ref[(b * nref + r) * 2 + 1] = R[2 * nb + nbr + nref + r];
+    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
+    blk_sync<NW>();
+    if (wave == 0) {
+      double* R = L.blk;
+      compute_results<V2>(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
+      sec_sync<NW>();
+      const int nb = P.nb, nbr = P.nbr, nref = P.nref;
+      if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
+      if (io.va) for (int i = lane; i < nb; i += WAVE) io.va[b * nb + i] = R[nb + i];
+      if (io.loading) for (int k = lane; k < nbr; k += WAVE) io.loading[b * nbr + k] = R[2 * nb + k];
+      if (io.s_ref) for (int r = lane; r < nref; r += WAVE) {
+        io.s_ref[(b * nref + r) * 2] = R[2 * nb + nbr + r];
+        io.s_ref[(b * nref + r) * 2 + 1] = R[2 * nb + nbr + nref + r];
+      }
+      if (io.q_gen) for (int i = lane; i < nb; i += WAVE) io.q_gen[b * nb + i] = R[2 * nb + nbr + 2 * nref + i];
+      if (lane == 0) {
+        if (io.converged) io.converged[b] = conv ? 1 : 0;
+        if (io.iterations) io.iterations[b] = iters;
+        if (io.max_mismatch) io.max_mismatch[b] = nrm;
+      }
     }
-    if (io.q_gen) for (int i = lane; i < nb; i += WAVE) io.q_gen[b * nb + i] = R[2 * nb + nbr + 2 * nref + i];
-    if (lane == 0) {
-      if (io.converged) io.converged[b] = conv ? 1 : 0;
-      if (io.iterations) io.iterations[b] = iters;
-      if (io.max_mismatch) io.max_mismatch[b] = nrm;
-    }
-    wave_sync();
+    blk_sync<NW>();
   }
 }
 
@@ -850,15 +1082,15 @@ __device__ __forceinline__ double xval(const double* xr, const double* sp, int s
 
 __device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
 
-template <bool V2>
-__global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
+template <bool V2, int NW>
+__global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
   // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
   const DevEnv& E = *Ep;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x;
-  const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc > 8 ? 5 * E.nc : 8);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   unsigned long long t_last__ = __builtin_readcyclecounter();
@@ -867,6 +1099,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
     OPFX_STAMP(15);
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
+    if (wave == 0) {
     for (int k = lane; k < E.na; k += WAVE) {
       const int slot = E.act_slot[k];
       double xv = xr[slot];
@@ -893,8 +1126,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
       L.sp[k] = xv;
     }
     corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
-    wave_sync();
+    }
+    blk_sync<NW>();
     if (io.mode == 2 || io.mode == 3) {
+      if (wave == 0) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
@@ -902,16 +1137,19 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
           io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : NaN);
       }
       if (lane == 0 && io.mean_correction) io.mean_correction[b] = corr;
-      wave_sync();
+      }
+      blk_sync<NW>();
       continue;
     }
     // ---- bus injections (makeSbus): lane = unit column (coalesced x reads), LDS accumulate --
+    if (wave == 0) {
     for (int i = lane; i < nb; i += WAVE) { L.psp[i] = 0.0; L.qsp[i] = 0.0; L.bt[i] = BT_PQ; }
     wave_fence();
     for (int e = lane; e < E.n_inj; e += WAVE) {
       const int bq = E.inj_bus[e];
       const double v = E.inj_coef[e] * xval(xr, L.sp, E.inj_slot[e], E.inj_act[e]);
       lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
+    }
     }
     OPFX_STAMP(0);
     // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
@@ -924,12 +1162,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
-      init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
-      wave_sync();
+      if (wave == 0) init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+      blk_sync<NW>();
       int iters; double nrm;
       t_last__ = __builtin_readcyclecounter();
-      const bool conv = solve_instance<V2>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
-      wave_sync();
+      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
+      blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) { conv0 = conv; iters0 = iters; nrm0 = nrm; if (!conv) break; }
       if (!conv) {
@@ -940,8 +1178,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
         continue;
       }
       double* R = L.blk;
+      if (wave == 0) {
       compute_results<V2>(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
-      wave_sync();
+      sec_sync<NW>();
       OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
       // violating lanes accumulate per-constraint sum / worst case / count in LDS
@@ -1046,10 +1285,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
         for (int j = lane; j < n; j += WAVE)
           io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : R[src + j]);
       }
-      wave_sync();
+      }
+      blk_sync<NW>();
     }
     OPFX_STAMP(9);
     // ---- reward (opf_env.py:515-530, reward.py:61-98) --------------------------
+    if (wave == 0) {
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
       if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
@@ -1112,7 +1353,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_step(const DevPlan P, const DevEnv*
       if (io.max_mismatch) io.max_mismatch[b] = nrm0;
       if (io.mean_correction) io.mean_correction[b] = corr;
     }
-    wave_sync();
+    }
+    blk_sync<NW>();
   }
 }
 
@@ -1242,8 +1484,20 @@ size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc 
   return (bytes + 15) & ~(size_t)15;
 }
 
+// Wavefronts per instance: grids whose LDS image leaves room for only a few instances per
+// CU get a team of waves per instance so that the SIMDs are not left idle.
+int pick_team(size_t lds, bool v2) {
+  if (!v2) return 1;
+  if (const char* ov = getenv("OPFX_TEAM")) { const int t = atoi(ov); if (t == 1 || t == 2 || t == 4) return t; }
+  const size_t granule = 1024;
+  const int inst = (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
+  if (inst <= 2) return 4;
+  if (inst <= 4) return 2;
+  return 1;
+}
+
 template <typename K>
-int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int* per_cu_cache) {
+int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int* per_cu_cache, int threads = WAVE) {
   if (*per_cu_cache > 0) {
     *grid = (int)std::max<long long>(1, std::min<long long>((long long)*per_cu_cache * n_cu, B));
     return OPFX_OK;
@@ -1255,7 +1509,7 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
   // The occupancy query can be one block high when the LDS request is not a multiple of the
   // allocation granule; an oversubscribed persistent grid runs its surplus blocks as a tail.
   {
@@ -1312,6 +1566,8 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   d.n_hrows = (int)p->lp_hrows.size();
+  PUT(lp_groups, lp_groups);
+  d.n_groups = (int)p->lp_groups.size() - 1;
   {
     std::vector<double> vr0(p->nb), vi0(p->nb);
     for (int i = 0; i < p->nb; ++i) { vr0[i] = p->vm_set[i] * std::cos(p->va_set[i]); vi0[i] = p->vm_set[i] * std::sin(p->va_set[i]); }
@@ -1338,13 +1594,14 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
-  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2);
+  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8);
   int grid = 0;
-  auto kern = ctx->v2 ? k_solve<true> : k_solve<false>;
-  int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu);
+  const int team = pick_team(lds, ctx->v2);
+  auto kern = !ctx->v2 ? k_solve<false, 1> : (team == 4 ? k_solve<true, 4> : (team == 2 ? k_solve<true, 2> : k_solve<true, 1>));
+  int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations};
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
@@ -1487,7 +1744,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2, 5 * d->nc);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8);
   *out = e;
   return OPFX_OK;
 }
@@ -1499,8 +1756,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1};
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  auto kern = env->ctx->v2 ? k_step<true> : k_step<false>;
-  int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu);
+  const int team = pick_team(env->lds_bytes, env->ctx->v2);
+  auto kern = !env->ctx->v2 ? k_step<false, 1>
+                            : (team == 4 ? k_step<true, 4> : (team == 2 ? k_step<true, 2> : k_step<true, 1>));
+  int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   StepIO s{};
   s.x = io->x; s.action = io->action; s.initial_obj = io->initial_obj;
@@ -1510,7 +1769,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.mean_correction = io->mean_correction; s.max_mismatch = io->max_mismatch;
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), env->lds_bytes, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      env->ctx->dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;

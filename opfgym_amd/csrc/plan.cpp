@@ -116,6 +116,7 @@ void build_lane_programs(opfx_plan* p) {
   // target may sit in the same round (the kernel accumulates with LDS atomics);
   // block targets first, rhs targets last, so that a round is mostly homogeneous.
   const int nlev = p->n_levels();
+  std::vector<int32_t> b_bounds{0}, c_bounds;
   std::vector<std::array<uint32_t, 2>> items;
   auto flush = [&]() {
     for (size_t o = 0; o < items.size(); o += 64) {
@@ -138,6 +139,7 @@ void build_lane_programs(opfx_plan* p) {
                            (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16)});
       }
     flush();
+    b_bounds.push_back((int32_t)(p->lp_b.size() / 128));
   }
   p->rb = (int32_t)(p->lp_b.size() / 128);
   // ---- C ---------------------------------------------------------------------
@@ -163,6 +165,7 @@ void build_lane_programs(opfx_plan* p) {
         citems.push_back(it);
       }
     flush_c(citems);
+    c_bounds.push_back((int32_t)(p->lp_c.size() / 192));
     for (int q = p0; q < p1; ++q) {
       const int u0 = p->piv_uptr[q], u1 = p->piv_uptr[q + 1];
       std::array<uint32_t, 3> it{(uint32_t)p->piv_bus[q] | ((uint32_t)p->diag_blk[p->piv_bus[q]] << 16),
@@ -172,8 +175,11 @@ void build_lane_programs(opfx_plan* p) {
       citems.push_back(it);
     }
     flush_c(citems);
+    c_bounds.push_back((int32_t)(p->lp_c.size() / 192));
   }
   p->rc = (int32_t)(p->lp_c.size() / 192);
+  p->lp_groups = b_bounds;
+  for (int32_t cb : c_bounds) if (p->rb + cb > p->lp_groups.back()) p->lp_groups.push_back(p->rb + cb);
   // ---- packed device forms ---------------------------------------------------------
   auto put_d = [](std::vector<uint32_t>& v, size_t at, double x) { std::memcpy(&v[at], &x, 8); };
   p->lp_bc.assign((size_t)(p->rb + p->rc) * 64 * 4, 0u);

@@ -53,6 +53,8 @@ struct opfx_plan {
   std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
+  std::vector<int32_t> lp_groups;          // round offsets into lp_bc: rounds of one group are mutually
+                                           // independent (an elimination level / its U pre-items / its solves)
   int32_t nnz_j = 0;
   int32_t max_level_width = 0;
   int32_t n_levels() const { return (int32_t)lev_tptr.size() - 1; }
