@@ -67,6 +67,7 @@ struct DevPlan {
   int n_hrows;
   const int* lp_groups;      // [n_groups+1] round offsets: independent groups of the B/C stream
   int n_groups;
+  double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
 };
 
 struct DevEnv {
@@ -1162,14 +1163,30 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
-      if (wave == 0) init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+      if (wave == 0) {
+        init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+        if (c > 0) {
+          // contingency cases start from the base-case solution (the reference restarts
+          // pandapower from scratch for each one; the converged result is the same)
+          const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
+          for (int i = lane; i < nb; i += WAVE) { L.vr[i] = wv[i]; L.vi[i] = wv[nb + i]; }
+        }
+      }
       blk_sync<NW>();
       int iters; double nrm;
       t_last__ = __builtin_readcyclecounter();
       const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
       blk_sync<NW>();
       OPFX_STAMP(5);
-      if (c == 0) { conv0 = conv; iters0 = iters; nrm0 = nrm; if (!conv) break; }
+      if (c == 0) {
+        conv0 = conv; iters0 = iters; nrm0 = nrm;
+        if (!conv) break;
+        if (E.n_cont > 0 && wave == 0) {
+          double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
+          for (int i = lane; i < nb; i += WAVE) { wv[i] = L.vr[i]; wv[nb + i] = L.vi[i]; }
+          __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same wavefront
+        }
+      }
       if (!conv) {
         // failed contingency: all invalid, +not_converged_penalty (sign as in the reference, D6)
         valid_acc = 0;
@@ -1568,6 +1585,13 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   d.n_hrows = (int)p->lp_hrows.size();
   PUT(lp_groups, lp_groups);
   d.n_groups = (int)p->lp_groups.size() - 1;
+  {
+    void* ws = nullptr;
+    const size_t n_ws = (size_t)c->n_cu * 16 * 2 * (size_t)p->nb;
+    if (hipMalloc(&ws, n_ws * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(warm-start scratch) failed"); return OPFX_ERR_HIP; }
+    A.ptrs.push_back(ws);
+    d.warm = static_cast<double*>(ws);
+  }
   {
     std::vector<double> vr0(p->nb), vi0(p->nb);
     for (int i = 0; i < p->nb; ++i) { vr0[i] = p->vm_set[i] * std::cos(p->va_set[i]); vi0[i] = p->vm_set[i] * std::sin(p->va_set[i]); }
