@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libopfx.so')
+# OPFX_LIB: developer override (the diagnostic build with cycle stamps, __graft_entry__.build_stamps)
+LIB_PATH = os.path.abspath(os.environ['OPFX_LIB']) if os.environ.get('OPFX_LIB') else os.path.join(_HERE, 'libopfx.so')
 
 OK = 0
 PQ, PV, REF = 1, 2, 3

@@ -395,6 +395,9 @@ __device__ __forceinline__ void lds_sub(double* p, double v) {
   __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+#ifdef OPFX_ENABLE_STAMPS
+#define OPFX_STAMP_INIT() unsigned long long t_last__ = __builtin_readcyclecounter()
+#define OPFX_STAMP_RESET() t_last__ = __builtin_readcyclecounter()
 #define OPFX_STAMP(slot)                                                                   \
   do {                                                                                      \
     if (P.stamps && blockIdx.x == 0) {                                                       \
@@ -403,6 +406,69 @@ __device__ __forceinline__ void lds_sub(double* p, double v) {
       t_last__ = __builtin_readcyclecounter();                                                \
     }                                                                                       \
   } while (0)
+#else
+// Product build: no probe code at all (a conditional store inside the Newton loops would
+// make the compiler's wait-count insertion conservative).  Diagnostic build: -DOPFX_ENABLE_STAMPS.
+#define OPFX_STAMP_INIT() do { } while (0)
+#define OPFX_STAMP_RESET() do { } while (0)
+#define OPFX_STAMP(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const unsigned tb = d.x & 0xFFFF;
+  if (tb == NONE) return;
+  const Blk bi = ld_blk(L.blk, d.x >> 16);
+  const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
+  const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+  const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
+  const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
+  const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
+  const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
+  if (tb & 0x8000u) {
+    const int i = tb & 0x7FFF, k = d.y >> 16;
+    const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
+    lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
+    lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
+  } else {
+    const Blk bj = ld_blk(L.blk, d.y >> 16);
+    double* tp = L.blk + 4 * tb;
+    lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
+    lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
+    lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
+    lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
+  }
+}
+
+__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const unsigned k = d.x & 0xFFFF;
+  if (k == NONE) return;
+  double d1 = 0.0, d2 = 0.0;
+  if ((d.y & 0xFFFF) != NONE) {
+    const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
+    const unsigned j = d.y >> 16;
+    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+  }
+  if ((d.z & 0xFFFF) != NONE) {
+    const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
+    const unsigned j = d.z >> 16;
+    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
+  }
+  const unsigned dblk = d.x >> 16;
+  if (dblk != NONE) {
+    const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
+    const Blk bk = ld_blk(L.blk, dblk);
+    const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+    L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
+    L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
+  } else {
+    lds_sub(&L.rhs[2 * k], d1);
+    lds_sub(&L.rhs[2 * k + 1], d2);
+  }
+}
 
 struct ARound { uint4 ent; double2 y[4]; double2 yd; unsigned dw; };
 
@@ -434,99 +500,47 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 #pragma unroll
     for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
   }
-  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc);
-  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
-  const int R = P.rb + P.rc;
-  const uint4 none4 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
-  auto ld_desc = [&](int r) { return r < R ? stream[(size_t)r * WAVE + lane] : none4; };
-  const bool skipB = P.debug_skip & 4, skipC = P.debug_skip & 8;
-
-  // one factor/forward item (r < rb) or one backward item (rb <= r < R)
-  auto do_round = [&](const uint4 d, int r) {
-    if (r >= R) return;
-    if (r < P.rb) {
-      const unsigned tb = d.x & 0xFFFF;
-      if (tb != NONE && !skipB) {
-        const Blk bi = ld_blk(L.blk, d.x >> 16);
-        const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
-        const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-        const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
-        const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
-        const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
-        const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
-        if (tb & 0x8000u) {
-          const int i = tb & 0x7FFF, k = d.y >> 16;
-          const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
-          lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
-          lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
-        } else {
-          const Blk bj = ld_blk(L.blk, d.y >> 16);
-          double* tp = L.blk + 4 * tb;
-          lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
-          lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
-          lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
-          lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
-        }
-      }
-    } else {
-      const unsigned k = d.x & 0xFFFF;
-      if (k != NONE && !skipC) {
-        double d1 = 0.0, d2 = 0.0;
-        if ((d.y & 0xFFFF) != NONE) {
-          const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
-          const unsigned j = d.y >> 16;
-          const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
-          d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-        }
-        if ((d.z & 0xFFFF) != NONE) {
-          const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
-          const unsigned j = d.z >> 16;
-          const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
-          d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-        }
-        const unsigned dblk = d.x >> 16;
-        if (dblk != NONE) {
-          const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
-          const Blk bk = ld_blk(L.blk, dblk);
-          const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-          L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
-          L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
-        } else {
-          lds_sub(&L.rhs[2 * k], d1);
-          lds_sub(&L.rhs[2 * k + 1], d2);
-        }
-      }
-    }
-    // Rounds of one level are independent; ordering is needed at level ends only, but on a
-    // single wave the fence is free (the LDS executes a wave's operations in order).
-    wave_fence();
-  };
+  // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
+  // that the compiler's wait-count insertion sees a fixed number of loads in flight and
+  // waits for the oldest only (a conditional load anywhere in these loops degrades every
+  // wait to vmcnt(0), i.e. one exposed L2 round trip per round).
+  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc) + lane;
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk) + lane;
+  const int RB = P.rb, R = P.rb + P.rc;                  // padded round counts (multiples of 4, R >= 4)
+  auto ld_desc = [&](int r) { return stream[(size_t)(r < R ? r : r - R) * WAVE]; };
+  const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
+  const int nfill4 = 4 * P.nfill;
+  double* const fill0 = L.blk + 4 * (P.nblk - P.nfill);   // fill blocks are numbered last (plan.cpp)
 
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
-  unsigned long long t_last__ = __builtin_readcyclecounter();
+  OPFX_STAMP_INIT();
   ARound cur = load_around(P, 0, lane);
+  uint4 hy = make_uint4(0, 0, 0, 0), he = make_uint4(NONE | (NONE << 16), 0, 0, 0);
+  if (P.rh > 0) { hy = hpk[0]; he = hpk[WAVE]; }
+  // rounds 0..3 of phases B/C; re-loaded by the tail of phase C for the next iteration
+  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   while (true) {
-    // descriptor stream of phases B and C: 4 rounds in flight while phase A runs
-    uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
     // ---- phase A -----------------------------------------------------------------
-    if (!(P.debug_skip & 32)) for (int f = lane; f < P.nfill; f += WAVE) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    for (int f = 2 * lane; f < nfill4; f += 2 * WAVE) *reinterpret_cast<double2*>(fill0 + f) = make_double2(0.0, 0.0);
     OPFX_STAMP(10);
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
-    if (P.rh > 0 && !(P.debug_skip & 1)) {
-      for (int h = lane; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
+    if (P.rh > 0) {
+      if (hrow0 >= 0) { L.rhs[2 * hrow0] = 0.0; L.rhs[2 * hrow0 + 1] = 0.0; }
+      for (int h = lane + WAVE; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
       wave_fence();
       for (int h = 0; h < P.rh; ++h) {
-        const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
-        const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
-        const unsigned ent = he.x;
+        const uint4 cy = hy, ce = he;
+        const int hn = h + 1 < P.rh ? h + 1 : 0;           // next round (or round 0 of the next iteration)
+        hy = hpk[(size_t)(hn * 2) * WAVE]; he = hpk[(size_t)(hn * 2 + 1) * WAVE];
+        const unsigned ent = ce.x;
         const unsigned j = ent & 0xFFFF;
         if (j != NONE) {
-          const int i = he.y;
-          double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
-          double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
+          const int i = ce.y;
+          double g = __longlong_as_double(((long long)cy.y << 32) | cy.x);
+          double b = __longlong_as_double(((long long)cy.w << 32) | cy.z);
           if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
           if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
           const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
@@ -547,7 +561,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     OPFX_STAMP(11);
     double my = 0.0;
-    for (int r = 0; r < ((P.debug_skip & 2) ? 0 : P.ra); ++r) {
+    for (int r = 0; r < P.ra; ++r) {
       const ARound a = cur;
       cur = load_around(P, r + 1 < P.ra ? r + 1 : 0, lane);     // next round (or round 0 of the next iteration)
       const int i = lane + WAVE * r;
@@ -614,17 +628,25 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     if (it >= o.max_iter) { conv = false; break; }
     ++it;
     wave_fence();
-    // ---- phases B and C: block LU + forward substitution, then back substitution ----------
-    for (int r = 0; r < R; r += 4) {
-      do_round(q0, r);     q0 = ld_desc(r + 4);
-      do_round(q1, r + 1); q1 = ld_desc(r + 5);
-      do_round(q2, r + 2); q2 = ld_desc(r + 6);
-      do_round(q3, r + 3); q3 = ld_desc(r + 7);
-      if (r + 4 >= P.rb && r < P.rb) OPFX_STAMP(2);
+    // ---- phase B: block LU + forward substitution; phase C: back substitution ---------------
+    // Rounds of one level are independent; ordering is needed at level ends only, but on a
+    // single wave the fence is free (the LDS executes a wave's operations in order).
+    for (int r = 0; r < RB; r += 4) {
+      item_factor(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+    }
+    OPFX_STAMP(2);
+    for (int r = RB; r < R; r += 4) {
+      item_solve(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_solve(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_solve(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_solve(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
-    if (!(P.debug_skip & 16)) {
+    {
       double big = 0.0;
       for (int i = lane; i < nb; i += WAVE)
         if (L.bt[i] != BT_REF) big = fmax(big, fabs(L.rhs[2 * i]));      // (rhs of REF rows is never written)
@@ -667,62 +689,6 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // last bits of the result — may differ between runs (the single-wave kernel is
 // bit-reproducible).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
-  constexpr unsigned NONE = 0xFFFFu;
-  const unsigned tb = d.x & 0xFFFF;
-  if (tb == NONE) return;
-  const Blk bi = ld_blk(L.blk, d.x >> 16);
-  const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
-  const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-  const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
-  const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
-  const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
-  const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
-  if (tb & 0x8000u) {
-    const int i = tb & 0x7FFF, k = d.y >> 16;
-    const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
-    lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
-    lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
-  } else {
-    const Blk bj = ld_blk(L.blk, d.y >> 16);
-    double* tp = L.blk + 4 * tb;
-    lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
-    lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
-    lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
-    lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
-  }
-}
-
-__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
-  constexpr unsigned NONE = 0xFFFFu;
-  const unsigned k = d.x & 0xFFFF;
-  if (k == NONE) return;
-  double d1 = 0.0, d2 = 0.0;
-  if ((d.y & 0xFFFF) != NONE) {
-    const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
-    const unsigned j = d.y >> 16;
-    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
-    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-  }
-  if ((d.z & 0xFFFF) != NONE) {
-    const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
-    const unsigned j = d.z >> 16;
-    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
-    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-  }
-  const unsigned dblk = d.x >> 16;
-  if (dblk != NONE) {
-    const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
-    const Blk bk = ld_blk(L.blk, dblk);
-    const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-    L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
-    L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
-  } else {
-    lds_sub(&L.rhs[2 * k], d1);
-    lds_sub(&L.rhs[2 * k + 1], d2);
-  }
-}
-
 template <int NW>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int out_br,
                              int* iters_out, double* nrm_out) {
@@ -1094,7 +1060,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc > 8 ? 5 * E.nc : 8);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
-  unsigned long long t_last__ = __builtin_readcyclecounter();
+  OPFX_STAMP_INIT();
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     double* xr = io.x + b * E.nx;
     OPFX_STAMP(15);
@@ -1174,7 +1140,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       }
       blk_sync<NW>();
       int iters; double nrm;
-      t_last__ = __builtin_readcyclecounter();
+      OPFX_STAMP_RESET();
       const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
       blk_sync<NW>();
       OPFX_STAMP(5);
@@ -1573,7 +1539,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(ref_bus, ref_bus);
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
-  d.ra = p->ra; d.rh = p->rh; d.rb = p->rb; d.rc = p->rc;
+  d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   d.stamps = nullptr;
   if (getenv("OPFX_STAMPS")) {

@@ -58,6 +58,29 @@ struct BlockMap {
 //     A_ij -= A_ik Kinv A_kj / y_i -= A_ik Kinv y_k (accumulated with LDS atomics);
 //  C  per level in reverse: extra U-term items (accumulated with LDS atomics), then
 //     solve items with up to two U-terms inline.
+// Block ids: Jacobian blocks first, fill blocks last, so that the kernels zero the fill
+// part of the LU value array as one contiguous range (no index list to chase).
+void renumber_fill_last(opfx_plan* p) {
+  const int32_t n = p->n_blk;
+  std::vector<char> is_fill(n, 0);
+  for (int32_t f : p->fill_blk) is_fill[f] = 1;
+  std::vector<int32_t> perm(n);
+  int32_t next = 0;
+  for (int32_t b = 0; b < n; ++b) if (!is_fill[b]) perm[b] = next++;
+  for (int32_t b = 0; b < n; ++b) if (is_fill[b]) perm[b] = next++;
+  auto map = [&](std::vector<int32_t>& v) { for (auto& x : v) if (x >= 0) x = perm[x]; };
+  map(p->y_blk); map(p->diag_blk); map(p->fill_blk); map(p->tgt_blk);
+  map(p->src_ik); map(p->src_kk); map(p->u_blk);
+  const int32_t ntgt = (int32_t)p->tgt_blk.size();
+  for (int32_t t = 0; t < ntgt; ++t)
+    if (p->tgt_blk[t] >= 0)                      // src_kj of an rhs target is a bus, not a block
+      for (int32_t s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) p->src_kj[s] = perm[p->src_kj[s]];
+  std::vector<int32_t> row(n), col(n);
+  for (int32_t b = 0; b < n; ++b) { row[perm[b]] = p->blk_row[b]; col[perm[b]] = p->blk_col[b]; }
+  p->blk_row.swap(row); p->blk_col.swap(col);
+  std::sort(p->fill_blk.begin(), p->fill_blk.end());
+}
+
 void build_lane_programs(opfx_plan* p) {
   constexpr int KA = opfx_plan::KA;
   constexpr uint32_t NONE = 0xFFFFu;
@@ -178,11 +201,21 @@ void build_lane_programs(opfx_plan* p) {
     c_bounds.push_back((int32_t)(p->lp_c.size() / 192));
   }
   p->rc = (int32_t)(p->lp_c.size() / 192);
+  // The packed stream pads each part to a multiple of 4 rounds with empty items: the kernel
+  // keeps 4 rounds in flight in a rotating register set and loads unconditionally.
+  p->rb_pad = (p->rb + 3) & ~3;
+  p->rc_pad = (p->rc + 3) & ~3;
+  if (p->rb_pad + p->rc_pad < 4) p->rc_pad = 4;
   p->lp_groups = b_bounds;
-  for (int32_t cb : c_bounds) if (p->rb + cb > p->lp_groups.back()) p->lp_groups.push_back(p->rb + cb);
+  if (p->rb_pad > p->rb) p->lp_groups.push_back(p->rb_pad);
+  for (int32_t cb : c_bounds) if (p->rb_pad + cb > p->lp_groups.back()) p->lp_groups.push_back(p->rb_pad + cb);
+  if (p->rc_pad > p->rc) p->lp_groups.push_back(p->rb_pad + p->rc_pad);
   // ---- packed device forms ---------------------------------------------------------
   auto put_d = [](std::vector<uint32_t>& v, size_t at, double x) { std::memcpy(&v[at], &x, 8); };
-  p->lp_bc.assign((size_t)(p->rb + p->rc) * 64 * 4, 0u);
+  p->lp_bc.assign((size_t)(p->rb_pad + p->rc_pad) * 64 * 4, 0u);
+  for (size_t q = 0; q < p->lp_bc.size(); q += 4) {
+    p->lp_bc[q] = NONE | (NONE << 16); p->lp_bc[q + 1] = NONE | (NONE << 16); p->lp_bc[q + 2] = NONE | (NONE << 16);
+  }
   for (int r = 0; r < p->rb; ++r)
     for (int l = 0; l < 64; ++l) {
       p->lp_bc[((size_t)r * 64 + l) * 4 + 0] = p->lp_b[((size_t)r * 64 + l) * 2];
@@ -191,7 +224,7 @@ void build_lane_programs(opfx_plan* p) {
   for (int r = 0; r < p->rc; ++r)
     for (int l = 0; l < 64; ++l)
       for (int w = 0; w < 3; ++w)
-        p->lp_bc[((size_t)(p->rb + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 3 + w];
+        p->lp_bc[((size_t)(p->rb_pad + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 3 + w];
   p->lp_apk.assign((size_t)p->ra * 7 * 64 * 4, 0u);
   for (int r = 0; r < p->ra; ++r)
     for (int l = 0; l < 64; ++l) {
@@ -383,6 +416,7 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
     }
   }
   p->n_blk = (int32_t)p->blk_row.size();
+  renumber_fill_last(p);
   build_lane_programs(p);
   *out = p;
   return OPFX_OK;

@@ -39,6 +39,7 @@ struct opfx_plan {
   // descriptors with one coalesced access per round, once per kernel.
   static constexpr int KA = 4;             // ELL width: off-diagonal Ybus entries per bus row
   int32_t ra = 0, rh = 0, rb = 0, rc = 0;  // rounds: bus rows, heavy-row overflow, factor/forward, backward
+  int32_t rb_pad = 0, rc_pad = 0;          // rounds of the two parts of lp_bc (multiples of 4)
   std::vector<uint32_t> lp_a_ent;          // [ra][KA][64]  j | blk<<16   (0xFFFF = none)
   std::vector<double> lp_a_y;              // [ra][KA][64][2] g,b
   std::vector<double> lp_a_ydiag;          // [ra][64][2]
@@ -49,7 +50,7 @@ struct opfx_plan {
   std::vector<uint32_t> lp_b;              // [rb][64][2]  tb|ik<<16 , kk|kj<<16
   std::vector<uint32_t> lp_c;              // [rc][64][3]  k|dblk<<16 , blk1|j1<<16 , blk2|j2<<16
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
-  std::vector<uint32_t> lp_bc;             // [rb+rc][64][4]  B: w0,w1,0,0   C: w0,w1,w2,0
+  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  B: w0,w1,-,0   C: w0,w1,w2,0 (pad: empty items)
   std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
