@@ -71,25 +71,26 @@ struct DevPlan {
 };
 
 struct DevEnv {
-  int nx, na, npoly, npwl, nseg, nprice, nc, nobs, nres, ncost;
+  int nx, na, npoly, npwl, nseg, nc, nobs, nres, ncost, ncost_pre;
+  int nblk_d;                // doubles reserved for [LU blocks | result bank | staged table row beyond rhs]
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
-  int n_cont, n_inj, n_oseg, need_angle;
+  int n_cont, n_inj, n_oseg, need_angle, ncel;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
   double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
   double invalid_objective_share, diff_step, clipped_action_penalty;
   double not_converged_penalty;
-  const int *inj_slot, *inj_bus, *inj_act;         // flat list: bus | isQ<<16, sorted by slot (coalesced x reads)
-  const double *inj_coef, *qg_min, *qg_max;
+  const uint4* inj_pk;                             // flat list: {bus | isQ<<16, source, coefficient (2 words)}
+  const double *qg_min, *qg_max;
   const int *oseg_kind, *oseg_src, *oseg_dst, *oseg_n;   // observation = list of contiguous copies
   const int *act_slot, *act_lo_slot, *act_hi_slot, *clamp_lo_slot, *clamp_hi_slot;
   const double *act_scaling, *act_lo_const, *act_hi_const, *clamp_lo_const, *clamp_hi_const;
-  const int *cost_kind, *cost_pidx, *cost_qidx, *cost_pact, *cost_qact, *pwl_is_q;
+  // cost rows in processing order: rows fed by table values/set-points first (ncost_pre), then
+  // rows fed by the solve.  meta = kind | is_pwl<<4 | pwl_is_q<<5; sources: see src_val()
+  const int *cost_meta, *cost_psrc, *cost_qsrc, *cost_cbase, *coef_xslot;
   const double *cost_scale, *cost_coef;
-  const int *price_slot, *price_coef, *coef_price;   // coef_price: coef index -> price ordinal or -1
-  const int *con_ptr, *con_src, *con_worst, *con_grp;
-  int ncel;
+  const int2* con_pk;                              // {result index, constraint}
+  const int* con_worst;
   const double *con_min, *con_max, *con_autoscale, *con_pfac, *con_ppow, *con_cpen;
-  const int *obs_kind, *obs_idx, *obs_act;
   const int *cont_branch;
 };
 
@@ -186,11 +187,15 @@ __device__ __forceinline__ int wave_any(int pred) { return __any(pred); }
 
 // NW = wavefronts per instance.  Sections that only wavefront 0 executes use sec_sync
 // (never a workgroup barrier); hand-overs between wavefront 0 and the team use blk_sync.
-template <int NW> __device__ __forceinline__ void blk_sync() { __syncthreads(); }
-template <int NW> __device__ __forceinline__ void sec_sync() {
-  if (NW == 1) { __syncthreads(); }
-  else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void wave_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
 }
+// With one wavefront per instance both are compiler-only fences (see wave_fence below): a
+// __syncthreads() would drain every prefetched global load and every store (s_waitcnt vmcnt(0)).
+template <int NW> __device__ __forceinline__ void blk_sync() { if (NW == 1) wave_fence(); else __syncthreads(); }
+template <int NW> __device__ __forceinline__ void sec_sync() { wave_fence(); }
 
 struct Blk { double a11, a12, a21, a22; };
 __device__ __forceinline__ Blk ld_blk(const double* blk, int id) {
@@ -378,11 +383,6 @@ __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // making one lane's LDS writes visible to the other lanes needs no hardware wait at all:
 // only the COMPILER must not move or cache LDS accesses across this point.  (A
 // __syncthreads()/fence here would also drain the prefetched global loads: s_waitcnt vmcnt(0).)
-__device__ __forceinline__ void wave_fence() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
-}
 // 1/x by hardware estimate + two Newton steps (relative error ~1e-16; no denormal/overflow
 // special-casing: Jacobian pivots are O(1..1e4) in per-unit)
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -1043,12 +1043,58 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
 // ---------------------------------------------------------------------------
 // fused env.step kernel (opfx_step)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double xval(const double* xr, const double* sp, int slot, int act) {
-  return act >= 0 ? sp[act] : xr[slot];
+// value of a table cell during a step: src >= 0 -> staged table row, src < 0 -> set-point of
+// action ~src (a column written by an action is read from the set-point), NOSRC -> absent (0)
+constexpr int NOSRC = 0x7FFFFFFF;
+__device__ __forceinline__ double src_val(const double* xs, const double* sp, int src) {
+  return src == NOSRC ? 0.0 : (src >= 0 ? xs[src] : sp[~src]);
 }
 
 __device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
 
+__device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
+// constants or sampled prices living in the instance's table row `xc`
+__device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, int meta, int cbase, double pw_, double qv_) {
+  if (!(meta & 16)) {
+    double cf[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int xsl = E.coef_xslot[cbase + q];
+      cf[q] = xsl >= 0 ? xc[xsl] : E.cost_coef[cbase + q];
+    }
+    double pc = cf[0]; pc += cf[1] * pw_; pc += cf[2] * (pw_ * pw_);          // :38-40
+    double qc = cf[3]; qc += cf[4] * qv_; qc += cf[5] * (qv_ * qv_);          // :41-43
+    return pc + qc;
+  }
+  const double pwr = (meta & 32) ? qv_ : pw_;
+  const double s = sgn(pwr), pa = fabs(pwr);
+  double cst = 0.0;
+  for (int sg = 0; sg < E.nseg; ++sg) {                                     // :60-75
+    const int ci = cbase + sg * 3;
+    const double lo = E.cost_coef[ci], hi = E.cost_coef[ci + 1];
+    const int xsl = E.coef_xslot[ci + 2];
+    const double price = xsl >= 0 ? xc[xsl] : E.cost_coef[ci + 2];
+    const double la = fabs(lo), ha = fabs(hi);
+    const double inside = fmin(la, ha);
+    const bool same = (s == sgn(lo + hi));
+    const bool in_f = (pa > inside) && same;
+    const bool out_f = pa > fmax(la, ha);
+    if (out_f) cst += s * (hi - lo) * price;
+    if (in_f && !out_f) cst += s * (pa - inside) * price;
+  }
+  return cst;
+}
+
+// One launch = one env.step() for B instances.  Per instance: (1) the table row is staged in
+// LDS with coalesced loads (all HBM traffic of the prologue is in flight at once; every later
+// gather hits LDS), actions -> set-points, bus injections, table observations and the cost
+// rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
+// costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
+// indices) so that each phase pays one L2 round trip, not one per 64 items.
 template <bool V2, int NW>
 __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
@@ -1056,67 +1102,131 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
   const DevEnv& E = *Ep;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const Lds L = carve<V2>(P, E.na, E.nres, smem, 5 * E.nc > 8 ? 5 * E.nc : 8);
+  constexpr int NT = WAVE * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
+  double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
   OPFX_STAMP_INIT();
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     double* xr = io.x + b * E.nx;
+    const bool apply = io.mode != 1 && io.mode != 3;
     OPFX_STAMP(15);
+    // ---- stage the row ------------------------------------------------------------
+    {
+      const int nx = E.nx;
+      int q = tid;
+      for (; q + 7 * NT < nx; q += 8 * NT) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = xr[q + u * NT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xs[q + u * NT] = t[u];
+      }
+      for (; q < nx; q += NT) xs[q] = xr[q];
+    }
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
     if (wave == 0) {
-    for (int k = lane; k < E.na; k += WAVE) {
-      const int slot = E.act_slot[k];
-      double xv = xr[slot];
-      if (io.mode != 1 && io.mode != 3) {
-        double a = io.action[b * E.na + k];
-        a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                         // :429 (a NaN action stays NaN -> failed row)
-        const double lo = E.act_lo_slot[k] >= 0 ? xr[E.act_lo_slot[k]] : E.act_lo_const[k];
-        const double hi = E.act_hi_slot[k] >= 0 ? xr[E.act_hi_slot[k]] : E.act_hi_const[k];
-        const double delta = hi - lo;
-        const double sc = E.act_scaling[k];
-        double spt;
-        if (E.diff_step != 0.0) spt = (a * 2.0 - 1.0) * E.diff_step * delta + xv * sc;   // :453-458
-        else spt = a * delta + lo;                                                   // :461
-        if (E.clamp_enabled) {                                                       // :464-470
-          const int ch = E.clamp_hi_slot[k], cl = E.clamp_lo_slot[k];
-          if (ch > -2) { const double m = ch >= 0 ? xr[ch] : E.clamp_hi_const[k]; if (spt > m) spt = m; }
-          if (cl > -2) { const double m = cl >= 0 ? xr[cl] : E.clamp_lo_const[k]; if (spt < m) spt = m; }
+      for (int k0 = 0; k0 < E.na; k0 += 2 * WAVE) {
+        int slot[2], los[2], his[2], cls_[2], chs[2];
+        double av[2], sc[2], loc[2], hic[2], clc[2], chc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = k0 + u * WAVE + lane, kk = k < E.na ? k : E.na - 1;
+          slot[u] = E.act_slot[kk]; los[u] = E.act_lo_slot[kk]; his[u] = E.act_hi_slot[kk];
+          sc[u] = E.act_scaling[kk]; loc[u] = E.act_lo_const[kk]; hic[u] = E.act_hi_const[kk];
+          av[u] = apply ? io.action[b * E.na + kk] : 0.0;
+          cls_[u] = chs[u] = -2; clc[u] = chc[u] = 0.0;
+          if (E.clamp_enabled) {
+            cls_[u] = E.clamp_lo_slot[kk]; chs[u] = E.clamp_hi_slot[kk];
+            clc[u] = E.clamp_lo_const[kk]; chc[u] = E.clamp_hi_const[kk];
+          }
         }
-        xv = spt / sc;                                                               // :472-474
-        xr[slot] = xv;                                                               // :483
-        const double cur = (xv * sc - lo) / delta;                                   // :586
-        corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
+        if (k0 == 0) wave_fence();            // staged row visible (single wave: LDS executes in order)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = k0 + u * WAVE + lane;
+          if (k >= E.na) continue;
+          double xv = xs[slot[u]];
+          if (apply) {
+            double a = av[u];
+            a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                         // :429 (a NaN action stays NaN -> failed row)
+            const double lo = los[u] >= 0 ? xs[los[u]] : loc[u];
+            const double hi = his[u] >= 0 ? xs[his[u]] : hic[u];
+            const double delta = hi - lo;
+            double spt;
+            if (E.diff_step != 0.0) spt = (a * 2.0 - 1.0) * E.diff_step * delta + xv * sc[u];   // :453-458
+            else spt = a * delta + lo;                                                   // :461
+            if (E.clamp_enabled) {                                                       // :464-470
+              if (chs[u] > -2) { const double m = chs[u] >= 0 ? xs[chs[u]] : chc[u]; if (spt > m) spt = m; }
+              if (cls_[u] > -2) { const double m = cls_[u] >= 0 ? xs[cls_[u]] : clc[u]; if (spt < m) spt = m; }
+            }
+            xv = spt / sc[u];                                                            // :472-474
+            xr[slot[u]] = xv;                                                            // :483
+            const double cur = (xv * sc[u] - lo) / delta;                                // :586
+            corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
+          }
+          L.sp[k] = xv;
+        }
       }
-      L.sp[k] = xv;
+      corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
     }
-    corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
+    blk_sync<NW>();       // NW > 1: row staged by all waves, set-points by wave 0
+    // (limits are read before any set-point of this step is written back: xs keeps the
+    //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
+    // ---- table observations: do not depend on the solve ----------------------------------------
+    if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+      const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+      if (kind == 1) {
+        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = NaN;
+        continue;
+      }
+      const double* from = (kind == 0 ? xs : L.sp) + src;
+      for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = from[j];
     }
-    blk_sync<NW>();
     if (io.mode == 2 || io.mode == 3) {
-      if (wave == 0) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
-      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
-        const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
-        for (int j = lane; j < n; j += WAVE)
-          io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : NaN);
-      }
-      if (lane == 0 && io.mean_correction) io.mean_correction[b] = corr;
-      }
+      if (tid == 0 && io.mean_correction) io.mean_correction[b] = corr;
       blk_sync<NW>();
       continue;
     }
-    // ---- bus injections (makeSbus): lane = unit column (coalesced x reads), LDS accumulate --
+    double csum = 0.0;                       // this lane's share of the cost rows
     if (wave == 0) {
-    for (int i = lane; i < nb; i += WAVE) { L.psp[i] = 0.0; L.qsp[i] = 0.0; L.bt[i] = BT_PQ; }
-    wave_fence();
-    for (int e = lane; e < E.n_inj; e += WAVE) {
-      const int bq = E.inj_bus[e];
-      const double v = E.inj_coef[e] * xval(xr, L.sp, E.inj_slot[e], E.inj_act[e]);
-      lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
-    }
+      // ---- bus injections (makeSbus): flat list, LDS accumulate ----------------------------------
+      for (int i = lane; i < nb; i += WAVE) { L.psp[i] = 0.0; L.qsp[i] = 0.0; L.bt[i] = BT_PQ; }
+      wave_fence();
+      for (int e0 = 0; e0 < E.n_inj; e0 += 4 * WAVE) {
+        uint4 d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE + lane; d[u] = E.inj_pk[e < E.n_inj ? e : E.n_inj - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * WAVE + lane;
+          if (e >= E.n_inj) continue;
+          const int bq = d[u].x;
+          const double v = u2d(d[u].z, d[u].w) * src_val(xs, L.sp, (int)d[u].y);
+          lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
+        }
+      }
+      // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
+      for (int r0 = 0; r0 < E.ncost_pre; r0 += 2 * WAVE) {
+        int meta[2], ps[2], qs[2], cb[2];
+        double scl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = r0 + u * WAVE + lane, rr = r < E.ncost_pre ? r : E.ncost_pre - 1;
+          meta[u] = E.cost_meta[rr]; ps[u] = E.cost_psrc[rr]; qs[u] = E.cost_qsrc[rr]; cb[u] = E.cost_cbase[rr];
+          scl[u] = E.cost_scale[rr];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = r0 + u * WAVE + lane;
+          if (r >= E.ncost_pre) continue;
+          csum += cost_row(E, xs, meta[u], cb[u], src_val(xs, L.sp, ps[u]) * scl[u], src_val(xs, L.sp, qs[u]) * scl[u]);
+        }
+      }
     }
     OPFX_STAMP(0);
     // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
@@ -1170,21 +1280,32 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       {
         for (int q = lane; q < 5 * E.nc; q += WAVE) L.acc[q] = 0.0;
         wave_fence();
-        for (int e = lane; e < E.ncel; e += WAVE) {
-          const double v = R[E.con_src[e]];
-          const double lo = E.con_min[e], hi = E.con_max[e];
-          double* a = L.acc + 5 * E.con_grp[e];
-          if (v < lo) {
-            const double d = fabs(v - lo);
-            lds_sub(a + 0, -d); lds_sub(a + 4, -1.0);
-            __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 2), (unsigned long long)__double_as_longlong(d),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int e0 = 0; e0 < E.ncel; e0 += 2 * WAVE) {
+          int2 cd[2];
+          double lo[2], hi[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * WAVE + lane, ee = e < E.ncel ? e : E.ncel - 1;
+            cd[u] = E.con_pk[ee]; lo[u] = E.con_min[ee]; hi[u] = E.con_max[ee];
           }
-          if (v > hi) {
-            const double d = fabs(v - hi);
-            lds_sub(a + 1, -d); lds_sub(a + 4, -1.0);
-            __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 3), (unsigned long long)__double_as_longlong(d),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * WAVE + lane;
+            if (e >= E.ncel) continue;
+            const double v = R[cd[u].x];
+            double* a = L.acc + 5 * cd[u].y;
+            if (v < lo[u]) {
+              const double d = fabs(v - lo[u]);
+              lds_sub(a + 0, -d); lds_sub(a + 4, -1.0);
+              __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 2), (unsigned long long)__double_as_longlong(d),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (v > hi[u]) {
+              const double d = fabs(v - hi[u]);
+              lds_sub(a + 1, -d); lds_sub(a + 4, -1.0);
+              __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 3), (unsigned long long)__double_as_longlong(d),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
           }
         }
         wave_fence();
@@ -1205,56 +1326,16 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       }
       OPFX_STAMP(7);
       if (c == 0) {
-        // ---- objective (objective.py:6-87) --------------------------------------
-        double csum = 0.0;
+        // ---- cost rows fed by the solve: ext-grid P/Q, generator Q (objective.py:50-52) -----------
         const double* r_pe = R + 2 * nb + P.nbr;
         const double* r_qe = r_pe + P.nref;
         const double* r_qg = r_qe + P.nref;
-        for (int r = lane; r < E.ncost; r += WAVE) {
-          const int kind = E.cost_kind[r];
+        for (int r = E.ncost_pre + lane; r < E.ncost; r += WAVE) {
+          const int meta = E.cost_meta[r], pi = E.cost_psrc[r];
           double pw_, qv_;
-          if (kind == OPFX_COST_UNIT) {
-            const double sc = E.cost_scale[r];
-            pw_ = E.cost_pidx[r] >= 0 ? xval(xr, L.sp, E.cost_pidx[r], E.cost_pact[r]) * sc : 0.0;
-            qv_ = E.cost_qidx[r] >= 0 ? xval(xr, L.sp, E.cost_qidx[r], E.cost_qact[r]) * sc : 0.0;
-          } else if (kind == OPFX_COST_EXT_GRID) {
-            pw_ = r_pe[E.cost_pidx[r]]; qv_ = r_qe[E.cost_pidx[r]];
-          } else {
-            const double sc = E.cost_scale[r];
-            pw_ = E.cost_qidx[r] >= 0 ? xval(xr, L.sp, E.cost_qidx[r], E.cost_qact[r]) * sc : 0.0;
-            qv_ = r_qg[E.cost_pidx[r]];
-          }
-          if (r < E.npoly) {
-            double cf[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              const int ci = r * 6 + q;
-              const int pr = E.coef_price[ci];
-              cf[q] = pr >= 0 ? xr[E.price_slot[pr]] : E.cost_coef[ci];
-            }
-            double pc = cf[0]; pc += cf[1] * pw_; pc += cf[2] * (pw_ * pw_);          // :38-40
-            double qc = cf[3]; qc += cf[4] * qv_; qc += cf[5] * (qv_ * qv_);          // :41-43
-            csum += pc + qc;
-          } else {
-            const int w = r - E.npoly;
-            const double pwr = E.pwl_is_q[w] ? qv_ : pw_;
-            const double s = sgn(pwr), pa = fabs(pwr);
-            double cst = 0.0;
-            for (int sg = 0; sg < E.nseg; ++sg) {                                     // :60-75
-              const int ci = E.npoly * 6 + (w * E.nseg + sg) * 3;
-              const double lo = E.cost_coef[ci], hi = E.cost_coef[ci + 1];
-              const int pr = E.coef_price[ci + 2];
-              const double price = pr >= 0 ? xr[E.price_slot[pr]] : E.cost_coef[ci + 2];
-              const double la = fabs(lo), ha = fabs(hi);
-              const double inside = fmin(la, ha);
-              const bool same = (s == sgn(lo + hi));
-              const bool in_f = (pa > inside) && same;
-              const bool out_f = pa > fmax(la, ha);
-              if (out_f) cst += s * (hi - lo) * price;
-              if (in_f && !out_f) cst += s * (pa - inside) * price;
-            }
-            csum += cst;
-          }
+          if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
+          else { pw_ = src_val(xr, L.sp, E.cost_qsrc[r]) * E.cost_scale[r]; qv_ = r_qg[pi]; }
+          csum += cost_row(E, xr, meta, E.cost_cbase[r], pw_, qv_);
         }
         objective = -wave_sum_dpp(csum);                                                 // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
@@ -1263,10 +1344,9 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
-        const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
-        if (kind != 1 && c != 0) continue;              // table values do not depend on the solved case
-        for (int j = lane; j < n; j += WAVE)
-          io.obs[b * E.nobs + dst + j] = kind == 0 ? xr[src + j] : (kind == 2 ? L.sp[src + j] : R[src + j]);
+        if (E.oseg_kind[sg] != 1) continue;
+        const int src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+        for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = R[src + j];
       }
       }
       blk_sync<NW>();
@@ -1276,6 +1356,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     if (wave == 0) {
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
+      __builtin_amdgcn_s_waitcnt(0);      // the table observations written above are overwritten
       if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
       if (lane < E.nc) {
         if (io.valids) io.valids[b * E.nc + lane] = 0;
@@ -1610,7 +1691,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   e->ctx = ctx;
   DevEnv& E = e->de;
   E.nx = d->nx; E.na = d->na; E.npoly = d->npoly; E.npwl = d->npwl; E.nseg = d->nseg;
-  E.nprice = d->nprice; E.nc = d->nc; E.nobs = d->nobs; E.ncost = d->npoly + d->npwl;
+  E.nc = d->nc; E.nobs = d->nobs; E.ncost = d->npoly + d->npwl;
   E.nres = 3 * nb + p.nbr + 2 * p.nref;
   E.reward_kind = d->reward_kind; E.diff_objective = d->diff_objective;
   E.steps_per_episode = d->steps_per_episode; E.clamp_enabled = d->clamp_enabled;
@@ -1636,25 +1717,24 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   int rc = OPFX_OK;
   const size_t np_ = d->pinj_ptr[nb], nq_ = d->qinj_ptr[nb];
 #define PUTN(field, ptr, n) if (rc == OPFX_OK) rc = A.put(ptr, (size_t)(n), &E.field)
+  auto src_of = [&](int32_t slot) { return slot < 0 ? NOSRC : (slot_act[slot] >= 0 ? ~slot_act[slot] : slot); };
   {
-    // flat injection list sorted by column so that a wave reads x in coalesced runs
-    struct Inj { int32_t slot, bus, act; double coef; };
+    // flat injection list sorted by column; one 16-byte record per entry
+    struct Inj { int32_t slot, bus; double coef; };
     std::vector<Inj> inj;
     for (int i = 0; i < nb; ++i) {
-      for (int e = d->pinj_ptr[i]; e < d->pinj_ptr[i + 1]; ++e)
-        inj.push_back({d->pinj_slot[e], i, slot_act[d->pinj_slot[e]], d->pinj_coef[e]});
-      for (int e = d->qinj_ptr[i]; e < d->qinj_ptr[i + 1]; ++e)
-        inj.push_back({d->qinj_slot[e], i | (1 << 16), slot_act[d->qinj_slot[e]], d->qinj_coef[e]});
+      for (int e = d->pinj_ptr[i]; e < d->pinj_ptr[i + 1]; ++e) inj.push_back({d->pinj_slot[e], i, d->pinj_coef[e]});
+      for (int e = d->qinj_ptr[i]; e < d->qinj_ptr[i + 1]; ++e) inj.push_back({d->qinj_slot[e], i | (1 << 16), d->qinj_coef[e]});
     }
     std::stable_sort(inj.begin(), inj.end(), [](const Inj& a, const Inj& b) { return a.slot < b.slot; });
-    std::vector<int32_t> sl, bu, ac; std::vector<double> co;
-    for (auto& q : inj) { sl.push_back(q.slot); bu.push_back(q.bus); ac.push_back(q.act); co.push_back(q.coef); }
+    std::vector<uint4> pk;
+    for (auto& q : inj) {
+      if (q.slot < 0 || q.slot >= d->nx) { delete e; opfx_set_error("opfx_env_create: injection slot out of range"); return OPFX_ERR_INVALID; }
+      uint32_t w[2]; std::memcpy(w, &q.coef, 8);
+      pk.push_back(make_uint4((uint32_t)q.bus, (uint32_t)src_of(q.slot), w[0], w[1]));
+    }
     E.n_inj = (int)inj.size();
-    if (rc == OPFX_OK) rc = A.put(sl, &E.inj_slot);
-    if (rc == OPFX_OK) rc = A.put(bu, &E.inj_bus);
-    if (rc == OPFX_OK) rc = A.put(ac, &E.inj_act);
-    if (rc == OPFX_OK) rc = A.put(co, &E.inj_coef);
-    (void)np_; (void)nq_;
+    if (rc == OPFX_OK) rc = A.put(pk, &E.inj_pk);
   }
   if (d->qg_min && d->qg_max) { PUTN(qg_min, d->qg_min, nb); PUTN(qg_max, d->qg_max, nb); }
   PUTN(act_slot, d->act_slot, d->na); PUTN(act_scaling, d->act_scaling, d->na);
@@ -1666,37 +1746,45 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   }
   const size_t ncost = (size_t)d->npoly + d->npwl;
   const size_t ncoef = (size_t)d->npoly * 6 + (size_t)d->npwl * d->nseg * 3;
-  PUTN(cost_kind, d->cost_kind, ncost); PUTN(cost_pidx, d->cost_pidx, ncost); PUTN(cost_qidx, d->cost_qidx, ncost);
-  PUTN(cost_scale, d->cost_scale, ncost); PUTN(pwl_is_q, d->pwl_is_q, d->npwl); PUTN(cost_coef, d->cost_coef, ncoef);
+  PUTN(cost_coef, d->cost_coef, ncoef);
   {
-    std::vector<int32_t> pa(ncost, -1), qa(ncost, -1);
-    for (size_t r = 0; r < ncost; ++r) {
-      if (d->cost_kind[r] == OPFX_COST_UNIT) {
-        if (d->cost_pidx[r] >= 0) pa[r] = slot_act[d->cost_pidx[r]];
-        if (d->cost_qidx[r] >= 0) qa[r] = slot_act[d->cost_qidx[r]];
-      } else if (d->cost_kind[r] == OPFX_COST_GEN) {
-        if (d->cost_qidx[r] >= 0) qa[r] = slot_act[d->cost_qidx[r]];   // gen: qidx = slot of p_mw
-      }
-    }
-    if (rc == OPFX_OK) rc = A.put(pa, &E.cost_pact);
-    if (rc == OPFX_OK) rc = A.put(qa, &E.cost_qact);
-  }
-  PUTN(price_slot, d->price_slot, d->nprice); PUTN(price_coef, d->price_coef, d->nprice);
-  {
-    std::vector<int32_t> cp(ncoef, -1);
+    std::vector<int32_t> cx(ncoef, -1);
     for (int k = 0; k < d->nprice; ++k) {
-      if (d->price_coef[k] < 0 || (size_t)d->price_coef[k] >= ncoef) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: price_coef out of range"); break; }
-      cp[d->price_coef[k]] = k;
+      if (d->price_coef[k] < 0 || (size_t)d->price_coef[k] >= ncoef || d->price_slot[k] < 0 || d->price_slot[k] >= d->nx) {
+        rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: price_coef/price_slot out of range"); break;
+      }
+      cx[d->price_coef[k]] = d->price_slot[k];
     }
-    if (rc == OPFX_OK) rc = A.put(cp, &E.coef_price);
+    if (rc == OPFX_OK) rc = A.put(cx, &E.coef_xslot);
+    std::vector<int32_t> meta, ps, qs, cb;
+    std::vector<double> scl;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (size_t r = 0; r < ncost; ++r) {
+        const int kind = d->cost_kind[r];
+        if ((kind == OPFX_COST_UNIT) != (pass == 0)) continue;
+        const bool pwl = r >= (size_t)d->npoly;
+        const size_t w = pwl ? r - d->npoly : 0;
+        meta.push_back(kind | (pwl ? 16 : 0) | (pwl && d->pwl_is_q[w] ? 32 : 0));
+        cb.push_back(pwl ? (int32_t)(d->npoly * 6 + w * d->nseg * 3) : (int32_t)(r * 6));
+        scl.push_back(d->cost_scale[r]);
+        if (kind == OPFX_COST_UNIT) { ps.push_back(src_of(d->cost_pidx[r])); qs.push_back(src_of(d->cost_qidx[r])); }
+        else if (kind == OPFX_COST_GEN) { ps.push_back(d->cost_pidx[r]); qs.push_back(src_of(d->cost_qidx[r])); }   // gen: qidx = slot of p_mw
+        else { ps.push_back(d->cost_pidx[r]); qs.push_back(NOSRC); }
+      }
+      if (pass == 0) E.ncost_pre = (int)meta.size();
+    }
+    if (rc == OPFX_OK) rc = A.put(meta, &E.cost_meta);
+    if (rc == OPFX_OK) rc = A.put(ps, &E.cost_psrc);
+    if (rc == OPFX_OK) rc = A.put(qs, &E.cost_qsrc);
+    if (rc == OPFX_OK) rc = A.put(cb, &E.cost_cbase);
+    if (rc == OPFX_OK) rc = A.put(scl, &E.cost_scale);
   }
   const size_t ncel = d->nc ? d->con_ptr[d->nc] : 0;
-  PUTN(con_ptr, d->con_ptr, d->nc + 1); PUTN(con_src, d->con_src, ncel);
   {
-    std::vector<int32_t> grp(ncel);
-    for (int g = 0; g < d->nc; ++g) for (int e = d->con_ptr[g]; e < d->con_ptr[g + 1]; ++e) grp[e] = g;
+    std::vector<int2> pk(ncel);
+    for (int g = 0; g < d->nc; ++g) for (int e = d->con_ptr[g]; e < d->con_ptr[g + 1]; ++e) pk[e] = make_int2(d->con_src[e], g);
     E.ncel = (int)ncel;
-    if (rc == OPFX_OK) rc = A.put(grp, &E.con_grp);
+    if (rc == OPFX_OK) rc = A.put(pk, &E.con_pk);
   }
   {
     // NaN bound = absent boundary: comparisons against it must be false
@@ -1709,7 +1797,6 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   PUTN(con_autoscale, d->con_autoscale, d->nc); PUTN(con_pfac, d->con_penalty_factor, d->nc);
   PUTN(con_ppow, d->con_penalty_power, d->nc); PUTN(con_cpen, d->con_count_penalty, d->nc);
   PUTN(con_worst, d->con_worst_case, d->nc);
-  PUTN(obs_kind, d->obs_kind, d->nobs); PUTN(obs_idx, d->obs_idx, d->nobs);
   {
     // observation as maximal contiguous runs: kind 0 = x[src..], 1 = result bank, 2 = action set-points
     std::vector<int32_t> sk, ss, sd, sn;
@@ -1732,9 +1819,14 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
 #undef PUTN
   for (size_t i = 0; rc == OPFX_OK && i < ncel; ++i)
     if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }
+  {
+    // the table row is staged over [rhs | LU blocks]: make that region large enough
+    const int nbe = (nb + 1) & ~1;
+    E.nblk_d = std::max(E.nres, d->nx - 2 * nbe);
+  }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nres, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8);
   *out = e;
   return OPFX_OK;
 }
