@@ -1043,6 +1043,14 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
 // ---------------------------------------------------------------------------
 // fused env.step kernel (opfx_step)
 // ---------------------------------------------------------------------------
+// Pointers read out of a descriptor that itself lives in memory are generic to the compiler
+// (flat_load: counted on vmcnt AND lgkmcnt, serialising them with the LDS traffic); all of
+// ours are hipMalloc'ed, so say so.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+  return (const __attribute__((address_space(1))) T*)p;
+}
+
 // value of a table cell during a step: src >= 0 -> staged table row, src < 0 -> set-point of
 // action ~src (a column written by an action is read from the set-point), NOSRC -> absent (0)
 constexpr int NOSRC = 0x7FFFFFFF;
@@ -1061,11 +1069,11 @@ __device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
 __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, int meta, int cbase, double pw_, double qv_) {
   if (!(meta & 16)) {
     double cf[6];
+    int xsl[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int xsl = E.coef_xslot[cbase + q];
-      cf[q] = xsl >= 0 ? xc[xsl] : E.cost_coef[cbase + q];
-    }
+    for (int q = 0; q < 6; ++q) { xsl[q] = as_global(E.coef_xslot)[cbase + q]; cf[q] = as_global(E.cost_coef)[cbase + q]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (xsl[q] >= 0) cf[q] = xc[xsl[q]];
     double pc = cf[0]; pc += cf[1] * pw_; pc += cf[2] * (pw_ * pw_);          // :38-40
     double qc = cf[3]; qc += cf[4] * qv_; qc += cf[5] * (qv_ * qv_);          // :41-43
     return pc + qc;
@@ -1075,9 +1083,10 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
   double cst = 0.0;
   for (int sg = 0; sg < E.nseg; ++sg) {                                     // :60-75
     const int ci = cbase + sg * 3;
-    const double lo = E.cost_coef[ci], hi = E.cost_coef[ci + 1];
-    const int xsl = E.coef_xslot[ci + 2];
-    const double price = xsl >= 0 ? xc[xsl] : E.cost_coef[ci + 2];
+    const double lo = as_global(E.cost_coef)[ci], hi = as_global(E.cost_coef)[ci + 1];
+    const int xsl = as_global(E.coef_xslot)[ci + 2];
+    double price = as_global(E.cost_coef)[ci + 2];
+    if (xsl >= 0) price = xc[xsl];
     const double la = fabs(lo), ha = fabs(hi);
     const double inside = fmin(la, ha);
     const bool same = (s == sgn(lo + hi));
@@ -1129,20 +1138,19 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
     if (wave == 0) {
+      // (no action row in modes 1/3: any readable row keeps the loads unconditional)
+      const double* act_row = apply ? io.action + b * E.na : xr;
       for (int k0 = 0; k0 < E.na; k0 += 2 * WAVE) {
         int slot[2], los[2], his[2], cls_[2], chs[2];
         double av[2], sc[2], loc[2], hic[2], clc[2], chc[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int k = k0 + u * WAVE + lane, kk = k < E.na ? k : E.na - 1;
-          slot[u] = E.act_slot[kk]; los[u] = E.act_lo_slot[kk]; his[u] = E.act_hi_slot[kk];
-          sc[u] = E.act_scaling[kk]; loc[u] = E.act_lo_const[kk]; hic[u] = E.act_hi_const[kk];
-          av[u] = apply ? io.action[b * E.na + kk] : 0.0;
-          cls_[u] = chs[u] = -2; clc[u] = chc[u] = 0.0;
-          if (E.clamp_enabled) {
-            cls_[u] = E.clamp_lo_slot[kk]; chs[u] = E.clamp_hi_slot[kk];
-            clc[u] = E.clamp_lo_const[kk]; chc[u] = E.clamp_hi_const[kk];
-          }
+          slot[u] = as_global(E.act_slot)[kk]; los[u] = as_global(E.act_lo_slot)[kk]; his[u] = as_global(E.act_hi_slot)[kk];
+          sc[u] = as_global(E.act_scaling)[kk]; loc[u] = as_global(E.act_lo_const)[kk]; hic[u] = as_global(E.act_hi_const)[kk];
+          av[u] = act_row[kk];
+          cls_[u] = as_global(E.clamp_lo_slot)[kk]; chs[u] = as_global(E.clamp_hi_slot)[kk];
+          clc[u] = as_global(E.clamp_lo_const)[kk]; chc[u] = as_global(E.clamp_hi_const)[kk];
         }
         if (k0 == 0) wave_fence();            // staged row visible (single wave: LDS executes in order)
 #pragma unroll
@@ -1178,7 +1186,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
     if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
-      const int kind = E.oseg_kind[sg], src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+      const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
       if (kind == 1) {
         if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = NaN;
         continue;
@@ -1200,7 +1208,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       for (int e0 = 0; e0 < E.n_inj; e0 += 4 * WAVE) {
         uint4 d[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE + lane; d[u] = E.inj_pk[e < E.n_inj ? e : E.n_inj - 1]; }
+        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE + lane; const auto* q = as_global(reinterpret_cast<const unsigned*>(E.inj_pk)) + 4 * (size_t)(e < E.n_inj ? e : E.n_inj - 1); d[u] = make_uint4(q[0], q[1], q[2], q[3]); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u * WAVE + lane;
@@ -1217,8 +1225,8 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int r = r0 + u * WAVE + lane, rr = r < E.ncost_pre ? r : E.ncost_pre - 1;
-          meta[u] = E.cost_meta[rr]; ps[u] = E.cost_psrc[rr]; qs[u] = E.cost_qsrc[rr]; cb[u] = E.cost_cbase[rr];
-          scl[u] = E.cost_scale[rr];
+          meta[u] = as_global(E.cost_meta)[rr]; ps[u] = as_global(E.cost_psrc)[rr]; qs[u] = as_global(E.cost_qsrc)[rr]; cb[u] = as_global(E.cost_cbase)[rr];
+          scl[u] = as_global(E.cost_scale)[rr];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1237,7 +1245,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     double nrm0 = 0.0;
     const int base_out = io.outage ? io.outage[b] : -1;
     for (int c = 0; c <= E.n_cont; ++c) {
-      const int out_br = c == 0 ? base_out : E.cont_branch[c - 1];
+      const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
@@ -1286,7 +1294,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int e = e0 + u * WAVE + lane, ee = e < E.ncel ? e : E.ncel - 1;
-            cd[u] = E.con_pk[ee]; lo[u] = E.con_min[ee]; hi[u] = E.con_max[ee];
+            { const auto* q = as_global(reinterpret_cast<const int*>(E.con_pk)) + 2 * (size_t)ee; cd[u] = make_int2(q[0], q[1]); } lo[u] = as_global(E.con_min)[ee]; hi[u] = as_global(E.con_max)[ee];
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -1313,12 +1321,12 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           const int g = lane;
           const double* a = L.acc + 5 * g;
           const double cnt = a[4];
-          double viol = E.con_worst[g] ? a[2] + a[3] : a[0] + a[1];                  // :113-122, :93-98
-          const double as = E.con_autoscale[g];
+          double viol = as_global(E.con_worst)[g] ? a[2] + a[3] : a[0] + a[1];                  // :113-122, :93-98
+          const double as = as_global(E.con_autoscale)[g];
           if (as != 0.0) viol *= as;                                                 // :82-83
-          const double pw = E.con_ppow[g];
-          double pen = (pw == 1.0 ? viol : pow(viol, pw)) * E.con_pfac[g];
-          pen += cnt * E.con_cpen[g];                                                // :124-128
+          const double pw = as_global(E.con_ppow)[g];
+          double pen = (pw == 1.0 ? viol : pow(viol, pw)) * as_global(E.con_pfac)[g];
+          pen += cnt * as_global(E.con_cpen)[g];                                                // :124-128
           valid_acc = valid_acc && (cnt == 0.0);
           viol_acc += viol;
           pen_acc += -pen;
@@ -1331,11 +1339,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
         const double* r_qe = r_pe + P.nref;
         const double* r_qg = r_qe + P.nref;
         for (int r = E.ncost_pre + lane; r < E.ncost; r += WAVE) {
-          const int meta = E.cost_meta[r], pi = E.cost_psrc[r];
+          const int meta = as_global(E.cost_meta)[r], pi = as_global(E.cost_psrc)[r];
           double pw_, qv_;
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
-          else { pw_ = src_val(xr, L.sp, E.cost_qsrc[r]) * E.cost_scale[r]; qv_ = r_qg[pi]; }
-          csum += cost_row(E, xr, meta, E.cost_cbase[r], pw_, qv_);
+          else { pw_ = src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r]; qv_ = r_qg[pi]; }
+          csum += cost_row(E, xr, meta, as_global(E.cost_cbase)[r], pw_, qv_);
         }
         objective = -wave_sum_dpp(csum);                                                 // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
@@ -1344,8 +1352,8 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
-        if (E.oseg_kind[sg] != 1) continue;
-        const int src = E.oseg_src[sg], dst = E.oseg_dst[sg], n = E.oseg_n[sg];
+        if (as_global(E.oseg_kind)[sg] != 1) continue;
+        const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
         for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = R[src + j];
       }
       }
@@ -1740,9 +1748,18 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   PUTN(act_slot, d->act_slot, d->na); PUTN(act_scaling, d->act_scaling, d->na);
   PUTN(act_lo_slot, d->act_lo_slot, d->na); PUTN(act_hi_slot, d->act_hi_slot, d->na);
   PUTN(act_lo_const, d->act_lo_const, d->na); PUTN(act_hi_const, d->act_hi_const, d->na);
-  if (d->clamp_enabled) {
-    PUTN(clamp_lo_slot, d->clamp_lo_slot, d->na); PUTN(clamp_hi_slot, d->clamp_hi_slot, d->na);
-    PUTN(clamp_lo_const, d->clamp_lo_const, d->na); PUTN(clamp_hi_const, d->clamp_hi_const, d->na);
+  {
+    // always present on the device (slot -2 = no clamp) so that the kernel loads them unconditionally
+    std::vector<int32_t> cls_(d->na, -2), chs(d->na, -2);
+    std::vector<double> clc(d->na, 0.0), chc(d->na, 0.0);
+    if (d->clamp_enabled) {
+      cls_.assign(d->clamp_lo_slot, d->clamp_lo_slot + d->na); chs.assign(d->clamp_hi_slot, d->clamp_hi_slot + d->na);
+      clc.assign(d->clamp_lo_const, d->clamp_lo_const + d->na); chc.assign(d->clamp_hi_const, d->clamp_hi_const + d->na);
+    }
+    if (rc == OPFX_OK) rc = A.put(cls_, &E.clamp_lo_slot);
+    if (rc == OPFX_OK) rc = A.put(chs, &E.clamp_hi_slot);
+    if (rc == OPFX_OK) rc = A.put(clc, &E.clamp_lo_const);
+    if (rc == OPFX_OK) rc = A.put(chc, &E.clamp_hi_const);
   }
   const size_t ncost = (size_t)d->npoly + d->npwl;
   const size_t ncoef = (size_t)d->npoly * 6 + (size_t)d->npwl * d->nseg * 3;
