@@ -134,6 +134,12 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ double nan_max(double a, double b) {
   return (a != a) ? a : ((b != b) ? b : fmax(a, b));
 }
+// Same for NON-NEGATIVE operands (|x|, NaN with its sign cleared), branch-free: their bit
+// patterns order like unsigned integers and every NaN pattern lies above +inf.
+__device__ __forceinline__ double nn_max(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  return __longlong_as_double((long long)(ua > ub ? ua : ub));
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = nan_max(v, __shfl_xor(v, o, WAVE));
@@ -169,13 +175,13 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   v += dpp_f64<0x143, 0xC>(0.0, v);       // row_bcast:31 -> rows 2,3
   return read_lane63(v);
 }
-__device__ __forceinline__ double wave_max_dpp(double v) {   // NaN-propagating
-  v = nan_max(v, dpp_f64<0xB1, 0xF>(v, v));
-  v = nan_max(v, dpp_f64<0x4E, 0xF>(v, v));
-  v = nan_max(v, dpp_f64<0x141, 0xF>(v, v));
-  v = nan_max(v, dpp_f64<0x140, 0xF>(v, v));
-  v = nan_max(v, dpp_f64<0x142, 0xA>(v, v));
-  v = nan_max(v, dpp_f64<0x143, 0xC>(v, v));
+__device__ __forceinline__ double wave_max_dpp(double v) {   // NaN-propagating; v >= 0 or NaN
+  v = nn_max(v, dpp_f64<0xB1, 0xF>(v, v));
+  v = nn_max(v, dpp_f64<0x4E, 0xF>(v, v));
+  v = nn_max(v, dpp_f64<0x141, 0xF>(v, v));
+  v = nn_max(v, dpp_f64<0x140, 0xF>(v, v));
+  v = nn_max(v, dpp_f64<0x142, 0xA>(v, v));
+  v = nn_max(v, dpp_f64<0x143, 0xC>(v, v));
   return read_lane63(v);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -489,17 +495,63 @@ __device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane)
   return a;
 }
 
+// ---- a branch out of service (per-instance outage, N-1 contingency) -------------------
+// Phase A runs on the shared Ybus; afterwards two lanes (one per end bus of the outaged
+// branch) take that branch's four stamps out again: mismatch, the (f,t)/(t,f) Jacobian
+// blocks and the two diagonal blocks.  (Comparing every Ybus entry against the outage
+// would cost ~25 instructions per entry in every solve.)  Stash in L.acc[4..15] — free
+// during a solve: lane l keeps {Y_ii, Y_ij} of its end in acc[4+4l..], block ids in acc[12+l].
+__device__ __forceinline__ void outage_stash(const DevPlan& P, const Lds& L, int lane, int out_br) {
+  if (lane < 2) {
+    const double* y = P.br_y + out_br * 8;            // ff, ft, tf, tt (g,b each)
+    double* st = L.acc + 4 + 4 * lane;
+    st[0] = y[lane == 0 ? 0 : 6]; st[1] = y[lane == 0 ? 1 : 7];
+    st[2] = y[lane == 0 ? 2 : 4]; st[3] = y[lane == 0 ? 3 : 5];
+    const int i = lane == 0 ? P.br_f[out_br] : P.br_t[out_br];
+    reinterpret_cast<int2*>(L.acc + 12)[lane] = make_int2(P.y_blk[P.br_pos[out_br * 4 + 1 + lane]], P.diag_blk[i]);
+  }
+  wave_fence();
+}
+__device__ __forceinline__ double outage_fixup(const Lds& L, int lane, int of, int ot, double my) {
+  const int i = lane == 0 ? of : ot, j = lane == 0 ? ot : of;
+  const double* st = L.acc + 4 + 4 * lane;
+  const double yii_g = st[0], yii_b = st[1], yij_g = st[2], yij_b = st[3];
+  const int2 ids = reinterpret_cast<const int2*>(L.acc + 12)[lane];
+  const double vri = L.vr[i], vii = L.vi[i], vrj = L.vr[j], vij = L.vi[j];
+  const double tr = yij_g * vrj - yij_b * vij, ti = yij_g * vij + yij_b * vrj;
+  const double dcr = vri * tr + vii * ti, dci = vii * tr - vri * ti;      // V_i conj(Y_ij V_j) of the branch
+  const double v2 = vri * vri + vii * vii;
+  const double dyr = yii_g * v2, dyi = -yii_b * v2;                         // conj(Y_ii)|V_i|^2 of the branch
+  const int t = L.bt[i];
+  if (t == BT_REF) {                       // parked injection S_i
+    L.rhs[2 * i] -= dcr + dyr;
+    L.rhs[2 * i + 1] -= dci + dyi;
+    return my;
+  }
+  const bool pv = t == BT_PV;
+  const double r0 = L.rhs[2 * i] + (dcr + dyr);
+  L.rhs[2 * i] = r0;
+  double r1 = 0.0;
+  if (!pv) { r1 = L.rhs[2 * i + 1] + (dci + dyi); L.rhs[2 * i + 1] = r1; }
+  if (ids.x >= 0) {
+    Blk o = ld_blk(L.blk, ids.x);
+    o.a11 -= dci; o.a12 -= dcr;
+    if (!pv) { o.a21 += dcr; o.a22 -= dci; }
+    st_blk(L.blk, ids.x, o);
+  }
+  Blk d = ld_blk(L.blk, ids.y);
+  d.a11 += dci; d.a12 -= 2.0 * dyr + dcr;
+  if (!pv) { d.a21 -= dcr; d.a22 -= 2.0 * dyi + dci; }
+  st_blk(L.blk, ids.y, d);
+  return nn_max(my, nn_max(fabs(r0), fabs(r1)));
+}
+
 __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
                         int* iters_out, double* nrm_out) {
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
   int of = -1, ot = -1;
-  double oy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (out_br >= 0) {
-    of = P.br_f[out_br]; ot = P.br_t[out_br];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
-  }
+  if (out_br >= 0) { of = P.br_f[out_br]; ot = P.br_t[out_br]; outage_stash(P, L, lane, out_br); }
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
   // that the compiler's wait-count insertion sees a fixed number of loads in flight and
   // waits for the oldest only (a conditional load anywhere in these loops degrades every
@@ -525,6 +577,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     // ---- phase A -----------------------------------------------------------------
     for (int f = 2 * lane; f < nfill4; f += 2 * WAVE) *reinterpret_cast<double2*>(fill0 + f) = make_double2(0.0, 0.0);
     OPFX_STAMP(10);
+    double my = 0.0;
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
     if (P.rh > 0) {
@@ -539,10 +592,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         const unsigned j = ent & 0xFFFF;
         if (j != NONE) {
           const int i = ce.y;
-          double g = __longlong_as_double(((long long)cy.y << 32) | cy.x);
-          double b = __longlong_as_double(((long long)cy.w << 32) | cy.z);
-          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+          const double g = __longlong_as_double(((long long)cy.y << 32) | cy.x);
+          const double b = __longlong_as_double(((long long)cy.w << 32) | cy.z);
           const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
           const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
@@ -560,7 +611,6 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       wave_fence();
     }
     OPFX_STAMP(11);
-    double my = 0.0;
     for (int r = 0; r < P.ra; ++r) {
       const ARound a = cur;
       cur = load_around(P, r + 1 < P.ra ? r + 1 : 0, lane);     // next round (or round 0 of the next iteration)
@@ -577,9 +627,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         for (int k = 0; k < 4; ++k) {
           const unsigned jr = ent[k] & 0xFFFF;
           const unsigned j = jr != NONE ? jr : (unsigned)i;
-          double g = a.y[k].x, b = a.y[k].y;
-          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
+          const double g = a.y[k].x, b = a.y[k].y;
           const double vrj = L.vr[j], vij = L.vi[j];
           const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
@@ -593,9 +641,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           }
         }
         if (t != BT_REF) {
-          double g = a.yd.x, b = a.yd.y;
-          if (i == of) { g -= oy[0]; b -= oy[1]; }
-          if (i == ot) { g -= oy[6]; b -= oy[7]; }
+          const double g = a.yd.x, b = a.yd.y;
           const double v2 = vri * vri + vii * vii;
           const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
           const double pc = sr + yr, qc = si + yi;
@@ -603,7 +649,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
           L.rhs[2 * i] = -fp;
           L.rhs[2 * i + 1] = -fq;
-          my = nan_max(my, nan_max(fabs(fp), fabs(fq)));
+          if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: see outage_fixup)
           // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
@@ -611,15 +657,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         } else {
           // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
           // in its rhs slots so that the result pass needs no second walk over the row
-          double g = a.yd.x, b = a.yd.y;
-          if (i == of) { g -= oy[0]; b -= oy[1]; }
-          if (i == ot) { g -= oy[6]; b -= oy[7]; }
+          const double g = a.yd.x, b = a.yd.y;
           const double v2 = vri * vri + vii * vii;
           L.rhs[2 * i] = sr + g * v2;
           L.rhs[2 * i + 1] = si - b * v2;
         }
       }
     }
+    if (of >= 0) { wave_fence(); if (lane < 2) my = outage_fixup(L, lane, of, ot, my); wave_fence(); }
     OPFX_STAMP(12);
     nrm = wave_max_dpp(my);
     OPFX_STAMP(1);
@@ -697,12 +742,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = P.nb;
   int of = -1, ot = -1;
-  double oy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (out_br >= 0) {
-    of = P.br_f[out_br]; ot = P.br_t[out_br];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) oy[q] = P.br_y[out_br * 8 + q];
-  }
+  if (out_br >= 0) { of = P.br_f[out_br]; ot = P.br_t[out_br]; if (wave == 0) outage_stash(P, L, lane, out_br); }
   const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc);
   const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
   double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
@@ -723,8 +763,6 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const int i = he.y;
         double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
         double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
-        if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-        if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
         const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
         const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
         const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
@@ -755,8 +793,6 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           const unsigned jr = ent[k] & 0xFFFF;
           const unsigned j = jr != NONE ? jr : (unsigned)i;
           double g = a.y[k].x, b = a.y[k].y;
-          if (i == of && (int)j == ot) { g -= oy[2]; b -= oy[3]; }
-          if (i == ot && (int)j == of) { g -= oy[4]; b -= oy[5]; }
           const double vrj = L.vr[j], vij = L.vi[j];
           const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
@@ -769,8 +805,6 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           }
         }
         double g = a.yd.x, b = a.yd.y;
-        if (i == of) { g -= oy[0]; b -= oy[1]; }
-        if (i == ot) { g -= oy[6]; b -= oy[7]; }
         const double v2 = vri * vri + vii * vii;
         const double yr = g * v2, yi = -b * v2;
         if (t != BT_REF) {
@@ -779,7 +813,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
           L.rhs[2 * i] = -fp;
           L.rhs[2 * i + 1] = -fq;
-          my = nan_max(my, nan_max(fabs(fp), fabs(fq)));
+          if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: outage_fixup)
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
           st_blk(L.blk, a.dw & 0xFFFF, jb);
@@ -789,12 +823,13 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         }
       }
     }
+    if (of >= 0) { __syncthreads(); if (tid < 2) my = outage_fixup(L, tid, of, ot, my); }
     my = wave_max_dpp(my);
     if (lane == 0) xw[wave] = my;
     __syncthreads();
     nrm = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) nrm = nan_max(nrm, xw[w]);
+    for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
     if (!(nrm == nrm)) { conv = false; break; }
     if (nrm < o.tol) { conv = true; break; }
     if (it >= o.max_iter) { conv = false; break; }
@@ -1002,7 +1037,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
-  const Lds L = carve<V2>(P, 0, nres_, smem, 8);
+  const Lds L = carve<V2>(P, 0, nres_, smem, 16);
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
@@ -1113,7 +1148,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8);
+  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 16 ? 5 * E.nc : 16);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
@@ -1673,7 +1708,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
-  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8);
+  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 16);
   int grid = 0;
   const int team = pick_team(lds, ctx->v2);
   auto kern = !ctx->v2 ? k_solve<false, 1> : (team == 4 ? k_solve<true, 4> : (team == 2 ? k_solve<true, 2> : k_solve<true, 1>));
@@ -1843,7 +1878,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 16 ? 5 * d->nc : 16);
   *out = e;
   return OPFX_OK;
 }
