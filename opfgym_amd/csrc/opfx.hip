@@ -222,7 +222,22 @@ constexpr int BT_PQ = 1, BT_PV = 2, BT_REF = 3, BT_PQ_HI = 4, BT_PQ_LO = 5;
 struct Lds {
   double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp, *acc;
   unsigned char* bt;
+  // second-generation kernels: structure-of-arrays images.  rhs = P-row values [nb], rq =
+  // Q-row values [nb]; block component c of block id at blk[c * bs + id].  A wave's 64-bit
+  // LDS accesses are served in two groups of 32 lanes over 32 eight-byte bank pairs: with
+  // one double per id the bank depends on (id mod 32) only, whereas 32-byte block records
+  // (16-byte rhs pairs) put every access of a group on 8 (16) of the 32 bank pairs.
+  double* rq;
+  int bs;
 };
+__device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
+  const double* p = L.blk + id;
+  return Blk{p[0], p[L.bs], p[2 * L.bs], p[3 * L.bs]};
+}
+__device__ __forceinline__ void st_blk2(const Lds& L, int id, const Blk& b) {
+  double* p = L.blk + id;
+  p[0] = b.a11; p[L.bs] = b.a12; p[2 * L.bs] = b.a21; p[3 * L.bs] = b.a22;
+}
 
 // Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
 __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
@@ -424,8 +439,8 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
   if (tb == NONE) return;
-  const Blk bi = ld_blk(L.blk, d.x >> 16);
-  const Blk bk = ld_blk(L.blk, d.y & 0xFFFF);
+  const Blk bi = ld_blk2(L, d.x >> 16);
+  const Blk bk = ld_blk2(L, d.y & 0xFFFF);
   const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
   const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
   const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
@@ -433,16 +448,16 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
   if (tb & 0x8000u) {
     const int i = tb & 0x7FFF, k = d.y >> 16;
-    const double r1 = L.rhs[2 * k], r2 = L.rhs[2 * k + 1];
-    lds_sub(&L.rhs[2 * i], w11 * r1 + w12 * r2);
-    lds_sub(&L.rhs[2 * i + 1], w21 * r1 + w22 * r2);
+    const double r1 = L.rhs[k], r2 = L.rq[k];
+    lds_sub(&L.rhs[i], w11 * r1 + w12 * r2);
+    lds_sub(&L.rq[i], w21 * r1 + w22 * r2);
   } else {
-    const Blk bj = ld_blk(L.blk, d.y >> 16);
-    double* tp = L.blk + 4 * tb;
-    lds_sub(tp + 0, w11 * bj.a11 + w12 * bj.a21);
-    lds_sub(tp + 1, w11 * bj.a12 + w12 * bj.a22);
-    lds_sub(tp + 2, w21 * bj.a11 + w22 * bj.a21);
-    lds_sub(tp + 3, w21 * bj.a12 + w22 * bj.a22);
+    const Blk bj = ld_blk2(L, d.y >> 16);
+    double* tp = L.blk + tb;
+    lds_sub(tp, w11 * bj.a11 + w12 * bj.a21);
+    lds_sub(tp + L.bs, w11 * bj.a12 + w12 * bj.a22);
+    lds_sub(tp + 2 * L.bs, w21 * bj.a11 + w22 * bj.a21);
+    lds_sub(tp + 3 * L.bs, w21 * bj.a12 + w22 * bj.a22);
   }
 }
 
@@ -452,27 +467,27 @@ __device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
   if (k == NONE) return;
   double d1 = 0.0, d2 = 0.0;
   if ((d.y & 0xFFFF) != NONE) {
-    const Blk a = ld_blk(L.blk, d.y & 0xFFFF);
+    const Blk a = ld_blk2(L, d.y & 0xFFFF);
     const unsigned j = d.y >> 16;
-    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    const double x1 = L.rhs[j], x2 = L.rq[j];
     d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
   }
   if ((d.z & 0xFFFF) != NONE) {
-    const Blk a = ld_blk(L.blk, d.z & 0xFFFF);
+    const Blk a = ld_blk2(L, d.z & 0xFFFF);
     const unsigned j = d.z >> 16;
-    const double x1 = L.rhs[2 * j], x2 = L.rhs[2 * j + 1];
+    const double x1 = L.rhs[j], x2 = L.rq[j];
     d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
   }
   const unsigned dblk = d.x >> 16;
   if (dblk != NONE) {
-    const double y1 = L.rhs[2 * k] - d1, y2 = L.rhs[2 * k + 1] - d2;
-    const Blk bk = ld_blk(L.blk, dblk);
+    const double y1 = L.rhs[k] - d1, y2 = L.rq[k] - d2;
+    const Blk bk = ld_blk2(L, dblk);
     const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-    L.rhs[2 * k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
-    L.rhs[2 * k + 1] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
+    L.rhs[k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
+    L.rq[k] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
   } else {
-    lds_sub(&L.rhs[2 * k], d1);
-    lds_sub(&L.rhs[2 * k + 1], d2);
+    lds_sub(&L.rhs[k], d1);
+    lds_sub(&L.rq[k], d2);
   }
 }
 
@@ -524,25 +539,25 @@ __device__ __forceinline__ double outage_fixup(const Lds& L, int lane, int of, i
   const double dyr = yii_g * v2, dyi = -yii_b * v2;                         // conj(Y_ii)|V_i|^2 of the branch
   const int t = L.bt[i];
   if (t == BT_REF) {                       // parked injection S_i
-    L.rhs[2 * i] -= dcr + dyr;
-    L.rhs[2 * i + 1] -= dci + dyi;
+    L.rhs[i] -= dcr + dyr;
+    L.rq[i] -= dci + dyi;
     return my;
   }
   const bool pv = t == BT_PV;
-  const double r0 = L.rhs[2 * i] + (dcr + dyr);
-  L.rhs[2 * i] = r0;
+  const double r0 = L.rhs[i] + (dcr + dyr);
+  L.rhs[i] = r0;
   double r1 = 0.0;
-  if (!pv) { r1 = L.rhs[2 * i + 1] + (dci + dyi); L.rhs[2 * i + 1] = r1; }
+  if (!pv) { r1 = L.rq[i] + (dci + dyi); L.rq[i] = r1; }
   if (ids.x >= 0) {
-    Blk o = ld_blk(L.blk, ids.x);
+    Blk o = ld_blk2(L, ids.x);
     o.a11 -= dci; o.a12 -= dcr;
     if (!pv) { o.a21 += dcr; o.a22 -= dci; }
-    st_blk(L.blk, ids.x, o);
+    st_blk2(L, ids.x, o);
   }
-  Blk d = ld_blk(L.blk, ids.y);
+  Blk d = ld_blk2(L, ids.y);
   d.a11 += dci; d.a12 -= 2.0 * dyr + dcr;
   if (!pv) { d.a21 -= dcr; d.a22 -= 2.0 * dyi + dci; }
-  st_blk(L.blk, ids.y, d);
+  st_blk2(L, ids.y, d);
   return nn_max(my, nn_max(fabs(r0), fabs(r1)));
 }
 
@@ -561,8 +576,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   const int RB = P.rb, R = P.rb + P.rc;                  // padded round counts (multiples of 4, R >= 4)
   auto ld_desc = [&](int r) { return stream[(size_t)(r < R ? r : r - R) * WAVE]; };
   const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
-  const int nfill4 = 4 * P.nfill;
-  double* const fill0 = L.blk + 4 * (P.nblk - P.nfill);   // fill blocks are numbered last (plan.cpp)
+  const int fill_lo = P.nblk - P.nfill;                    // fill blocks are numbered last (plan.cpp)
 
   int it = 0;
   double nrm = 0.0;
@@ -575,14 +589,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   while (true) {
     // ---- phase A -----------------------------------------------------------------
-    for (int f = 2 * lane; f < nfill4; f += 2 * WAVE) *reinterpret_cast<double2*>(fill0 + f) = make_double2(0.0, 0.0);
+    for (int f = fill_lo + lane; f < P.nblk; f += WAVE) st_blk2(L, f, Blk{0.0, 0.0, 0.0, 0.0});
     OPFX_STAMP(10);
     double my = 0.0;
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
     if (P.rh > 0) {
-      if (hrow0 >= 0) { L.rhs[2 * hrow0] = 0.0; L.rhs[2 * hrow0 + 1] = 0.0; }
-      for (int h = lane + WAVE; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
+      if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
+      for (int h = lane + WAVE; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
       wave_fence();
       for (int h = 0; h < P.rh; ++h) {
         const uint4 cy = hy, ce = he;
@@ -602,10 +616,10 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           if (bid != NONE && t != BT_REF) {
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk(L.blk, bid, jb);
+            st_blk2(L, bid, jb);
           }
-          lds_sub(&L.rhs[2 * i], -cr);
-          lds_sub(&L.rhs[2 * i + 1], -ci);
+          lds_sub(&L.rhs[i], -cr);
+          lds_sub(&L.rq[i], -ci);
         }
       }
       wave_fence();
@@ -619,7 +633,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         const int t = L.bt[i];
         const double vri = L.vr[i], vii = L.vi[i];
         double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
-        if (a.dw >> 16) { sr = L.rhs[2 * i]; si = L.rhs[2 * i + 1]; }
+        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
         const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
         // branch-free over the 4 ELL slots (padding slots carry Y = 0 and read V_i): the four
         // dependency chains interleave instead of being serialised by exec-mask branches
@@ -637,7 +651,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
             // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk(L.blk, bid, jb);
+            st_blk2(L, bid, jb);
           }
         }
         if (t != BT_REF) {
@@ -647,20 +661,20 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double pc = sr + yr, qc = si + yi;
           const double fp = pc - L.psp[i];
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
-          L.rhs[2 * i] = -fp;
-          L.rhs[2 * i + 1] = -fq;
+          L.rhs[i] = -fp;
+          L.rq[i] = -fq;
           if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: see outage_fixup)
           // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk(L.blk, a.dw & 0xFFFF, jb);
+          st_blk2(L, a.dw & 0xFFFF, jb);
         } else {
           // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
           // in its rhs slots so that the result pass needs no second walk over the row
           const double g = a.yd.x, b = a.yd.y;
           const double v2 = vri * vri + vii * vii;
-          L.rhs[2 * i] = sr + g * v2;
-          L.rhs[2 * i + 1] = si - b * v2;
+          L.rhs[i] = sr + g * v2;
+          L.rq[i] = si - b * v2;
         }
       }
     }
@@ -694,11 +708,11 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     {
       double big = 0.0;
       for (int i = lane; i < nb; i += WAVE)
-        if (L.bt[i] != BT_REF) big = fmax(big, fabs(L.rhs[2 * i]));      // (rhs of REF rows is never written)
+        if (L.bt[i] != BT_REF) big = fmax(big, fabs(L.rhs[i]));      // (rhs of REF rows is never written)
       const bool small = !(wave_max_dpp(big) > 0.25);          // wave-uniform (false for NaN too)
       for (int i = lane; i < nb; i += WAVE) {
         if (L.bt[i] == BT_REF) continue;
-        const double dth = L.rhs[2 * i], sc = 1.0 + L.rhs[2 * i + 1];
+        const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
         double sn, cs;
         if (small) {
           // |dth| <= 0.25: Taylor series to x^15 / x^14, truncation error < 1e-21
@@ -751,8 +765,8 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   bool conv = false;
   while (true) {
     // ---- phase A ------------------------------------------------------------------
-    for (int f = tid; f < P.nfill; f += NT) st_blk(L.blk, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
-    for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[2 * i] = 0.0; L.rhs[2 * i + 1] = 0.0; }
+    for (int f = tid; f < P.nfill; f += NT) st_blk2(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
     __syncthreads();
     for (int h = wave; h < P.rh; h += NW) {
       const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
@@ -771,10 +785,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         if (bid != NONE && t != BT_REF) {
           Blk jb{ci, cr, -cr, ci};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-          st_blk(L.blk, bid, jb);
+          st_blk2(L, bid, jb);
         }
-        lds_sub(&L.rhs[2 * i], -cr);
-        lds_sub(&L.rhs[2 * i + 1], -ci);
+        lds_sub(&L.rhs[i], -cr);
+        lds_sub(&L.rq[i], -ci);
       }
     }
     __syncthreads();
@@ -786,7 +800,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const int t = L.bt[i];
         const double vri = L.vr[i], vii = L.vi[i];
         double sr = 0.0, si = 0.0;
-        if (a.dw >> 16) { sr = L.rhs[2 * i]; si = L.rhs[2 * i + 1]; }
+        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
         const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -801,7 +815,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           if (bid != NONE && t != BT_REF) {
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk(L.blk, bid, jb);
+            st_blk2(L, bid, jb);
           }
         }
         double g = a.yd.x, b = a.yd.y;
@@ -811,15 +825,15 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           const double pc = sr + yr, qc = si + yi;
           const double fp = pc - L.psp[i];
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
-          L.rhs[2 * i] = -fp;
-          L.rhs[2 * i + 1] = -fq;
+          L.rhs[i] = -fp;
+          L.rq[i] = -fq;
           if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: outage_fixup)
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk(L.blk, a.dw & 0xFFFF, jb);
+          st_blk2(L, a.dw & 0xFFFF, jb);
         } else {
-          L.rhs[2 * i] = sr + yr;
-          L.rhs[2 * i + 1] = si + yi;
+          L.rhs[i] = sr + yr;
+          L.rq[i] = si + yi;
         }
       }
     }
@@ -847,7 +861,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
       if (L.bt[i] == BT_REF) continue;
-      const double dth = L.rhs[2 * i], sc = 1.0 + L.rhs[2 * i + 1];
+      const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
       double sn, cs;
       sincos(dth, &sn, &cs);
       const double vr = L.vr[i], vi = L.vi[i];
@@ -964,8 +978,8 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     double qgen = 0.0;
     if (V2 && t == BT_REF) {
       const int ro = P.ref_ord[i];
-      r_pe[ro] = (L.rhs[2 * i] - L.psp[i]) * base;
-      r_qe[ro] = (L.rhs[2 * i + 1] - L.qsp[i]) * base;
+      r_pe[ro] = (L.rhs[i] - L.psp[i]) * base;          // (V2: rhs/rq are separate arrays)
+      r_qe[ro] = (L.rq[i] - L.qsp[i]) * base;
     } else if (t == BT_REF || t == BT_PV) {
       double ir = 0.0, ii = 0.0;
       for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
@@ -1021,8 +1035,10 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   if (V2) { L.vm = nullptr; L.va = nullptr; }
   else { L.vm = nxt; L.va = L.vm + nbe; nxt = L.va + nbe; }
   L.psp = nxt; L.qsp = L.psp + nbe; L.rhs = L.qsp + nbe;
+  L.rq = L.rhs + nbe;
   L.blk = L.rhs + 2 * nbe;
-  const int nblk_d = 4 * P.nblk > nres ? 4 * P.nblk : nres;
+  L.bs = (P.nblk + 1) & ~1;
+  const int nblk_d = 4 * L.bs > nres ? 4 * L.bs : nres;
   L.sp = L.blk + ((nblk_d + 1) & ~1);
   L.acc = L.sp + na;
   L.bt = reinterpret_cast<unsigned char*>(L.acc + nacc);
@@ -1585,7 +1601,7 @@ namespace {
 
 size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc = 0) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
-  size_t blk = (std::max<size_t>((size_t)4 * p.n_blk, (size_t)nres) + 1) & ~(size_t)1;
+  size_t blk = (std::max<size_t>((size_t)4 * (((size_t)p.n_blk + 1) & ~(size_t)1), (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
