@@ -415,6 +415,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
 __device__ __forceinline__ void lds_sub(double* p, double v) {
   __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 
 #ifdef OPFX_ENABLE_STAMPS
 #define OPFX_STAMP_INIT() unsigned long long t_last__ = __builtin_readcyclecounter()
@@ -441,23 +444,24 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if (tb == NONE) return;
   const Blk bi = ld_blk2(L, d.x >> 16);
   const Blk bk = ld_blk2(L, d.y & 0xFFFF);
-  const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
-  const double w11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * rdet;
-  const double w12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * rdet;
-  const double w21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * rdet;
-  const double w22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * rdet;
+  // m = -A_ik A_kk^-1 (the sign folded into the reciprocal: the update is an atomic ADD of m A_kj)
+  const double nrdet = fast_rcp(bk.a12 * bk.a21 - bk.a11 * bk.a22);
+  const double m11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * nrdet;
+  const double m12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * nrdet;
+  const double m21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * nrdet;
+  const double m22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * nrdet;
   if (tb & 0x8000u) {
     const int i = tb & 0x7FFF, k = d.y >> 16;
     const double r1 = L.rhs[k], r2 = L.rq[k];
-    lds_sub(&L.rhs[i], w11 * r1 + w12 * r2);
-    lds_sub(&L.rq[i], w21 * r1 + w22 * r2);
+    lds_add(&L.rhs[i], m11 * r1 + m12 * r2);
+    lds_add(&L.rq[i], m21 * r1 + m22 * r2);
   } else {
     const Blk bj = ld_blk2(L, d.y >> 16);
     double* tp = L.blk + tb;
-    lds_sub(tp, w11 * bj.a11 + w12 * bj.a21);
-    lds_sub(tp + L.bs, w11 * bj.a12 + w12 * bj.a22);
-    lds_sub(tp + 2 * L.bs, w21 * bj.a11 + w22 * bj.a21);
-    lds_sub(tp + 3 * L.bs, w21 * bj.a12 + w22 * bj.a22);
+    lds_add(tp, m11 * bj.a11 + m12 * bj.a21);
+    lds_add(tp + L.bs, m11 * bj.a12 + m12 * bj.a22);
+    lds_add(tp + 2 * L.bs, m21 * bj.a11 + m22 * bj.a21);
+    lds_add(tp + 3 * L.bs, m21 * bj.a12 + m22 * bj.a22);
   }
 }
 
@@ -618,8 +622,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
             st_blk2(L, bid, jb);
           }
-          lds_sub(&L.rhs[i], -cr);
-          lds_sub(&L.rq[i], -ci);
+          lds_add(&L.rhs[i], cr);
+          lds_add(&L.rq[i], ci);
         }
       }
       wave_fence();
@@ -787,8 +791,8 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
           st_blk2(L, bid, jb);
         }
-        lds_sub(&L.rhs[i], -cr);
-        lds_sub(&L.rq[i], -ci);
+        lds_add(&L.rhs[i], cr);
+        lds_add(&L.rq[i], ci);
       }
     }
     __syncthreads();
@@ -1186,6 +1190,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       }
       for (; q < nx; q += NT) xs[q] = xr[q];
     }
+    blk_sync<NW>();       // staged row visible (one wave: compiler fence; team: all waves staged)
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
     if (wave == 0) {
@@ -1203,7 +1208,6 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           cls_[u] = as_global(E.clamp_lo_slot)[kk]; chs[u] = as_global(E.clamp_hi_slot)[kk];
           clc[u] = as_global(E.clamp_lo_const)[kk]; chc[u] = as_global(E.clamp_hi_const)[kk];
         }
-        if (k0 == 0) wave_fence();            // staged row visible (single wave: LDS executes in order)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int k = k0 + u * WAVE + lane;
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           if (e >= E.n_inj) continue;
           const int bq = d[u].x;
           const double v = u2d(d[u].z, d[u].w) * src_val(xs, L.sp, (int)d[u].y);
-          lds_sub(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), -v);
+          lds_add(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), v);
         }
       }
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
@@ -1355,13 +1359,13 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
             double* a = L.acc + 5 * cd[u].y;
             if (v < lo[u]) {
               const double d = fabs(v - lo[u]);
-              lds_sub(a + 0, -d); lds_sub(a + 4, -1.0);
+              lds_add(a + 0, d); lds_add(a + 4, 1.0);
               __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 2), (unsigned long long)__double_as_longlong(d),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
             if (v > hi[u]) {
               const double d = fabs(v - hi[u]);
-              lds_sub(a + 1, -d); lds_sub(a + 4, -1.0);
+              lds_add(a + 1, d); lds_add(a + 4, 1.0);
               __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 3), (unsigned long long)__double_as_longlong(d),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }

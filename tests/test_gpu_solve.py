@@ -91,6 +91,8 @@ def test_outage_axis():
     assert (out['converged'].astype(bool) == ok).all()
     assert np.abs(out['vm'][ok] - ref['vm'][ok]).max() < TOL_V
     assert np.abs(out['loading'][ok] - ref['loading'][ok]).max() < 1e-6
+    # an inexact Jacobian (wrong outage correction) would still converge, only more slowly
+    assert (np.abs(out['iterations'][ok] - ref['iterations'][ok]) <= 1).all(), (out['iterations'], ref['iterations'])
 
 
 def test_enforce_q_lims():
