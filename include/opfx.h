@@ -120,7 +120,8 @@ enum {
   OPFX_ARR_PIV_BUS, OPFX_ARR_PIV_UPTR, OPFX_ARR_U_BLK, OPFX_ARR_U_COL,
   OPFX_ARR_BLK_ROW, OPFX_ARR_BLK_COL,
   OPFX_ARR_LP_A_ENT, OPFX_ARR_LP_A_DBLK, OPFX_ARR_LP_H_ENT, OPFX_ARR_LP_H_ROW,
-  OPFX_ARR_LP_B, OPFX_ARR_LP_C
+  OPFX_ARR_LP_B, OPFX_ARR_LP_C,
+  OPFX_ARR_BR_ISLAND   /* [nbr] 1 = taking this branch out cuts some bus off every REF bus */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };

@@ -56,7 +56,7 @@ struct DevPlan {
   const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
   const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
   const int *lev_pptr, *piv_bus, *piv_uptr, *u_blk, *u_col;
-  const int *br_f, *br_t, *br_pos, *ref_bus, *ref_ord;
+  const int *br_f, *br_t, *br_pos, *br_island, *ref_bus, *ref_ord;
   const double *vm_set, *va_set, *vr0, *vi0, *y_g, *y_b, *br_y, *br_kf, *br_kt;
   // lane programme (plan.h)
   int ra, rh, rb, rc;
@@ -909,6 +909,10 @@ template <bool V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm) {
   const int wave = threadIdx.x >> 6;
+  // An outage that cuts buses off every REF bus makes the Newton matrix singular: reported as
+  // the CPU restatement reports it (one step into NaN, not converged) without spending the
+  // iterations a nearly singular matrix would otherwise burn.
+  if (out_br >= 0 && P.br_island[out_br]) { *iters = 1; *nrm = __builtin_nan(""); return false; }
   int total = 0;
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
@@ -1680,7 +1684,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(diag_blk, diag_blk); PUT(fill_blk, fill_blk); PUT(lev_tptr, lev_tptr); PUT(tgt_blk, tgt_blk);
   PUT(tgt_sptr, tgt_sptr); PUT(src_ik, src_ik); PUT(src_kk, src_kk); PUT(src_kj, src_kj);
   PUT(lev_pptr, lev_pptr); PUT(piv_bus, piv_bus); PUT(piv_uptr, piv_uptr); PUT(u_blk, u_blk);
-  PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(ref_bus, ref_bus);
+  PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(br_island, br_island); PUT(ref_bus, ref_bus);
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc

@@ -321,6 +321,27 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
     p->br_pos[k * 4 + 2] = ypos(t, f); p->br_pos[k * 4 + 3] = ypos(t, t);
   }
 
+  // ---- islanding outages: the Newton matrix of such a case is singular; the solvers report
+  // them as not converged at once (pandapower would de-energise the island instead) ----------
+  {
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> nbrs(nb);      // (other bus, branch)
+    for (int32_t k = 0; k < nbr; ++k) { nbrs[p->br_f[k]].push_back({p->br_t[k], k}); nbrs[p->br_t[k]].push_back({p->br_f[k], k}); }
+    p->br_island.assign(nbr, 0);
+    std::vector<char> seen(nb);
+    std::vector<int32_t> stack;
+    for (int32_t out = 0; out < nbr; ++out) {
+      std::fill(seen.begin(), seen.end(), 0);
+      stack.clear();
+      for (int32_t r : p->ref_bus) { seen[r] = 1; stack.push_back(r); }
+      int32_t reached = (int32_t)stack.size();
+      while (!stack.empty()) {
+        const int32_t u = stack.back(); stack.pop_back();
+        for (auto& e : nbrs[u]) if (e.second != out && !seen[e.first]) { seen[e.first] = 1; ++reached; stack.push_back(e.first); }
+      }
+      p->br_island[out] = reached < nb ? 1 : 0;
+    }
+  }
+
   // ---- Jacobian block pattern on non-REF buses -------------------------------
   BlockMap bm{nb, {}, &p->blk_row, &p->blk_col};
   std::vector<std::set<int32_t>> adj(nb);
@@ -452,6 +473,7 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_H_ROW: v = u32(p->lp_h_row); break;
     case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
+    case OPFX_ARR_BR_ISLAND: v = &p->br_island; break;
     case OPFX_ARR_Y_PTR: v = &p->y_ptr; break;
     case OPFX_ARR_Y_COL: v = &p->y_col; break;
     case OPFX_ARR_Y_BLK: v = &p->y_blk; break;

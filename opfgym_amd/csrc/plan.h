@@ -21,6 +21,7 @@ struct opfx_plan {
   std::vector<double> y_g, y_b;
   // per-branch positions of its four stamps in the CSR (for per-instance outages)
   std::vector<int32_t> br_pos;         // [nbr*4] ff, ft, tf, tt
+  std::vector<int32_t> br_island;      // [nbr] 1 = outage of this branch leaves a bus without a path to a REF bus
   // block LU pattern
   int32_t n_blk = 0;
   std::vector<int32_t> blk_row, blk_col;   // [n_blk]

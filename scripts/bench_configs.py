@@ -12,13 +12,22 @@ CONFIGS = {
     'config4_qmarket_mv_urban_shard': (envs.QMarket, dict(simbench_network_name='1-MV-urban--0-sw'), 8192),
     'config5_n1_voltage_control_hv_urban': (envs.SecurityConstrainedVoltageControl,
                                             dict(simbench_network_name='1-HV-urban--0-sw',
-                                                 n_minus_one_lines=tuple(range(1, 9))), 4096),
+                                                 n_minus_one_lines='first8_non_islanding'), 4096),
     'config1_max_renewable_lv_rural': (envs.MaxRenewable, dict(simbench_network_name='1-LV-rural1--0-sw',
                                                                min_sgen_power=0.005, min_storage_power=0.005), 8192),
 }
 only = sys.argv[1:] or list(CONFIGS)
 for name in only:
     cls, kw, B = CONFIGS[name]
+    kw = dict(kw)
+    if kw.get('n_minus_one_lines') == 'first8_non_islanding':
+        # contingencies = lines whose removal does not island (here: the first 8 of them)
+        from opfgym_amd import grids
+        from opfgym_amd.case import net_to_case
+        from helpers import non_bridge_branches
+        case_ = net_to_case(grids.get_grid(kw['simbench_network_name'])[0])
+        ok = [int(case_.br_elem[b]) for b in non_bridge_branches(case_) if case_.br_kind[b] == 0]
+        kw['n_minus_one_lines'] = tuple(ok[:8])
     env = cls(batch_size=B, device='cuda:0', seed=0, **kw)
     rng = np.random.default_rng(0)
     t0 = time.perf_counter(); env.reset(options={'step': rng.choice(env.train_steps, B)}); torch.cuda.synchronize()

@@ -16,14 +16,19 @@ ctx = capi.Context(plan, 0)
 p, q = random_injections(net, case, B, 1)
 dev = torch.device('cuda:0')
 pt, qt = torch.tensor(p, device=dev), torch.tensor(q, device=dev)
+kw = {}
+if os.environ.get('OUTAGE'):
+    from helpers import non_bridge_branches
+    cand = non_bridge_branches(case)
+    kw['outage'] = torch.tensor(cand[np.arange(B) % len(cand)].astype(np.int32), device=dev)
 for _ in range(3):
-    out = capi.solve(ctx, pt, qt)
+    out = capi.solve(ctx, pt, qt, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 20
 e0.record()
 for _ in range(reps):
-    out = capi.solve(ctx, pt, qt)
+    out = capi.solve(ctx, pt, qt, **kw)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps

@@ -108,3 +108,17 @@ def test_ctx_create_fails_loudly_without_gpu(built_lib):
     plan = capi.Plan(net_to_case(grids.two_bus()))
     with pytest.raises(capi.OpfxError):
         capi.Context(plan, 0)
+
+
+def test_islanding_outages_flagged():
+    """OPFX_ARR_BR_ISLAND marks exactly the branches whose outage cuts a bus off every REF bus."""
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    from helpers import non_bridge_branches
+    for code in ('1-MV-urban--0-sw', '1-HV-urban--0-sw', 'hv-small'):
+        net, _ = grids.get_grid(code)
+        case = net_to_case(net)
+        plan = capi.Plan(case)
+        island = plan.array('br_island')
+        assert len(island) == case.nbr
+        assert set(np.flatnonzero(island == 0).tolist()) == set(non_bridge_branches(case).tolist())
