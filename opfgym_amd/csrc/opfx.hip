@@ -65,8 +65,8 @@ struct DevPlan {
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
   const int* lp_hrows;
   int n_hrows;
-  const int* lp_groups;      // [n_groups+1] round offsets: independent groups of the B/C stream
-  int n_groups;
+  const unsigned *lp_team2, *lp_team4;   // per-wave streams of the cooperative kernels (plan.h)
+  int team_rounds2, team_rounds4;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
 };
 
@@ -752,6 +752,17 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // last bits of the result — may differ between runs (the single-wave kernel is
 // bit-reproducible).
 // ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
+// descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
+  const unsigned flags = __builtin_amdgcn_readfirstlane(d.w);      // same for every item of a round
+  if (flags & 2u) item_solve(L, d); else item_factor(L, d);
+  if (flags & 1u) lds_barrier();
+}
+
 template <int NW>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int out_br,
                              int* iters_out, double* nrm_out) {
@@ -761,12 +772,15 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   const int nb = P.nb;
   int of = -1, ot = -1;
   if (out_br >= 0) { of = P.br_f[out_br]; ot = P.br_t[out_br]; if (wave == 0) outage_stash(P, L, lane, out_br); }
-  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc);
+  const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
+  const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4;        // multiple of 4, >= 4
+  auto ld_desc = [&](int k) { return stream[(size_t)(k < K ? k : k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
   const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
   double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
+  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   while (true) {
     // ---- phase A ------------------------------------------------------------------
     for (int f = tid; f < P.nfill; f += NT) st_blk2(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
@@ -852,15 +866,13 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     if (nrm < o.tol) { conv = true; break; }
     if (it >= o.max_iter) { conv = false; break; }
     ++it;
-    // ---- phases B and C: independent groups of rounds, one barrier per group ------------------
-    for (int g = 0; g < P.n_groups; ++g) {
-      const int r0 = P.lp_groups[g], r1 = P.lp_groups[g + 1];
-      if (r0 == r1) continue;
-      for (int r = r0 + wave; r < r1; r += NW) {
-        const uint4 d = stream[(size_t)r * WAVE + lane];
-        if (r < P.rb) item_factor(L, d); else item_solve(L, d);
-      }
-      __syncthreads();
+    // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
+    // group of mutually independent rounds ends ------------------------------------------------
+    for (int k = 0; k < K; k += 4) {
+      team_step(L, q0); q0 = ld_desc(k + 4);
+      team_step(L, q1); q1 = ld_desc(k + 5);
+      team_step(L, q2); q2 = ld_desc(k + 6);
+      team_step(L, q3); q3 = ld_desc(k + 7);
     }
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
@@ -1697,8 +1709,9 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   d.n_hrows = (int)p->lp_hrows.size();
-  PUT(lp_groups, lp_groups);
-  d.n_groups = (int)p->lp_groups.size() - 1;
+  if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
+  if (rc == OPFX_OK) rc = A.put(p->lp_team[1], &d.lp_team4);
+  d.team_rounds2 = p->team_rounds[0]; d.team_rounds4 = p->team_rounds[1];
   {
     void* ws = nullptr;
     const size_t n_ws = (size_t)c->n_cu * 16 * 2 * (size_t)p->nb;

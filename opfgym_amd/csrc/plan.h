@@ -55,6 +55,11 @@ struct opfx_plan {
   std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
+  // cooperative kernels (2 or 4 wavefronts per instance): the rounds of each group dealt round-robin
+  // to the waves and laid out per wave, [round][wave][64][4]; word 3 of an item carries flags:
+  // bit 0 = workgroup barrier after this round (end of a group), bit 1 = back-substitution item.
+  std::vector<uint32_t> lp_team[2];        // [0]: 2 waves, [1]: 4 waves
+  int32_t team_rounds[2] = {0, 0};         // rounds per wave (multiples of 4)
   std::vector<int32_t> lp_groups;          // round offsets into lp_bc: rounds of one group are mutually
                                            // independent (an elimination level / its U pre-items / its solves)
   int32_t nnz_j = 0;
