@@ -75,6 +75,7 @@ struct DevEnv {
   int nblk_d;                // doubles reserved for [LU blocks | result bank | staged table row beyond rhs]
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
   int n_cont, n_inj, n_oseg, need_angle, ncel;
+  int max_mod;               // modifier records reserved per instance (env modifiers + outage + contingency)
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
   double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
   double invalid_objective_share, diff_step, clipped_action_penalty;
@@ -229,6 +230,7 @@ struct Lds {
   // (16-byte rhs pairs) put every access of a group on 8 (16) of the 32 bank pairs.
   double* rq;
   int bs;
+  double* mod;               // per-instance branch modifiers (MOD_DOUBLES each), see mods_*
 };
 __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
   const double* p = L.blk + id;
@@ -514,63 +516,85 @@ __device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane)
   return a;
 }
 
-// ---- a branch out of service (per-instance outage, N-1 contingency) -------------------
-// Phase A runs on the shared Ybus; afterwards two lanes (one per end bus of the outaged
-// branch) take that branch's four stamps out again: mismatch, the (f,t)/(t,f) Jacobian
-// blocks and the two diagonal blocks.  (Comparing every Ybus entry against the outage
-// would cost ~25 instructions per entry in every solve.)  Stash in L.acc[4..15] — free
-// during a solve: lane l keeps {Y_ii, Y_ij} of its end in acc[4+4l..], block ids in acc[12+l].
-__device__ __forceinline__ void outage_stash(const DevPlan& P, const Lds& L, int lane, int out_br) {
-  if (lane < 2) {
-    const double* y = P.br_y + out_br * 8;            // ff, ft, tf, tt (g,b each)
-    double* st = L.acc + 4 + 4 * lane;
-    st[0] = y[lane == 0 ? 0 : 6]; st[1] = y[lane == 0 ? 1 : 7];
-    st[2] = y[lane == 0 ? 2 : 4]; st[3] = y[lane == 0 ? 3 : 5];
-    const int i = lane == 0 ? P.br_f[out_br] : P.br_t[out_br];
-    reinterpret_cast<int2*>(L.acc + 12)[lane] = make_int2(P.y_blk[P.br_pos[out_br * 4 + 1 + lane]], P.diag_blk[i]);
-  }
+// ---- per-instance branch modifiers ------------------------------------------------------
+// An instance may differ from the shared Ybus in a few branches: one out of service (outage
+// axis, N-1 contingency, an open switch), a transformer on another tap.  Each such branch is a
+// MODIFIER: the change dY of its four stamps (ff, ft, tf, tt; 0 - Y for a removed branch) plus
+// the ids the correction needs.  Phase A runs on the shared Ybus; afterwards two lanes per
+// modifier (one per end bus) add V conj(dY V) to the mismatch, the (f,t)/(t,f) Jacobian blocks
+// and the two diagonal blocks with LDS atomics (several modifiers may meet on one bus), and
+// the mismatch norm is recomputed.  (Comparing every Ybus entry against the modifiers would
+// cost ~25 instructions per entry in every solve of every instance.)
+constexpr int MOD_DOUBLES = 12;     // dY[8] | ints: f, t, blk_ft, blk_tf, dblk_f, dblk_t, branch, removed
+__device__ __forceinline__ double* mod_dy(const Lds& L, int m) { return L.mod + m * MOD_DOUBLES; }
+__device__ __forceinline__ int* mod_ids(const Lds& L, int m) { return reinterpret_cast<int*>(L.mod + m * MOD_DOUBLES + 8); }
+
+// Writes modifier m for branch br.  Lanes 0..7 hold dY[lane] in `dy_lane` (ignored when
+// `removed`: dY = -Y); lanes 8..12 fetch the ids.  Ends with a wave fence.
+__device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane, int m, int br, double dy_lane, bool removed) {
+  if (lane < 8) mod_dy(L, m)[lane] = removed ? -P.br_y[br * 8 + lane] : dy_lane;
+  int* id = mod_ids(L, m);
+  if (lane == 8) { const int f = P.br_f[br]; id[0] = f; id[4] = P.diag_blk[f]; }
+  if (lane == 9) { const int t = P.br_t[br]; id[1] = t; id[5] = P.diag_blk[t]; }
+  if (lane == 10) id[2] = P.y_blk[P.br_pos[br * 4 + 1]];
+  if (lane == 11) id[3] = P.y_blk[P.br_pos[br * 4 + 2]];
+  if (lane == 12) { id[6] = br; id[7] = removed ? 1 : 0; }
   wave_fence();
 }
-__device__ __forceinline__ double outage_fixup(const Lds& L, int lane, int of, int ot, double my) {
-  const int i = lane == 0 ? of : ot, j = lane == 0 ? ot : of;
-  const double* st = L.acc + 4 + 4 * lane;
-  const double yii_g = st[0], yii_b = st[1], yij_g = st[2], yij_b = st[3];
-  const int2 ids = reinterpret_cast<const int2*>(L.acc + 12)[lane];
+
+// lanes 0 .. 2*n_mod-1: end e = lane & 1 of modifier lane >> 1
+__device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
+  if (lane >= 2 * n_mod) return;
+  const int m = lane >> 1, e = lane & 1;
+  const double* dy = mod_dy(L, m);
+  const int* id = mod_ids(L, m);
+  const int i = id[e], j = id[1 - e], ob = id[2 + e], db = id[4 + e];
+  const double yii_g = dy[e ? 6 : 0], yii_b = dy[e ? 7 : 1], yij_g = dy[e ? 4 : 2], yij_b = dy[e ? 5 : 3];
   const double vri = L.vr[i], vii = L.vi[i], vrj = L.vr[j], vij = L.vi[j];
   const double tr = yij_g * vrj - yij_b * vij, ti = yij_g * vij + yij_b * vrj;
-  const double dcr = vri * tr + vii * ti, dci = vii * tr - vri * ti;      // V_i conj(Y_ij V_j) of the branch
+  const double dcr = vri * tr + vii * ti, dci = vii * tr - vri * ti;      // V_i conj(dY_ij V_j)
   const double v2 = vri * vri + vii * vii;
-  const double dyr = yii_g * v2, dyi = -yii_b * v2;                         // conj(Y_ii)|V_i|^2 of the branch
+  const double dyr = yii_g * v2, dyi = -yii_b * v2;                         // conj(dY_ii)|V_i|^2
   const int t = L.bt[i];
   if (t == BT_REF) {                       // parked injection S_i
-    L.rhs[i] -= dcr + dyr;
-    L.rq[i] -= dci + dyi;
-    return my;
+    lds_add(&L.rhs[i], dcr + dyr);
+    lds_add(&L.rq[i], dci + dyi);
+    return;
   }
   const bool pv = t == BT_PV;
-  const double r0 = L.rhs[i] + (dcr + dyr);
-  L.rhs[i] = r0;
-  double r1 = 0.0;
-  if (!pv) { r1 = L.rq[i] + (dci + dyi); L.rq[i] = r1; }
-  if (ids.x >= 0) {
-    Blk o = ld_blk2(L, ids.x);
-    o.a11 -= dci; o.a12 -= dcr;
-    if (!pv) { o.a21 += dcr; o.a22 -= dci; }
-    st_blk2(L, ids.x, o);
+  lds_add(&L.rhs[i], -(dcr + dyr));        // rhs = -F
+  if (!pv) lds_add(&L.rq[i], -(dci + dyi));
+  if (ob >= 0) {                           // dS_i/dth_j = -j c, dS_i/dln|V_j| = c
+    double* p = L.blk + ob;
+    lds_add(p, dci); lds_add(p + L.bs, dcr);
+    if (!pv) { lds_add(p + 2 * L.bs, -dcr); lds_add(p + 3 * L.bs, dci); }
   }
-  Blk d = ld_blk2(L, ids.y);
-  d.a11 += dci; d.a12 -= 2.0 * dyr + dcr;
-  if (!pv) { d.a21 -= dcr; d.a22 -= 2.0 * dyi + dci; }
-  st_blk2(L, ids.y, d);
-  return nn_max(my, nn_max(fabs(r0), fabs(r1)));
+  double* p = L.blk + db;                  // {-S_off.im, Y|V|^2.re + P, S_off.re, Y|V|^2.im + Q}
+  lds_add(p, -dci); lds_add(p + L.bs, 2.0 * dyr + dcr);
+  if (!pv) { lds_add(p + 2 * L.bs, dcr); lds_add(p + 3 * L.bs, 2.0 * dyi + dci); }
 }
 
-__device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
+// current injected at bus i by the modifiers: I_i += dY_ii V_i + dY_ij V_j
+__device__ __forceinline__ void mods_row_current(const Lds& L, int n_mod, int i, double& ir, double& ii) {
+  for (int m = 0; m < n_mod; ++m) {
+    const int* id = mod_ids(L, m);
+    const double* dy = mod_dy(L, m);
+    const int f = id[0], t = id[1];
+    if (i == f) {
+      ir += dy[0] * L.vr[f] - dy[1] * L.vi[f] + dy[2] * L.vr[t] - dy[3] * L.vi[t];
+      ii += dy[0] * L.vi[f] + dy[1] * L.vr[f] + dy[2] * L.vi[t] + dy[3] * L.vr[t];
+    }
+    if (i == t) {
+      ir += dy[4] * L.vr[f] - dy[5] * L.vi[f] + dy[6] * L.vr[t] - dy[7] * L.vi[t];
+      ii += dy[4] * L.vi[f] + dy[5] * L.vr[f] + dy[6] * L.vi[t] + dy[7] * L.vr[t];
+    }
+  }
+}
+
+__device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
                         int* iters_out, double* nrm_out) {
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
-  int of = -1, ot = -1;
-  if (out_br >= 0) { of = P.br_f[out_br]; ot = P.br_t[out_br]; outage_stash(P, L, lane, out_br); }
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
   // that the compiler's wait-count insertion sees a fixed number of loads in flight and
   // waits for the oldest only (a conditional load anywhere in these loops degrades every
@@ -667,7 +691,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
-          if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: see outage_fixup)
+          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
           // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
@@ -682,7 +706,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         }
       }
     }
-    if (of >= 0) { wave_fence(); if (lane < 2) my = outage_fixup(L, lane, of, ot, my); wave_fence(); }
+    if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
+      wave_fence();
+      mods_apply(L, lane, n_mod);
+      wave_fence();
+      my = 0.0;
+      for (int i = lane; i < nb; i += WAVE)
+        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
+    }
     OPFX_STAMP(12);
     nrm = wave_max_dpp(my);
     OPFX_STAMP(1);
@@ -764,14 +795,12 @@ __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
 }
 
 template <int NW>
-__device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int out_br,
+__device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
                              int* iters_out, double* nrm_out) {
   constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = P.nb;
-  int of = -1, ot = -1;
-  if (out_br >= 0) { of = P.br_f[out_br]; ot = P.br_t[out_br]; if (wave == 0) outage_stash(P, L, lane, out_br); }
   const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
   const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4;        // multiple of 4, >= 4
   auto ld_desc = [&](int k) { return stream[(size_t)(k < K ? k : k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
@@ -845,7 +874,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
-          if (i != of && i != ot) my = nn_max(my, nn_max(fabs(fp), fabs(fq)));   // (outage ends: outage_fixup)
+          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
           st_blk2(L, a.dw & 0xFFFF, jb);
@@ -855,7 +884,14 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         }
       }
     }
-    if (of >= 0) { __syncthreads(); if (tid < 2) my = outage_fixup(L, tid, of, ot, my); }
+    if (n_mod > 0) {
+      __syncthreads();
+      if (wave == 0) mods_apply(L, lane, n_mod);
+      __syncthreads();
+      my = 0.0;
+      for (int i = tid; i < nb; i += NT)
+        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
+    }
     my = wave_max_dpp(my);
     if (lane == 0) xw[wave] = my;
     __syncthreads();
@@ -918,7 +954,7 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
 
 // Outer loop: NR + enforce_q_lims PV->PQ switching.
 template <bool V2, int NW>
-__device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br,
+__device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm) {
   const int wave = threadIdx.x >> 6;
   // An outage that cuts buses off every REF bus makes the Newton matrix singular: reported as
@@ -929,8 +965,8 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
-    if (NW > 1) conv = newton2_coop<NW>(P, L, o, out_br, &it, nrm);
-    else conv = V2 ? newton2(P, L, o, lane, out_br, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
+    if (NW > 1) conv = newton2_coop<NW>(P, L, o, n_mod, &it, nrm);
+    else conv = V2 ? newton2(P, L, o, lane, n_mod, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
@@ -943,7 +979,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
         for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
           const int j = P.y_col[e];
           double g = P.y_g[e], b = P.y_b[e];
-          if (out_br >= 0) {
+          if (!V2 && out_br >= 0) {          // first-generation kernel: single outage by stamp position
             if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
             if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
             if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
@@ -952,6 +988,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
           ir += g * L.vr[j] - b * L.vi[j];
           ii += g * L.vi[j] + b * L.vr[j];
         }
+        if (V2) mods_row_current(L, n_mod, i, ir, ii);
         const double qc = L.vi[i] * ir - L.vr[i] * ii;
         const double qg = qc - L.qsp[i];
         const double lo = qg_min[i], hi = qg_max[i];
@@ -977,7 +1014,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
 // after convergence: result bank in LDS region R (reuses the LU block storage)
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 template <bool V2>
-__device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br,
+__device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle) {
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
@@ -1005,7 +1042,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
       for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
         const int j = P.y_col[e];
         double g = P.y_g[e], b = P.y_b[e];
-        if (out_br >= 0) {
+        if (!V2 && out_br >= 0) {
           if (e == P.br_pos[out_br * 4 + 0]) { g -= P.br_y[out_br * 8 + 0]; b -= P.br_y[out_br * 8 + 1]; }
           if (e == P.br_pos[out_br * 4 + 1]) { g -= P.br_y[out_br * 8 + 2]; b -= P.br_y[out_br * 8 + 3]; }
           if (e == P.br_pos[out_br * 4 + 2]) { g -= P.br_y[out_br * 8 + 4]; b -= P.br_y[out_br * 8 + 5]; }
@@ -1014,6 +1051,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
         ir += g * L.vr[j] - b * L.vi[j];
         ii += g * L.vi[j] + b * L.vr[j];
       }
+      if (V2) mods_row_current(L, n_mod, i, ir, ii);
       const double pc = L.vr[i] * ir + L.vi[i] * ii, qc = L.vi[i] * ir - L.vr[i] * ii;
       if (t == BT_REF) {
         const int ro = P.ref_ord[i];
@@ -1031,9 +1069,20 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   }
   for (int k = lane; k < nbr; k += WAVE) {
     double ld = 0.0;
-    if (k != out_br) {
+    double y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = P.br_y[8 * k + q];
+    bool removed = !V2 && k == out_br;
+    if (V2) for (int m = 0; m < n_mod; ++m) {
+      const int* id = mod_ids(L, m);
+      if (id[6] != k) continue;
+      const double* dy = mod_dy(L, m);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] += dy[q];
+      removed = removed || id[7] != 0;
+    }
+    if (!removed) {
       const int f = P.br_f[k], t = P.br_t[k];
-      const double* y = P.br_y + 8 * k;
       const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
       const double ifr = y[0] * vfr - y[1] * vfi + y[2] * vtr - y[3] * vti;
       const double ifi = y[0] * vfi + y[1] * vfr + y[2] * vti + y[3] * vtr;
@@ -1046,7 +1095,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
 }
 
 template <bool V2>
-__device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc = 0) {
+__device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc, int nmod) {
   Lds L;
   const int nb = P.nb;
   const int nbe = (nb + 1) & ~1;               // even count keeps every array 16-byte aligned
@@ -1061,7 +1110,8 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   const int nblk_d = 4 * L.bs > nres ? 4 * L.bs : nres;
   L.sp = L.blk + ((nblk_d + 1) & ~1);
   L.acc = L.sp + na;
-  L.bt = reinterpret_cast<unsigned char*>(L.acc + nacc);
+  L.mod = L.acc + nacc;
+  L.bt = reinterpret_cast<unsigned char*>(L.mod + MOD_DOUBLES * nmod);
   return L;
 }
 
@@ -1073,7 +1123,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
-  const Lds L = carve<V2>(P, 0, nres_, smem, 16);
+  const Lds L = carve<V2>(P, 0, nres_, smem, 8, 1);
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
@@ -1083,14 +1133,16 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
       }
       init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims != 0);
     }
-    blk_sync<NW>();
     const int out_br = io.outage ? io.outage[b] : -1;
+    const int n_mod = (V2 && out_br >= 0) ? 1 : 0;
+    if (n_mod && wave == 0) mod_set(P, L, lane, 0, out_br, 0.0, true);
+    blk_sync<NW>();
     int iters; double nrm;
-    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, io.qg_min, io.qg_max, &iters, &nrm);
+    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm);
     blk_sync<NW>();
     if (wave == 0) {
       double* R = L.blk;
-      compute_results<V2>(P, L, lane, out_br, io.qg_min, io.qg_max, R, false, io.va != nullptr);
+      compute_results<V2>(P, L, lane, out_br, n_mod, io.qg_min, io.qg_max, R, false, io.va != nullptr);
       sec_sync<NW>();
       const int nb = P.nb, nbr = P.nbr, nref = P.nref;
       if (io.vm) for (int i = lane; i < nb; i += WAVE) io.vm[b * nb + i] = R[i];
@@ -1184,7 +1236,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 16 ? 5 * E.nc : 16);
+  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8, E.max_mod);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
@@ -1315,9 +1367,14 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     int iters0 = 0;
     double nrm0 = 0.0;
     const int base_out = io.outage ? io.outage[b] : -1;
+    // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
+    int n_mod_base = 0;
+    if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true); ++n_mod_base; }
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
+      int n_mod = n_mod_base;
+      if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true); ++n_mod; }
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
         if (c > 0) {
@@ -1330,7 +1387,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, E.qg_min, E.qg_max, &iters, &nrm);
+      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm);
       blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) {
@@ -1351,7 +1408,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       }
       double* R = L.blk;
       if (wave == 0) {
-      compute_results<V2>(P, L, lane, out_br, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
+      compute_results<V2>(P, L, lane, out_br, n_mod, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
       sec_sync<NW>();
       OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
@@ -1619,10 +1676,10 @@ struct opfx_env {
 
 namespace {
 
-size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc = 0) {
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>((size_t)4 * (((size_t)p.n_blk + 1) & ~(size_t)1), (size_t)nres) + 1) & ~(size_t)1;
-  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc;
+  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
 }
@@ -1745,7 +1802,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
-  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 16);
+  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1);
   int grid = 0;
   const int team = pick_team(lds, ctx->v2);
   auto kern = !ctx->v2 ? k_solve<false, 1> : (team == 4 ? k_solve<true, 4> : (team == 2 ? k_solve<true, 2> : k_solve<true, 1>));
@@ -1782,6 +1839,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   E.invalid_objective_share = d->invalid_objective_share;
   E.diff_step = d->diff_action_step_size; E.clipped_action_penalty = d->clipped_action_penalty;
   E.n_cont = d->n_cont; E.not_converged_penalty = d->not_converged_penalty;
+  E.max_mod = 2;
   // slot -> action map: a column written by an action is read from the set-point, not from x
   std::vector<int32_t> slot_act(d->nx, -1);
   for (int k = 0; k < d->na; ++k) {
@@ -1915,7 +1973,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 16 ? 5 * d->nc : 16);
+  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod);
   *out = e;
   return OPFX_OK;
 }
