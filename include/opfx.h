@@ -179,6 +179,9 @@ enum { OPFX_COST_UNIT = 0, OPFX_COST_EXT_GRID = 1, OPFX_COST_GEN = 2 };
 enum { OPFX_REWARD_SUMMATION = 0, OPFX_REWARD_REPLACEMENT = 1,
        OPFX_REWARD_PARAMETERIZED = 2, OPFX_REWARD_ONLY_OBJECTIVE = 3 };
 
+/* kinds of actuator columns (opfx_env_desc.act_kind) */
+enum { OPFX_ACT_CONTINUOUS = 0, OPFX_ACT_INTEGER = 1 /* np.round */, OPFX_ACT_BOOLEAN = 2 /* np.round(..).astype(bool) */ };
+
 typedef struct opfx_env_desc {
   int32_t nx;                /* columns of the per-instance store           */
   /* bus injections: P_i = sum coef*x[slot] over p-list of bus i (p.u.) */
@@ -244,6 +247,22 @@ typedef struct opfx_env_desc {
   int32_t n_cont;
   const int32_t* cont_branch;     /* [n_cont] case branch index              */
   double not_converged_penalty;   /* security_constrained.py:27,63-64        */
+  /* discrete actuators (opf_env.py:476-481): OPFX_ACT_* per action, NULL = all continuous */
+  const int32_t* act_kind;        /* [na] */
+  /* Branch state columns — actuators that change Ybus values per instance
+   * (examples/network_reconfiguration.py:34-35, mixed_continuous_discrete.py:40-41:
+   * ('switch','closed'), ('trafo','tap_pos'), ('line'|'trafo','in_service')).  Row m names a
+   * case branch whose four stamps follow an integer state column of the store:
+   * stamps = bmod_y[bmod_ptr[m] + clip(round(x[bmod_slot[m]]) - bmod_lo[m], 0, bmod_n[m]-1)];
+   * an all-zero table row takes the branch out of service.  The plan is compiled with every
+   * such branch present; at most one state column per branch. */
+  int32_t n_bmod;
+  const int32_t* bmod_branch;     /* [n_bmod] case branch index              */
+  const int32_t* bmod_slot;       /* [n_bmod] column of the store            */
+  const int32_t* bmod_lo;         /* [n_bmod] state value of table row 0     */
+  const int32_t* bmod_n;          /* [n_bmod] table rows                     */
+  const int32_t* bmod_ptr;        /* [n_bmod] first row in bmod_y            */
+  const double* bmod_y;           /* [rows][8] ff, ft, tf, tt as (g, b), p.u. */
 } opfx_env_desc;
 
 int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);

@@ -214,6 +214,30 @@ def get_obs_and_state_space(net, obs_or_state_keys, add_time_obs=False, add_mean
                seed=seed)
 
 
+_DISCRETE_KIND = {'closed': capi.ACT_BOOLEAN, 'in_service': capi.ACT_BOOLEAN,
+                  'tap_pos': capi.ACT_INTEGER, 'step': capi.ACT_INTEGER}          # opf_env.py:476-481
+
+
+def _case_all_branches_in(net, act_keys):
+    """The plan is compiled with every branch an actuator can switch present (closed / in
+    service); their per-instance state then only changes Ybus VALUES (opfx_env_desc.bmod_*)."""
+    saved = []
+    for unit, col, idxs in act_keys:
+        if col in ('closed', 'in_service') and unit in ('switch', 'line', 'trafo') and len(idxs):
+            saved.append((unit, col, list(idxs), net[unit].loc[list(idxs), col].copy()))
+            net[unit].loc[list(idxs), col] = True
+    try:
+        return net_to_case(net)
+    finally:
+        for unit, col, idxs, old in saved:
+            net[unit].loc[idxs, col] = old
+
+
+def _branch_stamps(case, k):
+    y = (case.yff[k], case.yft[k], case.ytf[k], case.ytt[k])
+    return [v for z in y for v in (float(np.real(z)), float(np.imag(z)))]
+
+
 def _keep(lst, arr, kind):
     a = np.ascontiguousarray(arr, dtype=np.float64 if kind == 'd' else np.int32)
     lst.append(a)
@@ -295,7 +319,7 @@ class BatchedOpfEnv:
         self.np_random = np.random.default_rng(seed)
 
         # ---- compile the grid --------------------------------------------------
-        self.case = net_to_case(net)
+        self.case = _case_all_branches_in(net, self.act_keys)
         self.plan = capi.Plan(self.case)
         self.store = ColumnStore(net)
         for tbl in ('load', 'sgen', 'storage'):
@@ -414,6 +438,53 @@ class BatchedOpfEnv:
         self._sampling_ops(self.ops)
 
     # ------------------------------------------------------------------ compile
+    def _branch_state_column(self, unit, col, idxs, rows, bmod):
+        """Actuator columns that change Ybus values per instance: transformer tap
+        positions (one stamp table row per integer position, computed by the case builder itself)
+        and line/trafo switches or in_service flags (stamps or nothing)."""
+        net, c, st = self.net, self.case, self.store
+        br_of = {(int(kd), int(e)): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem))}
+
+        def branch(kind, pos, what):
+            if (kind, int(pos)) not in br_of:
+                raise ValueError(f'{what}: the element is not part of the energised grid')
+            return br_of[(kind, int(pos))]
+        slot0 = st.slot(unit, col, dynamic=True)
+        if col == 'tap_pos' and unit == 'trafo':
+            df = net['trafo']
+            lo_col = 'min_min_tap_pos' if 'min_min_tap_pos' in df.columns else 'min_tap_pos'
+            hi_col = 'max_max_tap_pos' if 'max_max_tap_pos' in df.columns else 'max_tap_pos'
+            lo = int(np.floor(df[lo_col].loc[list(idxs)].min()))
+            hi = int(np.ceil(df[hi_col].loc[list(idxs)].max()))
+            saved = df['tap_pos'].copy()
+            tables = {int(r): [] for r in rows}
+            try:
+                for pos in range(lo, hi + 1):
+                    df.loc[list(idxs), 'tap_pos'] = pos
+                    cp = _case_all_branches_in(net, self.act_keys)
+                    assert cp.nbr == c.nbr
+                    for r in rows:
+                        tables[int(r)].append(_branch_stamps(cp, branch(KIND_TRAFO, r, 'trafo.tap_pos')))
+            finally:
+                net['trafo']['tap_pos'] = saved
+            for r in rows:
+                bmod.append(dict(branch=branch(KIND_TRAFO, r, 'trafo.tap_pos'), slot=slot0 + int(r), lo=lo,
+                                 table=tables[int(r)]))
+        elif col in ('closed', 'in_service') and unit in ('switch', 'line', 'trafo'):
+            for r in rows:
+                if unit == 'switch':
+                    et, elem = net['switch']['et'].iloc[int(r)], int(net['switch']['element'].iloc[int(r)])
+                    if et not in ('l', 't'):
+                        raise NotImplementedError('bus-bus switches as actuators change the bus set of the '
+                                                  'compiled plan: not supported')
+                    tbl = 'line' if et == 'l' else 'trafo'
+                    k = branch(KIND_LINE if et == 'l' else KIND_TRAFO, st.rows(tbl, [elem])[0], 'switch.closed')
+                else:
+                    k = branch(KIND_LINE if unit == 'line' else KIND_TRAFO, r, f'{unit}.in_service')
+                bmod.append(dict(branch=k, slot=slot0 + int(r), lo=0, table=[[0.0] * 8, _branch_stamps(c, k)]))
+        else:
+            raise NotImplementedError(f'actuator {unit}.{col} is not supported')
+
     def _range_source(self, unit, name, rows):
         """(slots, consts) for a range/clamp column: per-instance slot if the
         sampling programme writes it, the net's static value otherwise."""
@@ -470,15 +541,17 @@ class BatchedOpfEnv:
                 self.obs_segments.append(len(sl))
         # ---- actions (opf_env.py:421-491) ------------------------------------------
         a_slot, a_sc, lo_s, hi_s, lo_c, hi_c = [], [], [], [], [], []
+        a_kind, bmod = [], []
         cl_s, ch_s, cl_c, ch_c = [], [], [], []
         clamp = (not self.autoscale_actions) or bool(self.diff_action_step_size)
         for unit, col, idxs in self.act_keys:
             if len(idxs) == 0:
                 continue
-            if col in ('closed', 'in_service', 'tap_pos', 'step'):
-                raise NotImplementedError('topology/tap actions change Ybus per instance: not supported yet')
             df = net[unit]
             rows = st.rows(unit, idxs)
+            a_kind += [_DISCRETE_KIND.get(col, capi.ACT_CONTINUOUS)] * len(rows)
+            if col in _DISCRETE_KIND:
+                self._branch_state_column(unit, col, idxs, rows, bmod)
             a_slot += (st.slot(unit, col) + rows).tolist()
             a_sc += (df['scaling'].to_numpy(float)[rows] if 'scaling' in df.columns
                      else np.ones(len(rows))).tolist()
@@ -633,6 +706,17 @@ class BatchedOpfEnv:
         d.n_cont = len(cont)
         d.cont_branch = _keep(keep, cont, 'i')
         d.not_converged_penalty = float(self.not_converged_penalty)
+        d.act_kind = _keep(keep, a_kind, 'i')
+        d.n_bmod = len(bmod)
+        if bmod:
+            ptr = np.cumsum([0] + [len(b['table']) for b in bmod])
+            d.bmod_branch = _keep(keep, [b['branch'] for b in bmod], 'i')
+            d.bmod_slot = _keep(keep, [b['slot'] for b in bmod], 'i')
+            d.bmod_lo = _keep(keep, [b['lo'] for b in bmod], 'i')
+            d.bmod_n = _keep(keep, [len(b['table']) for b in bmod], 'i')
+            d.bmod_ptr = _keep(keep, ptr[:-1], 'i')
+            d.bmod_y = _keep(keep, np.concatenate([np.asarray(b['table'], float).ravel() for b in bmod]), 'd')
+        self.branch_state_columns = bmod
         if self._env_handle is not None:
             capi.lib().opfx_env_destroy(self._env_handle)
             self._env_handle = None

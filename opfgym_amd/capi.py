@@ -85,7 +85,13 @@ class EnvDesc(C.Structure):
         ('invalid_objective_share', C.c_double), ('diff_objective', C.c_int32),
         ('nobs', C.c_int32), ('obs_kind', _pi), ('obs_idx', _pi),
         ('steps_per_episode', C.c_int32),
-        ('n_cont', C.c_int32), ('cont_branch', _pi), ('not_converged_penalty', C.c_double)]
+        ('n_cont', C.c_int32), ('cont_branch', _pi), ('not_converged_penalty', C.c_double),
+        ('act_kind', _pi),
+        ('n_bmod', C.c_int32), ('bmod_branch', _pi), ('bmod_slot', _pi), ('bmod_lo', _pi),
+        ('bmod_n', _pi), ('bmod_ptr', _pi), ('bmod_y', _pd)]
+
+
+ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2
 
 
 class StepIO(C.Structure):

@@ -76,6 +76,9 @@ struct DevEnv {
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
   int n_cont, n_inj, n_oseg, need_angle, ncel;
   int max_mod;               // modifier records reserved per instance (env modifiers + outage + contingency)
+  int n_bmod;                // branch state columns (taps, switches): see opfx_env_desc.bmod_*
+  const int *act_kind, *bmod_branch, *bmod_src, *bmod_lo, *bmod_n, *bmod_ptr;
+  const double* bmod_y;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
   double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
   double invalid_objective_share, diff_step, clipped_action_penalty;
@@ -531,8 +534,17 @@ __device__ __forceinline__ int* mod_ids(const Lds& L, int m) { return reinterpre
 
 // Writes modifier m for branch br.  Lanes 0..7 hold dY[lane] in `dy_lane` (ignored when
 // `removed`: dY = -Y); lanes 8..12 fetch the ids.  Ends with a wave fence.
-__device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane, int m, int br, double dy_lane, bool removed) {
-  if (lane < 8) mod_dy(L, m)[lane] = removed ? -P.br_y[br * 8 + lane] : dy_lane;
+// A removal also cancels what the first n_prev modifiers changed on the same branch (a
+// contingency on a transformer whose tap position differs from the compiled one).
+__device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane, int m, int br, double dy_lane, bool removed, int n_prev) {
+  if (lane < 8) {
+    double v = dy_lane;
+    if (removed) {
+      v = -P.br_y[br * 8 + lane];
+      for (int j = 0; j < n_prev; ++j) if (mod_ids(L, j)[6] == br) v -= mod_dy(L, j)[lane];
+    }
+    mod_dy(L, m)[lane] = v;
+  }
   int* id = mod_ids(L, m);
   if (lane == 8) { const int f = P.br_f[br]; id[0] = f; id[4] = P.diag_blk[f]; }
   if (lane == 9) { const int t = P.br_t[br]; id[1] = t; id[5] = P.diag_blk[t]; }
@@ -1135,7 +1147,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
     }
     const int out_br = io.outage ? io.outage[b] : -1;
     const int n_mod = (V2 && out_br >= 0) ? 1 : 0;
-    if (n_mod && wave == 0) mod_set(P, L, lane, 0, out_br, 0.0, true);
+    if (n_mod && wave == 0) mod_set(P, L, lane, 0, out_br, 0.0, true, 0);
     blk_sync<NW>();
     int iters; double nrm;
     const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm);
@@ -1265,7 +1277,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       // (no action row in modes 1/3: any readable row keeps the loads unconditional)
       const double* act_row = apply ? io.action + b * E.na : xr;
       for (int k0 = 0; k0 < E.na; k0 += 2 * WAVE) {
-        int slot[2], los[2], his[2], cls_[2], chs[2];
+        int slot[2], los[2], his[2], cls_[2], chs[2], kind[2];
         double av[2], sc[2], loc[2], hic[2], clc[2], chc[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1273,6 +1285,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           slot[u] = as_global(E.act_slot)[kk]; los[u] = as_global(E.act_lo_slot)[kk]; his[u] = as_global(E.act_hi_slot)[kk];
           sc[u] = as_global(E.act_scaling)[kk]; loc[u] = as_global(E.act_lo_const)[kk]; hic[u] = as_global(E.act_hi_const)[kk];
           av[u] = act_row[kk];
+          kind[u] = as_global(E.act_kind)[kk];
           cls_[u] = as_global(E.clamp_lo_slot)[kk]; chs[u] = as_global(E.clamp_hi_slot)[kk];
           clc[u] = as_global(E.clamp_lo_const)[kk]; chc[u] = as_global(E.clamp_hi_const)[kk];
         }
@@ -1295,6 +1308,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
               if (cls_[u] > -2) { const double m = cls_[u] >= 0 ? xs[cls_[u]] : clc[u]; if (spt < m) spt = m; }
             }
             xv = spt / sc[u];                                                            // :472-474
+            if (kind[u] != OPFX_ACT_CONTINUOUS) {                                        // :476-481 (np.round: half to even)
+              xv = rint(xv);
+              if (kind[u] == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0;
+            }
             xr[slot[u]] = xv;                                                            // :483
             const double cur = (xv * sc[u] - lo) / delta;                                // :586
             corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
@@ -1369,12 +1386,23 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     const int base_out = io.outage ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
-    if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true); ++n_mod_base; }
+    if (V2) for (int m = 0; m < E.n_bmod; ++m) {
+      // stamps of this branch for the instance's state (tap position, switch / in_service flag)
+      const int br = as_global(E.bmod_branch)[m];
+      const int st = (int)rint(src_val(xs, L.sp, as_global(E.bmod_src)[m])) - as_global(E.bmod_lo)[m];
+      const int row = as_global(E.bmod_ptr)[m] + min(max(st, 0), as_global(E.bmod_n)[m] - 1);
+      double y = 0.0, dy = 0.0;
+      if (lane < 8) { y = as_global(E.bmod_y)[row * 8 + lane]; dy = y - P.br_y[br * 8 + lane]; }
+      if (br == base_out || !__any(dy != 0.0)) continue;      // outaged anyway / state = compiled state
+      if (wave == 0) mod_set(P, L, lane, n_mod_base, br, dy, !__any(y != 0.0), 0);
+      ++n_mod_base;
+    }
+    if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true, 0); ++n_mod_base; }
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
       int n_mod = n_mod_base;
-      if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true); ++n_mod; }
+      if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true, n_mod_base); ++n_mod; }
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
         if (c > 0) {
@@ -1839,7 +1867,10 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   E.invalid_objective_share = d->invalid_objective_share;
   E.diff_step = d->diff_action_step_size; E.clipped_action_penalty = d->clipped_action_penalty;
   E.n_cont = d->n_cont; E.not_converged_penalty = d->not_converged_penalty;
-  E.max_mod = 2;
+  E.n_bmod = d->n_bmod;
+  E.max_mod = d->n_bmod + 2;
+  if (d->n_bmod > 0 && !ctx->v2) { delete e; opfx_set_error("opfx_env_create: branch state columns need the lane-programme kernels"); return OPFX_ERR_INVALID; }
+  if (d->n_bmod > 24) { delete e; opfx_set_error("opfx_env_create: at most 24 branch state columns"); return OPFX_ERR_INVALID; }
   // slot -> action map: a column written by an action is read from the set-point, not from x
   std::vector<int32_t> slot_act(d->nx, -1);
   for (int k = 0; k < d->na; ++k) {
@@ -1963,6 +1994,27 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     for (size_t i = 0; i < ncel; ++i) if (d->con_src[i] >= nb && d->con_src[i] < 2 * nb) E.need_angle = 1;
   }
   PUTN(cont_branch, d->cont_branch, d->n_cont);
+  {
+    std::vector<int32_t> kind(d->na, OPFX_ACT_CONTINUOUS);
+    if (d->act_kind) kind.assign(d->act_kind, d->act_kind + d->na);
+    if (rc == OPFX_OK) rc = A.put(kind, &E.act_kind);
+  }
+  if (d->n_bmod > 0) {
+    size_t rows = 0;
+    std::vector<int32_t> src(d->n_bmod);
+    for (int m = 0; m < d->n_bmod; ++m) {
+      if (d->bmod_branch[m] < 0 || d->bmod_branch[m] >= p.nbr || d->bmod_slot[m] < 0 || d->bmod_slot[m] >= d->nx || d->bmod_n[m] < 1) {
+        rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: bad branch state column"); break;
+      }
+      for (int j = 0; j < m; ++j) if (d->bmod_branch[j] == d->bmod_branch[m]) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: two state columns for one branch"); }
+      rows = std::max(rows, (size_t)d->bmod_ptr[m] + d->bmod_n[m]);
+      src[m] = src_of(d->bmod_slot[m]);
+    }
+    PUTN(bmod_branch, d->bmod_branch, d->n_bmod); PUTN(bmod_lo, d->bmod_lo, d->n_bmod);
+    PUTN(bmod_n, d->bmod_n, d->n_bmod); PUTN(bmod_ptr, d->bmod_ptr, d->n_bmod);
+    PUTN(bmod_y, d->bmod_y, rows * 8);
+    if (rc == OPFX_OK) rc = A.put(src, &E.bmod_src);
+  }
 #undef PUTN
   for (size_t i = 0; rc == OPFX_OK && i < ncel; ++i)
     if (d->con_src[i] < 0 || d->con_src[i] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: con_src out of range"); }

@@ -329,6 +329,44 @@ class MultiStageOpf(MultiStageOpfEnv):
         return net, profiles
 
 
+class NetworkReconfiguration(BatchedOpfEnv):
+    """examples/network_reconfiguration.py:16-72: selected line switches and all transformer tap
+    changers as (discrete) actuators, loss cost at the slack.  The switch states and tap positions
+    change Ybus VALUES per instance (opfx_env_desc.bmod_*); the plan is compiled once with every
+    controllable switch closed."""
+
+    def __init__(self, simbench_network_name='1-HV-urban--0-sw', controllable_switch_idxs=(1, 3),
+                 *args, **kwargs):
+        self.controllable_switch_idxs = np.array(controllable_switch_idxs)                      # :20
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        obs_keys = [('sgen', 'p_mw', net.sgen.index), ('load', 'p_mw', net.load.index),         # :27-31
+                    ('load', 'q_mvar', net.load.index)]
+        act_keys = [('switch', 'closed', net.switch.index[net.switch.controllable.to_numpy(bool)]),   # :34-35
+                    ('trafo', 'tap_pos', net.trafo.index[net.trafo.controllable.to_numpy(bool)])]
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.switch['controllable'] = False                                                      # :45-46
+        net.switch.loc[self.controllable_switch_idxs, 'controllable'] = True
+        net.switch['min_closed'] = 0                                                            # :49-53
+        net.switch['max_closed'] = 1
+        net.switch['min_min_closed'] = 0
+        net.switch['max_max_closed'] = 1
+        net.trafo['controllable'] = True                                                        # :56-60
+        net.trafo['min_tap_pos'] = -1
+        net.trafo['max_tap_pos'] = 1
+        net.trafo['min_min_tap_pos'] = -1
+        net.trafo['max_max_tap_pos'] = 1
+        for unit_type in ('load', 'sgen', 'gen', 'storage'):                                    # :63-64
+            net[unit_type]['controllable'] = False
+        for idx in net.ext_grid.index:                                                          # :67-68
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=1)
+        ppn.finalize(net)
+        return net, profiles
+
+
 class SecurityConstrainedVoltageControl(VoltageControl):
     """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
     of security_constrained.py (no such class in the reference; composed as

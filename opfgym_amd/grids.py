@@ -412,6 +412,17 @@ def synthetic_hv_small(seed: int = 0):
                         load_share=0.5, sgen_share=0.4)
 
 
+def synthetic_hv_small_sw(seed: int = 0):
+    """hv-small with a (closed) line switch at the from-bus of every line, switch index = line
+    index — the shape of the SimBench '-sw' variants as far as the switch actuators of
+    examples/network_reconfiguration.py need it."""
+    from . import net as ppn
+    net, prof = synthetic_hv_small(seed)
+    for idx in net.line.index:
+        ppn.create_switch(net, int(net.line.at[idx, 'from_bus']), int(idx), 'l', closed=True)
+    return net, prof
+
+
 GRIDS = {
     '1-LV-rural1--0-sw': synthetic_lv_rural1,
     '1-MV-urban--0-sw': synthetic_mv_urban,
@@ -419,6 +430,7 @@ GRIDS = {
     '1-HV-urban--0-sw': synthetic_hv_urban,
     'mv-small': synthetic_mv_small,
     'hv-small': synthetic_hv_small,
+    'hv-small-sw': synthetic_hv_small_sw,
 }
 
 

@@ -142,7 +142,7 @@ TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'QMarket': lambda net, d: tail_voltage_control(net, d, True),
          'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
          'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding,
-         'MultiStageOpf': lambda net, d: None}
+         'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None}
 
 
 # ---------------------------------------------------------------------------
@@ -171,7 +171,12 @@ def apply_actions(net, act_keys, action, autoscale=True, diff_step=None):
                 sp = np.minimum(sp, df[f'max_{col}'].loc[idxs].to_numpy(float))
             if f'min_{col}' in df.columns:
                 sp = np.maximum(sp, df[f'min_{col}'].loc[idxs].to_numpy(float))
-        net[unit].loc[idxs, col] = sp / sc                                  # :472-483
+        sp = sp / sc                                                        # :472-474
+        if col in ('closed', 'in_service'):                                 # :476-478
+            sp = np.round(sp).astype(bool)
+        elif col in ('tap_pos', 'step'):                                    # :479-481
+            sp = np.round(sp)
+        net[unit].loc[idxs, col] = sp                                       # :483
         k += n
     cur = current_actions(net, act_keys, autoscale, from_results=False)
     with np.errstate(invalid='ignore'):

@@ -27,10 +27,12 @@ import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc  # noqa: E402
 from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
+import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
-       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf}
+       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
+       'NetworkReconfiguration': ref_nr.NetworkReconfiguration}
 
 
 def snapshot(net):
@@ -158,9 +160,13 @@ def run(name):
         push('trafo_loading', env.net.res_trafo.loading_percent.to_numpy())
         push('p_ext', env.net.res_ext_grid.p_mw.to_numpy())
         push('q_ext', env.net.res_ext_grid.q_mvar.to_numpy())
-        push('current_actions', env.get_current_actions())
-        for tbl, col in (('sgen', 'q_mvar'), ('sgen', 'p_mw'), ('storage', 'q_mvar'), ('gen', 'p_mw')):
-            if len(env.net[tbl]):
+        try:
+            push('current_actions', env.get_current_actions())
+        except KeyError:      # no res_switch / res_trafo.tap_pos in pandapower: only the table route works
+            push('current_actions', env.get_current_actions(from_results_table=False))
+        for tbl, col in (('sgen', 'q_mvar'), ('sgen', 'p_mw'), ('storage', 'q_mvar'), ('gen', 'p_mw'),
+                         ('switch', 'closed'), ('trafo', 'tap_pos')):
+            if tbl in env.net and len(env.net[tbl]) and col in env.net[tbl].columns:
                 push(f'post__{tbl}__{col}', np.array(env.net[tbl][col].to_numpy(dtype=float), copy=True))
     out = {k: np.stack(v) for k, v in rec.items()}
     out['n_obs'] = np.array(env.observation_space.shape[0])

@@ -58,6 +58,13 @@ SCENARIOS.update({
     'multistage_lv': ('MultiStageOpf', dict(simbench_network_name='1-LV-rural1--0-sw', steps_per_episode=4), 4, 20),
 })
 
+SCENARIOS.update({
+    # discrete actuators that change Ybus per instance: line switches + transformer taps
+    # (examples/network_reconfiguration.py; opf_env.py:476-481)
+    'reconf_hv_small_sw': ('NetworkReconfiguration', dict(simbench_network_name='hv-small-sw',
+                                                          controllable_switch_idxs=(1, 3)), 8, 21),
+})
+
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
 EPISODE_STEPS = {'vc_multistep_diff': 3, 'multistage_lv': 4}
 # explicit start steps (else drawn from the training steps): 670 runs into the first validation week at 672
@@ -70,3 +77,4 @@ TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_m
            ('storage', 'max_q_mvar'), ('storage', 'min_q_mvar'),
            ('poly_cost', 'cq2_eur_per_mvar2'), ('poly_cost', 'cp1_eur_per_mw'),
            ('pwl_cost', 'cp1_eur_per_mw'), ('load', 'max_p_mw')]
+# (switch states / tap positions are not snapshotted: they are outputs of the step, see 'tab_after__*')

@@ -64,6 +64,11 @@ def test_env_matches_reference_golden(name):
     out = env.step(g['action'])
     assert _np(out[4]['converged']).all()
     assert np.allclose(_np(env.get_current_actions()), g['current_actions'], rtol=0, atol=1e-9, equal_nan=True)
+    for key in g:                              # table state after the step (set-points, switch states, taps)
+        if key.startswith('post__'):
+            _, tbl, col = key.split('__')
+            if (tbl, col) in env.store.ranges:
+                assert np.allclose(_np(env.table_column(tbl, col)), g[key], rtol=0, atol=1e-9), key
     n1 = bool(env.n_minus_one_keys)
     for k in range(n):
         ref = {key: g[key][k] for key in g if g[key].ndim and len(g[key]) == n and not key.startswith('fail_')}
@@ -85,7 +90,7 @@ def test_env_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize('name,B', [('vc_mv_small', 48), ('qm_mv_small', 32), ('eco_hv_small', 24),
-                                    ('sc_hv_small', 12), ('vc_resobs_diff', 16)])
+                                    ('sc_hv_small', 12), ('vc_resobs_diff', 16), ('reconf_hv_small_sw', 32)])
 def test_env_matches_oracle_random_batch(name, B):
     env = product_env(name, batch_size=B)
     orc = oracle_env(name, product_env(name, defer_device=True))
@@ -204,3 +209,52 @@ def test_reward_scaling_from_batched_estimate():
     want = 0.5 * (obj * sp['objective_factor'] + sp['objective_bias']) + \
         0.5 * (pen * sp['penalty_factor'] + sp['penalty_bias'])
     assert np.allclose(_np(reward), want, rtol=1e-12, atol=1e-12)
+
+
+def test_n_minus_one_on_switched_and_tapped_branches():
+    """Contingencies that hit branches whose state is already per-instance: a line that a switch
+    actuator may have opened, and a transformer on a tap position other than the compiled one
+    (the removal has to cancel the tap modifier of that branch)."""
+    from opfgym_amd import envs
+    from opfgym_amd.batched_env import SecurityConstrainedOpfEnv
+    from oracle import env_oracle
+    from env_cases import reward_dict
+
+    class ReconfN1(SecurityConstrainedOpfEnv):
+        def __init__(self, **kw):
+            self.controllable_switch_idxs = np.array((1, 3))
+            net, profiles = envs.NetworkReconfiguration._define_opf(self, 'hv-small-sw')
+            obs_keys = [('load', 'p_mw', net.load.index)]
+            act_keys = [('switch', 'closed', net.switch.index[net.switch.controllable.to_numpy(bool)]),
+                        ('trafo', 'tap_pos', net.trafo.index)]
+            keys = (('line', 'in_service', np.array([1, 5])), ('trafo', 'in_service', np.array([1])))
+            SecurityConstrainedOpfEnv.__init__(self, net, act_keys, obs_keys, n_minus_one_keys=keys,
+                                               profiles=profiles, **kw)
+    B = 16
+    env = ReconfN1(batch_size=B, device='cuda:0', seed=3)
+    d = ReconfN1(batch_size=1, defer_device=True, seed=3).host_definition()
+    h = ReconfN1(batch_size=1, defer_device=True, seed=3)
+    orc = env_oracle.EnvOracle(
+        d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
+        reward_dict(d['reward_function']), lambda net, dr: None,
+        autoscale_actions=h.autoscale_actions, diff_action_step_size=h.diff_action_step_size,
+        clipped_action_penalty=h.clipped_action_penalty, diff_objective=h.diff_objective,
+        add_mean_obs=h.add_mean_obs, pf_for_obs=h.pf_for_obs, steps_per_episode=h.steps_per_episode,
+        n_minus_one_keys=h.n_minus_one_keys, not_converged_penalty=h.not_converged_penalty,
+        data=h.train_data, state_keys=h.state_keys, sampling_params=h.sampling_params,
+        bus_wise_obs=h.bus_wise_obs, multi_stage=False,
+        split=(h.test_steps, h.validation_steps, h.train_steps))
+    rng = np.random.default_rng(5)
+    steps = rng.choice(env.train_steps, B)
+    actions = rng.random((B, env.n_actions))
+    env.reset(options={'step': steps})
+    out = env.step(actions)
+    n_ok = 0
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=True)
+            n_ok += 1
+    assert n_ok >= B // 2
