@@ -8,3 +8,4 @@ from .batched_env import (BatchedOpfEnv, MultiStageOpfEnv, SecurityConstrainedOp
 from .solver_plugin import BatchedPowerFlowSolver, power_flow_solver  # noqa: F401
 
 OpfEnv = BatchedOpfEnv
+from .vector_env import OpfVectorEnv, make_vec, register  # noqa: F401,E402

@@ -258,3 +258,48 @@ def test_n_minus_one_on_switched_and_tapped_branches():
             _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=True)
             n_ok += 1
     assert n_ok >= B // 2
+
+
+def test_vector_env_same_step_autoreset():
+    """OpfVectorEnv: gymnasium.vector-shaped face of a batched env; single-step episodes end on
+    every step, 'same_step' autoreset hands back the first observation of the next episode and
+    keeps the terminal one in info['final_obs']."""
+    from opfgym_amd.vector_env import make_vec
+    B = 64
+    vec = make_vec('VoltageControl-v0', B, simbench_network_name='mv-small', device='cuda:0', seed=1)
+    assert vec.num_envs == B and vec.observation_space.shape == (B,) + vec.single_observation_space.shape
+    obs0, _ = vec.reset(seed=11)
+    x0 = vec.env.x.clone()
+    a = np.random.default_rng(0).random((B, vec.single_action_space.shape[0]))
+    obs, reward, term, trunc, info = vec.step(a)
+    assert _np(term).all() and '_final_obs' in info and _np(info['_final_obs']).all()
+    assert not np.allclose(_np(obs), _np(info['final_obs']))          # new episode: new sampled state
+    assert not np.allclose(_np(vec.env.x), _np(x0))
+    assert np.isfinite(_np(reward)).all() and np.isfinite(_np(obs)).all()
+    # the returned observation is the one a plain reset would give for the state now in the store
+    obs2, reward2, *_ = vec.step(a)
+    assert np.isfinite(_np(reward2)).all() and not np.allclose(_np(obs2), _np(obs))
+
+
+def test_vector_env_next_step_and_partial_reset():
+    from opfgym_amd import envs
+    from opfgym_amd.vector_env import OpfVectorEnv
+    B = 8
+    env = envs.VoltageControl(simbench_network_name='mv-small', batch_size=B, device='cuda:0', seed=2,
+                              steps_per_episode=3, diff_action_step_size=0.2)
+    vec = OpfVectorEnv(env, autoreset_mode='next_step')
+    vec.reset(seed=5)
+    a = np.random.default_rng(1).random((B, env.n_actions))
+    for s_ in range(3):
+        obs, reward, term, trunc, info = vec.step(a)
+    assert _np(trunc).all()                                           # episode over after 3 steps
+    obs, reward, term, trunc, info = vec.step(a)                      # this call only resets
+    assert (_np(reward) == 0).all() and not _np(term).any() and not _np(trunc).any()
+    assert (_np(env.step_count) == 0).all()
+    # partial reset keeps the other rows
+    import torch
+    mask = torch.zeros(B, dtype=torch.bool, device='cuda:0')
+    mask[::2] = True
+    x_before = env.x.clone()
+    vec._reset_rows(mask)
+    assert torch.equal(env.x[1::2], x_before[1::2]) and not torch.equal(env.x[::2], x_before[::2])

@@ -222,3 +222,18 @@ def test_build_simbench_net_columns():          # reference tests/test_simbench.
     assert (prof[('sgen', 'p_mw')].to_numpy() >= 0).all()
     assert np.allclose(net.storage.min_min_p_mw, -net.storage.max_max_p_mw)
     assert 'mean_q_mvar' in net.ext_grid and 'std_dev_p_mw' in net.load
+
+
+def test_vector_env_ids_mirror_reference_registration():
+    """opfgym/envs/__init__.py:12-35 registers five ids; the vector module carries the same ids
+    and resolves each to a batched environment class (gymnasium itself is not installed here)."""
+    from opfgym_amd import envs, vector_env
+    assert set(vector_env.ENV_IDS) == {'MaxRenewable-v0', 'QMarket-v0', 'VoltageControl-v0',
+                                       'EcoDispatch-v0', 'LoadShedding-v0'}
+    for env_id, cls in vector_env.ENV_IDS.items():
+        assert hasattr(envs, cls) and callable(getattr(vector_env, f'_vector_entry_{cls}'))
+    try:
+        import gymnasium  # noqa: F401
+        assert vector_env.register() is True
+    except ImportError:
+        assert vector_env.register() is False
