@@ -101,6 +101,7 @@ typedef struct opfx_plan_info {
   int32_t lds_doubles;       /* solver LDS footprint per instance (doubles)  */
   /* register-resident lane programme (rounds of 64 work items); -1 = not built */
   int32_t lp_rounds_a, lp_rounds_h, lp_rounds_b, lp_rounds_c;
+  int32_t n_full;            /* blocks [0,n_full) store 4 values, [n_full,n_blk) two (a,b of [[a,b],[-b,a]]) */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block

@@ -48,7 +48,7 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'nb', 'nbr', 'nref', 'npv', 'npq', 'nnz_y', 'nnz_j', 'n_blk', 'n_fill', 'n_levels',
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
-        'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c')]
+        'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

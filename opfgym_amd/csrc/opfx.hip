@@ -51,7 +51,7 @@ constexpr int MODE_ENV = 1;
 // device-resident plan
 // ---------------------------------------------------------------------------
 struct DevPlan {
-  int nb, nbr, nref, nblk, nlev, nfill, npv;
+  int nb, nbr, nref, nblk, nlev, nfill, npv, nfull;
   double base_mva;
   const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
   const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
@@ -232,18 +232,25 @@ struct Lds {
   // one double per id the bank depends on (id mod 32) only, whereas 32-byte block records
   // (16-byte rhs pairs) put every access of a group on 8 (16) of the 32 bank pairs.
   double* rq;
-  int bs;
+  int bs;                    // entries of the a11 / a12 arrays (all blocks)
+  int nfull;                 // blocks [0, nfull) also have a21 / a22 entries (arrays at o2, o3)
+  int o2, o3;
   double* mod;               // per-instance branch modifiers (MOD_DOUBLES each), see mods_*
 };
+// Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
+// (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
 __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
   const double* p = L.blk + id;
-  return Blk{p[0], p[L.bs], p[2 * L.bs], p[3 * L.bs]};
+  Blk b{p[0], p[L.bs], 0.0, 0.0};
+  if (id < L.nfull) { b.a21 = p[L.o2]; b.a22 = p[L.o3]; }
+  else { b.a21 = -b.a12; b.a22 = b.a11; }
+  return b;
 }
 __device__ __forceinline__ void st_blk2(const Lds& L, int id, const Blk& b) {
   double* p = L.blk + id;
-  p[0] = b.a11; p[L.bs] = b.a12; p[2 * L.bs] = b.a21; p[3 * L.bs] = b.a22;
+  p[0] = b.a11; p[L.bs] = b.a12;
+  if (id < L.nfull) { p[L.o2] = b.a21; p[L.o3] = b.a22; }
 }
-
 // Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
 __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
                        int out_br, int* iters_out, double* nrm_out) {
@@ -465,8 +472,8 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
     double* tp = L.blk + tb;
     lds_add(tp, m11 * bj.a11 + m12 * bj.a21);
     lds_add(tp + L.bs, m11 * bj.a12 + m12 * bj.a22);
-    lds_add(tp + 2 * L.bs, m21 * bj.a11 + m22 * bj.a21);
-    lds_add(tp + 3 * L.bs, m21 * bj.a12 + m22 * bj.a22);
+    lds_add(tp + L.o2, m21 * bj.a11 + m22 * bj.a21);
+    lds_add(tp + L.o3, m21 * bj.a12 + m22 * bj.a22);
   }
 }
 
@@ -579,11 +586,11 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   if (ob >= 0) {                           // dS_i/dth_j = -j c, dS_i/dln|V_j| = c
     double* p = L.blk + ob;
     lds_add(p, dci); lds_add(p + L.bs, dcr);
-    if (!pv) { lds_add(p + 2 * L.bs, -dcr); lds_add(p + 3 * L.bs, dci); }
+    if (!pv && ob < L.nfull) { lds_add(p + L.o2, -dcr); lds_add(p + L.o3, dci); }   // (two-value blocks: implied)
   }
   double* p = L.blk + db;                  // {-S_off.im, Y|V|^2.re + P, S_off.re, Y|V|^2.im + Q}
   lds_add(p, -dci); lds_add(p + L.bs, 2.0 * dyr + dcr);
-  if (!pv) { lds_add(p + 2 * L.bs, dcr); lds_add(p + 3 * L.bs, 2.0 * dyi + dci); }
+  if (!pv) { lds_add(p + L.o2, dcr); lds_add(p + L.o3, 2.0 * dyi + dci); }
 }
 
 // current injected at bus i by the modifiers: I_i += dY_ii V_i + dY_ij V_j
@@ -616,7 +623,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   const int RB = P.rb, R = P.rb + P.rc;                  // padded round counts (multiples of 4, R >= 4)
   auto ld_desc = [&](int r) { return stream[(size_t)(r < R ? r : r - R) * WAVE]; };
   const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
-  const int fill_lo = P.nblk - P.nfill;                    // fill blocks are numbered last (plan.cpp)
+  const int fill_lo = P.nfull - P.nfill;                   // fill blocks: ids [nfull - nfill, nfull) (plan.cpp)
 
   int it = 0;
   double nrm = 0.0;
@@ -629,7 +636,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   while (true) {
     // ---- phase A -----------------------------------------------------------------
-    for (int f = fill_lo + lane; f < P.nblk; f += WAVE) st_blk2(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+    for (int f = fill_lo + lane; f < P.nfull; f += WAVE) st_blk2(L, f, Blk{0.0, 0.0, 0.0, 0.0});
     OPFX_STAMP(10);
     double my = 0.0;
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
@@ -1119,7 +1126,11 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   L.rq = L.rhs + nbe;
   L.blk = L.rhs + 2 * nbe;
   L.bs = (P.nblk + 1) & ~1;
-  const int nblk_d = 4 * L.bs > nres ? 4 * L.bs : nres;
+  L.nfull = V2 ? P.nfull : P.nblk;
+  const int nfs = (L.nfull + 1) & ~1;
+  L.o2 = 2 * L.bs; L.o3 = 2 * L.bs + nfs;
+  const int nval = V2 ? 2 * L.bs + 2 * nfs : 4 * L.bs;      // (first-generation kernel: 32-byte records)
+  const int nblk_d = nval > nres ? nval : nres;
   L.sp = L.blk + ((nblk_d + 1) & ~1);
   L.acc = L.sp + na;
   L.mod = L.acc + nacc;
@@ -1706,7 +1717,8 @@ namespace {
 
 size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
-  size_t blk = (std::max<size_t>((size_t)4 * (((size_t)p.n_blk + 1) & ~(size_t)1), (size_t)nres) + 1) & ~(size_t)1;
+  const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)p.n_full + 1) & ~(size_t)1;
+  size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
@@ -1784,6 +1796,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(br_island, br_island); PUT(ref_bus, ref_bus);
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
+  d.nfull = p->n_full;
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   d.stamps = nullptr;

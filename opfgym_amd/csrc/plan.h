@@ -24,6 +24,7 @@ struct opfx_plan {
   std::vector<int32_t> br_island;      // [nbr] 1 = outage of this branch leaves a bus without a path to a REF bus
   // block LU pattern
   int32_t n_blk = 0;
+  int32_t n_full = 0;                      // blocks [0, n_full) hold four values, the rest two (plan.cpp renumber_blocks)
   std::vector<int32_t> blk_row, blk_col;   // [n_blk]
   std::vector<int32_t> diag_blk;           // [nb] (-1 for REF)
   std::vector<int32_t> fill_blk;
