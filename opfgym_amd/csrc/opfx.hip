@@ -68,6 +68,7 @@ struct DevPlan {
   const unsigned *lp_team2, *lp_team4;   // per-wave streams of the cooperative kernels (plan.h)
   int team_rounds2, team_rounds4;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
+  double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
 };
 
 struct DevEnv {
@@ -630,6 +631,9 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   bool conv = false;
   OPFX_STAMP_INIT();
   ARound cur = load_around(P, 0, lane);
+  // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
+  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
+  double pcur = psp_g[lane < nb ? lane : nb - 1], qcur = qsp_g[lane < nb ? lane : nb - 1];
   uint4 hy = make_uint4(0, 0, 0, 0), he = make_uint4(NONE | (NONE << 16), 0, 0, 0);
   if (P.rh > 0) { hy = hpk[0]; he = hpk[WAVE]; }
   // rounds 0..3 of phases B/C; re-loaded by the tail of phase C for the next iteration
@@ -674,7 +678,13 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     OPFX_STAMP(11);
     for (int r = 0; r < P.ra; ++r) {
       const ARound a = cur;
-      cur = load_around(P, r + 1 < P.ra ? r + 1 : 0, lane);     // next round (or round 0 of the next iteration)
+      const double p_sched = pcur, q_sched = qcur;
+      {
+        const int rn = r + 1 < P.ra ? r + 1 : 0;                 // next round (or round 0 of the next iteration)
+        cur = load_around(P, rn, lane);
+        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+        pcur = psp_g[in_]; qcur = qsp_g[in_];
+      }
       const int i = lane + WAVE * r;
       if (i < nb) {
         const int t = L.bt[i];
@@ -706,8 +716,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double v2 = vri * vri + vii * vii;
           const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
           const double pc = sr + yr, qc = si + yi;
-          const double fp = pc - L.psp[i];
-          const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
+          const double fp = pc - p_sched;
+          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
           my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
@@ -1122,7 +1132,13 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   double* nxt = L.vi + nbe;
   if (V2) { L.vm = nullptr; L.va = nullptr; }
   else { L.vm = nxt; L.va = L.vm + nbe; nxt = L.va + nbe; }
-  L.psp = nxt; L.qsp = L.psp + nbe; L.rhs = L.qsp + nbe;
+  if (V2) {
+    // scheduled P/Q are touched by the lane that owns the bus row only (phase A, q-limits,
+    // results): they live in a per-workgroup row of global memory (L2-resident, read one round
+    // ahead with the descriptors) and free 16*nb bytes of LDS — the resource that sets how many
+    // instances a CU holds
+    L.psp = P.pq + (size_t)blockIdx.x * 2 * nbe; L.qsp = L.psp + nbe; L.rhs = nxt;
+  } else { L.psp = nxt; L.qsp = L.psp + nbe; L.rhs = L.qsp + nbe; }
   L.rq = L.rhs + nbe;
   L.blk = L.rhs + 2 * nbe;
   L.bs = (P.nblk + 1) & ~1;
@@ -1354,7 +1370,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     double csum = 0.0;                       // this lane's share of the cost rows
     if (wave == 0) {
       // ---- bus injections (makeSbus): flat list, LDS accumulate ----------------------------------
-      for (int i = lane; i < nb; i += WAVE) { L.psp[i] = 0.0; L.qsp[i] = 0.0; L.bt[i] = BT_PQ; }
+      // accumulated in the voltage arrays (free until init_voltage), then written to this
+      // workgroup's P/Q row
+      double* const pacc = V2 ? L.vr : L.psp;
+      double* const qacc = V2 ? L.vi : L.qsp;
+      for (int i = lane; i < nb; i += WAVE) { pacc[i] = 0.0; qacc[i] = 0.0; L.bt[i] = BT_PQ; }
       wave_fence();
       for (int e0 = 0; e0 < E.n_inj; e0 += 4 * WAVE) {
         uint4 d[4];
@@ -1366,8 +1386,12 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           if (e >= E.n_inj) continue;
           const int bq = d[u].x;
           const double v = u2d(d[u].z, d[u].w) * src_val(xs, L.sp, (int)d[u].y);
-          lds_add(((bq >> 16) ? L.qsp : L.psp) + (bq & 0xFFFF), v);
+          lds_add(((bq >> 16) ? qacc : pacc) + (bq & 0xFFFF), v);
         }
+      }
+      if (V2) {
+        wave_fence();
+        for (int i = lane; i < nb; i += WAVE) { L.psp[i] = pacc[i]; L.qsp[i] = qacc[i]; }
       }
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
       for (int r0 = 0; r0 < E.ncost_pre; r0 += 2 * WAVE) {
@@ -1719,7 +1743,7 @@ size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc,
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
   const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)p.n_full + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
-  size_t d = (v2 ? 6 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
+  size_t d = (v2 ? 4 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
   return (bytes + 15) & ~(size_t)15;
 }
@@ -1816,6 +1840,11 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
     if (hipMalloc(&ws, n_ws * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(warm-start scratch) failed"); return OPFX_ERR_HIP; }
     A.ptrs.push_back(ws);
     d.warm = static_cast<double*>(ws);
+    void* pq = nullptr;
+    const size_t nbe = ((size_t)p->nb + 1) & ~(size_t)1;
+    if (hipMalloc(&pq, (size_t)c->n_cu * 16 * 2 * nbe * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(P/Q scratch) failed"); return OPFX_ERR_HIP; }
+    A.ptrs.push_back(pq);
+    d.pq = static_cast<double*>(pq);
   }
   {
     std::vector<double> vr0(p->nb), vi0(p->nb);
