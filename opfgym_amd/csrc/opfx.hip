@@ -51,7 +51,9 @@ constexpr int MODE_ENV = 1;
 // device-resident plan
 // ---------------------------------------------------------------------------
 struct DevPlan {
-  int nb, nbr, nref, nblk, nlev, nfill, npv, nfull;
+  int nb, nbr, nref, nblk, nlev, nfill, npv;
+  int nfull;                 // blocks [0, nfull) are stored with four values (per launch: choose_block_storage)
+  int fill_lo;               // fill blocks: ids [fill_lo, fill_lo + nfill)
   double base_mva;
   const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
   const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
@@ -240,17 +242,19 @@ struct Lds {
 };
 // Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
 // (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
+template <bool PK>
 __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
   const double* p = L.blk + id;
   Blk b{p[0], p[L.bs], 0.0, 0.0};
-  if (id < L.nfull) { b.a21 = p[L.o2]; b.a22 = p[L.o3]; }
+  if (!PK || id < L.nfull) { b.a21 = p[L.o2]; b.a22 = p[L.o3]; }
   else { b.a21 = -b.a12; b.a22 = b.a11; }
   return b;
 }
+template <bool PK>
 __device__ __forceinline__ void st_blk2(const Lds& L, int id, const Blk& b) {
   double* p = L.blk + id;
   p[0] = b.a11; p[L.bs] = b.a12;
-  if (id < L.nfull) { p[L.o2] = b.a21; p[L.o3] = b.a22; }
+  if (!PK || id < L.nfull) { p[L.o2] = b.a21; p[L.o3] = b.a22; }
 }
 // Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
 __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
@@ -451,12 +455,13 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 #define OPFX_STAMP(slot) do { } while (0)
 #endif
 
+template <bool PK>
 __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
   if (tb == NONE) return;
-  const Blk bi = ld_blk2(L, d.x >> 16);
-  const Blk bk = ld_blk2(L, d.y & 0xFFFF);
+  const Blk bi = ld_blk2<PK>(L, d.x >> 16);
+  const Blk bk = ld_blk2<PK>(L, d.y & 0xFFFF);
   // m = -A_ik A_kk^-1 (the sign folded into the reciprocal: the update is an atomic ADD of m A_kj)
   const double nrdet = fast_rcp(bk.a12 * bk.a21 - bk.a11 * bk.a22);
   const double m11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * nrdet;
@@ -469,7 +474,7 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
     lds_add(&L.rhs[i], m11 * r1 + m12 * r2);
     lds_add(&L.rq[i], m21 * r1 + m22 * r2);
   } else {
-    const Blk bj = ld_blk2(L, d.y >> 16);
+    const Blk bj = ld_blk2<PK>(L, d.y >> 16);
     double* tp = L.blk + tb;
     lds_add(tp, m11 * bj.a11 + m12 * bj.a21);
     lds_add(tp + L.bs, m11 * bj.a12 + m12 * bj.a22);
@@ -478,19 +483,20 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   }
 }
 
+template <bool PK>
 __device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned k = d.x & 0xFFFF;
   if (k == NONE) return;
   double d1 = 0.0, d2 = 0.0;
   if ((d.y & 0xFFFF) != NONE) {
-    const Blk a = ld_blk2(L, d.y & 0xFFFF);
+    const Blk a = ld_blk2<PK>(L, d.y & 0xFFFF);
     const unsigned j = d.y >> 16;
     const double x1 = L.rhs[j], x2 = L.rq[j];
     d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
   }
   if ((d.z & 0xFFFF) != NONE) {
-    const Blk a = ld_blk2(L, d.z & 0xFFFF);
+    const Blk a = ld_blk2<PK>(L, d.z & 0xFFFF);
     const unsigned j = d.z >> 16;
     const double x1 = L.rhs[j], x2 = L.rq[j];
     d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
@@ -498,7 +504,7 @@ __device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
   const unsigned dblk = d.x >> 16;
   if (dblk != NONE) {
     const double y1 = L.rhs[k] - d1, y2 = L.rq[k] - d2;
-    const Blk bk = ld_blk2(L, dblk);
+    const Blk bk = ld_blk2<PK>(L, dblk);
     const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
     L.rhs[k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
     L.rq[k] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
@@ -611,6 +617,7 @@ __device__ __forceinline__ void mods_row_current(const Lds& L, int n_mod, int i,
   }
 }
 
+template <bool PK>
 __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
                         int* iters_out, double* nrm_out) {
   constexpr unsigned NONE = 0xFFFFu;
@@ -624,7 +631,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   const int RB = P.rb, R = P.rb + P.rc;                  // padded round counts (multiples of 4, R >= 4)
   auto ld_desc = [&](int r) { return stream[(size_t)(r < R ? r : r - R) * WAVE]; };
   const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
-  const int fill_lo = P.nfull - P.nfill;                   // fill blocks: ids [nfull - nfill, nfull) (plan.cpp)
+  const int fill_lo = P.fill_lo;                           // fill blocks: ids [fill_lo, fill_lo + nfill) (plan.cpp)
 
   int it = 0;
   double nrm = 0.0;
@@ -640,7 +647,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   while (true) {
     // ---- phase A -----------------------------------------------------------------
-    for (int f = fill_lo + lane; f < P.nfull; f += WAVE) st_blk2(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+    for (int f = fill_lo + lane; f < fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
     OPFX_STAMP(10);
     double my = 0.0;
     // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
@@ -667,7 +674,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           if (bid != NONE && t != BT_REF) {
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2(L, bid, jb);
+            st_blk2<PK>(L, bid, jb);
           }
           lds_add(&L.rhs[i], cr);
           lds_add(&L.rq[i], ci);
@@ -708,7 +715,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
             // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2(L, bid, jb);
+            st_blk2<PK>(L, bid, jb);
           }
         }
         if (t != BT_REF) {
@@ -724,7 +731,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk2(L, a.dw & 0xFFFF, jb);
+          st_blk2<PK>(L, a.dw & 0xFFFF, jb);
         } else {
           // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
           // in its rhs slots so that the result pass needs no second walk over the row
@@ -755,17 +762,17 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     // Rounds of one level are independent; ordering is needed at level ends only, but on a
     // single wave the fence is free (the LDS executes a wave's operations in order).
     for (int r = 0; r < RB; r += 4) {
-      item_factor(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_factor<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(2);
     for (int r = RB; r < R; r += 4) {
-      item_solve(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_solve(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_solve(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_solve(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_solve<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_solve<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_solve<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_solve<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
@@ -817,13 +824,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+template <bool PK>
 __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   const unsigned flags = __builtin_amdgcn_readfirstlane(d.w);      // same for every item of a round
-  if (flags & 2u) item_solve(L, d); else item_factor(L, d);
+  if (flags & 2u) item_solve<PK>(L, d); else item_factor<PK>(L, d);
   if (flags & 1u) lds_barrier();
 }
 
-template <int NW>
+template <int NW, bool PK>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
                              int* iters_out, double* nrm_out) {
   constexpr unsigned NONE = 0xFFFFu;
@@ -839,9 +847,15 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   double nrm = 0.0;
   bool conv = false;
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
+  // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
+  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
+  const int r_first = wave < P.ra ? wave : 0;
+  ARound a_next = load_around(P, r_first, lane);
+  double p_next, q_next;
+  { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
   while (true) {
     // ---- phase A ------------------------------------------------------------------
-    for (int f = tid; f < P.nfill; f += NT) st_blk2(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
+    for (int f = tid; f < P.nfill; f += NT) st_blk2<PK>(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
     for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
     __syncthreads();
     for (int h = wave; h < P.rh; h += NW) {
@@ -861,7 +875,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         if (bid != NONE && t != BT_REF) {
           Blk jb{ci, cr, -cr, ci};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-          st_blk2(L, bid, jb);
+          st_blk2<PK>(L, bid, jb);
         }
         lds_add(&L.rhs[i], cr);
         lds_add(&L.rq[i], ci);
@@ -870,7 +884,14 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     __syncthreads();
     double my = 0.0;
     for (int r = wave; r < P.ra; r += NW) {
-      const ARound a = load_around(P, r, lane);
+      const ARound a = a_next;
+      const double p_sched = p_next, q_sched = q_next;
+      {
+        const int rn = r + NW < P.ra ? r + NW : r_first;       // (last round: first round of the next iteration)
+        a_next = load_around(P, rn, lane);
+        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+        p_next = psp_g[in_]; q_next = qsp_g[in_];
+      }
       const int i = lane + WAVE * r;
       if (i < nb) {
         const int t = L.bt[i];
@@ -891,7 +912,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           if (bid != NONE && t != BT_REF) {
             Blk jb{ci, cr, -cr, ci};
             if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2(L, bid, jb);
+            st_blk2<PK>(L, bid, jb);
           }
         }
         double g = a.yd.x, b = a.yd.y;
@@ -899,14 +920,14 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const double yr = g * v2, yi = -b * v2;
         if (t != BT_REF) {
           const double pc = sr + yr, qc = si + yi;
-          const double fp = pc - L.psp[i];
-          const double fq = (t == BT_PV) ? 0.0 : qc - L.qsp[i];
+          const double fp = pc - p_sched;
+          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
           my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
           Blk jb{-si, yr + pc, sr, yi + qc};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk2(L, a.dw & 0xFFFF, jb);
+          st_blk2<PK>(L, a.dw & 0xFFFF, jb);
         } else {
           L.rhs[i] = sr + yr;
           L.rq[i] = si + yi;
@@ -934,10 +955,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
     for (int k = 0; k < K; k += 4) {
-      team_step(L, q0); q0 = ld_desc(k + 4);
-      team_step(L, q1); q1 = ld_desc(k + 5);
-      team_step(L, q2); q2 = ld_desc(k + 6);
-      team_step(L, q3); q3 = ld_desc(k + 7);
+      team_step<PK>(L, q0); q0 = ld_desc(k + 4);
+      team_step<PK>(L, q1); q1 = ld_desc(k + 5);
+      team_step<PK>(L, q2); q2 = ld_desc(k + 6);
+      team_step<PK>(L, q3); q3 = ld_desc(k + 7);
     }
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
@@ -960,7 +981,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
 // A bus that an earlier solve of this instance pinned at a reactive limit gets
 // its generator share removed from q_sp again (L.bt must hold valid codes).
-template <bool V2>
+template <int V2>
 __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
                              const double* qg_max, bool enforce_q_lims) {
   for (int i = lane; i < P.nb; i += WAVE) {
@@ -982,7 +1003,7 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
 }
 
 // Outer loop: NR + enforce_q_lims PV->PQ switching.
-template <bool V2, int NW>
+template <int V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm) {
   const int wave = threadIdx.x >> 6;
@@ -994,8 +1015,8 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
-    if (NW > 1) conv = newton2_coop<NW>(P, L, o, n_mod, &it, nrm);
-    else conv = V2 ? newton2(P, L, o, lane, n_mod, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm);
+    else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
@@ -1042,7 +1063,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
 
 // after convergence: result bank in LDS region R (reuses the LU block storage)
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
-template <bool V2>
+template <int V2>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle) {
@@ -1123,7 +1144,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   }
 }
 
-template <bool V2>
+template <int V2>
 __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc, int nmod) {
   Lds L;
   const int nb = P.nb;
@@ -1157,7 +1178,7 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
 // ---------------------------------------------------------------------------
 // pure power flow kernel (opfx_solve)
 // ---------------------------------------------------------------------------
-template <bool V2, int NW>
+template <int V2, int NW>
 __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1266,7 +1287,7 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <bool V2, int NW>
+template <int V2, int NW>
 __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
@@ -1735,13 +1756,14 @@ struct opfx_env {
   DevArena arena;
   size_t lds_bytes = 0;
   int per_cu = 0;
+  int n_full = 0;        // four-value blocks this environment's kernels run with (choose_block_storage)
 };
 
 namespace {
 
-size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod) {
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod, int n_full) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
-  const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)p.n_full + 1) & ~(size_t)1;
+  const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)n_full + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 4 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
   size_t bytes = d * sizeof(double) + (size_t)p.nb;
@@ -1750,6 +1772,23 @@ size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc,
 
 // Wavefronts per instance: grids whose LDS image leaves room for only a few instances per
 // CU get a team of waves per instance so that the SIMDs are not left idle.
+int instances_per_cu(size_t lds) {
+  const size_t granule = 1024;
+  return (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
+}
+
+// Two-value storage of the plain off-diagonal blocks (plan.cpp renumber_blocks) costs a divergent
+// branch per block read; it is used only when the LDS it saves lets a CU hold more instances.
+// Returns the LDS bytes per instance and the number of four-value blocks to run with.
+template <typename F>
+size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
+  const size_t full = lds_for(p.n_blk), packed = lds_for(p.n_full);
+  bool use_packed = packed <= 160 * 1024 && (full > 160 * 1024 || instances_per_cu(packed) > instances_per_cu(full));
+  if (const char* ov = getenv("OPFX_PACKED")) use_packed = atoi(ov) != 0 && packed <= 160 * 1024;     // developer probe
+  *n_full_out = use_packed ? p.n_full : p.n_blk;
+  return use_packed ? packed : full;
+}
+
 int pick_team(size_t lds, bool v2) {
   if (!v2) return 1;
   if (const char* ov = getenv("OPFX_TEAM")) { const int t = atoi(ov); if (t == 1 || t == 2 || t == 4) return t; }
@@ -1821,6 +1860,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
   d.nfull = p->n_full;
+  d.fill_lo = p->n_full - (int)p->fill_blk.size();
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc
   d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   d.stamps = nullptr;
@@ -1872,14 +1912,20 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
-  size_t lds = solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1);
+  int n_full = ctx->plan.n_blk;
+  size_t lds = choose_block_storage(ctx->plan, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
+  DevPlan dp = ctx->dp;
+  dp.nfull = n_full;
   int grid = 0;
   const int team = pick_team(lds, ctx->v2);
-  auto kern = !ctx->v2 ? k_solve<false, 1> : (team == 4 ? k_solve<true, 4> : (team == 2 ? k_solve<true, 2> : k_solve<true, 1>));
+  const bool packed = n_full < ctx->plan.n_blk;
+  auto kern = !ctx->v2 ? k_solve<0, 1>
+            : packed ? (team == 4 ? k_solve<2, 4> : (team == 2 ? k_solve<2, 2> : k_solve<2, 1>))
+                     : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
   int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations};
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), ctx->dp, io, o,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
@@ -2067,7 +2113,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod);
+  e->lds_bytes = choose_block_storage(p, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod, nf); }, &e->n_full);
   *out = e;
   return OPFX_OK;
 }
@@ -2080,8 +2126,12 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
   const int team = pick_team(env->lds_bytes, env->ctx->v2);
-  auto kern = !env->ctx->v2 ? k_step<false, 1>
-                            : (team == 4 ? k_step<true, 4> : (team == 2 ? k_step<true, 2> : k_step<true, 1>));
+  DevPlan dp = env->ctx->dp;
+  dp.nfull = env->n_full;
+  const bool packed = env->n_full < env->ctx->plan.n_blk;
+  auto kern = !env->ctx->v2 ? k_step<0, 1>
+            : packed ? (team == 4 ? k_step<2, 4> : (team == 2 ? k_step<2, 2> : k_step<2, 1>))
+                     : (team == 4 ? k_step<1, 4> : (team == 2 ? k_step<1, 2> : k_step<1, 1>));
   int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   StepIO s{};
@@ -2093,7 +2143,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
-                     env->ctx->dp, env->d_de, s, o, (long long)B);
+                     dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }

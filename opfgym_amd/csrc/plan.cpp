@@ -74,6 +74,7 @@ void renumber_blocks(opfx_plan* p) {
   for (int32_t b = 0; b < n; ++b)
     if (p->blk_row[b] == p->blk_col[b] || p->bus_type[p->blk_row[b]] != OPFX_PQ) needs_full[b] = 1;
   for (int32_t tb : p->tgt_blk) if (tb >= 0) needs_full[tb] = 1;
+  if (getenv("OPFX_PLAN_NO_PACK")) std::fill(needs_full.begin(), needs_full.end(), 1);   // developer probe
   std::vector<int32_t> perm(n);
   int32_t next = 0;
   for (int32_t b = 0; b < n; ++b) if (!is_fill[b] && needs_full[b]) perm[b] = next++;
