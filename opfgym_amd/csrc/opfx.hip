@@ -250,6 +250,8 @@ __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
   else { b.a21 = -b.a12; b.a22 = b.a11; }
   return b;
 }
+// second row of a block of a PV bus row (always a four-value block): the Q equation is replaced by d|V| = 0
+__device__ __forceinline__ void blk_zero_row2(const Lds& L, int id) { L.blk[id + L.o2] = 0.0; L.blk[id + L.o3] = 0.0; }
 template <bool PK>
 __device__ __forceinline__ void st_blk2(const Lds& L, int id, const Blk& b) {
   double* p = L.blk + id;
@@ -671,11 +673,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
           const unsigned bid = ent >> 16;
           const int t = L.bt[i];
-          if (bid != NONE && t != BT_REF) {
-            Blk jb{ci, cr, -cr, ci};
-            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2<PK>(L, bid, jb);
-          }
+          if (bid != NONE) { st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci}); if (t == BT_PV) blk_zero_row2(L, bid); }
           lds_add(&L.rhs[i], cr);
           lds_add(&L.rq[i], ci);
         }
@@ -703,20 +701,21 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         // dependency chains interleave instead of being serialised by exec-mask branches
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned jr = ent[k] & 0xFFFF;
-          const unsigned j = jr != NONE ? jr : (unsigned)i;
+          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
           const double g = a.y[k].x, b = a.y[k].y;
           const double vrj = L.vr[j], vij = L.vi[j];
           const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
           sr += cr; si += ci;
           const unsigned bid = ent[k] >> 16;
-          if (bid != NONE && t != BT_REF) {
-            // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c
-            Blk jb{ci, cr, -cr, ci};
-            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2<PK>(L, bid, jb);
+          if (bid != NONE) {                                 // (rows and columns of REF buses have no blocks)
+            // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c ; PV rows are patched after the loop
+            st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});
           }
+        }
+        if (t == BT_PV) {                                    // rare: skipped as a whole when the wave has no PV row
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
         if (t != BT_REF) {
           const double g = a.yd.x, b = a.yd.y;
@@ -901,19 +900,18 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned jr = ent[k] & 0xFFFF;
-          const unsigned j = jr != NONE ? jr : (unsigned)i;
+          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
           double g = a.y[k].x, b = a.y[k].y;
           const double vrj = L.vr[j], vij = L.vi[j];
           const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
           sr += cr; si += ci;
           const unsigned bid = ent[k] >> 16;
-          if (bid != NONE && t != BT_REF) {
-            Blk jb{ci, cr, -cr, ci};
-            if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-            st_blk2<PK>(L, bid, jb);
-          }
+          if (bid != NONE) st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});   // (PV rows are patched after the loop)
+        }
+        if (t == BT_PV) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
         double g = a.yd.x, b = a.yd.y;
         const double v2 = vri * vri + vii * vii;

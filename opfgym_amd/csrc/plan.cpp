@@ -102,6 +102,12 @@ void build_lane_programs(opfx_plan* p) {
   // ---- A ---------------------------------------------------------------------
   p->ra = (nb + 63) / 64;
   p->lp_a_ent.assign((size_t)p->ra * KA * 64, NONE | (NONE << 16));
+  for (int r = 0; r < p->ra; ++r)                   // padding slots read the row's own bus (Y = 0): no select in the kernel
+    for (int k = 0; k < KA; ++k)
+      for (int l = 0; l < 64; ++l) {
+        const int i = r * 64 + l;
+        p->lp_a_ent[((size_t)r * KA + k) * 64 + l] = (uint32_t)(i < nb ? i : 0) | (NONE << 16);
+      }
   p->lp_a_y.assign((size_t)p->ra * KA * 64 * 2, 0.0);
   p->lp_a_ydiag.assign((size_t)p->ra * 64 * 2, 0.0);
   p->lp_a_dblk.assign((size_t)p->ra * 64, NONE);
