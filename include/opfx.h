@@ -264,6 +264,18 @@ typedef struct opfx_env_desc {
   const int32_t* bmod_n;          /* [n_bmod] table rows                     */
   const int32_t* bmod_ptr;        /* [n_bmod] first row in bmod_y            */
   const double* bmod_y;           /* [rows][8] ff, ft, tf, tt as (g, b), p.u. */
+  /* per-instance voltage set-points (a sampled ext_grid.vm_pu,
+   * examples/mixed_continuous_discrete.py:102-104): REF/PV bus i holds |V| = x[vset_slot[i]]
+   * instead of the compiled magnitude; -1 = compiled value; NULL = none */
+  const int32_t* vset_slot;       /* [nb] */
+  /* objective terms on the result bank — the device form of the `objective_function` seam
+   * (opf_env.py:52,80-84) for objectives like (vm_pu - 1)^2 per bus
+   * (mixed_continuous_discrete.py:17-19): the objective vector gets, after the cost rows,
+   * qterm_weight[k] * (result[qterm_idx[k]] - qterm_target[k])^2 */
+  int32_t n_qterm;
+  const int32_t* qterm_idx;       /* [n_qterm] result-bank index             */
+  const double* qterm_target;     /* [n_qterm] */
+  const double* qterm_weight;     /* [n_qterm] */
 } opfx_env_desc;
 
 int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);

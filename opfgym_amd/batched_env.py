@@ -260,9 +260,14 @@ class BatchedOpfEnv:
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
                  defer_device=False, validate_actions=False, **kwargs):
-        if objective_function is not None or power_flow_solver is not None:
-            raise NotImplementedError('Python objective/solver callables cannot run inside the fused '
-                                      'GPU step; use the reference OpfEnv with opfgym_amd.power_flow_solver')
+        from .objectives import QuadraticDeviation
+        terms = objective_function if isinstance(objective_function, (list, tuple)) else \
+            ([objective_function] if objective_function is not None else [])
+        if power_flow_solver is not None or not all(isinstance(f, QuadraticDeviation) for f in terms):
+            raise NotImplementedError('Python objective/solver callables cannot run inside the fused GPU step; '
+                                      'use an opfgym_amd.objectives object, or the reference OpfEnv with '
+                                      'opfgym_amd.power_flow_solver')
+        self.objective_terms = list(terms)           # opf_env.py:80-84: replaces the pandapower cost tables
         self.bus_wise_obs = bool(bus_wise_obs)
         self.net = net
         self.device_spec = device
@@ -617,6 +622,8 @@ class BatchedOpfEnv:
                 return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc
             return capi.COST_UNIT, st.slot(et, 'p_mw') + pos, st.slot(et, 'q_mvar') + pos, sc
         poly, pwl = net['poly_cost'], net['pwl_cost']
+        if self.objective_terms:                   # objective_function replaces get_pandapower_costs (opf_env.py:80-84)
+            poly, pwl = poly.iloc[:0], pwl.iloc[:0]
         ck, cp, cq, cs, coef, is_q = [], [], [], [], [], []
         for _, row in poly.iterrows():
             k, pi, qi, sc = cost_source(row['et'], row['element'])
@@ -707,6 +714,26 @@ class BatchedOpfEnv:
         d.cont_branch = _keep(keep, cont, 'i')
         d.not_converged_penalty = float(self.not_converged_penalty)
         d.act_kind = _keep(keep, a_kind, 'i')
+        # per-instance voltage set-points: ext_grid.vm_pu / gen.vm_pu columns that the sampling writes
+        vset = np.full(nb, -1, dtype=np.int32)
+        for tbl in ('ext_grid', 'gen'):
+            if (tbl, 'vm_pu') in st.dynamic and len(net[tbl]):
+                s0 = st.slot(tbl, 'vm_pu')
+                for pos, b in enumerate(net[tbl]['bus'].to_numpy()):
+                    if int(b) in c.bus_lookup and vset[c.bus_lookup[int(b)]] < 0:
+                        vset[c.bus_lookup[int(b)]] = s0 + pos
+        if (vset >= 0).any():
+            d.vset_slot = _keep(keep, vset, 'i')
+        q_idx, q_tgt, q_w = [], [], []
+        for f in self.objective_terms:
+            idxs = net[f.unit].index if f.idxs is None else f.idxs
+            ridx = self._result_index(f.unit, f.column, idxs)
+            if (ridx < 0).any():
+                raise ValueError(f'objective term on res_{f.unit}.{f.column} touches a de-energised element')
+            q_idx += ridx.tolist(); q_tgt += [f.target] * len(ridx); q_w += [f.weight] * len(ridx)
+        d.n_qterm = len(q_idx)
+        if q_idx:
+            d.qterm_idx, d.qterm_target, d.qterm_weight = _keep(keep, q_idx, 'i'), _keep(keep, q_tgt, 'd'), _keep(keep, q_w, 'd')
         d.n_bmod = len(bmod)
         if bmod:
             ptr = np.cumsum([0] + [len(b['table']) for b in bmod])

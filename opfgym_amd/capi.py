@@ -88,7 +88,9 @@ class EnvDesc(C.Structure):
         ('n_cont', C.c_int32), ('cont_branch', _pi), ('not_converged_penalty', C.c_double),
         ('act_kind', _pi),
         ('n_bmod', C.c_int32), ('bmod_branch', _pi), ('bmod_slot', _pi), ('bmod_lo', _pi),
-        ('bmod_n', _pi), ('bmod_ptr', _pi), ('bmod_y', _pd)]
+        ('bmod_n', _pi), ('bmod_ptr', _pi), ('bmod_y', _pd),
+        ('vset_slot', _pi),
+        ('n_qterm', C.c_int32), ('qterm_idx', _pi), ('qterm_target', _pd), ('qterm_weight', _pd)]
 
 
 ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2

@@ -82,6 +82,10 @@ struct DevEnv {
   int n_bmod;                // branch state columns (taps, switches): see opfx_env_desc.bmod_*
   const int *act_kind, *bmod_branch, *bmod_src, *bmod_lo, *bmod_n, *bmod_ptr;
   const double* bmod_y;
+  const int* vset_src;       // [nb] source of a per-instance |V| set-point (NOSRC: compiled value), or nullptr
+  int n_qterm;               // quadratic objective terms on the result bank
+  const int* qterm_idx;
+  const double *qterm_target, *qterm_weight;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
   double penalty_factor, penalty_bias, valid_reward, invalid_penalty;
   double invalid_objective_share, diff_step, clipped_action_penalty;
@@ -1459,6 +1463,14 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true, n_mod_base); ++n_mod; }
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+        if (E.vset_src) for (int i = lane; i < nb; i += WAVE) {
+          // per-instance |V| set-point of a REF / PV bus (a sampled ext_grid.vm_pu)
+          const int src = as_global(E.vset_src)[i];
+          if (src == NOSRC) continue;
+          const double f = src_val(xr, L.sp, src) / P.vm_set[i];
+          L.vr[i] *= f; L.vi[i] *= f;
+          if (!V2) L.vm[i] *= f;
+        }
         if (c > 0) {
           // contingency cases start from the base-case solution (the reference restarts
           // pandapower from scratch for each one; the converged result is the same)
@@ -1554,6 +1566,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
           else { pw_ = src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r]; qv_ = r_qg[pi]; }
           csum += cost_row(E, xr, meta, as_global(E.cost_cbase)[r], pw_, qv_);
+        }
+        for (int k = lane; k < E.n_qterm; k += WAVE) {            // objective_function seam: w (result - target)^2
+          const double dv = R[as_global(E.qterm_idx)[k]] - as_global(E.qterm_target)[k];
+          csum += as_global(E.qterm_weight)[k] * dv * dv;
         }
         objective = -wave_sum_dpp(csum);                                                 // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
@@ -2084,6 +2100,24 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     std::vector<int32_t> kind(d->na, OPFX_ACT_CONTINUOUS);
     if (d->act_kind) kind.assign(d->act_kind, d->act_kind + d->na);
     if (rc == OPFX_OK) rc = A.put(kind, &E.act_kind);
+  }
+  E.vset_src = nullptr;
+  if (d->vset_slot) {
+    std::vector<int32_t> src(nb, NOSRC);
+    bool any = false;
+    for (int i = 0; i < nb; ++i) if (d->vset_slot[i] >= 0) {
+      if (d->vset_slot[i] >= d->nx) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: vset_slot out of range"); break; }
+      src[i] = src_of(d->vset_slot[i]); any = true;
+    }
+    if (any && rc == OPFX_OK) rc = A.put(src, &E.vset_src);
+  }
+  E.n_qterm = d->n_qterm;
+  if (d->n_qterm > 0) {
+    for (int k = 0; k < d->n_qterm; ++k)
+      if (d->qterm_idx[k] < 0 || d->qterm_idx[k] >= E.nres) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: qterm_idx out of range"); break; }
+    PUTN(qterm_idx, d->qterm_idx, d->n_qterm); PUTN(qterm_target, d->qterm_target, d->n_qterm);
+    PUTN(qterm_weight, d->qterm_weight, d->n_qterm);
+    for (int k = 0; k < d->n_qterm; ++k) if (d->qterm_idx[k] >= nb && d->qterm_idx[k] < 2 * nb) E.need_angle = 1;
   }
   if (d->n_bmod > 0) {
     size_t rows = 0;

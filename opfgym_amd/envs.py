@@ -367,6 +367,49 @@ class NetworkReconfiguration(BatchedOpfEnv):
         return net, profiles
 
 
+class MixedContinuousDiscrete(BatchedOpfEnv):
+    """examples/mixed_continuous_discrete.py:22-104: reactive power of all sgens (continuous) and the
+    transformer taps (discrete) as actuators, quadratic voltage deviation as objective, slack
+    voltage sampled per instance."""
+
+    def __init__(self, simbench_network_name='1-LV-urban6--0-sw', cos_phi=0.95, *args, **kwargs):
+        from .objectives import QuadraticDeviation
+        self.cos_phi = cos_phi                                                                   # :26
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        obs_keys = [('ext_grid', 'vm_pu', net.ext_grid.index), ('sgen', 'p_mw', net.sgen.index),  # :32-37
+                    ('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]
+        act_keys = [('sgen', 'q_mvar', net.sgen.index), ('trafo', 'tap_pos', net.trafo.index)]   # :40-41
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles,
+                         objective_function=QuadraticDeviation('bus', 'vm_pu', 1.0), *args, **kwargs)   # :17-19,44
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.trafo['controllable'] = True                                                        # :53-55
+        net.trafo['min_tap_pos'] = -2
+        net.trafo['max_tap_pos'] = 2
+        net.sgen['controllable'] = True                                                         # :58-64
+        net.sgen['max_s_mva'] = net.sgen['max_max_p_mw'] / self.cos_phi
+        net.sgen['max_max_q_mvar'] = (net.sgen['max_s_mva'] ** 2 - net.sgen['max_max_p_mw'] ** 2) ** 0.5
+        net.sgen['min_min_q_mvar'] = -net.sgen['max_max_q_mvar']
+        net.sgen['max_q_mvar'] = net.sgen['max_max_q_mvar']
+        net.sgen['min_q_mvar'] = -net.sgen['max_max_q_mvar']
+        for unit_type in ('load', 'gen', 'storage'):                                            # :67-68
+            net[unit_type]['controllable'] = False
+        net.ext_grid['min_vm_pu'] = 0.95                                                        # :71-72
+        net.ext_grid['max_vm_pu'] = 1.05
+        ppn.finalize(net)
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        net = self.net
+        eg = net.ext_grid                                                                       # :80-84
+        ops.uniform('ext_grid', 'vm_pu', eg.index, eg['min_vm_pu'].to_numpy(float), eg['max_vm_pu'].to_numpy(float))
+        sc = net.sgen.scaling.to_numpy(float)                                                   # :88-90
+        ops.affine('sgen', 'max_p_mw', 'p_mw', sc, 1e-9)
+        ops.affine('sgen', 'min_p_mw', 'p_mw', sc, -1e-9)
+
+
 class SecurityConstrainedVoltageControl(VoltageControl):
     """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
     of security_constrained.py (no such class in the reference; composed as

@@ -112,6 +112,14 @@ def tail_voltage_control(net, draws, market_based):
         df['q_mvar'] = 0.0
 
 
+def tail_mixed_continuous_discrete(net, draws):
+    """examples/mixed_continuous_discrete.py:99-110."""
+    sample_from_range(net, 'ext_grid', 'vm_pu', net.ext_grid.index, draws)
+    df = net['sgen']
+    df['max_p_mw'] = df.p_mw * df.scaling + 1e-9
+    df['min_p_mw'] = df.p_mw * df.scaling - 1e-9
+
+
 def tail_eco_dispatch(net, draws):
     """eco_dispatch.py:111-123."""
     sample_from_range(net, 'poly_cost', 'cp1_eur_per_mw', net.poly_cost.index, draws)
@@ -142,7 +150,8 @@ TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'QMarket': lambda net, d: tail_voltage_control(net, d, True),
          'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
          'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding,
-         'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None}
+         'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None,
+         'MixedContinuousDiscrete': tail_mixed_continuous_discrete}
 
 
 # ---------------------------------------------------------------------------
@@ -331,7 +340,8 @@ class EnvOracle:
                  diff_objective=False, add_mean_obs=False, pf_for_obs=False, steps_per_episode=1,
                  n_minus_one_keys=(), not_converged_penalty=1, enforce_q_lims=True,
                  data='simbench', state_keys=None, sampling_params=None, bus_wise_obs=False,
-                 multi_stage=False, split=None):
+                 multi_stage=False, split=None, objective=None):
+        self.objective_fn = objective            # `objective_function(net)` seam (opf_env.py:80-84)
         self.base_net = net
         self.net = copy.deepcopy(net)
         self.act_keys, self.obs_keys = act_keys, obs_keys
@@ -347,6 +357,9 @@ class EnvOracle:
         self.sampling_params = sampling_params or {}
         self.bus_wise_obs, self.multi_stage, self.split = bus_wise_obs, multi_stage, split
         self.initial_obj = 0.0
+
+    def costs(self):
+        return np.asarray(self.objective_fn(self.net), float) if self.objective_fn else cost_vector(self.net)
 
     def solve(self):
         try:
@@ -377,7 +390,7 @@ class EnvOracle:
         apply_actions(self.net, self.act_keys, act, self.autoscale, None)
         if self.pf_for_obs:                                                 # :209-216
             assert self.solve()
-            self.initial_obj = float(np.sum(-cost_vector(self.net)))
+            self.initial_obj = float(np.sum(-self.costs()))
         return observation(self.net, self.obs_keys, self.add_mean_obs, bus_wise_obs=self.bus_wise_obs)
 
     def violations(self):
@@ -390,7 +403,7 @@ class EnvOracle:
         corr = apply_actions(self.net, self.act_keys, action, self.autoscale, self.diff_step)
         if not self.solve():
             return dict(converged=False)
-        objective = float(np.sum(-cost_vector(self.net)))                   # :493-500, 517
+        objective = float(np.sum(-self.costs()))                            # :493-500, 517
         if self.diff_objective:
             objective -= self.initial_obj
         valids, viol, pen = self.violations()

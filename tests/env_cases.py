@@ -46,7 +46,8 @@ def oracle_env(name, env=None):
         steps_per_episode=env.steps_per_episode, n_minus_one_keys=env.n_minus_one_keys,
         not_converged_penalty=env.not_converged_penalty, data=env.train_data, state_keys=env.state_keys,
         sampling_params=env.sampling_params, bus_wise_obs=env.bus_wise_obs,
-        multi_stage=cls == 'MultiStageOpf', split=(env.test_steps, env.validation_steps, env.train_steps))
+        multi_stage=cls == 'MultiStageOpf', split=(env.test_steps, env.validation_steps, env.train_steps),
+        objective=(lambda net: np.concatenate([f(net) for f in env.objective_terms])) if env.objective_terms else None)
 
 
 def noise_factors(name, raw):

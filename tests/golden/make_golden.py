@@ -28,11 +28,13 @@ import opfgym.examples.security_constrained as ref_sc  # noqa: E402
 from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
+import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
        'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
-       'NetworkReconfiguration': ref_nr.NetworkReconfiguration}
+       'NetworkReconfiguration': ref_nr.NetworkReconfiguration,
+       'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete}
 
 
 def snapshot(net):

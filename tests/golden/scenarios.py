@@ -63,6 +63,9 @@ SCENARIOS.update({
     # (examples/network_reconfiguration.py; opf_env.py:476-481)
     'reconf_hv_small_sw': ('NetworkReconfiguration', dict(simbench_network_name='hv-small-sw',
                                                           controllable_switch_idxs=(1, 3)), 8, 21),
+    # continuous + discrete actuators, objective_function seam, per-instance slack voltage
+    # (examples/mixed_continuous_discrete.py)
+    'mixed_lv': ('MixedContinuousDiscrete', dict(simbench_network_name='1-LV-rural1--0-sw'), 8, 22),
 })
 
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
@@ -76,5 +79,5 @@ TRACKED = [('load', 'p_mw'), ('load', 'q_mvar'), ('sgen', 'p_mw'), ('sgen', 'q_m
            ('sgen', 'max_p_mw'), ('sgen', 'min_p_mw'), ('sgen', 'max_q_mvar'), ('sgen', 'min_q_mvar'),
            ('storage', 'max_q_mvar'), ('storage', 'min_q_mvar'),
            ('poly_cost', 'cq2_eur_per_mvar2'), ('poly_cost', 'cp1_eur_per_mw'),
-           ('pwl_cost', 'cp1_eur_per_mw'), ('load', 'max_p_mw')]
+           ('pwl_cost', 'cp1_eur_per_mw'), ('load', 'max_p_mw'), ('ext_grid', 'vm_pu')]
 # (switch states / tap positions are not snapshotted: they are outputs of the step, see 'tab_after__*')

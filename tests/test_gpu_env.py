@@ -90,7 +90,8 @@ def test_env_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize('name,B', [('vc_mv_small', 48), ('qm_mv_small', 32), ('eco_hv_small', 24),
-                                    ('sc_hv_small', 12), ('vc_resobs_diff', 16), ('reconf_hv_small_sw', 32)])
+                                    ('sc_hv_small', 12), ('vc_resobs_diff', 16), ('reconf_hv_small_sw', 32),
+                                    ('mixed_lv', 32)])
 def test_env_matches_oracle_random_batch(name, B):
     env = product_env(name, batch_size=B)
     orc = oracle_env(name, product_env(name, defer_device=True))
