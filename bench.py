@@ -39,9 +39,17 @@ def byte_model(env, mean_it):
     nnz_lu = 4 * info['n_blk']
     per_it = 8 * (2 * info['nnz_j'] + 2 * nnz_lu + 4 * n_j + 4 * info['nb'])
     b_step = 8 * (n_in + n_out) + mean_it * per_it
+    # FP64 operation count of the same step (for the "what actually bounds it" report):
+    # per NR iteration  A: 24 per off-diagonal Ybus entry + 40 per bus,  B: 46 per update term,
+    # C: 8 per U-term + 20 per pivot,  D: 40 per bus;  one more phase A for the final check.
+    nnz_off = info['nnz_y'] - info['nb']
+    n_piv = info['nb'] - info['nref']
+    a_flops = 24 * nnz_off + 40 * info['nb']
+    flops_it = a_flops + 46 * info['n_sources'] + 8 * info['n_uterms'] + 20 * n_piv + 40 * info['nb']
+    flops = mean_it * flops_it + a_flops + 10 * info['nbr'] * 4 + 30 * info['nb']
     return dict(nb=info['nb'], nbr=info['nbr'], nJ=n_j, nnzJ=info['nnz_j'], nnzLU=nnz_lu,
                 n_in=n_in, n_out=n_out, it=mean_it, io_bytes=8 * (n_in + n_out),
-                bytes_per_iteration=per_it, B_step=b_step)
+                bytes_per_iteration=per_it, B_step=b_step, fp64_flops_per_step=flops)
 
 
 def cpu_baseline(budget_s=15.0):
@@ -159,9 +167,12 @@ def main():
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
                          'algorithmic_bytes_per_launch': bm['B_step'] * B,
                          'kernel': 'k_step', 'kernel_ms': kernel_ms,
+                         'fp64_tflops_achieved': bm['fp64_flops_per_step'] * B / (kernel_ms * 1e-3) / 1e12,
+                         'fp64_vector_peak_tflops': 78.6,
                          'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory '
                                  'once per NR phase) x 8192 / kernel time; the kernel keeps that state in LDS, '
-                                 'so real HBM traffic is ~ io_bytes per instance (see DESIGN.md)'},
+                                 'so real HBM traffic is ~ io_bytes per instance; the kernel is bound by '
+                                 'instruction issue (profiles/*_sq_counters.txt), see DESIGN.md'},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
