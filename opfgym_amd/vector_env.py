@@ -30,8 +30,9 @@ class OpfVectorEnv:
       'next_step' — the reset happens in the NEXT `step()` call, whose action is ignored for
           those rows (reward 0, not terminated).
       'disabled' — the caller resets.
-    Observations, rewards and flags are torch tensors on the environment's device
-    (`as_numpy=True` copies them to the host).
+    Observations, rewards and flags are torch tensors on the environment's device, views of its
+    persistent output buffers: valid until the next reset/step call (`as_numpy=True` copies them to
+    the host instead).
     """
 
     def __init__(self, env, autoreset_mode='same_step', as_numpy=False):
@@ -100,8 +101,20 @@ class OpfVectorEnv:
             return self._out(obs), self._out(reward), self._out(term), self._out(trunc), \
                 {k: self._out(v) for k, v in info.items()}
         obs, reward, term, trunc, info = env.step(actions)
-        done = term.bool() | trunc.bool()
         info = dict(info)
+        if self.autoreset_mode == 'same_step' and env.steps_per_episode == 1:
+            # single-step episodes: every row ends on every step (opf_env.py:406-414) — no flag
+            # inspection (a host sync) and no masking; only the observation buffer is reused by reset
+            final_obs = obs.clone()
+            if env.pf_for_obs:      # that reset runs a power flow through the same output buffers (opf_env.py:209-216)
+                reward, term, trunc = reward.clone(), term.clone(), trunc.clone()
+                info = {k: (v.clone() if hasattr(v, 'clone') else v) for k, v in info.items()}
+            obs = env.reset()[0]
+            info['final_obs'] = self._out(final_obs)
+            info['_final_obs'] = self._out(term)
+            return self._out(obs), self._out(reward), self._out(term), self._out(trunc), \
+                {k: self._out(v) for k, v in info.items()}
+        done = term.bool() | trunc.bool()
         if self.autoreset_mode == 'same_step' and bool(done.any()):
             final_obs = obs.clone()
             reward, term, trunc = reward.clone(), term.clone(), trunc.clone()

@@ -277,7 +277,8 @@ def test_vector_env_same_step_autoreset():
     assert not np.allclose(_np(obs), _np(info['final_obs']))          # new episode: new sampled state
     assert not np.allclose(_np(vec.env.x), _np(x0))
     assert np.isfinite(_np(reward)).all() and np.isfinite(_np(obs)).all()
-    # the returned observation is the one a plain reset would give for the state now in the store
+    # (returned tensors are views of the environment's persistent buffers: valid until the next call)
+    obs = obs.clone()
     obs2, reward2, *_ = vec.step(a)
     assert np.isfinite(_np(reward2)).all() and not np.allclose(_np(obs2), _np(obs))
 
