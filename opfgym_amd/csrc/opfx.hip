@@ -62,7 +62,6 @@ struct DevPlan {
   const double *vm_set, *va_set, *vr0, *vi0, *y_g, *y_b, *br_y, *br_kf, *br_kt;
   // lane programme (plan.h)
   int ra, rh, rb, rc;
-  int debug_skip;            // developer probe (OPFX_DEBUG_SKIP): bit mask of phases to skip
   unsigned long long* stamps; // developer probe (OPFX_STAMPS): per-phase cycle sums of workgroup 0
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
   const int* lp_hrows;
@@ -156,11 +155,6 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = nan_max(v, __shfl_xor(v, o, WAVE));
   return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
-}
 
 // ---- DPP wave reductions (no LDS traffic): quad xor-1, xor-2, half-row mirror, row
 // mirror give every lane its 16-lane row total; row_bcast:15 / row_bcast:31 fold the
@@ -194,11 +188,6 @@ __device__ __forceinline__ double wave_max_dpp(double v) {   // NaN-propagating;
   v = nn_max(v, dpp_f64<0x142, 0xA>(v, v));
   v = nn_max(v, dpp_f64<0x143, 0xC>(v, v));
   return read_lane63(v);
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
 }
 __device__ __forceinline__ int wave_any(int pred) { return __any(pred); }
 
@@ -1876,7 +1865,6 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   d.nfull = p->n_full;
   d.fill_lo = p->n_full - (int)p->fill_blk.size();
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc
-  d.debug_skip = getenv("OPFX_DEBUG_SKIP") ? atoi(getenv("OPFX_DEBUG_SKIP")) : 0;
   d.stamps = nullptr;
   if (getenv("OPFX_STAMPS")) {
     void* st = nullptr;
