@@ -410,6 +410,99 @@ class MixedContinuousDiscrete(BatchedOpfEnv):
         ops.affine('sgen', 'min_p_mw', 'p_mw', sc, -1e-9)
 
 
+class ConstraintSatisfaction(BatchedOpfEnv):
+    """examples/pure_constraint_satisfaction.py:8-53: no objective at all; sgen active power must
+    keep the slack import, a tight voltage band and the line loadings within bounds."""
+
+    def __init__(self, **kwargs):
+        net, profiles = self._define_opf(**{k: kwargs[k] for k in ('grid_seed',) if k in kwargs})
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]       # :15-18
+        act_keys = [('sgen', 'p_mw', net.sgen.index)]                                           # :21
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, **kwargs)
+
+    def _define_opf(self, **kwargs):
+        net, profiles = build_simbench_net('1-LV-rural1--0-sw', **kwargs)                         # :26
+        net.sgen['controllable'] = True                                                         # :28-32
+        net.sgen['min_p_mw'] = 0
+        net.sgen['max_p_mw'] = net.sgen['max_max_p_mw']
+        net.sgen['min_q_mvar'] = 0
+        net.sgen['max_q_mvar'] = 0
+        for unit_type in ('load', 'gen', 'storage'):                                            # :35-36
+            net[unit_type]['controllable'] = False
+        net.ext_grid['max_p_mw'] = 1                                                            # :39-42
+        net.bus['max_vm_pu'] = 1.02
+        net.bus['min_vm_pu'] = 0.98
+        net.line['max_loading_percent'] = 60
+        ppn.finalize(net)
+        return net, profiles
+
+
+class PartiallyObservable(BatchedOpfEnv):
+    """examples/partial_obs.py:13-65: only some loads are observed; the state keys (what is sampled)
+    still cover all of them."""
+
+    def __init__(self, simbench_network_name='1-LV-rural1--0-sw', observable_loads=np.arange(10),
+                 *args, **kwargs):
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        if isinstance(observable_loads, str) and observable_loads == 'all':                      # :21-22
+            observable_loads = net.load.index
+        obs_keys = [('load', 'p_mw', observable_loads), ('load', 'q_mvar', observable_loads)]    # :26-29
+        state_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]      # :33-36
+        act_keys = [('sgen', 'p_mw', net.sgen.index)]                                           # :39
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, state_keys=state_keys, profiles=profiles, *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.sgen['controllable'] = True                                                         # :48-52
+        net.sgen['min_p_mw'] = 0
+        net.sgen['max_p_mw'] = net.sgen['max_max_p_mw']
+        net.sgen['min_q_mvar'] = 0
+        net.sgen['max_q_mvar'] = 0
+        for unit_type in ('load', 'gen', 'storage'):                                            # :55-56
+            net[unit_type]['controllable'] = False
+        for idx in net.ext_grid.index:                                                          # :59-60
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=1)
+        ppn.finalize(net)
+        return net, profiles
+
+
+class NonSimbenchNet(BatchedOpfEnv):
+    """examples/non_simbench_net.py:13-67: a pandapower OPF case without time series: generator
+    active power as actions, load states drawn from a normal distribution around the case values
+    (`std_dev_*` columns).  The reference loads `pp.networks.case_ieee30()`; that data set is not
+    available offline, so the default here is the OPF-ready 9-bus case (`net=` takes any other)."""
+
+    def __init__(self, train_data='normal_around_mean', test_data='normal_around_mean', net=None,
+                 *args, **kwargs):
+        assert 'simbench' not in train_data and 'simbench' not in test_data                     # :18
+        net = self._define_opf(net)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]       # :24-27
+        act_keys = [('gen', 'p_mw', net.gen.index)]                                             # :30
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, train_data=train_data, test_data=test_data, *args, **kwargs)
+
+    def _define_opf(self, net=None):
+        from . import grids
+        net = net if net is not None else grids.case9_opf()                                      # :38
+        net.gen['min_q_mvar'] = 0                                                               # :41-42
+        net.gen['max_q_mvar'] = 0
+        rng_ = 0.3                                                                              # :45-50
+        net.load['min_min_p_mw'] = net.load['p_mw'] * (1 - rng_)
+        net.load['max_max_p_mw'] = net.load['p_mw'] * (1 + rng_)
+        net.load['min_min_q_mvar'] = net.load['q_mvar'] * (1 - rng_)
+        net.load['max_max_q_mvar'] = net.load['q_mvar'] * (1 + rng_)
+        net.load['mean_p_mw'] = net.load['p_mw']                                                # :53-56
+        net.load['std_dev_p_mw'] = rng_ * net.load['p_mw']
+        net.load['mean_q_mvar'] = net.load['q_mvar']
+        net.load['std_dev_q_mvar'] = rng_ * net.load['q_mvar']
+        net.ext_grid['mean_p_mw'] = net.load['mean_p_mw'].sum() - net.gen['p_mw'].sum()         # :59-60
+        net.ext_grid['mean_q_mvar'] = net.load['mean_q_mvar'].sum() - (net.gen['max_q_mvar'] - net.gen['max_q_mvar']).sum()
+        ppn.finalize(net)
+        return net
+
+
 class SecurityConstrainedVoltageControl(VoltageControl):
     """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
     of security_constrained.py (no such class in the reference; composed as

@@ -76,6 +76,24 @@ def case9() -> Net:
     return ppn.finalize(net)
 
 
+def case9_opf() -> Net:
+    """case9 with what a pandapower OPF case carries: generator active-power ranges and quadratic
+    generation costs (MATPOWER case9 gencost).  Stand-in for `pp.networks.case_ieee30()` of
+    examples/non_simbench_net.py (the IEEE 30-bus data is not available offline)."""
+    net = case9()
+    net.gen['min_p_mw'] = [10.0, 10.0]
+    net.gen['max_p_mw'] = [300.0, 270.0]
+    net.gen['min_min_p_mw'] = net.gen['min_p_mw']
+    net.gen['max_max_p_mw'] = net.gen['max_p_mw']
+    net.gen['controllable'] = True
+    net.ext_grid['min_p_mw'] = 10.0
+    net.ext_grid['max_p_mw'] = 250.0
+    for et, el, c2, c1, c0 in (('ext_grid', 0, 0.11, 5.0, 150.0), ('gen', 0, 0.085, 1.2, 600.0),
+                               ('gen', 1, 0.1225, 1.0, 335.0)):
+        ppn.create_poly_cost(net, el, et, cp1_eur_per_mw=c1, cp2_eur_per_mw2=c2, cp0_eur=c0)
+    return ppn.finalize(net)
+
+
 # Published load-flow result of the WSCC 3-machine 9-bus system (Anderson &
 # Fouad, "Power System Control and Stability", fig. 2.19; the same numbers the
 # survey quotes in SURVEY.md §8c), re-indexed to the bus numbering used above:

@@ -5,7 +5,7 @@ from opfgym_amd import net as _ppn
 from opfgym_amd.net import Net as pandapowerNet  # noqa: F401
 from oracle import pf_oracle as _po
 
-from . import powerflow, optimal_powerflow  # noqa: F401
+from . import powerflow, optimal_powerflow, networks  # noqa: F401
 
 
 def runpp(net, enforce_q_lims=False, **kwargs):

@@ -29,12 +29,17 @@ from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # 
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
 import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
+import opfgym.examples.pure_constraint_satisfaction as ref_cs  # noqa: E402
+import opfgym.examples.partial_obs as ref_po  # noqa: E402
+import opfgym.examples.non_simbench_net as ref_ns  # noqa: E402
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
        'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
        'NetworkReconfiguration': ref_nr.NetworkReconfiguration,
-       'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete}
+       'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete,
+       'ConstraintSatisfaction': ref_cs.ConstraintSatisfaction, 'PartiallyObservable': ref_po.PartiallyObservable,
+       'NonSimbenchNet': ref_ns.NonSimbenchNet}
 
 
 def snapshot(net):

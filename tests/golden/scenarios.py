@@ -66,6 +66,10 @@ SCENARIOS.update({
     # continuous + discrete actuators, objective_function seam, per-instance slack voltage
     # (examples/mixed_continuous_discrete.py)
     'mixed_lv': ('MixedContinuousDiscrete', dict(simbench_network_name='1-LV-rural1--0-sw'), 8, 22),
+    # the remaining example environments of the reference (examples/*.py)
+    'constraint_sat_lv': ('ConstraintSatisfaction', dict(), 5, 23),
+    'partial_obs_lv': ('PartiallyObservable', dict(simbench_network_name='1-LV-rural1--0-sw'), 4, 24),
+    'nonsimbench_case9': ('NonSimbenchNet', dict(), 5, 25),
 })
 
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
