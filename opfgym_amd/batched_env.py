@@ -520,12 +520,31 @@ class BatchedOpfEnv:
             for pos in self.store.rows(unit, idxs):
                 bus = int(self.net.ext_grid['bus'].iloc[pos])
                 out.append(off + ordinal[c.bus_lookup[bus]] if bus in c.bus_lookup else -1)
+        elif unit in ('sgen', 'load', 'storage', 'gen') and col in ('p_mw', 'q_mvar', 's_mva'):
+            # res_<unit> echoes of the set-points (= table value x scaling) and their apparent power:
+            # derived rows behind the solver's result bank (opfx_env_desc.xres_*), allocated on demand
+            if unit == 'gen' and col != 'p_mw':
+                raise NotImplementedError('res_gen.q_mvar per generator is not in the device result bank')
+            df = self.net[unit]
+            base = 3 * nb + nbr + 2 * nref
+            p0 = self.store.slot(unit, 'p_mw')
+            q0 = self.store.slot(unit, 'q_mvar') if unit != 'gen' else None
+            for pos in self.store.rows(unit, idxs):
+                key = (unit, col, int(pos))
+                if key not in self._xres:
+                    sc = float(df['scaling'].iloc[pos]) if 'scaling' in df.columns else 1.0
+                    kind = capi.XRES_S if col == 's_mva' else capi.XRES_P
+                    psl = (q0 if col == 'q_mvar' else p0) + int(pos)
+                    qsl = q0 + int(pos) if col == 's_mva' else -1
+                    self._xres[key] = (len(self._xres), kind, psl, qsl, sc)
+                out.append(base + self._xres[key][0])
         else:
             raise NotImplementedError(f'result column res_{unit}.{col} is not in the device result bank')
         return np.array(out, dtype=np.int64)
 
     def _create_env(self):
         net, c, st = self.net, self.case, self.store
+        self._xres = {}
         nb, base = c.nb, c.base_mva
         keep = []
         d = capi.EnvDesc()
@@ -732,6 +751,11 @@ class BatchedOpfEnv:
                 raise ValueError(f'objective term on res_{f.unit}.{f.column} touches a de-energised element')
             q_idx += ridx.tolist(); q_tgt += [f.target] * len(ridx); q_w += [f.weight] * len(ridx)
         d.n_qterm = len(q_idx)
+        xr_ = sorted(self._xres.values())
+        d.n_xres = len(xr_)
+        if xr_:
+            d.xres_kind, d.xres_p = _keep(keep, [v[1] for v in xr_], 'i'), _keep(keep, [v[2] for v in xr_], 'i')
+            d.xres_q, d.xres_scale = _keep(keep, [v[3] for v in xr_], 'i'), _keep(keep, [v[4] for v in xr_], 'd')
         if q_idx:
             d.qterm_idx, d.qterm_target, d.qterm_weight = _keep(keep, q_idx, 'i'), _keep(keep, q_tgt, 'd'), _keep(keep, q_w, 'd')
         d.n_bmod = len(bmod)
@@ -752,7 +776,7 @@ class BatchedOpfEnv:
         self._env_handle = h
         self.n_obs_raw = len(oidx)
         self.n_constraints = len(self.constraints)
-        self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses)
+        self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses) + len(self._xres)
         t = self.torch
         as_i = lambda v: t.as_tensor(np.asarray(v, dtype=np.int64), device=self.device)
         as_d = lambda v: t.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)

@@ -14,17 +14,33 @@ import numpy as np
 import pandas as pd
 
 
+class ApparentPower:
+    """`get_values` of a custom constraint that the fused evaluator understands: apparent power
+    sqrt(P^2 + Q^2) of res_<unit> (examples/custom_constraint.py:9-11).  Also a plain callable with
+    the reference's signature, so the same object works in the reference's `Constraint`."""
+
+    def __init__(self, unit_type: str = 'sgen'):
+        self.unit_type = unit_type
+
+    def __call__(self, net):
+        res = net['res_' + self.unit_type]
+        return (res.p_mw ** 2 + res.q_mvar ** 2) ** 0.5
+
+
 class Constraint:
     def __init__(self, unit_type: str, values_column: str, get_values=None, get_boundaries=None,
                  only_worst_case_violations: bool = False, autoscale_violation=True,
                  scale_bounded_values: bool = False, penalty_factor: float = 1.0,
                  penalty_power: float = 1.0, violation_count_penalty: float = 0.0):
-        if get_values is not None or get_boundaries is not None:
+        if get_values is not None and not isinstance(get_values, ApparentPower):
             raise NotImplementedError(
-                'Python callables cannot be evaluated by the fused GPU evaluator; '
-                'use the table/column form of Constraint')
+                'Python value callables cannot be evaluated by the fused GPU evaluator; '
+                'use the table/column form of Constraint or opfgym_amd.constraints.ApparentPower')
+        # constraints.py:62-65; a boundary callable is evaluated ONCE, when the environment is compiled
+        # (boundaries that change per reset belong into min_/max_ table columns)
+        self.get_values, self.get_boundaries_fn = get_values, get_boundaries
         self.unit_type = unit_type
-        self.values_column = values_column
+        self.values_column = 's_mva' if isinstance(get_values, ApparentPower) else values_column
         self.only_worst_case_violations = only_worst_case_violations
         self.autoscale_violation = autoscale_violation
         self.scale_bounded_values = scale_bounded_values
@@ -42,6 +58,9 @@ class Constraint:
         """constraints.py:93-108: (min, max) arrays aligned with net[unit_type]
         rows, NaN where the boundary column is absent; p/q bounds × scaling."""
         tbl = net[self.unit_type]
+        if self.get_boundaries_fn is not None:
+            b = self.get_boundaries_fn(net)
+            return tuple(np.asarray(b[w], dtype=float) if w in b else np.full(len(tbl), np.nan) for w in ('min', 'max'))
         out = []
         for which in ('min', 'max'):
             col = f'{which}_{self.values_column}'

@@ -83,6 +83,9 @@ struct DevEnv {
   const double* bmod_y;
   const int* vset_src;       // [nb] source of a per-instance |V| set-point (NOSRC: compiled value), or nullptr
   int n_qterm;               // quadratic objective terms on the result bank
+  int n_xres, nres_base;     // derived result rows [nres_base, nres_base + n_xres)
+  const int *xres_kind, *xres_p, *xres_q;
+  const double* xres_scale;
   const int* qterm_idx;
   const double *qterm_target, *qterm_weight;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
@@ -1492,6 +1495,13 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       double* R = L.blk;
       if (wave == 0) {
       compute_results<V2>(P, L, lane, out_br, n_mod, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
+      for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
+        const double sc = as_global(E.xres_scale)[k];
+        const double pv_ = src_val(xr, L.sp, as_global(E.xres_p)[k]) * sc;
+        double v = pv_;
+        if (as_global(E.xres_kind)[k] == OPFX_XRES_S) { const double qv = src_val(xr, L.sp, as_global(E.xres_q)[k]) * sc; v = sqrt(pv_ * pv_ + qv * qv); }
+        R[E.nres_base + k] = v;
+      }
       sec_sync<NW>();
       OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
@@ -1947,7 +1957,9 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   DevEnv& E = e->de;
   E.nx = d->nx; E.na = d->na; E.npoly = d->npoly; E.npwl = d->npwl; E.nseg = d->nseg;
   E.nc = d->nc; E.nobs = d->nobs; E.ncost = d->npoly + d->npwl;
-  E.nres = 3 * nb + p.nbr + 2 * p.nref;
+  E.nres_base = 3 * nb + p.nbr + 2 * p.nref;
+  E.n_xres = d->n_xres;
+  E.nres = E.nres_base + d->n_xres;
   E.reward_kind = d->reward_kind; E.diff_objective = d->diff_objective;
   E.steps_per_episode = d->steps_per_episode; E.clamp_enabled = d->clamp_enabled;
   E.penalty_weight = d->penalty_weight; E.clip_lo = d->clip_lo; E.clip_hi = d->clip_hi;
@@ -2098,6 +2110,16 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
       src[i] = src_of(d->vset_slot[i]); any = true;
     }
     if (any && rc == OPFX_OK) rc = A.put(src, &E.vset_src);
+  }
+  if (d->n_xres > 0) {
+    std::vector<int32_t> ps(d->n_xres), qs(d->n_xres);
+    for (int k = 0; k < d->n_xres; ++k) {
+      if (d->xres_p[k] < 0 || d->xres_p[k] >= d->nx || d->xres_q[k] >= d->nx) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: xres column out of range"); break; }
+      ps[k] = src_of(d->xres_p[k]); qs[k] = src_of(d->xres_q[k]);
+    }
+    PUTN(xres_kind, d->xres_kind, d->n_xres); PUTN(xres_scale, d->xres_scale, d->n_xres);
+    if (rc == OPFX_OK) rc = A.put(ps, &E.xres_p);
+    if (rc == OPFX_OK) rc = A.put(qs, &E.xres_q);
   }
   E.n_qterm = d->n_qterm;
   if (d->n_qterm > 0) {

@@ -503,6 +503,47 @@ class NonSimbenchNet(BatchedOpfEnv):
         return net
 
 
+class AddCustomConstraint(BatchedOpfEnv):
+    """examples/custom_constraint.py:19-74: sgen reactive power as actions, the default constraints
+    plus an apparent-power limit per sgen.  (The reference example hands its list over as
+    `constraints=...`, a keyword `OpfEnv.__init__` swallows, so its custom constraint is never active;
+    here it goes to `custom_constraints`, as the example intends.)"""
+
+    def __init__(self, simbench_network_name='1-LV-urban6--0-sw', cos_phi=0.95, constraint_kwargs=None,
+                 *args, **kwargs):
+        from . import constraints as cons
+        self.cos_phi = cos_phi
+        net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]       # :27-30
+        act_keys = [('sgen', 'q_mvar', net.sgen.index)]                                         # :32
+        constraint_kwargs = constraint_kwargs or {}
+        constraints_list = cons.create_default_constraints(net, constraint_kwargs)               # :35-37
+        constraints_list.append(cons.Constraint(                                                # :40-45
+            'sgen', 's_mva', get_values=cons.ApparentPower('sgen'),
+            get_boundaries=lambda net_: {'max': net_.sgen.max_max_p_mw / 0.95}, **constraint_kwargs))
+        kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, custom_constraints=constraints_list,
+                         *args, **kwargs)
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net.sgen['controllable'] = True                                                         # :57-59
+        net.sgen['min_q_mvar'] = -0.3
+        net.sgen['max_q_mvar'] = 0.3
+        net.sgen['max_s_mva'] = net.sgen['max_max_p_mw'] / self.cos_phi                          # :62
+        for unit_type in ('load', 'gen', 'storage'):                                            # :65-66
+            net[unit_type]['controllable'] = False
+        for idx in net.ext_grid.index:                                                          # :68-69
+            ppn.create_poly_cost(net, idx, 'ext_grid', cp1_eur_per_mw=1)
+        ppn.finalize(net)
+        return net, profiles
+
+    def _sampling_ops(self, ops: OpsBuilder) -> None:
+        sc = self.net.sgen.scaling.to_numpy(float)                                              # :79-80
+        ops.affine('sgen', 'max_p_mw', 'p_mw', sc, 1e-9)
+        ops.affine('sgen', 'min_p_mw', 'p_mw', sc, -1e-9)
+
+
 class SecurityConstrainedVoltageControl(VoltageControl):
     """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
     of security_constrained.py (no such class in the reference; composed as

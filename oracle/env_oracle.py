@@ -120,6 +120,13 @@ def tail_mixed_continuous_discrete(net, draws):
     df['min_p_mw'] = df.p_mw * df.scaling - 1e-9
 
 
+def tail_custom_constraint(net, draws):
+    """examples/custom_constraint.py:74-80."""
+    df = net['sgen']
+    df['max_p_mw'] = df.p_mw * df.scaling + 1e-9
+    df['min_p_mw'] = df.p_mw * df.scaling - 1e-9
+
+
 def tail_eco_dispatch(net, draws):
     """eco_dispatch.py:111-123."""
     sample_from_range(net, 'poly_cost', 'cp1_eur_per_mw', net.poly_cost.index, draws)
@@ -153,7 +160,7 @@ TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None,
          'MixedContinuousDiscrete': tail_mixed_continuous_discrete,
          'ConstraintSatisfaction': lambda net, d: None, 'PartiallyObservable': lambda net, d: None,
-         'NonSimbenchNet': lambda net, d: None}
+         'NonSimbenchNet': lambda net, d: None, 'AddCustomConstraint': tail_custom_constraint}
 
 
 # ---------------------------------------------------------------------------
@@ -257,16 +264,25 @@ def violation_metrics(net, con):
     """`con`: any object with the reference Constraint's attributes
     (unit_type, values_column, only_worst_case_violations, autoscale_violation,
     scale_bounded_values, penalty_factor, penalty_power, violation_count_penalty)."""
-    values = net['res_' + con.unit_type][con.values_column].to_numpy(float)
+    get_values = getattr(con, 'get_values', None)                           # constraints.py:62-63
+    values = np.asarray(get_values(net), float) if get_values is not None else \
+        net['res_' + con.unit_type][con.values_column].to_numpy(float)
     tbl = net[con.unit_type]
     violation, n_viol = 0.0, 0
+    custom_bounds = getattr(con, 'get_boundaries_fn', None)                 # constraints.py:64-65
+    custom_bounds = custom_bounds(net) if custom_bounds is not None else None
     for which in ('min', 'max'):                                            # :93-98
         col = f'{which}_{con.values_column}'
-        if col not in tbl:
-            continue
-        bound = tbl[col].to_numpy(float)
-        if con.scale_bounded_values or ('scaling' in tbl and con.values_column in ('p_mw', 'q_mvar')):
-            bound = bound * tbl['scaling'].to_numpy(float)                  # :104-108
+        if custom_bounds is not None:
+            if which not in custom_bounds:
+                continue
+            bound = np.asarray(custom_bounds[which], float)
+        else:
+            if col not in tbl:
+                continue
+            bound = tbl[col].to_numpy(float)
+            if con.scale_bounded_values or ('scaling' in tbl and con.values_column in ('p_mw', 'q_mvar')):
+                bound = bound * tbl['scaling'].to_numpy(float)              # :104-108
         invalid = values > bound if which == 'max' else values < bound      # :110-111
         n_viol += int(invalid.sum())
         if invalid.any():                                                   # :113-122

@@ -32,6 +32,32 @@ import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
 import opfgym.examples.pure_constraint_satisfaction as ref_cs  # noqa: E402
 import opfgym.examples.partial_obs as ref_po  # noqa: E402
 import opfgym.examples.non_simbench_net as ref_ns  # noqa: E402
+import opfgym.examples.custom_constraint as ref_cc  # noqa: E402
+import opfgym.constraints as ref_constraints  # noqa: E402
+import opfgym.opf_env as ref_opf_env  # noqa: E402
+
+
+class RefAddCustomConstraint(ref_opf_env.OpfEnv):
+    """examples/custom_constraint.py with its constraint list handed to the parameter OpfEnv
+    actually reads (`custom_constraints`; the example's `constraints=` keyword is swallowed): the
+    reference's own Constraint class with the example's value/boundary callables."""
+
+    def __init__(self, simbench_network_name, cos_phi=0.95, **kwargs):
+        self.cos_phi = cos_phi
+        net, profiles = ref_cc.AddCustomConstraint._define_opf(self, simbench_network_name)
+        obs_keys = [('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]
+        act_keys = [('sgen', 'q_mvar', net.sgen.index)]
+        cl = ref_constraints.create_default_constraints(net, {})
+        cl.append(ref_constraints.Constraint('sgen', 's_mva', get_values=ref_cc.get_s_mva_values,
+                                             get_boundaries=ref_cc.get_s_mva_boundaries))
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, optimal_power_flow_solver=False,
+                         custom_constraints=cl, **kwargs)
+
+    def _sampling(self, *args, **kwargs):            # examples/custom_constraint.py:74-80
+        super()._sampling(*args, **kwargs)
+        self.net.sgen['max_p_mw'] = self.net.sgen.p_mw * self.net.sgen.scaling + 1e-9
+        self.net.sgen['min_p_mw'] = self.net.sgen.p_mw * self.net.sgen.scaling - 1e-9
+
 
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
@@ -39,7 +65,7 @@ REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMar
        'NetworkReconfiguration': ref_nr.NetworkReconfiguration,
        'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete,
        'ConstraintSatisfaction': ref_cs.ConstraintSatisfaction, 'PartiallyObservable': ref_po.PartiallyObservable,
-       'NonSimbenchNet': ref_ns.NonSimbenchNet}
+       'NonSimbenchNet': ref_ns.NonSimbenchNet, 'AddCustomConstraint': RefAddCustomConstraint}
 
 
 def snapshot(net):

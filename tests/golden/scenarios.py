@@ -70,6 +70,8 @@ SCENARIOS.update({
     'constraint_sat_lv': ('ConstraintSatisfaction', dict(), 5, 23),
     'partial_obs_lv': ('PartiallyObservable', dict(simbench_network_name='1-LV-rural1--0-sw'), 4, 24),
     'nonsimbench_case9': ('NonSimbenchNet', dict(), 5, 25),
+    # custom constraint with value/boundary callables (examples/custom_constraint.py, constraints.py:62-65)
+    'custom_constraint_lv': ('AddCustomConstraint', dict(simbench_network_name='1-LV-rural1--0-sw'), 6, 26),
 })
 
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
