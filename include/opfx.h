@@ -370,6 +370,10 @@ typedef struct opfx_reset_desc {
   int32_t init_off;          /* offset into consts of an nx-long row template copied
                                 into x before the tables are applied, or -1  */
   int32_t n_normal;          /* standard-normal draws consumed per instance  */
+  /* `train_data='mixed'` (opf_env.py:242-251): every reset draws ONE of the data sources per
+   * instance.  op_mode[k] is the set of sources (bit 0 SimBench profiles, bit 1 uniform, bit 2
+   * normal) under which op k runs; NULL = every op always.  The profile tables apply under source 0. */
+  const int32_t* op_mode;    /* [n_ops] or NULL */
 } opfx_reset_desc;
 
 int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d);
@@ -393,6 +397,7 @@ typedef struct opfx_reset_io {
   const double* normal;
   double normal_noise_factor;
   double* x;
+  const int32_t* mode;       /* [B] data source per instance (0, 1, 2) or NULL = no source selection */
 } opfx_reset_io;
 
 int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);

@@ -82,6 +82,7 @@ class OpsBuilder:
         self.ops = []          # (code, dst, a, n, c0, c1, c2) with c* numpy vectors or None
         self.n_uniform = 0
         self.n_normal = 0
+        self.mode_mask = 7     # data sources under which the ops added next run ('mixed' sampling)
 
     def _emit(self, code, dst, a, c0=None, c1=None, c2=None):
         """dst/a: arrays of slots; split into runs where both are contiguous."""
@@ -96,7 +97,8 @@ class OpsBuilder:
             self.ops.append((code, int(dst[s]), int(a[s]), int(e - s),
                              None if c0 is None else np.broadcast_to(np.asarray(c0, float), (n,))[sl].copy(),
                              None if c1 is None else np.broadcast_to(np.asarray(c1, float), (n,))[sl].copy(),
-                             None if c2 is None else np.broadcast_to(np.asarray(c2, float), (n,))[sl].copy()))
+                             None if c2 is None else np.broadcast_to(np.asarray(c2, float), (n,))[sl].copy(),
+                             self.mode_mask))
 
     def _all(self, table, col, rows=None, dynamic=False):
         base = self.store.slot(table, col, dynamic)
@@ -391,16 +393,21 @@ class BatchedOpfEnv:
         self.ops = OpsBuilder(self.store)
         self.tables = []
         modes = {self.train_data, self.test_data}
-        if modes - {'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean'}:
-            raise NotImplementedError(f'data distributions {modes} are not supported yet ("mixed" draws a '
-                                      f'different distribution per reset)')
-        self.noise_factor = float(self.sampling_params.get('noise_factor', 0.0))
+        if modes - {'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean', 'mixed'}:
+            raise NotImplementedError(f'data distributions {modes} are not supported')
+        # 'mixed' (opf_env.py:242-251): every reset draws one of the three sources per instance; the
+        # ops of all three are compiled with the set of sources they run under
+        self.mixed = 'mixed' in modes and 'noise_factor' not in self.sampling_params     # (:231 comes first)
+        if 'mixed' in modes and len(modes) > 1:
+            raise NotImplementedError("'mixed' must be both the train and the test distribution")
+        self.data_probabilities = tuple(self.sampling_params.get('data_probabilities', (0.5, 0.75, 1.0)))
+        self.noise_factor = float(self.sampling_params.get('noise_factor', 0.1 if self.mixed else 0.0))   # :318 default
         if 'noisy_simbench' in modes and 'noise_factor' not in self.sampling_params:
             self.noise_factor = 0.1                                        # opf_env.py:318 default
         self.noise_distribution = self.sampling_params.get('noise_distribution', 'uniform')
         assert self.noise_distribution in ('uniform', 'normal')
         self.interpolate_steps = bool(self.sampling_params.get('interpolate_steps', False))
-        self.uses_profiles = bool(modes & {'simbench', 'noisy_simbench'})
+        self.uses_profiles = bool(modes & {'simbench', 'noisy_simbench', 'mixed'})
         if self.uses_profiles:
             for key in self.profiles.keys():                               # opf_env.py:339-372
                 df = self.profiles[key]
@@ -411,10 +418,11 @@ class BatchedOpfEnv:
                 slots = self.store.slots(unit, col, df.columns, dynamic=True)
                 self.tables.append(dict(rel=rel, typ=typ, peak=peak, slot=slots,
                                         col_min=df.min().to_numpy(float), col_max=df.max().to_numpy(float)))
-        if len(modes) > 1 and modes & {'full_uniform', 'normal_around_mean'}:
+        if len(modes) > 1 and modes & {'full_uniform', 'normal_around_mean', 'mixed'}:
             raise NotImplementedError('different train/test distributions are only supported among the '
                                       'simbench variants')
-        if 'normal_around_mean' in modes:                                  # opf_env.py:286-315
+        if 'normal_around_mean' in modes or self.mixed:                    # opf_env.py:286-315
+            self.ops.mode_mask = 4 if self.mixed else 7
             if self.sampling_params.get('truncated'):
                 raise NotImplementedError('truncated normal sampling (scipy.stats.truncnorm) is not supported')
             rel = self.sampling_params.get('relative_std')
@@ -430,7 +438,8 @@ class BatchedOpfEnv:
                 std = rel * diff if rel else df[f'std_dev_{col}'].to_numpy(float)[rows]
                 _normal_and_clip(self.ops, unit, col, idxs, df[f'mean_{col}'].to_numpy(float)[rows],
                                  std * diff, lo, hi)                         # (std * diff as at :312)
-        if 'full_uniform' in modes:
+        if 'full_uniform' in modes or self.mixed:
+            self.ops.mode_mask = 2 if self.mixed else 7
             for unit, col, idxs in self.state_keys:                        # opf_env.py:253-284
                 if 'res_' in unit:
                     continue
@@ -440,6 +449,7 @@ class BatchedOpfEnv:
                 hi = df[f'max_max_{col}' if f'max_max_{col}' in df else f'max_{col}'].to_numpy(float)[rows]
                 sc = df['scaling'].to_numpy(float)[rows] if 'scaling' in df else 1.0
                 self.ops.uniform(unit, col, idxs, lo, hi, sc)
+        self.ops.mode_mask = 7
         self._sampling_ops(self.ops)
 
     # ------------------------------------------------------------------ compile
@@ -816,6 +826,8 @@ class BatchedOpfEnv:
         r.n_consts, r.consts = len(consts), _keep(keep, consts, 'd')
         r.n_uniform = self.ops.n_uniform
         r.n_normal = self.ops.n_normal
+        if self.mixed:
+            r.op_mode = _keep(keep, [op[7] for op in self.ops.ops], 'i')
         r.init_off = 0
         capi.check(capi.lib().opfx_env_set_reset(self._env_handle, C.byref(r)), 'opfx_env_set_reset')
         self.n_uniform = self.ops.n_uniform
@@ -910,7 +922,8 @@ class BatchedOpfEnv:
                 return a.to(device=dev, dtype=t.float64).contiguous()
             return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         data_distr = self.test_data if self.test else self.train_data
-        noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params)
+        noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params
+                                  or self.mixed)
         nf = self.noise_factor if noisy else 0.0
         normal_noise = noisy and self.noise_distribution == 'normal'
         noise_t = options.get('noise')
@@ -944,6 +957,17 @@ class BatchedOpfEnv:
         rio.normal = nrm_t.data_ptr() if nrm_t is not None else None
         rio.normal_noise_factor = float(nf) if normal_noise else 0.0
         rio.x = self.x.data_ptr()
+        mode_t = None
+        if self.mixed:                                                     # opf_env.py:242-251
+            mode_t = options.get('mode')
+            if mode_t is None:
+                r = t.rand(B, generator=self._gen, device=dev, dtype=t.float64)
+                p0, p1 = self.data_probabilities[0], self.data_probabilities[1]
+                mode_t = ((r >= p0).to(t.int32) + (r >= p1).to(t.int32))
+            else:
+                mode_t = t.as_tensor(np.broadcast_to(np.asarray(mode_t, dtype=np.int32), (B,)).copy()).to(dev)
+            rio.mode = mode_t.contiguous().data_ptr()
+            self.sampling_mode = mode_t
         with t.cuda.device(self.device):
             capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
         self.step_count.zero_()

@@ -119,13 +119,13 @@ class ResetDesc(C.Structure):
                 ('n_ops', C.c_int32), ('op_code', _pi), ('op_dst', _pi), ('op_a', _pi),
                 ('op_n', _pi), ('op_c0', _pi), ('op_c1', _pi), ('op_c2', _pi),
                 ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32),
-                ('init_off', C.c_int32), ('n_normal', C.c_int32)]
+                ('init_off', C.c_int32), ('n_normal', C.c_int32), ('op_mode', _pi)]
 
 
 class ResetIO(C.Structure):
     _fields_ = [('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
                 ('uniform', C.c_void_p), ('normal', C.c_void_p), ('normal_noise_factor', C.c_double),
-                ('x', C.c_void_p)]
+                ('x', C.c_void_p), ('mode', C.c_void_p)]
 
 
 _lib = None

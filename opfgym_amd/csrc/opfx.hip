@@ -1667,7 +1667,7 @@ constexpr int MAX_TABLES = 8;
 struct DevReset {
   int n_tables, n_ops, n_uniform, n_normal, n_noise, nx, init_off;
   DevTable tab[MAX_TABLES];
-  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2;
+  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2, *op_mode;
   const double* consts;
 };
 
@@ -1676,6 +1676,7 @@ struct ResetIO {
   const double *noise, *interp, *uniform, *normal;
   double normal_noise_factor;
   double* x;
+  const int* mode;
 };
 
 __global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long B) {
@@ -1686,8 +1687,9 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long
   for (long long b = w; b < B; b += nw) {
     double* xr = io.x + b * R.nx;
     const int step = io.step_idx[b];
+    const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
     if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) xr[j] = R.consts[R.init_off + j];
-    for (int t = 0; t < R.n_tables; ++t) {
+    for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
       const DevTable& T = R.tab[t];
       const double* row = T.rel + (long long)step * T.n_types;
       const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
@@ -1707,6 +1709,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long
     // element j of every op is handled by lane j%64, so a value written by one op is
     // read back by the same thread in a later op (program order suffices).
     for (int k = 0; k < R.n_ops; ++k) {
+      if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
       const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
       const double* c0 = R.op_c0[k] >= 0 ? R.consts + R.op_c0[k] : nullptr;
       const double* c1 = R.op_c1[k] >= 0 ? R.consts + R.op_c1[k] : nullptr;
@@ -2259,6 +2262,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   PUTN(op_code, d->op_code, d->n_ops); PUTN(op_dst, d->op_dst, d->n_ops); PUTN(op_a, d->op_a, d->n_ops);
   PUTN(op_n, d->op_n, d->n_ops); PUTN(op_c0, d->op_c0, d->n_ops); PUTN(op_c1, d->op_c1, d->n_ops);
   PUTN(op_c2, d->op_c2, d->n_ops); PUTN(consts, d->consts, d->n_consts);
+  if (d->op_mode) { PUTN(op_mode, d->op_mode, d->n_ops); }
 #undef PUTN
   if (rc != OPFX_OK) return rc;
   env->has_reset = true;
@@ -2275,7 +2279,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(env->ctx->device));
   const int grid = (int)std::min<long long>((B + 3) / 4, (long long)env->ctx->n_cu * 8);
-  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x};
+  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode};
   hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, r, (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;

@@ -391,11 +391,17 @@ class EnvOracle:
         self.step_in_episode = 0
         self.current_step = step
         draws = iter(np.asarray(uniform, float))
-        if self.data == 'full_uniform':                                     # opf_env.py:238-239, 253-264
+        data = self.data
+        if data == 'mixed' and 'noise_factor' not in self.sampling_params:  # opf_env.py:242-251
+            r = float(np.asarray(interp, float).ravel()[0])                 # the first draw of the reset (:244)
+            probs = self.sampling_params.get('data_probabilities', (0.5, 0.75, 1.0))
+            data = 'noisy_simbench' if r < probs[0] else ('full_uniform' if r < probs[1] else 'normal_around_mean')
+            interp = None
+        if data == 'full_uniform':                                          # opf_env.py:238-239, 253-264
             for unit, col, idxs in self.state_keys:
                 if 'res_' not in unit:
                     sample_from_range(self.net, unit, col, idxs, draws)
-        elif self.data == 'normal_around_mean':                             # :240-241
+        elif data == 'normal_around_mean':                                  # :240-241
             sample_normal(self.net, self.state_keys, iter(np.asarray(normal, float)),
                           self.sampling_params.get('relative_std'))
         else:

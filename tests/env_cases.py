@@ -55,7 +55,7 @@ def noise_factors(name, raw):
     None when the scenario samples without noise (factor exactly 1.0)."""
     kwargs = SCENARIOS[name][1]
     sp = kwargs.get('sampling_params') or {}
-    nf = sp.get('noise_factor', 0.0)
+    nf = sp.get('noise_factor', 0.1 if kwargs.get('train_data') == 'mixed' else 0.0)   # opf_env.py:318 default
     if not nf or raw.size == 0:
         return None
     if sp.get('noise_distribution') == 'normal':
@@ -70,3 +70,14 @@ def draws(g, k, prefix=''):
         arr = g.get(prefix + key)
         out[key] = arr[k] if arr is not None and arr.shape[1] else None
     return out
+
+
+def mixed_modes(name, g, prefix=''):
+    """'mixed' sampling: the reset's first draw r (recorded like an interpolation draw) -> data source
+    per sample (opf_env.py:244-251); None for other scenarios."""
+    kwargs = SCENARIOS[name][1]
+    if kwargs.get('train_data') != 'mixed':
+        return None
+    p = (kwargs.get('sampling_params') or {}).get('data_probabilities', (0.5, 0.75, 1.0))
+    r = g[prefix + 'interp'][:, 0]
+    return (r >= p[0]).astype(np.int32) + (r >= p[1]).astype(np.int32)

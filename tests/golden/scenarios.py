@@ -45,6 +45,16 @@ SCENARIOS = {
     'vc_normal_mean': ('VoltageControl', dict(
         simbench_network_name='mv-small', train_data='normal_around_mean', test_data='normal_around_mean',
         sampling_params=dict(relative_std=0.3)), 4, 17),
+    # train_data='mixed' (opf_env.py:242-251) with the source forced by the probabilities, one scenario each
+    'vc_mixed_simbench': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='mixed', test_data='mixed',
+        sampling_params=dict(data_probabilities=(1.0, 1.0, 1.0))), 3, 27),
+    'vc_mixed_uniform': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='mixed', test_data='mixed',
+        sampling_params=dict(data_probabilities=(0.0, 1.0, 1.0))), 3, 28),
+    'vc_mixed_normal': ('VoltageControl', dict(
+        simbench_network_name='mv-small', train_data='mixed', test_data='mixed',
+        sampling_params=dict(data_probabilities=(0.0, 0.0, 1.0), relative_std=0.25)), 3, 29),
     # multi-step episodes with incremental actions (opf_env.py:451-458, 406-414)
     'vc_multistep_diff': ('VoltageControl', dict(
         simbench_network_name='mv-small', steps_per_episode=3, diff_action_step_size=0.2), 3, 14),

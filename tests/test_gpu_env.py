@@ -10,7 +10,7 @@ Jacobian times 1e-8 at most)."""
 import numpy as np
 import pytest
 
-from env_cases import EPISODE_STEPS, SINGLE_STEP, golden, noise_factors, oracle_env, product_env
+from env_cases import mixed_modes, EPISODE_STEPS, SINGLE_STEP, golden, noise_factors, oracle_env, product_env
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,9 @@ def test_env_matches_reference_golden(name):
     if noise_factors(name, g['noise'][0]) is not None:
         noise = np.stack([noise_factors(name, g['noise'][k]) for k in range(n)])
     extra = {k: g[k] for k in ('interp', 'normal') if k in g and g[k].shape[1]}
+    if mixed_modes(name, g) is not None:           # 'mixed': that draw selects the data source
+        extra.pop('interp')
+        extra['mode'] = mixed_modes(name, g)
     obs0, _ = env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None,
                                  'noise': noise, **extra})
     for key in g:
@@ -305,3 +308,27 @@ def test_vector_env_next_step_and_partial_reset():
     x_before = env.x.clone()
     vec._reset_rows(mask)
     assert torch.equal(env.x[1::2], x_before[1::2]) and not torch.equal(env.x[::2], x_before[::2])
+
+
+def test_mixed_sampling_draws_a_source_per_instance():
+    """train_data='mixed' (opf_env.py:242-251): every instance draws its data source with the default
+    probabilities 0.5 / 0.25 / 0.25; instances of one source obey that source's law."""
+    from opfgym_amd import envs
+    B = 4096
+    env = envs.VoltageControl(simbench_network_name='mv-small', batch_size=B, device='cuda:0', seed=4,
+                              train_data='mixed', test_data='mixed')
+    env.reset(seed=9)
+    mode = _np(env.sampling_mode)
+    frac = np.bincount(mode, minlength=3) / B
+    assert np.abs(frac - np.array([0.5, 0.25, 0.25])).max() < 0.04
+    # uniform source: load.p_mw in [min_min, max_max] / scaling, spread over the whole range
+    p = _np(env.table_column('load', 'p_mw'))
+    ld = env.net.load
+    lo = (ld.min_min_p_mw / ld.scaling).to_numpy(float)
+    hi = (ld.max_max_p_mw / ld.scaling).to_numpy(float)
+    u = p[mode == 1]
+    assert (u >= lo - 1e-12).all() and (u <= hi + 1e-12).all()
+    rel = (u - lo) / (hi - lo)
+    assert abs(rel.mean() - 0.5) < 0.03
+    out = env.step(np.random.default_rng(0).random((B, env.n_actions)))
+    assert _np(out[4]['converged']).mean() > 0.95
