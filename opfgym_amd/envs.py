@@ -37,8 +37,12 @@ class VoltageControl(BatchedOpfEnv):
         kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
         super().__init__(net, act_keys, obs_keys, profiles=profiles, *args, **kwargs)
 
+    def _build_net(self, simbench_network_name, *args, **kwargs):
+        """Grid + profiles the problem is defined on (hook for variants on other stand-in grids)."""
+        return build_simbench_net(simbench_network_name, *args, **kwargs)
+
     def _define_opf(self, simbench_network_name, *args, **kwargs):
-        net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
+        net, profiles = self._build_net(simbench_network_name, *args, **kwargs)
         net.load['controllable'] = False
         net.sgen['controllable'] = net.sgen.max_max_p_mw > self.min_sgen_power                 # :68
         net.sgen['max_s_mva'] = net.sgen['max_max_p_mw'] / self.cos_phi                         # :70
@@ -555,7 +559,7 @@ class SecurityConstrainedVoltageControl(VoltageControl):
         super().__init__(simbench_network_name, *args, n_minus_one_keys=keys,
                          not_converged_penalty=not_converged_penalty, **kwargs)
 
-    def _define_opf(self, simbench_network_name, *args, **kwargs):
+    def _build_net(self, simbench_network_name, *args, **kwargs):
         net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
         # VoltageControl asserts a grid without `gen` units (voltage_control.py:102):
         # on the HV stand-in the PV generators become fixed sgens.
@@ -577,9 +581,4 @@ class SecurityConstrainedVoltageControl(VoltageControl):
             net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
             net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
             set_constraints_from_profiles(net, profiles)
-        saved = build_simbench_net
-        try:
-            globals()['build_simbench_net'] = lambda *a, **k: (net, profiles)
-            return super()._define_opf(simbench_network_name, *args, **kwargs)
-        finally:
-            globals()['build_simbench_net'] = saved
+        return net, profiles
