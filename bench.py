@@ -8,8 +8,9 @@ One "step" = one `env.step()` of the whole batch = ONE launch of the fused
 kernel (apply actions -> NR power flow -> results -> objective -> violations
 -> reward -> observation).  Inputs are resident in HBM when the timed region
 starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank steps its own 8192-instance shard (weak scaling) and the rewards are
-re-assembled on every rank with one RCCL all-gather per step.
+rank steps its own 8192-instance shard (weak scaling).  Instances are
+independent, so the data path has NO collective; `--gather reward|obs` adds the
+optional RCCL all-gather a centralised learner would want.
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -83,7 +84,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather-obs', action='store_true')
+    ap.add_argument('--gather', choices=('none', 'reward', 'obs'), default='none',
+                    help='optional per-step RCCL all-gather of the rewards (and observations) on every rank')
     args = ap.parse_args()
 
     import torch
@@ -101,11 +103,11 @@ def main():
     env.reset(options={'step': rng.choice(env.train_steps, B)})
     act_rng = np.random.default_rng(4321 + rank)
     actions = torch.as_tensor(act_rng.random((B, env.n_actions)), device=device)
-    gather = ('reward', 'obs') if args.gather_obs else ('reward',)
+    gather = {'none': (), 'reward': ('reward',), 'obs': ('reward', 'obs')}[args.gather]
 
     def one_step():
         obs, reward, term, trunc, info = env.step(actions)
-        if world > 1:
+        if world > 1 and gather:
             odist.all_gather_rows(reward, world)
             if 'obs' in gather:
                 odist.all_gather_rows(obs, world)
@@ -160,7 +162,7 @@ def main():
             'config': {'workload': f'VoltageControl env, synthetic stand-in for SimBench {GRID} '
                                    f'({bm["nb"]} buses), batch={B} per GPU, step() only',
                        'batch_per_gpu': B, 'parallelism': f'shard{world}',
-                       'collective': 'all_gather(reward)' + ('+obs' if args.gather_obs else '') if world > 1 else 'none',
+                       'collective': {'none': 'none', 'reward': 'all_gather(reward)', 'obs': 'all_gather(reward+obs)'}[args.gather] if world > 1 else 'none',
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it,
                        'tolerance_pu': env.solve_opts.tol, 'byte_model': bm},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
