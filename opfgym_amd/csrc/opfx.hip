@@ -1837,6 +1837,7 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
     if (by_lds >= 1 && per_cu > by_lds) per_cu = by_lds;
   }
   if (per_cu < 1) per_cu = 1;
+  if (per_cu > 16) per_cu = 16;       // the per-workgroup scratch rows (warm start, scheduled P/Q) are sized for 16 per CU
   if (const char* ov = getenv("OPFX_WAVES_PER_CU")) per_cu = atoi(ov);     // developer override
   if (getenv("OPFX_VERBOSE")) fprintf(stderr, "[opfx] lds=%zu B/instance, resident waves per CU=%d, CUs=%d\n", lds, per_cu, n_cu);
   *per_cu_cache = per_cu;
