@@ -122,7 +122,8 @@ enum {
   OPFX_ARR_BLK_ROW, OPFX_ARR_BLK_COL,
   OPFX_ARR_LP_A_ENT, OPFX_ARR_LP_A_DBLK, OPFX_ARR_LP_H_ENT, OPFX_ARR_LP_H_ROW,
   OPFX_ARR_LP_B, OPFX_ARR_LP_C,
-  OPFX_ARR_BR_ISLAND   /* [nbr] 1 = taking this branch out cuts some bus off every REF bus */
+  OPFX_ARR_BR_ISLAND,  /* [nbr] 1 = taking this branch out cuts some bus off every REF bus */
+  OPFX_ARR_ISL_PTR, OPFX_ARR_ISL_BUS   /* CSR [nbr+1] -> the buses that outage cuts off (they are de-energised) */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };

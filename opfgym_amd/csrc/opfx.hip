@@ -58,7 +58,7 @@ struct DevPlan {
   const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
   const int *lev_tptr, *tgt_blk, *tgt_sptr, *src_ik, *src_kk, *src_kj;
   const int *lev_pptr, *piv_bus, *piv_uptr, *u_blk, *u_col;
-  const int *br_f, *br_t, *br_pos, *br_island, *ref_bus, *ref_ord;
+  const int *br_f, *br_t, *br_pos, *br_island, *isl_ptr, *isl_bus, *ref_bus, *ref_ord;
   const double *vm_set, *va_set, *vr0, *vi0, *y_g, *y_b, *br_y, *br_kf, *br_kt;
   // lane programme (plan.h)
   int ra, rh, rb, rc;
@@ -219,6 +219,9 @@ __device__ __forceinline__ void st_blk(double* blk, int id, const Blk& b) {
 }
 
 constexpr int BT_PQ = 1, BT_PV = 2, BT_REF = 3, BT_PQ_HI = 4, BT_PQ_LO = 5;
+// a bus that this instance's outage cuts off every REF bus: de-energised (pandapower's
+// check_connectivity takes such buses out of service): identity rows, NaN results
+constexpr int BT_DEAD = 6;
 
 // Per-instance LDS image.  The lane-programme kernel (V2) keeps the voltage in
 // rectangular form only (no |V|/angle arrays) to fit 6 instances per CU.
@@ -566,6 +569,33 @@ __device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane
   wave_fence();
 }
 
+// De-energised buses (mark_island): their rows become identity rows — off-diagonal blocks 0,
+// diagonal block I, right-hand side 0.  Runs after phase A in the modifier path only (an island
+// always comes with the modifier of the branch that cut it off), re-reading the row descriptors.
+template <bool PK>
+__device__ void dead_rows_patch(const DevPlan& P, const Lds& L, int lane) {
+  constexpr unsigned NONE = 0xFFFFu;
+  bool any = false;
+  for (int i = lane; i < P.nb; i += WAVE) any = any || L.bt[i] == BT_DEAD;
+  if (!__any(any)) return;
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk) + lane;
+  for (int h = 0; h < P.rh; ++h) {
+    const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE];
+    const unsigned bid = he.x >> 16;
+    if ((he.x & 0xFFFF) != NONE && bid != NONE && L.bt[he.y] == BT_DEAD) st_blk2<PK>(L, bid, Blk{0.0, 0.0, 0.0, 0.0});
+  }
+  for (int r = 0; r < P.ra; ++r) {
+    const ARound a = load_around(P, r, lane);
+    const int i = lane + WAVE * r;
+    if (i >= P.nb || L.bt[i] != BT_DEAD) continue;
+    const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) st_blk2<PK>(L, ent[k] >> 16, Blk{0.0, 0.0, 0.0, 0.0});
+    st_blk2<PK>(L, a.dw & 0xFFFF, Blk{1.0, 0.0, 0.0, 1.0});
+    L.rhs[i] = 0.0; L.rq[i] = 0.0;
+  }
+}
+
 // lanes 0 .. 2*n_mod-1: end e = lane & 1 of modifier lane >> 1
 __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   if (lane >= 2 * n_mod) return;
@@ -580,6 +610,7 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   const double v2 = vri * vri + vii * vii;
   const double dyr = yii_g * v2, dyi = -yii_b * v2;                         // conj(dY_ii)|V_i|^2
   const int t = L.bt[i];
+  if (t == BT_DEAD) return;                // de-energised end: identity row
   if (t == BT_REF) {                       // parked injection S_i
     lds_add(&L.rhs[i], dcr + dyr);
     lds_add(&L.rq[i], dci + dyi);
@@ -739,6 +770,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
       wave_fence();
+      dead_rows_patch<PK>(P, L, lane);
+      wave_fence();
       mods_apply(L, lane, n_mod);
       wave_fence();
       my = 0.0;
@@ -867,7 +900,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
         const unsigned bid = ent >> 16;
         const int t = L.bt[i];
-        if (bid != NONE && t != BT_REF) {
+        if (bid != NONE) {
           Blk jb{ci, cr, -cr, ci};
           if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
           st_blk2<PK>(L, bid, jb);
@@ -930,7 +963,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
     if (n_mod > 0) {
       __syncthreads();
-      if (wave == 0) mods_apply(L, lane, n_mod);
+      if (wave == 0) { dead_rows_patch<PK>(P, L, lane); wave_fence(); mods_apply(L, lane, n_mod); }
       __syncthreads();
       my = 0.0;
       for (int i = tid; i < nb; i += NT)
@@ -997,14 +1030,34 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
 }
 
 // Outer loop: NR + enforce_q_lims PV->PQ switching.
+// 0: no islanding outage among the n_rem removed branches; 1: exactly one removed branch and it
+// islands (its cut-off set is precomputed); 2: islanding with several branches out (unknown set)
+__device__ __forceinline__ int island_state(bool v2, int n_rem, bool any_island) {
+  return !any_island ? 0 : ((v2 && n_rem == 1) ? 1 : 2);
+}
+
+// De-energise the buses that outage `br` cuts off (single outage only: the island sets are
+// precomputed per branch, plan.cpp).  Call after init_voltage.
+__device__ __forceinline__ void mark_island(const DevPlan& P, const Lds& L, int lane, int br,
+                                            const double* qg_min, const double* qg_max) {
+  for (int q = P.isl_ptr[br] + lane; q < P.isl_ptr[br + 1]; q += WAVE) {
+    const int i = P.isl_bus[q];
+    const int t = L.bt[i];
+    if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];       // undo the start pin of init_voltage
+    if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
+    L.bt[i] = (unsigned char)BT_DEAD;
+  }
+}
+
 template <int V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
-                               const double* qg_min, const double* qg_max, int* iters, double* nrm) {
+                               const double* qg_min, const double* qg_max, int* iters, double* nrm, int isl_state = 0) {
   const int wave = threadIdx.x >> 6;
-  // An outage that cuts buses off every REF bus makes the Newton matrix singular: reported as
-  // the CPU restatement reports it (one step into NaN, not converged) without spending the
-  // iterations a nearly singular matrix would otherwise burn.
-  if (out_br >= 0 && P.br_island[out_br]) { *iters = 1; *nrm = __builtin_nan(""); return false; }
+  // isl_state (islanding outages, see island_state): 1 = the caller has de-energised the island
+  // (mark_island) and the solve proceeds on the rest; 2 = the cut-off set is not known exactly
+  // (several branches out at once, or the first-generation kernel): the Newton matrix would be
+  // singular, reported as not converged at once.
+  if (isl_state == 2) { *iters = 1; *nrm = __builtin_nan(""); return false; }
   int total = 0;
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
@@ -1077,7 +1130,9 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     const int t = L.bt[i];
     double qgen = 0.0;
-    if (V2 && t == BT_REF) {
+    if (t == BT_DEAD) {                      // de-energised: no voltage (NaN as in pandapower's res_bus)
+      r_vm[i] = __builtin_nan(""); r_va[i] = __builtin_nan("");
+    } else if (V2 && t == BT_REF) {
       const int ro = P.ref_ord[i];
       r_pe[ro] = (L.rhs[i] - L.psp[i]) * base;          // (V2: rhs/rq are separate arrays)
       r_qe[ro] = (L.rq[i] - L.qsp[i]) * base;
@@ -1127,6 +1182,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     if (!removed) {
       const int f = P.br_f[k], t = P.br_t[k];
+      if (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD) { r_ld[k] = __builtin_nan(""); continue; }
       const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
       const double ifr = y[0] * vfr - y[1] * vfi + y[2] * vtr - y[3] * vti;
       const double ifi = y[0] * vfi + y[1] * vfr + y[2] * vti + y[3] * vtr;
@@ -1190,9 +1246,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
     const int out_br = io.outage ? io.outage[b] : -1;
     const int n_mod = (V2 && out_br >= 0) ? 1 : 0;
     if (n_mod && wave == 0) mod_set(P, L, lane, 0, out_br, 0.0, true, 0);
+    const int isl = island_state(V2 != 0, out_br >= 0 ? 1 : 0, out_br >= 0 && P.br_island[out_br]);
+    if (isl == 1 && wave == 0) mark_island(P, L, lane, out_br, io.qg_min, io.qg_max);
     blk_sync<NW>();
     int iters; double nrm;
-    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm);
+    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, isl);
     blk_sync<NW>();
     if (wave == 0) {
       double* R = L.blk;
@@ -1436,6 +1494,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     const int base_out = io.outage ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
+    int n_rem_base = 0, isl_br_base = -1;       // removed branches so far / one of them that islands
     if (V2) for (int m = 0; m < E.n_bmod; ++m) {
       // stamps of this branch for the instance's state (tap position, switch / in_service flag)
       const int br = as_global(E.bmod_branch)[m];
@@ -1444,17 +1503,24 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       double y = 0.0, dy = 0.0;
       if (lane < 8) { y = as_global(E.bmod_y)[row * 8 + lane]; dy = y - P.br_y[br * 8 + lane]; }
       if (br == base_out || !__any(dy != 0.0)) continue;      // outaged anyway / state = compiled state
-      if (wave == 0) mod_set(P, L, lane, n_mod_base, br, dy, !__any(y != 0.0), 0);
+      const bool removed = !__any(y != 0.0);
+      if (wave == 0) mod_set(P, L, lane, n_mod_base, br, dy, removed, 0);
       ++n_mod_base;
+      if (removed) { ++n_rem_base; if (P.br_island[br]) isl_br_base = br; }
     }
     if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true, 0); ++n_mod_base; }
+    if (base_out >= 0) { ++n_rem_base; if (P.br_island[base_out]) isl_br_base = base_out; }
     for (int c = 0; c <= E.n_cont; ++c) {
       const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
       int n_mod = n_mod_base;
       if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true, n_mod_base); ++n_mod; }
+      const int n_rem = n_rem_base + (c > 0 ? 1 : 0);
+      const int isl_br = (c > 0 && P.br_island[out_br]) ? out_br : isl_br_base;
+      const int isl = island_state(V2 != 0, n_rem, isl_br >= 0);
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+        if (isl == 1) mark_island(P, L, lane, isl_br, E.qg_min, E.qg_max);
         if (E.vset_src) for (int i = lane; i < nb; i += WAVE) {
           // per-instance |V| set-point of a REF / PV bus (a sampled ext_grid.vm_pu)
           const int src = as_global(E.vset_src)[i];
@@ -1473,7 +1539,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm);
+      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, isl);
       blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) {
@@ -1873,7 +1939,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   PUT(diag_blk, diag_blk); PUT(fill_blk, fill_blk); PUT(lev_tptr, lev_tptr); PUT(tgt_blk, tgt_blk);
   PUT(tgt_sptr, tgt_sptr); PUT(src_ik, src_ik); PUT(src_kk, src_kk); PUT(src_kj, src_kj);
   PUT(lev_pptr, lev_pptr); PUT(piv_bus, piv_bus); PUT(piv_uptr, piv_uptr); PUT(u_blk, u_blk);
-  PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(br_island, br_island); PUT(ref_bus, ref_bus);
+  PUT(u_col, u_col); PUT(br_f, br_f); PUT(br_t, br_t); PUT(br_pos, br_pos); PUT(br_island, br_island); PUT(isl_ptr, isl_ptr); PUT(isl_bus, isl_bus); PUT(ref_bus, ref_bus);
   PUT(ref_ord, ref_ord); PUT(vm_set, vm_set); PUT(va_set, va_set); PUT(y_g, y_g); PUT(y_b, y_b);
   PUT(br_y, br_y); PUT(br_kf, br_kf); PUT(br_kt, br_kt);
   d.nfull = p->n_full;

@@ -376,6 +376,7 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> nbrs(nb);      // (other bus, branch)
     for (int32_t k = 0; k < nbr; ++k) { nbrs[p->br_f[k]].push_back({p->br_t[k], k}); nbrs[p->br_t[k]].push_back({p->br_f[k], k}); }
     p->br_island.assign(nbr, 0);
+    p->isl_ptr.assign(1, 0);
     std::vector<char> seen(nb);
     std::vector<int32_t> stack;
     for (int32_t out = 0; out < nbr; ++out) {
@@ -388,6 +389,8 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
         for (auto& e : nbrs[u]) if (e.second != out && !seen[e.first]) { seen[e.first] = 1; ++reached; stack.push_back(e.first); }
       }
       p->br_island[out] = reached < nb ? 1 : 0;
+      if (reached < nb) for (int32_t i = 0; i < nb; ++i) if (!seen[i]) p->isl_bus.push_back(i);
+      p->isl_ptr.push_back((int32_t)p->isl_bus.size());
     }
   }
 
@@ -527,6 +530,8 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
     case OPFX_ARR_BR_ISLAND: v = &p->br_island; break;
+    case OPFX_ARR_ISL_PTR: v = &p->isl_ptr; break;
+    case OPFX_ARR_ISL_BUS: v = &p->isl_bus; break;
     case OPFX_ARR_Y_PTR: v = &p->y_ptr; break;
     case OPFX_ARR_Y_COL: v = &p->y_col; break;
     case OPFX_ARR_Y_BLK: v = &p->y_blk; break;

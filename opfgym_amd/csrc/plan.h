@@ -22,6 +22,7 @@ struct opfx_plan {
   // per-branch positions of its four stamps in the CSR (for per-instance outages)
   std::vector<int32_t> br_pos;         // [nbr*4] ff, ft, tf, tt
   std::vector<int32_t> br_island;      // [nbr] 1 = outage of this branch leaves a bus without a path to a REF bus
+  std::vector<int32_t> isl_ptr, isl_bus;   // CSR: buses that outage k cuts off (empty for most branches)
   // block LU pattern
   int32_t n_blk = 0;
   int32_t n_full = 0;                      // blocks [0, n_full) hold four values, the rest two (plan.cpp renumber_blocks)

@@ -121,10 +121,13 @@ def solve_case(case, p_inj, q_inj, qg_min=None, qg_max=None, qd_bus=None,
     p = np.asarray(p_inj, float).copy()
     q = np.asarray(q_inj, float).copy()
     v = case.vm_set * np.exp(1j * case.va_set) if v_init is None else v_init.copy()
+    # pandapower `check_connectivity=True`: buses without a path to a slack are taken
+    # out of service; their voltages come back as NaN.
+    alive = energised_buses(case, br_status)
     total_it = 0
     while True:
-        pv = np.flatnonzero(bus_type == PV)
-        pq = np.flatnonzero(bus_type == PQ)
+        pv = np.flatnonzero((bus_type == PV) & alive)
+        pq = np.flatnonzero((bus_type == PQ) & alive)
         v, ok, it, nrm = newtonpf(ybus, p + 1j * q, v, pv, pq, tol, max_it)
         total_it += it
         if not ok or not enforce_q_lims or qg_min is None or len(pv) == 0:
@@ -139,8 +142,29 @@ def solve_case(case, p_inj, q_inj, qg_min=None, qg_max=None, qd_bus=None,
         q[pv[hi]] = qg_max[pv[hi]] - qd_bus[pv[hi]]
         q[pv[lo]] = qg_min[pv[lo]] - qd_bus[pv[lo]]
         bus_type[fix] = PQ
+    v = np.where(alive, v, np.nan + 0j)
     return dict(V=v, converged=ok, iterations=total_it, max_mismatch=nrm,
                 bus_type=bus_type, ybus=ybus)
+
+
+def energised_buses(case, br_status=None):
+    """Buses with a path of in-service branches to a REF bus."""
+    nb = case.nb
+    on = np.ones(case.nbr, bool) if br_status is None else np.asarray(br_status) != 0
+    adj = [[] for _ in range(nb)]
+    for k in np.flatnonzero(on):
+        adj[int(case.f[k])].append(int(case.t[k])); adj[int(case.t[k])].append(int(case.f[k]))
+    alive = np.zeros(nb, bool)
+    stack = [int(i) for i in np.flatnonzero(case.bus_type == REF)]
+    for i in stack:
+        alive[i] = True
+    while stack:
+        u = stack.pop()
+        for w in adj[u]:
+            if not alive[w]:
+                alive[w] = True
+                stack.append(w)
+    return alive
 
 
 def branch_results(case, v, br_status=None):
@@ -152,6 +176,7 @@ def branch_results(case, v, br_status=None):
     s_f = v[case.f] * np.conj(i_f)
     s_t = v[case.t] * np.conj(i_t)
     loading = np.maximum(np.abs(i_f) * case.kf, np.abs(i_t) * case.kt)
+    loading = np.where(s == 0, 0.0, loading)              # out of service: 0 %, also next to a dead bus
     return dict(s_from=s_f, s_to=s_t, i_from=np.abs(i_f), i_to=np.abs(i_t),
                 loading_percent=loading)
 
