@@ -208,7 +208,7 @@ typedef struct opfx_env_desc {
   const int32_t* clamp_hi_slot;
   const double* clamp_lo_const;
   const double* clamp_hi_const;
-  int32_t clamp_enabled;
+  int32_t clamp_enabled;          /* bit 0: clamp in step(), bit 1: clamp in reset() (= autoscale off) */
   double diff_action_step_size;   /* 0 → absolute set-points (:451-461)     */
   double clipped_action_penalty;  /* :403-404 */
   /* costs (objective.py:34-77); coefficient table = [npoly*6 | npwl*nseg*3] */
@@ -324,7 +324,10 @@ typedef struct opfx_step_io {
  * `action` (`apply_action=False`, opf_env.py:197,386); 2 = apply `action` and
  * write the table observation only, no power flow (reset of an environment
  * whose observation needs no results, opf_env.py:207,218); 3 = table observation of the
- * current x only (no action, no power flow; multi_stage.py:56). */
+ * current x only (no action, no power flow; multi_stage.py:56); 4 = full step with the action
+ * applied the way reset applies its initial action (opf_env.py:207-216: absolute set-points
+ * even when the environment steps incrementally, clamping only without autoscaling).
+ * Modes 2 and 4 are the two forms of reset. */
 int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
               const opfx_solve_opts* opts, int32_t mode, void* stream);
 

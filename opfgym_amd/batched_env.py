@@ -712,7 +712,7 @@ class BatchedOpfEnv:
         d.act_lo_const, d.act_hi_const = _keep(keep, lo_c, 'd'), _keep(keep, hi_c, 'd')
         d.clamp_lo_slot, d.clamp_hi_slot = _keep(keep, cl_s, 'i'), _keep(keep, ch_s, 'i')
         d.clamp_lo_const, d.clamp_hi_const = _keep(keep, cl_c, 'd'), _keep(keep, ch_c, 'd')
-        d.clamp_enabled = int(clamp)
+        d.clamp_enabled = int(clamp) | (int(not self.autoscale_actions) << 1)
         d.diff_action_step_size = float(self.diff_action_step_size or 0.0)
         d.clipped_action_penalty = float(self.clipped_action_penalty or 0.0)
         d.npoly, d.npwl, d.nseg = len(poly), len(pwl), nseg
@@ -979,7 +979,7 @@ class BatchedOpfEnv:
                 act = self._center_action                                  # :206
         act = self._as_action(act)
         if self.pf_for_obs:                                                # :209-216
-            self._launch_step(act, mode=0, with_initial_obj=False)
+            self._launch_step(act, mode=4, with_initial_obj=False)
             if not bool(self.buf['converged'].all()):
                 raise RuntimeError('power flow failed in reset for some instances '
                                    '(the reference re-samples recursively, opf_env.py:211-214)')

@@ -1376,6 +1376,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     if (wave == 0) {
       // (no action row in modes 1/3: any readable row keeps the loads unconditional)
       const double* act_row = apply ? io.action + b * E.na : xr;
+      // reset applies its initial action as ABSOLUTE set-points (opf_env.py:207 passes no step size),
+      // and clamps only without autoscaling (:464)
+      const bool as_reset = io.mode == 2 || io.mode == 4;
+      const double diff_step = as_reset ? 0.0 : E.diff_step;
+      const bool clamp = as_reset ? (E.clamp_enabled & 2) != 0 : (E.clamp_enabled & 1) != 0;
       for (int k0 = 0; k0 < E.na; k0 += 2 * WAVE) {
         int slot[2], los[2], his[2], cls_[2], chs[2], kind[2];
         double av[2], sc[2], loc[2], hic[2], clc[2], chc[2];
@@ -1401,9 +1406,9 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
             const double hi = his[u] >= 0 ? xs[his[u]] : hic[u];
             const double delta = hi - lo;
             double spt;
-            if (E.diff_step != 0.0) spt = (a * 2.0 - 1.0) * E.diff_step * delta + xv * sc[u];   // :453-458
+            if (diff_step != 0.0) spt = (a * 2.0 - 1.0) * diff_step * delta + xv * sc[u];       // :453-458
             else spt = a * delta + lo;                                                   // :461
-            if (E.clamp_enabled) {                                                       // :464-470
+            if (clamp) {                                                                 // :464-470
               if (chs[u] > -2) { const double m = chs[u] >= 0 ? xs[chs[u]] : chc[u]; if (spt > m) spt = m; }
               if (cls_[u] > -2) { const double m = cls_[u] >= 0 ? xs[cls_[u]] : clc[u]; if (spt < m) spt = m; }
             }
@@ -2262,7 +2267,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
 
 extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                          int32_t mode, void* stream) {
-  if (!env || !io || !io->x || B < 0 || ((mode == 0 || mode == 2) && env->de.na > 0 && !io->action)) {
+  if (!env || !io || !io->x || B < 0 || mode < 0 || mode > 4 || ((mode == 0 || mode == 2 || mode == 4) && env->de.na > 0 && !io->action)) {
     opfx_set_error("opfx_step: bad argument");
     return OPFX_ERR_INVALID;
   }
