@@ -402,6 +402,12 @@ typedef struct opfx_reset_io {
   double normal_noise_factor;
   double* x;
   const int32_t* mode;       /* [B] data source per instance (0, 1, 2) or NULL = no source selection */
+  /* optional, the reset of an environment whose observation needs no power flow in ONE launch
+   * (opf_env.py:201-207,217-218): with `obs` given the kernel also applies `action` (the initial
+   * action, absolute set-points; NULL = keep the sampled values) and writes the table part of the
+   * observation (result entries NaN) — what opfx_step mode 2 / 3 do in a second launch */
+  const double* action;      /* [B,na] or NULL */
+  double* obs;               /* [B,nobs] or NULL */
 } opfx_reset_io;
 
 int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);

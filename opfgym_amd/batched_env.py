@@ -968,9 +968,6 @@ class BatchedOpfEnv:
                 mode_t = t.as_tensor(np.broadcast_to(np.asarray(mode_t, dtype=np.int32), (B,)).copy()).to(dev)
             rio.mode = mode_t.contiguous().data_ptr()
             self.sampling_mode = mode_t
-        with t.cuda.device(self.device):
-            capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
-        self.step_count.zero_()
         act = options.get('initial_action')
         if act is None:
             if self.initial_action == 'random':                            # :201-203
@@ -978,14 +975,20 @@ class BatchedOpfEnv:
             else:
                 act = self._center_action                                  # :206
         act = self._as_action(act)
+        if not self.pf_for_obs:
+            # no power flow needed for the observation: sampling, initial action and the table
+            # observation in ONE launch (opf_env.py:199-207, 217-218)
+            rio.action = act.data_ptr()
+            rio.obs = self.buf['obs'].data_ptr()
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
+        self.step_count.zero_()
         if self.pf_for_obs:                                                # :209-216
             self._launch_step(act, mode=4, with_initial_obj=False)
             if not bool(self.buf['converged'].all()):
                 raise RuntimeError('power flow failed in reset for some instances '
                                    '(the reference re-samples recursively, opf_env.py:211-214)')
             self.initial_obj.copy_(self.buf['objective'])
-        else:
-            self._launch_step(act, mode=2)
         return self._finish_obs(), {}
 
     def step(self, action):

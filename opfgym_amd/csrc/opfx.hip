@@ -1748,37 +1748,48 @@ struct ResetIO {
   double normal_noise_factor;
   double* x;
   const int* mode;
+  const double* action;      // optional: initial action [B,na] (reset without power flow)
+  double* obs;               // optional: table observation [B,nobs]
 };
 
-__global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long B) {
-  // one wave per instance, 4 instances per workgroup
-  const int lane = threadIdx.x & 63;
-  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long nw = (long long)gridDim.x * 4;
+// One wavefront per instance; the row is built in LDS (template -> profile values -> vector-op
+// programme -> optionally the initial action and the table observation, opf_env.py:201-207,218)
+// and leaves with one coalesced store: the intermediate values never make a round trip through
+// memory and the reset of an environment whose observation needs no power flow is ONE launch.
+__global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
+                                               int row_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  double* const row = smem + (size_t)wib * row_doubles;
+  double* const sp = row + ((R.nx + 1) & ~1);
+  const long long w = (long long)blockIdx.x * wpb + wib;
+  const long long nw = (long long)gridDim.x * wpb;
+  const double NaN = __builtin_nan("");
   for (long long b = w; b < B; b += nw) {
     double* xr = io.x + b * R.nx;
     const int step = io.step_idx[b];
     const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-    if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) xr[j] = R.consts[R.init_off + j];
+    if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) row[j] = R.consts[R.init_off + j];
+    else for (int j = lane; j < R.nx; j += 64) row[j] = xr[j];
+    wave_fence();
     for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
       const DevTable& T = R.tab[t];
-      const double* row = T.rel + (long long)step * T.n_types;
+      const double* rw = T.rel + (long long)step * T.n_types;
       const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
       const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
       for (int j = lane; j < T.n_cols; j += 64) {
-        double v = row[T.typ[j]] * T.peak[j];                                      // :343
-        if (interp) v = v * rr + (row[T.n_types + T.typ[j]] * T.peak[j]) * (1.0 - rr);   // :347-349
+        double v = rw[T.typ[j]] * T.peak[j];                                       // :343
+        if (interp) v = v * rr + (rw[T.n_types + T.typ[j]] * T.peak[j]) * (1.0 - rr);    // :347-349
         if (io.noise) {
           const double nz = io.noise[b * R.n_noise + T.noise_off + j];
           if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz;   // :359-360
           else v = v * nz;                                                          // :354-356
         }
         v = fmin(fmax(v, T.col_min[j]), T.col_max[j]);                              // :364-369
-        xr[T.slot[j]] = v;                                                          // :371-372
+        row[T.slot[j]] = v;                                                         // :371-372
       }
     }
-    // element j of every op is handled by lane j%64, so a value written by one op is
-    // read back by the same thread in a later op (program order suffices).
+    wave_fence();
     for (int k = 0; k < R.n_ops; ++k) {
       if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
       const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
@@ -1788,16 +1799,53 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, ResetIO io, long long
       for (int j = lane; j < n; j += 64) {
         double v;
         if (code == OPFX_OP_SET_CONST) v = c0[j];
-        else if (code == OPFX_OP_AFFINE) v = xr[a + j] * c0[j] + c1[j];
-        else if (code == OPFX_OP_SQRT_DIFF) { const double s = c0[j], pz = xr[a + j]; v = sqrt(s * s - pz * pz); }
-        else if (code == OPFX_OP_NEG) v = -xr[a + j];
+        else if (code == OPFX_OP_AFFINE) v = row[a + j] * c0[j] + c1[j];
+        else if (code == OPFX_OP_SQRT_DIFF) { const double s = c0[j], pz = row[a + j]; v = sqrt(s * s - pz * pz); }
+        else if (code == OPFX_OP_NEG) v = -row[a + j];
         else if (code == OPFX_OP_UNIFORM) { const double u = io.uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
         else if (code == OPFX_OP_NORMAL) v = c0[j] + c1[j] * io.normal[b * R.n_normal + a + j];
-        else if (code == OPFX_OP_CLIP) v = fmin(fmax(xr[a + j], c0[j]), c1[j]);
-        else v = xr[a + j] / c0[j];
-        xr[dst + j] = v;
+        else if (code == OPFX_OP_CLIP) v = fmin(fmax(row[a + j], c0[j]), c1[j]);
+        else v = row[a + j] / c0[j];
+        row[dst + j] = v;
+      }
+      wave_fence();
+    }
+    if (io.obs && Ep) {
+      // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
+      // table part of the observation (:218); result entries are NaN
+      const DevEnv& E = *Ep;
+      for (int k = lane; k < E.na; k += 64) {
+        const int slot = as_global(E.act_slot)[k];
+        double xv = row[slot];
+        if (io.action) {
+          double a = io.action[b * E.na + k];
+          a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
+          const int ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
+          const double lo = ls >= 0 ? row[ls] : as_global(E.act_lo_const)[k];
+          const double hi = hs >= 0 ? row[hs] : as_global(E.act_hi_const)[k];
+          double spt = a * (hi - lo) + lo;                                              // :461
+          if (E.clamp_enabled & 2) {                                                    // :464-470 (autoscale off)
+            const int ch = as_global(E.clamp_hi_slot)[k], cl = as_global(E.clamp_lo_slot)[k];
+            if (ch > -2) { const double m = ch >= 0 ? row[ch] : as_global(E.clamp_hi_const)[k]; if (spt > m) spt = m; }
+            if (cl > -2) { const double m = cl >= 0 ? row[cl] : as_global(E.clamp_lo_const)[k]; if (spt < m) spt = m; }
+          }
+          xv = spt / as_global(E.act_scaling)[k];                                       // :472-474
+          const int kind = as_global(E.act_kind)[k];
+          if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
+        }
+        sp[k] = xv;
+      }
+      wave_fence();          // (limits are read before any set-point is written into the row)
+      for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k];
+      wave_fence();
+      for (int sg = 0; sg < E.n_oseg; ++sg) {
+        const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
+        for (int j = lane; j < n; j += 64)
+          io.obs[b * E.nobs + dst + j] = kind == 1 ? NaN : (kind == 0 ? row[src + j] : sp[src + j]);
       }
     }
+    for (int j = lane; j < R.nx; j += 64) xr[j] = row[j];
+    wave_fence();
   }
 }
 
@@ -2350,9 +2398,19 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   if (env->dr.n_normal > 0 && !io->normal) { opfx_set_error("opfx_reset: normal draws required"); return OPFX_ERR_INVALID; }
   if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(env->ctx->device));
-  const int grid = (int)std::min<long long>((B + 3) / 4, (long long)env->ctx->n_cu * 8);
-  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode};
-  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), env->dr, r, (long long)B);
+  const int na = env->de.na, nx = env->dr.nx;
+  const int row_doubles = ((nx + 1) & ~1) + ((na + 1) & ~1);
+  const size_t row_bytes = (size_t)row_doubles * sizeof(double);
+  if (row_bytes > 160 * 1024) { opfx_set_error("opfx_reset: table row does not fit the LDS"); return OPFX_ERR_TOO_LARGE; }
+  const int wpb = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
+  const size_t lds = wpb * row_bytes;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * 8);
+  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
+            io->action, io->obs};
+  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
+                     (long long)B, row_doubles);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }
