@@ -1165,8 +1165,8 @@ class MultiStageOpfEnv(BatchedOpfEnv):
         return obs, reward, terminated, truncated, info
 
     def _resample_current(self):
-        """reset kernel at self.steps_dev into self.x, then the table observation (mode 2 step
-        with the centre action, as `_sampling` + `_get_obs` do at multi_stage.py:49-56)."""
+        """reset kernel at self.steps_dev into self.x together with the table observation, no action
+        (what `_sampling` + `_get_obs` do at multi_stage.py:49-56) — one launch."""
         B, t = self.B, self.torch
         rio = capi.ResetIO()
         rio.step_idx = self.steps_dev.data_ptr()
@@ -1174,12 +1174,9 @@ class MultiStageOpfEnv(BatchedOpfEnv):
             if self.n_uniform else None
         rio.uniform = uni.data_ptr() if uni is not None else None
         rio.x = self.x.data_ptr()
+        rio.obs = self.buf['obs'].data_ptr()
         with t.cuda.device(self.device):
             capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
-        io = self._io(None, False)
-        with t.cuda.device(self.device):
-            capi.check(capi.lib().opfx_step(self._env_handle, B, C.byref(io), C.byref(self.solve_opts), 3,
-                                            capi._stream()), 'opfx_step')
 
 
 class StochasticObservation:
