@@ -95,14 +95,15 @@ def test_outage_axis():
     assert (np.abs(out['iterations'][ok] - ref['iterations'][ok]) <= 1).all(), (out['iterations'], ref['iterations'])
 
 
-def test_islanding_outage_de_energises_the_island():
+@pytest.mark.parametrize('code', ['1-HV-urban--0-sw', '1-MV-urban--0-sw'])     # wave team / single wave, two-value blocks
+def test_islanding_outage_de_energises_the_island(code):
     """A bridge out of service cuts buses off every slack: pandapower (check_connectivity) takes them
     out of service and solves the rest; their voltages and the loadings of their branches are NaN,
     the outaged branch shows 0 %.  Same in the CPU restatement and in the kernels."""
     import torch
     from opfgym_amd import capi, grids
     from opfgym_amd.case import net_to_case
-    net, _ = grids.get_grid('1-HV-urban--0-sw')
+    net, _ = grids.get_grid(code)
     case = net_to_case(net)
     plan = capi.Plan(case)
     ctx = capi.Context(plan, 0)
