@@ -119,6 +119,7 @@ def run_episodes(name):
             push(key, np.stack(vals))
     out = {k: np.stack(v) for k, v in rec.items()}
     out['n_obs'] = np.array(env.observation_space.shape[0])
+    out['obs_low'], out['obs_high'] = env.observation_space.low, env.observation_space.high
     out['n_act'] = np.array(env.action_space.shape[0])
     out['n_bus'] = np.array(len(env.net.bus))
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
