@@ -45,6 +45,10 @@ SCENARIOS = {
     'vc_normal_mean': ('VoltageControl', dict(
         simbench_network_name='mv-small', train_data='normal_around_mean', test_data='normal_around_mean',
         sampling_params=dict(relative_std=0.3)), 4, 17),
+    # autoscale_violation=False: ext-grid violations scaled by 1/|mean| (constraints.py:179-192), the others not
+    'vc_no_autoscale': ('VoltageControl', dict(
+        simbench_network_name='mv-small', max_q_exchange=0.05,
+        constraint_params=dict(autoscale_violation=False)), 4, 30),
     # train_data='mixed' (opf_env.py:242-251) with the source forced by the probabilities, one scenario each
     'vc_mixed_simbench': ('VoltageControl', dict(
         simbench_network_name='mv-small', train_data='mixed', test_data='mixed',
