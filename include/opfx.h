@@ -98,7 +98,7 @@ typedef struct opfx_plan_info {
   int32_t n_sources;         /* forward update terms                         */
   int32_t n_uterms;          /* backward substitution terms                  */
   int32_t max_level_width;   /* widest level in work items                   */
-  int32_t lds_doubles;       /* solver LDS footprint per instance (doubles)  */
+  int32_t lds_doubles;       /* solver state per instance in LDS (doubles), two-value block storage */
   /* register-resident lane programme (rounds of 64 work items); -1 = not built */
   int32_t lp_rounds_a, lp_rounds_h, lp_rounds_b, lp_rounds_c;
   int32_t n_full;            /* blocks [0,n_full) store 4 values, [n_full,n_blk) two (a,b of [[a,b],[-b,a]]) */

@@ -513,7 +513,12 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->n_sources = (int32_t)p->src_ik.size();
   o->n_uterms = (int32_t)p->u_blk.size();
   o->max_level_width = p->max_level_width;
-  o->lds_doubles = 8 * p->nb + 4 * p->n_blk;
+  {
+    // solver state of the lane-programme kernels with two-value storage of the plain blocks
+    // (vr, vi, rhs, rq + block values; scheduled P/Q live in global memory)
+    const int32_t nbe = (p->nb + 1) & ~1, bs = (p->n_blk + 1) & ~1, nfs = (p->n_full + 1) & ~1;
+    o->lds_doubles = 4 * nbe + 2 * bs + 2 * nfs;
+  }
   o->lp_rounds_a = p->ra; o->lp_rounds_h = p->rh; o->lp_rounds_b = p->rb; o->lp_rounds_c = p->rc;
   return OPFX_OK;
 }

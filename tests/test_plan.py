@@ -98,7 +98,14 @@ def test_plan_structure_invariants(built_lib):
         for e in range(P['y_ptr'][i], P['y_ptr'][i + 1]):
             y[i, P['y_col'][e]] = g[e] + 1j * b[e]
     assert np.abs(y - case.ybus_dense()).max() < 1e-12 * np.abs(y).max()   # summation order only
-    assert info['lds_doubles'] == 8 * nb + 4 * info['n_blk']
+    ev = lambda v: (v + 1) & ~1
+    assert info['lds_doubles'] == 4 * ev(nb) + 2 * ev(info['n_blk']) + 2 * ev(info['n_full'])
+    assert info['n_fill'] <= info['n_full'] <= info['n_blk']
+    # blocks beyond n_full are off-diagonal Jacobian blocks of PQ rows that no update targets
+    tgt = set(int(b) for b in P['tgt_blk'] if b >= 0)
+    for b in range(info['n_full'], info['n_blk']):
+        i, j = int(P['blk_row'][b]), int(P['blk_col'][b])
+        assert i != j and case.bus_type[i] == 1 and b not in tgt and b not in set(P['fill_blk'].tolist())
 
 
 def test_ctx_create_fails_loudly_without_gpu(built_lib):
