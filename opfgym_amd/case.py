@@ -161,28 +161,34 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     tr = net['trafo']
     rows = []  # (root_f, root_t, r, x, bc, ratio, shift, kind, elem_pos, kf_num, kt_num)
     vn = bus_df['vn_kv'].astype(float)
+    bus_pos = {int(b): i for i, b in enumerate(bus_ids)}
+    bus_on = lambda b: in_service_bus[bus_pos[b]]
     if len(ln):
         on = _col(ln, 'in_service', True).astype(bool)
         par = _col(ln, 'parallel', 1.0)
         dfac = _col(ln, 'df', 1.0)
         g_us = _col(ln, 'g_us_per_km', 0.0)
+        num = lambda c: ln[c].to_numpy(float)
+        fbs, tbs = ln['from_bus'].to_numpy().astype(np.int64), ln['to_bus'].to_numpy().astype(np.int64)
+        vn_f, vn_t = vn.reindex(fbs).to_numpy(), vn.reindex(tbs).to_numpy()
+        length = num('length_km')
+        zb = vn_f ** 2 / base
+        r_pu = num('r_ohm_per_km') * length / par / zb
+        x_pu = num('x_ohm_per_km') * length / par / zb
+        b_pu = 2 * np.pi * f_hz * num('c_nf_per_km') * 1e-9 * length * par * zb
+        g_pu = g_us * 1e-6 * length * par * zb
+        imax = num('max_i_ka') * dfac * par
+        with np.errstate(divide='ignore', invalid='ignore'):
+            kf_l = base / (np.sqrt(3.0) * vn_f * imax) * 100.0
+            kt_l = base / (np.sqrt(3.0) * vn_t * imax) * 100.0
         for pos, idx in enumerate(ln.index):
             if not on[pos] or int(idx) in line_off:
                 continue
-            fb, tb = int(ln.at[idx, 'from_bus']), int(ln.at[idx, 'to_bus'])
-            if not (in_service_bus[bus_ids.index(fb)] and in_service_bus[bus_ids.index(tb)]):
+            fb, tb = int(fbs[pos]), int(tbs[pos])
+            if not (bus_on(fb) and bus_on(tb)):
                 continue
-            length = float(ln.at[idx, 'length_km'])
-            zb = vn[fb] ** 2 / base
-            r = float(ln.at[idx, 'r_ohm_per_km']) * length / par[pos] / zb
-            x = float(ln.at[idx, 'x_ohm_per_km']) * length / par[pos] / zb
-            b = 2 * np.pi * f_hz * float(ln.at[idx, 'c_nf_per_km']) * 1e-9 * length * par[pos] * zb
-            g = g_us[pos] * 1e-6 * length * par[pos] * zb
-            bc = b - 1j * g                      # j*bc/2 = (g + jb)/2 per side
-            imax = float(ln.at[idx, 'max_i_ka']) * dfac[pos] * par[pos]
-            kf = base / (np.sqrt(3.0) * vn[fb] * imax) * 100.0
-            kt = base / (np.sqrt(3.0) * vn[tb] * imax) * 100.0
-            rows.append((fb, tb, r, x, bc, 1.0, 0.0, KIND_LINE, pos, kf, kt))
+            bc = b_pu[pos] - 1j * g_pu[pos]      # j*bc/2 = (g + jb)/2 per side
+            rows.append((fb, tb, r_pu[pos], x_pu[pos], bc, 1.0, 0.0, KIND_LINE, pos, kf_l[pos], kt_l[pos]))
     if len(tr):
         on = _col(tr, 'in_service', True).astype(bool)
         par = _col(tr, 'parallel', 1.0)
@@ -195,7 +201,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             if not on[pos] or int(idx) in trafo_off:
                 continue
             hb, lb = int(tr.at[idx, 'hv_bus']), int(tr.at[idx, 'lv_bus'])
-            if not (in_service_bus[bus_ids.index(hb)] and in_service_bus[bus_ids.index(lb)]):
+            if not (bus_on(hb) and bus_on(lb)):
                 continue
             sn = float(tr.at[idx, 'sn_mva'])
             vn_hv, vn_lv = float(tr.at[idx, 'vn_hv_kv']), float(tr.at[idx, 'vn_lv_kv'])
@@ -261,8 +267,8 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             continue
         alive.add(a)
         stack.extend(adj.get(a, ()))
-    alive = {r for r in alive if any(
-        in_service_bus[i] for i, b in enumerate(bus_ids) if roots[b] == r)}
+    live_roots = {roots[b] for i, b in enumerate(bus_ids) if in_service_bus[i]}
+    alive &= live_roots
     order = sorted(alive)
     root_to_case = {r: i for i, r in enumerate(order)}
     bus_lookup = {b: root_to_case[roots[b]] for i, b in enumerate(bus_ids)
