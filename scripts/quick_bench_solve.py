@@ -21,6 +21,9 @@ if os.environ.get('OUTAGE'):
     from helpers import non_bridge_branches
     cand = non_bridge_branches(case)
     kw['outage'] = torch.tensor(cand[np.arange(B) % len(cand)].astype(np.int32), device=dev)
+for k_, cast in (('tol', float), ('max_iter', int)):
+    if os.environ.get(k_.upper()):
+        kw[k_] = cast(os.environ[k_.upper()])
 for _ in range(3):
     out = capi.solve(ctx, pt, qt, **kw)
 torch.cuda.synchronize()
