@@ -779,11 +779,16 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
     }
     OPFX_STAMP(12);
-    nrm = wave_max_dpp(my);
-    OPFX_STAMP(1);
-    if (!(nrm == nrm)) { conv = false; break; }
-    if (nrm < o.tol) { conv = true; break; }
-    if (it >= o.max_iter) { conv = false; break; }
+    // the wave-uniform decisions are votes (two instructions each); the max reduction (~45
+    // instructions) runs once, on the way out.  Same outcome as testing the reduced norm:
+    // NaN anywhere -> not converged; every row below tol -> converged; else iterate to max_iter.
+    const bool below = !wave_any(!(my < o.tol));               // (false if any lane holds a NaN)
+    if (below || wave_any(my != my) || it >= o.max_iter) {
+      nrm = wave_max_dpp(my);
+      conv = below;
+      OPFX_STAMP(1);
+      break;
+    }
     ++it;
     wave_fence();
     // ---- phase B: block LU + forward substitution; phase C: back substitution ---------------
@@ -805,10 +810,10 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
     {
-      double big = 0.0;
+      bool large = false;
       for (int i = lane; i < nb; i += WAVE)
-        if (L.bt[i] != BT_REF) big = fmax(big, fabs(L.rhs[i]));      // (rhs of REF rows is never written)
-      const bool small = !(wave_max_dpp(big) > 0.25);          // wave-uniform (false for NaN too)
+        if (L.bt[i] != BT_REF) large = large || !(fabs(L.rhs[i]) <= 0.25);   // (rhs of REF rows is never written; NaN counts as large)
+      const bool small = !wave_any(large);                      // wave-uniform
       for (int i = lane; i < nb; i += WAVE) {
         if (L.bt[i] == BT_REF) continue;
         const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
