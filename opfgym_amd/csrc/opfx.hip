@@ -241,6 +241,7 @@ struct Lds {
 };
 // Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
 // (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
+__device__ __forceinline__ int blk_c(const Lds& L, int id, int c) { return id + (c == 0 ? 0 : c == 1 ? L.bs : c == 2 ? L.o2 : L.o3); }
 template <bool PK>
 __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
   const double* p = L.blk + id;
@@ -456,6 +457,61 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 #define OPFX_STAMP(slot) do { } while (0)
 #endif
 
+#ifdef OPFX_ROUNDPROBE
+// Diagnostic build (-DOPFX_ROUNDPROBE, scripts/probe_round.py): the factor item cut into segments by
+// cycle-counter reads that drain the LDS queue (descriptor wait | LDS reads | FP64 | LDS atomics), summed
+// over workgroup 0, plus a few LDS microbenchmarks at the start of newton2 (sized for the 144-bus grid).
+// Serialising the segments removes the overlap of the product code; the proportions are what it is for.
+__device__ unsigned long long g_probe[16];
+__device__ __forceinline__ unsigned long long clk_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t = __builtin_readcyclecounter();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return t;
+}
+template <bool PK>
+__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const unsigned long long t0 = clk_sync();
+  asm volatile("" :: "v"(d.x), "v"(d.y));
+  const unsigned long long t1 = clk_sync();
+  const unsigned tb = d.x & 0xFFFF;
+  Blk bi{0,0,0,0}, bk{1,0,0,1}, bj{0,0,0,0};
+  double r1 = 0, r2 = 0;
+  if (tb != NONE) {
+    bi = ld_blk2<PK>(L, d.x >> 16);
+    bk = ld_blk2<PK>(L, d.y & 0xFFFF);
+    if (tb & 0x8000u) { const int k = d.y >> 16; r1 = L.rhs[k]; r2 = L.rq[k]; }
+    else bj = ld_blk2<PK>(L, d.y >> 16);
+  }
+  asm volatile("" : "+v"(bi.a11), "+v"(bi.a12), "+v"(bi.a21), "+v"(bi.a22), "+v"(bk.a11), "+v"(bk.a12), "+v"(bk.a21), "+v"(bk.a22));
+  asm volatile("" : "+v"(bj.a11), "+v"(bj.a12), "+v"(bj.a21), "+v"(bj.a22), "+v"(r1), "+v"(r2));
+  const unsigned long long t2 = clk_sync();
+  const double nrdet = fast_rcp(bk.a12 * bk.a21 - bk.a11 * bk.a22);
+  const double m11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * nrdet;
+  const double m12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * nrdet;
+  const double m21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * nrdet;
+  const double m22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * nrdet;
+  const double u11 = m11 * bj.a11 + m12 * bj.a21, u12 = m11 * bj.a12 + m12 * bj.a22;
+  const double u21 = m21 * bj.a11 + m22 * bj.a21, u22 = m21 * bj.a12 + m22 * bj.a22;
+  const double w1 = m11 * r1 + m12 * r2, w2 = m21 * r1 + m22 * r2;
+  asm volatile("" :: "v"(u11), "v"(u12), "v"(u21), "v"(u22), "v"(w1), "v"(w2));
+  const unsigned long long t3 = clk_sync();
+  if (tb != NONE) {
+    if (tb & 0x8000u) { const int i = tb & 0x7FFF; lds_add(&L.rhs[i], w1); lds_add(&L.rq[i], w2); }
+    else {
+      lds_add(L.blk + blk_c(L, tb, 0), u11); lds_add(L.blk + blk_c(L, tb, 1), u12);
+      lds_add(L.blk + blk_c(L, tb, 2), u21); lds_add(L.blk + blk_c(L, tb, 3), u22);
+    }
+  }
+  const unsigned long long t4 = clk_sync();
+  const unsigned long long t5 = clk_sync();
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {
+    atomicAdd(&g_probe[0], t1 - t0); atomicAdd(&g_probe[1], t2 - t1); atomicAdd(&g_probe[2], t3 - t2);
+    atomicAdd(&g_probe[3], t4 - t3); atomicAdd(&g_probe[4], t5 - t4); atomicAdd(&g_probe[5], 1ull);
+  }
+}
+#else
 template <bool PK>
 __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
@@ -476,13 +532,14 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
     lds_add(&L.rq[i], m21 * r1 + m22 * r2);
   } else {
     const Blk bj = ld_blk2<PK>(L, d.y >> 16);
-    double* tp = L.blk + tb;
-    lds_add(tp, m11 * bj.a11 + m12 * bj.a21);
-    lds_add(tp + L.bs, m11 * bj.a12 + m12 * bj.a22);
-    lds_add(tp + L.o2, m21 * bj.a11 + m22 * bj.a21);
-    lds_add(tp + L.o3, m21 * bj.a12 + m22 * bj.a22);
+    lds_add(L.blk + blk_c(L, tb, 0), m11 * bj.a11 + m12 * bj.a21);
+    lds_add(L.blk + blk_c(L, tb, 1), m11 * bj.a12 + m12 * bj.a22);
+    lds_add(L.blk + blk_c(L, tb, 2), m21 * bj.a11 + m22 * bj.a21);
+    lds_add(L.blk + blk_c(L, tb, 3), m21 * bj.a12 + m22 * bj.a22);
   }
 }
+
+#endif
 
 template <bool PK>
 __device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
@@ -620,13 +677,12 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   lds_add(&L.rhs[i], -(dcr + dyr));        // rhs = -F
   if (!pv) lds_add(&L.rq[i], -(dci + dyi));
   if (ob >= 0) {                           // dS_i/dth_j = -j c, dS_i/dln|V_j| = c
-    double* p = L.blk + ob;
-    lds_add(p, dci); lds_add(p + L.bs, dcr);
-    if (!pv && ob < L.nfull) { lds_add(p + L.o2, -dcr); lds_add(p + L.o3, dci); }   // (two-value blocks: implied)
+    lds_add(L.blk + blk_c(L, ob, 0), dci); lds_add(L.blk + blk_c(L, ob, 1), dcr);
+    if (!pv && ob < L.nfull) { lds_add(L.blk + blk_c(L, ob, 2), -dcr); lds_add(L.blk + blk_c(L, ob, 3), dci); }   // (two-value blocks: implied)
   }
-  double* p = L.blk + db;                  // {-S_off.im, Y|V|^2.re + P, S_off.re, Y|V|^2.im + Q}
-  lds_add(p, -dci); lds_add(p + L.bs, 2.0 * dyr + dcr);
-  if (!pv) { lds_add(p + L.o2, dcr); lds_add(p + L.o3, 2.0 * dyi + dci); }
+  // {-S_off.im, Y|V|^2.re + P, S_off.re, Y|V|^2.im + Q}
+  lds_add(L.blk + blk_c(L, db, 0), -dci); lds_add(L.blk + blk_c(L, db, 1), 2.0 * dyr + dcr);
+  if (!pv) { lds_add(L.blk + blk_c(L, db, 2), dcr); lds_add(L.blk + blk_c(L, db, 3), 2.0 * dyi + dci); }
 }
 
 // current injected at bus i by the modifiers: I_i += dY_ii V_i + dY_ij V_j
@@ -665,6 +721,58 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
+#ifdef OPFX_ROUNDPROBE
+  if (blockIdx.x == 0) {   // calibration of the tick: dependent FMA chain, LDS throughput, LDS dependent chain
+    double x = L.vr[lane & 7] * 1e-9 + 1.0;
+    unsigned long long c0 = clk_sync();
+#pragma unroll 1
+    for (int k = 0; k < 32; ++k) { x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9;
+                                   x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; }
+    asm volatile("" :: "v"(x));
+    unsigned long long c1 = clk_sync();
+    double acc = 0.0;
+    const double* base = L.vr + ((lane * 37) & 127);            // scattered 8-byte reads
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += base[(k * 5) & 15];
+    asm volatile("" :: "v"(acc));
+    unsigned long long c2 = clk_sync();
+    int idx = lane & 15;
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) idx = (int)(L.bt[idx & 63] & 15) + (lane & 3);   // dependent LDS byte reads
+    asm volatile("" :: "v"(idx));
+    unsigned long long c3 = clk_sync();
+    // more LDS microbenchmarks (16 independent reads each, summed): b128 linear, b64 random, b128 random, b64 linear stride-1
+    unsigned long long e[5];
+    {
+      double a2 = 0.0;
+      e[0] = clk_sync();
+      { const double2* b2 = reinterpret_cast<const double2*>(L.vr) + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const double2 v = b2[64 * (k & 3) + (k >> 2)]; a2 += v.x + v.y; } }
+      asm volatile("" :: "v"(a2));
+      e[1] = clk_sync();
+      { unsigned h = lane * 2654435761u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h = h * 1664525u + 1013904223u; a2 += L.vr[(h >> 8) & 1023]; } }
+      asm volatile("" :: "v"(a2));
+      e[2] = clk_sync();
+      { unsigned h = lane * 2654435761u; const double2* b2 = reinterpret_cast<const double2*>(L.vr);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h = h * 1664525u + 1013904223u; const double2 v = b2[(h >> 8) & 511]; a2 += v.x + v.y; } }
+      asm volatile("" :: "v"(a2));
+      e[3] = clk_sync();
+      {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a2 += L.vr[lane + 64 * k]; }
+      asm volatile("" :: "v"(a2));
+      e[4] = clk_sync();
+      if (a2 == 12345.678) L.vr[1] = a2;
+    }
+    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&g_probe[10 + k], e[k + 1] - e[k]); }
+    if (lane == 0) { atomicAdd(&g_probe[6], c1 - c0); atomicAdd(&g_probe[7], c2 - c1); atomicAdd(&g_probe[8], c3 - c2); atomicAdd(&g_probe[9], 1ull); }
+    if (x + acc + idx == 12345.678) L.vr[0] = x;
+  }
+#endif
   OPFX_STAMP_INIT();
   ARound cur = load_around(P, 0, lane);
   // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
@@ -2040,6 +2148,13 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
 }
 
 extern "C" void opfx_ctx_destroy(opfx_ctx* ctx) { delete ctx; }
+#ifdef OPFX_ROUNDPROBE
+extern "C" int opfx_debug_read_probe(unsigned long long* out) {     // read and clear
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
                           const double* qg_min, const double* qg_max, const int32_t* outage,
