@@ -151,7 +151,9 @@ void opfx_version(int* major, int* minor, int* patch);
  * p.u. (NULL = unlimited) are the generator capability used by enforce_q_lims.
  * outage: NULL (all branches in service) or [B] int32: the one branch that is
  * out of service in that instance, -1 = none — the N-1 axis of
- * security_constrained.py:44-66. */
+ * security_constrained.py:44-66.
+ * B = 0 (an empty batch) is a no-op that returns OPFX_OK for opfx_solve, opfx_step and
+ * opfx_reset alike; the batch buffers may then be NULL. */
 typedef struct opfx_solve_opts {
   double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
   int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */

@@ -2164,8 +2164,8 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                           const opfx_solve_opts* opts, double* vm, double* va, double* loading,
                           double* s_ref, double* q_gen, uint8_t* converged, int32_t* iterations,
                           double* max_mismatch, void* stream) {
+  if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
-  if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
@@ -2438,11 +2438,11 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
 
 extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                          int32_t mode, void* stream) {
+  if (env && io && B == 0 && mode >= 0 && mode <= 4) return OPFX_OK;       // empty batch (buffers may be null)
   if (!env || !io || !io->x || B < 0 || mode < 0 || mode > 4 || ((mode == 0 || mode == 2 || mode == 4) && env->de.na > 0 && !io->action)) {
     opfx_set_error("opfx_step: bad argument");
     return OPFX_ERR_INVALID;
   }
-  if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(env->ctx->device));
   return do_step(env, B, io, opts, mode, stream);
 }
@@ -2513,6 +2513,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
 }
 
 extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream) {
+  if (env && env->has_reset && io && B == 0) return OPFX_OK;               // empty batch (buffers may be null)
   if (!env || !env->has_reset || !io || !io->step_idx || !io->x || B < 0) {
     opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
     return OPFX_ERR_INVALID;

@@ -65,6 +65,32 @@ def test_full_batch_properties():
     assert (vm2[:4] == vm2[4:8]).all() and (vm2[:4] == vm2[28:]).all()
 
 
+@pytest.mark.parametrize('B', [1, 3, 2049 * 3 + 5])
+def test_ragged_batches_give_the_same_rows(B):
+    """Batch sizes that are not a multiple of the persistent grid (2048 workgroups on the 144-bus
+    grid), and tiny ones: every row equals, bit for bit, the row of the same inputs in a batch of
+    another size (one wavefront per instance, no cross-instance state), and empty batches are a no-op."""
+    import torch
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = grids.get_grid('1-MV-urban--0-sw')
+    case = net_to_case(net)
+    ctx = capi.Context(capi.Plan(case), 0)
+    p, q = random_injections(net, case, B, 3)
+    dev = torch.device('cuda:0')
+    full = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
+    assert full['converged'].astype(bool).all() and full['vm'].shape == (B, case.nb)
+    pick = np.unique(np.r_[0, B - 1, np.arange(0, B, 613)])
+    part = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p[pick], device=dev), torch.tensor(q[pick], device=dev)).items()}
+    for k in ('vm', 'va', 'loading', 's_ref', 'iterations', 'max_mismatch'):
+        assert (full[k][pick] == part[k]).all(), k
+    ref = oracle_batch(case, p[pick[:4]], q[pick[:4]])
+    assert np.abs(part['vm'][:4] - ref['vm']).max() < TOL_V
+    empty = capi.solve(ctx, torch.zeros((0, case.nb), dtype=torch.float64, device=dev),
+                       torch.zeros((0, case.nb), dtype=torch.float64, device=dev))
+    assert empty['vm'].shape[0] == 0
+
+
 def test_outage_axis():
     """N-1 axis: one branch out of service per instance (meshed HV grid)."""
     import torch
