@@ -719,12 +719,6 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   const int fill_lo = P.fill_lo;                           // fill blocks: ids [fill_lo, fill_lo + nfill) (plan.cpp)
 
   int it = 0;
-  // bus types of this lane's rows (rows lane + 64 r), constant during the iterations: four bits
-  // each in one register instead of an LDS byte read per row and phase (rows beyond 8 rounds:
-  // read from LDS as before)
-  unsigned btpk = 0;
-  for (int r = 0; r < 8; ++r) { const int i = lane + WAVE * r; if (i < nb) btpk |= (unsigned)L.bt[i] << (4 * r); }
-  auto row_type = [&](int r, int i) -> int { return r < 8 ? (int)((btpk >> (4 * r)) & 15u) : (int)L.bt[i]; };
   double nrm = 0.0;
   bool conv = false;
 #ifdef OPFX_ROUNDPROBE
@@ -833,7 +827,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       }
       const int i = lane + WAVE * r;
       if (i < nb) {
-        const int t = row_type(r, i);
+        const int t = L.bt[i];
         const double vri = L.vr[i], vii = L.vi[i];
         double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
         if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
@@ -924,12 +918,15 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
     {
-      for (int r = 0, i = lane; i < nb; i += WAVE, ++r) {
-        if (row_type(r, i) == BT_REF) continue;                 // (rhs of REF rows is never written)
+      bool large = false;
+      for (int i = lane; i < nb; i += WAVE)
+        if (L.bt[i] != BT_REF) large = large || !(fabs(L.rhs[i]) <= 0.25);   // (rhs of REF rows is never written; NaN counts as large)
+      const bool small = !wave_any(large);                      // wave-uniform
+      for (int i = lane; i < nb; i += WAVE) {
+        if (L.bt[i] == BT_REF) continue;
         const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
         double sn, cs;
-        // (a divergent branch: the library path is skipped as a whole unless some lane needs it)
-        if (fabs(dth) <= 0.25) {
+        if (small) {
           // |dth| <= 0.25: Taylor series to x^15 / x^14, truncation error < 1e-21
           const double z = dth * dth;
           sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
