@@ -173,8 +173,9 @@ def main():
                          'fp64_vector_peak_tflops': 78.6,
                          'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory '
                                  'once per NR phase) x 8192 / kernel time; the kernel keeps that state in LDS, '
-                                 'so real HBM traffic is ~ io_bytes per instance; the kernel is bound by '
-                                 'instruction issue (profiles/*_sq_counters.txt), see DESIGN.md'},
+                                 'so real HBM traffic is ~ io_bytes per instance; the kernel is bound by what one '
+                                 'wave gets through (dependent issue, LDS return rate) at 2 waves per SIMD '
+                                 '(profiles/*_sq_counters.txt, DESIGN.md)'},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
