@@ -400,6 +400,17 @@ class BatchedOpfEnv:
         self.mixed = 'mixed' in modes and 'noise_factor' not in self.sampling_params     # (:231 comes first)
         if 'mixed' in modes and len(modes) > 1:
             raise NotImplementedError("'mixed' must be both the train and the test distribution")
+        # Data source per distribution: 0 profile row (+noise), 1 uniform in the data range, 2 normal around
+        # the mean (opf_env.py:231-241; a `noise_factor` in sampling_params sends EVERY distribution down the
+        # profile path, :231).  Train and test distribution may differ (the reference's default is
+        # test_data='simbench' whatever train_data is): the ops of each source are then compiled with the
+        # source they run under, as for 'mixed', and a reset runs all its instances in the source of the
+        # distribution it samples from.
+        src = {'simbench': 0, 'noisy_simbench': 0, 'full_uniform': 1, 'normal_around_mean': 2}
+        force0 = 'noise_factor' in self.sampling_params
+        self.source_of = {d: (0 if force0 else src[d]) for d in modes if d != 'mixed'}
+        self.per_source = self.mixed or len(set(self.source_of.values())) > 1
+        sources = {0, 1, 2} if self.mixed else set(self.source_of.values())
         self.data_probabilities = tuple(self.sampling_params.get('data_probabilities', (0.5, 0.75, 1.0)))
         self.noise_factor = float(self.sampling_params.get('noise_factor', 0.1 if self.mixed else 0.0))   # :318 default
         if 'noisy_simbench' in modes and 'noise_factor' not in self.sampling_params:
@@ -407,7 +418,7 @@ class BatchedOpfEnv:
         self.noise_distribution = self.sampling_params.get('noise_distribution', 'uniform')
         assert self.noise_distribution in ('uniform', 'normal')
         self.interpolate_steps = bool(self.sampling_params.get('interpolate_steps', False))
-        self.uses_profiles = bool(modes & {'simbench', 'noisy_simbench', 'mixed'})
+        self.uses_profiles = 0 in sources
         if self.uses_profiles:
             for key in self.profiles.keys():                               # opf_env.py:339-372
                 df = self.profiles[key]
@@ -418,11 +429,8 @@ class BatchedOpfEnv:
                 slots = self.store.slots(unit, col, df.columns, dynamic=True)
                 self.tables.append(dict(rel=rel, typ=typ, peak=peak, slot=slots,
                                         col_min=df.min().to_numpy(float), col_max=df.max().to_numpy(float)))
-        if len(modes) > 1 and modes & {'full_uniform', 'normal_around_mean', 'mixed'}:
-            raise NotImplementedError('different train/test distributions are only supported among the '
-                                      'simbench variants')
-        if 'normal_around_mean' in modes or self.mixed:                    # opf_env.py:286-315
-            self.ops.mode_mask = 4 if self.mixed else 7
+        if 2 in sources:                                                   # opf_env.py:286-315
+            self.ops.mode_mask = 4 if self.per_source else 7
             if self.sampling_params.get('truncated'):
                 raise NotImplementedError('truncated normal sampling (scipy.stats.truncnorm) is not supported')
             rel = self.sampling_params.get('relative_std')
@@ -438,8 +446,8 @@ class BatchedOpfEnv:
                 std = rel * diff if rel else df[f'std_dev_{col}'].to_numpy(float)[rows]
                 _normal_and_clip(self.ops, unit, col, idxs, df[f'mean_{col}'].to_numpy(float)[rows],
                                  std * diff, lo, hi)                         # (std * diff as at :312)
-        if 'full_uniform' in modes or self.mixed:
-            self.ops.mode_mask = 2 if self.mixed else 7
+        if 1 in sources:
+            self.ops.mode_mask = 2 if self.per_source else 7
             for unit, col, idxs in self.state_keys:                        # opf_env.py:253-284
                 if 'res_' in unit:
                     continue
@@ -826,7 +834,7 @@ class BatchedOpfEnv:
         r.n_consts, r.consts = len(consts), _keep(keep, consts, 'd')
         r.n_uniform = self.ops.n_uniform
         r.n_normal = self.ops.n_normal
-        if self.mixed:
+        if self.per_source:
             r.op_mode = _keep(keep, [op[7] for op in self.ops.ops], 'i')
         r.init_off = 0
         capi.check(capi.lib().opfx_env_set_reset(self._env_handle, C.byref(r)), 'opfx_env_set_reset')
@@ -890,12 +898,43 @@ class BatchedOpfEnv:
     def reset(self, seed=None, options=None):
         """opf_env.py:177-220 for the whole batch.  options: 'test' (bool),
         'step' (int or [B] array), plus 'noise' [B,n_noise] / 'uniform'
-        [B,n_uniform] / 'initial_action' [B,na] to replay explicit draws."""
+        [B,n_uniform] / 'initial_action' [B,na] to replay explicit draws.
+
+        When the observation needs a power flow (`pf_for_obs`) and it fails for some instances, those
+        instances are sampled again with fresh random draws until they converge — the reference's
+        `return self.reset()` (opf_env.py:211-214), per row: the others keep their state."""
         t = self.torch
         if seed is not None:
             self.np_random = np.random.default_rng(seed)
             self._gen.manual_seed(int(seed))
         options = options or {}
+        self._sample_and_initialise(options)
+        if self.pf_for_obs and not bool(self.buf['converged'].all()):
+            ok = self.buf['converged'].clone()
+            state = lambda: [self.x, self.steps_dev, self.initial_obj] + \
+                ([self.sampling_mode] if self.per_source else []) + list(self.buf.values())
+            for _ in range(self.max_reset_retries):
+                saved = [v.clone() for v in state()]
+                self._sample_and_initialise({'test': self.test})           # fresh steps and draws for every row
+                again = ~ok                                                # rows that take the new sample
+                for cur, old in zip(state(), saved):
+                    sel = again.view(-1, *([1] * (cur.dim() - 1)))
+                    cur.copy_(t.where(sel, cur, old))
+                ok = ok | self.buf['converged']                            # (kept rows carry their old flag = True)
+                self.current_simbench_step = None
+                if bool(ok.all()):
+                    break
+            else:
+                raise RuntimeError(f'power flow failed in reset for some instances after '
+                                   f'{self.max_reset_retries} new samples (opf_env.py:211-214)')
+        return self._finish_obs(), {}
+
+    max_reset_retries = 20
+
+    def _sample_and_initialise(self, options):
+        """One pass of opf_env.py:196-216 for every row: sample the state, apply the initial action, run
+        the power flow when the observation needs it (convergence flags in buf['converged'])."""
+        t = self.torch
         B = self.B
         dev = self.device
         self.test = bool(options.get('test', False))
@@ -968,6 +1007,10 @@ class BatchedOpfEnv:
                 mode_t = t.as_tensor(np.broadcast_to(np.asarray(mode_t, dtype=np.int32), (B,)).copy()).to(dev)
             rio.mode = mode_t.contiguous().data_ptr()
             self.sampling_mode = mode_t
+        elif self.per_source:                                              # train and test distribution differ
+            mode_t = t.full((B,), self.source_of[data_distr], dtype=t.int32, device=dev)
+            rio.mode = mode_t.data_ptr()
+            self.sampling_mode = mode_t
         act = options.get('initial_action')
         if act is None:
             if self.initial_action == 'random':                            # :201-203
@@ -985,11 +1028,7 @@ class BatchedOpfEnv:
         self.step_count.zero_()
         if self.pf_for_obs:                                                # :209-216
             self._launch_step(act, mode=4, with_initial_obj=False)
-            if not bool(self.buf['converged'].all()):
-                raise RuntimeError('power flow failed in reset for some instances '
-                                   '(the reference re-samples recursively, opf_env.py:211-214)')
             self.initial_obj.copy_(self.buf['objective'])
-        return self._finish_obs(), {}
 
     def step(self, action):
         """opf_env.py:374-419 for the whole batch: (obs, reward, terminated,
@@ -1173,6 +1212,11 @@ class MultiStageOpfEnv(BatchedOpfEnv):
         uni = t.rand(B, self.n_uniform, generator=self._gen, device=self.device, dtype=t.float64) \
             if self.n_uniform else None
         rio.uniform = uni.data_ptr() if uni is not None else None
+        nrm = t.randn(B, self.n_normal, generator=self._gen, device=self.device, dtype=t.float64) \
+            if self.n_normal else None
+        rio.normal = nrm.data_ptr() if nrm is not None else None
+        if self.per_source:
+            rio.mode = self.sampling_mode.data_ptr()                       # the sources the episode started with
         rio.x = self.x.data_ptr()
         rio.obs = self.buf['obs'].data_ptr()
         with t.cuda.device(self.device):

@@ -386,12 +386,16 @@ class EnvOracle:
         except pf_oracle.LoadflowNotConverged:
             return False
 
-    def reset(self, step, uniform=(), noise=None, initial_action=None, interp=None, normal=()):
+    def reset(self, step, uniform=(), noise=None, initial_action=None, interp=None, normal=(), data=None):
+        """`data`: the distribution to sample from when it is not the training one (the reference picks
+        test_data for reset(options={'test': True}), opf_env.py:226)."""
         self.net = copy.deepcopy(self.base_net)
         self.step_in_episode = 0
         self.current_step = step
         draws = iter(np.asarray(uniform, float))
-        data = self.data
+        data = data or self.data
+        if 'noise_factor' in self.sampling_params and data != 'mixed':      # opf_env.py:231 comes first
+            data = 'noisy_simbench'
         if data == 'mixed' and 'noise_factor' not in self.sampling_params:  # opf_env.py:242-251
             r = float(np.asarray(interp, float).ravel()[0])                 # the first draw of the reset (:244)
             probs = self.sampling_params.get('data_probabilities', (0.5, 0.75, 1.0))

@@ -334,6 +334,62 @@ def test_mixed_sampling_draws_a_source_per_instance():
     assert _np(out[4]['converged']).mean() > 0.95
 
 
+@pytest.mark.parametrize('train,test', [('full_uniform', 'simbench'), ('normal_around_mean', 'noisy_simbench'),
+                                        ('noisy_simbench', 'full_uniform')])
+def test_train_and_test_distributions_may_differ(train, test):
+    """The reference samples from train_data, or from test_data for reset(options={'test': True})
+    (opf_env.py:226-241; its default test_data is 'simbench' whatever the training distribution is):
+    both kinds of reset on one environment equal the oracle sampling from that distribution."""
+    B = 12
+    kw = dict(train_data=train, test_data=test)
+    env = product_env('vc_mv_small', batch_size=B, **kw)
+    orc = oracle_env('vc_mv_small', product_env('vc_mv_small', defer_device=True, **kw))
+    rng = np.random.default_rng(5)
+    for is_test, distr in ((False, train), (True, test), (False, train)):
+        pool = env.test_steps if is_test else env.train_steps
+        steps = rng.choice(pool, B)
+        uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+        normal = rng.standard_normal((B, env.n_normal)) if env.n_normal else None
+        noise = rng.random((B, env.n_noise)) * 0.2 + 0.9 if distr == 'noisy_simbench' else None
+        obs0, _ = env.reset(options={'step': steps, 'uniform': uniform, 'normal': normal, 'noise': noise,
+                                     'test': is_test})
+        obs0 = _np(obs0).copy()
+        actions = rng.random((B, env.n_actions))
+        out = env.step(actions)
+        for k in range(B):
+            ob = orc.reset(int(steps[k]), uniform[k] if uniform is not None else (),
+                           noise[k] if noise is not None else None,
+                           normal=normal[k] if normal is not None else (), data=distr)
+            assert np.allclose(obs0[k], ob, rtol=0, atol=R_TOL), (distr, k)
+            ref = orc.step(actions[k])
+            assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+            if ref['converged']:
+                _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+
+
+def test_reset_resamples_rows_whose_power_flow_fails():
+    """opf_env.py:209-214: a failed power flow in reset() makes the reference sample again.  Per row here:
+    instances that converged keep their first sample, the others get fresh draws until they converge."""
+    import torch
+    B = 512
+    kw = dict(add_res_obs=True, train_data='normal_around_mean', test_data='normal_around_mean')
+    env = product_env('qm_mv_small', batch_size=B, **kw)
+    env._gen.manual_seed(123)
+    env._sample_and_initialise({})
+    ok0 = env.buf['converged'].clone()
+    assert 0 < int((~ok0).sum()) < B // 2, 'the scenario is expected to contain a few non-convergent samples'
+    x0 = env.x.clone()
+    obs, _ = env.reset(seed=123)
+    assert bool(env.buf['converged'].all()) and bool(torch.isfinite(obs).all())
+    assert bool((env.x[ok0] == x0[ok0]).all())                  # converged rows: untouched
+    assert bool((env.x[~ok0] != x0[~ok0]).any(dim=1).all())      # the others: a new sample each
+    out = env.step(np.random.default_rng(0).random((B, env.n_actions)))
+    assert np.isfinite(_np(out[1])[_np(out[4]['converged'])]).all()
+    env.max_reset_retries = 0
+    with pytest.raises(RuntimeError, match='power flow failed in reset'):
+        env.reset(seed=123)
+
+
 def test_n_minus_one_with_an_islanding_contingency():
     """A contingency that cuts buses off the slack: pandapower de-energises them and evaluates the
     constraints on the rest (NaN values never violate); so do the oracle and the kernel."""
