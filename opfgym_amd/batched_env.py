@@ -81,6 +81,7 @@ class OpsBuilder:
         self.store = store
         self.ops = []          # (code, dst, a, n, c0, c1, c2) with c* numpy vectors or None
         self.n_uniform = 0
+        self.uniform_runs = []     # (first column, count, source mask) of every uniform op
         self.n_normal = 0
         self.mode_mask = 7     # data sources under which the ops added next run ('mixed' sampling)
 
@@ -133,8 +134,16 @@ class OpsBuilder:
         rows = self.store.rows(table, idxs)
         dst = self._all(table, col, rows, True)
         src = self.n_uniform + np.arange(len(rows))
+        self.uniform_runs.append((self.n_uniform, len(rows), self.mode_mask))
         self.n_uniform += len(rows)
         self._emit(capi.OP_UNIFORM, dst, src, c0=lo, c1=hi, c2=scale)
+
+    def uniform_columns(self, source: int):
+        """Columns of the [B, n_uniform] draw matrix that a reset under data source `source` consumes, in
+        the order the reference would draw them (the matrix has one fixed column per op whatever the
+        source; the reference draws sequentially and only what the source needs)."""
+        cols = [np.arange(s, s + n) for s, n, mask in self.uniform_runs if (mask >> source) & 1]
+        return np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
 
 
 def _normal_and_clip(ops, table, col, idxs, mean, std, lo, hi):

@@ -1628,7 +1628,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     }
     if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true, 0); ++n_mod_base; }
     if (base_out >= 0) { ++n_rem_base; if (P.br_island[base_out]) isl_br_base = base_out; }
-    for (int c = 0; c <= E.n_cont; ++c) {
+    // (a reset runs the base case only: the reference's reset calls run_power_flow, opf_env.py:209-216;
+    // the N-1 loop belongs to calculate_violations, security_constrained.py:37)
+    const int n_cont_run = (io.mode == 2 || io.mode == 4) ? 0 : E.n_cont;
+    for (int c = 0; c <= n_cont_run; ++c) {
       const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
       int n_mod = n_mod_base;

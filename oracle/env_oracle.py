@@ -185,10 +185,15 @@ def apply_actions(net, act_keys, action, autoscale=True, diff_step=None):
         else:
             sp = a * (hi - lo) + lo                                         # :461
         if not autoscale or diff_step:                                      # :464-470
-            if f'max_{col}' in df.columns:
-                sp = np.minimum(sp, df[f'max_{col}'].loc[idxs].to_numpy(float))
-            if f'min_{col}' in df.columns:
-                sp = np.maximum(sp, df[f'min_{col}'].loc[idxs].to_numpy(float))
+            # (masked assignment as in the reference: a NaN bound — e.g. sqrt of a negative reactive
+            # headroom — compares False and leaves the set-point alone; np.minimum would propagate it)
+            with np.errstate(invalid='ignore'):
+                if f'max_{col}' in df.columns:
+                    mx = df[f'max_{col}'].loc[idxs].to_numpy(float)
+                    sp = np.where(sp > mx, mx, sp)
+                if f'min_{col}' in df.columns:
+                    mn = df[f'min_{col}'].loc[idxs].to_numpy(float)
+                    sp = np.where(sp < mn, mn, sp)
         sp = sp / sc                                                        # :472-474
         if col in ('closed', 'in_service'):                                 # :476-478
             sp = np.round(sp).astype(bool)

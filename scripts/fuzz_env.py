@@ -2,7 +2,7 @@
 random combinations of the in-scope OpfEnv options on the small scenario grids, one reset
 and up to three steps each, every instance compared with the oracle on the same draws.
 
-    python scripts/fuzz_env.py [n_configs] [seed]
+    python scripts/fuzz_env.py [n_configs] [seed] [only_config]
 
 Prints one line per configuration and a summary; exits non-zero on the first mismatch."""
 import os
@@ -16,7 +16,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', '
 from env_cases import oracle_env, product_env  # noqa: E402
 
 R_TOL, V_TOL = 1e-6, 1e-8
-BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv']
+REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
+BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
+         'sc_hv_small', 'reconf_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
+         'custom_constraint_lv']
 
 
 def pick(rng, seq):
@@ -65,10 +68,22 @@ def random_options(rng):
         cp['autoscale_violation'] = False
     if cp:
         kw['constraint_params'] = cp
-    data = pick(rng, ['simbench', 'simbench', 'full_uniform', 'normal_around_mean'])
+    data = pick(rng, ['simbench', 'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean'])
     kw['train_data'] = data
-    if data == 'simbench' and rng.random() < 0.4:
-        kw['sampling_params'] = dict(noise_factor=0.1)
+    sp = {}
+    if data in ('simbench', 'noisy_simbench'):
+        if rng.random() < 0.4:
+            sp['noise_factor'] = pick(rng, [0.05, 0.1])
+        if sp and rng.random() < 0.4:
+            sp['noise_distribution'] = 'normal'
+        if rng.random() < 0.3:
+            sp['interpolate_steps'] = True
+    if data == 'normal_around_mean' and rng.random() < 0.5:
+        sp['relative_std'] = 0.1
+    if sp:
+        kw['sampling_params'] = sp
+    if rng.random() < 0.3:
+        kw['test_data'] = pick(rng, ['simbench', 'noisy_simbench', 'full_uniform'])
     return kw
 
 
@@ -79,13 +94,23 @@ def np_(t):
 def run_one(base, kw, rng, B=8):
     env = product_env(base, batch_size=B, **kw)
     orc = oracle_env(base, product_env(base, defer_device=True, **kw))
-    steps = rng.choice(env.train_steps, B)
+    is_test = 'test_data' in kw and rng.random() < 0.5
+    distr = env.test_data if is_test else env.train_data
+    steps = rng.choice(env.test_steps if is_test else env.train_steps, B)
     uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
-    noise = rng.random((B, env.n_noise)) * 0.2 + 0.9 if env.noise_factor else None
+    noisy = env.n_noise and (distr == 'noisy_simbench' or 'noise_factor' in env.sampling_params)
+    noise = None
+    if noisy and env.noise_distribution == 'normal':
+        noise = rng.standard_normal((B, env.n_noise))
+    elif noisy:
+        noise = rng.random((B, env.n_noise)) * (2 * env.noise_factor) + (1 - env.noise_factor)
     normal = rng.standard_normal((B, env.n_normal)) if getattr(env, 'n_normal', 0) else None
-    opts = {'step': steps, 'uniform': uniform, 'noise': noise}
+    interp = rng.random((B, len(env.tables))) if env.interpolate_steps and env.uses_profiles else None
+    opts = {'step': steps, 'uniform': uniform, 'noise': noise, 'test': is_test}
     if normal is not None:
         opts['normal'] = normal
+    if interp is not None:
+        opts['interp'] = interp
     if kw.get('initial_action') == 'random':
         opts['initial_action'] = rng.random((B, env.n_actions))
     obs0, _ = env.reset(options=opts)
@@ -101,10 +126,16 @@ def run_one(base, kw, rng, B=8):
                          cost=np_(o[4]['cost']).copy(), vm=np_(env.result_table('bus', 'vm_pu')).copy()))
     checked = 0
     for k in range(B):
-        rk = dict(uniform=uniform[k] if uniform is not None else (), noise=noise[k] if noise is not None else None)
-        extra = {}
+        # (the reference draws sequentially and only what the data source needs; the product has one
+        # fixed draw column per op)
+        src = env.source_of[distr]
+        rk = dict(uniform=uniform[k][env.ops.uniform_columns(src)] if uniform is not None else (),
+                  noise=noise[k] if noise is not None else None)
+        extra = {'data': distr}
         if normal is not None:
             extra['normal'] = normal[k]
+        if interp is not None:
+            extra['interp'] = interp[k]
         if 'initial_action' in opts:
             extra['initial_action'] = opts['initial_action'][k]
         try:
@@ -117,7 +148,9 @@ def run_one(base, kw, rng, B=8):
             assert not np.allclose(obs0[k], 0.0), ('product row after a failed reset', k)
             print(f'      row {k}: reset power flow fails in the oracle at step {int(steps[k])}; re-sampled by the product')
             continue
-        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL), ('reset obs', k, np.abs(obs0[k] - ob0).max())
+        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL), ('reset obs', k, np.abs(obs0[k] - ob0).max(),
+                                                                 'nan product/oracle', int(np.isnan(obs0[k]).sum()), int(np.isnan(ob0).sum()),
+                                                                 'first bad', int(np.flatnonzero(~np.isclose(obs0[k], ob0, rtol=0, atol=R_TOL))[0]), 'is_test', is_test)
         for s_ in range(n_steps):
             ref = orc.step(acts[s_, k])
             got = outs[s_]
@@ -125,14 +158,15 @@ def run_one(base, kw, rng, B=8):
             if not ref['converged']:
                 break
             assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL), ('obs', k, s_, np.abs(got['obs'][k] - ref['obs']).max())
-            assert np.isclose(got['reward'][k], ref['reward'], rtol=1e-9, atol=R_TOL), ('reward', k, s_, got['reward'][k], ref['reward'])
+            assert np.isclose(got['reward'][k], ref['reward'], rtol=REL, atol=R_TOL), ('reward', k, s_, got['reward'][k], ref['reward'])
             nc = len(ref['valids'])
             assert (got['valids'][k][:nc] == ref['valids']).all(), ('valids', k, s_)
-            assert np.allclose(got['viol'][k][:nc], ref['violations'], rtol=1e-9, atol=R_TOL), ('violations', k, s_)
-            assert np.allclose(got['pen'][k][:nc], ref['penalties'], rtol=1e-9, atol=R_TOL), ('penalties', k, s_)
-            assert np.isclose(got['cost'][k], ref['cost'], rtol=1e-9, atol=R_TOL), ('cost', k, s_)
+            assert np.allclose(got['viol'][k][:nc], ref['violations'], rtol=REL, atol=R_TOL), ('violations', k, s_)
+            assert np.allclose(got['pen'][k][:nc], ref['penalties'], rtol=REL, atol=R_TOL), ('penalties', k, s_)
+            assert np.isclose(got['cost'][k], ref['cost'], rtol=REL, atol=R_TOL), ('cost', k, s_)
             assert bool(got['term'][k]) == bool(ref['terminated']), ('terminated', k, s_)
-            assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k, s_)
+            if not env.n_minus_one_keys:          # (after an N-1 step the tables hold the last contingency, D7)
+                assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k, s_)
             checked += 1
             if ref['terminated'] or ref.get('truncated'):
                 break
@@ -142,11 +176,17 @@ def run_one(base, kw, rng, B=8):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    rng = np.random.default_rng(seed)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # replay one configuration
     total = bad = 0
     for c in range(n):
+        if only is not None and c != only:
+            continue
+        rng = np.random.default_rng([seed, c])
         base = pick(rng, BASES)
         kw = random_options(rng)
+        if base == 'nonsimbench_case9':              # (no profiles: the class brings its own distributions)
+            for key in ('train_data', 'test_data', 'sampling_params'):
+                kw.pop(key, None)
         try:
             checked = run_one(base, kw, rng)
             total += checked

@@ -390,6 +390,52 @@ def test_reset_resamples_rows_whose_power_flow_fails():
         env.reset(seed=123)
 
 
+def test_reset_of_an_n_minus_one_env_runs_the_base_case_only():
+    """SecurityConstrained + add_res_obs: the reset observation shows the base-case power flow
+    (opf_env.py:209-216 calls run_power_flow; the N-1 loop belongs to calculate_violations,
+    security_constrained.py:37) — not the last contingency."""
+    B = 6
+    kw = dict(add_res_obs=True)
+    env = product_env('sc_hv_small', batch_size=B, **kw)
+    orc = oracle_env('sc_hv_small', product_env('sc_hv_small', defer_device=True, **kw))
+    rng = np.random.default_rng(8)
+    steps = rng.choice(env.train_steps, B)
+    obs0 = _np(env.reset(options={'step': steps})[0]).copy()
+    actions = rng.random((B, env.n_actions))
+    out = env.step(actions)
+    for k in range(B):
+        assert np.allclose(obs0[k], orc.reset(int(steps[k])), rtol=0, atol=R_TOL)
+        ref = orc.step(actions[k])
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=True)
+
+
+def test_option_fuzz_matches_oracle():
+    """A fixed slice of scripts/fuzz_env.py: random combinations of the OpfEnv options (reward
+    classes and parameters, observation flags, action modes, constraint parameters, data
+    distributions for train and test) on the small grids, every instance against the CPU oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_env', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts', 'fuzz_env.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    compared = 0
+    for c in range(16):
+        rng = np.random.default_rng([11, c])
+        base = fz.pick(rng, fz.BASES)
+        kw = fz.random_options(rng)
+        if base == 'nonsimbench_case9':
+            for key in ('train_data', 'test_data', 'sampling_params'):
+                kw.pop(key, None)
+        try:
+            compared += fz.run_one(base, kw, rng)
+        except (NotImplementedError, KeyError):
+            continue                    # combinations the reference rejects too (missing min_min_ columns, ...)
+    assert compared >= 60
+
+
 def test_n_minus_one_with_an_islanding_contingency():
     """A contingency that cuts buses off the slack: pandapower de-energises them and evaluates the
     constraints on the rest (NaN values never violate); so do the oracle and the kernel."""
