@@ -87,6 +87,40 @@ def random_options(rng):
     return kw
 
 
+def class_options(rng, base):
+    """Constructor parameters of the benchmark classes (they change the grid the env is built on)."""
+    kw = {}
+    if base in ('vc_mv_small', 'qm_mv_small'):
+        if rng.random() < 0.5:
+            kw['load_scaling'] = pick(rng, [1.2, 2.0])
+        if rng.random() < 0.5:
+            kw['gen_scaling'] = pick(rng, [1.0, 1.6])
+        if rng.random() < 0.4:
+            kw['cos_phi'] = 0.9
+        if rng.random() < 0.4:
+            kw['max_q_exchange'] = pick(rng, [0.2, 1.0])
+        if rng.random() < 0.3:
+            kw['market_based'] = base == 'vc_mv_small'
+        if base == 'vc_mv_small' and rng.random() < 0.25:
+            kw['bus_wise_obs'] = True
+    elif base == 'eco_hv_small':
+        if rng.random() < 0.5:
+            kw['max_price_eur_gwh'] = pick(rng, [0.3, 1.0])
+        if rng.random() < 0.4:
+            kw['load_scaling'] = 1.2
+    elif base == 'loadshed_mv_small':
+        if rng.random() < 0.5:
+            kw['max_p_exchange'] = pick(rng, [4.0, 12.0])
+        if rng.random() < 0.4:
+            kw['storage_efficiency'] = 0.9
+    elif base == 'sc_hv_small':
+        if rng.random() < 0.5:
+            kw['n_minus_one_lines'] = pick(rng, [(1,), (0, 2, 5), (1, 3, 7, 9)])
+        if rng.random() < 0.3:
+            kw['not_converged_penalty'] = 5.0
+    return kw
+
+
 def np_(t):
     return t.detach().cpu().numpy()
 
@@ -183,7 +217,7 @@ def main():
             continue
         rng = np.random.default_rng([seed, c])
         base = pick(rng, BASES)
-        kw = random_options(rng)
+        kw = dict(random_options(rng), **class_options(rng, base))
         if base == 'nonsimbench_case9':              # (no profiles: the class brings its own distributions)
             for key in ('train_data', 'test_data', 'sampling_params'):
                 kw.pop(key, None)

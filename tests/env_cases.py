@@ -37,9 +37,14 @@ def oracle_env(name, env=None):
     cls, kwargs, _, _ = SCENARIOS[name]
     env = env or product_env(name, defer_device=True)
     d = env.host_definition()
+    tail = env_oracle.TAILS[cls]
+    if cls in ('VoltageControl', 'QMarket'):          # constructor parameters of the `_sampling` tails
+        tail = lambda net, dr: env_oracle.tail_voltage_control(net, dr, bool(env.market_based))
+    elif cls == 'LoadShedding':
+        tail = lambda net, dr: env_oracle.tail_load_shedding(net, dr, env.storage_efficiency)
     return env_oracle.EnvOracle(
         d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
-        reward_dict(d['reward_function']), env_oracle.TAILS[cls],
+        reward_dict(d['reward_function']), tail,
         autoscale_actions=env.autoscale_actions, diff_action_step_size=env.diff_action_step_size,
         clipped_action_penalty=env.clipped_action_penalty, diff_objective=env.diff_objective,
         add_mean_obs=env.add_mean_obs, pf_for_obs=env.pf_for_obs,
