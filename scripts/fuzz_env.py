@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 from env_cases import oracle_env, product_env  # noqa: E402
 
-R_TOL, V_TOL = 1e-6, 1e-8
+R_TOL, V_TOL = 1e-6, 1e-7      # (both Newton solvers stop at ||F||inf < 1e-8 p.u.; north-star bar 1e-6 p.u.)
 REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
 BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
          'sc_hv_small', 'reconf_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
@@ -68,8 +68,13 @@ def random_options(rng):
         cp['autoscale_violation'] = False
     if cp:
         kw['constraint_params'] = cp
-    data = pick(rng, ['simbench', 'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean'])
+    data = pick(rng, ['simbench', 'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean', 'mixed'])
     kw['train_data'] = data
+    if data == 'mixed':
+        kw['test_data'] = 'mixed'                    # ('mixed' must be both)
+        if rng.random() < 0.5:
+            kw['sampling_params'] = dict(data_probabilities=(0.3, 0.6, 1.0))
+        return kw
     sp = {}
     if data in ('simbench', 'noisy_simbench'):
         if rng.random() < 0.4:
@@ -130,6 +135,8 @@ def run_one(base, kw, rng, B=8):
     orc = oracle_env(base, product_env(base, defer_device=True, **kw))
     is_test = 'test_data' in kw and rng.random() < 0.5
     distr = env.test_data if is_test else env.train_data
+    if env.mixed:
+        return run_mixed(env, orc, kw, rng, B)
     steps = rng.choice(env.test_steps if is_test else env.train_steps, B)
     uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
     noisy = env.n_noise and (distr == 'noisy_simbench' or 'noise_factor' in env.sampling_params)
@@ -200,10 +207,47 @@ def run_one(base, kw, rng, B=8):
             assert np.isclose(got['cost'][k], ref['cost'], rtol=REL, atol=R_TOL), ('cost', k, s_)
             assert bool(got['term'][k]) == bool(ref['terminated']), ('terminated', k, s_)
             if not env.n_minus_one_keys:          # (after an N-1 step the tables hold the last contingency, D7)
-                assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k, s_)
+                assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k, s_, float(np.nanmax(np.abs(got['vm'][k] - ref['vm_pu']))))
             checked += 1
             if ref['terminated'] or ref.get('truncated'):
                 break
+    return checked
+
+
+def run_mixed(env, orc, kw, rng, B):
+    """train_data='mixed' (opf_env.py:242-251): the first draw r of a reset picks the data source."""
+    steps = rng.choice(env.train_steps, B)
+    r = rng.random(B)
+    p0, p1 = env.data_probabilities[0], env.data_probabilities[1]
+    mode = (r >= p0).astype(np.int32) + (r >= p1).astype(np.int32)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    normal = rng.standard_normal((B, env.n_normal)) if env.n_normal else None
+    noise = rng.random((B, env.n_noise)) * (2 * env.noise_factor) + (1 - env.noise_factor) if env.n_noise else None
+    opts = {'step': steps, 'uniform': uniform, 'normal': normal, 'noise': noise, 'mode': mode}
+    init = rng.random((B, env.n_actions)) if kw.get('initial_action') == 'random' else None
+    if init is not None:
+        opts['initial_action'] = init
+    obs0 = np_(env.reset(options=opts)[0]).copy()
+    acts = rng.random((B, env.n_actions))
+    o = env.step(acts)
+    got = dict(obs=np_(o[0]), reward=np_(o[1]), conv=np_(o[4]['converged']), vm=np_(env.result_table('bus', 'vm_pu')))
+    checked = 0
+    for k in range(B):
+        m = int(mode[k])
+        uni = uniform[k][env.ops.uniform_columns(m)] if uniform is not None else ()
+        ob0 = orc.reset(int(steps[k]), uni, noise[k] if (noise is not None and m == 0) else None,
+                        interp=[r[k]], normal=normal[k] if normal is not None else (),
+                        initial_action=init[k] if init is not None else None)
+        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL), ('mixed reset obs', k, m, np.abs(obs0[k] - ob0).max())
+        ref = orc.step(acts[k])
+        assert bool(got['conv'][k]) == bool(ref['converged']), ('converged', k)
+        if not ref['converged']:
+            continue
+        assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL), ('obs', k)
+        assert np.isclose(got['reward'][k], ref['reward'], rtol=REL, atol=R_TOL), ('reward', k)
+        if not env.n_minus_one_keys:
+            assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k)
+        checked += 1
     return checked
 
 
