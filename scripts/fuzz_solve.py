@@ -1,0 +1,137 @@
+"""Differential fuzz of opfx_solve against the SciPy oracle on random grids (developer script, GPU box):
+radial and meshed synthetic networks of random size with random taps, phase shifts, parallel lines,
+shunts, elements out of service and closed bus-bus switches; random injections; optionally a random
+branch outage per instance and generator reactive limits.
+
+    python scripts/fuzz_solve.py [n_grids] [seed]
+
+Exercises the symbolic plan (ordering, levels, fill, lane programmes, wave teams) on topologies the
+fixed test grids do not have."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+from helpers import oracle_batch  # noqa: E402
+from opfgym_amd import capi, grids  # noqa: E402
+from opfgym_amd.case import net_to_case  # noqa: E402
+
+TOL_V = 1e-8
+
+
+def random_grid(rng):
+    kind = rng.integers(3)
+    seed = int(rng.integers(1 << 30))
+    if kind == 0:
+        nb = int(rng.integers(12, 420))
+        n_ext = int(rng.integers(1, 4))
+        n_gen = int(rng.integers(0, max(1, min(24, nb // 8))))
+        net, _ = grids.synthetic_hv(seed, nb=nb, n_ext=n_ext, n_gen=n_gen, trafos_per_ext=int(rng.integers(1, 4)))
+        desc = f'hv nb={nb} ext={n_ext} gen={n_gen}'
+    elif kind == 1:
+        n = int(rng.integers(6, 260))
+        net, _ = grids.synthetic_mv_small(seed, n_nodes=n, n_storage=int(rng.integers(0, 3)))
+        desc = f'mv n={n}'
+    else:
+        net, _ = grids.get_grid(['1-LV-rural1--0-sw', 'mv-small', 'hv-small', '1-MV-urban--0-sw'][int(rng.integers(4))], seed=seed % 7)
+        desc = 'named'
+    # random electrical modifications
+    tr = net['trafo']
+    if len(tr) and rng.random() < 0.6:
+        tr['tap_pos'] = rng.integers(-3, 4, len(tr)).astype(float)
+    if len(tr) and rng.random() < 0.3:
+        tr['shift_degree'] = float(rng.choice([30.0, 150.0]))       # (one vector group for all: no circulating currents)
+    ln = net['line']
+    if rng.random() < 0.4:
+        ln['parallel'] = rng.choice([1, 1, 2], len(ln))
+    if rng.random() < 0.3 and len(ln) > 8:
+        off = rng.choice(len(ln), max(1, len(ln) // 20), replace=False)
+        ln.loc[ln.index[off], 'in_service'] = False
+    if rng.random() < 0.3:
+        import pandas as pd
+        buses = rng.choice(net['bus'].index.to_numpy(), min(3, len(net['bus'])), replace=False)
+        net['shunt'] = pd.DataFrame(dict(bus=buses, p_mw=0.0, q_mvar=rng.uniform(-0.5, 0.5, len(buses)),
+                                         vn_kv=net['bus']['vn_kv'].loc[buses].to_numpy(), step=1, in_service=True))
+    return net, desc
+
+
+def random_injections(net, case, B, rng, lo=0.1, hi=1.0):
+    """As tests/helpers.random_injections, but units on de-energised buses are skipped."""
+    p = np.zeros((B, case.nb))
+    q = np.zeros((B, case.nb))
+    for tbl, sign in (('load', -1.0), ('sgen', 1.0), ('storage', -1.0), ('gen', 1.0)):
+        df = net[tbl]
+        for pos in range(len(df)):
+            b = int(df['bus'].iloc[pos])
+            if b not in case.bus_lookup:
+                continue
+            i = case.bus_lookup[b]
+            p[:, i] += df['p_mw'].iloc[pos] * rng.uniform(lo, hi, B) * sign / case.base_mva
+            if tbl != 'gen':
+                q[:, i] += df['q_mvar'].iloc[pos] * rng.uniform(lo, hi, B) * sign / case.base_mva
+    return p, q
+
+
+def main():
+    import torch
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = done = 0
+    dev = torch.device('cuda:0')
+    for g in range(n):
+        rng = np.random.default_rng([seed, g])
+        try:
+            net, desc = random_grid(rng)
+            case = net_to_case(net)
+            plan = capi.Plan(case)
+            info = plan.info
+            ctx = capi.Context(plan, 0)
+            B = 12
+            p, q = random_injections(net, case, B, rng)
+            kw, okw = {}, {}
+            if rng.random() < 0.4 and case.nbr > 3:
+                out = rng.integers(-1, case.nbr, B).astype(np.int32)
+                kw['outage'] = torch.tensor(out, device=dev)
+                okw['outage'] = out
+            if (case.bus_type == 2).any() and 'outage' not in kw and rng.random() < 0.6:
+                # generator capability per PV bus, tight enough that some limits bind (PV -> PQ switching)
+                lim = rng.uniform(0.02, 0.4, case.nb) * 100.0 / case.base_mva
+                kw.update(qg_min=torch.tensor(-lim, device=dev), qg_max=torch.tensor(lim, device=dev), enforce_q_lims=True)
+                okw.update(qg_min=-lim, qg_max=lim, enforce_q_lims=True)
+            got = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw).items()}
+            ref = oracle_batch(case, p, q, **okw)
+            both = ref['converged'] & got['converged'].astype(bool)
+            # islanding outages de-energise the island (NaN voltages there): compared separately below
+            isl = np.isnan(got['vm']).any(axis=1)
+            cmp_rows = both & ~isl
+            assert (got['converged'].astype(bool)[~isl] == ref['converged'][~isl]).all(), ('converged flags', desc)
+            if cmp_rows.any():
+                dv = np.abs(got['vm'][cmp_rows] - ref['vm'][cmp_rows]).max()
+                dl = np.abs(got['loading'][cmp_rows] - ref['loading'][cmp_rows]).max()
+                assert dv < TOL_V, ('vm', desc, dv)
+                assert dl < 1e-5, ('loading', desc, dl)
+                assert (np.abs(got['iterations'][cmp_rows] - ref['iterations'][cmp_rows]) <= 1).all(), ('iterations', desc)
+            # islanded rows: the same buses are de-energised (NaN) and the rest of the grid agrees
+            for r_ in np.flatnonzero(isl & both):
+                assert (np.isnan(got['vm'][r_]) == np.isnan(ref['vm'][r_])).all(), ('dead buses', desc, int(r_))
+                live = ~np.isnan(ref['vm'][r_])
+                assert np.abs(got['vm'][r_][live] - ref['vm'][r_][live]).max() < TOL_V, ('vm of the energised part', desc, int(r_))
+            done += int(cmp_rows.sum()) + int((isl & both).sum())
+            print(f'[{g}] ok   {desc}: nb={info["nb"]} nbr={info["nbr"]} levels={info["n_levels"]} blocks={info["n_blk"]} '
+                  f'{"qlims " if "qg_min" in okw else ""}compared={int(cmp_rows.sum())} islanded={int(isl.sum())} not-converged={int((~ref["converged"]).sum())}')
+        except AssertionError as e:
+            bad += 1
+            print(f'[{g}] MISMATCH {e.args}')
+        except Exception:
+            bad += 1
+            print(f'[{g}] ERROR')
+            traceback.print_exc()
+    print(f'{n} grids, {done} solves compared, {bad} failures')
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
