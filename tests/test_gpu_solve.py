@@ -91,6 +91,21 @@ def test_ragged_batches_give_the_same_rows(B):
     assert empty['vm'].shape[0] == 0
 
 
+def test_random_grid_fuzz_slice():
+    """A fixed slice of scripts/fuzz_solve.py: random radial and meshed grids (12-420 buses, several
+    slacks, PV buses, taps, phase shifts, parallel lines, shunts, outages incl. islanding, Q limits)
+    solved on the GPU and by the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'fuzz_solve.py'), '14', '7'],
+                       capture_output=True, text=True, timeout=900)
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    assert r.returncode == 0 and last.endswith('0 failures'), r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(last.split(' grids, ')[1].split(' solves')[0]) >= 100
+
+
 def test_outage_axis():
     """N-1 axis: one branch out of service per instance (meshed HV grid)."""
     import torch
