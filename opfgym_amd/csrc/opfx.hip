@@ -1162,6 +1162,37 @@ __device__ __forceinline__ void mark_island(const DevPlan& P, const Lds& L, int 
   }
 }
 
+// Several branches out at once (open switches and/or an outage and/or a contingency): whether and what
+// they cut off is decided per instance by label propagation from the REF buses over the branches that
+// remain (a rare path: O(diameter) sweeps over the branch list; flags in the not-yet-used rhs area).
+// Unreached buses are de-energised exactly as mark_island does.  Call after init_voltage and mod_set.
+__device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int n_mod,
+                                   const double* qg_min, const double* qg_max) {
+  unsigned char* reach = reinterpret_cast<unsigned char*>(L.rhs);
+  for (int i = lane; i < P.nb; i += WAVE) reach[i] = P.bus_type[i] == BT_REF ? 1 : 0;
+  wave_fence();
+  for (int sweep = 0; sweep < P.nb; ++sweep) {
+    int changed = 0;
+    for (int k = lane; k < P.nbr; k += WAVE) {
+      bool removed = false;
+      for (int m = 0; m < n_mod; ++m) { const int* id = mod_ids(L, m); removed = removed || (id[6] == k && id[7] != 0); }
+      if (removed) continue;
+      const int f = P.br_f[k], t = P.br_t[k];
+      if (reach[f] != reach[t]) { reach[f] = 1; reach[t] = 1; changed = 1; }
+    }
+    wave_fence();
+    if (!wave_any(changed)) break;
+  }
+  for (int i = lane; i < P.nb; i += WAVE) {
+    if (reach[i]) continue;
+    const int t = L.bt[i];
+    if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];       // undo the start pin of init_voltage
+    if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
+    L.bt[i] = (unsigned char)BT_DEAD;
+  }
+  wave_fence();
+}
+
 template <int V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, int isl_state = 0) {
@@ -1638,10 +1669,13 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       if (V2 && c > 0) { if (wave == 0) mod_set(P, L, lane, n_mod, out_br, 0.0, true, n_mod_base); ++n_mod; }
       const int n_rem = n_rem_base + (c > 0 ? 1 : 0);
       const int isl_br = (c > 0 && P.br_island[out_br]) ? out_br : isl_br_base;
-      const int isl = island_state(V2 != 0, n_rem, isl_br >= 0);
+      // one branch out: its cut-off set is precomputed; several: connectivity is labelled per instance
+      const bool multi = V2 != 0 && n_rem >= 2;
+      const int isl = multi ? 1 : island_state(V2 != 0, n_rem, isl_br >= 0);
       if (wave == 0) {
         init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
-        if (isl == 1) mark_island(P, L, lane, isl_br, E.qg_min, E.qg_max);
+        if (multi) mark_islands_multi(P, L, lane, n_mod, E.qg_min, E.qg_max);
+        else if (isl == 1) mark_island(P, L, lane, isl_br, E.qg_min, E.qg_max);
         if (E.vset_src) for (int i = lane; i < nb; i += WAVE) {
           // per-instance |V| set-point of a REF / PV bus (a sampled ext_grid.vm_pu)
           const int src = as_global(E.vset_src)[i];

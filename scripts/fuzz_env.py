@@ -95,6 +95,8 @@ def random_options(rng):
 def class_options(rng, base):
     """Constructor parameters of the benchmark classes (they change the grid the env is built on)."""
     kw = {}
+    if base not in ('nonsimbench_case9', 'constraint_sat_lv') and rng.random() < 0.5:
+        kw['grid_seed'] = int(rng.integers(1, 50))      # another instance of the synthetic grid family
     if base in ('vc_mv_small', 'qm_mv_small'):
         if rng.random() < 0.5:
             kw['load_scaling'] = pick(rng, [1.2, 2.0])

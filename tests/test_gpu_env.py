@@ -436,6 +436,33 @@ def test_option_fuzz_matches_oracle():
     assert compared >= 60
 
 
+def test_several_open_switches_with_an_island():
+    """NetworkReconfiguration on a grid instance where opening the controllable switches cuts a part of
+    the grid off: with SEVERAL branches out at once the connectivity of the instance is labelled on
+    the device (no precomputed cut-off set exists for combinations), the island is de-energised
+    (pandapower's check_connectivity) and the rest solves — as the oracle does."""
+    kw = dict(grid_seed=26)
+    B = 4
+    env = product_env('reconf_hv_small_sw', batch_size=B, **kw)
+    orc = oracle_env('reconf_hv_small_sw', product_env('reconf_hv_small_sw', defer_device=True, **kw))
+    steps = np.random.default_rng(3).choice(env.train_steps, B)
+    env.reset(options={'step': steps})
+    n_sw = len(env.act_keys[0][2])
+    actions = np.full((B, env.n_actions), 0.5)
+    actions[:, :n_sw] = [[0.0] * n_sw, [1.0] * n_sw, [0.0] + [1.0] * (n_sw - 1), [1.0] * (n_sw - 1) + [0.0]]
+    out = env.step(actions)
+    vm = _np(env.result_table('bus', 'vm_pu'))
+    n_dead = []
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert ref['converged'] and bool(_np(out[4]['converged'])[k])
+        assert (np.isnan(vm[k]) == np.isnan(ref['vm_pu'])).all()
+        _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+        n_dead.append(int(np.isnan(ref['vm_pu']).sum()))
+    assert n_dead[0] > 0 and n_dead[1] == 0          # all open: an island; all closed: none
+
+
 def test_n_minus_one_with_an_islanding_contingency():
     """A contingency that cuts buses off the slack: pandapower de-energises them and evaluates the
     constraints on the rest (NaN values never violate); so do the oracle and the kernel."""
