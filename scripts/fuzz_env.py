@@ -191,16 +191,16 @@ def run_one(base, kw, rng, B=8):
             assert not np.allclose(obs0[k], 0.0), ('product row after a failed reset', k)
             print(f'      row {k}: reset power flow fails in the oracle at step {int(steps[k])}; re-sampled by the product')
             continue
-        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL), ('reset obs', k, np.abs(obs0[k] - ob0).max(),
+        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL, equal_nan=True), ('reset obs', k, np.abs(obs0[k] - ob0).max(),
                                                                  'nan product/oracle', int(np.isnan(obs0[k]).sum()), int(np.isnan(ob0).sum()),
-                                                                 'first bad', int(np.flatnonzero(~np.isclose(obs0[k], ob0, rtol=0, atol=R_TOL))[0]), 'is_test', is_test)
+                                                                 'first bad', int(np.flatnonzero(~np.isclose(obs0[k], ob0, rtol=0, atol=R_TOL, equal_nan=True))[0]), 'is_test', is_test)
         for s_ in range(n_steps):
             ref = orc.step(acts[s_, k])
             got = outs[s_]
             assert bool(got['conv'][k]) == bool(ref['converged']), ('converged', k, s_)
             if not ref['converged']:
                 break
-            assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL), ('obs', k, s_, np.abs(got['obs'][k] - ref['obs']).max())
+            assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL, equal_nan=True), ('obs', k, s_, np.abs(got['obs'][k] - ref['obs']).max())
             assert np.isclose(got['reward'][k], ref['reward'], rtol=REL, atol=R_TOL), ('reward', k, s_, got['reward'][k], ref['reward'])
             nc = len(ref['valids'])
             assert (got['valids'][k][:nc] == ref['valids']).all(), ('valids', k, s_)
@@ -240,12 +240,12 @@ def run_mixed(env, orc, kw, rng, B):
         ob0 = orc.reset(int(steps[k]), uni, noise[k] if (noise is not None and m == 0) else None,
                         interp=[r[k]], normal=normal[k] if normal is not None else (),
                         initial_action=init[k] if init is not None else None)
-        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL), ('mixed reset obs', k, m, np.abs(obs0[k] - ob0).max())
+        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL, equal_nan=True), ('mixed reset obs', k, m, np.abs(obs0[k] - ob0).max())
         ref = orc.step(acts[k])
         assert bool(got['conv'][k]) == bool(ref['converged']), ('converged', k)
         if not ref['converged']:
             continue
-        assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL), ('obs', k)
+        assert np.allclose(got['obs'][k], ref['obs'], rtol=0, atol=R_TOL, equal_nan=True), ('obs', k)
         assert np.isclose(got['reward'][k], ref['reward'], rtol=REL, atol=R_TOL), ('reward', k)
         if not env.n_minus_one_keys:
             assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k)
