@@ -76,9 +76,19 @@ class BatchedPowerFlowSolver:
                 vm[pos], va[pos] = r['vm'][i], np.degrees(r['va'][i])
         net['res_bus'] = pd.DataFrame({'vm_pu': vm, 'va_degree': va}, index=net['bus'].index)
         for tbl, kind in (('line', KIND_LINE), ('trafo', KIND_TRAFO)):
-            load = np.zeros(len(net[tbl]))
+            # in the solved case: its loading; out of service or behind an open switch: 0 % (no flow);
+            # in service but at a de-energised bus: NaN (as pandapower's result tables)
+            load = np.full(len(net[tbl]), np.nan)
             sel = case.br_kind == kind
             load[case.br_elem[sel]] = r['loading'][sel]
+            if len(net[tbl]):
+                off = ~net[tbl]['in_service'].to_numpy(bool) if 'in_service' in net[tbl].columns \
+                    else np.zeros(len(net[tbl]), bool)
+                sw = net['switch'] if 'switch' in net else None
+                if sw is not None and len(sw):
+                    opened = sw['element'][(sw['et'] == tbl[0]) & ~sw['closed'].to_numpy(bool)].to_numpy()
+                    off = off | np.isin(net[tbl].index.to_numpy(), opened)
+                load[off & np.isnan(load)] = 0.0
             net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
         ref_buses = np.flatnonzero(case.bus_type == REF)
         ordinal = {int(b): k for k, b in enumerate(ref_buses)}

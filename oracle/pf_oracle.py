@@ -259,13 +259,15 @@ def write_results(net, case, sol, p_mw_bus, q_mvar_bus, qd_mvar_bus):
         load = np.full(len(net[tbl]), np.nan)
         sel = case.br_kind == kind
         load[case.br_elem[sel]] = br['loading_percent'][sel]
-        if tbl == 'line' and len(net[tbl]):
+        if len(net[tbl]):
+            # an element that is out of service or behind an open switch carries no flow: 0 % (pypower's
+            # pfsoln zeroes the flows of status-0 branches); an in-service element at a de-energised bus: NaN
             off = ~net[tbl]['in_service'].to_numpy(bool)
             sw = net['switch'] if 'switch' in net else None
-            if sw is not None and len(sw):        # a line behind an open switch: taken out by net_to_case
-                opened = sw['element'][(sw['et'] == 'l') & ~sw['closed'].to_numpy(bool)].to_numpy()
+            if sw is not None and len(sw):        # behind an open switch: taken out by net_to_case
+                opened = sw['element'][(sw['et'] == tbl[0]) & ~sw['closed'].to_numpy(bool)].to_numpy()
                 off = off | np.isin(net[tbl].index.to_numpy(), opened)
-            load[off & np.isnan(load)] = 0.0     # pandapower reports 0 % for open lines
+            load[off & np.isnan(load)] = 0.0
         net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
     s_bus = v * np.conj(sol['ybus'] @ v) * base
     eg = net['ext_grid']

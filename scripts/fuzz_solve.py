@@ -120,6 +120,33 @@ def main():
                 live = ~np.isnan(ref['vm'][r_])
                 assert np.abs(got['vm'][r_][live] - ref['vm'][r_][live]).max() < TOL_V, ('vm of the energised part', desc, int(r_))
             done += int(cmp_rows.sum()) + int((isl & both).sum())
+            # the batch-1 plug-in on the same grid: net.res_* tables against the oracle's runpp restatement
+            import copy
+            from opfgym_amd import power_flow_solver
+            from oracle import pf_oracle as po
+            a_net, b_net = copy.deepcopy(net), copy.deepcopy(net)
+            fail_a = fail_b = False
+            try:
+                power_flow_solver(a_net, enforce_q_lims=True)
+            except Exception as e:
+                if 'converge' not in str(e).lower():
+                    raise
+                fail_a = True
+            try:
+                po.runpp(b_net, enforce_q_lims=True)
+            except Exception as e:
+                if 'converge' not in str(e).lower():
+                    raise
+                fail_b = True
+            assert fail_a == fail_b, ('plug-in convergence', desc, fail_a, fail_b)
+            if not fail_a:
+                for tbl, cols, tol in (('res_bus', ('vm_pu', 'va_degree'), 1e-7), ('res_line', ('loading_percent',), 1e-5),
+                                       ('res_trafo', ('loading_percent',), 1e-5), ('res_ext_grid', ('p_mw', 'q_mvar'), 1e-5),
+                                       ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-5), ('res_load', ('p_mw', 'q_mvar'), 0),
+                                       ('res_sgen', ('p_mw', 'q_mvar'), 0)):
+                    for col in cols:
+                        x, y = a_net[tbl][col].to_numpy(float), b_net[tbl][col].to_numpy(float)
+                        assert x.shape == y.shape and np.allclose(x, y, rtol=0, atol=tol, equal_nan=True), ('plug-in', desc, tbl, col)
             print(f'[{g}] ok   {desc}: nb={info["nb"]} nbr={info["nbr"]} levels={info["n_levels"]} blocks={info["n_blk"]} '
                   f'{"qlims " if "qg_min" in okw else ""}compared={int(cmp_rows.sum())} islanded={int(isl.sum())} not-converged={int((~ref["converged"]).sum())}')
         except AssertionError as e:
