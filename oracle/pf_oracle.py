@@ -22,6 +22,8 @@ numerical power-flow result at all, and pandapower cannot be run
 here.  This oracle is pinned instead by (tests/test_oracle_pf.py):
   * the closed-form two-bus solution,
   * the published WSCC 9-bus (`case9`) voltage profile,
+  * the published IEEE 14-bus solution (off-nominal taps, bus shunt, four PV buses; |V| to the three
+    published decimals, angles to 0.001 degree, slack generation and losses to 0.01 MW),
   * algebraic self-checks (mismatch < tol, power balance = losses).
 """
 from __future__ import annotations

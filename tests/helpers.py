@@ -79,3 +79,44 @@ def non_bridge_branches(case):
         if seen.all():
             out.append(k)
     return np.array(out, dtype=np.int32)
+
+
+def ieee14_ppc():
+    """IEEE 14-bus test system in pypower matrix form (public textbook data, MATPOWER `case14`;
+    0-based bus numbers) and its published power-flow solution (MATPOWER `runpf(case14)`: voltage
+    magnitudes to 3 decimals, angles in degrees, slack generation in MW / MVAr)."""
+    z = 0.0
+    bus = np.array([      # bus type Pd Qd Gs Bs area Vm Va baseKV zone Vmax Vmin
+        [0, 3, 0.0, 0.0, z, z, 1, 1.060, 0.0, 0, 1, 1.06, 0.94],
+        [1, 2, 21.7, 12.7, z, z, 1, 1.045, 0.0, 0, 1, 1.06, 0.94],
+        [2, 2, 94.2, 19.0, z, z, 1, 1.010, 0.0, 0, 1, 1.06, 0.94],
+        [3, 1, 47.8, -3.9, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [4, 1, 7.6, 1.6, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [5, 2, 11.2, 7.5, z, z, 1, 1.070, 0.0, 0, 1, 1.06, 0.94],
+        [6, 1, 0.0, 0.0, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [7, 2, 0.0, 0.0, z, z, 1, 1.090, 0.0, 0, 1, 1.06, 0.94],
+        [8, 1, 29.5, 16.6, z, 19.0, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [9, 1, 9.0, 5.8, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [10, 1, 3.5, 1.8, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [11, 1, 6.1, 1.6, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [12, 1, 13.5, 5.8, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94],
+        [13, 1, 14.9, 5.0, z, z, 1, 1.0, 0.0, 0, 1, 1.06, 0.94]])
+    br = [  # from to r x b tap   (1-based as published)
+        (1, 2, 0.01938, 0.05917, 0.0528, 0), (1, 5, 0.05403, 0.22304, 0.0492, 0), (2, 3, 0.04699, 0.19797, 0.0438, 0),
+        (2, 4, 0.05811, 0.17632, 0.0340, 0), (2, 5, 0.05695, 0.17388, 0.0346, 0), (3, 4, 0.06701, 0.17103, 0.0128, 0),
+        (4, 5, 0.01335, 0.04211, 0.0, 0), (4, 7, 0.0, 0.20912, 0.0, 0.978), (4, 9, 0.0, 0.55618, 0.0, 0.969),
+        (5, 6, 0.0, 0.25202, 0.0, 0.932), (6, 11, 0.09498, 0.19890, 0.0, 0), (6, 12, 0.12291, 0.25581, 0.0, 0),
+        (6, 13, 0.06615, 0.13027, 0.0, 0), (7, 8, 0.0, 0.17615, 0.0, 0), (7, 9, 0.0, 0.11001, 0.0, 0),
+        (9, 10, 0.03181, 0.08450, 0.0, 0), (9, 14, 0.12711, 0.27038, 0.0, 0), (10, 11, 0.08205, 0.19207, 0.0, 0),
+        (12, 13, 0.22092, 0.19988, 0.0, 0), (13, 14, 0.17093, 0.34802, 0.0, 0)]
+    branch = np.array([[f - 1, t - 1, r, x, b, 0, 0, 0, tap, 0, 1, -360, 360] for f, t, r, x, b, tap in br], dtype=float)
+    gen = np.array([      # bus Pg Qg Qmax Qmin Vg mBase status
+        [0, 232.4, -16.9, 10.0, 0.0, 1.060, 100, 1], [1, 40.0, 42.4, 50.0, -40.0, 1.045, 100, 1],
+        [2, 0.0, 23.4, 40.0, 0.0, 1.010, 100, 1], [5, 0.0, 12.2, 24.0, -6.0, 1.070, 100, 1],
+        [7, 0.0, 17.4, 24.0, -6.0, 1.090, 100, 1]])
+    published = dict(
+        vm=np.array([1.060, 1.045, 1.010, 1.018, 1.020, 1.070, 1.062, 1.090, 1.056, 1.051, 1.057, 1.055, 1.050, 1.036]),
+        va_deg=np.array([0.0, -4.983, -12.725, -10.313, -8.774, -14.221, -13.360, -13.360, -14.939, -15.097,
+                         -14.791, -15.076, -15.156, -16.034]),
+        p_slack_mw=232.39, q_slack_mvar=-16.55, losses_mw=13.39)
+    return 100.0, bus, branch, gen, published

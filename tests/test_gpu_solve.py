@@ -106,6 +106,29 @@ def test_random_grid_fuzz_slice():
     assert int(last.split(' grids, ')[1].split(' solves')[0]) >= 100
 
 
+def test_ieee14_published_solution_on_the_gpu():
+    """The kernel itself against a published answer (not only against the oracle): IEEE 14-bus case
+    (taps, bus shunt, four PV buses) through `case_from_ppc` -> plan -> opfx_solve."""
+    import torch
+    from helpers import ieee14_ppc
+    from opfgym_amd import capi
+    from opfgym_amd.ppci_io import case_from_ppc
+    base, bus, branch, gen, pub = ieee14_ppc()
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev))
+    assert bool(out['converged'][0]) and int(out['iterations'][0]) <= 5
+    vm, va = out['vm'][0].cpu().numpy(), np.degrees(out['va'][0].cpu().numpy())
+    assert np.abs(vm - pub['vm']).max() < 6e-4                   # published to 3 decimals
+    assert np.abs(va - pub['va_deg']).max() < 1e-3
+    # s_ref = calculated bus power - scheduled injection (p holds the scheduled Pg of the slack unit; Q of
+    # generators is not part of q): slack generation = s_ref + schedule
+    s_ref = out['s_ref'][0].cpu().numpy() * base
+    assert abs(s_ref[0, 0] + gen[0, 1] - pub['p_slack_mw']) < 0.01
+    assert abs(s_ref[0, 1] - pub['q_slack_mvar']) < 0.01
+
+
 def test_outage_axis():
     """N-1 axis: one branch out of service per instance (meshed HV grid)."""
     import torch

@@ -64,3 +64,23 @@ def test_not_converged_raises():
     net = grids.two_bus(p_mw=500.0, q_mvar=200.0)
     with pytest.raises(po.LoadflowNotConverged):
         po.runpp(net)
+
+
+def test_ieee14_published_solution():
+    """Known-answer test on a second public system with off-nominal taps, a bus shunt and four PV
+    buses: the IEEE 14-bus case in pypower matrix form (tests/helpers.ieee14_ppc) against its
+    published solution — |V| to the three published decimals, angles to 0.001 degree, slack
+    generation 232.39 MW / -16.55 MVAr, losses 13.39 MW."""
+    from helpers import ieee14_ppc
+    from opfgym_amd.ppci_io import case_from_ppc
+    base, bus, branch, gen, pub = ieee14_ppc()
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    sol = po.solve_case(case, p, q)
+    v = sol['V']
+    assert sol['converged'] and sol['iterations'] <= 5
+    assert np.abs(np.abs(v) - pub['vm']).max() < 6e-4            # published to 3 decimals
+    assert np.abs(np.degrees(np.angle(v)) - pub['va_deg']).max() < 1e-3
+    s = v * np.conj(sol['ybus'] @ v) * base
+    assert abs(s[0].real + bus[0, 2] - pub['p_slack_mw']) < 0.01
+    assert abs(s[0].imag + bus[0, 3] - pub['q_slack_mvar']) < 0.01
+    assert abs(s.real.sum() - pub['losses_mw']) < 0.01
