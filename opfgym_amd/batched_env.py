@@ -407,8 +407,6 @@ class BatchedOpfEnv:
         # 'mixed' (opf_env.py:242-251): every reset draws one of the three sources per instance; the
         # ops of all three are compiled with the set of sources they run under
         self.mixed = 'mixed' in modes and 'noise_factor' not in self.sampling_params     # (:231 comes first)
-        if 'mixed' in modes and len(modes) > 1:
-            raise NotImplementedError("'mixed' must be both the train and the test distribution")
         # Data source per distribution: 0 profile row (+noise), 1 uniform in the data range, 2 normal around
         # the mean (opf_env.py:231-241; a `noise_factor` in sampling_params sends EVERY distribution down the
         # profile path, :231).  Train and test distribution may differ (the reference's default is
@@ -417,7 +415,7 @@ class BatchedOpfEnv:
         # distribution it samples from.
         src = {'simbench': 0, 'noisy_simbench': 0, 'full_uniform': 1, 'normal_around_mean': 2}
         force0 = 'noise_factor' in self.sampling_params
-        self.source_of = {d: (0 if force0 else src[d]) for d in modes if d != 'mixed'}
+        self.source_of = {d: (0 if force0 else src.get(d, 0)) for d in modes if d != 'mixed' or force0}
         self.per_source = self.mixed or len(set(self.source_of.values())) > 1
         sources = {0, 1, 2} if self.mixed else set(self.source_of.values())
         self.data_probabilities = tuple(self.sampling_params.get('data_probabilities', (0.5, 0.75, 1.0)))
@@ -971,7 +969,7 @@ class BatchedOpfEnv:
             return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         data_distr = self.test_data if self.test else self.train_data
         noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params
-                                  or self.mixed)
+                                  or (self.mixed and data_distr == 'mixed'))
         nf = self.noise_factor if noisy else 0.0
         normal_noise = noisy and self.noise_distribution == 'normal'
         noise_t = options.get('noise')
@@ -1006,7 +1004,7 @@ class BatchedOpfEnv:
         rio.normal_noise_factor = float(nf) if normal_noise else 0.0
         rio.x = self.x.data_ptr()
         mode_t = None
-        if self.mixed:                                                     # opf_env.py:242-251
+        if self.mixed and data_distr == 'mixed':                           # opf_env.py:242-251
             mode_t = options.get('mode')
             if mode_t is None:
                 r = t.rand(B, generator=self._gen, device=dev, dtype=t.float64)

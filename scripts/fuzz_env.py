@@ -71,7 +71,7 @@ def random_options(rng):
     data = pick(rng, ['simbench', 'simbench', 'noisy_simbench', 'full_uniform', 'normal_around_mean', 'mixed'])
     kw['train_data'] = data
     if data == 'mixed':
-        kw['test_data'] = 'mixed'                    # ('mixed' must be both)
+        kw['test_data'] = pick(rng, ['mixed', 'simbench', 'full_uniform'])
         if rng.random() < 0.5:
             kw['sampling_params'] = dict(data_probabilities=(0.3, 0.6, 1.0))
         return kw
@@ -137,7 +137,7 @@ def run_one(base, kw, rng, B=8):
     orc = oracle_env(base, product_env(base, defer_device=True, **kw))
     is_test = 'test_data' in kw and rng.random() < 0.5
     distr = env.test_data if is_test else env.train_data
-    if env.mixed:
+    if env.mixed and distr == 'mixed':
         return run_mixed(env, orc, kw, rng, B)
     steps = rng.choice(env.test_steps if is_test else env.train_steps, B)
     uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
@@ -237,9 +237,14 @@ def run_mixed(env, orc, kw, rng, B):
     for k in range(B):
         m = int(mode[k])
         uni = uniform[k][env.ops.uniform_columns(m)] if uniform is not None else ()
-        ob0 = orc.reset(int(steps[k]), uni, noise[k] if (noise is not None and m == 0) else None,
-                        interp=[r[k]], normal=normal[k] if normal is not None else (),
-                        initial_action=init[k] if init is not None else None)
+        try:
+            ob0 = orc.reset(int(steps[k]), uni, noise[k] if (noise is not None and m == 0) else None,
+                            interp=[r[k]], normal=normal[k] if normal is not None else (),
+                            initial_action=init[k] if init is not None else None)
+        except AssertionError as e:
+            if e.args:
+                raise
+            continue          # reset power flow fails in the oracle: the product re-sampled this row
         assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL, equal_nan=True), ('mixed reset obs', k, m, np.abs(obs0[k] - ob0).max())
         ref = orc.step(acts[k])
         assert bool(got['conv'][k]) == bool(ref['converged']), ('converged', k)
