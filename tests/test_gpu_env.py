@@ -463,6 +463,39 @@ def test_several_open_switches_with_an_island():
     assert n_dead[0] > 0 and n_dead[1] == 0          # all open: an island; all closed: none
 
 
+@pytest.mark.parametrize('name,kw', [('reconf_hv_small_sw', dict(grid_seed=26)), ('sc_hv_small', dict(add_res_obs=True)),
+                                     ('mixed_lv', {})])
+def test_wave_reuse_with_per_instance_branch_states(name, kw):
+    """More instances than resident wavefronts: every wavefront works through several instances in
+    turn, each with its own switch states / tap positions / contingencies / islands.  Rows from the
+    first, a middle and the last pass equal the oracle (nothing of the previous instance's modifier
+    records, de-energised flags or warm-start voltages leaks into the next)."""
+    B = 16 * 256 * 2 + 37            # > 2 passes even at 16 resident workgroups per CU
+    env = product_env(name, batch_size=B, **kw)
+    orc = oracle_env(name, product_env(name, defer_device=True, **kw))
+    rng = np.random.default_rng(21)
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    obs0 = _np(env.reset(options={'step': steps, 'uniform': uniform})[0]).copy()
+    actions = rng.random((B, env.n_actions))
+    out = env.step(actions)
+    conv = _np(out[4]['converged'])
+    rows = np.r_[0:5, 4096:4101, B - 5:B]
+    n_ok = 0
+    for k in rows:
+        ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        assert np.allclose(obs0[k], ob0, rtol=0, atol=R_TOL, equal_nan=True)
+        ref = orc.step(actions[k])
+        assert bool(conv[k]) == ref['converged']
+        if ref['converged']:
+            got_obs = _np(out[0])[k]
+            assert np.allclose(got_obs, ref['obs'], rtol=0, atol=R_TOL, equal_nan=True)
+            assert np.isclose(_np(out[1])[k], ref['reward'], rtol=1e-7, atol=R_TOL)
+            assert (_np(out[4]['valids'])[k][:len(ref['valids'])] == ref['valids']).all()
+            n_ok += 1
+    assert n_ok >= 10
+
+
 def test_n_minus_one_with_an_islanding_contingency():
     """A contingency that cuts buses off the slack: pandapower de-energises them and evaluates the
     constraints on the rest (NaN values never violate); so do the oracle and the kernel."""
