@@ -111,6 +111,9 @@ def class_options(rng, base):
         if base == 'vc_mv_small' and rng.random() < 0.25:
             kw['bus_wise_obs'] = True
     elif base == 'eco_hv_small':
+        if rng.random() < 0.3:
+            kw['simbench_network_name'] = '1-HV-mixed--0-sw'     # 306 buses: the wave-team kernel
+            kw.pop('grid_seed', None)
         if rng.random() < 0.5:
             kw['max_price_eur_gwh'] = pick(rng, [0.3, 1.0])
         if rng.random() < 0.4:
@@ -121,6 +124,9 @@ def class_options(rng, base):
         if rng.random() < 0.4:
             kw['storage_efficiency'] = 0.9
     elif base == 'sc_hv_small':
+        if rng.random() < 0.3:
+            kw['simbench_network_name'] = '1-HV-urban--0-sw'     # 372 buses: the wave-team kernel, N-1
+            kw.pop('grid_seed', None)
         if rng.random() < 0.5:
             kw['n_minus_one_lines'] = pick(rng, [(1,), (0, 2, 5), (1, 3, 7, 9)])
         if rng.random() < 0.3:
