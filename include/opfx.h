@@ -410,6 +410,11 @@ typedef struct opfx_reset_io {
    * observation (result entries NaN) — what opfx_step mode 2 / 3 do in a second launch */
   const double* action;      /* [B,na] or NULL */
   double* obs;               /* [B,nobs] or NULL */
+  /* 0: every row starts from the compiled table template (independent episodes); 1: from the
+   * instance's current row in x, as the reference's single net does between episodes and between
+   * the stages of a multi-stage episode (multi_stage.py:49-56: only the sampled columns change, the
+   * set-points of the last action stay) */
+  int32_t keep_state;
 } opfx_reset_io;
 
 int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);

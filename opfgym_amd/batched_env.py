@@ -270,7 +270,7 @@ class BatchedOpfEnv:
                  objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
-                 defer_device=False, validate_actions=False, **kwargs):
+                 defer_device=False, validate_actions=False, carry_over_state=False, **kwargs):
         from .objectives import QuadraticDeviation
         terms = objective_function if isinstance(objective_function, (list, tuple)) else \
             ([objective_function] if objective_function is not None else [])
@@ -285,6 +285,12 @@ class BatchedOpfEnv:
         # opf_env.py:382 asserts on NaN actions; checking that on the host costs a device sync per
         # step, so it is opt-in here: by default a NaN action yields a failed (NaN) row instead
         self.validate_actions = bool(validate_actions)
+        # False (default): every reset starts from the table template — independent episodes.  True: from
+        # the instance's state at the end of its previous episode, as the reference's single net does; a
+        # column that the previous data source set and the current one does not sample then carries over
+        # (reference defect D12: e.g. gen.p_mw of the last profile row under train_data='mixed').
+        self.carry_over_state = bool(carry_over_state)
+        self._state_valid = False
         self.batch_size = int(batch_size)
         self.obs_keys = list(observation_keys)
         self.state_keys = list(state_keys) if state_keys else copy.copy(self.obs_keys)
@@ -855,6 +861,7 @@ class BatchedOpfEnv:
         u8 = dict(dtype=t.bool, device=dev)          # one byte each; the kernel writes 0/1
         nc = max(1, self.n_constraints)
         self.B = B
+        self._state_valid = False
         self.x = t.zeros(B, self.nx, **f64)
         self.buf = dict(
             obs=t.zeros(B, max(1, self.n_obs_raw), **f64), reward=t.zeros(B, **f64),
@@ -1003,6 +1010,8 @@ class BatchedOpfEnv:
         rio.normal = nrm_t.data_ptr() if nrm_t is not None else None
         rio.normal_noise_factor = float(nf) if normal_noise else 0.0
         rio.x = self.x.data_ptr()
+        rio.keep_state = 1 if (self.carry_over_state and self._state_valid) else 0
+        self._state_valid = True
         mode_t = None
         if self.mixed and data_distr == 'mixed':                           # opf_env.py:242-251
             mode_t = options.get('mode')
@@ -1201,6 +1210,7 @@ class MultiStageOpfEnv(BatchedOpfEnv):
             obs = obs.clone()          # (the observation buffer is about to be overwritten)
             steps_old, x_old = self.steps_dev, self.x
             self.steps_dev = (self.steps_dev + 1).clamp(max=len(self._step_kind) - 2).int()
+            self._x_next.copy_(x_old)      # (only the sampled columns change: multi_stage.py:49-56 works on the same net)
             self.x = self._x_next
             self._resample_current()
             new_obs = self._finish_obs()
@@ -1225,6 +1235,7 @@ class MultiStageOpfEnv(BatchedOpfEnv):
         if self.per_source:
             rio.mode = self.sampling_mode.data_ptr()                       # the sources the episode started with
         rio.x = self.x.data_ptr()
+        rio.keep_state = 1
         rio.obs = self.buf['obs'].data_ptr()
         with t.cuda.device(self.device):
             capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')

@@ -125,7 +125,8 @@ class ResetDesc(C.Structure):
 class ResetIO(C.Structure):
     _fields_ = [('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
                 ('uniform', C.c_void_p), ('normal', C.c_void_p), ('normal_noise_factor', C.c_double),
-                ('x', C.c_void_p), ('mode', C.c_void_p), ('action', C.c_void_p), ('obs', C.c_void_p)]
+                ('x', C.c_void_p), ('mode', C.c_void_p), ('action', C.c_void_p), ('obs', C.c_void_p),
+                ('keep_state', C.c_int32)]
 
 
 _lib = None

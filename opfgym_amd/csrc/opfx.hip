@@ -1900,6 +1900,7 @@ struct ResetIO {
   const int* mode;
   const double* action;      // optional: initial action [B,na] (reset without power flow)
   double* obs;               // optional: table observation [B,nobs]
+  int keep_state;            // start from the instance's current row instead of the template
 };
 
 // One wavefront per instance; the row is built in LDS (template -> profile values -> vector-op
@@ -1919,7 +1920,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
     double* xr = io.x + b * R.nx;
     const int step = io.step_idx[b];
     const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-    if (R.init_off >= 0) for (int j = lane; j < R.nx; j += 64) row[j] = R.consts[R.init_off + j];
+    if (R.init_off >= 0 && !io.keep_state) for (int j = lane; j < R.nx; j += 64) row[j] = R.consts[R.init_off + j];
     else for (int j = lane; j < R.nx; j += 64) row[j] = xr[j];
     wave_fence();
     for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
@@ -2566,7 +2567,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * 8);
   ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
-            io->action, io->obs};
+            io->action, io->obs, io->keep_state};
   hipLaunchKernelGGL(k_reset, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
                      (long long)B, row_doubles);
   HIP_TRY(hipGetLastError());

@@ -366,6 +366,11 @@ class EnvOracle:
                  multi_stage=False, split=None, objective=None):
         self.objective_fn = objective            # `objective_function(net)` seam (opf_env.py:80-84)
         self.base_net = net
+        # carry_over=True keeps the net of the previous episode at reset, as the reference's single env does:
+        # a column that one data source samples and another does not (e.g. gen.p_mw set by the profile row
+        # but not by _sample_uniform when it is no state key) then leaks into the next episode (defect D12).
+        # Default False: every reset starts from the base net (what the batched product does).
+        self.carry_over = False
         self.net = copy.deepcopy(net)
         self.act_keys, self.obs_keys = act_keys, obs_keys
         self.profiles, self.ranges = profiles, profile_ranges(profiles) if profiles else None
@@ -394,7 +399,8 @@ class EnvOracle:
     def reset(self, step, uniform=(), noise=None, initial_action=None, interp=None, normal=(), data=None):
         """`data`: the distribution to sample from when it is not the training one (the reference picks
         test_data for reset(options={'test': True}), opf_env.py:226)."""
-        self.net = copy.deepcopy(self.base_net)
+        if not (self.carry_over and getattr(self, 'net', None) is not None):
+            self.net = copy.deepcopy(self.base_net)
         self.step_in_episode = 0
         self.current_step = step
         draws = iter(np.asarray(uniform, float))

@@ -496,6 +496,49 @@ def test_wave_reuse_with_per_instance_branch_states(name, kw):
     assert n_ok >= 10
 
 
+def test_carry_over_state_between_episodes():
+    """`carry_over_state=True` starts a reset from the instance's previous state, as the reference's
+    single net does: a column that the previous data source set and the current one does not sample
+    (here gen.p_mw: profile row in the 'simbench' episode, no state key for 'full_uniform') carries
+    over — reference defect D12, reproduced on request; checked against the oracle in its
+    `carry_over` mode, which tests/golden/fuzz_reference.py pins to the reference's own classes."""
+    B = 6
+    kw = dict(train_data='simbench', test_data='full_uniform', add_res_obs=True)
+    env = product_env('reconf_hv_small_sw', batch_size=B, carry_over_state=True, **kw)
+    fresh = product_env('reconf_hv_small_sw', batch_size=B, **kw)
+    orc = oracle_env('reconf_hv_small_sw', product_env('reconf_hv_small_sw', defer_device=True, **kw))
+    orc.carry_over = True
+    rng = np.random.default_rng(12)
+    plan = [(False, 'simbench'), (True, 'full_uniform'), (False, 'simbench'), (True, 'full_uniform')]
+    draws = []
+    for is_test, distr in plan:
+        steps = rng.choice(env.test_steps if is_test else env.train_steps, B)
+        uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+        actions = rng.random((B, env.n_actions))
+        draws.append((is_test, distr, steps, uniform, actions))
+    got, got_fresh = [], []
+    for e, out_list in ((env, got), (fresh, got_fresh)):
+        for is_test, distr, steps, uniform, actions in draws:
+            obs0 = _np(e.reset(options={'step': steps, 'uniform': uniform, 'test': is_test})[0]).copy()
+            out = e.step(actions)
+            out_list.append((obs0, _np(out[0]).copy(), _np(out[1]).copy(), _np(out[4]['converged']).copy()))
+    differs = False
+    for k in range(B):
+        orc.net = None                                   # a new env instance per row
+        for ep, (is_test, distr, steps, uniform, actions) in enumerate(draws):
+            src = env.source_of[distr]
+            uni = uniform[k][env.ops.uniform_columns(src)] if uniform is not None else ()
+            ob0 = orc.reset(int(steps[k]), uni, None, data=distr)
+            assert np.allclose(got[ep][0][k], ob0, rtol=0, atol=R_TOL, equal_nan=True), (k, ep)
+            ref = orc.step(actions[k])
+            assert bool(got[ep][3][k]) == ref['converged']
+            if ref['converged']:
+                assert np.allclose(got[ep][1][k], ref['obs'], rtol=0, atol=R_TOL, equal_nan=True), (k, ep)
+                assert np.isclose(got[ep][2][k], ref['reward'], rtol=1e-7, atol=R_TOL), (k, ep)
+            differs = differs or not np.allclose(got[ep][0][k], got_fresh[ep][0][k], rtol=0, atol=R_TOL, equal_nan=True)
+    assert differs            # the carried-over column does change the later episodes of this scenario
+
+
 def test_n_minus_one_with_an_islanding_contingency():
     """A contingency that cuts buses off the slack: pandapower de-energises them and evaluates the
     constraints on the rest (NaN values never violate); so do the oracle and the kernel."""
