@@ -1183,8 +1183,6 @@ class MultiStageOpfEnv(BatchedOpfEnv):
     def __init__(self, *args, steps_per_episode: int = 4, **kwargs):
         assert steps_per_episode > 1, 'At least two steps required for a multi-stage OPF.'
         super().__init__(*args, steps_per_episode=steps_per_episode, **kwargs)
-        if self.pf_for_obs:
-            raise NotImplementedError('result observations are not supported by the multi-stage variant yet')
 
     def attach_device(self):
         super().attach_device()
@@ -1208,11 +1206,16 @@ class MultiStageOpfEnv(BatchedOpfEnv):
         if bool(cont.any()):
             # re-sample every row at step+1 into a scratch store, keep it for the continuing rows
             obs = obs.clone()          # (the observation buffer is about to be overwritten)
+            if self.pf_for_obs:        # ... and so are the step's outputs, by the power flow of the new state
+                reward = reward.clone()
+                info = {k: (v.clone() if t.is_tensor(v) else v) for k, v in info.items()}
             steps_old, x_old = self.steps_dev, self.x
             self.steps_dev = (self.steps_dev + 1).clamp(max=len(self._step_kind) - 2).int()
             self._x_next.copy_(x_old)      # (only the sampled columns change: multi_stage.py:49-56 works on the same net)
             self.x = self._x_next
             self._resample_current()
+            if self.pf_for_obs:        # multi_stage.py:52-53: power flow of the new state with the set-points kept
+                self._launch_step(self._center_action, mode=1)
             new_obs = self._finish_obs()
             self.x = t.where(cont[:, None], self._x_next, x_old)
             self._x_next = x_old

@@ -477,6 +477,8 @@ class EnvOracle:
                 self.current_step = new_step
                 set_simbench_state(self.net, self.profiles, new_step, None, self.ranges)   # :50
                 self.tail(self.net, iter(()))
+                if self.pf_for_obs:                                         # :52-53
+                    self.solve()
                 obs = observation(self.net, self.obs_keys, False)           # :56 (no mean obs there)
         return dict(converged=True, obs=obs,
                     reward=reward, terminated=term, truncated=trunc, valids=valids, violations=viol,

@@ -19,7 +19,7 @@ R_TOL, V_TOL = 1e-6, 1e-7      # (both Newton solvers stop at ||F||inf < 1e-8 p.
 REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
 BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
          'sc_hv_small', 'reconf_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
-         'custom_constraint_lv']
+         'custom_constraint_lv', 'multistage_lv']
 
 
 def pick(rng, seq):
@@ -275,9 +275,11 @@ def main():
         rng = np.random.default_rng([seed, c])
         base = pick(rng, BASES)
         kw = dict(random_options(rng), **class_options(rng, base))
-        if base == 'nonsimbench_case9':              # (no profiles: the class brings its own distributions)
+        if base in ('nonsimbench_case9', 'multistage_lv'):   # (own distributions / re-sampling inside step)
             for key in ('train_data', 'test_data', 'sampling_params'):
                 kw.pop(key, None)
+        if base == 'multistage_lv':
+            kw['steps_per_episode'] = pick(rng, [2, 4])
         try:
             checked = run_one(base, kw, rng)
             total += checked

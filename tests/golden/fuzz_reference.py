@@ -33,7 +33,7 @@ fz = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(fz)
 
 TOL = 1e-9
-BASES = [b for b in fz.BASES if b != 'custom_constraint_lv']      # (its reference class is a local subclass)
+BASES = [b for b in fz.BASES if b != 'custom_constraint_lv'] + ['multistage_lv']      # (custom_constraint: a local subclass)
 
 
 def noise_factors(kwargs, raw, distr):
@@ -111,9 +111,11 @@ def main():
         base = fz.pick(rng, BASES)
         kw = dict(fz.random_options(rng), **fz.class_options(rng, base))
         kw.pop('simbench_network_name', None)
-        if base == 'nonsimbench_case9':
+        if base in ('nonsimbench_case9', 'multistage_lv'):      # (own distributions / re-sampling inside step)
             for key in ('train_data', 'test_data', 'sampling_params'):
                 kw.pop(key, None)
+        if base == 'multistage_lv':
+            kw['steps_per_episode'] = fz.pick(rng, [2, 4])
         try:
             checked = run_one(base, kw, rng)
             total += checked

@@ -426,9 +426,11 @@ def test_option_fuzz_matches_oracle():
         rng = np.random.default_rng([11, c])
         base = fz.pick(rng, fz.BASES)
         kw = fz.random_options(rng)
-        if base == 'nonsimbench_case9':
+        if base in ('nonsimbench_case9', 'multistage_lv'):
             for key in ('train_data', 'test_data', 'sampling_params'):
                 kw.pop(key, None)
+        if base == 'multistage_lv':
+            kw['steps_per_episode'] = fz.pick(rng, [2, 4])
         try:
             compared += fz.run_one(base, kw, rng)
         except (NotImplementedError, KeyError):
@@ -537,6 +539,41 @@ def test_carry_over_state_between_episodes():
                 assert np.isclose(got[ep][2][k], ref['reward'], rtol=1e-7, atol=R_TOL), (k, ep)
             differs = differs or not np.allclose(got[ep][0][k], got_fresh[ep][0][k], rtol=0, atol=R_TOL, equal_nan=True)
     assert differs            # the carried-over column does change the later episodes of this scenario
+
+
+@pytest.mark.parametrize('kw', [dict(add_res_obs=True, add_act_obs=True), dict(diff_objective=True, diff_action_step_size=0.2),
+                                dict(add_act_obs=True, autoscale_actions=False)])
+def test_multi_stage_with_result_observations_and_kept_set_points(kw):
+    """multi_stage.py:49-56: the next stage is sampled on the SAME net — the set-points of the last
+    action stay (they show in add_act_obs and are the base of incremental actions) — and, when the
+    observation needs results, a power flow of the new state follows.  Against the oracle, which
+    tests/golden/fuzz_reference.py pins to the reference's own MultiStageOpf for these options."""
+    B, S = 8, 4
+    env = product_env('multistage_lv', batch_size=B, **kw)
+    orc = oracle_env('multistage_lv', product_env('multistage_lv', defer_device=True, **kw))
+    rng = np.random.default_rng(31)
+    steps = rng.choice(env.train_steps, B)
+    obs0 = _np(env.reset(options={'step': steps})[0]).copy()
+    acts = rng.random((S, B, env.n_actions))
+    outs = []
+    for s_ in range(S):
+        o = env.step(acts[s_])
+        outs.append((_np(o[0]).copy(), _np(o[1]).copy(), _np(o[2]).copy(), _np(o[3]).copy(), _np(o[4]['converged']).copy()))
+    n = 0
+    for k in range(B):
+        assert np.allclose(obs0[k], orc.reset(int(steps[k])), rtol=0, atol=R_TOL)
+        for s_ in range(S):
+            ref = orc.step(acts[s_, k])
+            assert bool(outs[s_][4][k]) == ref['converged']
+            if not ref['converged']:
+                break
+            assert np.allclose(outs[s_][0][k], ref['obs'], rtol=0, atol=R_TOL, equal_nan=True), (k, s_)
+            assert np.isclose(outs[s_][1][k], ref['reward'], rtol=1e-7, atol=R_TOL), (k, s_)
+            assert bool(outs[s_][2][k]) == bool(ref['terminated']) and bool(outs[s_][3][k]) == bool(ref['truncated'])
+            n += 1
+            if ref['terminated'] or ref['truncated']:
+                break
+    assert n >= B * 2
 
 
 def test_n_minus_one_with_an_islanding_contingency():
