@@ -51,19 +51,26 @@ def run_one(base, kw, rng, n_samples=3):
     kwargs = dict(base_kwargs)
     kwargs.update(kw)
     kwargs.pop('grid_seed', None)                     # (a parameter of this repo's synthetic grids only)
-    kwargs.pop('initial_action', None)                # (drawn from the action space's own generator)
     kwargs.pop('n_minus_one_lines', None)             # (the reference example hard-codes lines 1, 3, 7)
     ref = mg.REF[cls](seed=seed, **kwargs)
     prod = getattr(product_envs, cls)(seed=seed, batch_size=1, defer_device=True, **kwargs)
     orc = env_cases.oracle_env(base, prod)
     orc.carry_over = True        # the reference keeps its net between episodes (see EnvOracle.carry_over, D12)
     S = kwargs.get('steps_per_episode', 1)
+    sampled = []                                      # initial_action='random': the action space's own draws
+    space_sample = ref.action_space.sample
+
+    def logged_sample(*a, **k):
+        sampled.append(np.array(space_sample(*a, **k), dtype=float))
+        return sampled[-1]
+    ref.action_space.sample = logged_sample
     checked = 0
     for k in range(n_samples):
         is_test = 'test_data' in kwargs and rng.random() < 0.4
         distr = kwargs.get('test_data', 'simbench') if is_test else kwargs.get('train_data', 'simbench')
         pool = ref.test_steps if is_test else ref.train_steps
         step = int(rng.choice(pool))
+        del sampled[:]
         try:
             obs0, _ = ref.reset(seed=seed * 100 + k, options={'step': step, 'test': is_test})
         except RecursionError:
@@ -77,7 +84,8 @@ def run_one(base, kw, rng, n_samples=3):
         if any(kd not in ('uniform', 'random', 'random_scalar', 'normal') for kd, _ in log):
             raise AssertionError(('unexpected draw kinds', sorted({kd for kd, _ in log})))
         ob = orc.reset(step, uni, noise_factors(kwargs, noise, distr), interp=interp if interp.size else None,
-                       normal=normal if normal.size else (), data=distr)
+                       normal=normal if normal.size else (), data=distr,
+                       initial_action=sampled[-1] if sampled else None)
         assert np.allclose(obs0, ob, rtol=0, atol=TOL, equal_nan=True), ('reset obs', k, float(np.nanmax(np.abs(obs0 - ob))))
         for s_ in range(S):
             action = rng.random(ref.action_space.shape[0])
