@@ -55,6 +55,11 @@ def run_one(base, kw, rng, n_samples=3):
     ref = mg.REF[cls](seed=seed, **kwargs)
     prod = getattr(product_envs, cls)(seed=seed, batch_size=1, defer_device=True, **kwargs)
     orc = env_cases.oracle_env(base, prod)
+    # spaces of the host mirror (get_obs_and_state_space, opf_env.py:720-803)
+    assert prod.action_space.shape == ref.action_space.shape, ('action space', prod.action_space.shape, ref.action_space.shape)
+    assert prod.observation_space.shape == ref.observation_space.shape, ('obs space shape',)
+    assert np.allclose(prod.observation_space.low, ref.observation_space.low, rtol=0, atol=1e-9, equal_nan=True), ('obs low',)
+    assert np.allclose(prod.observation_space.high, ref.observation_space.high, rtol=0, atol=1e-9, equal_nan=True), ('obs high',)
     orc.carry_over = True        # the reference keeps its net between episodes (see EnvOracle.carry_over, D12)
     S = kwargs.get('steps_per_episode', 1)
     sampled = []                                      # initial_action='random': the action space's own draws
