@@ -514,10 +514,25 @@ class BatchedOpfEnv:
                         raise NotImplementedError('bus-bus switches as actuators change the bus set of the '
                                                   'compiled plan: not supported')
                     tbl = 'line' if et == 'l' else 'trafo'
-                    k = branch(KIND_LINE if et == 'l' else KIND_TRAFO, st.rows(tbl, [elem])[0], 'switch.closed')
+                    kind, pos = (KIND_LINE if et == 'l' else KIND_TRAFO), st.rows(tbl, [elem])[0]
+                    k = branch(kind, pos, 'switch.closed')
+                    # open: the element stays connected at its other end (a shunt there, case.py
+                    # open_ended_stamps) unless a second switch is open too — asked from the case builder itself
+                    sw_idx = net['switch'].index[int(r)]
+                    saved = bool(net['switch'].at[sw_idx, 'closed'])
+                    others = [(u, cl, [i for i in ix if not (u == 'switch' and i == sw_idx)])
+                              for u, cl, ix in self.act_keys]
+                    try:
+                        net['switch'].at[sw_idx, 'closed'] = False
+                        cp = _case_all_branches_in(net, others)
+                    finally:
+                        net['switch'].at[sw_idx, 'closed'] = saved
+                    hit = [j for j, (kd, e) in enumerate(zip(cp.br_kind, cp.br_elem)) if (int(kd), int(e)) == (kind, int(pos))]
+                    opened = _branch_stamps(cp, hit[0]) if hit else [0.0] * 8
                 else:
                     k = branch(KIND_LINE if unit == 'line' else KIND_TRAFO, r, f'{unit}.in_service')
-                bmod.append(dict(branch=k, slot=slot0 + int(r), lo=0, table=[[0.0] * 8, _branch_stamps(c, k)]))
+                    opened = [0.0] * 8
+                bmod.append(dict(branch=k, slot=slot0 + int(r), lo=0, table=[opened, _branch_stamps(c, k)]))
         else:
             raise NotImplementedError(f'actuator {unit}.{col} is not supported')
 

@@ -81,6 +81,24 @@ def branch_stamps(r, x, bc, ratio, shift_rad):
     return yff, yft, ytf, ytt
 
 
+def open_ended_stamps(yff, yft, ytf, ytt, side):
+    """Branch with an open switch at one end (side 1: from/hv end open, 2: to/lv end open): no current
+    enters at the open end, so its voltage follows from I = 0 there and what remains is a shunt at
+    the connected end — ytt - ytf yft / yff, resp. yff - yft ytf / ytt — exactly what pandapower's
+    auxiliary bus at the open end gives."""
+    yff, yft, ytf, ytt = (np.array(a, dtype=complex) for a in (yff, yft, ytf, ytt))
+    side = np.asarray(side)
+    o1, o2 = side == 1, side == 2
+    with np.errstate(divide='ignore', invalid='ignore'):
+        eq_t = ytt - ytf * yft / yff
+        eq_f = yff - yft * ytf / ytt
+    ytt = np.where(o1, eq_t, np.where(o2, 0.0, ytt))
+    yff = np.where(o2, eq_f, np.where(o1, 0.0, yff))
+    yft = np.where(o1 | o2, 0.0, yft)
+    ytf = np.where(o1 | o2, 0.0, ytf)
+    return yff, yft, ytf, ytt
+
+
 class _UnionFind:
     def __init__(self, keys):
         self.p = {k: k for k in keys}
@@ -112,10 +130,13 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     """Convert the element tables of `net` into a per-unit :class:`Case`.
 
     Restates pandapower `_pd2ppc` (third party):
-      * closed bus-bus switches fuse buses; an open line/trafo switch takes
-        the element out of service (pandapower keeps an open-ended line
-        charged through an auxiliary bus; that residual charging current is
-        neglected here — documented deviation);
+      * closed bus-bus switches fuse buses; a line / transformer with an open
+        switch at BOTH ends is out of service; with an open switch at ONE end
+        it stays connected at the other (pandapower re-routes the open end to
+        an auxiliary bus, so the element keeps drawing its charging /
+        magnetising current): here the auxiliary bus is eliminated exactly —
+        the branch becomes a shunt y = Yff - Yft Ytf / Ytt at its connected
+        end (`open_ended_stamps`), with no coupling to the other bus;
       * line:  r,x [Ω/km]·len/parallel ÷ Zbase,  b = 2πf·C·len·parallel·Zbase,
         Zbase = vn_kv(from bus)² / sn_mva;
       * trafo: short-circuit impedance from vk/vkr referred to the LV side,
@@ -132,7 +153,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
 
     # --- switches ---------------------------------------------------------
     uf = _UnionFind(bus_ids)
-    line_off, trafo_off = set(), set()
+    line_open, trafo_open = {}, {}          # element -> buses at which one of its switches is open
     sw = net['switch'] if 'switch' in net else None
     if sw is not None and len(sw):
         for b, e, et, closed in zip(sw['bus'], sw['element'], sw['et'], sw['closed']):
@@ -141,10 +162,15 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
                     uf.union(int(b), int(e))
             elif et == 'l':
                 if not closed:
-                    line_off.add(int(e))
+                    line_open.setdefault(int(e), set()).add(int(b))
             elif et == 't':
                 if not closed:
-                    trafo_off.add(int(e))
+                    trafo_open.setdefault(int(e), set()).add(int(b))
+
+    def open_side(opened, elem, fb, tb):
+        """0: connected at both ends, 1: open at the from/hv end, 2: at the to/lv end, 3: both"""
+        at = opened.get(elem, ())
+        return (1 if fb in at else 0) | (2 if tb in at else 0)
 
     # --- ext_grid / gen decide angle handling -------------------------------
     eg = net['ext_grid']
@@ -159,7 +185,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     # --- branches -----------------------------------------------------------
     ln = net['line']
     tr = net['trafo']
-    rows = []  # (root_f, root_t, r, x, bc, ratio, shift, kind, elem_pos, kf_num, kt_num)
+    rows = []  # (root_f, root_t, r, x, bc, ratio, shift, kind, elem_pos, kf_num, kt_num, open side)
     vn = bus_df['vn_kv'].astype(float)
     bus_pos = {int(b): i for i, b in enumerate(bus_ids)}
     bus_on = lambda b: in_service_bus[bus_pos[b]]
@@ -182,13 +208,14 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             kf_l = base / (np.sqrt(3.0) * vn_f * imax) * 100.0
             kt_l = base / (np.sqrt(3.0) * vn_t * imax) * 100.0
         for pos, idx in enumerate(ln.index):
-            if not on[pos] or int(idx) in line_off:
-                continue
             fb, tb = int(fbs[pos]), int(tbs[pos])
+            side = open_side(line_open, int(idx), fb, tb)
+            if not on[pos] or side == 3:
+                continue
             if not (bus_on(fb) and bus_on(tb)):
                 continue
             bc = b_pu[pos] - 1j * g_pu[pos]      # j*bc/2 = (g + jb)/2 per side
-            rows.append((fb, tb, r_pu[pos], x_pu[pos], bc, 1.0, 0.0, KIND_LINE, pos, kf_l[pos], kt_l[pos]))
+            rows.append((fb, tb, r_pu[pos], x_pu[pos], bc, 1.0, 0.0, KIND_LINE, pos, kf_l[pos], kt_l[pos], side))
     if len(tr):
         on = _col(tr, 'in_service', True).astype(bool)
         par = _col(tr, 'parallel', 1.0)
@@ -198,9 +225,10 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         tap_step = _col(tr, 'tap_step_percent', np.nan)
         shift = _col(tr, 'shift_degree', 0.0)
         for pos, idx in enumerate(tr.index):
-            if not on[pos] or int(idx) in trafo_off:
-                continue
             hb, lb = int(tr.at[idx, 'hv_bus']), int(tr.at[idx, 'lv_bus'])
+            oside = open_side(trafo_open, int(idx), hb, lb)
+            if not on[pos] or oside == 3:
+                continue
             if not (bus_on(hb) and bus_on(lb)):
                 continue
             sn = float(tr.at[idx, 'sn_mva'])
@@ -247,7 +275,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             sh = np.deg2rad(shift[pos]) if calc_angles else 0.0
             kf = base * (vn_hv / vb_hv) / sn * 100.0 / (par[pos] * dfac[pos])
             kt = base * (vn_lv / vb_lv) / sn * 100.0 / (par[pos] * dfac[pos])
-            rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt))
+            rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt, oside))
 
     # --- which fused buses are alive: connected to a REF through branches ----
     roots = {b: uf.find(b) for b in bus_ids}
@@ -256,6 +284,8 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         raise ValueError('net has no in-service ext_grid (no slack bus)')
     adj = {}
     for row in rows:
+        if row[11]:                       # open-ended: hangs on one bus, connects nothing
+            continue
         a, b = roots[row[0]], roots[row[1]]
         adj.setdefault(a, set()).add(b)
         adj.setdefault(b, set()).add(a)
@@ -275,12 +305,25 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
                   if roots[b] in root_to_case and in_service_bus[i]}
     nb = len(order)
 
-    rows = [r for r in rows if roots[r[0]] in root_to_case and roots[r[1]] in root_to_case]
-    fcase = np.array([root_to_case[roots[r[0]]] for r in rows], dtype=np.int32)
-    tcase = np.array([root_to_case[roots[r[1]]] for r in rows], dtype=np.int32)
+    def energised(r):
+        near = [roots[r[0]] in root_to_case, roots[r[1]] in root_to_case]
+        return all(near) if not r[11] else near[2 - r[11]]       # open-ended: its connected end must be alive
+    rows = [r for r in rows if energised(r)]
+
+    def end(r, which):
+        """case bus of an end; the open end of an open-ended branch couples to nothing, so when its bus
+        is not part of the case any other bus serves as the (unused) second index"""
+        root = roots[r[which]]
+        if root in root_to_case:
+            return root_to_case[root]
+        other = root_to_case[roots[r[1 - which]]]
+        return (other + 1) % nb
+    fcase = np.array([end(r, 0) for r in rows], dtype=np.int32)
+    tcase = np.array([end(r, 1) for r in rows], dtype=np.int32)
     yff, yft, ytf, ytt = branch_stamps(
         [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
         [r[5] for r in rows], [r[6] for r in rows])
+    yff, yft, ytf, ytt = open_ended_stamps(yff, yft, ytf, ytt, np.array([r[11] for r in rows], dtype=np.int32))
 
     bus_type = np.full(nb, PQ, dtype=np.int32)
     vm_set = np.ones(nb)
@@ -319,7 +362,8 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     # start angles: propagate the REF angle through transformer phase shifts
     # (equivalent in effect to pandapower's init='dc' for shifted MV grids:
     # the converged solution does not depend on the start)
-    va0 = _propagate_angles(nb, fcase, tcase, [r[6] for r in rows], bus_type, va_set)
+    conn = np.array([r[11] == 0 for r in rows], dtype=bool)
+    va0 = _propagate_angles(nb, fcase[conn], tcase[conn], [r[6] for r in rows if r[11] == 0], bus_type, va_set)
     va_set = np.where(bus_type == REF, va_set, va0)
 
     return Case(

@@ -600,7 +600,11 @@ __device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane)
 // and the two diagonal blocks with LDS atomics (several modifiers may meet on one bus), and
 // the mismatch norm is recomputed.  (Comparing every Ybus entry against the modifiers would
 // cost ~25 instructions per entry in every solve of every instance.)
-constexpr int MOD_DOUBLES = 12;     // dY[8] | ints: f, t, blk_ft, blk_tf, dblk_f, dblk_t, branch, removed
+constexpr int MOD_DOUBLES = 12;     // dY[8] | ints: f, t, blk_ft, blk_tf, dblk_f, dblk_t, branch, state
+// state of the modified branch: 0 coupled (another tap position), MOD_REMOVED out of service (no stamps at
+// all), MOD_OPEN_ENDED behind one open switch (a shunt at its connected end, see case.py:open_ended_stamps):
+// both of the latter connect nothing any more, only the first carries no current
+constexpr int MOD_REMOVED = 1, MOD_OPEN_ENDED = 2;
 __device__ __forceinline__ double* mod_dy(const Lds& L, int m) { return L.mod + m * MOD_DOUBLES; }
 __device__ __forceinline__ int* mod_ids(const Lds& L, int m) { return reinterpret_cast<int*>(L.mod + m * MOD_DOUBLES + 8); }
 
@@ -608,7 +612,8 @@ __device__ __forceinline__ int* mod_ids(const Lds& L, int m) { return reinterpre
 // `removed`: dY = -Y); lanes 8..12 fetch the ids.  Ends with a wave fence.
 // A removal also cancels what the first n_prev modifiers changed on the same branch (a
 // contingency on a transformer whose tap position differs from the compiled one).
-__device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane, int m, int br, double dy_lane, bool removed, int n_prev) {
+__device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane, int m, int br, double dy_lane, bool removed, int n_prev,
+                                        bool open_ended = false) {
   if (lane < 8) {
     double v = dy_lane;
     if (removed) {
@@ -620,9 +625,10 @@ __device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane
   int* id = mod_ids(L, m);
   if (lane == 8) { const int f = P.br_f[br]; id[0] = f; id[4] = P.diag_blk[f]; }
   if (lane == 9) { const int t = P.br_t[br]; id[1] = t; id[5] = P.diag_blk[t]; }
-  if (lane == 10) id[2] = P.y_blk[P.br_pos[br * 4 + 1]];
-  if (lane == 11) id[3] = P.y_blk[P.br_pos[br * 4 + 2]];
-  if (lane == 12) { id[6] = br; id[7] = removed ? 1 : 0; }
+  // (a branch compiled without coupling — open-ended in the net itself — has no off-diagonal stamps: -1)
+  if (lane == 10) { const int e = P.br_pos[br * 4 + 1]; id[2] = e >= 0 ? P.y_blk[e] : -1; }
+  if (lane == 11) { const int e = P.br_pos[br * 4 + 2]; id[3] = e >= 0 ? P.y_blk[e] : -1; }
+  if (lane == 12) { id[6] = br; id[7] = removed ? MOD_REMOVED : (open_ended ? MOD_OPEN_ENDED : 0); }
   wave_fence();
 }
 
@@ -1322,11 +1328,13 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
       const double* dy = mod_dy(L, m);
 #pragma unroll
       for (int q = 0; q < 8; ++q) y[q] += dy[q];
-      removed = removed || id[7] != 0;
+      removed = removed || id[7] == MOD_REMOVED;
     }
+    // |V| of a de-energised bus is NaN and so is every current computed with it (pandapower divides the
+    // branch's apparent power by it), in service or not
+    const int f = P.br_f[k], t = P.br_t[k];
+    if (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD) { r_ld[k] = __builtin_nan(""); continue; }
     if (!removed) {
-      const int f = P.br_f[k], t = P.br_t[k];
-      if (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD) { r_ld[k] = __builtin_nan(""); continue; }
       const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
       const double ifr = y[0] * vfr - y[1] * vfi + y[2] * vtr - y[3] * vti;
       const double ifi = y[0] * vfi + y[1] * vfr + y[2] * vti + y[3] * vtr;
@@ -1653,9 +1661,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       if (lane < 8) { y = as_global(E.bmod_y)[row * 8 + lane]; dy = y - P.br_y[br * 8 + lane]; }
       if (br == base_out || !__any(dy != 0.0)) continue;      // outaged anyway / state = compiled state
       const bool removed = !__any(y != 0.0);
-      if (wave == 0) mod_set(P, L, lane, n_mod_base, br, dy, removed, 0);
+      const bool uncoupled = !__any(lane >= 2 && lane < 6 && y != 0.0);     // out of service or open-ended
+      if (wave == 0) mod_set(P, L, lane, n_mod_base, br, dy, removed, 0, uncoupled);
       ++n_mod_base;
-      if (removed) { ++n_rem_base; if (P.br_island[br]) isl_br_base = br; }
+      if (uncoupled) { ++n_rem_base; if (P.br_island[br]) isl_br_base = br; }
     }
     if (V2 && base_out >= 0) { if (wave == 0) mod_set(P, L, lane, n_mod_base, base_out, 0.0, true, 0); ++n_mod_base; }
     if (base_out >= 0) { ++n_rem_base; if (P.br_island[base_out]) isl_br_base = base_out; }

@@ -340,12 +340,17 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
   std::vector<std::map<int32_t, std::pair<double, double>>> rows(nb);
   for (int32_t i = 0; i < nb; ++i)
     rows[i][i] = {c->gs ? c->gs[i] : 0.0, c->bs ? c->bs[i] : 0.0};
+  // a branch without coupling terms (open-ended in the net itself: a shunt at its connected end, case.py
+  // open_ended_stamps) adds to the diagonal only: no structural (f,t) entry, no edge for connectivity
+  std::vector<char> coupled(nbr, 1);
   for (int32_t k = 0; k < nbr; ++k) {
     const double* y = &p->br_y[(size_t)k * 8];
     int32_t f = p->br_f[k], t = p->br_t[k];
+    coupled[k] = (y[2] != 0.0 || y[3] != 0.0 || y[4] != 0.0 || y[5] != 0.0) ? 1 : 0;
     auto add = [&](int32_t i, int32_t j, double g, double b) {
       auto& e = rows[i][j]; e.first += g; e.second += b; };
-    add(f, f, y[0], y[1]); add(f, t, y[2], y[3]); add(t, f, y[4], y[5]); add(t, t, y[6], y[7]);
+    add(f, f, y[0], y[1]); add(t, t, y[6], y[7]);
+    if (coupled[k]) { add(f, t, y[2], y[3]); add(t, f, y[4], y[5]); }
   }
   p->y_ptr.assign(nb + 1, 0);
   p->y_diag.assign(nb, -1);
@@ -366,15 +371,15 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
   p->br_pos.resize((size_t)nbr * 4);
   for (int32_t k = 0; k < nbr; ++k) {
     int32_t f = p->br_f[k], t = p->br_t[k];
-    p->br_pos[k * 4 + 0] = ypos(f, f); p->br_pos[k * 4 + 1] = ypos(f, t);
-    p->br_pos[k * 4 + 2] = ypos(t, f); p->br_pos[k * 4 + 3] = ypos(t, t);
+    p->br_pos[k * 4 + 0] = ypos(f, f); p->br_pos[k * 4 + 1] = coupled[k] ? ypos(f, t) : -1;
+    p->br_pos[k * 4 + 2] = coupled[k] ? ypos(t, f) : -1; p->br_pos[k * 4 + 3] = ypos(t, t);
   }
 
   // ---- islanding outages: the Newton matrix of such a case is singular; the solvers report
   // them as not converged at once (pandapower would de-energise the island instead) ----------
   {
     std::vector<std::vector<std::pair<int32_t, int32_t>>> nbrs(nb);      // (other bus, branch)
-    for (int32_t k = 0; k < nbr; ++k) { nbrs[p->br_f[k]].push_back({p->br_t[k], k}); nbrs[p->br_t[k]].push_back({p->br_f[k], k}); }
+    for (int32_t k = 0; k < nbr; ++k) if (coupled[k]) { nbrs[p->br_f[k]].push_back({p->br_t[k], k}); nbrs[p->br_t[k]].push_back({p->br_f[k], k}); }
     p->br_island.assign(nbr, 0);
     p->isl_ptr.assign(1, 0);
     std::vector<char> seen(nb);

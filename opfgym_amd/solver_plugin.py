@@ -38,17 +38,24 @@ class BatchedPowerFlowSolver:
         self.device = device
         self.tol, self.max_it = tolerance, max_iteration
         self._cache = {}
+        self.max_cached_plans = 256
 
     def _context(self, case):
         key = (case.nb, case.nbr, case.bus_type.tobytes(), case.f.tobytes(), case.t.tobytes(),
                case.yff.tobytes(), case.yft.tobytes(), case.ytf.tobytes(), case.ytt.tobytes(),
                case.vm_set.tobytes(), case.va_set.tobytes(), case.gs.tobytes(), case.bs.tobytes())
-        hit = self._cache.get('key')
-        if hit != key:
+        # Compiled plans are kept per topology (most recently used last): the reference's N-1 loop
+        # (security_constrained.py:44-62) toggles one element at a time and comes back to every topology
+        # in every step, so each contingency is compiled once, not once per call.
+        ctx = self._cache.pop(key, None)
+        if ctx is None:
             import torch
             dev = torch.device(self.device)
-            self._cache = {'key': key, 'ctx': capi.Context(capi.Plan(case), dev.index or 0)}
-        return self._cache['ctx']
+            ctx = capi.Context(capi.Plan(case), dev.index or 0)
+            while len(self._cache) >= self.max_cached_plans:
+                self._cache.pop(next(iter(self._cache)))
+        self._cache[key] = ctx
+        return ctx
 
     def __call__(self, net, enforce_q_lims=True, **kwargs):
         import torch
@@ -76,19 +83,20 @@ class BatchedPowerFlowSolver:
                 vm[pos], va[pos] = r['vm'][i], np.degrees(r['va'][i])
         net['res_bus'] = pd.DataFrame({'vm_pu': vm, 'va_degree': va}, index=net['bus'].index)
         for tbl, kind in (('line', KIND_LINE), ('trafo', KIND_TRAFO)):
-            # in the solved case: its loading; out of service or behind an open switch: 0 % (no flow);
-            # in service but at a de-energised bus: NaN (as pandapower's result tables)
+            # part of the solved case: its loading (a branch behind ONE open switch is, it still carries its
+            # charging current).  Not part of it (out of service, open at both ends): 0 MVA over the voltages
+            # of its end buses, as pandapower computes i_ka — 0 % between energised buses, NaN next to a
+            # de-energised one.
             load = np.full(len(net[tbl]), np.nan)
             sel = case.br_kind == kind
             load[case.br_elem[sel]] = r['loading'][sel]
-            if len(net[tbl]):
-                off = ~net[tbl]['in_service'].to_numpy(bool) if 'in_service' in net[tbl].columns \
-                    else np.zeros(len(net[tbl]), bool)
-                sw = net['switch'] if 'switch' in net else None
-                if sw is not None and len(sw):
-                    opened = sw['element'][(sw['et'] == tbl[0]) & ~sw['closed'].to_numpy(bool)].to_numpy()
-                    off = off | np.isin(net[tbl].index.to_numpy(), opened)
-                load[off & np.isnan(load)] = 0.0
+            ends = ('from_bus', 'to_bus') if tbl == 'line' else ('hv_bus', 'lv_bus')
+            in_case = np.zeros(len(net[tbl]), bool)
+            in_case[case.br_elem[sel]] = True
+            for pos in np.flatnonzero(~in_case):
+                alive = all(int(net[tbl][e].iloc[pos]) in case.bus_lookup and
+                            not np.isnan(vm[net['bus'].index.get_loc(int(net[tbl][e].iloc[pos]))]) for e in ends)
+                load[pos] = 0.0 if alive else np.nan
             net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
         ref_buses = np.flatnonzero(case.bus_type == REF)
         ordinal = {int(b): k for k, b in enumerate(ref_buses)}

@@ -1,30 +1,38 @@
-"""CPU oracle for the solver half of the hot path (SURVEY.md §8a rows P3–P7).
+"""CPU oracle for the solver half of the hot path (SURVEY.md §8a rows P2–P7).
 
 TEST INFRASTRUCTURE ONLY.  Nothing in the product package `opfgym_amd/` may
 import or call this module; only `tests/`, `__graft_entry__.smoke()` and the
 `cpu_baseline` leg of `bench.py` do, and only as the checker / the timed CPU
-baseline.
+baseline.  Conversely nothing under `oracle/` imports the product: the case
+this solver works on is built by `oracle/pd2ppc.py` from the net's tables.
 
 What it restates: the Newton-Raphson AC power flow that the reference reaches
 through `pandapower.runpp(net, enforce_q_lims=True)` at
 `/root/reference/opfgym/opf_env.py:703`.  pandapower (`>=2.13.1,<3.0`,
 pyproject.toml:32) is a third-party dependency that is NOT vendored in
 /root/reference and NOT installed here, so this file restates the published
-pypower/MATPOWER algorithm it derives from: `makeYbus`, `makeSbus`, `newtonpf`
-(polar full Newton on [ΔP(pv∪pq); ΔQ(pq)], ∞-norm stop at `tol`, ≤10
-iterations, sparse direct solve — here SciPy SuperLU with partial pivoting, the
-same class of solver pandapower uses without lightsim2grid), the
-`enforce_q_lims` outer loop, `pfsoln` branch flows and pandapower's
-`loading_percent` definitions.
+pypower/MATPOWER algorithm it derives from: `makeYbus` (from r, x, b, tap,
+shift — not from admittance stamps), `makeSbus`, `newtonpf` (polar full Newton
+on [ΔP(pv∪pq); ΔQ(pq)], ∞-norm stop at `tol`, ≤10 iterations, sparse direct
+solve — here SciPy SuperLU with partial pivoting, the same class of solver
+pandapower uses without lightsim2grid), the per-generator `enforce_q_lims`
+outer loop of pypower's `runpf` (a generator beyond a limit is switched off,
+its bus becomes PQ and carries the limit as negative demand), `pfsoln` (branch
+flows; reactive dispatch split among generators sharing a bus in proportion to
+their ranges) and pandapower's result definitions (`i_ka`, `loading_percent`
+of lines and transformers with `trafo_loading='current'`).
 
 PARITY UNPINNED against pandapower: the reference's own tests hold no
 numerical power-flow result at all, and pandapower cannot be run
 here.  This oracle is pinned instead by (tests/test_oracle_pf.py):
   * the closed-form two-bus solution,
-  * the published WSCC 9-bus (`case9`) voltage profile,
-  * the published IEEE 14-bus solution (off-nominal taps, bus shunt, four PV buses; |V| to the three
-    published decimals, angles to 0.001 degree, slack generation and losses to 0.01 MW),
-  * algebraic self-checks (mismatch < tol, power balance = losses).
+  * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
+    (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to
+    0.001 degree, slack generation and losses to 0.01 MW), Grainger & Stevenson 4-bus, Wood &
+    Wollenberg 6-bus,
+  * algebraic self-checks (mismatch < tol, power balance = losses),
+  * `fixtures/*.npz` written by scripts/export_pandapower_case.py wherever pandapower exists
+    (none can be produced in this container: the test skips while the directory is empty).
 """
 from __future__ import annotations
 
@@ -32,7 +40,10 @@ import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.linalg import splu
 
-PQ, PV, REF = 1, 2, 3
+from . import pd2ppc
+from .pd2ppc import NONE, PPC, PQ, PV, REF
+
+EPS = np.finfo(float).eps
 
 
 class LoadflowNotConverged(Exception):
@@ -42,14 +53,41 @@ class LoadflowNotConverged(Exception):
 # --------------------------------------------------------------------------
 # P3: makeYbus / makeSbus
 # --------------------------------------------------------------------------
-def make_ybus(case, br_status=None) -> sp.csr_matrix:
-    nb = case.nb
-    s = np.ones(case.nbr) if br_status is None else np.asarray(br_status, float)
-    rows = np.concatenate([case.f, case.f, case.t, case.t, np.arange(nb)])
-    cols = np.concatenate([case.f, case.t, case.f, case.t, np.arange(nb)])
-    vals = np.concatenate([case.yff * s, case.yft * s, case.ytf * s, case.ytt * s,
-                           case.gs + 1j * case.bs])
-    return sp.csr_matrix((vals, (rows, cols)), shape=(nb, nb))
+def branch_admittances(ppc: PPC, status=None):
+    """pypower makeYbus, branch part: Ys = stat/(r+jx); Bc = stat*b; tap = ratio e^{j shift};
+    Ytt = Ys + j Bc/2; Yff = Ytt/(tap conj(tap)); Yft = -Ys/conj(tap); Ytf = -Ys/tap."""
+    stat = (ppc.status if status is None else np.asarray(status)).astype(float)
+    ys = stat / (ppc.r + 1j * ppc.x)
+    bc = stat * ppc.b
+    tap = ppc.tap * np.exp(1j * np.pi / 180.0 * ppc.shift)
+    ytt = ys + 1j * bc / 2.0
+    yff = ytt / (tap * np.conj(tap))
+    yft = -ys / np.conj(tap)
+    ytf = -ys / tap
+    return yff, yft, ytf, ytt
+
+
+def make_ybus(ppc: PPC, status=None) -> sp.csr_matrix:
+    nb, nl = ppc.nb, ppc.nbr
+    yff, yft, ytf, ytt = branch_admittances(ppc, status)
+    ysh = (ppc.gs + 1j * ppc.bs) / ppc.base_mva
+    cf = sp.csr_matrix((np.ones(nl), (np.arange(nl), ppc.f)), (nl, nb))
+    ct = sp.csr_matrix((np.ones(nl), (np.arange(nl), ppc.t)), (nl, nb))
+    yf = sp.diags(yff) @ cf + sp.diags(yft) @ ct
+    yt = sp.diags(ytf) @ cf + sp.diags(ytt) @ ct
+    return (cf.T @ yf + ct.T @ yt + sp.diags(ysh)).tocsr()
+
+
+def make_sbus(ppc: PPC, pd=None, qd=None, g_p=None, g_q=None, g_status=None):
+    """Net complex bus injection in p.u.: generation - demand."""
+    pd = ppc.pd if pd is None else pd
+    qd = ppc.qd if qd is None else qd
+    on = (ppc.g_status if g_status is None else g_status) > 0
+    s = -(pd + 1j * qd)
+    gp = ppc.g_p if g_p is None else g_p
+    gq = np.zeros(len(ppc.g_bus)) if g_q is None else g_q
+    np.add.at(s, ppc.g_bus[on], gp[on] + 1j * gq[on])
+    return s / ppc.base_mva
 
 
 # --------------------------------------------------------------------------
@@ -103,202 +141,256 @@ def newtonpf(ybus, sbus, v0, pv, pq, tol=1e-8, max_it=10):
     return v, bool(norm_f < tol), it, float(norm_f)
 
 
-# --------------------------------------------------------------------------
-# P5 + P6: outer q-limit loop and results
-# --------------------------------------------------------------------------
-def solve_case(case, p_inj, q_inj, qg_min=None, qg_max=None, qd_bus=None,
-               enforce_q_lims=False, tol=1e-8, max_it=10, br_status=None, v_init=None):
-    """Solve one instance.
+def start_voltage(ppc: PPC, init='flat'):
+    """'flat': |V| = 1 (set-points at PV/REF buses), angle = the slack angle carried through the
+    transformer phase shifts (a 150 degree vector group makes a literal flat start useless; pandapower's
+    default for such grids is init='dc').  'dc': angles of the DC power flow (pandapower `init='dc'`)."""
+    nb = ppc.nb
+    va = np.radians(ppc.va.copy())
+    seen = ppc.bus_type == REF
+    adj = [[] for _ in range(nb)]
+    for k in range(ppc.nbr):
+        if ppc.status[k]:
+            sh = np.radians(ppc.shift[k])
+            adj[int(ppc.f[k])].append((int(ppc.t[k]), -sh))
+            adj[int(ppc.t[k])].append((int(ppc.f[k]), +sh))
+    seen = seen.copy()
+    stack = [int(i) for i in np.flatnonzero(seen)]
+    while stack:
+        a = stack.pop()
+        for w, d in adj[a]:
+            if not seen[w]:
+                seen[w] = True
+                va[w] = va[a] + d
+                stack.append(w)
+    if init == 'dc':
+        va = _dc_angles(ppc, va)
+    return ppc.vm * np.exp(1j * va)
 
-    p_inj/q_inj: net bus injections in p.u. (generation − demand); q_inj at PV
-    buses is ignored while the bus is PV.  qg_min/qg_max/qd_bus [nb] in p.u.
-    describe the reactive capability of the generators at PV buses and the
-    reactive demand there (for the enforce_q_lims loop): when the
-    solved generator Q leaves [qg_min, qg_max] the bus becomes PQ with Q pinned
-    at the violated limit and the case is solved again.
-    Returns dict(V, converged, iterations, max_mismatch, bus_type).
-    """
-    ybus = make_ybus(case, br_status)
-    bus_type = case.bus_type.copy()
-    p = np.asarray(p_inj, float).copy()
-    q = np.asarray(q_inj, float).copy()
-    v = case.vm_set * np.exp(1j * case.va_set) if v_init is None else v_init.copy()
-    # pandapower `check_connectivity=True` (SURVEY P1): buses without a path to a slack are taken
-    # out of service; their voltages come back as NaN.
-    alive = energised_buses(case, br_status)
+
+def _dc_angles(ppc: PPC, va_start):
+    """pypower `makeBdc` + `dcpf` on the supplied part of the grid."""
+    on = ppc.status > 0
+    nb = ppc.nb
+    bdc = on / ppc.x / ppc.tap
+    nl = ppc.nbr
+    cft = sp.csr_matrix((np.r_[np.ones(nl), -np.ones(nl)], (np.r_[np.arange(nl), np.arange(nl)], np.r_[ppc.f, ppc.t])), (nl, nb))
+    bf = sp.diags(bdc) @ cft
+    bbus = (cft.T @ bf).tocsr()
+    pfinj = bdc * (-np.radians(ppc.shift))
+    pbusinj = cft.T @ pfinj
+    s = make_sbus(ppc).real - pbusinj - ppc.gs / ppc.base_mva
+    live = ppc.bus_type != NONE
+    free = np.flatnonzero(live & (ppc.bus_type != REF))
+    ref = np.flatnonzero(ppc.bus_type == REF)
+    va = va_start.copy()
+    if len(free):
+        rhs = s[free] - bbus[free][:, ref] @ va[ref]
+        va[free] = splu(bbus[free][:, free].tocsc()).solve(rhs)
+    return va
+
+
+# --------------------------------------------------------------------------
+# P5 + P6: outer q-limit loop (pypower runpf) and pfsoln
+# --------------------------------------------------------------------------
+def _gen_q_dispatch(ppc: PPC, sbus_calc, qd, g_status):
+    """pypower `pfsoln`, generator part: total reactive injection of a bus + local demand, shared
+    among the generators of the bus in proportion to their reactive ranges."""
+    on = np.flatnonzero(g_status > 0)
+    qg = np.zeros(len(ppc.g_bus))
+    if not len(on):
+        return qg
+    gbus = ppc.g_bus[on]
+    total = sbus_calc.imag[gbus] * ppc.base_mva + qd[gbus]
+    n_at = np.zeros(ppc.nb)
+    np.add.at(n_at, gbus, 1.0)
+    qg[on] = total / n_at[gbus]
+    if len(on) > 1:
+        qmin_b, qmax_b = np.zeros(ppc.nb), np.zeros(ppc.nb)
+        np.add.at(qmin_b, gbus, ppc.g_qmin[on])
+        np.add.at(qmax_b, gbus, ppc.g_qmax[on])
+        q_tot = np.zeros(ppc.nb)
+        np.add.at(q_tot, gbus, qg[on])
+        zero_range = qmin_b[gbus] == qmax_b[gbus]
+        share = ppc.g_qmin[on] + ((q_tot - qmin_b) / (qmax_b - qmin_b + EPS))[gbus] * (ppc.g_qmax[on] - ppc.g_qmin[on])
+        qg[on] = np.where(zero_range, qg[on], share)
+    return qg
+
+
+def solve(ppc: PPC, enforce_q_lims=False, tol=1e-8, max_it=10, status=None, v_init=None, init='flat'):
+    """Solve the case.  `status`: optional branch status vector replacing ppc.status (N-1 / outage
+    studies); buses that lose their supply are isolated as pandapower's `check_connectivity` does.
+    Returns dict(V, converged, iterations, max_mismatch, bus_type, ybus, qg, pg, supplied)."""
+    st = ppc.status if status is None else np.asarray(status).astype(np.int64)
+    ybus = make_ybus(ppc, st)
+    supplied = pd2ppc.supplied_buses(ppc, st) & (ppc.bus_type != NONE)
+    bus_type = np.where(supplied, ppc.bus_type, NONE)
+    g_status = ppc.g_status * supplied[ppc.g_bus]
+    pd_, qd_ = ppc.pd.copy(), ppc.qd.copy()
+    if v_init is not None:
+        v = v_init.copy()
+    elif status is None:
+        v = start_voltage(ppc, init)
+    else:
+        saved = ppc.status
+        ppc.status = st
+        try:
+            v = start_voltage(ppc, init)
+        finally:
+            ppc.status = saved
+    v = np.where(supplied, v, 1.0 + 0j)
     total_it = 0
+    g_q = np.zeros(len(ppc.g_bus))
+    fixed = np.zeros(len(ppc.g_bus), dtype=bool)        # generators pinned at a reactive limit
     while True:
-        pv = np.flatnonzero((bus_type == PV) & alive)
-        pq = np.flatnonzero((bus_type == PQ) & alive)
-        v, ok, it, nrm = newtonpf(ybus, p + 1j * q, v, pv, pq, tol, max_it)
+        # a bus keeps its PV type only while a voltage-controlling generator is on there (pypower `bustypes`)
+        has_gen = np.zeros(ppc.nb, dtype=bool)
+        has_gen[ppc.g_bus[(g_status > 0) & ~fixed]] = True
+        bt = np.where((bus_type == PV) & ~has_gen, PQ, bus_type)
+        pv = np.flatnonzero(bt == PV)
+        pq = np.flatnonzero(bt == PQ)
+        free_status = np.where(fixed, 0, g_status)
+        sbus = make_sbus(ppc, pd_, qd_, g_status=free_status)
+        v, ok, it, nrm = newtonpf(ybus, sbus, v, pv, pq, tol, max_it)
         total_it += it
-        if not ok or not enforce_q_lims or qg_min is None or len(pv) == 0:
-            break
         s_calc = v * np.conj(ybus @ v)
-        qg = s_calc.imag[pv] + qd_bus[pv]
-        hi = qg > qg_max[pv]
-        lo = qg < qg_min[pv]
+        qg_free = _gen_q_dispatch(ppc, s_calc, qd_, free_status)
+        g_q = np.where(fixed, g_q, qg_free)
+        if not ok or not enforce_q_lims:
+            break
+        cand = (free_status > 0) & (bt[ppc.g_bus] == PV)
+        hi = cand & (g_q > ppc.g_qmax)
+        lo = cand & (g_q < ppc.g_qmin)
         if not (hi.any() or lo.any()):
             break
-        fix = pv[hi | lo]
-        q[pv[hi]] = qg_max[pv[hi]] - qd_bus[pv[hi]]
-        q[pv[lo]] = qg_min[pv[lo]] - qd_bus[pv[lo]]
-        bus_type[fix] = PQ
-    v = np.where(alive, v, np.nan + 0j)
-    return dict(V=v, converged=ok, iterations=total_it, max_mismatch=nrm,
-                bus_type=bus_type, ybus=ybus)
+        g_q = np.where(hi, ppc.g_qmax, np.where(lo, ppc.g_qmin, g_q))
+        for g in np.flatnonzero(hi | lo):               # switched off, output booked as negative demand
+            fixed[g] = True
+            pd_[ppc.g_bus[g]] -= ppc.g_p[g]
+            qd_[ppc.g_bus[g]] -= g_q[g]
+    # slack generation (pfsoln): P of the first generator at each REF bus balances the bus
+    g_p = ppc.g_p.copy()
+    for i in np.flatnonzero(bus_type == REF):
+        at = np.flatnonzero((ppc.g_bus == i) & (g_status > 0))
+        if len(at):
+            others = g_p[at[1:]].sum()
+            g_p[at[0]] = s_calc[i].real * ppc.base_mva + ppc.pd[i] - others
+    v_out = np.where(supplied, v, np.nan + 0j)
+    return dict(V=v_out, converged=ok, iterations=total_it, max_mismatch=nrm, bus_type=bt, ybus=ybus,
+                qg=g_q, pg=g_p, supplied=supplied, status=st, fixed=fixed)
 
 
-def energised_buses(case, br_status=None):
-    """Buses with a path of in-service branches to a REF bus."""
-    nb = case.nb
-    on = np.ones(case.nbr, bool) if br_status is None else np.asarray(br_status) != 0
-    adj = [[] for _ in range(nb)]
-    for k in np.flatnonzero(on):
-        adj[int(case.f[k])].append(int(case.t[k])); adj[int(case.t[k])].append(int(case.f[k]))
-    alive = np.zeros(nb, bool)
-    stack = [int(i) for i in np.flatnonzero(case.bus_type == REF)]
-    for i in stack:
-        alive[i] = True
-    while stack:
-        u = stack.pop()
-        for w in adj[u]:
-            if not alive[w]:
-                alive[w] = True
-                stack.append(w)
-    return alive
+def branch_flows(ppc: PPC, v, status=None):
+    """pfsoln, branch part: complex power into the branch at both ends, p.u."""
+    st = ppc.status if status is None else np.asarray(status)
+    yff, yft, ytf, ytt = branch_admittances(ppc, st)
+    vf, vt = v[ppc.f], v[ppc.t]
+    s_f = vf * np.conj(yff * vf + yft * vt)
+    s_t = vt * np.conj(ytf * vf + ytt * vt)
+    return s_f, s_t
 
 
-def branch_results(case, v, br_status=None):
-    """pfsoln branch part + pandapower loading definitions:
-    i_ka = |S|/(√3·vm·vn) so |I| p.u. × kf/kt gives percent of rating."""
-    s = np.ones(case.nbr) if br_status is None else np.asarray(br_status, float)
-    i_f = (case.yff * v[case.f] + case.yft * v[case.t]) * s
-    i_t = (case.ytf * v[case.f] + case.ytt * v[case.t]) * s
-    s_f = v[case.f] * np.conj(i_f)
-    s_t = v[case.t] * np.conj(i_t)
-    loading = np.maximum(np.abs(i_f) * case.kf, np.abs(i_t) * case.kt)
-    loading = np.where(s == 0, 0.0, loading)              # out of service: 0 %, also next to a dead bus
-    return dict(s_from=s_f, s_to=s_t, i_from=np.abs(i_f), i_to=np.abs(i_t),
-                loading_percent=loading)
+def loading_percent(ppc: PPC, net, v, status=None):
+    """pandapower `_get_line_results` / `_get_trafo_results` / `_get_trafo3w_results`:
+    i_ka = |S| / (sqrt(3) |V| vn_bus); lines: max(i_from, i_to) / (max_i_ka df parallel);
+    transformers (`trafo_loading='current'`): max over the windings of i_ka vn_rated sqrt(3) / sn,
+    divided by parallel and df.  A branch that is switched off carries no power: 0 %; |V| of an
+    isolated bus is NaN and so is every current computed with it (the maxima propagate NaN, as
+    numpy's do).  Returns {table: array over the table's rows}."""
+    st = ppc.status if status is None else np.asarray(status)
+    s_f, s_t = branch_flows(ppc, np.nan_to_num(v, nan=0.0), st)
+    vm = np.abs(v)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        i_f = np.abs(s_f) * ppc.base_mva / (np.sqrt(3.0) * vm[ppc.f] * ppc.base_kv[ppc.f])
+        i_t = np.abs(s_t) * ppc.base_mva / (np.sqrt(3.0) * vm[ppc.t] * ppc.base_kv[ppc.t])
+    out = {}
+    for table in ('line', 'trafo', 'trafo3w'):
+        df = net[table] if table in net else None
+        n = 0 if df is None else len(df)
+        res = np.full(n, np.nan)
+        first = np.ones(n, dtype=bool)
+        for k in np.flatnonzero(np.array([tb == table for tb in ppc.br_table], dtype=bool)) if n else ():
+            pos = int(ppc.br_pos[k])
+            if table == 'line':
+                i_max = float(df['max_i_ka'].iloc[pos]) * _opt(df, 'df', pos, 1.0) * _opt(df, 'parallel', pos, 1.0)
+                res[pos] = np.maximum(i_f[k], i_t[k]) / i_max * 100.0
+            elif table == 'trafo':
+                sn = float(df['sn_mva'].iloc[pos])
+                ld = np.maximum(i_f[k] * float(df['vn_hv_kv'].iloc[pos]), i_t[k] * float(df['vn_lv_kv'].iloc[pos]))
+                res[pos] = ld * np.sqrt(3.0) / sn * 100.0 / _opt(df, 'parallel', pos, 1.0) / _opt(df, 'df', pos, 1.0)
+            else:
+                side = ppc.br_side[k]
+                sn = float(df[f'sn_{side}_mva'].iloc[pos])
+                i_side = i_f[k] if side == 'hv' else i_t[k]          # current at the terminal, not at the star point
+                ld = i_side * float(df[f'vn_{side}_kv'].iloc[pos]) * np.sqrt(3.0) / sn * 100.0
+                res[pos] = ld if first[pos] else np.maximum(res[pos], ld)
+                first[pos] = False
+        out[table] = res
+    return out
+
+
+def _opt(df, col, pos, default):
+    if col not in df.columns:
+        return default
+    v = df[col].iloc[pos]
+    try:
+        v = float(v)
+    except (TypeError, ValueError):
+        return default
+    return default if np.isnan(v) else v
 
 
 # --------------------------------------------------------------------------
 # DataFrame level: the `power_flow_solver(net)` contract (opf_env.py:53,657)
 # --------------------------------------------------------------------------
-def bus_injections(net, case):
-    """makeSbus on the element tables: generation − demand per case bus, MW."""
-    nb = case.nb
-    p = np.zeros(nb)
-    q = np.zeros(nb)
-    qd = np.zeros(nb)
-    for tbl, sign in (('load', -1.0), ('sgen', 1.0), ('storage', -1.0)):
-        df = net[tbl]
-        if not len(df):
-            continue
-        on = df['in_service'].to_numpy(bool) if 'in_service' in df.columns else np.ones(len(df), bool)
-        sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns else np.ones(len(df))
-        for pos, b in enumerate(df['bus'].to_numpy()):
-            if on[pos] and int(b) in case.bus_lookup:
-                i = case.bus_lookup[int(b)]
-                p[i] += sign * float(df['p_mw'].iloc[pos]) * sc[pos]
-                qv = sign * float(df['q_mvar'].iloc[pos]) * sc[pos]
-                q[i] += qv
-                qd[i] -= qv
-    gen = net['gen']
-    qmin = np.full(nb, -np.inf)
-    qmax = np.full(nb, np.inf)
-    if len(gen):
-        on = gen['in_service'].to_numpy(bool)
-        sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns else np.ones(len(gen))
-        lim_lo = np.zeros(nb)
-        lim_hi = np.zeros(nb)
-        has = np.zeros(nb, bool)
-        for pos, b in enumerate(gen['bus'].to_numpy()):
-            if on[pos] and int(b) in case.bus_lookup:
-                i = case.bus_lookup[int(b)]
-                p[i] += float(gen['p_mw'].iloc[pos]) * sc[pos]
-                lo = float(gen['min_q_mvar'].iloc[pos]) if 'min_q_mvar' in gen.columns else np.nan
-                hi = float(gen['max_q_mvar'].iloc[pos]) if 'max_q_mvar' in gen.columns else np.nan
-                lim_lo[i] += -np.inf if np.isnan(lo) else lo
-                lim_hi[i] += np.inf if np.isnan(hi) else hi
-                has[i] = True
-        qmin[has], qmax[has] = lim_lo[has], lim_hi[has]
-    return p, q, qd, qmin, qmax
-
-
-def runpp(net, enforce_q_lims=True, tol=1e-8, max_it=10, **kwargs):
+def runpp(net, enforce_q_lims=True, tol=1e-8, max_it=10, init='flat', **kwargs):
     """`power_flow_solver(net)` built on the oracle: same contract as
     OpfEnv.default_power_flow (opf_env.py:696-709) — mutates `net.res_*` in
     place, raises LoadflowNotConverged on failure."""
-    import pandas as pd
-    from opfgym_amd.case import net_to_case
-    case = net_to_case(net)
-    base = case.base_mva
-    p, q, qd, qmin, qmax = bus_injections(net, case)
-    sol = solve_case(case, p / base, q / base, qmin / base, qmax / base, qd / base,
-                     enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it)
+    ppc = pd2ppc.build_ppc(net)
+    sol = solve(ppc, enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it, init=init)
     if not sol['converged']:
         exc = kwargs.get('not_converged_exception', LoadflowNotConverged)
         raise exc('power flow did not converge')
-    write_results(net, case, sol, p, q, qd)
+    write_results(net, ppc, sol)
+    sol['ppc'] = ppc
     return sol
 
 
-def write_results(net, case, sol, p_mw_bus, q_mvar_bus, qd_mvar_bus):
+def write_results(net, ppc: PPC, sol):
     import pandas as pd
     v = sol['V']
-    base = case.base_mva
     vm = np.full(len(net['bus']), np.nan)
     va = np.full(len(net['bus']), np.nan)
+    on = net['bus']['in_service'].to_numpy(bool) if 'in_service' in net['bus'].columns else np.ones(len(vm), bool)
     for pos, b in enumerate(net['bus'].index):
-        if int(b) in case.bus_lookup:
-            i = case.bus_lookup[int(b)]
+        i = ppc.bus_lookup[int(b)]
+        if on[pos] and sol['supplied'][i]:
             vm[pos], va[pos] = abs(v[i]), np.degrees(np.angle(v[i]))
     net['res_bus'] = pd.DataFrame({'vm_pu': vm, 'va_degree': va}, index=net['bus'].index)
-    br = branch_results(case, v)
-    for tbl, kind in (('line', 0), ('trafo', 1)):
-        load = np.full(len(net[tbl]), np.nan)
-        sel = case.br_kind == kind
-        load[case.br_elem[sel]] = br['loading_percent'][sel]
-        if len(net[tbl]):
-            # an element that is out of service or behind an open switch carries no flow: 0 % (pypower's
-            # pfsoln zeroes the flows of status-0 branches); an in-service element at a de-energised bus: NaN
-            off = ~net[tbl]['in_service'].to_numpy(bool)
-            sw = net['switch'] if 'switch' in net else None
-            if sw is not None and len(sw):        # behind an open switch: taken out by net_to_case
-                opened = sw['element'][(sw['et'] == tbl[0]) & ~sw['closed'].to_numpy(bool)].to_numpy()
-                off = off | np.isin(net[tbl].index.to_numpy(), opened)
-            load[off & np.isnan(load)] = 0.0
-        net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
-    s_bus = v * np.conj(sol['ybus'] @ v) * base
-    eg = net['ext_grid']
-    pe = np.full(len(eg), np.nan)
-    qe = np.full(len(eg), np.nan)
-    for pos, b in enumerate(eg['bus'].to_numpy()):
-        if int(b) in case.bus_lookup:
-            i = case.bus_lookup[int(b)]
-            pe[pos] = s_bus[i].real - p_mw_bus[i]
-            qe[pos] = s_bus[i].imag - q_mvar_bus[i]
+    ld = loading_percent(ppc, net, v, sol['status'])
+    for table in ('line', 'trafo', 'trafo3w'):
+        if table in net:
+            net['res_' + table] = pd.DataFrame({'loading_percent': ld[table]}, index=net[table].index)
+    eg, gen = net['ext_grid'], net['gen']
+    pe, qe = np.full(len(eg), np.nan), np.full(len(eg), np.nan)
+    pg, qg, vg = np.full(len(gen), np.nan), np.full(len(gen), np.nan), np.full(len(gen), np.nan)
+    for g in range(len(ppc.g_bus)):
+        live = ppc.g_status[g] > 0 and sol['supplied'][ppc.g_bus[g]]
+        pos = int(ppc.g_pos[g])
+        if ppc.g_table[g] == 'ext_grid':
+            if live:
+                pe[pos], qe[pos] = sol['pg'][g], sol['qg'][g]
+        elif live:
+            pg[pos], qg[pos], vg[pos] = sol['pg'][g], sol['qg'][g], abs(v[ppc.g_bus[g]])
     net['res_ext_grid'] = pd.DataFrame({'p_mw': pe, 'q_mvar': qe}, index=eg.index)
+    if len(gen):
+        net['res_gen'] = pd.DataFrame({'p_mw': pg, 'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
+    else:
+        net['res_gen'] = pd.DataFrame({'p_mw': [], 'q_mvar': [], 'vm_pu': []})
     for tbl in ('load', 'sgen', 'storage'):
         df = net[tbl]
         sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns and len(df) else 1.0
         net['res_' + tbl] = pd.DataFrame(
             {'p_mw': df['p_mw'].to_numpy(float) * sc if len(df) else [],
              'q_mvar': df['q_mvar'].to_numpy(float) * sc if len(df) else []}, index=df.index)
-    gen = net['gen']
-    if len(gen):
-        sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns else 1.0
-        qg = np.full(len(gen), np.nan)
-        vmg = np.full(len(gen), np.nan)
-        for pos, b in enumerate(gen['bus'].to_numpy()):
-            if int(b) in case.bus_lookup:
-                i = case.bus_lookup[int(b)]
-                # reactive output = calculated bus injection + local reactive demand
-                qg[pos] = s_bus[i].imag + qd_mvar_bus[i]
-                vmg[pos] = abs(v[i])
-        net['res_gen'] = pd.DataFrame({'p_mw': gen['p_mw'].to_numpy(float) * sc,
-                                       'q_mvar': qg, 'vm_pu': vmg}, index=gen.index)
-    else:
-        net['res_gen'] = pd.DataFrame({'p_mw': [], 'q_mvar': [], 'vm_pu': []})

@@ -102,7 +102,7 @@ def main():
                 kw.update(qg_min=torch.tensor(-lim, device=dev), qg_max=torch.tensor(lim, device=dev), enforce_q_lims=True)
                 okw.update(qg_min=-lim, qg_max=lim, enforce_q_lims=True)
             got = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw).items()}
-            ref = oracle_batch(case, p, q, **okw)
+            ref = oracle_batch(net, case, p, q, **okw)
             both = ref['converged'] & got['converged'].astype(bool)
             # islanding outages de-energise the island (NaN voltages there): compared separately below
             isl = np.isnan(got['vm']).any(axis=1)

@@ -1,13 +1,20 @@
-"""Shared helpers for the test-suite (test code only)."""
+"""Shared helpers for the test-suite (test code only).
+
+The two sides of every parity test are built independently: the product side from
+`opfgym_amd.case.net_to_case` (branch admittance stamps, product bus order), the oracle side from
+`oracle.pd2ppc.build_ppc` (r/x/b/tap/shift branch table, its own bus order, auxiliary buses).  The
+only thing they share is the NET's bus / element indices, through which results are matched."""
+import copy
+
 import numpy as np
 
-from opfgym_amd.case import net_to_case
+from oracle import pd2ppc
 from oracle import pf_oracle as po
 
 
 def random_injections(net, case, B, seed, lo=0.2, hi=1.1):
     """B instances: every unit's P/Q scaled by its own uniform factor; returns
-    p_inj, q_inj [B, nb] in p.u. (generation - demand)."""
+    p_inj, q_inj [B, nb] in p.u. (generation - demand) in the product's bus order."""
     rng = np.random.default_rng(seed)
     base = case.base_mva
     nb = case.nb
@@ -28,33 +35,73 @@ def random_injections(net, case, B, seed, lo=0.2, hi=1.1):
     return p, q
 
 
-def oracle_batch(case, p, q, **kw):
-    """Solve every row with the SciPy oracle."""
+class OracleSide:
+    """The oracle's own case of `net` plus the index maps product order -> oracle order (via the net)."""
+
+    def __init__(self, net, case):
+        self.net, self.case = net, case
+        self.ppc = pd2ppc.build_ppc(net)
+        first = {}
+        for b, i in case.bus_lookup.items():
+            first.setdefault(i, b)
+        self.bus_map = np.array([self.ppc.bus_lookup[first[i]] for i in range(case.nb)])   # product bus -> ppc bus
+        tables = {0: 'line', 1: 'trafo'}
+        self.br_map = np.array([self.ppc.branch_of(tables[int(kd)], int(e)) for kd, e in zip(case.br_kind, case.br_elem)])
+        assert (self.br_map >= 0).all()
+        self.ref = np.flatnonzero(case.bus_type == 3)
+
+    def solve(self, p, q, outage=-1, qg_min=None, qg_max=None, enforce_q_lims=False, tol=1e-8, max_it=10):
+        """One instance: bus injections p, q [nb] (p.u., product order; generator active power included
+        in p) -> results in product order."""
+        ppc, case = copy.copy(self.ppc), self.case
+        base = ppc.base_mva
+        ppc.pd, ppc.qd = np.zeros(ppc.nb), np.zeros(ppc.nb)
+        ppc.pd[self.bus_map] = -p * base
+        ppc.qd[self.bus_map] = -q * base
+        ppc.g_p = np.zeros(len(ppc.g_bus))
+        if qg_min is not None:                 # per product bus, shared equally by the generators of the bus
+            ppc.g_qmin, ppc.g_qmax = ppc.g_qmin.copy(), ppc.g_qmax.copy()
+            inv = {int(b): i for i, b in enumerate(self.bus_map)}
+            n_at = np.bincount(ppc.g_bus, minlength=ppc.nb)
+            for g in range(len(ppc.g_bus)):
+                if ppc.g_table[g] == 'gen' and int(ppc.g_bus[g]) in inv:
+                    i = inv[int(ppc.g_bus[g])]
+                    ppc.g_qmin[g] = max(qg_min[i] * base / n_at[ppc.g_bus[g]], -1e9)
+                    ppc.g_qmax[g] = min(qg_max[i] * base / n_at[ppc.g_bus[g]], 1e9)
+        status = None
+        if outage is not None and outage >= 0:
+            status = ppc.status.copy()
+            status[self.br_map[outage]] = 0
+        sol = po.solve(ppc, enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it, status=status)
+        v = sol['V'][self.bus_map]
+        ld = po.loading_percent(ppc, self.net, sol['V'], sol['status'])
+        loading = np.array([ld['line' if kd == 0 else 'trafo'][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])
+        s_calc = (sol['V'] * np.conj(sol['ybus'] @ np.nan_to_num(sol['V'])))[self.bus_map]
+        sref = np.stack([s_calc.real[self.ref] - p[self.ref], s_calc.imag[self.ref] - q[self.ref]], axis=1)
+        return dict(vm=np.abs(v), va=np.angle(v), loading=loading, s_ref=sref, converged=sol['converged'],
+                    iterations=sol['iterations'], V=v)
+
+
+def oracle_batch(net, case, p, q, **kw):
+    """Solve every row with the oracle, built from `net` by the oracle's own converter."""
+    side = OracleSide(net, case)
     B = p.shape[0]
-    vm = np.zeros((B, case.nb))
-    va = np.zeros((B, case.nb))
-    load = np.zeros((B, case.nbr))
-    sref = np.zeros((B, int((case.bus_type == 3).sum()), 2))
-    conv = np.zeros(B, bool)
-    its = np.zeros(B, int)
+    out = dict(vm=np.zeros((B, case.nb)), va=np.zeros((B, case.nb)), loading=np.zeros((B, case.nbr)),
+               s_ref=np.zeros((B, len(side.ref), 2)), converged=np.zeros(B, bool), iterations=np.zeros(B, int))
+    outage = kw.pop('outage', None)
     for b in range(B):
-        outage = kw.get('outage')
-        st = None
-        if outage is not None and outage[b] >= 0:
-            st = np.ones(case.nbr)
-            st[outage[b]] = 0.0
-        sol = po.solve_case(case, p[b], q[b], qg_min=kw.get('qg_min'), qg_max=kw.get('qg_max'),
-                            qd_bus=-q[b], enforce_q_lims=kw.get('enforce_q_lims', False),
-                            tol=kw.get('tol', 1e-8), max_it=kw.get('max_it', 10), br_status=st)
-        v = sol['V']
-        vm[b], va[b] = np.abs(v), np.angle(v)
-        conv[b], its[b] = sol['converged'], sol['iterations']
-        load[b] = po.branch_results(case, v, st)['loading_percent']
-        s = v * np.conj(sol['ybus'] @ v)
-        ref = np.flatnonzero(case.bus_type == 3)
-        sref[b, :, 0] = s.real[ref] - p[b, ref]
-        sref[b, :, 1] = s.imag[ref] - q[b, ref]
-    return dict(vm=vm, va=va, loading=load, s_ref=sref, converged=conv, iterations=its)
+        r = side.solve(p[b], q[b], outage=-1 if outage is None else int(outage[b]), **kw)
+        for k in out:
+            out[k][b] = r[k]
+    return out
+
+
+def oracle_ppc_solve(base, bus, branch, gen, **kw):
+    """A published case given as pypower matrices, solved by the oracle (its own matrix reader)."""
+    ppc = pd2ppc.ppc_from_matrices(base, bus, branch, gen)
+    sol = po.solve(ppc, **kw)
+    sol['ppc'] = ppc
+    return sol
 
 
 def non_bridge_branches(case):
@@ -120,3 +167,44 @@ def ieee14_ppc():
                          -14.791, -15.076, -15.156, -16.034]),
         p_slack_mw=232.39, q_slack_mvar=-16.55, losses_mw=13.39)
     return 100.0, bus, branch, gen, published
+
+
+def _ppc(base_kv, bus_rows, br_rows, gen_rows):
+    """pypower matrices from compact rows: bus (type, Pd, Qd, Vm), branch (from, to, r, x, b; 1-based),
+    gen (bus (1-based), Pg, Vg, Qmax, Qmin)."""
+    bus = np.array([[i, t, pd_, qd_, 0.0, 0.0, 1, vm, 0.0, base_kv, 1, 1.1, 0.9] for i, (t, pd_, qd_, vm) in enumerate(bus_rows)])
+    branch = np.array([[f - 1, t - 1, r, x, b, 0, 0, 0, 0, 0, 1, -360, 360] for f, t, r, x, b in br_rows], dtype=float)
+    gen = np.array([[b - 1, pg, 0.0, qmax, qmin, vg, 100, 1] for b, pg, vg, qmax, qmin in gen_rows], dtype=float)
+    return 100.0, bus, branch, gen
+
+
+def published_cases():
+    """Textbook systems with published load-flow solutions (public data, typed in by hand; 0-based bus
+    numbers).  name -> (base, bus, branch, gen, published): `published` holds the printed numbers and the
+    tolerance their printed precision allows.
+      * gs4:  Grainger & Stevenson, "Power System Analysis", 4-bus example (MATPOWER `case4gs`);
+      * ww6:  Wood & Wollenberg, "Power Generation, Operation and Control", 6-bus system (`case6ww`);
+      * sea5: Stagg & El-Abiad, "Computer Methods in Power System Analysis", 5-bus system (its generator at
+              bus 2 is a fixed P,Q source: booked as negative demand).
+    (IEEE 14-bus: `ieee14_ppc`; WSCC 9-bus: opfgym_amd.grids.case9.)"""
+    gs4 = _ppc(230.0, [(3, 50, 30.99, 1.0), (1, 170, 105.35, 1.0), (1, 200, 123.94, 1.0), (2, 80, 49.58, 1.02)],
+               [(1, 2, 0.01008, 0.0504, 0.1025), (1, 3, 0.00744, 0.0372, 0.0775), (2, 4, 0.00744, 0.0372, 0.0775),
+                (3, 4, 0.01272, 0.0636, 0.1275)], [(1, 0, 1.0, 1e4, -1e4), (4, 318, 1.02, 1e4, -1e4)])
+    ww6 = _ppc(230.0, [(3, 0, 0, 1.05), (2, 0, 0, 1.05), (2, 0, 0, 1.07), (1, 70, 70, 1.0), (1, 70, 70, 1.0), (1, 70, 70, 1.0)],
+               [(1, 2, 0.1, 0.2, 0.04), (1, 4, 0.05, 0.2, 0.04), (1, 5, 0.08, 0.3, 0.06), (2, 3, 0.05, 0.25, 0.06),
+                (2, 4, 0.05, 0.1, 0.02), (2, 5, 0.1, 0.3, 0.04), (2, 6, 0.07, 0.2, 0.05), (3, 5, 0.12, 0.26, 0.05),
+                (3, 6, 0.02, 0.1, 0.02), (4, 5, 0.2, 0.4, 0.08), (5, 6, 0.1, 0.3, 0.06)],
+               [(1, 0, 1.05, 1e4, -1e4), (2, 50, 1.05, 1e4, -1e4), (3, 60, 1.07, 1e4, -1e4)])
+    sea5 = _ppc(100.0, [(3, 0, 0, 1.06), (1, 20 - 40, 10 - 30, 1.0), (1, 45, 15, 1.0), (1, 40, 5, 1.0), (1, 60, 10, 1.0)],
+                [(1, 2, 0.02, 0.06, 0.06), (1, 3, 0.08, 0.24, 0.05), (2, 3, 0.06, 0.18, 0.04), (2, 4, 0.06, 0.18, 0.04),
+                 (2, 5, 0.04, 0.12, 0.03), (3, 4, 0.01, 0.03, 0.02), (4, 5, 0.08, 0.24, 0.05)], [(1, 0, 1.06, 1e4, -1e4)])
+    return {
+        'gs4': gs4 + (dict(vm=[1.0, 0.982, 0.969, 1.02], vm_tol=6e-4, va_deg=[0.0, -0.976, -1.872, 1.523], va_tol=6e-4,
+                           pg={0: 186.81}, qg={0: 114.50, 1: 181.43}, s_tol=6e-3),),
+        'ww6': ww6 + (dict(vm=[1.05, 1.05, 1.07, 0.9894, 0.9854, 1.0044], vm_tol=6e-5,
+                           va_deg=[0.0, -3.67, -4.27, -4.20, -5.28, -5.95], va_tol=6e-3,
+                           pg={0: 107.87}, qg={0: 15.96, 1: 74.36, 2: 89.63}, s_tol=1.1e-2),),
+        'sea5': sea5 + (dict(vm=[1.06, 1.0474, 1.0242, 1.0236, 1.0179], vm_tol=1.1e-4,
+                             va_deg=[0.0, -2.806, -4.997, -5.329, -6.150], va_tol=1.1e-3,
+                             pg={0: 129.59}, qg={0: -7.42}, s_tol=1.1e-2),),
+    }

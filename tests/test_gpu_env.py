@@ -36,8 +36,8 @@ def _check_step(env, out, ref, k, n1=False):
         assert np.allclose(_np(env.result_table('bus', 'vm_pu'))[k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True)
         dva = np.deg2rad(_np(env.result_table('bus', 'va_degree'))[k] - ref['va_degree'])
         assert np.nanmax(np.abs(np.angle(np.exp(1j * dva)))) < V_TOL
-        assert np.allclose(_np(env.result_table('line', 'loading_percent'))[k], ref['line_loading'], rtol=0, atol=R_TOL)
-        assert np.allclose(_np(env.result_table('trafo', 'loading_percent'))[k], ref['trafo_loading'], rtol=0, atol=R_TOL)
+        assert np.allclose(_np(env.result_table('line', 'loading_percent'))[k], ref['line_loading'], rtol=0, atol=R_TOL, equal_nan=True)
+        assert np.allclose(_np(env.result_table('trafo', 'loading_percent'))[k], ref['trafo_loading'], rtol=0, atol=R_TOL, equal_nan=True)
         assert np.allclose(_np(env.result_table('ext_grid', 'p_mw'))[k], ref['p_ext'], rtol=0, atol=R_TOL)
         assert np.allclose(_np(env.result_table('ext_grid', 'q_mvar'))[k], ref['q_ext'], rtol=0, atol=R_TOL)
 

@@ -23,15 +23,15 @@ def _run(code, B, seed, **kw):
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw)
     torch.cuda.synchronize()
-    return case, p, q, {k: v.cpu().numpy() for k, v in out.items()}
+    return net, case, p, q, {k: v.cpu().numpy() for k, v in out.items()}
 
 
 @pytest.mark.parametrize('code,B', [('case9', 64), ('1-LV-rural1--0-sw', 128),
                                     ('1-MV-urban--0-sw', 256), ('1-HV-mixed--0-sw', 48),
                                     ('1-HV-urban--0-sw', 32)])
 def test_solve_matches_oracle(code, B):
-    case, p, q, out = _run(code, B, seed=11)
-    ref = oracle_batch(case, p, q)
+    net, case, p, q, out = _run(code, B, seed=11)
+    ref = oracle_batch(net, case, p, q)
     assert ref['converged'].all()
     assert out['converged'].astype(bool).all()
     assert np.abs(out['vm'] - ref['vm']).max() < TOL_V
@@ -47,11 +47,11 @@ def test_full_batch_properties():
     """B = 8192 (BASELINE config 2 size): every instance converges and the
     solution satisfies the power-flow equations — checked for all rows through
     the kernel's own mismatch norm and for a sample against the oracle."""
-    case, p, q, out = _run('1-MV-urban--0-sw', 8192, seed=5)
+    net, case, p, q, out = _run('1-MV-urban--0-sw', 8192, seed=5)
     assert out['converged'].astype(bool).all()
     assert (out['max_mismatch'] < 1e-8).all()
     idx = np.arange(0, 8192, 257)
-    ref = oracle_batch(case, p[idx], q[idx])
+    ref = oracle_batch(net, case, p[idx], q[idx])
     assert np.abs(out['vm'][idx] - ref['vm']).max() < TOL_V
     # identical inputs give identical outputs regardless of which wave ran them
     p2 = np.concatenate([p[:4]] * 8)
@@ -84,7 +84,7 @@ def test_ragged_batches_give_the_same_rows(B):
     part = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p[pick], device=dev), torch.tensor(q[pick], device=dev)).items()}
     for k in ('vm', 'va', 'loading', 's_ref', 'iterations', 'max_mismatch'):
         assert (full[k][pick] == part[k]).all(), k
-    ref = oracle_batch(case, p[pick[:4]], q[pick[:4]])
+    ref = oracle_batch(net, case, p[pick[:4]], q[pick[:4]])
     assert np.abs(part['vm'][:4] - ref['vm']).max() < TOL_V
     empty = capi.solve(ctx, torch.zeros((0, case.nb), dtype=torch.float64, device=dev),
                        torch.zeros((0, case.nb), dtype=torch.float64, device=dev))
@@ -129,6 +129,95 @@ def test_ieee14_published_solution_on_the_gpu():
     assert abs(s_ref[0, 1] - pub['q_slack_mvar']) < 0.01
 
 
+@pytest.mark.parametrize('name', ['gs4', 'ww6', 'sea5'])
+def test_published_textbook_solutions_on_the_gpu(name):
+    """Three more published load flows (tests/helpers.published_cases) asserted on the kernel's result to
+    the printed precision, and against the oracle's own matrix route at 1e-9."""
+    import torch
+    from helpers import oracle_ppc_solve, published_cases
+    from opfgym_amd import capi
+    from opfgym_amd.ppci_io import case_from_ppc
+    base, bus, branch, gen, pub = published_cases()[name]
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    out = {k: v[0].cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev)).items()}
+    assert bool(out['converged']) and int(out['iterations']) <= 5
+    assert np.abs(out['vm'] - np.array(pub['vm'])).max() < pub['vm_tol']
+    assert np.abs(np.degrees(out['va']) - np.array(pub['va_deg'])).max() < pub['va_tol']
+    ref = oracle_ppc_solve(base, bus, branch, gen)
+    assert np.abs(out['vm'] - np.abs(ref['V'])).max() < TOL_V
+    assert np.abs(np.angle(np.exp(1j * (out['va'] - np.angle(ref['V']))))).max() < TOL_V
+    # slack generation = calculated injection of the REF bus - its scheduled share (p holds Pg - Pd)
+    s_ref = out['s_ref'] * base
+    assert abs(s_ref[0, 0] + gen[0, 1] - pub['pg'][0]) < pub['s_tol']
+    assert abs(s_ref[0, 1] - pub['qg'][0]) < pub['s_tol']
+    # reactive output of the voltage-controlled generators
+    pv = np.flatnonzero(case.bus_type == 2)
+    for g, val in pub['qg'].items():
+        i = int(gen[g, 0])
+        if i in pv:
+            assert abs(out['q_gen'][i] * base - val) < pub['s_tol'], (g, out['q_gen'][i] * base)
+
+
+def test_pandapower_export_fixtures_on_the_gpu():
+    """fixtures/*.npz (pandapower's own matrices, tables and results; see fixtures/README.md): the HIP path
+    against pandapower at 1e-6 p.u., through both the matrix route and the table route.  Skips while no
+    export exists (pandapower is not installed in the build container)."""
+    import glob
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'fixtures', '*.npz')))
+    if not files:
+        pytest.skip('no pandapower exports under fixtures/')
+    sys.path.insert(0, os.path.join(root, 'scripts'))
+    from export_pandapower_case import load_tables
+    from opfgym_amd import capi, power_flow_solver
+    from opfgym_amd.ppci_io import load_exported_case
+    dev = torch.device('cuda:0')
+    for path in files:
+        case, p, q, qmin, qmax, ref = load_exported_case(path)
+        ctx = capi.Context(capi.Plan(case), 0)
+        out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev),
+                         qg_min=torch.tensor(qmin, device=dev), qg_max=torch.tensor(qmax, device=dev), enforce_q_lims=True)
+        assert bool(out['converged'][0]), path
+        assert np.abs(out['vm'][0].cpu().numpy() - ref['vm']).max() < 1e-6, path
+        z = np.load(path, allow_pickle=False)
+        net = load_tables(z)
+        power_flow_solver(net, enforce_q_lims=True)
+        for key in z.files:
+            if key.startswith('out__'):
+                _, tbl, col = key.split('__')
+                tol = 1e-6 if col == 'vm_pu' else 1e-4
+                assert np.allclose(net[tbl][col].to_numpy(float), z[key], rtol=0, atol=tol, equal_nan=True), (path, key)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_switched_nets_match_the_oracle(seed):
+    """Random three-level nets with random line / transformer / shunt parameters and open switches
+    (tests/test_pd2ppc_differential._random_net): the product converter + kernel against the oracle's
+    converter (auxiliary buses) + solver, through the batch-1 plug-in tables."""
+    import copy
+    from opfgym_amd import power_flow_solver
+    from oracle import pf_oracle as po
+    from test_pd2ppc_differential import _random_net
+    net = _random_net(np.random.default_rng(500 + seed))
+    ref = copy.deepcopy(net)
+    try:
+        po.runpp(ref, enforce_q_lims=True)
+    except po.LoadflowNotConverged:
+        pytest.skip('random case without a solution')
+    power_flow_solver(net, enforce_q_lims=True)
+    for tbl, cols, tol in (('res_bus', ('vm_pu', 'va_degree'), 1e-8), ('res_line', ('loading_percent',), 1e-6),
+                           ('res_trafo', ('loading_percent',), 1e-6), ('res_ext_grid', ('p_mw', 'q_mvar'), 1e-6),
+                           ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6)):
+        for col in cols:
+            a, b = net[tbl][col].to_numpy(float), ref[tbl][col].to_numpy(float)
+            assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=tol, equal_nan=True), (tbl, col, a, b)
+
+
 def test_outage_axis():
     """N-1 axis: one branch out of service per instance (meshed HV grid)."""
     import torch
@@ -149,7 +238,7 @@ def test_outage_axis():
     out = capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev),
                      outage=torch.tensor(outage, device=dev))
     out = {k: v.cpu().numpy() for k, v in out.items()}
-    ref = oracle_batch(case, p, q, outage=outage)
+    ref = oracle_batch(net, case, p, q, outage=outage)
     ok = ref['converged']
     assert ok.sum() >= B // 2
     assert (out['converged'].astype(bool) == ok).all()
@@ -184,14 +273,14 @@ def test_islanding_outage_de_energises_the_island(code):
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), outage=torch.tensor(outage, device=dev))
     out = {k: v.cpu().numpy() for k, v in out.items()}
-    ref = oracle_batch(case, p, q, outage=outage)
+    ref = oracle_batch(net, case, p, q, outage=outage)
     assert (out['converged'].astype(bool) == ref['converged']).all() and ref['converged'].all()
     assert (np.isnan(out['vm']) == np.isnan(ref['vm'])).all()
     for b in range(0, B, 2):
         k = outage[b]
         dead = isl_bus[isl_ptr[k]:isl_ptr[k + 1]]
         assert len(dead) > 0 and np.isnan(out['vm'][b, dead]).all() and np.isnan(out['vm'][b]).sum() == len(dead)
-        assert out['loading'][b, k] == 0.0
+        assert np.isnan(out['loading'][b, k])      # 0 MVA over the NaN voltage of its dead end (pandapower's i_ka)
     assert np.allclose(out['vm'], ref['vm'], rtol=0, atol=TOL_V, equal_nan=True)
     assert np.allclose(out['loading'], ref['loading'], rtol=0, atol=1e-6, equal_nan=True)
     assert (np.abs(out['iterations'] - ref['iterations']) <= 1).all()
@@ -217,7 +306,7 @@ def test_enforce_q_lims():
                      qg_min=torch.tensor(qmin, device=dev), qg_max=torch.tensor(qmax, device=dev),
                      enforce_q_lims=True)
     out = {k: v.cpu().numpy() for k, v in out.items()}
-    ref = oracle_batch(case, p, q, qg_min=qmin, qg_max=qmax, enforce_q_lims=True)
+    ref = oracle_batch(net, case, p, q, qg_min=qmin, qg_max=qmax, enforce_q_lims=True)
     ok = ref['converged']
     assert ok.all()
     assert out['converged'].astype(bool).all()

@@ -1,0 +1,181 @@
+"""CPU: differential test of the two independent net -> per-unit conversions.
+
+Product: `opfgym_amd.case.net_to_case` — admittance stamps per branch, open-ended branches reduced to a
+shunt, `kf/kt` loading factors.  Oracle: `oracle.pd2ppc.build_ppc` — pandapower-shaped (r, x, b, tap, shift)
+branch table with auxiliary buses, loadings from i_ka.  They share no code; here their admittance
+matrices (auxiliary buses eliminated), bus types, set-points, injections and loading percentages must
+agree on every synthetic grid and on randomly parameterised lines, transformers, shunts and switches."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import OracleSide
+from opfgym_amd import grids, net as ppn
+from opfgym_amd.case import bus_injections, net_to_case
+from oracle import pf_oracle as po
+
+
+def _compare(net, tol=1e-9):
+    case = net_to_case(net)
+    side = OracleSide(net, case)
+    ppc = side.ppc
+    # ---- same set of energised buses -------------------------------------------------
+    live = {b for b, i in ppc.bus_lookup.items() if ppc.bus_type[i] != 4}
+    assert live == set(case.bus_lookup), (sorted(live ^ set(case.bus_lookup)))
+    # ---- admittance matrix: eliminate what the product does not carry (auxiliary / isolated buses) ----
+    y = po.make_ybus(ppc).toarray()
+    keep = list(side.bus_map)
+    drop = [i for i in range(ppc.nb) if i not in set(keep) and ppc.bus_type[i] != 4]
+    yk = y[np.ix_(keep, keep)]
+    if drop:
+        yk = yk - y[np.ix_(keep, drop)] @ np.linalg.solve(y[np.ix_(drop, drop)], y[np.ix_(drop, keep)])
+    scale = max(1.0, np.abs(yk).max())
+    assert np.abs(yk - case.ybus_dense()).max() < tol * scale
+    # ---- bus types and set-points ------------------------------------------------------------------------
+    assert (ppc.bus_type[side.bus_map] == case.bus_type).all()
+    ctl = case.bus_type != 1
+    assert np.allclose(ppc.vm[side.bus_map][ctl], case.vm_set[ctl], rtol=0, atol=1e-15)
+    ref = case.bus_type == 3
+    assert np.allclose(np.radians(ppc.va[side.bus_map][ref]), case.va_set[ref], rtol=0, atol=1e-15)
+    # ---- injections (makeSbus) ------------------------------------------------------------------------------
+    p, q, qmin, qmax = bus_injections(net, case)
+    s = po.make_sbus(ppc) * ppc.base_mva
+    assert np.allclose(s.real[side.bus_map], p, rtol=0, atol=1e-12)
+    assert np.allclose(s.imag[side.bus_map], q, rtol=0, atol=1e-12)
+    # ---- loading: the oracle's i_ka route vs the product's kf / kt factors, on a random voltage profile ----
+    rng = np.random.default_rng(len(net['bus']))
+    v_case = rng.uniform(0.9, 1.1, case.nb) * np.exp(1j * rng.uniform(-0.3, 0.3, case.nb))
+    v = np.ones(ppc.nb, dtype=complex)
+    v[side.bus_map] = v_case
+    if drop:                       # auxiliary buses: no injection -> their voltage follows from the others
+        v[drop] = -np.linalg.solve(y[np.ix_(drop, drop)], y[np.ix_(drop, keep)] @ v_case)
+    v[ppc.bus_type == 4] = np.nan
+    ld = po.loading_percent(ppc, net, v)
+    i_f = np.abs(case.yff * v_case[case.f] + case.yft * v_case[case.t])
+    i_t = np.abs(case.ytf * v_case[case.f] + case.ytt * v_case[case.t])
+    mine = np.maximum(i_f * case.kf, i_t * case.kt)
+    theirs = np.array([ld['line' if kd == 0 else 'trafo'][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])
+    assert np.allclose(mine, theirs, rtol=1e-9, atol=1e-9), np.abs(mine - theirs).max()
+    return case, ppc
+
+
+@pytest.mark.parametrize('code', ['1-LV-rural1--0-sw', '1-MV-urban--0-sw', '1-HV-mixed--0-sw', '1-HV-urban--0-sw',
+                                  'mv-small', 'hv-small', 'hv-small-sw'])
+def test_every_grid(code):
+    net, _ = grids.get_grid(code)
+    _compare(net)
+
+
+def test_textbook_cases():
+    _compare(grids.case9())
+    _compare(grids.two_bus())
+
+
+def _random_net(rng):
+    """Small three-voltage-level grid with every element parameter drawn at random."""
+    net = ppn.Net('rnd', f_hz=float(rng.choice([50.0, 60.0])), sn_mva=float(rng.choice([1.0, 10.0, 100.0])))
+    n_hv, n_mv, n_lv = 4, 8, 4
+    hv = [ppn.create_bus(net, 110.0) for _ in range(n_hv)]
+    mv = [ppn.create_bus(net, 20.0) for _ in range(n_mv)]
+    lv = [ppn.create_bus(net, 0.4) for _ in range(n_lv)]
+    ppn.create_ext_grid(net, hv[0], vm_pu=float(rng.uniform(0.98, 1.05)), va_degree=float(rng.uniform(-5, 5)))
+    if rng.random() < 0.5:
+        ppn.create_ext_grid(net, hv[2], vm_pu=float(rng.uniform(0.98, 1.05)), va_degree=float(rng.uniform(-5, 5)))
+
+    def line(a, b, kv):
+        ppn.create_line_from_parameters(
+            net, a, b, float(rng.uniform(0.1, 20.0)), float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.05, 0.5)),
+            float(rng.uniform(0.0, 300.0)), float(rng.uniform(0.1, 1.0)), g_us_per_km=float(rng.choice([0.0, rng.uniform(0, 5)])),
+            df=float(rng.choice([1.0, rng.uniform(0.5, 1.0)])), parallel=int(rng.choice([1, 1, 2, 3])),
+            in_service=bool(rng.random() > 0.1))
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 0), (0, 2)):
+        line(hv[a], hv[b], 110.0)
+    for k in range(n_mv - 1):
+        line(mv[k], mv[k + 1], 20.0)
+    line(mv[0], mv[4], 20.0)
+    for k in range(n_lv - 1):
+        line(lv[k], lv[k + 1], 0.4)
+
+    def trafo(hb, lb, vh, vl, sn):
+        ppn.create_transformer_from_parameters(
+            net, hb, lb, sn, vh * float(rng.choice([1.0, 1.0, rng.uniform(0.95, 1.05)])),
+            vl * float(rng.choice([1.0, 1.0, rng.uniform(0.95, 1.05)])), float(rng.uniform(4.0, 18.0)),
+            float(rng.uniform(0.2, 1.5)), float(rng.choice([0.0, rng.uniform(0.0, 60.0)])),
+            float(rng.choice([0.0, rng.uniform(0.0, 0.5)])), shift_degree=float(rng.choice([0.0, 30.0, 150.0])),
+            tap_side=[None, 'hv', 'lv'][int(rng.integers(3))], tap_neutral=float(rng.integers(-1, 2)),
+            tap_pos=float(rng.integers(-4, 5)), tap_step_percent=float(rng.uniform(0.5, 2.5)),
+            parallel=int(rng.choice([1, 1, 2])), df=float(rng.choice([1.0, rng.uniform(0.6, 1.0)])),
+            in_service=bool(rng.random() > 0.1))
+    shift = float(rng.choice([0.0, 150.0]))
+    for hb, lb in ((hv[1], mv[0]), (hv[3], mv[5])):
+        trafo(hb, lb, 110.0, 20.0, float(rng.uniform(20.0, 63.0)))
+    net.trafo.loc[net.trafo.index[:2], 'shift_degree'] = shift       # one vector group per voltage level
+    trafo(mv[7], lv[0], 20.0, 0.4, float(rng.uniform(0.25, 0.8)))
+    for b in mv[1:] + lv:
+        ppn.create_load(net, b, float(rng.uniform(0.01, 0.5)), float(rng.uniform(-0.1, 0.2)),
+                        scaling=float(rng.uniform(0.5, 1.5)), in_service=bool(rng.random() > 0.1))
+    for b in rng.choice(mv, 4, replace=False):
+        ppn.create_sgen(net, int(b), float(rng.uniform(0.0, 1.0)), float(rng.uniform(-0.2, 0.2)),
+                        scaling=float(rng.uniform(0.5, 1.5)))
+    ppn.create_storage(net, mv[3], float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.1, 0.1)), scaling=0.8,
+                       min_p_mw=-1.0, max_p_mw=1.0, min_q_mvar=-1.0, max_q_mvar=1.0)
+    ppn.create_gen(net, hv[2] if len(net.ext_grid) == 1 else hv[1], float(rng.uniform(1.0, 20.0)),
+                   vm_pu=float(rng.uniform(0.99, 1.04)), scaling=float(rng.uniform(0.8, 1.2)),
+                   min_q_mvar=-10.0, max_q_mvar=10.0)
+    ppn.create_shunt(net, mv[2], float(rng.uniform(-1.0, 1.0)), p_mw=float(rng.uniform(0.0, 0.05)),
+                     vn_kv=float(rng.choice([20.0, 21.0])), step=int(rng.integers(1, 3)))
+    ppn.finalize(net)
+    # switches: a closed and an open bus-bus switch, line switches open at one end / both ends, a transformer
+    # switch open at one end
+    extra = ppn.create_bus(net, 20.0)
+    ppn.create_load(net, extra, 0.2, 0.05)
+    ppn.create_switch(net, mv[6], extra, 'b', closed=True)
+    extra2 = ppn.create_bus(net, 20.0)                    # isolated behind an open bus-bus switch
+    ppn.create_switch(net, mv[6], extra2, 'b', closed=False)
+    lines = net.line.index.to_numpy()
+    mv_lines = [int(i) for i in lines if net.bus.vn_kv[net.line.from_bus[i]] == 20.0]
+    a, b, c = rng.choice(mv_lines, 3, replace=False)
+    ppn.create_switch(net, int(net.line.from_bus[a]), int(a), 'l', closed=False)
+    ppn.create_switch(net, int(net.line.to_bus[b]), int(b), 'l', closed=bool(rng.random() < 0.5))
+    ppn.create_switch(net, int(net.line.from_bus[c]), int(c), 'l', closed=False)
+    ppn.create_switch(net, int(net.line.to_bus[c]), int(c), 'l', closed=False)
+    t_sw = int(rng.integers(0, 2))
+    end = 'hv_bus' if rng.random() < 0.5 else 'lv_bus'
+    ppn.create_switch(net, int(net.trafo[end].iloc[t_sw]), int(net.trafo.index[t_sw]), 't', closed=bool(rng.random() < 0.5))
+    ppn.finalize(net)
+    return net
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_parameters(seed):
+    rng = np.random.default_rng(seed)
+    net = _random_net(rng)
+    try:
+        case = net_to_case(net)
+    except ValueError:
+        pytest.skip('no slack left')
+    _compare(net)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_nets_solve_to_the_same_result(seed):
+    """The oracle's own solve on its auxiliary-bus case vs a dense Newton on the product's reduced
+    admittance matrix: same voltages and the same loadings at the buses both carry."""
+    rng = np.random.default_rng(1000 + seed)
+    net = _random_net(rng)
+    net.shunt = net.shunt.iloc[0:0]
+    try:
+        case = net_to_case(net)
+    except ValueError:
+        pytest.skip('no slack left')
+    side = OracleSide(net, case)
+    p, q, *_ = bus_injections(net, case)
+    ref = side.solve(p / case.base_mva, q / case.base_mva)
+    if not ref['converged']:
+        pytest.skip('random case without a solution')
+    v = ref['V']
+    s = v * np.conj(case.ybus_dense() @ v)
+    free = case.bus_type != 3
+    assert np.abs(s.real[free] - p[free] / case.base_mva).max() < 1e-7
+    pq = case.bus_type == 1
+    assert np.abs(s.imag[pq] - q[pq] / case.base_mva).max() < 1e-7

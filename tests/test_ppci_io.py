@@ -3,6 +3,7 @@ SURVEY §8f N3) gives the same per-unit case — and the same power flow — as 
 table route for the WSCC 9-bus system typed in MATPOWER `case9` layout."""
 import numpy as np
 
+from helpers import oracle_ppc_solve
 from opfgym_amd import grids
 from opfgym_amd.case import net_to_case
 from opfgym_amd.ppci_io import case_from_ppc
@@ -30,17 +31,16 @@ def _ppc_case9():
 
 
 def test_ppc_route_equals_table_route():
+    """Product: matrices -> Case (ppci_io) vs tables -> Case (net_to_case): same admittances.  Oracle: its own
+    matrix reader vs its own table converter: same solution, and the published voltage profile."""
     case, p, q, qmin, qmax = case_from_ppc(*_ppc_case9())
-    sol = po.solve_case(case, p, q)
     net = grids.case9()
     ref_case = net_to_case(net)
+    assert np.abs(case.ybus_dense() - ref_case.ybus_dense()).max() < 1e-9
+    sol = oracle_ppc_solve(*_ppc_case9())
     ref = po.runpp(net, enforce_q_lims=False)
     assert sol['converged']
-    assert np.abs(case.ybus_dense() - ref_case.ybus_dense()).max() < 1e-9
     assert np.abs(sol['V'] - ref['V']).max() < 1e-10
     assert np.abs(np.abs(sol['V']) - grids.CASE9_VM).max() < 1e-3
-    # loading against RATE_A: |S|/|V| * base / rate
-    br = po.branch_results(case, sol['V'])
-    s_from = np.abs(br['s_from']) * 100.0
-    assert np.allclose(br['loading_percent'], np.maximum(
-        s_from / np.abs(sol['V'][case.f]), np.abs(br['s_to']) * 100 / np.abs(sol['V'][case.t])) / 250.0 * 100.0)
+    # the product's loading scale of a matrix case: percent of RATE_A at nominal voltage
+    assert np.allclose(case.kf, 100.0 / 250.0 * 100.0) and np.allclose(case.kt, case.kf)
