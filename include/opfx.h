@@ -426,6 +426,12 @@ int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
                     const opfx_solve_opts* opts, int32_t reps, void* stream,
                     float* elapsed_ms);
 
+/* Launch configuration of the environment's fused step kernel (report/diagnostics; bench.py prints it):
+ * wavefronts that share one instance (1, 2 or 4), LDS bytes per instance, and instances resident per CU
+ * (0 until the first opfx_step has queried the occupancy).  Any out pointer may be NULL. */
+int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
+                      int32_t* instances_per_cu);
+
 #ifdef __cplusplus
 }
 #endif

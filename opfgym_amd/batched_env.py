@@ -333,6 +333,8 @@ class BatchedOpfEnv:
             self.constraints = constraints_mod.create_default_constraints(net, constraint_params or {})
         else:
             self.constraints = list(custom_constraints)
+        if callable(n_minus_one_keys):             # decided on the prepared net (e.g. every non-islanding line)
+            n_minus_one_keys = n_minus_one_keys(net)
         self.n_minus_one_keys = n_minus_one_keys or ()
         for _, column, _ in self.n_minus_one_keys:
             assert column in ('in_service', 'closed')                      # security_constrained.py:34-35

@@ -134,7 +134,7 @@ _lib = None
 EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_plan_get_array',
            'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
-           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps']
+           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info']
 
 
 def lib():
@@ -176,6 +176,7 @@ def lib():
     L.opfx_reset.argtypes = [vp, C.c_int64, C.POINTER(ResetIO), vp]
     L.opfx_time_steps.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32,
                                   vp, C.POINTER(C.c_float)]
+    L.opfx_env_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     _lib = L
     return L
 

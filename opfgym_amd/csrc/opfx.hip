@@ -2513,6 +2513,15 @@ extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
   return rc;
 }
 
+extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
+                                 int32_t* instances_per_cu) {
+  if (!env) { opfx_set_error("opfx_env_get_info: null environment"); return OPFX_ERR_INVALID; }
+  if (waves_per_instance) *waves_per_instance = pick_team(env->lds_bytes, env->ctx->v2);
+  if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
+  if (instances_per_cu) *instances_per_cu = env->per_cu;
+  return OPFX_OK;
+}
+
 extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   if (!env || !d || d->n_tables < 0 || d->n_tables > MAX_TABLES) {
     opfx_set_error("opfx_env_set_reset: bad argument (at most 8 profile tables)");

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import net as ppn
 from .batched_env import BatchedOpfEnv, MultiStageOpfEnv, OpsBuilder, SecurityConstrainedOpfEnv
-from .simbench_build import build_simbench_net
+from .simbench_build import build_simbench_net, gens_to_fixed_sgens, non_islanding_lines
 
 
 class VoltageControl(BatchedOpfEnv):
@@ -551,34 +551,18 @@ class AddCustomConstraint(BatchedOpfEnv):
 class SecurityConstrainedVoltageControl(VoltageControl):
     """BASELINE config 5: VoltageControl problem definition with the N-1 wrapper
     of security_constrained.py (no such class in the reference; composed as
-    SURVEY.md Appendix A.5 describes)."""
+    SURVEY.md Appendix A.5 describes).  `n_minus_one_lines='all'`: every in-service line whose outage
+    does not island."""
 
     def __init__(self, simbench_network_name='1-HV-urban--0-sw', n_minus_one_lines=(1, 3, 7),
                  not_converged_penalty=1, *args, **kwargs):
-        keys = (('line', 'in_service', np.array(n_minus_one_lines)),)
+        def keys(net):
+            lines = non_islanding_lines(net) if isinstance(n_minus_one_lines, str) else np.array(n_minus_one_lines)
+            return (('line', 'in_service', lines),)
         super().__init__(simbench_network_name, *args, n_minus_one_keys=keys,
                          not_converged_penalty=not_converged_penalty, **kwargs)
 
     def _build_net(self, simbench_network_name, *args, **kwargs):
         net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
-        # VoltageControl asserts a grid without `gen` units (voltage_control.py:102):
-        # on the HV stand-in the PV generators become fixed sgens.
-        if len(net.gen):
-            g = net.gen
-            start = (int(net.sgen.index.max()) + 1) if len(net.sgen) else 0
-            for k, (idx, row) in enumerate(g.iterrows()):
-                net.sgen.loc[start + k] = {c: row[c] if c in row else np.nan for c in net.sgen.columns}
-                net.sgen.loc[start + k, 'q_mvar'] = 0.0
-            if ('gen', 'p_mw') in profiles:
-                df = profiles.pop(('gen', 'p_mw'))
-                df.columns = [start + k for k in range(df.shape[1])]
-                import pandas as pd
-                profiles[('sgen', 'p_mw')] = pd.concat([profiles[('sgen', 'p_mw')], df], axis=1)
-                if hasattr(profiles, 'rel'):
-                    profiles.rel.pop(('sgen', 'p_mw'), None)
-            net.gen = net.gen.iloc[0:0]
-            from .simbench_build import set_constraints_from_profiles
-            net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
-            net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
-            set_constraints_from_profiles(net, profiles)
+        gens_to_fixed_sgens(net, profiles)
         return net, profiles

@@ -81,6 +81,59 @@ def set_constraints_from_profiles(net, profiles):
     net.ext_grid['mean_q_mvar'] = load_q.mean()
 
 
+def gens_to_fixed_sgens(net, profiles):
+    """Stand-in helper (no counterpart in the reference): VoltageControl asserts a grid without `gen`
+    units (voltage_control.py:102), the HV stand-in grids carry PV generators — they become sgens with
+    q = 0 that follow the generators' active-power profiles.  In place; a no-op without generators."""
+    import pandas as pd
+    if not len(net.gen):
+        return net, profiles
+    start = (int(net.sgen.index.max()) + 1) if len(net.sgen) else 0
+    for k, (idx, row) in enumerate(net.gen.iterrows()):
+        net.sgen.loc[start + k] = {c: row[c] if c in row else np.nan for c in net.sgen.columns}
+        net.sgen.loc[start + k, 'q_mvar'] = 0.0
+    if ('gen', 'p_mw') in profiles:
+        df = profiles.pop(('gen', 'p_mw'))
+        df.columns = [start + k for k in range(df.shape[1])]
+        profiles[('sgen', 'p_mw')] = pd.concat([profiles[('sgen', 'p_mw')], df], axis=1)
+        if hasattr(profiles, 'rel'):
+            profiles.rel.pop(('sgen', 'p_mw'), None)
+    net.gen = net.gen.iloc[0:0]
+    net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
+    net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
+    set_constraints_from_profiles(net, profiles)
+    return net, profiles
+
+
+def non_islanding_lines(net):
+    """Index values of the in-service lines whose outage leaves every energised bus connected to a
+    slack (the contingency list of BASELINE config 5)."""
+    from .case import KIND_LINE, net_to_case
+    case = net_to_case(net)
+    nb = case.nb
+    ref = np.flatnonzero(case.bus_type == 3)
+    coupled = (case.yft != 0) | (case.ytf != 0)
+    out = []
+    for k in np.flatnonzero((case.br_kind == KIND_LINE) & coupled):
+        adj = [[] for _ in range(nb)]
+        for m in np.flatnonzero(coupled):
+            if m != k:
+                adj[case.f[m]].append(case.t[m])
+                adj[case.t[m]].append(case.f[m])
+        seen = np.zeros(nb, bool)
+        seen[ref] = True
+        stack = list(ref)
+        while stack:
+            a = stack.pop()
+            for b in adj[a]:
+                if not seen[b]:
+                    seen[b] = True
+                    stack.append(b)
+        if seen.all():
+            out.append(int(net.line.index[case.br_elem[k]]))
+    return np.array(out, dtype=np.int64)
+
+
 def define_test_train_split(test_share=0.2, random_test_steps=False, validation_share=0.2,
                             random_validation_steps=False, **kwargs):
     """data_split.py:5-59: deterministic weekly blocks out of 35 136 steps

@@ -2,7 +2,7 @@
 E2–E11): one instance at a time, plain numpy on the net's tables.
 
 TEST INFRASTRUCTURE ONLY — imported by tests/, `__graft_entry__.smoke()` and
-the `cpu_baseline` leg of bench.py, never by `opfgym_amd/`.
+the `cpu_baseline` leg of bench.py, never by the product package.
 
 Each function restates one piece of `/root/reference/opfgym/` (file:line cited
 per function).  The oracle is PINNED: tests/test_oracle_env.py replays the

@@ -1,8 +1,8 @@
 """net -> per-unit power-flow case of the CPU oracle.
 
 TEST INFRASTRUCTURE ONLY, and deliberately INDEPENDENT of the product: nothing
-here imports `opfgym_amd`, and the product's own converter
-(`opfgym_amd/case.py:net_to_case`) shares no code with it.  The two are compared
+here imports the product package, and the product's own converter
+(`case.py:net_to_case` there) shares no code with it.  The two are compared
 against each other by `tests/test_pd2ppc_differential.py`.
 
 What it restates: the third-party conversion that `pandapower.runpp` performs

@@ -1,6 +1,6 @@
 """CPU oracle for the solver half of the hot path (SURVEY.md §8a rows P2–P7).
 
-TEST INFRASTRUCTURE ONLY.  Nothing in the product package `opfgym_amd/` may
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package may
 import or call this module; only `tests/`, `__graft_entry__.smoke()` and the
 `cpu_baseline` leg of `bench.py` do, and only as the checker / the timed CPU
 baseline.  Conversely nothing under `oracle/` imports the product: the case

@@ -37,8 +37,8 @@ def oracle_env(name, env=None):
     cls, kwargs, _, _ = SCENARIOS[name]
     env = env or product_env(name, defer_device=True)
     d = env.host_definition()
-    tail = env_oracle.TAILS[cls]
-    if cls in ('VoltageControl', 'QMarket'):          # constructor parameters of the `_sampling` tails
+    tail = env_oracle.TAILS.get(cls)
+    if cls in ('VoltageControl', 'QMarket', 'SecurityConstrainedVoltageControl'):          # constructor parameters of the `_sampling` tails
         tail = lambda net, dr: env_oracle.tail_voltage_control(net, dr, bool(env.market_based))
     elif cls == 'LoadShedding':
         tail = lambda net, dr: env_oracle.tail_load_shedding(net, dr, env.storage_efficiency)

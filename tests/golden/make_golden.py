@@ -24,7 +24,8 @@ sys.path[:0] = [os.path.join(HERE, '_stubs'), ROOT, '/root/reference', HERE]
 import numpy as np  # noqa: E402
 
 import opfgym.envs  # noqa: E402,F401  (reference)
-import opfgym.examples.security_constrained as ref_sc  # noqa: E402
+import opfgym.examples.security_constrained as ref_sc_example  # noqa: E402
+import opfgym.security_constrained as ref_sc  # noqa: E402
 from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
@@ -59,9 +60,39 @@ class RefAddCustomConstraint(ref_opf_env.OpfEnv):
         self.net.sgen['min_p_mw'] = self.net.sgen.p_mw * self.net.sgen.scaling - 1e-9
 
 
-REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMarket,
+class RefScVoltageControl(opfgym.envs.VoltageControl, ref_sc.SecurityConstrainedOpfEnv):
+    """BASELINE config 5 on the reference side: the reference's own VoltageControl (its `_define_opf`,
+    `_sampling`, keys) composed with the reference's own SecurityConstrainedOpfEnv (its N-1
+    `calculate_violations`) by inheritance — no reference code is restated here.  The stand-in grid's PV
+    generators become fixed sgens first (VoltageControl asserts a grid without `gen` rows), with the same
+    helper the product uses; contingencies: every in-service line whose outage does not island."""
+
+    def __init__(self, simbench_network_name, n_minus_one_lines='all', **kwargs):
+        import opfgym.envs.voltage_control as vc_mod
+        from opfgym_amd.simbench_build import gens_to_fixed_sgens, non_islanding_lines
+        original = vc_mod.build_simbench_net
+        chosen = {}
+
+        def prepared(*a, **k):
+            net, profiles = original(*a, **k)
+            gens_to_fixed_sgens(net, profiles)
+            chosen['lines'] = non_islanding_lines(net) if isinstance(n_minus_one_lines, str) \
+                else np.array(n_minus_one_lines)
+            return net, profiles
+
+        class _Keys(tuple):          # resolved once the net exists (VoltageControl builds it inside __init__)
+            def __iter__(self_inner):
+                return iter((('line', 'in_service', chosen['lines']),))
+        vc_mod.build_simbench_net = prepared
+        try:
+            super().__init__(simbench_network_name, n_minus_one_keys=_Keys(), **kwargs)
+        finally:
+            vc_mod.build_simbench_net = original
+
+
+REF = {'VoltageControl': opfgym.envs.VoltageControl, 'SecurityConstrainedVoltageControl': RefScVoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
-       'SecurityConstrained': ref_sc.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
+       'SecurityConstrained': ref_sc_example.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
        'NetworkReconfiguration': ref_nr.NetworkReconfiguration,
        'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete,
        'ConstraintSatisfaction': ref_cs.ConstraintSatisfaction, 'PartiallyObservable': ref_po.PartiallyObservable,

@@ -88,6 +88,15 @@ SCENARIOS.update({
     'custom_constraint_lv': ('AddCustomConstraint', dict(simbench_network_name='1-LV-rural1--0-sw'), 6, 26),
 })
 
+SCENARIOS.update({
+    # BASELINE configs 3 and 5 on their own grids: EcoDispatch on the 306-bus meshed HV
+    # stand-in (wave teams of two), N-1 VoltageControl on the 372-bus stand-in with every non-islanding
+    # line as contingency (250 of them; wave teams of four)
+    'eco_hv_mixed': ('EcoDispatch', dict(simbench_network_name='1-HV-mixed--0-sw'), 4, 31),
+    'sc_vc_hv_urban': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
+                                                                 n_minus_one_lines='all'), 2, 32),
+})
+
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
 EPISODE_STEPS = {'vc_multistep_diff': 3, 'multistage_lv': 4}
 # explicit start steps (else drawn from the training steps): 670 runs into the first validation week at 672

@@ -148,6 +148,69 @@ def test_full_batch_voltage_control_properties():
     assert np.array_equal(r1, _np(reward2), equal_nan=True)
 
 
+@pytest.mark.parametrize('name,B,n_check,team', [('eco_hv_mixed', 8192, 16, 4), ('sc_vc_hv_urban', 4096, 16, 4),
+                                                 ('eco_hv_mixed', 2048, 8, 2)])
+def test_full_batch_hv_configs(name, B, n_check, team, monkeypatch):
+    """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
+    (B = 8192, four wavefronts per instance; a smaller batch with teams of two forced through the
+    developer switch OPFX_TEAM) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
+    contingency (B = 4096 x 251 solves, four wavefronts per instance).  All rows:
+    size-independent properties; `n_check` rows spread over the batch: the full step against the oracle."""
+    if team == 2:
+        monkeypatch.setenv('OPFX_TEAM', '2')
+    env = product_env(name, batch_size=B)
+    orc = oracle_env(name, product_env(name, defer_device=True))
+    rng = np.random.default_rng(17)
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    actions = rng.random((B, env.n_actions))
+    obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    out = env.step(actions)
+    obs, reward, term, trunc, info = out
+    conv = _np(info['converged'])
+    assert conv.mean() > 0.99
+    r, obj, pen = _np(reward)[conv], _np(info['objective'])[conv], _np(info['unscaled_penalties'])[conv]
+    assert np.isfinite(r).all() and np.isfinite(_np(obs)[conv]).all()
+    assert np.allclose(r, 0.5 * obj + 0.5 * pen.sum(axis=1), rtol=1e-12, atol=1e-9)       # Summation, reward.py:78-81
+    if not env.n_minus_one_keys:
+        assert (pen <= 0).all()
+        assert ((_np(info['violations'])[conv] == 0) == _np(info['valids'])[conv]).all()
+    assert (_np(info['max_mismatch'])[conv] < 1e-8).all()
+    assert _np(term).all()
+    # the same inputs in another row order give the same rows (no cross-instance state; wave teams sum in
+    # a run-dependent order, so to rounding only)
+    perm = rng.permutation(B)
+    reward_first = _np(reward).copy()          # (step() returns its persistent output buffers)
+    env.reset(options={'step': steps[perm], 'uniform': uniform[perm] if uniform is not None else None})
+    out2 = env.step(actions[perm])
+    assert np.allclose(_np(out2[1]), reward_first[perm], rtol=1e-9, atol=1e-9, equal_nan=True)
+    obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    out = env.step(actions)
+    conv = _np(out[4]['converged'])
+    n_ok = 0
+    for k in np.linspace(0, B - 1, n_check).astype(int):
+        ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        assert np.allclose(_np(obs0)[k], ob0, rtol=0, atol=R_TOL)
+        ref = orc.step(actions[k])
+        assert bool(conv[k]) == ref['converged']
+        if not ref['converged']:
+            continue
+        ref = dict(ref, obs_step=ref['obs'])
+        _check_step(env, out, ref, k, n1=bool(env.n_minus_one_keys))
+        n_ok += 1
+    assert n_ok >= n_check - 2
+    assert capi_team(env) == team
+
+
+def capi_team(env):
+    """wavefronts per instance the environment's kernels run with (LDS footprint -> team size, opfx.hip pick_team)"""
+    import ctypes as C
+    from opfgym_amd import capi
+    n = C.c_int32()
+    capi.check(capi.lib().opfx_env_get_info(env._env_handle, C.byref(n), None, None), 'opfx_env_get_info')
+    return n.value
+
+
 @pytest.mark.parametrize('name', list(EPISODE_STEPS))
 def test_env_multi_step_episodes(name):
     """steps_per_episode > 1: the column store x carries the set-points from step to step
