@@ -1,21 +1,32 @@
-"""Benchmark of the hot path: env.step()/s at batch 8192 per GPU.
+"""Benchmark of the hot path: env.step()/s of the batched, fused step kernel.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--config C] --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): VoltageControl on the synthetic stand-in
-for SimBench 1-MV-urban--0-sw (144 buses), B = 8192 instances per GPU, FP64.
-One "step" = one `env.step()` of the whole batch = ONE launch of the fused
-kernel (apply actions -> NR power flow -> results -> objective -> violations
--> reward -> observation).  Inputs are resident in HBM when the timed region
-starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank steps its own 8192-instance shard (weak scaling).  Instances are
-independent, so the data path has NO collective; `--gather reward|obs` adds the
-optional RCCL all-gather a centralised learner would want.
-Rank 0 prints one JSON line.
+`--config` selects one of BASELINE.json's configurations (default 2, the one the headline metric is
+quoted on):
+  1  MaxRenewable,            1-LV-rural1--0-sw (15 buses),  batch 1: the plumbing case (launch-latency bound)
+  2  VoltageControl,          1-MV-urban--0-sw (144 buses),  8192 instances per GPU            (weak)
+  3  EcoDispatch,             1-HV-mixed--0-sw (306 buses),  8192 instances per GPU            (weak)
+  4  QMarket,                 1-MV-urban--0-sw (144 buses),  65536 instances sharded over N    (strong)
+  5  N-1 VoltageControl,      1-HV-urban--0-sw (372 buses),  4096 instances x (1 + K) solves,
+                              K = every non-islanding line, sharded over N                     (strong)
+All grids are synthetic stand-ins of the named SimBench codes (SimBench is unavailable offline).
+
+One "step" = one `env.step()` of the whole batch = ONE launch of the fused kernel (apply actions -> NR
+power flow [-> K contingency solves] -> results -> objective -> violations -> reward -> observation).
+Inputs are resident in HBM when the timed region starts.
+
+`--gpus N` with N > 1: one process per GPU over torch.distributed (nccl = RCCL).  Launched by
+`torch.distributed.run` the ranks are taken from the environment; launched plainly, this script starts
+the N ranks itself (child processes, before anything touches a GPU) and relays rank 0's line.  Instances
+are independent, so the data path has NO collective; for N > 1 the rewards are all-gathered per step
+(`--gather reward`, the default; `obs` adds the observations, `none` removes it) — the one exchange a
+centralised learner needs.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,13 +35,22 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', '
 
 import numpy as np  # noqa: E402
 
-BATCH = 8192
-GRID = '1-MV-urban--0-sw'
+# config -> (env class, constructor kwargs, batch, scaling, golden scenario of the CPU oracle)
+CONFIGS = {
+    1: ('MaxRenewable', dict(simbench_network_name='1-LV-rural1--0-sw', min_sgen_power=0.005, min_storage_power=0.005),
+        1, 'weak', 'maxren_lv'),
+    2: ('VoltageControl', dict(simbench_network_name='1-MV-urban--0-sw'), 8192, 'weak', 'vc_mv_urban'),
+    3: ('EcoDispatch', dict(simbench_network_name='1-HV-mixed--0-sw'), 8192, 'weak', 'eco_hv_mixed'),
+    4: ('QMarket', dict(simbench_network_name='1-MV-urban--0-sw'), 65536, 'strong', 'qm_mv_urban'),
+    5: ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw', n_minus_one_lines='all'),
+        4096, 'strong', 'sc_vc_hv_urban'),
+}
 
 
-def byte_model(env, mean_it):
+def byte_model(env, mean_it_per_solve, solves_per_step):
     """ALGORITHMIC bytes per instance-step:
-    B_step = 8*(n_in + n_out) + it*8*(2*nnzJ + 2*nnzLU + 4*nJ + 4*nb)."""
+    B_step = 8*(n_in + n_out) + it*8*(2*nnzJ + 2*nnzLU + 4*nJ + 4*nb), `it` = NR iterations of ALL solves
+    of the step (base case + contingencies)."""
     info = env.plan.info
     net = env.net
     n_price = sum(1 for k in env.store.dynamic if k[0] in ('poly_cost', 'pwl_cost'))
@@ -39,71 +59,133 @@ def byte_model(env, mean_it):
     n_j = info['npv'] + 2 * info['npq']
     nnz_lu = 4 * info['n_blk']
     per_it = 8 * (2 * info['nnz_j'] + 2 * nnz_lu + 4 * n_j + 4 * info['nb'])
-    b_step = 8 * (n_in + n_out) + mean_it * per_it
+    it_step = mean_it_per_solve * solves_per_step
+    b_step = 8 * (n_in + n_out) + it_step * per_it
     # FP64 operation count of the same step (for the "what actually bounds it" report):
     # per NR iteration  A: 24 per off-diagonal Ybus entry + 40 per bus,  B: 46 per update term,
-    # C: 8 per U-term + 20 per pivot,  D: 40 per bus;  one more phase A for the final check.
+    # C: 8 per U-term + 20 per pivot,  D: 40 per bus;  one more phase A per solve for the final check.
     nnz_off = info['nnz_y'] - info['nb']
     n_piv = info['nb'] - info['nref']
     a_flops = 24 * nnz_off + 40 * info['nb']
     flops_it = a_flops + 46 * info['n_sources'] + 8 * info['n_uterms'] + 20 * n_piv + 40 * info['nb']
-    flops = mean_it * flops_it + a_flops + 10 * info['nbr'] * 4 + 30 * info['nb']
-    return dict(nb=info['nb'], nbr=info['nbr'], nJ=n_j, nnzJ=info['nnz_j'], nnzLU=nnz_lu,
-                n_in=n_in, n_out=n_out, it=mean_it, io_bytes=8 * (n_in + n_out),
-                bytes_per_iteration=per_it, B_step=b_step, fp64_flops_per_step=flops)
+    flops = it_step * flops_it + solves_per_step * (a_flops + 10 * info['nbr'] * 4 + 30 * info['nb'])
+    return dict(nb=info['nb'], nbr=info['nbr'], nJ=n_j, nnzJ=info['nnz_j'], nnzLU=nnz_lu, levels=info['n_levels'],
+                n_in=n_in, n_out=n_out, it_per_solve=mean_it_per_solve, solves_per_step=solves_per_step,
+                it=it_step, io_bytes=8 * (n_in + n_out), bytes_per_iteration=per_it, B_step=b_step,
+                fp64_flops_per_step=flops)
 
 
-def cpu_baseline(budget_s=15.0):
-    """The CPU oracle (numpy/SciPy restatement of the reference path: pandas
-    tables + SuperLU Newton) timed on this box, one core, on a bounded sample of
-    the same workload."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (numpy/SciPy restatement of the reference path: pandas tables + SuperLU
+# Newton) on this box's host cores, in worker processes (one, then one per host core up to 32)
+# ---------------------------------------------------------------------------------------------------
+def cpu_worker(scenario, budget_s, seed):
+    """One core: env.step() of the oracle environment for `budget_s` seconds; prints one JSON line."""
     from env_cases import oracle_env, product_env
-    orc = oracle_env('vc_mv_urban', product_env('vc_mv_urban', defer_device=True))
-    rng = np.random.default_rng(0)
+    host = product_env(scenario, defer_device=True)
+    orc = oracle_env(scenario, host)
+    n_uniform = host.ops.n_uniform          # price draws of the `_sampling` tails
+    rng = np.random.default_rng(seed)
     pool = np.arange(2000, 30000)
     n_act = sum(len(i) for _, _, i in orc.act_keys)
     t_step, n = 0.0, 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        orc.reset(int(rng.choice(pool)))
+    while time.perf_counter() - t0 < budget_s or n == 0:
+        orc.reset(int(rng.choice(pool)), rng.random(n_uniform))
         a = rng.random(n_act)
         t1 = time.perf_counter()
         out = orc.step(a)
         t_step += time.perf_counter() - t1
         n += bool(out['converged'])
-    return dict(value=n / t_step, unit='env.step()/s', cores=1, kind='port',
-                sample=f'{n} instance-steps of VoltageControl/{GRID} with the numpy+SciPy oracle '
-                       f'(oracle/env_oracle.py + pf_oracle.py), step() only, {t_step:.1f} s of CPU work; '
-                       f'pandapower itself is not installed')
+    print(json.dumps({'steps': n, 'cpu_s': t_step}))
+
+
+def cpu_baseline(config, budget_s=10.0):
+    scenario = CONFIGS[config][4]
+    cores = os.cpu_count() or 1
+
+    def run(n_proc):
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', scenario,
+                                   '--cpu-budget', str(budget_s), '--cpu-seed', str(k)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1'))
+                 for k in range(n_proc)]
+        res = []
+        for p in procs:
+            out, _ = p.communicate()
+            lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+            if lines:
+                res.append(json.loads(lines[-1]))
+        return res
+    one = run(1)
+    rate1 = one[0]['steps'] / one[0]['cpu_s'] if one else float('nan')
+    n_many = min(cores, 32)          # (every worker is a Python process with pandas + SciPy: bounded memory)
+    many = run(n_many) if n_many > 1 else one
+    rate_p = sum(r['steps'] / r['cpu_s'] for r in many) if many else float('nan')
+    return dict(value=rate1, unit='env.step()/s', cores=1, kind='port',
+                all_cores=dict(value=rate_p, cores=len(many), host_cores=cores),
+                sample=f'{one[0]["steps"] if one else 0} instance-steps of {CONFIGS[config][0]} (scenario {scenario}) with '
+                       f'the numpy+SciPy oracle (oracle/env_oracle.py + pf_oracle.py), step() only, '
+                       f'{one[0]["cpu_s"] if one else 0:.1f} s of CPU work on one core; then {len(many)} independent '
+                       f'processes, one per host core; pandapower itself is not installed')
+
+
+# ---------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Plain `python bench.py --gpus N` (N > 1): start the N ranks as children, relay rank 0's line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--batch', type=int, default=None, help='instances per GPU (default: the configuration\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather', choices=('none', 'reward', 'obs'), default='none',
-                    help='optional per-step RCCL all-gather of the rewards (and observations) on every rank')
+    ap.add_argument('--gather', choices=('none', 'reward', 'obs'), default=None,
+                    help='per-step RCCL all-gather of the rewards (and observations) on every rank; '
+                         'default: reward when N > 1')
+    ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-budget', type=float, default=10.0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker, args.cpu_budget, args.cpu_seed)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))           # nothing has touched a GPU in this process
 
     import torch
     import torch.distributed as dist
     from opfgym_amd import capi, dist as odist, envs
     rank, world, local_rank = odist.init_from_env()
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node N'
     if os.environ.get('OPFX_BENCH_SHARE_GPU'):       # debugging aid: all ranks on GPU 0 (use with gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
-    B = args.batch
-    env = envs.VoltageControl(simbench_network_name=GRID, batch_size=B, device=device, seed=rank)
+    cls_name, kw, batch_cfg, scaling, _ = CONFIGS[args.config]
+    gather_mode = args.gather or ('reward' if world > 1 else 'none')
+    if args.batch is not None:
+        B = args.batch
+    elif scaling == 'weak':
+        B = batch_cfg
+    else:                                          # strong: the configuration's total, whole instances per rank
+        lo, hi = odist.shard_bounds(batch_cfg, rank, world)
+        B = hi - lo
+    total_B = B * world if (args.batch is not None or scaling == 'weak') else batch_cfg
+    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=rank, **kw)
     rng = np.random.default_rng(1234 + rank)
     env.reset(options={'step': rng.choice(env.train_steps, B)})
     act_rng = np.random.default_rng(4321 + rank)
     actions = torch.as_tensor(act_rng.random((B, env.n_actions)), device=device)
-    gather = {'none': (), 'reward': ('reward',), 'obs': ('reward', 'obs')}[args.gather]
+    gather = {'none': (), 'reward': ('reward',), 'obs': ('reward', 'obs')}[gather_mode]
 
     def one_step():
         obs, reward, term, trunc, info = env.step(actions)
@@ -131,56 +213,82 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     conv = float(info['converged'].double().mean().item())
-    mean_it = float(info['iterations'].double().mean().item())
+    solves_per_step = 1 + len(env.contingencies)
+    mean_it_total = float(info['total_iterations'].double().mean().item())
+    mean_it_base = float(info['iterations'].double().mean().item())
+    min_pivot = float(info['min_pivot'].min().item())
 
     # kernel duration: HIP events on the launch stream around back-to-back launches
     io = env._io(actions, False)
     ms = capi.C.c_float()
+    reps = max(5, min(args.steps, 50))
     with torch.cuda.device(device):
         capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io),
-                                              capi.C.byref(env.solve_opts), max(5, args.steps),
+                                              capi.C.byref(env.solve_opts), reps,
                                               capi._stream(), capi.C.byref(ms)), 'opfx_time_steps')
-    kernel_ms = ms.value / max(5, args.steps)
+    kernel_ms = ms.value / reps
+
+    # the cycle of a single-step benchmark environment: reset (device-side sampling) + step
+    n_cyc = max(3, min(args.steps, 20))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_cyc):
+        env.reset()
+        env.step(actions)
+    torch.cuda.synchronize()
+    cycle_ms = (time.perf_counter() - t1) / n_cyc * 1e3
 
     if rank == 0:
-        bm = byte_model(env, mean_it)
+        team, lds, per_cu = capi.C.c_int32(), capi.C.c_int64(), capi.C.c_int32()
+        capi.check(capi.lib().opfx_env_get_info(env._env_handle, capi.C.byref(team), capi.C.byref(lds), capi.C.byref(per_cu)))
+        bm = byte_model(env, mean_it_total / solves_per_step, solves_per_step)
         achieved = bm['B_step'] * B / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
-        # separate runs of this same script, see profiles/README.md) — not measurable in-process
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate
+        # runs of this same script, see profiles/README.md) — not measurable in-process
         traffic = None
         pmc_file = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-        if B == BATCH and os.path.exists(pmc_file):
-            traffic = json.load(open(pmc_file))['hbm_bytes_per_launch_fetch_x2']
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            ent = pmc.get(f'config{args.config}', pmc if args.config == 2 and 'hbm_bytes_per_launch_fetch_x2' in pmc else None)
+            if ent and ent.get('batch', 8192) == B:
+                traffic = ent['hbm_bytes_per_launch_fetch_x2']
+        kernel_name = f'k_step<{"2" if env.plan.info["n_full"] < env.plan.info["n_blk"] else "1"}|1,{team.value}>'
         out = {
             'metric': 'env.step()/s (batched NR power-flow solves/s) at batch 8192',
-            'value': world * B * args.steps / elapsed,
+            'value': total_B * args.steps / elapsed,
             'unit': 'env.step()/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': scaling if args.batch is None else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'VoltageControl env, synthetic stand-in for SimBench {GRID} '
-                                   f'({bm["nb"]} buses), batch={B} per GPU, step() only',
-                       'batch_per_gpu': B, 'parallelism': f'shard{world}',
-                       'collective': {'none': 'none', 'reward': 'all_gather(reward)', 'obs': 'all_gather(reward+obs)'}[args.gather] if world > 1 else 'none',
-                       'converged_fraction': conv, 'mean_nr_iterations': mean_it,
-                       'tolerance_pu': env.solve_opts.tol, 'byte_model': bm},
+            'config': {'workload': f'BASELINE config {args.config}: {cls_name} env, synthetic stand-in for SimBench '
+                                   f'{kw["simbench_network_name"]} ({bm["nb"]} buses), batch={total_B} '
+                                   f'({B} per GPU), {solves_per_step} NR solve(s) per step, step() only',
+                       'baseline_config': args.config, 'batch_per_gpu': B, 'batch_total': total_B,
+                       'parallelism': f'shard{world}',
+                       'collective': {'none': 'none', 'reward': 'all_gather(reward)', 'obs': 'all_gather(reward+obs)'}[gather_mode] if world > 1 else 'none',
+                       'converged_fraction': conv, 'mean_nr_iterations': mean_it_base,
+                       'mean_nr_iterations_all_solves': mean_it_total, 'solves_per_step': solves_per_step,
+                       'nr_solves_per_s': total_B * solves_per_step * args.steps / elapsed,
+                       'reset_plus_step_ms': cycle_ms, 'episodes_per_s_reset_plus_step': B * world / (cycle_ms * 1e-3),
+                       'min_relative_pivot': min_pivot,
+                       'tolerance_pu': env.solve_opts.tol, 'byte_model': bm,
+                       'kernel_launch': {'waves_per_instance': team.value, 'lds_bytes_per_instance': lds.value,
+                                         'instances_per_cu': per_cu.value}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
                          'algorithmic_bytes_per_launch': bm['B_step'] * B,
-                         'kernel': 'k_step', 'kernel_ms': kernel_ms,
+                         'compulsory_io_bytes_per_launch': bm['io_bytes'] * B,
+                         'kernel': kernel_name, 'kernel_ms': kernel_ms,
                          'fp64_tflops_achieved': bm['fp64_flops_per_step'] * B / (kernel_ms * 1e-3) / 1e12,
                          'fp64_vector_peak_tflops': 78.6,
-                         'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory '
-                                 'once per NR phase) x 8192 / kernel time; the kernel keeps that state in LDS, '
-                                 'so real HBM traffic is ~ io_bytes per instance; the kernel is bound by what one '
-                                 'wave gets through (dependent issue, LDS return rate) at 2 waves per SIMD '
-                                 '(profiles/*_sq_counters.txt, DESIGN.md)'},
+                         'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory once per NR '
+                                 'phase) x instances per launch / kernel time; the kernel keeps that state in LDS, so '
+                                 'real HBM traffic is ~ io_bytes per instance (`traffic`); what bounds the kernel is a '
+                                 'wave\'s own issue / LDS-return rate (profiles/*_sq_counters.txt, DESIGN.md)'},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
-        else:
-            out['cpu_baseline'] = None
+        # timed after the GPU work, in child processes (one, then one per host core)
+        out['cpu_baseline'] = cpu_baseline(args.config) if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

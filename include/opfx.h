@@ -145,7 +145,12 @@ void opfx_version(int* major, int* minor, int* patch);
  * source at each REF bus (calculated injection minus p_inj/q_inj there), P,Q
  * p.u. interleaved, REF buses in increasing bus order; q_gen [B,nb] reactive
  * output of the generator at each PV bus, p.u. (0 elsewhere); converged [B],
- * iterations [B], max_mismatch [B] (final inf-norm of [dP;dQ], p.u.).
+ * iterations [B], max_mismatch [B] (final inf-norm of [dP;dQ], p.u.),
+ * min_pivot [B]: the smallest RELATIVE pivot of the block-LU over all iterations,
+ * |det| / (|a11 a22| + |a12 a21|) of the 2x2 diagonal block each bus is eliminated
+ * with (1 = no cancellation; towards 0 the static pivoting inside the blocks is
+ * breaking down and a "not converged" may be numerical, not physical; NaN from the
+ * first-generation fallback kernel, which does not monitor it).
  * q_inj at a PV bus is the reactive injection of everything EXCEPT the voltage-
  * controlling generator there (so Qgen = Qcalc - q_inj); qg_min/qg_max [nb]
  * p.u. (NULL = unlimited) are the generator capability used by enforce_q_lims.
@@ -165,7 +170,7 @@ int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_in
                const int32_t* outage, const opfx_solve_opts* opts,
                double* vm, double* va, double* loading, double* s_ref, double* q_gen,
                uint8_t* converged, int32_t* iterations, double* max_mismatch,
-               void* stream);
+               double* min_pivot, void* stream);
 
 /* ---- environment evaluation ------------------------------------------------
  * Per-instance state lives in one row-major column store x[B,nx] owned by the
@@ -316,8 +321,10 @@ typedef struct opfx_step_io {
   double* results;           /* [B,nres] result bank                         */
   double* mean_correction;   /* [B]                                          */
   uint8_t* converged;        /* [B]                                          */
-  int32_t* iterations;       /* [B]                                          */
+  int32_t* iterations;       /* [B]  NR iterations of the base case          */
   double* max_mismatch;      /* [B]                                          */
+  int32_t* total_iterations; /* [B]  NR iterations summed over the base case and every contingency solve */
+  double* min_pivot;         /* [B]  smallest relative 2x2 pivot of all solves of the step, see opfx_solve */
 } opfx_step_io;
 
 /* One env.step() for B instances: apply actions → injections → NR → results →

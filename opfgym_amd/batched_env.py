@@ -886,7 +886,8 @@ class BatchedOpfEnv:
             violations=t.zeros(B, nc, **f64), penalties=t.zeros(B, nc, **f64), cost=t.zeros(B, **f64),
             objective=t.zeros(B, **f64), results=t.zeros(B, self.n_results, **f64),
             mean_correction=t.zeros(B, **f64), converged=t.zeros(B, **u8),
-            iterations=t.zeros(B, dtype=t.int32, device=dev), max_mismatch=t.zeros(B, **f64))
+            iterations=t.zeros(B, dtype=t.int32, device=dev), max_mismatch=t.zeros(B, **f64),
+            total_iterations=t.zeros(B, dtype=t.int32, device=dev), min_pivot=t.zeros(B, **f64))
         self.initial_obj = t.zeros(B, **f64)
         self.step_count = t.zeros(B, dtype=t.int32, device=dev)
         self.steps_dev = t.zeros(B, dtype=t.int32, device=dev)
@@ -1077,7 +1078,8 @@ class BatchedOpfEnv:
         info = {'valids': b['valids'], 'violations': b['violations'],
                 'unscaled_penalties': b['penalties'], 'cost': b['cost'],
                 'converged': b['converged'], 'iterations': b['iterations'],
-                'max_mismatch': b['max_mismatch'], 'objective': b['objective']}
+                'max_mismatch': b['max_mismatch'], 'objective': b['objective'],
+                'total_iterations': b['total_iterations'], 'min_pivot': b['min_pivot']}
         return self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info
 
     def _finish_obs(self):

@@ -105,7 +105,8 @@ class StepIO(C.Structure):
                 ('truncated', C.c_void_p), ('valids', C.c_void_p), ('violations', C.c_void_p),
                 ('penalties', C.c_void_p), ('cost', C.c_void_p), ('objective', C.c_void_p),
                 ('results', C.c_void_p), ('mean_correction', C.c_void_p),
-                ('converged', C.c_void_p), ('iterations', C.c_void_p), ('max_mismatch', C.c_void_p)]
+                ('converged', C.c_void_p), ('iterations', C.c_void_p), ('max_mismatch', C.c_void_p),
+                ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p)]
 
 
 class ProfileDesc(C.Structure):
@@ -167,7 +168,7 @@ def lib():
     L.opfx_ctx_destroy.restype = None
     L.opfx_version.argtypes = [C.POINTER(C.c_int)] * 3
     L.opfx_version.restype = None
-    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 9
+    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 10
     L.opfx_env_create.argtypes = [vp, C.POINTER(EnvDesc), C.POINTER(vp)]
     L.opfx_env_destroy.argtypes = [vp]
     L.opfx_env_destroy.restype = None
@@ -313,11 +314,12 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
     out['converged'] = torch.empty(B, dtype=torch.uint8, device=dev)
     out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
     out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
+    out['min_pivot'] = torch.empty(B, dtype=torch.float64, device=dev)
     opts = SolveOpts(float(tol), int(max_iter), int(bool(enforce_q_lims)))
     with torch.cuda.device(dev):
         check(lib().opfx_solve(
             ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),
             _ptr(outage), C.byref(opts), _ptr(out.get('vm')), _ptr(out.get('va')),
             _ptr(out.get('loading')), _ptr(out.get('s_ref')), _ptr(out.get('q_gen')), _ptr(out['converged']),
-            _ptr(out['iterations']), _ptr(out['max_mismatch']), _stream()), 'opfx_solve')
+            _ptr(out['iterations']), _ptr(out['max_mismatch']), _ptr(out['min_pivot']), _stream()), 'opfx_solve')
     return out

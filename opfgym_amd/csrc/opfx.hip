@@ -113,6 +113,7 @@ struct SolveIO {
   double *vm, *va, *loading, *s_ref, *q_gen, *max_mismatch;
   unsigned char* converged;
   int* iterations;
+  double* min_pivot;
 };
 
 struct StepIO {
@@ -124,6 +125,8 @@ struct StepIO {
   double *mean_correction, *max_mismatch;
   unsigned char *terminated, *truncated, *valids, *converged;
   int* iterations;
+  int* total_iterations;
+  double* min_pivot;
   int mode;
 };
 
@@ -190,6 +193,20 @@ __device__ __forceinline__ double wave_max_dpp(double v) {   // NaN-propagating;
   v = nn_max(v, dpp_f64<0x140, 0xF>(v, v));
   v = nn_max(v, dpp_f64<0x142, 0xA>(v, v));
   v = nn_max(v, dpp_f64<0x143, 0xC>(v, v));
+  return read_lane63(v);
+}
+// min of NON-NEGATIVE operands by their bit patterns (a NaN pattern lies above +inf: ignored unless both are NaN)
+__device__ __forceinline__ double nn_min(double a, double b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  return __longlong_as_double((long long)(ua < ub ? ua : ub));
+}
+__device__ __forceinline__ double wave_min_dpp(double v) {   // v >= 0
+  v = nn_min(v, dpp_f64<0xB1, 0xF>(v, v));
+  v = nn_min(v, dpp_f64<0x4E, 0xF>(v, v));
+  v = nn_min(v, dpp_f64<0x141, 0xF>(v, v));
+  v = nn_min(v, dpp_f64<0x140, 0xF>(v, v));
+  v = nn_min(v, dpp_f64<0x142, 0xA>(v, v));
+  v = nn_min(v, dpp_f64<0x143, 0xC>(v, v));
   return read_lane63(v);
 }
 __device__ __forceinline__ int wave_any(int pred) { return __any(pred); }
@@ -541,8 +558,11 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
 
 #endif
 
+// `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
+// diagonal block a pivot is solved with (1 = no cancellation, -> 0 = the block is numerically singular:
+// static pivoting inside the blocks has broken down, SURVEY §7 hard part 2).
 template <bool PK>
-__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
+__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d, double& piv) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned k = d.x & 0xFFFF;
   if (k == NONE) return;
@@ -563,7 +583,10 @@ __device__ __forceinline__ void item_solve(const Lds& L, const uint4 d) {
   if (dblk != NONE) {
     const double y1 = L.rhs[k] - d1, y2 = L.rq[k] - d2;
     const Blk bk = ld_blk2<PK>(L, dblk);
-    const double rdet = fast_rcp(bk.a11 * bk.a22 - bk.a12 * bk.a21);
+    const double p1 = bk.a11 * bk.a22, p2 = bk.a12 * bk.a21;
+    const double det = p1 - p2;
+    const double rdet = fast_rcp(det);
+    piv = nn_min(piv, fabs(det) * __builtin_amdgcn_rcp(fabs(p1) + fabs(p2)));
     L.rhs[k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
     L.rq[k] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
   } else {
@@ -710,7 +733,8 @@ __device__ __forceinline__ void mods_row_current(const Lds& L, int n_mod, int i,
 
 template <bool PK>
 __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
-                        int* iters_out, double* nrm_out) {
+                        int* iters_out, double* nrm_out, double* piv_out) {
+  double piv = 1.0;
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
@@ -916,10 +940,10 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     OPFX_STAMP(2);
     for (int r = RB; r < R; r += 4) {
-      item_solve<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_solve<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_solve<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_solve<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_solve<PK>(L, q0, piv); wave_fence(); q0 = ld_desc(r + 4);
+      item_solve<PK>(L, q1, piv); wave_fence(); q1 = ld_desc(r + 5);
+      item_solve<PK>(L, q2, piv); wave_fence(); q2 = ld_desc(r + 6);
+      item_solve<PK>(L, q3, piv); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(3);
     // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
@@ -952,6 +976,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   }
   *iters_out = it;
   *nrm_out = nrm;
+  *piv_out = wave_min_dpp(piv);
   return conv;
 }
 
@@ -972,15 +997,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 template <bool PK>
-__device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
+__device__ __forceinline__ void team_step(const Lds& L, const uint4 d, double& piv) {
   const unsigned flags = __builtin_amdgcn_readfirstlane(d.w);      // same for every item of a round
-  if (flags & 2u) item_solve<PK>(L, d); else item_factor<PK>(L, d);
+  if (flags & 2u) item_solve<PK>(L, d, piv); else item_factor<PK>(L, d);
   if (flags & 1u) lds_barrier();
 }
 
 template <int NW, bool PK>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
-                             int* iters_out, double* nrm_out) {
+                             int* iters_out, double* nrm_out, double* piv_out) {
+  double piv = 1.0;
   constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1101,10 +1127,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
     for (int k = 0; k < K; k += 4) {
-      team_step<PK>(L, q0); q0 = ld_desc(k + 4);
-      team_step<PK>(L, q1); q1 = ld_desc(k + 5);
-      team_step<PK>(L, q2); q2 = ld_desc(k + 6);
-      team_step<PK>(L, q3); q3 = ld_desc(k + 7);
+      team_step<PK>(L, q0, piv); q0 = ld_desc(k + 4);
+      team_step<PK>(L, q1, piv); q1 = ld_desc(k + 5);
+      team_step<PK>(L, q2, piv); q2 = ld_desc(k + 6);
+      team_step<PK>(L, q3, piv); q3 = ld_desc(k + 7);
     }
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
@@ -1119,8 +1145,16 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     __syncthreads();
   }
   __syncthreads();          // xw (aliases the constraint accumulators) is free again
+  piv = wave_min_dpp(piv);
+  if (lane == 0) xw[wave] = piv;
+  __syncthreads();
+  piv = xw[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) piv = nn_min(piv, xw[w]);
+  __syncthreads();
   *iters_out = it;
   *nrm_out = nrm;
+  *piv_out = piv;
   return conv;
 }
 
@@ -1201,7 +1235,8 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 
 template <int V2, int NW>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
-                               const double* qg_min, const double* qg_max, int* iters, double* nrm, int isl_state = 0) {
+                               const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
+                               int isl_state = 0) {
   const int wave = threadIdx.x >> 6;
   // isl_state (islanding outages, see island_state): 1 = the caller has de-energised the island
   // (mark_island) and the solve proceeds on the rest; 2 = the cut-off set is not known exactly
@@ -1212,9 +1247,11 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   bool conv = false;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm);
-    else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm) : newton(P, L, o, lane, out_br, &it, nrm);
+    double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm, &pv_);
+    else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm, &pv_) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
+    *min_piv = (pv_ == pv_) ? fmin(*min_piv, pv_) : *min_piv;
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
     int changed = 0;
@@ -1402,7 +1439,8 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
     if (isl == 1 && wave == 0) mark_island(P, L, lane, out_br, io.qg_min, io.qg_max);
     blk_sync<NW>();
     int iters; double nrm;
-    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, isl);
+    double min_piv = V2 ? 1.0 : __builtin_nan("");
+    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
     blk_sync<NW>();
     if (wave == 0) {
       double* R = L.blk;
@@ -1421,6 +1459,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
         if (io.converged) io.converged[b] = conv ? 1 : 0;
         if (io.iterations) io.iterations[b] = iters;
         if (io.max_mismatch) io.max_mismatch[b] = nrm;
+        if (io.min_pivot) io.min_pivot[b] = min_piv;
       }
     }
     blk_sync<NW>();
@@ -1646,8 +1685,9 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
     double objective = 0.0, viol_acc = 0.0, pen_acc = 0.0;   // lane g < nc holds group g
     int valid_acc = 1;
     bool conv0 = false;
-    int iters0 = 0;
+    int iters0 = 0, iters_all = 0;
     double nrm0 = 0.0;
+    double min_piv = V2 ? 1.0 : __builtin_nan("");
     const int base_out = io.outage ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
@@ -1703,7 +1743,8 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, isl);
+      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
+      iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) {
@@ -1879,6 +1920,8 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       if (io.iterations) io.iterations[b] = iters0;
       if (io.max_mismatch) io.max_mismatch[b] = nrm0;
       if (io.mean_correction) io.mean_correction[b] = corr;
+      if (io.total_iterations) io.total_iterations[b] = iters_all;
+      if (io.min_pivot) io.min_pivot[b] = min_piv;
     }
     }
     blk_sync<NW>();
@@ -2207,7 +2250,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                           const double* qg_min, const double* qg_max, const int32_t* outage,
                           const opfx_solve_opts* opts, double* vm, double* va, double* loading,
                           double* s_ref, double* q_gen, uint8_t* converged, int32_t* iterations,
-                          double* max_mismatch, void* stream) {
+                          double* max_mismatch, double* min_pivot, void* stream) {
   if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -2226,7 +2269,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                      : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
   int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
-  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations};
+  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
@@ -2474,6 +2517,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.mean_correction = io->mean_correction; s.max_mismatch = io->max_mismatch;
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
+  s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());

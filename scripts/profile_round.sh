@@ -1,48 +1,54 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for bench.py's k_step on the GPU box (run through gpurun):
-#   scripts/profile_round.sh <tag>   ->  gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_summary.json, sq_counters.txt}
+#   scripts/profile_round.sh <tag> [config] [steps]
+#     ->  gpurun_out/prof_<tag>/{kernel_stats.csv, pmc_summary.json, sq_counters.txt}
 # Passes (never combined, MI355X_MICROARCH.md "rocprofv3 PMC slots"): kernel trace + stats;
 # --pmc FETCH_SIZE; --pmc WRITE_SIZE; three SQ counter sets.
 set -u
 tag=${1:-latest}
+cfg=${2:-2}
+steps=${3:-20}
+psteps=$(( steps < 5 ? steps : 5 ))
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 20 --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --config $cfg --steps $steps --no-cpu-baseline > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --no-cpu-baseline > $out/$c.log 2>&1
 done
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
            "SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq$i -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/sq$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq$i -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --no-cpu-baseline > $out/sq$i.log 2>&1
 done
 cd $root
-python3 - "$out" "$tag" <<'PY'
+python3 - "$out" "$tag" "$cfg" "$psteps" <<'PY'
 import sys, glob, csv, collections, json, shutil
-out, tag = sys.argv[1], sys.argv[2]
+out, tag, cfg, psteps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 st = glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)
 if st:
     shutil.copy(st[0], out + '/kernel_stats.csv')
 acc = collections.defaultdict(list)
+name = ''
 for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if 'k_step' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            name = r['Kernel_Name']
 mean = {k: sum(v) / len(v) for k, v in acc.items()}
 with open(out + '/sq_counters.txt', 'w') as fh:
-    fh.write('# rocprofv3 --pmc, mean per k_step launch (B = 8192 instances), bench.py --steps 5 --warmup 2\n')
+    fh.write('# rocprofv3 --pmc, mean per k_step launch, bench.py --config %s --steps %s --warmup 2\n# %s\n' % (cfg, psteps, name))
     for k in sorted(mean):
         if k not in ('FETCH_SIZE', 'WRITE_SIZE'):
             fh.write('%-28s %16.0f  (n=%d)\n' % (k, mean[k], len(acc[k])))
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     fk, wk = mean['FETCH_SIZE'], mean['WRITE_SIZE']
-    json.dump({'kernel': 'k_step<true,1>, B=8192 instances per launch', 'tag': tag,
-               'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline (one pass per counter)',
+    json.dump({'kernel': name, 'tag': tag, 'config': int(cfg),
+               'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --config %s --steps %s --warmup 2 --no-cpu-baseline (one pass per counter)' % (cfg, psteps),
                'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk,
                'FETCH_SIZE_launches': len(acc['FETCH_SIZE']), 'WRITE_SIZE_launches': len(acc['WRITE_SIZE']),
                'hbm_bytes_per_launch_raw': (fk + wk) * 1024, 'hbm_bytes_per_launch_fetch_x2': (2 * fk + wk) * 1024,

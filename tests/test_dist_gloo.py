@@ -69,3 +69,69 @@ def test_two_rank_gather_equals_single_process(total):
         out = orc.step(actions[k])
         assert full_r[k] == out['reward']
         assert np.array_equal(full_o[k], out['obs'])
+
+
+class _OracleRows:
+    """Per-rank environment for the ShardedBatch test: the CPU oracle behind the batched interface
+    (reset(options={'step': [b]}) / step(actions [b, na]) -> torch tensors)."""
+
+    def __init__(self, b):
+        from env_cases import oracle_env
+        self.orc = oracle_env('maxren_lv')
+        self.b = b
+
+    def reset(self, options):
+        self.steps = options['step']
+
+    def step(self, actions):
+        outs = []
+        for k in range(self.b):
+            self.orc.reset(int(self.steps[k]))
+            outs.append(self.orc.step(actions[k].numpy()))
+        f64 = lambda key: torch.tensor(np.array([o[key] for o in outs]), dtype=torch.float64)
+        flags = torch.tensor([bool(o['terminated']) for o in outs])
+        return f64('obs'), f64('reward'), flags, torch.zeros_like(flags), {'cost': f64('cost')}
+
+
+def _sharded_worker(rank, world, port, total, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here, os.path.join(here, 'golden')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from opfgym_amd.dist import ShardedBatch, init_from_env
+    r_, w_, _ = init_from_env('gloo')
+    assert (r_, w_) == (rank, world)
+    sb = ShardedBatch(_OracleRows, total, rank, world, gather=('reward', 'obs', 'terminated', 'cost'))
+    rng = np.random.default_rng(11)
+    steps = rng.integers(2000, 30000, total)
+    actions = torch.tensor(rng.random((total, 3)))
+    sb.reset(options={'step': steps[sb.lo:sb.hi]})
+    local, full = sb.step(actions[sb.lo:sb.hi])
+    assert local[1].shape[0] == sb.hi - sb.lo and sum(sb.sizes) == total
+    if rank == 0:
+        q.put(({k: v.numpy() for k, v in full.items()}, steps, actions.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('total', [5, 8])
+def test_sharded_batch_reassembles_the_full_batch(total):
+    """`opfgym_amd.dist.ShardedBatch` (the wrapper bench.py's N > 1 path is built from): contiguous
+    whole-instance shards, one all-gather per requested output, ragged shards included — every rank ends
+    up with the rows a single process computes."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + total
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, steps, actions = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _OracleRows(total)
+    ref.reset({'step': steps})
+    obs, reward, term, _, info = ref.step(torch.tensor(actions))
+    assert np.array_equal(full['reward'], reward.numpy())
+    assert np.array_equal(full['obs'], obs.numpy())
+    assert np.array_equal(full['terminated'], term.double().numpy())
+    assert np.array_equal(full['cost'], info['cost'].numpy())
