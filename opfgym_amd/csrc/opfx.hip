@@ -255,6 +255,7 @@ struct Lds {
   int nfull;                 // blocks [0, nfull) also have a21 / a22 entries (arrays at o2, o3)
   int o2, o3;
   double* mod;               // per-instance branch modifiers (MOD_DOUBLES each), see mods_*
+  unsigned short* dg;        // [nb] diagonal block of every bus (copied from the plan once per workgroup)
 };
 // Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
 // (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
@@ -448,6 +449,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
+// one Newton step (relative error ~ 1e-14): enough for the elimination multipliers — every item that uses a
+// pivot block derives the same value from it, so the factorisation is that of a matrix perturbed by 1e-14
+// and Newton's convergence does not notice; the solution itself (solve_pivot) takes two steps
+__device__ __forceinline__ double fast_rcp1(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 __device__ __forceinline__ void lds_sub(double* p, double v) {
   __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -558,41 +567,22 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
 
 #endif
 
+// Phase D of the lane-programme kernels: after the back-substitution items y_i of bus i holds its
+// right-hand side with every U-term removed; x_i = A_ii^-1 y_i, then V_i <- V_i (1 + d|V|/|V|) e^{j dth}.
 // `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
-// diagonal block a pivot is solved with (1 = no cancellation, -> 0 = the block is numerically singular:
+// diagonal block the bus is solved with (1 = no cancellation, -> 0 = the block is numerically singular:
 // static pivoting inside the blocks has broken down, SURVEY §7 hard part 2).
-template <bool PK>
-__device__ __forceinline__ void item_solve(const Lds& L, const uint4 d, double& piv) {
-  constexpr unsigned NONE = 0xFFFFu;
-  const unsigned k = d.x & 0xFFFF;
-  if (k == NONE) return;
-  double d1 = 0.0, d2 = 0.0;
-  if ((d.y & 0xFFFF) != NONE) {
-    const Blk a = ld_blk2<PK>(L, d.y & 0xFFFF);
-    const unsigned j = d.y >> 16;
-    const double x1 = L.rhs[j], x2 = L.rq[j];
-    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-  }
-  if ((d.z & 0xFFFF) != NONE) {
-    const Blk a = ld_blk2<PK>(L, d.z & 0xFFFF);
-    const unsigned j = d.z >> 16;
-    const double x1 = L.rhs[j], x2 = L.rq[j];
-    d1 += a.a11 * x1 + a.a12 * x2; d2 += a.a21 * x1 + a.a22 * x2;
-  }
-  const unsigned dblk = d.x >> 16;
-  if (dblk != NONE) {
-    const double y1 = L.rhs[k] - d1, y2 = L.rq[k] - d2;
-    const Blk bk = ld_blk2<PK>(L, dblk);
-    const double p1 = bk.a11 * bk.a22, p2 = bk.a12 * bk.a21;
-    const double det = p1 - p2;
-    const double rdet = fast_rcp(det);
-    piv = nn_min(piv, fabs(det) * __builtin_amdgcn_rcp(fabs(p1) + fabs(p2)));
-    L.rhs[k] = (bk.a22 * y1 - bk.a12 * y2) * rdet;
-    L.rq[k] = (bk.a11 * y2 - bk.a21 * y1) * rdet;
-  } else {
-    lds_sub(&L.rhs[k], d1);
-    lds_sub(&L.rq[k], d2);
-  }
+__device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, double& dvm, double& piv) {
+  const int db = L.dg[i];
+  const double* p = L.blk + db;                       // (diagonal blocks always hold four values)
+  const double a11 = p[0], a12 = p[L.bs], a21 = p[L.o2], a22 = p[L.o3];
+  const double y1 = L.rhs[i], y2 = L.rq[i];
+  const double p1 = a11 * a22, p2 = a12 * a21;
+  const double det = p1 - p2;
+  const double rdet = fast_rcp(det);
+  piv = nn_min(piv, fabs(det) * __builtin_amdgcn_rcp(fabs(p1) + fabs(p2)));
+  dth = (a22 * y1 - a12 * y2) * rdet;
+  dvm = (a11 * y2 - a21 * y1) * rdet;
 }
 
 struct ARound { uint4 ent; double2 y[4]; double2 yd; unsigned dw; };
@@ -940,36 +930,33 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     OPFX_STAMP(2);
     for (int r = RB; r < R; r += 4) {
-      item_solve<PK>(L, q0, piv); wave_fence(); q0 = ld_desc(r + 4);
-      item_solve<PK>(L, q1, piv); wave_fence(); q1 = ld_desc(r + 5);
-      item_solve<PK>(L, q2, piv); wave_fence(); q2 = ld_desc(r + 6);
-      item_solve<PK>(L, q3, piv); wave_fence(); q3 = ld_desc(r + 7);
+      item_factor<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(3);
-    // ---- phase D: V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
-    {
-      bool large = false;
-      for (int i = lane; i < nb; i += WAVE)
-        if (L.bt[i] != BT_REF) large = large || !(fabs(L.rhs[i]) <= 0.25);   // (rhs of REF rows is never written; NaN counts as large)
-      const bool small = !wave_any(large);                      // wave-uniform
-      for (int i = lane; i < nb; i += WAVE) {
-        if (L.bt[i] == BT_REF) continue;
-        const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
-        double sn, cs;
-        if (small) {
-          // |dth| <= 0.25: Taylor series to x^15 / x^14, truncation error < 1e-21
-          const double z = dth * dth;
-          sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
-               + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
-          cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
-               + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
-        } else {
-          sincos(dth, &sn, &cs);
-        }
-        const double vr = L.vr[i], vi = L.vi[i];
-        L.vr[i] = (vr * cs - vi * sn) * sc;
-        L.vi[i] = (vr * sn + vi * cs) * sc;
+    // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
+    for (int i = lane; i < nb; i += WAVE) {
+      if (L.bt[i] == BT_REF) continue;                 // (rhs of a REF row holds its parked injection)
+      double dth, dvm;
+      solve_pivot(L, i, dth, dvm, piv);
+      const double sc = 1.0 + dvm;
+      double sn, cs;
+      if (fabs(dth) <= 0.25) {
+        // Taylor series to x^15 / x^14, truncation error < 1e-21 (the other branch is skipped as a whole
+        // while no lane needs it: after the first iteration the steps are small)
+        const double z = dth * dth;
+        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
+             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
+             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
+      } else {
+        sincos(dth, &sn, &cs);                         // (a NaN step ends here and stays NaN)
       }
+      const double vr = L.vr[i], vi = L.vi[i];
+      L.vr[i] = (vr * cs - vi * sn) * sc;
+      L.vi[i] = (vr * sn + vi * cs) * sc;
     }
     wave_fence();
     OPFX_STAMP(4);
@@ -996,11 +983,31 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#ifdef OPFX_ENABLE_STAMPS
+// diagnostic build: wave 0 of workgroup 0 splits its time in the B/C stream into work on items (slots
+// 20 factor / 21 solve) and waiting at the group barriers (22), and counts the barriers (23)
+#define OPFX_TEAM_STAMPS 1
+#endif
 template <bool PK>
-__device__ __forceinline__ void team_step(const Lds& L, const uint4 d, double& piv) {
+__device__ __forceinline__ void team_step(const DevPlan& P, const Lds& L, const uint4 d) {
   const unsigned flags = __builtin_amdgcn_readfirstlane(d.w);      // same for every item of a round
-  if (flags & 2u) item_solve<PK>(L, d, piv); else item_factor<PK>(L, d);
-  if (flags & 1u) lds_barrier();
+#ifdef OPFX_TEAM_STAMPS
+  const bool rec = P.stamps && blockIdx.x == 0 && threadIdx.x == 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+  item_factor<PK>(L, d);
+  if (!(flags & 1u)) asm volatile("" ::: "memory");     // (the same wavefront carries on: order by issue)
+#ifdef OPFX_TEAM_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (rec) P.stamps[20] += t1 - t0;
+#endif
+  if (flags & 1u) {
+    lds_barrier();
+#ifdef OPFX_TEAM_STAMPS
+    if (rec) { P.stamps[22] += __builtin_readcyclecounter() - t1; P.stamps[23] += 1; }
+#endif
+  }
 }
 
 template <int NW, bool PK>
@@ -1019,6 +1026,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
+  OPFX_STAMP_INIT();
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
   const double* psp_g = L.psp; const double* qsp_g = L.qsp;
@@ -1120,6 +1128,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     nrm = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
+    OPFX_STAMP(12);
     if (!(nrm == nrm)) { conv = false; break; }
     if (nrm < o.tol) { conv = true; break; }
     if (it >= o.max_iter) { conv = false; break; }
@@ -1127,15 +1136,18 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
     for (int k = 0; k < K; k += 4) {
-      team_step<PK>(L, q0, piv); q0 = ld_desc(k + 4);
-      team_step<PK>(L, q1, piv); q1 = ld_desc(k + 5);
-      team_step<PK>(L, q2, piv); q2 = ld_desc(k + 6);
-      team_step<PK>(L, q3, piv); q3 = ld_desc(k + 7);
+      team_step<PK>(P, L, q0); q0 = ld_desc(k + 4);
+      team_step<PK>(P, L, q1); q1 = ld_desc(k + 5);
+      team_step<PK>(P, L, q2); q2 = ld_desc(k + 6);
+      team_step<PK>(P, L, q3); q3 = ld_desc(k + 7);
     }
+    OPFX_STAMP(2);
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
       if (L.bt[i] == BT_REF) continue;
-      const double dth = L.rhs[i], sc = 1.0 + L.rq[i];
+      double dth, dvm;
+      solve_pivot(L, i, dth, dvm, piv);
+      const double sc = 1.0 + dvm;
       double sn, cs;
       sincos(dth, &sn, &cs);
       const double vr = L.vr[i], vi = L.vi[i];
@@ -1143,6 +1155,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       L.vi[i] = (vr * sn + vi * cs) * sc;
     }
     __syncthreads();
+    OPFX_STAMP(4);
   }
   __syncthreads();          // xw (aliases the constraint accumulators) is free again
   piv = wave_min_dpp(piv);
@@ -1411,6 +1424,7 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   L.acc = L.sp + na;
   L.mod = L.acc + nacc;
   L.bt = reinterpret_cast<unsigned char*>(L.mod + MOD_DOUBLES * nmod);
+  L.dg = reinterpret_cast<unsigned short*>(L.bt + ((nb + 1) & ~1));
   return L;
 }
 
@@ -1423,6 +1437,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
   const Lds L = carve<V2>(P, 0, nres_, smem, 8, 1);
+  if (V2) { for (int i = threadIdx.x; i < P.nb; i += blockDim.x) L.dg[i] = (unsigned short)P.diag_blk[i]; blk_sync<NW>(); }
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
@@ -1543,6 +1558,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
+  if (V2) { for (int i = tid; i < nb; i += NT) L.dg[i] = (unsigned short)P.diag_blk[i]; blk_sync<NW>(); }
   OPFX_STAMP_INIT();
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     double* xr = io.x + b * E.nx;
@@ -2104,7 +2120,7 @@ size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc,
   const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)n_full + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 4 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
-  size_t bytes = d * sizeof(double) + (size_t)p.nb;
+  size_t bytes = d * sizeof(double) + (((size_t)p.nb + 1) & ~(size_t)1) + (v2 ? 2 * (size_t)p.nb : 0);      // + bus types, diagonal block ids
   return (bytes + 15) & ~(size_t)15;
 }
 

@@ -185,41 +185,36 @@ void build_lane_programs(opfx_plan* p) {
   }
   p->rb = (int32_t)(p->lp_b.size() / 128);
   // ---- C ---------------------------------------------------------------------
-  auto flush_c = [&](std::vector<std::array<uint32_t, 3>>& its) {
-    for (size_t o = 0; o < its.size(); o += 64) {
+  // Back substitution in the SAME item form as the forward substitution of part B, column-oriented: once
+  // the right-hand side y_j of the pivots j of a level is final, every earlier pivot k whose row holds a
+  // block U_kj gets  y_k -= U_kj A_jj^-1 y_j  (an "rhs target" item: target k, block (k,j), pivot block
+  // (j,j), source j).  One group of mutually independent items per level, walked from the last level to the
+  // first; nothing is divided in place — the kernel's voltage update computes x_i = A_ii^-1 y_i for every
+  // bus at the end.  (A row-oriented sweep needs a second group per level for pivots with many U-terms.)
+  std::vector<std::vector<std::array<int32_t, 2>>> col_terms(nb);      // j -> (k, block (k,j))
+  for (size_t q = 0; q + 1 < p->piv_uptr.size(); ++q)
+    for (int u = p->piv_uptr[q]; u < p->piv_uptr[q + 1]; ++u)
+      col_terms[p->u_col[u]].push_back({p->piv_bus[q], p->u_blk[u]});
+  auto flush_c = [&]() {
+    for (size_t o = 0; o < items.size(); o += 64) {
       for (int lane = 0; lane < 64; ++lane) {
-        if (o + lane < its.size()) for (int w = 0; w < 3; ++w) p->lp_c.push_back(its[o + lane][w]);
-        else { p->lp_c.push_back(NONE | (NONE << 16)); p->lp_c.push_back(NONE | (NONE << 16)); p->lp_c.push_back(NONE | (NONE << 16)); }
+        if (o + lane < items.size()) { p->lp_c.push_back(items[o + lane][0]); p->lp_c.push_back(items[o + lane][1]); }
+        else { p->lp_c.push_back(NONE | (NONE << 16)); p->lp_c.push_back(0); }
       }
     }
-    its.clear();
+    items.clear();
   };
-  std::vector<std::array<uint32_t, 3>> citems;
   for (int lev = nlev - 1; lev >= 0; --lev) {
-    const int p0 = p->lev_pptr[lev], p1 = p->lev_pptr[lev + 1];
-    // U-terms beyond the two carried by the solve item: packed two per item, any number of
-    // items per pivot in a round (the kernel accumulates into y_k with LDS atomics)
-    for (int q = p0; q < p1; ++q)
-      for (int u = p->piv_uptr[q] + 2; u < p->piv_uptr[q + 1]; u += 2) {
-        std::array<uint32_t, 3> it{(uint32_t)p->piv_bus[q] | (NONE << 16),
-                                   (uint32_t)p->u_blk[u] | ((uint32_t)p->u_col[u] << 16), NONE | (NONE << 16)};
-        if (u + 1 < p->piv_uptr[q + 1]) it[2] = (uint32_t)p->u_blk[u + 1] | ((uint32_t)p->u_col[u + 1] << 16);
-        citems.push_back(it);
-      }
-    flush_c(citems);
-    c_bounds.push_back((int32_t)(p->lp_c.size() / 192));
-    for (int q = p0; q < p1; ++q) {
-      const int u0 = p->piv_uptr[q], u1 = p->piv_uptr[q + 1];
-      std::array<uint32_t, 3> it{(uint32_t)p->piv_bus[q] | ((uint32_t)p->diag_blk[p->piv_bus[q]] << 16),
-                                 NONE | (NONE << 16), NONE | (NONE << 16)};
-      if (u0 < u1) it[1] = (uint32_t)p->u_blk[u0] | ((uint32_t)p->u_col[u0] << 16);
-      if (u0 + 1 < u1) it[2] = (uint32_t)p->u_blk[u0 + 1] | ((uint32_t)p->u_col[u0 + 1] << 16);
-      citems.push_back(it);
+    for (int q = p->lev_pptr[lev]; q < p->lev_pptr[lev + 1]; ++q) {
+      const int j = p->piv_bus[q];
+      for (auto& kt : col_terms[j])
+        items.push_back({(0x8000u | (uint32_t)kt[0]) | ((uint32_t)kt[1] << 16),
+                         (uint32_t)p->diag_blk[j] | ((uint32_t)j << 16)});
     }
-    flush_c(citems);
-    c_bounds.push_back((int32_t)(p->lp_c.size() / 192));
+    flush_c();
+    c_bounds.push_back((int32_t)(p->lp_c.size() / 128));
   }
-  p->rc = (int32_t)(p->lp_c.size() / 192);
+  p->rc = (int32_t)(p->lp_c.size() / 128);
   // The packed stream pads each part to a multiple of 4 rounds with empty items: the kernel
   // keeps 4 rounds in flight in a rotating register set and loads unconditionally.
   p->rb_pad = (p->rb + 3) & ~3;
@@ -242,8 +237,8 @@ void build_lane_programs(opfx_plan* p) {
     }
   for (int r = 0; r < p->rc; ++r)
     for (int l = 0; l < 64; ++l)
-      for (int w = 0; w < 3; ++w)
-        p->lp_bc[((size_t)(p->rb_pad + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 3 + w];
+      for (int w = 0; w < 2; ++w)
+        p->lp_bc[((size_t)(p->rb_pad + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 2 + w];
   for (int t = 0; t < 2; ++t) {
     const int NW = t == 0 ? 2 : 4;
     std::vector<uint32_t>& out = p->lp_team[t];
@@ -253,13 +248,24 @@ void build_lane_programs(opfx_plan* p) {
         for (int l = 0; l < 64; ++l) { out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(flags); }
       ++K;
     };
+    // real groups (padding ranges dropped)
+    std::vector<std::pair<int, int>> groups;
     for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g) {
       const int r0 = p->lp_groups[g], r1 = p->lp_groups[g + 1];
       const bool pad_group = (r0 >= p->rb && r1 <= p->rb_pad) || r0 >= p->rb_pad + p->rc;
       if (r0 == r1 || pad_group) continue;
+      groups.push_back({r0, r1});
+    }
+    for (size_t g = 0; g < groups.size(); ++g) {
+      const int r0 = groups[g].first, r1 = groups[g].second;
       const int per = (r1 - r0 + NW - 1) / NW;
+      // A group of ONE round runs on wavefront 0 alone; when the next group is such a group too, the same
+      // wavefront carries on and its LDS operations execute in issue order: no workgroup barrier between them
+      // (the dense tail of a meshed grid is a long chain of one-round groups).
+      const bool single = r1 - r0 == 1;
+      const bool next_single = g + 1 < groups.size() && groups[g + 1].second - groups[g + 1].first == 1;
       for (int j = 0; j < per; ++j) {
-        const uint32_t flags = (r0 >= p->rb_pad ? 2u : 0u) | (j == per - 1 ? 1u : 0u);
+        const uint32_t flags = (j == per - 1 && !(single && next_single)) ? 1u : 0u;
         for (int w = 0; w < NW; ++w) {
           const int r = r0 + j * NW + w;
           for (int l = 0; l < 64; ++l) {

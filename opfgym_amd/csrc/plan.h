@@ -51,19 +51,19 @@ struct opfx_plan {
   std::vector<uint32_t> lp_h_row;          // [rh]      bus whose overflow entries this round holds
   std::vector<double> lp_h_y;              // [rh][64][2]
   std::vector<uint32_t> lp_b;              // [rb][64][2]  tb|ik<<16 , kk|kj<<16
-  std::vector<uint32_t> lp_c;              // [rc][64][3]  k|dblk<<16 , blk1|j1<<16 , blk2|j2<<16
+  std::vector<uint32_t> lp_c;              // [rc][64][2]  (0x8000|k)|blk(k,j)<<16 , blk(j,j)|j<<16  (back substitution, same item form as lp_b)
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
-  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  B: w0,w1,-,0   C: w0,w1,w2,0 (pad: empty items)
+  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,-,0 (pad: empty items)
   std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
   // cooperative kernels (2 or 4 wavefronts per instance): the rounds of each group dealt round-robin
   // to the waves and laid out per wave, [round][wave][64][4]; word 3 of an item carries flags:
-  // bit 0 = workgroup barrier after this round (end of a group), bit 1 = back-substitution item.
+  // bit 0 = workgroup barrier after this round (end of a group that another wavefront continues).
   std::vector<uint32_t> lp_team[2];        // [0]: 2 waves, [1]: 4 waves
   int32_t team_rounds[2] = {0, 0};         // rounds per wave (multiples of 4)
   std::vector<int32_t> lp_groups;          // round offsets into lp_bc: rounds of one group are mutually
-                                           // independent (an elimination level / its U pre-items / its solves)
+                                           // independent (an elimination level / the back-substitution terms of a level)
   int32_t nnz_j = 0;
   int32_t max_level_width = 0;
   int32_t n_levels() const { return (int32_t)lev_tptr.size() - 1; }

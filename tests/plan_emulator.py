@@ -145,7 +145,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
     h_row = plan.array('lp_h_row').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
     h_y = plan.darray('lp_h_y').reshape(rh, 64, 2) if rh else np.zeros((0, 64, 2))
     lp_b = plan.array('lp_b').view(np.uint32).reshape(rb, 64, 2)
-    lp_c = plan.array('lp_c').view(np.uint32).reshape(rc, 64, 3)
+    lp_c = plan.array('lp_c').view(np.uint32).reshape(rc, 64, 2)
     fill = plan.array('fill_blk')
     v = case.vm_set * np.exp(1j * case.va_set)
     nblk = info['n_blk']
@@ -229,25 +229,24 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
                 blk[tb] -= d
             for i, d in drhs.items():
                 rhs[i] -= d
-        for r in range(rc):
-            upd = {}
+        for r in range(rc):                       # back substitution: the same item form, column by column
+            drhs = {}
             for lane in range(64):
-                w0, w1, w2 = (int(x) for x in lp_c[r, lane])
-                k = w0 & 0xFFFF
-                if k == NONE:
+                w0, w1 = int(lp_c[r, lane, 0]), int(lp_c[r, lane, 1])
+                tb = w0 & 0xFFFF
+                if tb == NONE:
                     continue
-                d = np.zeros(2)
-                for w in (w1, w2):
-                    if (w & 0xFFFF) != NONE:
-                        d += blk[w & 0xFFFF] @ rhs[w >> 16]
-                dblk = w0 >> 16
-                if dblk != NONE:
-                    upd[k] = ('set', inv2(blk[dblk]) @ (rhs[k] - d))
-                else:
-                    prev = upd.get(k, ('sub', np.zeros(2)))[1]
-                    upd[k] = ('sub', prev + d)
-            for k, (kind, val) in upd.items():
-                rhs[k] = val if kind == 'set' else rhs[k] - val
+                assert tb & 0x8000
+                k = tb & 0x7FFF
+                w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
+                drhs[k] = drhs.get(k, 0) + w @ rhs[w1 >> 16]
+                assert (w1 >> 16) not in drhs          # a source of this round is final
+            for k, d in drhs.items():
+                rhs[k] -= d
+        diag = plan.array('diag_blk')
+        for i in range(nb):                       # x_i = A_ii^-1 y_i (phase D)
+            if bt[i] != REF:
+                rhs[i] = inv2(blk[diag[i]]) @ rhs[i]
         for i in range(nb):
             if bt[i] != REF:
                 v[i] = v[i] * (1.0 + rhs[i, 1]) * np.exp(1j * rhs[i, 0])
