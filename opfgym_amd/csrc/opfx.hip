@@ -483,89 +483,95 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 #define OPFX_STAMP(slot) do { } while (0)
 #endif
 
-#ifdef OPFX_ROUNDPROBE
-// Diagnostic build (-DOPFX_ROUNDPROBE, scripts/probe_round.py): the factor item cut into segments by
-// cycle-counter reads that drain the LDS queue (descriptor wait | LDS reads | FP64 | LDS atomics), summed
-// over workgroup 0, plus a few LDS microbenchmarks at the start of newton2 (sized for the 144-bus grid).
-// Serialising the segments removes the overlap of the product code; the proportions are what it is for.
-__device__ unsigned long long g_probe[16];
-__device__ __forceinline__ unsigned long long clk_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned long long t = __builtin_readcyclecounter();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  return t;
+// All LDS reads of an item — the two factor blocks AND the third operand (the block A_kj or the right-hand
+// side y_k) — are issued before anything is computed, branch-free: the reciprocal of the pivot determinant (a
+// chain of ~15 dependent FP64 operations) then overlaps the return of the third operand instead of being
+// followed by a second LDS round trip.  A two-value block reads its first row twice (clamped second-row
+// addresses) and selects.  With one wavefront busy per instance (the dense tail of a meshed grid) nothing
+// else hides that latency.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
+// descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 template <bool PK>
-__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+__device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a11, double& a12, double& x21, double& x22) {
+  const double* p = L.blk + id;
+  const unsigned idc = (!PK || id < (unsigned)L.nfull) ? id : 0u;
+  a11 = p[0]; a12 = p[L.bs]; x21 = L.blk[L.o2 + idc]; x22 = L.blk[L.o3 + idc];
+}
+// The twelve values an item reads.  Loading (item_load) and using them (item_apply) are separate steps so
+// that the reads of the NEXT round can be in flight while this round computes, whenever the plan marks the two
+// rounds as independent (ITEM_NEXT_INDEPENDENT: same elimination level / same back-substitution group).
+struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22; };
+constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;       // flags in word 3 of a round's items (plan.cpp)
+template <bool PK>
+__device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
-  const unsigned long long t0 = clk_sync();
-  asm volatile("" :: "v"(d.x), "v"(d.y));
-  const unsigned long long t1 = clk_sync();
   const unsigned tb = d.x & 0xFFFF;
-  Blk bi{0,0,0,0}, bk{1,0,0,1}, bj{0,0,0,0};
-  double r1 = 0, r2 = 0;
-  if (tb != NONE) {
-    bi = ld_blk2<PK>(L, d.x >> 16);
-    bk = ld_blk2<PK>(L, d.y & 0xFFFF);
-    if (tb & 0x8000u) { const int k = d.y >> 16; r1 = L.rhs[k]; r2 = L.rq[k]; }
-    else bj = ld_blk2<PK>(L, d.y >> 16);
-  }
-  asm volatile("" : "+v"(bi.a11), "+v"(bi.a12), "+v"(bi.a21), "+v"(bi.a22), "+v"(bk.a11), "+v"(bk.a12), "+v"(bk.a21), "+v"(bk.a22));
-  asm volatile("" : "+v"(bj.a11), "+v"(bj.a12), "+v"(bj.a21), "+v"(bj.a22), "+v"(r1), "+v"(r2));
-  const unsigned long long t2 = clk_sync();
-  const double nrdet = fast_rcp(bk.a12 * bk.a21 - bk.a11 * bk.a22);
-  const double m11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * nrdet;
-  const double m12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * nrdet;
-  const double m21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * nrdet;
-  const double m22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * nrdet;
-  const double u11 = m11 * bj.a11 + m12 * bj.a21, u12 = m11 * bj.a12 + m12 * bj.a22;
-  const double u21 = m21 * bj.a11 + m22 * bj.a21, u22 = m21 * bj.a12 + m22 * bj.a22;
-  const double w1 = m11 * r1 + m12 * r2, w2 = m21 * r1 + m22 * r2;
-  asm volatile("" :: "v"(u11), "v"(u12), "v"(u21), "v"(u22), "v"(w1), "v"(w2));
-  const unsigned long long t3 = clk_sync();
-  if (tb != NONE) {
-    if (tb & 0x8000u) { const int i = tb & 0x7FFF; lds_add(&L.rhs[i], w1); lds_add(&L.rq[i], w2); }
-    else {
-      lds_add(L.blk + blk_c(L, tb, 0), u11); lds_add(L.blk + blk_c(L, tb, 1), u12);
-      lds_add(L.blk + blk_c(L, tb, 2), u21); lds_add(L.blk + blk_c(L, tb, 3), u22);
-    }
-  }
-  const unsigned long long t4 = clk_sync();
-  const unsigned long long t5 = clk_sync();
-  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {
-    atomicAdd(&g_probe[0], t1 - t0); atomicAdd(&g_probe[1], t2 - t1); atomicAdd(&g_probe[2], t3 - t2);
-    atomicAdd(&g_probe[3], t4 - t3); atomicAdd(&g_probe[4], t5 - t4); atomicAdd(&g_probe[5], 1ull);
-  }
+  const bool live = tb != NONE;                     // (an empty item reads block 0 / bus 0 and adds nothing)
+  const unsigned ik = live ? d.x >> 16 : 0u, kk = live ? d.y & 0xFFFF : 0u, kj = live ? d.y >> 16 : 0u;
+  const bool rhs_t = live && (tb & 0x8000u) != 0;
+  ItemRegs r;
+  ld_blk_raw<PK>(L, ik, r.i11, r.i12, r.i21, r.i22);
+  ld_blk_raw<PK>(L, kk, r.k11, r.k12, r.k21, r.k22);
+  // third operand C: A_kj, or the column (y_k ; .) of the right-hand side
+  const unsigned kjb = rhs_t ? 0u : kj;                                  // (any valid block for the unused reads)
+  const unsigned kjc = (!PK || kjb < (unsigned)L.nfull) ? kjb : 0u;
+  const double* c1p = rhs_t ? (L.rhs + kj) : (L.blk + kj);
+  const double* c3p = rhs_t ? (L.rq + kj) : (L.blk + L.o2 + kjc);
+  r.c11 = *c1p; r.c21 = *c3p;
+  r.c12 = L.blk[L.bs + kjb]; r.c22 = L.blk[L.o3 + kjc];
+  return r;
 }
-#else
 template <bool PK>
-__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+__device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const ItemRegs& r) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
   if (tb == NONE) return;
-  const Blk bi = ld_blk2<PK>(L, d.x >> 16);
-  const Blk bk = ld_blk2<PK>(L, d.y & 0xFFFF);
-  // m = -A_ik A_kk^-1 (the sign folded into the reciprocal: the update is an atomic ADD of m A_kj)
+  const unsigned ik = d.x >> 16, kk = d.y & 0xFFFF, kj = d.y >> 16;
+  const bool rhs_t = (tb & 0x8000u) != 0;
+  Blk bi{r.i11, r.i12, r.i21, r.i22}, bk{r.k11, r.k12, r.k21, r.k22};
+  if (PK) {
+    const bool fi = ik < (unsigned)L.nfull, fk = kk < (unsigned)L.nfull;
+    bi.a21 = fi ? r.i21 : -r.i12; bi.a22 = fi ? r.i22 : r.i11;
+    bk.a21 = fk ? r.k21 : -r.k12; bk.a22 = fk ? r.k22 : r.k11;
+  }
+  const bool fj = !PK || rhs_t || kj < (unsigned)L.nfull;
+  const double c11 = r.c11, c12 = r.c12;
+  const double c21 = fj ? r.c21 : -c12, c22 = fj ? r.c22 : c11;
+  // m = -A_ik A_kk^-1 (the sign folded into the reciprocal: the update is an atomic ADD of m C)
   const double nrdet = fast_rcp(bk.a12 * bk.a21 - bk.a11 * bk.a22);
   const double m11 = (bi.a11 * bk.a22 - bi.a12 * bk.a21) * nrdet;
   const double m12 = (bi.a12 * bk.a11 - bi.a11 * bk.a12) * nrdet;
   const double m21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * nrdet;
   const double m22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * nrdet;
-  if (tb & 0x8000u) {
-    const int i = tb & 0x7FFF, k = d.y >> 16;
-    const double r1 = L.rhs[k], r2 = L.rq[k];
-    lds_add(&L.rhs[i], m11 * r1 + m12 * r2);
-    lds_add(&L.rq[i], m21 * r1 + m22 * r2);
-  } else {
-    const Blk bj = ld_blk2<PK>(L, d.y >> 16);
-    lds_add(L.blk + blk_c(L, tb, 0), m11 * bj.a11 + m12 * bj.a21);
-    lds_add(L.blk + blk_c(L, tb, 1), m11 * bj.a12 + m12 * bj.a22);
-    lds_add(L.blk + blk_c(L, tb, 2), m21 * bj.a11 + m22 * bj.a21);
-    lds_add(L.blk + blk_c(L, tb, 3), m21 * bj.a12 + m22 * bj.a22);
+  const unsigned ti = tb & 0x7FFF;
+  double* t1p = rhs_t ? (L.rhs + ti) : (L.blk + tb);
+  double* t3p = rhs_t ? (L.rq + ti) : (L.blk + L.o2 + tb);
+  lds_add(t1p, m11 * c11 + m12 * c21);
+  lds_add(t3p, m21 * c11 + m22 * c21);
+  if (!rhs_t) {
+    lds_add(L.blk + L.bs + tb, m11 * c12 + m12 * c22);
+    lds_add(L.blk + L.o3 + tb, m21 * c12 + m22 * c22);
   }
 }
-
-#endif
+template <bool PK>
+__device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
+  if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
+  const ItemRegs r = item_load<PK>(L, d);
+  item_apply<PK>(L, d, r);
+}
+// One round of a wave team's B/C stream.  (Issuing the NEXT round's reads before this round computes —
+// the plan marks independent rounds, ITEM_NEXT_INDEPENDENT — was tried and is slower: the compiler's wait-count
+// insertion treats loads that are pending across the loop's back edge conservatively and drains the LDS queue,
+// lgkmcnt(0), at the first use, so the early reads only lengthen that wait: config 3 2.27 -> 2.66 ms.)
+template <bool PK>
+__device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
+  const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
+  item_factor<PK>(L, d);
+  if (fl & ITEM_BARRIER) lds_barrier(); else wave_fence();        // (no barrier: the same wavefront carries on)
+}
 
 // Phase D of the lane-programme kernels: after the back-substitution items y_i of bus i holds its
 // right-hand side with every U-term removed; x_i = A_ii^-1 y_i, then V_i <- V_i (1 + d|V|/|V|) e^{j dth}.
@@ -741,58 +747,6 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
-#ifdef OPFX_ROUNDPROBE
-  if (blockIdx.x == 0) {   // calibration of the tick: dependent FMA chain, LDS throughput, LDS dependent chain
-    double x = L.vr[lane & 7] * 1e-9 + 1.0;
-    unsigned long long c0 = clk_sync();
-#pragma unroll 1
-    for (int k = 0; k < 32; ++k) { x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9;
-                                   x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; x = x * 1.0000001 + 1e-9; }
-    asm volatile("" :: "v"(x));
-    unsigned long long c1 = clk_sync();
-    double acc = 0.0;
-    const double* base = L.vr + ((lane * 37) & 127);            // scattered 8-byte reads
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc += base[(k * 5) & 15];
-    asm volatile("" :: "v"(acc));
-    unsigned long long c2 = clk_sync();
-    int idx = lane & 15;
-#pragma unroll 1
-    for (int k = 0; k < 16; ++k) idx = (int)(L.bt[idx & 63] & 15) + (lane & 3);   // dependent LDS byte reads
-    asm volatile("" :: "v"(idx));
-    unsigned long long c3 = clk_sync();
-    // more LDS microbenchmarks (16 independent reads each, summed): b128 linear, b64 random, b128 random, b64 linear stride-1
-    unsigned long long e[5];
-    {
-      double a2 = 0.0;
-      e[0] = clk_sync();
-      { const double2* b2 = reinterpret_cast<const double2*>(L.vr) + lane;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const double2 v = b2[64 * (k & 3) + (k >> 2)]; a2 += v.x + v.y; } }
-      asm volatile("" :: "v"(a2));
-      e[1] = clk_sync();
-      { unsigned h = lane * 2654435761u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { h = h * 1664525u + 1013904223u; a2 += L.vr[(h >> 8) & 1023]; } }
-      asm volatile("" :: "v"(a2));
-      e[2] = clk_sync();
-      { unsigned h = lane * 2654435761u; const double2* b2 = reinterpret_cast<const double2*>(L.vr);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { h = h * 1664525u + 1013904223u; const double2 v = b2[(h >> 8) & 511]; a2 += v.x + v.y; } }
-      asm volatile("" :: "v"(a2));
-      e[3] = clk_sync();
-      {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a2 += L.vr[lane + 64 * k]; }
-      asm volatile("" :: "v"(a2));
-      e[4] = clk_sync();
-      if (a2 == 12345.678) L.vr[1] = a2;
-    }
-    if (lane == 0) { for (int k = 0; k < 4; ++k) atomicAdd(&g_probe[10 + k], e[k + 1] - e[k]); }
-    if (lane == 0) { atomicAdd(&g_probe[6], c1 - c0); atomicAdd(&g_probe[7], c2 - c1); atomicAdd(&g_probe[8], c3 - c2); atomicAdd(&g_probe[9], 1ull); }
-    if (x + acc + idx == 12345.678) L.vr[0] = x;
-  }
-#endif
   OPFX_STAMP_INIT();
   ARound cur = load_around(P, 0, lane);
   // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
@@ -980,36 +934,6 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // ---------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-#ifdef OPFX_ENABLE_STAMPS
-// diagnostic build: wave 0 of workgroup 0 splits its time in the B/C stream into work on items (slots
-// 20 factor / 21 solve) and waiting at the group barriers (22), and counts the barriers (23)
-#define OPFX_TEAM_STAMPS 1
-#endif
-template <bool PK>
-__device__ __forceinline__ void team_step(const DevPlan& P, const Lds& L, const uint4 d) {
-  const unsigned flags = __builtin_amdgcn_readfirstlane(d.w);      // same for every item of a round
-#ifdef OPFX_TEAM_STAMPS
-  const bool rec = P.stamps && blockIdx.x == 0 && threadIdx.x == 0;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-#endif
-  item_factor<PK>(L, d);
-  if (!(flags & 1u)) asm volatile("" ::: "memory");     // (the same wavefront carries on: order by issue)
-#ifdef OPFX_TEAM_STAMPS
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  if (rec) P.stamps[20] += t1 - t0;
-#endif
-  if (flags & 1u) {
-    lds_barrier();
-#ifdef OPFX_TEAM_STAMPS
-    if (rec) { P.stamps[22] += __builtin_readcyclecounter() - t1; P.stamps[23] += 1; }
-#endif
-  }
-}
-
 template <int NW, bool PK>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
                              int* iters_out, double* nrm_out, double* piv_out) {
@@ -1136,10 +1060,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
     for (int k = 0; k < K; k += 4) {
-      team_step<PK>(P, L, q0); q0 = ld_desc(k + 4);
-      team_step<PK>(P, L, q1); q1 = ld_desc(k + 5);
-      team_step<PK>(P, L, q2); q2 = ld_desc(k + 6);
-      team_step<PK>(P, L, q3); q3 = ld_desc(k + 7);
+      team_step<PK>(L, q0); q0 = ld_desc(k + 4);
+      team_step<PK>(L, q1); q1 = ld_desc(k + 5);
+      team_step<PK>(L, q2); q2 = ld_desc(k + 6);
+      team_step<PK>(L, q3); q3 = ld_desc(k + 7);
     }
     OPFX_STAMP(2);
     // ---- phase D ---------------------------------------------------------------------------------
@@ -2254,13 +2178,6 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
 }
 
 extern "C" void opfx_ctx_destroy(opfx_ctx* ctx) { delete ctx; }
-#ifdef OPFX_ROUNDPROBE
-extern "C" int opfx_debug_read_probe(unsigned long long* out) {     // read and clear
-  unsigned long long z[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(z)) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
                           const double* qg_min, const double* qg_max, const int32_t* outage,

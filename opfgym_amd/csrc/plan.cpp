@@ -239,6 +239,12 @@ void build_lane_programs(opfx_plan* p) {
     for (int l = 0; l < 64; ++l)
       for (int w = 0; w < 2; ++w)
         p->lp_bc[((size_t)(p->rb_pad + r) * 64 + l) * 4 + w] = p->lp_c[((size_t)r * 64 + l) * 2 + w];
+  // word 3 of a round's items: bit 0 = workgroup barrier after the round (wave teams only), bit 1 = the
+  // next round of this wavefront belongs to the same group, i.e. does not depend on this one (the kernel
+  // then issues its LDS reads before this round computes)
+  for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
+    for (int r = p->lp_groups[g]; r + 1 < p->lp_groups[g + 1]; ++r)
+      for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = 2u;
   for (int t = 0; t < 2; ++t) {
     const int NW = t == 0 ? 2 : 4;
     std::vector<uint32_t>& out = p->lp_team[t];
@@ -265,7 +271,7 @@ void build_lane_programs(opfx_plan* p) {
       const bool single = r1 - r0 == 1;
       const bool next_single = g + 1 < groups.size() && groups[g + 1].second - groups[g + 1].first == 1;
       for (int j = 0; j < per; ++j) {
-        const uint32_t flags = (j == per - 1 && !(single && next_single)) ? 1u : 0u;
+        const uint32_t flags = ((j == per - 1 && !(single && next_single)) ? 1u : 0u) | (j < per - 1 ? 2u : 0u);
         for (int w = 0; w < NW; ++w) {
           const int r = r0 + j * NW + w;
           for (int l = 0; l < 64; ++l) {
