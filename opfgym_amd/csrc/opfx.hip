@@ -962,7 +962,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     // ---- phase A ------------------------------------------------------------------
     for (int f = tid; f < P.nfill; f += NT) st_blk2<PK>(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
     for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
-    __syncthreads();
+    lds_barrier();
     for (int h = wave; h < P.rh; h += NW) {
       const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
       const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
@@ -986,7 +986,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         lds_add(&L.rq[i], ci);
       }
     }
-    __syncthreads();
+    lds_barrier();
     double my = 0.0;
     for (int r = wave; r < P.ra; r += NW) {
       const ARound a = a_next;
@@ -1039,16 +1039,16 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       }
     }
     if (n_mod > 0) {
-      __syncthreads();
+      lds_barrier();
       if (wave == 0) { dead_rows_patch<PK>(P, L, lane); wave_fence(); mods_apply(L, lane, n_mod); }
-      __syncthreads();
+      lds_barrier();
       my = 0.0;
       for (int i = tid; i < nb; i += NT)
         if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
     }
     my = wave_max_dpp(my);
     if (lane == 0) xw[wave] = my;
-    __syncthreads();
+    lds_barrier();
     nrm = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
@@ -1073,22 +1073,30 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       solve_pivot(L, i, dth, dvm, piv);
       const double sc = 1.0 + dvm;
       double sn, cs;
-      sincos(dth, &sn, &cs);
+      if (fabs(dth) <= 0.25) {                         // (as in newton2: Taylor series, truncation error < 1e-21)
+        const double z = dth * dth;
+        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
+             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
+             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
+      } else {
+        sincos(dth, &sn, &cs);
+      }
       const double vr = L.vr[i], vi = L.vi[i];
       L.vr[i] = (vr * cs - vi * sn) * sc;
       L.vi[i] = (vr * sn + vi * cs) * sc;
     }
-    __syncthreads();
+    lds_barrier();
     OPFX_STAMP(4);
   }
-  __syncthreads();          // xw (aliases the constraint accumulators) is free again
+  lds_barrier();          // xw (aliases the constraint accumulators) is free again
   piv = wave_min_dpp(piv);
   if (lane == 0) xw[wave] = piv;
-  __syncthreads();
+  lds_barrier();
   piv = xw[0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) piv = nn_min(piv, xw[w]);
-  __syncthreads();
+  lds_barrier();
   *iters_out = it;
   *nrm_out = nrm;
   *piv_out = piv;
@@ -1234,10 +1242,12 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
 
 // after convergence: result bank in LDS region R (reuses the LU block storage)
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
+// `lane` / `stride`: the calling thread's index and the number of threads that share the work (a wavefront,
+// or the whole wave team)
 template <int V2>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
-                                bool want_angle) {
+                                bool want_angle, int stride = WAVE) {
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
   double* r_va = R + nb;
@@ -1246,7 +1256,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   double* r_qe = r_pe + nref;
   double* r_qg = r_qe + nref;
   const double base = physical ? P.base_mva : 1.0;
-  for (int i = lane; i < nb; i += WAVE) {
+  for (int i = lane; i < nb; i += stride) {
     r_vm[i] = sqrt(L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]);
     if (want_angle) {
       const double ang = atan2(L.vi[i], L.vr[i]);
@@ -1290,7 +1300,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     r_qg[i] = qgen;
   }
-  for (int k = lane; k < nbr; k += WAVE) {
+  for (int k = lane; k < nbr; k += stride) {
     double ld = 0.0;
     double y[8];
 #pragma unroll
@@ -1704,8 +1714,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
         continue;
       }
       double* R = L.blk;
+      // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
+      compute_results<V2>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle, NT);
+      blk_sync<NW>();
       if (wave == 0) {
-      compute_results<V2>(P, L, lane, out_br, n_mod, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle);
       for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
         const double sc = as_global(E.xres_scale)[k];
         const double pv_ = src_val(xr, L.sp, as_global(E.xres_p)[k]) * sc;
