@@ -336,7 +336,9 @@ typedef struct opfx_step_io {
  * current x only (no action, no power flow; multi_stage.py:56); 4 = full step with the action
  * applied the way reset applies its initial action (opf_env.py:207-216: absolute set-points
  * even when the environment steps incrementally, clamping only without autoscaling).
- * Modes 2 and 4 are the two forms of reset. */
+ * Modes 2 and 4 are the two forms of reset; 5 = as 4 (absolute set-points) but a complete evaluation,
+ * contingencies included: what `estimate_reward_distribution` does per sample (reward.py:186-193:
+ * `_apply_actions(action)` without a step size, power flow, objective, `calculate_violations`). */
 int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
               const opfx_solve_opts* opts, int32_t mode, void* stream);
 

@@ -1155,15 +1155,31 @@ class BatchedOpfEnv:
         off, n = self.store.ranges[(unit, col)]
         return self.x[:, off:off + n]
 
-    def sample_objective_penalty(self, num_samples):
-        """One batched reset + random action + power flow (reward.py:181-196)."""
+    def sample_objective_penalty(self, num_samples, draws=None):
+        """One batched reset + random action + power flow (reward.py:181-196): Σobjective and Σpenalty per
+        sample (NaN where the power flow failed).  `draws` replays explicit inputs instead of drawing them:
+        dict(step=[n], uniform=[n, n_uniform] | None, noise=[n, n_noise] raw U[0,1) draws | None,
+        action=[n, n_actions])."""
         old = (self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev, self._center_action)
         self._alloc(int(num_samples))
+        t = self.torch
         try:
-            self.reset()
+            if draws is None:
+                self.reset()
+                action = t.rand(self.B, self.n_actions, generator=self._gen, device=self.device, dtype=t.float64)
+            else:
+                opts = {'step': np.asarray(draws['step'])}
+                if draws.get('uniform') is not None and self.n_uniform:
+                    opts['uniform'] = draws['uniform']
+                if draws.get('noise') is not None and self.n_noise and np.size(draws['noise']):
+                    nf = self.noise_factor
+                    raw = np.asarray(draws['noise'], dtype=float)
+                    opts['noise'] = raw if self.noise_distribution == 'normal' else raw * nf * 2 + (1 - nf)   # opf_env.py:354-355
+                self.reset(options=opts)
+                action = self._as_action(draws['action'])
             self.step_count += 1
-            self._launch_step(self.torch.rand(self.B, self.n_actions, generator=self._gen, device=self.device,
-                                              dtype=self.torch.float64), mode=0)
+            # absolute set-points as `_apply_actions(action)` without a step size, contingencies included
+            self._launch_step(action, mode=5)
             conv = self.buf['converged'].cpu().numpy()
             obj = self.buf['objective'].cpu().numpy().copy()
             pen = self.buf['penalties'][:, :self.n_constraints].sum(dim=1).cpu().numpy().copy()

@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       const double* act_row = apply ? io.action + b * E.na : xr;
       // reset applies its initial action as ABSOLUTE set-points (opf_env.py:207 passes no step size),
       // and clamps only without autoscaling (:464)
-      const bool as_reset = io.mode == 2 || io.mode == 4;
+      const bool as_reset = io.mode == 2 || io.mode == 4 || io.mode == 5;
       const double diff_step = as_reset ? 0.0 : E.diff_step;
       const bool clamp = as_reset ? (E.clamp_enabled & 2) != 0 : (E.clamp_enabled & 1) != 0;
       for (int k0 = 0; k0 < E.na; k0 += 2 * WAVE) {
@@ -2471,8 +2471,8 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
 
 extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                          int32_t mode, void* stream) {
-  if (env && io && B == 0 && mode >= 0 && mode <= 4) return OPFX_OK;       // empty batch (buffers may be null)
-  if (!env || !io || !io->x || B < 0 || mode < 0 || mode > 4 || ((mode == 0 || mode == 2 || mode == 4) && env->de.na > 0 && !io->action)) {
+  if (env && io && B == 0 && mode >= 0 && mode <= 5) return OPFX_OK;       // empty batch (buffers may be null)
+  if (!env || !io || !io->x || B < 0 || mode < 0 || mode > 5 || ((mode == 0 || mode == 2 || mode == 4 || mode == 5) && env->de.na > 0 && !io->action)) {
     opfx_set_error("opfx_step: bad argument");
     return OPFX_ERR_INVALID;
   }

@@ -42,10 +42,11 @@ def select_reward_scaler(reward_scaling: str):
         raise NotImplementedError('This reward scaling does not exist!')
 
 
-def estimate_reward_distribution(env, num_samples: int = 3000) -> dict:
+def estimate_reward_distribution(env, num_samples: int = 3000, draws=None) -> dict:
     """reward.py:181-216 as one batch: random states, random actions, one
-    power flow each; statistics of Σobjective and Σpenalty over converged rows."""
-    objectives, penalties = env.sample_objective_penalty(num_samples)
+    power flow each; statistics of Σobjective and Σpenalty over converged rows.
+    `draws`: explicit inputs to replay (see BatchedOpfEnv.sample_objective_penalty)."""
+    objectives, penalties = env.sample_objective_penalty(num_samples, draws)
     objectives = objectives[~np.isnan(objectives)]
     penalties = penalties[~np.isnan(penalties)]
     return {

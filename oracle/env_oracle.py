@@ -489,3 +489,30 @@ class EnvOracle:
                     trafo_loading=self.net.res_trafo.loading_percent.to_numpy(float),
                     p_ext=self.net.res_ext_grid.p_mw.to_numpy(float),
                     q_ext=self.net.res_ext_grid.q_mvar.to_numpy(float))
+
+
+# ---------------------------------------------------------------------------
+# E12: estimate_reward_distribution  (reward.py:181-216)
+# ---------------------------------------------------------------------------
+def estimate_reward_distribution(orc: EnvOracle, steps, uniform, noise, actions) -> dict:
+    """The twelve statistics of reward.py:198-216 over explicit samples: per sample a reset at `steps[k]`
+    with the given draws (:186), the action applied as absolute set-points (:188, `_apply_actions` without a
+    step size), one power flow (:189), Σ(-costs) (:190) and Σ penalties incl. the N-1 loop (:191); rows
+    whose power flow failed are dropped (:197-198)."""
+    objectives, penalties = [], []
+    saved = orc.diff_step, orc.diff_objective
+    orc.diff_step, orc.diff_objective = None, False
+    try:
+        for k in range(len(steps)):
+            orc.reset(int(steps[k]), uniform[k] if uniform is not None else (), noise[k] if noise is not None else None)
+            out = orc.step(actions[k])
+            objectives.append(out['objective'] if out['converged'] else np.nan)
+            penalties.append(float(np.sum(out['penalties'])) if out['converged'] else np.nan)
+    finally:
+        orc.diff_step, orc.diff_objective = saved
+    o, p = np.array(objectives), np.array(penalties)
+    o, p = o[~np.isnan(o)], p[~np.isnan(p)]
+    return {'min_objective': o.min(), 'max_objective': o.max(), 'min_penalty': p.min(), 'max_penalty': p.max(),
+            'mean_objective': o.mean(), 'mean_penalty': p.mean(), 'std_objective': np.std(o), 'std_penalty': np.std(p),
+            'median_objective': np.median(o), 'median_penalty': np.median(p),
+            'mean_abs_objective': np.abs(o).mean(), 'mean_abs_penalty': np.abs(p).mean()}

@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc_example  # noqa: E402
 import opfgym.security_constrained as ref_sc  # noqa: E402
-from scenarios import EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
+from scenarios import E12_SCENARIOS, EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
 import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
@@ -243,7 +243,40 @@ def run(name):
           f'valid {out["valids"].all(axis=1)}')
 
 
+def run_e12(name):
+    """E12: the reference's own `estimate_reward_distribution` (reward.py:181-216) on a reference environment,
+    with every random input it consumes recorded — the step and draws of each reset, each sampled action —
+    next to the twelve statistics it returns."""
+    import opfgym.reward as ref_reward
+    scenario, n = E12_SCENARIOS[name]
+    cls, kwargs, _, seed = SCENARIOS[scenario]
+    env = REF[cls](seed=seed, **kwargs)
+    rec = {k: [] for k in ('step', 'uniform', 'noise', 'action')}
+    ref_reset, ref_sample = env.reset, env.action_space.sample
+
+    def reset(*a, **k):
+        env.np_random.log.clear() if hasattr(env, 'np_random') else None
+        out = ref_reset(*a, **k)
+        log = env.np_random.log
+        rec['step'].append(int(env.current_simbench_step))
+        rec['uniform'].append(np.concatenate([u.ravel() for kind, u in log if kind == 'uniform'] or [np.zeros(0)]))
+        rec['noise'].append(np.concatenate([u.ravel() for kind, u in log if kind == 'random'] or [np.zeros(0)]))
+        return out
+
+    def sample():
+        a = ref_sample()
+        rec['action'].append(np.array(a, copy=True))
+        return a
+    env.reset, env.action_space.sample = reset, sample
+    stats = ref_reward.estimate_reward_distribution(env, num_samples=n)
+    out = {k: np.stack(v) for k, v in rec.items()}
+    for k, v in stats.items():
+        out['stat__' + k] = np.array(float(v))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: {n} samples, ' + ', '.join(f'{k}={float(v):.4g}' for k, v in stats.items()))
+
+
 if __name__ == '__main__':
-    names = sys.argv[1:] or list(SCENARIOS)
+    names = sys.argv[1:] or (list(SCENARIOS) + list(E12_SCENARIOS))
     for nm in names:
-        run(nm)
+        run_e12(nm) if nm in E12_SCENARIOS else run(nm)

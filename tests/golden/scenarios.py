@@ -97,6 +97,10 @@ SCENARIOS.update({
                                                                  n_minus_one_lines='all'), 2, 32),
 })
 
+# E12 (`estimate_reward_distribution`, reward.py:181-216): fixture name -> (scenario whose environment is sampled, samples)
+E12_SCENARIOS = {'e12_vc_mv_small': ('vc_mv_small', 64), 'e12_sc_hv_small': ('sc_hv_small', 24),
+                 'e12_vc_noisy': ('vc_noisy', 32)}
+
 # scenarios whose episodes take several steps: the generator records EPISODE_STEPS steps per reset
 EPISODE_STEPS = {'vc_multistep_diff': 3, 'multistage_lv': 4}
 # explicit start steps (else drawn from the training steps): 670 runs into the first validation week at 672

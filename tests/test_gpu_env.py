@@ -261,6 +261,33 @@ def test_time_observation_and_stochastic_wrapper():
     assert (_np(noisy) >= lo - 1e-12).all() and (_np(noisy) <= hi + 1e-12).all()
 
 
+@pytest.mark.parametrize('name', ['e12_vc_mv_small', 'e12_sc_hv_small', 'e12_vc_noisy'])
+def test_reward_distribution_statistics_match_the_reference(name):
+    """E12 (reward.py:181-216): the batched estimate — ONE reset + one fused launch for all samples — on the
+    recorded resets and actions of the reference's own `estimate_reward_distribution` run gives its twelve
+    statistics (min / max / mean / std / median / mean-abs of the summed objective and penalty)."""
+    from opfgym_amd import reward as pr
+    from scenarios import E12_SCENARIOS
+    g = golden(name)
+    scenario, n = E12_SCENARIOS[name]
+    env = product_env(scenario, batch_size=1)
+    draws_ = dict(step=g['step'], uniform=g['uniform'] if g['uniform'].shape[1] else None,
+                  noise=g['noise'] if g['noise'].shape[1] else None, action=g['action'])
+    stats = pr.estimate_reward_distribution(env, n, draws=draws_)
+    assert set(stats) == {k[6:] for k in g if k.startswith('stat__')}
+    for k, v in stats.items():
+        assert np.isclose(v, float(g['stat__' + k]), rtol=1e-9, atol=1e-9), (k, v, float(g['stat__' + k]))
+    # and a reward scaling derived from it equals the reference's formula on the reference's statistics
+    ref = {k[6:]: np.float64(g[k]) for k in g if k.startswith('stat__')}
+    for scaling in ('minmax11', 'minmax01', 'normalization'):
+        if ref['std_penalty'] == 0:            # (all samples valid: the reference divides by zero here too)
+            continue
+        want = pr.select_reward_scaler(scaling)(**ref)
+        got = pr.select_reward_scaler(scaling)(**stats)
+        for k in want:
+            assert np.isclose(got[k], want[k], rtol=1e-8, atol=1e-9, equal_nan=True), (scaling, k)
+
+
 def test_reward_scaling_from_batched_estimate():
     """reward_scaling without given statistics triggers estimate_reward_distribution
     (reward.py:32-36, 181-216): here one batched reset+step of `num_samples` instances."""

@@ -218,6 +218,39 @@ def test_random_switched_nets_match_the_oracle(seed):
             assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=tol, equal_nan=True), (tbl, col, a, b)
 
 
+def test_min_pivot_diagnoses_a_near_singular_jacobian():
+    """Pivot monitoring (SURVEY §7 hard part 2): `min_pivot` is the smallest relative 2x2 pivot of the block
+    LU over all iterations.  On the two-bus system the only pivot IS the Jacobian, which becomes singular at
+    the nose of the PV curve: the indicator falls monotonically as the load approaches it, is tiny for the
+    last loads that still converge, and a load beyond the nose fails with a small pivot on record — a
+    numerical breakdown would look the same, so "not converged" is no longer silent about its cause."""
+    import torch
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    case = net_to_case(grids.two_bus())
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    load = np.linspace(0.5, 40.0, 160)                        # MW at cos(phi) ~ 0.96, far beyond the nose
+    p = np.zeros((len(load), 2)); q = np.zeros((len(load), 2))
+    p[:, 1], q[:, 1] = -load / case.base_mva, -0.3 * load / case.base_mva
+    out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
+    conv = out['converged'].astype(bool)
+    assert conv[0] and not conv[-1] and (np.diff(conv.astype(int)) <= 0).all()      # converges up to the nose, not beyond
+    piv = out['min_pivot']
+    assert np.isfinite(piv).all() and (piv > 0).all() and (piv <= 1.0).all()
+    last = np.flatnonzero(conv)[-1]
+    assert (np.diff(piv[:last + 1]) < 1e-6).all()              # closer to the nose = worse conditioned (1.0 plateau at light load)
+    assert piv[0] > 0.99 and piv[last] < 0.3
+    assert piv[~conv].min() < 0.5 * piv[last]                  # the failed rows carry the evidence
+    # a well-conditioned grid stays far from zero
+    net, _ = grids.get_grid('1-MV-urban--0-sw')
+    c2 = net_to_case(net)
+    ctx2 = capi.Context(capi.Plan(c2), 0)
+    p2, q2 = random_injections(net, c2, 64, 1)
+    o2 = capi.solve(ctx2, torch.tensor(p2, device=dev), torch.tensor(q2, device=dev))
+    assert bool(o2['converged'].all()) and float(o2['min_pivot'].min()) > 0.3
+
+
 def test_outage_axis():
     """N-1 axis: one branch out of service per instance (meshed HV grid)."""
     import torch

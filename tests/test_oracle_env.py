@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from env_cases import EPISODE_STEPS, SINGLE_STEP, draws, golden, noise_factors, oracle_env, product_env
+from scenarios import E12_SCENARIOS
 
 TAB_TOL = 1e-12
 
@@ -88,3 +89,19 @@ def test_observation_space_matches_reference(name):
     assert np.allclose(env.observation_space.low, g['obs_low'], rtol=0, atol=1e-12)
     assert np.allclose(env.observation_space.high, g['obs_high'], rtol=0, atol=1e-12)
     assert env.action_space.shape == (int(g['n_act']),)
+
+
+@pytest.mark.parametrize('name', list(E12_SCENARIOS))
+def test_reward_distribution_statistics_match_the_reference(name):
+    """E12: the twelve statistics the reference's own `estimate_reward_distribution` returned
+    (tests/golden/make_golden.py run_e12) from the recorded resets and actions."""
+    from oracle import env_oracle
+    g = golden(name)
+    scenario = E12_SCENARIOS[name][0]
+    orc = oracle_env(scenario)
+    noise = np.stack([noise_factors(scenario, g['noise'][k]) for k in range(len(g['step']))]) \
+        if g['noise'].shape[1] and noise_factors(scenario, g['noise'][0]) is not None else None
+    stats = env_oracle.estimate_reward_distribution(orc, g['step'], g['uniform'] if g['uniform'].shape[1] else None,
+                                                    noise, g['action'])
+    for k, v in stats.items():
+        assert np.isclose(v, float(g['stat__' + k]), rtol=1e-9, atol=1e-9), k
