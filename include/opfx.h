@@ -369,10 +369,12 @@ typedef struct opfx_profile_desc {
  *   OPFX_OP_NORMAL      x[dst] = c0 + c1*z,  z = normal[b, a+j]   (opf_env.py:311-312)
  *   OPFX_OP_CLIP        x[dst] = min(max(x[a], c0), c1)           (opf_env.py:313-314)
  *   OPFX_OP_DIV         x[dst] = x[a] / c0                        (load_shedding.py:137)
+ *   OPFX_OP_NORMINV     x[dst] = c0 + c1*Phi^-1(x[a])   (truncated normal by inverse CDF, opf_env.py:306-309:
+ *                       x[a] holds a probability drawn uniformly between Phi(lower) and Phi(upper))
  */
 enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
        OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6,
-       OPFX_OP_DIV = 7 };
+       OPFX_OP_DIV = 7, OPFX_OP_NORMINV = 8 };
 typedef struct opfx_reset_desc {
   int32_t n_tables;
   const opfx_profile_desc* tables;

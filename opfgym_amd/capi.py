@@ -21,7 +21,7 @@ PQ, PV, REF = 1, 2, 3
 SRC_X, SRC_RESULT = 0, 1
 COST_UNIT, COST_EXT_GRID, COST_GEN = 0, 1, 2
 REWARD_SUMMATION, REWARD_REPLACEMENT, REWARD_PARAMETERIZED, REWARD_ONLY_OBJECTIVE = 0, 1, 2, 3
-OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, OP_DIV = 0, 1, 2, 3, 4, 5, 6, 7
+OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, OP_DIV, OP_NORMINV = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',

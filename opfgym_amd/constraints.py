@@ -5,8 +5,9 @@ constructor parameters and default discovery (`create_default_constraints`,
 constraints.py:195-226).  The numbers are evaluated on the GPU inside
 `opfx_step` (csrc/opfx.hip, "constraints" section); these objects only carry
 the parameters and say which result column / boundary columns they bind.
-Arbitrary Python `get_values` / `get_boundaries` callables (constraints.py:
-44-45) cannot run inside a kernel and are rejected.
+Arbitrary Python `get_values` callables (constraints.py:44-45) cannot run inside
+a kernel: such a constraint is evaluated on the host after the launch
+(opfgym_amd/host_fallback.py, one call per instance — the documented fallback).
 """
 from __future__ import annotations
 
@@ -32,12 +33,11 @@ class Constraint:
                  only_worst_case_violations: bool = False, autoscale_violation=True,
                  scale_bounded_values: bool = False, penalty_factor: float = 1.0,
                  penalty_power: float = 1.0, violation_count_penalty: float = 0.0):
-        if get_values is not None and not isinstance(get_values, ApparentPower):
-            raise NotImplementedError(
-                'Python value callables cannot be evaluated by the fused GPU evaluator; '
-                'use the table/column form of Constraint or opfgym_amd.constraints.ApparentPower')
-        # constraints.py:62-65; a boundary callable is evaluated ONCE, when the environment is compiled
-        # (boundaries that change per reset belong into min_/max_ table columns)
+        # constraints.py:62-65.  An `ApparentPower` value object runs in the kernel; any other Python value
+        # callable makes this a HOST constraint (opfgym_amd/host_fallback.py: evaluated per instance after
+        # the launch).  A boundary callable of a device constraint is evaluated ONCE, when the environment is
+        # compiled (boundaries that change per reset belong into min_/max_ table columns); of a host
+        # constraint, per call.
         self.get_values, self.get_boundaries_fn = get_values, get_boundaries
         self.unit_type = unit_type
         self.values_column = 's_mva' if isinstance(get_values, ApparentPower) else values_column

@@ -1960,6 +1960,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
         else if (code == OPFX_OP_UNIFORM) { const double u = io.uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
         else if (code == OPFX_OP_NORMAL) v = c0[j] + c1[j] * io.normal[b * R.n_normal + a + j];
         else if (code == OPFX_OP_CLIP) v = fmin(fmax(row[a + j], c0[j]), c1[j]);
+        else if (code == OPFX_OP_NORMINV) v = c0[j] + c1[j] * normcdfinv(row[a + j]);
         else v = row[a + j] / c0[j];
         row[dst + j] = v;
       }

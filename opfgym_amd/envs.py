@@ -384,8 +384,8 @@ class MixedContinuousDiscrete(BatchedOpfEnv):
                     ('load', 'p_mw', net.load.index), ('load', 'q_mvar', net.load.index)]
         act_keys = [('sgen', 'q_mvar', net.sgen.index), ('trafo', 'tap_pos', net.trafo.index)]   # :40-41
         kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}
-        super().__init__(net, act_keys, obs_keys, profiles=profiles,
-                         objective_function=QuadraticDeviation('bus', 'vm_pu', 1.0), *args, **kwargs)   # :17-19,44
+        objective = kwargs.pop('objective_function', None) or QuadraticDeviation('bus', 'vm_pu', 1.0)   # :17-19,44
+        super().__init__(net, act_keys, obs_keys, profiles=profiles, objective_function=objective, *args, **kwargs)
 
     def _define_opf(self, simbench_network_name, *args, **kwargs):
         net, profiles = build_simbench_net(simbench_network_name, *args, **kwargs)
@@ -514,7 +514,9 @@ class AddCustomConstraint(BatchedOpfEnv):
     here it goes to `custom_constraints`, as the example intends.)"""
 
     def __init__(self, simbench_network_name='1-LV-urban6--0-sw', cos_phi=0.95, constraint_kwargs=None,
-                 *args, **kwargs):
+                 custom_constraint=None, *args, **kwargs):
+        """`custom_constraint`: replaces the example's apparent-power constraint object (e.g. by one with a
+        Python value callable, which then runs through the host fallback)."""
         from . import constraints as cons
         self.cos_phi = cos_phi
         net, profiles = self._define_opf(simbench_network_name, *args, **kwargs)
@@ -522,7 +524,7 @@ class AddCustomConstraint(BatchedOpfEnv):
         act_keys = [('sgen', 'q_mvar', net.sgen.index)]                                         # :32
         constraint_kwargs = constraint_kwargs or {}
         constraints_list = cons.create_default_constraints(net, constraint_kwargs)               # :35-37
-        constraints_list.append(cons.Constraint(                                                # :40-45
+        constraints_list.append(custom_constraint or cons.Constraint(                           # :40-45
             'sgen', 's_mva', get_values=cons.ApparentPower('sgen'),
             get_boundaries=lambda net_: {'max': net_.sgen.max_max_p_mw / 0.95}, **constraint_kwargs))
         kwargs = {k: v for k, v in kwargs.items() if k not in ('net', 'profiles', 'grid_seed')}

@@ -1,0 +1,163 @@
+"""Host fallback for arbitrary Python callables in the problem definition.
+
+The reference lets a user plug any Python function into three seams: `objective_function(net) -> array`
+(opf_env.py:52,80-84), a `Constraint` with `get_values(net)` / `get_boundaries(net)` callables
+(constraints.py:44-45,62-65), or a whole object with `get_violation_metrics(net)` (constraints.py:70).
+Such code cannot run inside the fused step kernel.  The batched environment then still does everything else
+on the GPU — actions, power flow, result tables, the built-in constraints and cost tables, the observation —
+and this module finishes the step on the HOST: per converged instance it materialises a net view (the
+instance's table columns and its `res_*` tables), calls the user's callables exactly as the reference would,
+and recomputes reward / cost / info with the reward function's host formulas (reward.py:61-98).
+
+Cost: O(B) Python calls and DataFrame writes per step (milliseconds per instance) — a compatibility path,
+not a fast one; objects that describe themselves (`opfgym_amd.objectives`, `constraints.ApparentPower`)
+stay on the device.  Not available together with N-1 contingencies (their per-contingency result tables
+never leave the kernel).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import pandas as pd
+
+
+class HostConstraint:
+    """A constraint evaluated on the host: either the product's `Constraint` carrying Python callables,
+    or any object with the reference's `get_violation_metrics(net) -> {'valid','violation','penalty'}`."""
+
+    def __init__(self, con):
+        self.con = con
+
+    def metrics(self, net):
+        if hasattr(self.con, 'get_violation_metrics'):
+            m = self.con.get_violation_metrics(net)
+            return bool(m['valid']), float(m['violation']), float(m['penalty'])
+        c = self.con                                          # constraints.py:70-128 on the host
+        values = np.asarray(c.get_values(net), dtype=float)
+        lo, hi = c.boundaries(net)
+        viol, n_viol = 0.0, 0
+        for bound, bad in ((lo, values < lo), (hi, values > hi)):
+            bad = bad & ~np.isnan(bound)
+            n_viol += int(bad.sum())
+            if bad.any():
+                d = np.abs(values - bound)[bad]
+                viol += float(d.max() if c.only_worst_case_violations else d.sum())
+        a = c.autoscale_factor(net)
+        if a:
+            viol *= a
+        pen = -(viol ** c.penalty_power * c.penalty_factor + n_viol * c.violation_count_penalty)
+        return n_viol == 0, viol, pen
+
+
+def is_host_constraint(con) -> bool:
+    from . import constraints as pc
+    if isinstance(con, pc.Constraint):
+        return con.get_values is not None and not isinstance(con.get_values, pc.ApparentPower)
+    return hasattr(con, 'get_violation_metrics')
+
+
+class HostFinisher:
+    """Built once per environment; `finish()` runs after every fused launch."""
+
+    def __init__(self, env, objective_function, host_constraints, order):
+        """`order`: for every constraint of the environment, ('dev', k) or ('host', k) — the position of its
+        columns in the info arrays follows the user's constraint list."""
+        self.env, self.objective_function = env, objective_function
+        self.host_constraints, self.order = host_constraints, order
+        self.net = copy.deepcopy(env.net)
+        c = env.case
+        net = self.net
+        self.bus_idx = env._result_index('bus', 'vm_pu', net.bus.index)
+        self.line_idx = env._result_index('line', 'loading_percent', net.line.index) if len(net.line) else np.zeros(0, int)
+        self.trafo_idx = env._result_index('trafo', 'loading_percent', net.trafo.index) if len(net.trafo) else np.zeros(0, int)
+        self.egp_idx = env._result_index('ext_grid', 'p_mw', net.ext_grid.index)
+        self.egq_idx = env._result_index('ext_grid', 'q_mvar', net.ext_grid.index)
+        nb, nbr, nref = c.nb, c.nbr, int((c.bus_type == 3).sum())
+        self.qgen_off = 2 * nb + nbr + 2 * nref
+        self.gen_bus = np.array([c.bus_lookup.get(int(b), -1) for b in net.gen.bus], dtype=int) if len(net.gen) else np.zeros(0, int)
+
+    def _gather(self, res, idx, off=0):
+        out = np.full(len(idx), np.nan)
+        ok = idx >= 0
+        out[ok] = res[idx[ok] + off]
+        return out
+
+    def net_view(self, x_row, res_row):
+        """The reference's net of ONE instance after its power flow: table columns from the column store,
+        `res_*` from the kernel's result bank."""
+        env, net = self.env, self.net
+        for (tbl, col), (off, n) in env.store.ranges.items():
+            if n:
+                net[tbl][col] = x_row[off:off + n]
+        nb = env.case.nb
+        net['res_bus'] = pd.DataFrame({'vm_pu': self._gather(res_row, self.bus_idx),
+                                       'va_degree': self._gather(res_row, self.bus_idx, nb)}, index=net.bus.index)
+        net['res_line'] = pd.DataFrame({'loading_percent': self._gather(res_row, self.line_idx)}, index=net.line.index)
+        net['res_trafo'] = pd.DataFrame({'loading_percent': self._gather(res_row, self.trafo_idx)}, index=net.trafo.index)
+        net['res_ext_grid'] = pd.DataFrame({'p_mw': self._gather(res_row, self.egp_idx),
+                                            'q_mvar': self._gather(res_row, self.egq_idx)}, index=net.ext_grid.index)
+        for tbl in ('load', 'sgen', 'storage'):
+            df = net[tbl]
+            sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns and len(df) else 1.0
+            net['res_' + tbl] = pd.DataFrame({'p_mw': df['p_mw'].to_numpy(float) * sc if len(df) else [],
+                                              'q_mvar': df['q_mvar'].to_numpy(float) * sc if len(df) else []}, index=df.index)
+        gen = net.gen
+        if len(gen):
+            sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns else 1.0
+            q = np.where(self.gen_bus >= 0, res_row[self.qgen_off + np.maximum(self.gen_bus, 0)], np.nan)
+            vm = np.where(self.gen_bus >= 0, res_row[np.maximum(self.gen_bus, 0)], np.nan)
+            net['res_gen'] = pd.DataFrame({'p_mw': gen['p_mw'].to_numpy(float) * sc, 'q_mvar': q, 'vm_pu': vm}, index=gen.index)
+        return net
+
+    def finish(self, mode, initial_obj=None):
+        """Overwrites objective / reward / cost and assembles valids / violations / penalties [B, nc] in the
+        user's constraint order.  Returns the dict of final info tensors."""
+        env = self.env
+        t = env.torch
+        b = env.buf
+        B = env.B
+        x = env.x.cpu().numpy()
+        res = b['results'].cpu().numpy()
+        conv = b['converged'].cpu().numpy().astype(bool)
+        n_dev = env.n_device_constraints
+        dv = b['valids'].cpu().numpy()[:, :max(1, n_dev)].astype(bool)
+        dvi = b['violations'].cpu().numpy()[:, :max(1, n_dev)]
+        dpe = b['penalties'].cpu().numpy()[:, :max(1, n_dev)]
+        nc = len(self.order)
+        valids = np.zeros((B, max(1, nc)), dtype=bool)
+        viol = np.ones((B, max(1, nc)))
+        pen = np.ones((B, max(1, nc)))
+        objective = b['objective'].cpu().numpy().copy()
+        corr = b['mean_correction'].cpu().numpy()
+        rf = env.reward_function
+        reward = np.full(B, np.nan)
+        cost = np.full(B, np.nan)
+        init = None if initial_obj is None else initial_obj.cpu().numpy()
+        for k in range(B):
+            if not conv[k]:
+                continue                                          # failure row: NaN reward, all-invalid info (opf_env.py:390-399)
+            net = self.net_view(x[k], res[k])
+            if self.objective_function is not None:
+                objective[k] = float(np.sum(-np.asarray(self.objective_function(net), dtype=float)))   # opf_env.py:493-500
+                if env.diff_objective and init is not None:
+                    objective[k] -= init[k]
+            for j, (where, idx) in enumerate(self.order):
+                if where == 'dev':
+                    valids[k, j], viol[k, j], pen[k, j] = dv[k, idx], dvi[k, idx], dpe[k, idx]
+                else:
+                    valids[k, j], viol[k, j], pen[k, j] = self.host_constraints[idx].metrics(net)
+            valid = bool(valids[k, :nc].all()) if nc else True
+            penalty = float(pen[k, :nc].sum()) if nc else 0.0
+            r = rf(objective[k], penalty, valid)                  # reward.py:61-98
+            if mode == 0 and env.clipped_action_penalty:
+                r -= corr[k] * env.clipped_action_penalty         # opf_env.py:403-404
+            reward[k] = r
+            cost[k] = rf.calculate_cost(penalty, valid)
+        objective[~conv] = np.nan
+        dev = env.device
+        b['objective'].copy_(t.as_tensor(objective, device=dev))
+        b['reward'].copy_(t.as_tensor(reward, device=dev))
+        b['cost'].copy_(t.as_tensor(cost, device=dev))
+        return dict(valids=t.as_tensor(valids, device=dev), violations=t.as_tensor(viol, device=dev),
+                    penalties=t.as_tensor(pen, device=dev))

@@ -94,6 +94,25 @@ def sample_normal(net, state_keys, zdraws, relative_std=None):
         net[unit].loc[idxs, col] = np.clip(vals, lo, hi)
 
 
+def sample_truncated_normal(net, state_keys, udraws, relative_std=None):
+    """opf_env.py:304-307 (`truncated=True`): `stats.truncnorm.rvs(min_values, max_values, mean, std * diff)`.
+    scipy's first two arguments are standardised bounds, so this is mean + std*diff * Z with Z a standard
+    normal truncated to [min_values, max_values] (as written in the reference, D14).  scipy draws from its
+    own generator; the oracle takes the uniform numbers `udraws` instead and applies the inverse CDF —
+    `truncnorm.ppf(u, a, b, loc, scale)`, the transform `rvs` applies to its uniform draws."""
+    from scipy import stats
+    for unit, col, idxs in state_keys:
+        if 'res_' in unit or 'poly_cost' in unit:
+            continue
+        df = net[unit].loc[idxs]
+        hi = (df[f'max_max_{col}'] / df.scaling).to_numpy(float)
+        lo = (df[f'min_min_{col}'] / df.scaling).to_numpy(float)
+        diff = hi - lo
+        std = relative_std * diff if relative_std else df[f'std_dev_{col}'].to_numpy(float)
+        u = np.array([next(udraws) for _ in range(len(idxs))])
+        net[unit].loc[idxs, col] = stats.truncnorm.ppf(u, lo, hi, df[f'mean_{col}'].to_numpy(float), std * diff)
+
+
 def tail_voltage_control(net, draws, market_based):
     """voltage_control.py:111-133."""
     if market_based:
@@ -416,6 +435,8 @@ class EnvOracle:
             for unit, col, idxs in self.state_keys:
                 if 'res_' not in unit:
                     sample_from_range(self.net, unit, col, idxs, draws)
+        elif data == 'normal_around_mean' and self.sampling_params.get('truncated'):   # :240-241, 304-307
+            sample_truncated_normal(self.net, self.state_keys, draws, self.sampling_params.get('relative_std'))
         elif data == 'normal_around_mean':                                  # :240-241
             sample_normal(self.net, self.state_keys, iter(np.asarray(normal, float)),
                           self.sampling_params.get('relative_std'))

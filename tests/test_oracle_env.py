@@ -105,3 +105,34 @@ def test_reward_distribution_statistics_match_the_reference(name):
                                                     noise, g['action'])
     for k, v in stats.items():
         assert np.isclose(v, float(g['stat__' + k]), rtol=1e-9, atol=1e-9), k
+
+
+def test_truncated_normal_transform_has_the_reference_distribution():
+    """opf_env.py:304-307 draws with `stats.truncnorm.rvs(min, max, mean, std*diff)` from scipy's own generator,
+    which cannot be replayed; the oracle (and the reset kernel) apply the inverse CDF to uniform draws.
+    Statistical check: per column, the transformed uniforms are indistinguishable from scipy's `rvs` with the
+    same four arguments (two-sample Kolmogorov-Smirnov) and stay inside mean + scale*[min, max]."""
+    from scipy import stats
+    from oracle import env_oracle
+    env = product_env('vc_normal_mean', defer_device=True)
+    net = env.net
+    rng = np.random.default_rng(0)
+    n = 4000
+    unit, col, idxs = next(k for k in env.state_keys if 'res_' not in k[0] and 'poly_cost' not in k[0])
+    df = net[unit].loc[idxs]
+    hi = (df[f'max_max_{col}'] / df.scaling).to_numpy(float)
+    lo = (df[f'min_min_{col}'] / df.scaling).to_numpy(float)
+    scale = 0.3 * (hi - lo) * (hi - lo)
+    mean = df[f'mean_{col}'].to_numpy(float)
+    got = np.empty((n, len(idxs)))
+    import copy
+    work = copy.deepcopy(net)
+    for k in range(n):
+        env_oracle.sample_truncated_normal(work, [(unit, col, idxs)], iter(rng.random(len(idxs))), 0.3)
+        got[k] = work[unit].loc[idxs, col].to_numpy(float)
+    for j in range(0, len(idxs), max(1, len(idxs) // 6)):
+        if scale[j] == 0:
+            continue
+        ref = stats.truncnorm.rvs(lo[j], hi[j], mean[j], scale[j], n, random_state=np.random.default_rng(j))
+        assert stats.ks_2samp(got[:, j], ref).pvalue > 1e-3
+        assert (got[:, j] >= mean[j] + scale[j] * lo[j] - 1e-12).all() and (got[:, j] <= mean[j] + scale[j] * hi[j] + 1e-12).all()
