@@ -191,7 +191,7 @@ enum { OPFX_REWARD_SUMMATION = 0, OPFX_REWARD_REPLACEMENT = 1,
 /* kinds of actuator columns (opfx_env_desc.act_kind) */
 enum { OPFX_ACT_CONTINUOUS = 0, OPFX_ACT_INTEGER = 1 /* np.round */, OPFX_ACT_BOOLEAN = 2 /* np.round(..).astype(bool) */ };
 
-enum { OPFX_XRES_P = 0, OPFX_XRES_S = 1 };
+enum { OPFX_XRES_P = 0, OPFX_XRES_S = 1, OPFX_XRES_MAX3 = 2 };
 
 typedef struct opfx_env_desc {
   int32_t nx;                /* columns of the per-instance store           */
@@ -290,12 +290,15 @@ typedef struct opfx_env_desc {
    * the res_<unit> echoes pandapower writes for controllable units and what custom constraints
    * compute from them (examples/custom_constraint.py:9-11):
    *   OPFX_XRES_P: x[xres_p[k]] * xres_scale[k]        (res_<unit>.p_mw / q_mvar = set-point * scaling)
-   *   OPFX_XRES_S: sqrt(P^2 + Q^2) of x[xres_p[k]], x[xres_q[k]] (apparent power) */
+   *   OPFX_XRES_S: sqrt(P^2 + Q^2) of x[xres_p[k]], x[xres_q[k]] (apparent power)
+   *   OPFX_XRES_MAX3: NaN-propagating max of the RESULT-BANK entries xres_p[k], xres_q[k], xres_r[k]:
+   *       res_trafo3w.loading_percent = the worst of the three windings of its star equivalent */
   int32_t n_xres;
   const int32_t* xres_kind;       /* [n_xres] OPFX_XRES_*                    */
   const int32_t* xres_p;          /* [n_xres] column of the store            */
   const int32_t* xres_q;          /* [n_xres] column of the store or -1      */
   const double* xres_scale;       /* [n_xres] */
+  const int32_t* xres_r;          /* [n_xres] third result index of OPFX_XRES_MAX3 rows (else unused); NULL = none */
 } opfx_env_desc;
 
 int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);

@@ -24,7 +24,7 @@ import numpy as np
 from . import capi
 from . import constraints as constraints_mod
 from . import reward as reward_mod
-from .case import KIND_LINE, KIND_TRAFO, PQ, PV, REF, net_to_case
+from .case import KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, PQ, PV, REF, net_to_case
 from .grids import factored_profile
 from .simbench_build import define_test_train_split, get_simbench_time_observation
 
@@ -601,6 +601,20 @@ class BatchedOpfEnv:
             pos_to_br = {int(e): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem)) if kd == kind}
             for pos in self.store.rows(unit, idxs):
                 out.append(2 * nb + pos_to_br[int(pos)] if int(pos) in pos_to_br else zero)
+        elif unit == 'trafo3w':
+            # pandapower's res_trafo3w.loading_percent = the worst of the three windings: a derived row
+            # (OPFX_XRES_MAX3) over the loadings of the three branches of its star equivalent
+            assert col == 'loading_percent'
+            base3 = 3 * nb + nbr + 2 * nref
+            for pos in self.store.rows(unit, idxs):
+                br = [k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem)) if kd == KIND_TRAFO3W and int(e) == int(pos)]
+                if len(br) != 3:
+                    out.append(zero)                               # out of service: 0 %
+                    continue
+                key = ('trafo3w', col, int(pos))
+                if key not in self._xres:
+                    self._xres[key] = (len(self._xres), capi.XRES_MAX3, 2 * nb + br[0], 2 * nb + br[1], 1.0, 2 * nb + br[2])
+                out.append(base3 + self._xres[key][0])
         elif unit == 'ext_grid':
             off = 2 * nb + nbr + (0 if col == 'p_mw' else nref)
             ordinal = {int(b): k for k, b in enumerate(ref_buses)}
@@ -623,7 +637,7 @@ class BatchedOpfEnv:
                     kind = capi.XRES_S if col == 's_mva' else capi.XRES_P
                     psl = (q0 if col == 'q_mvar' else p0) + int(pos)
                     qsl = q0 + int(pos) if col == 's_mva' else -1
-                    self._xres[key] = (len(self._xres), kind, psl, qsl, sc)
+                    self._xres[key] = (len(self._xres), kind, psl, qsl, sc, 0)
                 out.append(base + self._xres[key][0])
         else:
             raise NotImplementedError(f'result column res_{unit}.{col} is not in the device result bank')
@@ -843,6 +857,7 @@ class BatchedOpfEnv:
         if xr_:
             d.xres_kind, d.xres_p = _keep(keep, [v[1] for v in xr_], 'i'), _keep(keep, [v[2] for v in xr_], 'i')
             d.xres_q, d.xres_scale = _keep(keep, [v[3] for v in xr_], 'i'), _keep(keep, [v[4] for v in xr_], 'd')
+            d.xres_r = _keep(keep, [v[5] for v in xr_], 'i')
         if q_idx:
             d.qterm_idx, d.qterm_target, d.qterm_weight = _keep(keep, q_idx, 'i'), _keep(keep, q_tgt, 'd'), _keep(keep, q_w, 'd')
         d.n_bmod = len(bmod)

@@ -91,11 +91,12 @@ class EnvDesc(C.Structure):
         ('bmod_n', _pi), ('bmod_ptr', _pi), ('bmod_y', _pd),
         ('vset_slot', _pi),
         ('n_qterm', C.c_int32), ('qterm_idx', _pi), ('qterm_target', _pd), ('qterm_weight', _pd),
-        ('n_xres', C.c_int32), ('xres_kind', _pi), ('xres_p', _pi), ('xres_q', _pi), ('xres_scale', _pd)]
+        ('n_xres', C.c_int32), ('xres_kind', _pi), ('xres_p', _pi), ('xres_q', _pi), ('xres_scale', _pd),
+                ('xres_r', _pi)]
 
 
 ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2
-XRES_P, XRES_S = 0, 1
+XRES_P, XRES_S, XRES_MAX3 = 0, 1, 2
 
 
 class StepIO(C.Structure):

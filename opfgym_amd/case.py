@@ -8,7 +8,8 @@ scale factors that turn per-unit branch currents into `loading_percent`.
 `net_to_case` restates the third-party pandapower `_pd2ppc` conversion
  for the element types that occur in the SimBench
 benchmark grids: buses, lines, two-winding transformers, loads, sgens,
-storages, gens, ext_grids, shunts, bus-bus/line/trafo switches.  pandapower is
+storages, gens, ext_grids, shunts, bus-bus/line/trafo switches, three-winding
+transformers (star equivalent with an auxiliary bus).  pandapower is
 not importable here, so the element formulas are restated from its published
 documentation ("Electric model" pages of line / trafo); parity of this
 conversion against pandapower itself is NOT verified in this repository (see
@@ -21,7 +22,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 PQ, PV, REF = 1, 2, 3
-KIND_LINE, KIND_TRAFO = 0, 1
+KIND_LINE, KIND_TRAFO, KIND_TRAFO3W = 0, 1, 2
 
 
 @dataclass
@@ -44,7 +45,8 @@ class Case:
     kf: np.ndarray                # f64 [nbr] loading% = max(|If|*kf, |It|*kt)
     kt: np.ndarray
     br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo
-    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo
+    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w
+    br_side: np.ndarray = None    # int32 [nbr]  trafo3w: 0 hv, 1 mv, 2 lv winding of its star equivalent (else 0)
     # lookups back to the net
     bus_lookup: dict = field(default_factory=dict)   # net bus index -> case bus
     ref_elems: np.ndarray = None  # positional ext_grid rows per REF bus order
@@ -215,7 +217,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             if not (bus_on(fb) and bus_on(tb)):
                 continue
             bc = b_pu[pos] - 1j * g_pu[pos]      # j*bc/2 = (g + jb)/2 per side
-            rows.append((fb, tb, r_pu[pos], x_pu[pos], bc, 1.0, 0.0, KIND_LINE, pos, kf_l[pos], kt_l[pos], side))
+            rows.append((fb, tb, r_pu[pos], x_pu[pos], bc, 1.0, 0.0, KIND_LINE, pos, kf_l[pos], kt_l[pos], side, 0))
     if len(tr):
         on = _col(tr, 'in_service', True).astype(bool)
         par = _col(tr, 'parallel', 1.0)
@@ -275,10 +277,80 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             sh = np.deg2rad(shift[pos]) if calc_angles else 0.0
             kf = base * (vn_hv / vb_hv) / sn * 100.0 / (par[pos] * dfac[pos])
             kt = base * (vn_lv / vb_lv) / sn * 100.0 / (par[pos] * dfac[pos])
-            rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt, oside))
+            rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt, oside, 0))
+
+    # --- three-winding transformers: star equivalent (pandapower `_trafo_df_from_trafo3w`) -------------
+    # an auxiliary bus on the hv voltage level per transformer and three two-winding transformers
+    # hv-bus -> star, star -> mv-bus, star -> lv-bus; the pairwise short-circuit voltages (hv-mv, mv-lv,
+    # hv-lv, each on the smaller rating of its pair) are referred to sn_hv and turned from delta into wye
+    # values; iron losses and magnetising current sit on the hv winding (`trafo3w_losses='hv'`)
+    t3 = net['trafo3w'] if 'trafo3w' in net else None
+    aux_vn = []                                        # one auxiliary bus per (in-service) trafo3w: ids -1, -2, ...
+    if t3 is not None and len(t3):
+        on3 = _col(t3, 'in_service', True).astype(bool)
+        g = lambda c_, d=np.nan: _col(t3, c_, d)
+        sn3 = np.stack([g('sn_hv_mva'), g('sn_mv_mva'), g('sn_lv_mva')])
+        def on_hv(z):
+            return sn3[0] * np.array([z[0] / np.minimum(sn3[0], sn3[1]), z[1] / np.minimum(sn3[1], sn3[2]),
+                                      z[2] / np.minimum(sn3[0], sn3[2])])
+        def delta_to_wye(z):
+            return 0.5 * sn3 / sn3[0] * np.array([z[0] + z[2] - z[1], z[1] + z[0] - z[2], z[2] + z[1] - z[0]])
+        vk_d = on_hv(np.stack([g('vk_hv_percent', 0.0), g('vk_mv_percent', 0.0), g('vk_lv_percent', 0.0)]))
+        vkr_d = on_hv(np.stack([g('vkr_hv_percent', 0.0), g('vkr_mv_percent', 0.0), g('vkr_lv_percent', 0.0)]))
+        vki_w = delta_to_wye(np.sqrt(vk_d ** 2 - vkr_d ** 2))
+        vkr_w = delta_to_wye(vkr_d)
+        vk_w = np.sign(vki_w) * np.sqrt(vki_w ** 2 + vkr_w ** 2)
+        tap_pos3, tap_neu3, tap_stp3 = g('tap_pos'), g('tap_neutral', 0.0), g('tap_step_percent')
+        for pos, idx in enumerate(t3.index):
+            ends = [int(t3.at[idx, c_]) for c_ in ('hv_bus', 'mv_bus', 'lv_bus')]
+            if not on3[pos] or not all(bus_on(b) for b in ends):
+                continue
+            if (vk_w[:, pos] == 0).any():
+                raise ValueError('trafo3w: equivalent transformer with zero impedance')
+            star = -1 - len(aux_vn)
+            vn_h = float(t3.at[idx, 'vn_hv_kv'])
+            aux_vn.append(vn_h)
+            tside = t3.at[idx, 'tap_side'] if 'tap_side' in t3.columns else None
+            fac = 1.0
+            if isinstance(tside, str) and not np.isnan(tap_pos3[pos]) and not np.isnan(tap_stp3[pos]):
+                fac = 1.0 + (tap_pos3[pos] - tap_neu3[pos]) * tap_stp3[pos] / 100.0
+            for w, wname in enumerate(('hv', 'mv', 'lv')):
+                sn_w = float(sn3[w, pos])
+                vn_w = float(t3.at[idx, f'vn_{wname}_kv'])
+                if w == 0:          # hv bus -> star: rated vn_hv / vn_hv, tap on the hv side
+                    fb, tb, vb_f, vb_t = ends[0], star, float(vn[ends[0]]), vn_h
+                    vt_f, vt_t, rated_t = vn_h * (fac if tside == 'hv' else 1.0), vn_h, vn_h
+                else:               # star -> mv / lv bus: rated vn_hv / vn_side, tap on that side
+                    fb, tb, vb_f, vb_t = star, ends[w], vn_h, float(vn[ends[w]])
+                    vt_f, vt_t, rated_t = vn_h, vn_w * (fac if tside == wname else 1.0), vn_w
+                tap_lv = (vt_t / vb_t) ** 2 * base
+                z_sc = vk_w[w, pos] / 100.0 / sn_w * tap_lv
+                r_sc = vkr_w[w, pos] / 100.0 / sn_w * tap_lv
+                x_sc = np.sign(z_sc) * np.sqrt(max(z_sc ** 2 - r_sc ** 2, 0.0))
+                r_pi, x_pi, bc = r_sc, x_sc, 0.0 + 0.0j
+                pfe = float(g('pfe_kw', 0.0)[pos]) * 1e-3 if w == 0 else 0.0
+                i0 = float(g('i0_percent', 0.0)[pos]) if w == 0 else 0.0
+                if pfe or i0:
+                    base_r = vb_t ** 2 / base
+                    b_real = pfe / rated_t ** 2 * base_r
+                    b_img = np.sqrt(max((i0 / 100.0 * sn_w) ** 2 - pfe ** 2, 0.0)) * base_r / rated_t ** 2
+                    y = (-1j * b_real - b_img * np.sign(i0)) / (vt_t / rated_t) ** 2
+                    if y != 0:
+                        za = (r_sc + 1j * x_sc) / 2.0
+                        zc = -1j / y
+                        zsum = za * za + 2 * za * zc
+                        r_pi, x_pi, bc = (zsum / zc).real, (zsum / zc).imag, -2j / (zsum / za)
+                ratio = (vt_f / vt_t) / (vb_f / vb_t)
+                sh = np.deg2rad(float(g(f'shift_{wname}_degree', 0.0)[pos])) if (calc_angles and w) else 0.0
+                # loading: the current at the winding's own terminal (hv winding: from end, mv / lv: to end)
+                k_term = base * (vn_w / (vb_f if w == 0 else vb_t)) / sn_w * 100.0
+                rows.append((fb, tb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO3W, pos, k_term if w == 0 else 0.0,
+                             0.0 if w == 0 else k_term, 0, w))
 
     # --- which fused buses are alive: connected to a REF through branches ----
     roots = {b: uf.find(b) for b in bus_ids}
+    for a_ in range(len(aux_vn)):
+        roots[-1 - a_] = -1 - a_                   # auxiliary star buses of three-winding transformers
     eg_bus = [int(b) for b, on_ in zip(eg['bus'], eg_on) if on_] if len(eg) else []
     if not eg_bus:
         raise ValueError('net has no in-service ext_grid (no slack bus)')
@@ -297,9 +369,9 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             continue
         alive.add(a)
         stack.extend(adj.get(a, ()))
-    live_roots = {roots[b] for i, b in enumerate(bus_ids) if in_service_bus[i]}
+    live_roots = {roots[b] for i, b in enumerate(bus_ids) if in_service_bus[i]} | {-1 - a_ for a_ in range(len(aux_vn))}
     alive &= live_roots
-    order = sorted(alive)
+    order = sorted(r for r in alive if r >= 0) + sorted((r for r in alive if r < 0), reverse=True)   # auxiliary buses last
     root_to_case = {r: i for i, r in enumerate(order)}
     bus_lookup = {b: root_to_case[roots[b]] for i, b in enumerate(bus_ids)
                   if roots[b] in root_to_case and in_service_bus[i]}
@@ -328,7 +400,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     bus_type = np.full(nb, PQ, dtype=np.int32)
     vm_set = np.ones(nb)
     va_set = np.zeros(nb)
-    vn_case = np.array([float(vn[r]) for r in order])
+    vn_case = np.array([float(vn[r]) if r >= 0 else aux_vn[-1 - r] for r in order])
     gen = net['gen']
     if len(gen):
         g_on = _col(gen, 'in_service', True).astype(bool)
@@ -374,6 +446,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         kt=np.array([r[10] for r in rows], dtype=float),
         br_kind=np.array([r[7] for r in rows], dtype=np.int32),
         br_elem=np.array([r[8] for r in rows], dtype=np.int32),
+        br_side=np.array([r[12] for r in rows], dtype=np.int32),
         bus_lookup=bus_lookup, ref_elems=np.array(ref_elems, dtype=np.int32),
         meta={'calc_angles': calc_angles})
 

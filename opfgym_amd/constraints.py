@@ -96,6 +96,13 @@ class TrafoOverloadConstraint(Constraint):
         super().__init__('trafo', 'loading_percent', autoscale_violation=autoscale_violation, **args)
 
 
+class Trafo3wOverloadConstraint(Constraint):
+    def __init__(self, autoscale_violation=True, **args):
+        if autoscale_violation is True:
+            autoscale_violation = 1 / 30               # constraints.py:164-172
+        super().__init__('trafo3w', 'loading_percent', autoscale_violation=autoscale_violation, **args)
+
+
 class ExtGridActivePowerConstraint(Constraint):
     def __init__(self, **args):
         super().__init__('ext_grid', 'p_mw', **args)
@@ -124,7 +131,7 @@ def _defined(net, unit_type, column) -> bool:
 
 
 def create_default_constraints(net, constraint_kwargs: dict) -> list:
-    """constraints.py:195-226 (trafo3w is not modelled by the batched backend)."""
+    """constraints.py:195-226."""
     out = []
     if _defined(net, 'bus', 'max_vm_pu') or _defined(net, 'bus', 'min_vm_pu'):
         out.append(VoltageConstraint(**constraint_kwargs))
@@ -133,7 +140,7 @@ def create_default_constraints(net, constraint_kwargs: dict) -> list:
     if _defined(net, 'trafo', 'max_loading_percent'):
         out.append(TrafoOverloadConstraint(**constraint_kwargs))
     if _defined(net, 'trafo3w', 'max_loading_percent'):
-        raise NotImplementedError('three-winding transformers are not supported')
+        out.append(Trafo3wOverloadConstraint(**constraint_kwargs))
     if _defined(net, 'ext_grid', 'max_p_mw') or _defined(net, 'ext_grid', 'min_p_mw'):
         out.append(ExtGridActivePowerConstraint(**constraint_kwargs))
     if _defined(net, 'ext_grid', 'max_q_mvar') or _defined(net, 'ext_grid', 'min_q_mvar'):

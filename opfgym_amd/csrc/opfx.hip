@@ -84,7 +84,7 @@ struct DevEnv {
   const int* vset_src;       // [nb] source of a per-instance |V| set-point (NOSRC: compiled value), or nullptr
   int n_qterm;               // quadratic objective terms on the result bank
   int n_xres, nres_base;     // derived result rows [nres_base, nres_base + n_xres)
-  const int *xres_kind, *xres_p, *xres_q;
+  const int *xres_kind, *xres_p, *xres_q, *xres_r;
   const double* xres_scale;
   const int* qterm_idx;
   const double *qterm_target, *qterm_weight;
@@ -1720,9 +1720,15 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
       if (wave == 0) {
       for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
         const double sc = as_global(E.xres_scale)[k];
-        const double pv_ = src_val(xr, L.sp, as_global(E.xres_p)[k]) * sc;
-        double v = pv_;
-        if (as_global(E.xres_kind)[k] == OPFX_XRES_S) { const double qv = src_val(xr, L.sp, as_global(E.xres_q)[k]) * sc; v = sqrt(pv_ * pv_ + qv * qv); }
+        const int kind = as_global(E.xres_kind)[k];
+        double v;
+        if (kind == OPFX_XRES_MAX3) {                      // (rows of this kind come after the rows they read)
+          v = nan_max(nan_max(R[as_global(E.xres_p)[k]], R[as_global(E.xres_q)[k]]), R[as_global(E.xres_r)[k]]);
+        } else {
+          const double pv_ = src_val(xr, L.sp, as_global(E.xres_p)[k]) * sc;
+          v = pv_;
+          if (kind == OPFX_XRES_S) { const double qv = src_val(xr, L.sp, as_global(E.xres_q)[k]) * sc; v = sqrt(pv_ * pv_ + qv * qv); }
+        }
         R[E.nres_base + k] = v;
       }
       sec_sync<NW>();
@@ -2391,11 +2397,19 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     if (any && rc == OPFX_OK) rc = A.put(src, &E.vset_src);
   }
   if (d->n_xres > 0) {
-    std::vector<int32_t> ps(d->n_xres), qs(d->n_xres);
+    std::vector<int32_t> ps(d->n_xres), qs(d->n_xres), rs(d->n_xres, 0);
     for (int k = 0; k < d->n_xres; ++k) {
+      if (d->xres_kind[k] == OPFX_XRES_MAX3) {          // three entries of the solver's result bank
+        const int32_t lim = E.nres_base;
+        if (!d->xres_r || d->xres_p[k] < 0 || d->xres_p[k] >= lim || d->xres_q[k] < 0 || d->xres_q[k] >= lim ||
+            d->xres_r[k] < 0 || d->xres_r[k] >= lim) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: xres result index out of range"); break; }
+        ps[k] = d->xres_p[k]; qs[k] = d->xres_q[k]; rs[k] = d->xres_r[k];
+        continue;
+      }
       if (d->xres_p[k] < 0 || d->xres_p[k] >= d->nx || d->xres_q[k] >= d->nx) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: xres column out of range"); break; }
       ps[k] = src_of(d->xres_p[k]); qs[k] = src_of(d->xres_q[k]);
     }
+    if (rc == OPFX_OK) rc = A.put(rs, &E.xres_r);
     PUTN(xres_kind, d->xres_kind, d->n_xres); PUTN(xres_scale, d->xres_scale, d->n_xres);
     if (rc == OPFX_OK) rc = A.put(ps, &E.xres_p);
     if (rc == OPFX_OK) rc = A.put(qs, &E.xres_q);

@@ -441,6 +441,31 @@ def synthetic_hv_small_sw(seed: int = 0):
     return net, prof
 
 
+def synthetic_mv_3w(seed: int = 0):
+    """mv-small plus a 110/20/10 kV three-winding transformer in parallel to the two-winding ones: its mv
+    terminal on the first busbar section, a 10 kV bus with a load and an sgen on its lv terminal (test grid
+    for `Trafo3wOverloadConstraint`, constraints.py:164-172; not a BASELINE config)."""
+    from . import net as ppn
+    net, prof = synthetic_mv_small(seed)
+    lv = ppn.create_bus(net, 10.0, min_vm_pu=np.nan, max_vm_pu=np.nan)
+    ppn.create_transformer3w_from_parameters(
+        net, 0, 1, lv, 110.0, 20.0, 10.0, 40.0, 25.0, 15.0, vk_hv_percent=10.4, vk_mv_percent=6.4, vk_lv_percent=10.2,
+        vkr_hv_percent=0.28, vkr_mv_percent=0.32, vkr_lv_percent=0.35, pfe_kw=28.0, i0_percent=0.06,
+        shift_mv_degree=150.0, shift_lv_degree=150.0, tap_side='hv', tap_neutral=0, tap_pos=1, tap_step_percent=1.2,
+        max_loading_percent=12.0)
+    li = ppn.create_load(net, lv, 2.4, 0.7)
+    si = ppn.create_sgen(net, lv, 1.6, 0.0)
+    ppn.finalize(net)
+    rng = np.random.default_rng(seed + 7)
+    for key, idx, peak in ((('load', 'p_mw'), li, 2.4), (('load', 'q_mvar'), li, 0.7), (('sgen', 'p_mw'), si, 1.6)):
+        df = prof[key]
+        src = df.columns[int(rng.integers(len(df.columns)))]
+        df[idx] = df[src].to_numpy() / max(float(df[src].max()), 1e-9) * peak
+        if hasattr(prof, 'rel'):
+            prof.rel.pop(key, None)
+    return net, prof
+
+
 GRIDS = {
     '1-LV-rural1--0-sw': synthetic_lv_rural1,
     '1-MV-urban--0-sw': synthetic_mv_urban,
@@ -449,6 +474,7 @@ GRIDS = {
     'mv-small': synthetic_mv_small,
     'hv-small': synthetic_hv_small,
     'hv-small-sw': synthetic_hv_small_sw,
+    'mv-3w': synthetic_mv_3w,
 }
 
 

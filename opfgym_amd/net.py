@@ -25,7 +25,10 @@ _TABLES = {
               'shift_degree', 'tap_side', 'tap_neutral', 'tap_pos',
               'tap_step_percent', 'parallel', 'df', 'in_service',
               'max_loading_percent'],
-    'trafo3w': [],
+    'trafo3w': ['name', 'hv_bus', 'mv_bus', 'lv_bus', 'sn_hv_mva', 'sn_mv_mva', 'sn_lv_mva', 'vn_hv_kv',
+                'vn_mv_kv', 'vn_lv_kv', 'vk_hv_percent', 'vk_mv_percent', 'vk_lv_percent', 'vkr_hv_percent',
+                'vkr_mv_percent', 'vkr_lv_percent', 'pfe_kw', 'i0_percent', 'shift_mv_degree', 'shift_lv_degree',
+                'tap_side', 'tap_neutral', 'tap_pos', 'tap_step_percent', 'in_service', 'max_loading_percent'],
     'load': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
              'controllable'],
     'sgen': ['name', 'bus', 'p_mw', 'q_mvar', 'scaling', 'in_service',
@@ -46,7 +49,7 @@ _TABLES = {
 
 _OBJ_COLS = ('name', 'type', 'tap_side', 'et', 'points', 'power_type')
 _BOOL_COLS = ('in_service', 'controllable', 'closed')
-_INT_COLS = ('bus', 'from_bus', 'to_bus', 'hv_bus', 'lv_bus', 'element', 'parallel')
+_INT_COLS = ('bus', 'from_bus', 'to_bus', 'hv_bus', 'mv_bus', 'lv_bus', 'element', 'parallel')
 
 
 def _dtype_of(col):
@@ -118,7 +121,7 @@ def _finalize_dtypes(net) -> None:
                 conv = pd.to_numeric(df[col])
             except (ValueError, TypeError):
                 continue
-            if col in ('bus', 'from_bus', 'to_bus', 'hv_bus', 'lv_bus',
+            if col in ('bus', 'from_bus', 'to_bus', 'hv_bus', 'mv_bus', 'lv_bus',
                        'element', 'parallel') and not conv.isna().any():
                 conv = conv.astype(np.int64)
             df[col] = conv
@@ -157,6 +160,25 @@ def create_transformer_from_parameters(net, hv_bus, lv_bus, sn_mva, vn_hv_kv,
         tap_neutral=float(tap_neutral), tap_pos=float(tap_pos),
         tap_step_percent=float(tap_step_percent), parallel=int(parallel),
         df=float(df), in_service=bool(in_service), **kw), index)
+
+
+def create_transformer3w_from_parameters(net, hv_bus, mv_bus, lv_bus, vn_hv_kv, vn_mv_kv, vn_lv_kv, sn_hv_mva,
+                                         sn_mv_mva, sn_lv_mva, vk_hv_percent, vk_mv_percent, vk_lv_percent,
+                                         vkr_hv_percent, vkr_mv_percent, vkr_lv_percent, pfe_kw, i0_percent,
+                                         shift_mv_degree=0.0, shift_lv_degree=0.0, tap_side=None, tap_neutral=0,
+                                         tap_pos=0, tap_step_percent=np.nan, in_service=True, name=None, index=None,
+                                         **kw) -> int:
+    """Same parameters as pandapower.create_transformer3w_from_parameters (vk_hv: hv-mv, vk_mv: mv-lv,
+    vk_lv: hv-lv short-circuit voltage)."""
+    return _append(net, 'trafo3w', dict(
+        name=name, hv_bus=int(hv_bus), mv_bus=int(mv_bus), lv_bus=int(lv_bus), sn_hv_mva=float(sn_hv_mva),
+        sn_mv_mva=float(sn_mv_mva), sn_lv_mva=float(sn_lv_mva), vn_hv_kv=float(vn_hv_kv), vn_mv_kv=float(vn_mv_kv),
+        vn_lv_kv=float(vn_lv_kv), vk_hv_percent=float(vk_hv_percent), vk_mv_percent=float(vk_mv_percent),
+        vk_lv_percent=float(vk_lv_percent), vkr_hv_percent=float(vkr_hv_percent), vkr_mv_percent=float(vkr_mv_percent),
+        vkr_lv_percent=float(vkr_lv_percent), pfe_kw=float(pfe_kw), i0_percent=float(i0_percent),
+        shift_mv_degree=float(shift_mv_degree), shift_lv_degree=float(shift_lv_degree), tap_side=tap_side,
+        tap_neutral=float(tap_neutral), tap_pos=float(tap_pos), tap_step_percent=float(tap_step_percent),
+        in_service=bool(in_service), **kw), index)
 
 
 def _create_unit(net, table, bus, p_mw, q_mvar, scaling, in_service, name,

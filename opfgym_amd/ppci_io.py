@@ -63,6 +63,7 @@ def case_from_ppc(base_mva, bus, branch, gen, br_g=None):
         # percent of RATE_A [MVA] at nominal voltage: |I| p.u. * baseMVA / rate * 100
         kf=base_mva / rate * 100.0, kt=base_mva / rate * 100.0,
         br_kind=np.zeros(len(f), dtype=np.int32), br_elem=np.flatnonzero(on).astype(np.int32),
+        br_side=np.zeros(len(f), dtype=np.int32),
         bus_lookup={i: i for i in range(nb)}, ref_elems=np.zeros(0, dtype=np.int32),
         meta={'source': 'ppc'})
     return case, p, q, qmin, qmax

@@ -16,7 +16,7 @@ import numpy as np
 import pandas as pd
 
 from . import capi
-from .case import KIND_LINE, KIND_TRAFO, REF, bus_injections, net_to_case
+from .case import KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, bus_injections, net_to_case
 
 
 class LoadflowNotConverged(Exception):
@@ -98,6 +98,14 @@ class BatchedPowerFlowSolver:
                             not np.isnan(vm[net['bus'].index.get_loc(int(net[tbl][e].iloc[pos]))]) for e in ends)
                 load[pos] = 0.0 if alive else np.nan
             net['res_' + tbl] = pd.DataFrame({'loading_percent': load}, index=net[tbl].index)
+        if 'trafo3w' in net and len(net['trafo3w']):
+            # the worst of the three windings (NaN-propagating, as numpy's max); out of service: 0 %
+            ld3 = np.zeros(len(net['trafo3w']))
+            for pos in range(len(ld3)):
+                sel = (case.br_kind == KIND_TRAFO3W) & (case.br_elem == pos)
+                if sel.any():
+                    ld3[pos] = np.max(r['loading'][sel])
+            net['res_trafo3w'] = pd.DataFrame({'loading_percent': ld3}, index=net['trafo3w'].index)
         ref_buses = np.flatnonzero(case.bus_type == REF)
         ordinal = {int(b): k for k, b in enumerate(ref_buses)}
         eg = net['ext_grid']

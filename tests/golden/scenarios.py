@@ -93,6 +93,8 @@ SCENARIOS.update({
     # stand-in (wave teams of two), N-1 VoltageControl on the 372-bus stand-in with every non-islanding
     # line as contingency (250 of them; wave teams of four)
     'eco_hv_mixed': ('EcoDispatch', dict(simbench_network_name='1-HV-mixed--0-sw'), 4, 31),
+    # a grid with a three-winding transformer: Trafo3wOverloadConstraint among the defaults (constraints.py:164-172,210)
+    'vc_mv_3w': ('VoltageControl', dict(simbench_network_name='mv-3w'), 5, 33),
     'sc_vc_hv_urban': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
                                                                  n_minus_one_lines='all'), 2, 32),
 })

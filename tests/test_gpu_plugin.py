@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', 'mv-small', 'hv-small'])
+@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', 'mv-small', 'hv-small', 'mv-3w'])
 def test_plugin_matches_oracle_tables(code):
     from opfgym_amd import grids, power_flow_solver
     from oracle import pf_oracle as po
@@ -22,8 +22,11 @@ def test_plugin_matches_oracle_tables(code):
     power_flow_solver(net, enforce_q_lims=True)
     for tbl, cols, tol in (('res_bus', ('vm_pu', 'va_degree'), 1e-8),
                            ('res_line', ('loading_percent',), 1e-6), ('res_trafo', ('loading_percent',), 1e-6),
+                           ('res_trafo3w', ('loading_percent',), 1e-6),
                            ('res_ext_grid', ('p_mw', 'q_mvar'), 1e-6), ('res_sgen', ('p_mw', 'q_mvar'), 0),
                            ('res_load', ('p_mw', 'q_mvar'), 0), ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6)):
+        if tbl == 'res_trafo3w' and not len(net['trafo3w']):
+            continue
         for col in cols:
             a, b = net[tbl][col].to_numpy(float), ref[tbl][col].to_numpy(float)
             assert a.shape == b.shape

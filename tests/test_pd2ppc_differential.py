@@ -54,13 +54,16 @@ def _compare(net, tol=1e-9):
     i_f = np.abs(case.yff * v_case[case.f] + case.yft * v_case[case.t])
     i_t = np.abs(case.ytf * v_case[case.f] + case.ytt * v_case[case.t])
     mine = np.maximum(i_f * case.kf, i_t * case.kt)
-    theirs = np.array([ld['line' if kd == 0 else 'trafo'][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])
-    assert np.allclose(mine, theirs, rtol=1e-9, atol=1e-9), np.abs(mine - theirs).max()
+    two = case.br_kind != 2
+    theirs = np.array([ld['line' if kd == 0 else 'trafo'][int(e)] for kd, e in zip(case.br_kind[two], case.br_elem[two])])
+    assert np.allclose(mine[two], theirs, rtol=1e-9, atol=1e-9), np.abs(mine[two] - theirs).max()
+    for pos in np.unique(case.br_elem[~two]):          # three-winding transformers: the worst of the three terminals
+        assert np.isclose(mine[~two & (case.br_elem == pos)].max(), ld['trafo3w'][int(pos)], rtol=1e-9, atol=1e-9)
     return case, ppc
 
 
 @pytest.mark.parametrize('code', ['1-LV-rural1--0-sw', '1-MV-urban--0-sw', '1-HV-mixed--0-sw', '1-HV-urban--0-sw',
-                                  'mv-small', 'hv-small', 'hv-small-sw'])
+                                  'mv-small', 'hv-small', 'hv-small-sw', 'mv-3w'])
 def test_every_grid(code):
     net, _ = grids.get_grid(code)
     _compare(net)
@@ -84,7 +87,7 @@ def _random_net(rng):
 
     def line(a, b, kv):
         ppn.create_line_from_parameters(
-            net, a, b, float(rng.uniform(0.1, 20.0)), float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.05, 0.5)),
+            net, a, b, float(rng.uniform(0.1, {110.0: 20.0, 20.0: 4.0, 0.4: 0.2}[kv])), float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.05, 0.5)),
             float(rng.uniform(0.0, 300.0)), float(rng.uniform(0.1, 1.0)), g_us_per_km=float(rng.choice([0.0, rng.uniform(0, 5)])),
             df=float(rng.choice([1.0, rng.uniform(0.5, 1.0)])), parallel=int(rng.choice([1, 1, 2, 3])),
             in_service=bool(rng.random() > 0.1))
@@ -111,8 +114,21 @@ def _random_net(rng):
         trafo(hb, lb, 110.0, 20.0, float(rng.uniform(20.0, 63.0)))
     net.trafo.loc[net.trafo.index[:2], 'shift_degree'] = shift       # one vector group per voltage level
     trafo(mv[7], lv[0], 20.0, 0.4, float(rng.uniform(0.25, 0.8)))
+    net.trafo.loc[net.trafo.index[2], 'shift_degree'] = 0.0          # (vector groups consistent around every loop)
+    if rng.random() < 0.7:                 # a three-winding transformer 110 / 20 / 0.4 kV with random data
+        sn_h = float(rng.uniform(20.0, 40.0))
+        ppn.create_transformer3w_from_parameters(
+            net, hv[2], mv[3], lv[2], 110.0 * float(rng.choice([1.0, 1.02])), 20.0, 0.4 * float(rng.choice([1.0, 1.03])),
+            sn_h, sn_h * float(rng.uniform(0.5, 1.0)), sn_h * float(rng.uniform(0.2, 0.6)),
+            vk_hv_percent=float(rng.uniform(8, 14)), vk_mv_percent=float(rng.uniform(5, 9)), vk_lv_percent=float(rng.uniform(9, 15)),
+            vkr_hv_percent=float(rng.uniform(0.2, 0.5)), vkr_mv_percent=float(rng.uniform(0.2, 0.5)),
+            vkr_lv_percent=float(rng.uniform(0.2, 0.5)), pfe_kw=float(rng.choice([0.0, rng.uniform(5, 40)])),
+            i0_percent=float(rng.choice([0.0, rng.uniform(0.02, 0.3)])), shift_mv_degree=shift, shift_lv_degree=shift,
+            tap_side=[None, 'hv', 'mv', 'lv'][int(rng.integers(4))], tap_neutral=0, tap_pos=int(rng.integers(-3, 4)),
+            tap_step_percent=float(rng.uniform(0.5, 2.0)), in_service=bool(rng.random() > 0.1))
     for b in mv[1:] + lv:
-        ppn.create_load(net, b, float(rng.uniform(0.01, 0.5)), float(rng.uniform(-0.1, 0.2)),
+        size = 1.0 if b in mv else 0.03
+        ppn.create_load(net, b, size * float(rng.uniform(0.01, 0.5)), size * float(rng.uniform(-0.1, 0.2)),
                         scaling=float(rng.uniform(0.5, 1.5)), in_service=bool(rng.random() > 0.1))
     for b in rng.choice(mv, 4, replace=False):
         ppn.create_sgen(net, int(b), float(rng.uniform(0.0, 1.0)), float(rng.uniform(-0.2, 0.2)),
