@@ -285,7 +285,7 @@ class BatchedOpfEnv:
                  objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
-                 defer_device=False, validate_actions=False, carry_over_state=False, **kwargs):
+                 defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False, **kwargs):
         from .objectives import QuadraticDeviation
         terms = objective_function if isinstance(objective_function, (list, tuple)) else \
             ([objective_function] if objective_function is not None else [])
@@ -312,6 +312,9 @@ class BatchedOpfEnv:
         # column that the previous data source set and the current one does not sample then carries over
         # (reference defect D12: e.g. gen.p_mw of the last profile row under train_data='mixed').
         self.carry_over_state = bool(carry_over_state)
+        # True: reset()/step() return clones instead of the persistent output buffers (drop-in safe for rollout
+        # loops that keep what they were handed; costs one device copy per returned tensor and call)
+        self.copy_outputs = bool(copy_outputs)
         self._state_valid = False
         self.batch_size = int(batch_size)
         self.obs_keys = list(observation_keys)
@@ -987,7 +990,8 @@ class BatchedOpfEnv:
 
     # ------------------------------------------------------------------ gymnasium-shaped API
     def reset(self, seed=None, options=None):
-        """opf_env.py:177-220 for the whole batch.  options: 'test' (bool),
+        """opf_env.py:177-220 for the whole batch.  (The returned observation is a view of a persistent output
+        buffer, see `step`.)  options: 'test' (bool),
         'step' (int or [B] array), plus 'noise' [B,n_noise] / 'uniform'
         [B,n_uniform] / 'initial_action' [B,na] to replay explicit draws.
 
@@ -1018,7 +1022,8 @@ class BatchedOpfEnv:
             else:
                 raise RuntimeError(f'power flow failed in reset for some instances after '
                                    f'{self.max_reset_retries} new samples (opf_env.py:211-214)')
-        return self._finish_obs(), {}
+        obs = self._finish_obs()
+        return (obs.clone() if self.copy_outputs else obs), {}
 
     max_reset_retries = 20
 
@@ -1042,8 +1047,9 @@ class BatchedOpfEnv:
             self.current_simbench_step = None
         else:
             step = np.broadcast_to(np.asarray(step, dtype=np.int64), (B,))
-            if self.uses_profiles:
-                assert (step < len(self.profiles[('load', 'q_mvar')])).all()   # :335
+            n_steps = len(self.profiles[('load', 'q_mvar')]) if self.profiles else 1
+            if (step < 0).any() or (step >= n_steps).any():                # :335 (the reference's .loc raises KeyError)
+                raise KeyError(f"reset option 'step' outside the profile horizon [0, {n_steps})")
             self.current_simbench_step = step.copy()
             self.steps_dev.copy_(t.as_tensor(step.astype(np.int32)))
 
@@ -1052,23 +1058,7 @@ class BatchedOpfEnv:
                 return a.to(device=dev, dtype=t.float64).contiguous()
             return t.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         data_distr = self.test_data if self.test else self.train_data
-        noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params
-                                  or (self.mixed and data_distr == 'mixed'))
-        nf = self.noise_factor if noisy else 0.0
-        normal_noise = noisy and self.noise_distribution == 'normal'
-        noise_t = options.get('noise')
-        if noise_t is not None:
-            noise_t = as_dev(noise_t)          # uniform mode: factors; normal mode: standard-normal draws
-        elif noisy and normal_noise:
-            noise_t = t.randn(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64)   # :359-360
-        elif noisy and nf:
-            noise_t = t.rand(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64) * (nf * 2) \
-                + (1 - nf)                                                     # :354-355
-        interp_t = options.get('interp')
-        if interp_t is not None:
-            interp_t = as_dev(interp_t)
-        elif self.interpolate_steps and self.uses_profiles:
-            interp_t = t.rand(B, len(self.tables), generator=self._gen, device=dev, dtype=t.float64)   # :348
+        noise_t, interp_t, nnf = self._profile_draws(data_distr, options, as_dev)
         uni_t = options.get('uniform')
         if uni_t is None and self.n_uniform:
             uni_t = t.rand(B, self.n_uniform, generator=self._gen, device=dev, dtype=t.float64)
@@ -1085,7 +1075,7 @@ class BatchedOpfEnv:
         rio.interp = interp_t.data_ptr() if interp_t is not None else None
         rio.uniform = uni_t.data_ptr() if uni_t is not None else None
         rio.normal = nrm_t.data_ptr() if nrm_t is not None else None
-        rio.normal_noise_factor = float(nf) if normal_noise else 0.0
+        rio.normal_noise_factor = nnf
         rio.x = self.x.data_ptr()
         rio.keep_state = 1 if (self.carry_over_state and self._state_valid) else 0
         self._state_valid = True
@@ -1097,7 +1087,10 @@ class BatchedOpfEnv:
                 p0, p1 = self.data_probabilities[0], self.data_probabilities[1]
                 mode_t = ((r >= p0).to(t.int32) + (r >= p1).to(t.int32))
             else:
-                mode_t = t.as_tensor(np.broadcast_to(np.asarray(mode_t, dtype=np.int32), (B,)).copy()).to(dev)
+                mode_np = np.broadcast_to(np.asarray(mode_t, dtype=np.int32), (B,)).copy()
+                if (mode_np < 0).any() or (mode_np > 2).any():
+                    raise ValueError("reset option 'mode': 0 (profile row), 1 (uniform), 2 (normal around the mean)")
+                mode_t = t.as_tensor(mode_np).to(dev)
             rio.mode = mode_t.contiguous().data_ptr()
             self.sampling_mode = mode_t
         elif self.per_source:                                              # train and test distribution differ
@@ -1125,9 +1118,37 @@ class BatchedOpfEnv:
                 self._host_finisher.finish(4)
             self.initial_obj.copy_(self.buf['objective'])
 
+    def _profile_draws(self, data_distr, options, as_dev):
+        """Noise and interpolation draws of `_set_simbench_state` (opf_env.py:345-360) for every row:
+        (noise tensor or None, interpolation tensor or None, normal-noise factor).  Explicit draws in `options`
+        ('noise', 'interp') are replayed instead."""
+        t, B, dev = self.torch, self.B, self.device
+        noisy = self.n_noise and (data_distr == 'noisy_simbench' or 'noise_factor' in self.sampling_params
+                                  or (self.mixed and data_distr == 'mixed'))
+        nf = self.noise_factor if noisy else 0.0
+        normal_noise = noisy and self.noise_distribution == 'normal'
+        noise_t = options.get('noise')
+        if noise_t is not None:
+            noise_t = as_dev(noise_t)          # uniform mode: factors; normal mode: standard-normal draws
+        elif noisy and normal_noise:
+            noise_t = t.randn(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64)   # :359-360
+        elif noisy and nf:
+            noise_t = t.rand(B, self.n_noise, generator=self._gen, device=dev, dtype=t.float64) * (nf * 2) \
+                + (1 - nf)                                                     # :354-355
+        interp_t = options.get('interp')
+        if interp_t is not None:
+            interp_t = as_dev(interp_t)
+        elif self.interpolate_steps and self.uses_profiles:
+            interp_t = t.rand(B, len(self.tables), generator=self._gen, device=dev, dtype=t.float64)   # :348
+        return noise_t, interp_t, (float(nf) if normal_noise else 0.0)
+
     def step(self, action):
         """opf_env.py:374-419 for the whole batch: (obs, reward, terminated,
-        truncated, info) as torch tensors on the device."""
+        truncated, info) as torch tensors on the device.
+
+        LIFETIME: the returned tensors are the environment's persistent output buffers (or views of them) —
+        the next `reset()` / `step()` overwrites them in place.  A rollout loop that keeps them across calls
+        must `.clone()` them, or construct the environment with `copy_outputs=True`."""
         t = self.torch
         action = self._as_action(action)
         if self.validate_actions:
@@ -1144,7 +1165,10 @@ class BatchedOpfEnv:
                 'converged': b['converged'], 'iterations': b['iterations'],
                 'max_mismatch': b['max_mismatch'], 'objective': b['objective'],
                 'total_iterations': b['total_iterations'], 'min_pivot': b['min_pivot']}
-        return self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info
+        out = (self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info)
+        if self.copy_outputs:
+            out = tuple(v.clone() for v in out[:4]) + ({k: (v.clone() if self.torch.is_tensor(v) else v) for k, v in info.items()},)
+        return out
 
     def _finish_obs(self):
         """add_mean_obs / add_time_obs post-processing (opf_env.py:539-547)."""
@@ -1168,9 +1192,9 @@ class BatchedOpfEnv:
         else:
             parts = [obs]
         if self.add_time_obs:
-            step = self.current_simbench_step if self.current_simbench_step is not None \
-                else self.steps_dev.cpu().numpy()
-            tobs = get_simbench_time_observation(step)                     # intended semantics (defect D1)
+            # always the step the instance is at NOW (steps_dev is what the reset kernel sampled at and what
+            # multi-stage episodes / partial resets advance; a host copy of the reset option would go stale)
+            tobs = get_simbench_time_observation(self.steps_dev.cpu().numpy())   # intended semantics (defect D1)
             parts = [t.as_tensor(tobs, dtype=t.float64, device=self.device)] + parts
         return t.cat(parts, dim=1) if len(parts) > 1 else parts[0]
 
@@ -1327,10 +1351,18 @@ class MultiStageOpfEnv(BatchedOpfEnv):
 
     def _resample_current(self):
         """reset kernel at self.steps_dev into self.x together with the table observation, no action
-        (what `_sampling` + `_get_obs` do at multi_stage.py:49-56) — one launch."""
+        (what `_sampling(step=new_step)` + `_get_obs` do at multi_stage.py:49-56) — one launch.  `_sampling`
+        merges the environment's sampling_params (opf_env.py:228-237), so every stage draws fresh noise /
+        interpolation weights exactly as a reset does."""
         B, t = self.B, self.torch
         rio = capi.ResetIO()
         rio.step_idx = self.steps_dev.data_ptr()
+        data_distr = self.test_data if self.test else self.train_data
+        noise_t, interp_t, nnf = self._profile_draws(
+            data_distr, {}, lambda a: a.to(device=self.device, dtype=t.float64).contiguous())
+        rio.noise = noise_t.data_ptr() if noise_t is not None else None
+        rio.interp = interp_t.data_ptr() if interp_t is not None else None
+        rio.normal_noise_factor = nnf
         uni = t.rand(B, self.n_uniform, generator=self._gen, device=self.device, dtype=t.float64) \
             if self.n_uniform else None
         rio.uniform = uni.data_ptr() if uni is not None else None

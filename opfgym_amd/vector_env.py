@@ -51,6 +51,10 @@ class OpfVectorEnv:
         self._pending = None          # rows to reset at the start of the next step ('next_step')
         self.metadata = {'autoreset_mode': autoreset_mode}
 
+    # per-instance state a partial reset has to put back for the rows it must not touch (sampling_mode: the
+    # data source an episode started with under train_data='mixed' — multi-stage episodes keep sampling from it)
+    _STATE = ('x', 'step_count', 'initial_obj', 'steps_dev', 'sampling_mode')
+
     # ---- helpers ----------------------------------------------------------------------
     def _out(self, x):
         return x.detach().cpu().numpy() if self.as_numpy and hasattr(x, 'detach') else x
@@ -60,9 +64,9 @@ class OpfVectorEnv:
         (valid in the masked rows)."""
         env = self.env
         if bool(mask.all()):
-            return env.reset()[0]
+            return env.reset()[0].clone()           # (a view of the output buffer: the next step overwrites it)
         keep = ~mask
-        names = [n for n in ('x', 'step_count', 'initial_obj', 'steps_dev') if hasattr(env, n)]
+        names = [n for n in self._STATE if getattr(env, n, None) is not None]
         saved = {n: getattr(env, n).clone() for n in names}
         obs_new = env.reset()[0].clone()
         for n, old in saved.items():
@@ -85,7 +89,7 @@ class OpfVectorEnv:
             # is ignored.  The whole batch is stepped (one launch), then the reset rows get their
             # freshly reset state and observation back and neutral outputs.
             obs_reset = self._reset_rows(pending)
-            names = [n for n in ('x', 'step_count', 'initial_obj', 'steps_dev') if hasattr(env, n)]
+            names = [n for n in self._STATE if getattr(env, n, None) is not None]
             fresh = {n: getattr(env, n).clone() for n in names}
             obs, reward, term, trunc, info = env.step(actions)
             obs, reward, term, trunc = obs.clone(), reward.clone(), term.clone(), trunc.clone()

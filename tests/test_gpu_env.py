@@ -469,6 +469,7 @@ def test_vector_env_same_step_autoreset():
 
 
 def test_vector_env_next_step_and_partial_reset():
+    # (the observation handed out for reset rows is checked against a fresh reset observation below)
     from opfgym_amd import envs
     from opfgym_amd.vector_env import OpfVectorEnv
     B = 8
@@ -490,6 +491,80 @@ def test_vector_env_next_step_and_partial_reset():
     x_before = env.x.clone()
     vec._reset_rows(mask)
     assert torch.equal(env.x[1::2], x_before[1::2]) and not torch.equal(env.x[::2], x_before[::2])
+    # single-step episodes: every second call only resets (all rows) and its action is ignored — the observation
+    # handed out must be the RESET observation (set-points of the centred initial action), not the one of
+    # the ignored action's step that ran through the same output buffer
+    env1 = envs.VoltageControl(simbench_network_name='mv-small', batch_size=B, device='cuda:0', seed=3, add_act_obs=True)
+    vec1 = OpfVectorEnv(env1, autoreset_mode='next_step')
+    vec1.reset(seed=6)
+    vec1.step(np.full((B, env1.n_actions), 0.1))
+    obs, reward, term, trunc, info = vec1.step(np.full((B, env1.n_actions), 0.95))
+    assert (_np(reward) == 0).all()
+    assert np.allclose(_np(env1.get_current_actions()), 0.5, atol=1e-12)          # the state is the reset state
+    n_act = env1.n_actions
+    act_part = _np(obs)[:, -n_act:]
+    q_reset = _np(env1.x[:, env1._act_desc['slot']])
+    assert np.allclose(act_part, q_reset, rtol=0, atol=1e-12)                     # ... and so is the observation
+
+
+def test_returned_buffers_lifetime_and_copy_outputs():
+    """step()/reset() hand out the persistent output buffers (documented); `copy_outputs=True` returns clones
+    that a rollout loop may keep."""
+    from opfgym_amd import envs
+    B = 8
+    rng = np.random.default_rng(2)
+    for copy_ in (False, True):
+        env = envs.VoltageControl(simbench_network_name='mv-small', batch_size=B, device='cuda:0', seed=5,
+                                  copy_outputs=copy_)
+        env.reset(options={'step': rng.choice(env.train_steps, B)})
+        _, r1, *_ = env.step(rng.random((B, env.n_actions)))
+        kept = _np(r1).copy()
+        env.reset(options={'step': rng.choice(env.train_steps, B)})
+        _, r2, *_ = env.step(rng.random((B, env.n_actions)))
+        assert (r1.data_ptr() == r2.data_ptr()) == (not copy_)
+        if copy_:
+            assert np.array_equal(_np(r1), kept)                  # what was handed out stays what it was
+        else:
+            assert np.array_equal(_np(r1), _np(r2)) and not np.array_equal(_np(r1), kept)   # same buffer, overwritten
+
+
+def test_reset_options_are_validated():
+    from opfgym_amd import envs
+    env = envs.VoltageControl(simbench_network_name='mv-small', batch_size=4, device='cuda:0', seed=5,
+                              train_data='mixed', test_data='mixed')
+    with pytest.raises(KeyError):
+        env.reset(options={'step': -1})
+    with pytest.raises(KeyError):
+        env.reset(options={'step': 10 ** 6})
+    with pytest.raises(ValueError):
+        env.reset(options={'mode': 3})
+    env.reset(options={'step': 5, 'mode': 0})
+
+
+def test_multi_stage_resamples_noise_and_time_observation_every_stage():
+    """multi_stage.py:49-56 re-runs `_sampling(step=new_step)`, which merges the sampling_params
+    (opf_env.py:228-237): later stages are noisy too, and the time observation follows the stage's step even when
+    the episode was started at an explicit step."""
+    from opfgym_amd import envs
+    from opfgym_amd.simbench_build import get_simbench_time_observation
+    B = 16
+    env = envs.MultiStageOpf(simbench_network_name='1-LV-rural1--0-sw', steps_per_episode=3, batch_size=B,
+                             device='cuda:0', seed=9, add_time_obs=True, sampling_params={'noise_factor': 0.2})
+    ref = envs.MultiStageOpf(simbench_network_name='1-LV-rural1--0-sw', steps_per_episode=3, batch_size=B,
+                             device='cuda:0', seed=9, add_time_obs=True)
+    steps = np.full(B, 5000)
+    for e in (env, ref):
+        e.reset(options={'step': steps})
+    a = np.full((B, env.n_actions), 0.5)
+    o1, *_ = env.step(a)
+    o0, *_ = ref.step(a)
+    o1, o0 = _np(o1), _np(o0)
+    assert np.allclose(o1[:, :6], get_simbench_time_observation(steps + 1), rtol=0, atol=1e-12)     # advanced by one stage
+    assert np.allclose(o0[:, :6], o1[:, :6])
+    load = slice(6, 6 + len(env.net.load))
+    assert np.abs(o1[:, load] / o0[:, load] - 1).max() > 0.01                    # stage 2 of the noisy env IS noisy
+    assert np.abs(o1[:, load] / o0[:, load] - 1).max() <= 0.2 + 1e-9             # ... within the noise factor
+    assert np.abs(o1[0, load] - o1[1, load]).max() > 0                          # ... and per instance
 
 
 def test_mixed_sampling_draws_a_source_per_instance():
