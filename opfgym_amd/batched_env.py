@@ -405,6 +405,80 @@ class BatchedOpfEnv:
         if not defer_device:
             self.attach_device()
 
+    @classmethod
+    def from_reference(cls, ref_env, batch_size=1, device='cuda:0', sampling_ops=None, **overrides):
+        """Batched twin of a CONSTRUCTED reference environment (`opfgym.OpfEnv` or a subclass): the problem
+        definition is read off the object — `ref_env.net`, action / observation / state keys, profiles,
+        constraints, reward function with its (already estimated) scaling, the OpfEnv options, the data split,
+        N-1 keys — nothing of it is restated here.  What a Python object cannot hand over as data is its
+        `_sampling` override (the per-reset tail, e.g. voltage_control.py:111-133): `sampling_ops(env, ops)`
+        re-expresses it as reset-kernel ops; for the reference's own classes the tails of `opfgym_amd.envs` are
+        picked by class name.  Python callables in the objective / constraint seams run through the host
+        fallback (opfgym_amd/host_fallback.py)."""
+        from . import definition, envs as envs_mod
+        defn = definition.extract(ref_env)
+        names = [k.__name__ for k in type(ref_env).__mro__]
+        base = MultiStageOpfEnv if 'MultiStageOpfEnv' in names else cls
+        if sampling_ops is None:
+            tail_cls = next((getattr(envs_mod, n) for n in names if isinstance(getattr(envs_mod, n, None), type)
+                             and '_sampling_ops' in vars(getattr(envs_mod, n))), None)
+            overrides_sampling = any('_sampling' in vars(k) for k in type(ref_env).__mro__ if k.__name__ not in ('OpfEnv', 'object'))
+            if tail_cls is None and overrides_sampling:
+                raise NotImplementedError(
+                    f'{type(ref_env).__name__} overrides `_sampling`; pass sampling_ops=callable(env, ops) that '
+                    f're-expresses it with the OpsBuilder operations (see opfgym_amd/envs.py for the reference classes)')
+            sampling_ops = (lambda env, ops: tail_cls._sampling_ops(env, ops)) if tail_cls is not None else None
+        kind = type('FromReference' + type(ref_env).__name__, (base,),
+                    {'_sampling_ops': (lambda self, ops: sampling_ops(self, ops)) if sampling_ops else base._sampling_ops})
+        rf = ref_env.reward_function
+        prf = reward_mod.load_reward_class(type(rf).__name__)(**({} if type(rf).__name__ == 'OnlyObjective' else
+                                                              {'penalty_weight': rf.penalty_weight}))
+        prf.clip_range = getattr(rf, 'clip_range', None)
+        prf.scaling_params = dict(rf.scaling_params)
+        for attr in ('valid_reward', 'invalid_penalty', 'invalid_objective_share'):
+            if hasattr(rf, attr):
+                setattr(prf, attr, getattr(rf, attr))
+        cons = []
+        for c_ in ref_env.constraints:
+            twin = getattr(constraints_mod, type(c_).__name__, None)
+            custom_values = 'get_bounded_values' in vars(c_) or 'get_boundaries' in vars(c_)
+            if twin is None or custom_values or type(c_).__name__ == 'Constraint' and custom_values:
+                cons.append(c_)                        # evaluated on the host through its own get_violation_metrics
+                continue
+            args = dict(only_worst_case_violations=c_.only_worst_case_violations, autoscale_violation=c_.autoscale_violation,
+                        scale_bounded_values=c_.scale_bounded_values, penalty_factor=c_.penalty_factor,
+                        penalty_power=c_.penalty_power, violation_count_penalty=c_.violation_count_penalty)
+            cons.append(twin(c_.unit_type, c_.values_column, **args) if twin is constraints_mod.Constraint else twin(**args))
+        objective = getattr(ref_env, 'objective_function', None)
+        if getattr(objective, '__name__', '') == 'get_pandapower_costs':
+            objective = None                            # the cost tables of the net (objective.py:6-32): device
+        for attr in ('market_based', 'storage_efficiency'):          # constructor values the tails of envs.py read
+            if hasattr(ref_env, attr):
+                setattr(kind, attr, getattr(ref_env, attr))
+        if type(ref_env).__name__ == 'LoadShedding':
+            kind.pwl_price_columns = {'neg_price_eur_per_mw': 0, 'pos_price_eur_per_mw': 1}
+        kw = dict(state_keys=defn.state_keys, profiles=defn.profiles, evaluate_on=ref_env.evaluate_on,
+                  steps_per_episode=ref_env.steps_per_episode, bus_wise_obs=ref_env.bus_wise_obs,
+                  reward_function=prf, diff_objective=ref_env.diff_objective,
+                  add_time_obs=ref_env.add_time_obs, add_mean_obs=ref_env.add_mean_obs,
+                  train_data=ref_env.train_data, test_data=ref_env.test_data, sampling_params=dict(ref_env.sampling_params),
+                  custom_constraints=cons, autoscale_actions=ref_env.autoscale_actions,
+                  diff_action_step_size=ref_env.diff_action_step_size,
+                  clipped_action_penalty=ref_env.clipped_action_penalty, initial_action=ref_env.initial_action,
+                  objective_function=objective, batch_size=batch_size, device=device, defer_device=True)
+        if defn.n_minus_one_keys:
+            kw.update(n_minus_one_keys=defn.n_minus_one_keys, not_converged_penalty=ref_env.not_converged_penalty)
+        kw.update(overrides)
+        defer = kw.pop('defer_device') if 'defer_device' in overrides else False
+        kw['defer_device'] = True
+        env = kind(defn.net, defn.act_keys, defn.obs_keys, **kw)        # (obs_keys already carry the add_act/add_res keys)
+        env.test_steps, env.validation_steps, env.train_steps = (np.asarray(v) for v in (
+            ref_env.test_steps, ref_env.validation_steps, ref_env.train_steps))
+        env.definition = defn
+        if not defer:
+            env.attach_device()
+        return env
+
     def attach_device(self):
         """Upload the plan, create the device evaluator and allocate the batch
         buffers.  Everything before this point is host-only problem compilation."""

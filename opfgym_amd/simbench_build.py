@@ -1,84 +1,13 @@
-"""Grid + profile preparation for the benchmark environments.
-
-Host-side, once per environment.  Same behaviour as the reference's
-`opfgym/simbench/build_simbench_net.py:5-97`, `data_split.py:5-59` and
-`time_observation.py:4-22`, working on :class:`opfgym_amd.net.Net` tables (or a
-real pandapowerNet) and a profile dict.  The grid itself comes from
-`opfgym_amd.grids.get_grid` (synthetic stand-ins: SimBench is not available
-here) or from the caller.
+"""Host-side helpers around the SimBench time series: the train / validation / test split
+(`data_split.py:5-59`) and the time observation (`time_observation.py:4-22`) that the environment needs at
+run time, plus two helpers for the synthetic stand-in grids.  (Grid preparation itself — scaling columns,
+system constraints, profile repair, limits from the profiles, `build_simbench_net.py:5-97` — is the
+reference's and reaches this package as data, see opfgym_amd/definition.py.)
 """
 from __future__ import annotations
 
 import numpy as np
 
-from . import grids
-
-
-def build_simbench_net(simbench_network_name, gen_scaling=1.0, load_scaling=1.0,
-                       storage_scaling=1.0, voltage_band=0.05, max_loading=80,
-                       grid_seed=0, net=None, profiles=None, *args, **kwargs):
-    """build_simbench_net.py:5-23: scaling columns, system constraints,
-    profile repair, min/max/mean/std columns from the profiles."""
-    if net is None:
-        net, profiles = grids.get_grid(simbench_network_name, grid_seed)
-    set_unit_scaling(net, gen_scaling, load_scaling, storage_scaling)
-    set_system_constraints(net, voltage_band, max_loading)
-    repair_simbench_profiles(net, profiles)
-    set_constraints_from_profiles(net, profiles)
-    return net, profiles
-
-
-def set_unit_scaling(net, gen_scaling=1.0, load_scaling=1.0, storage_scaling=1.0):
-    # build_simbench_net.py:26-31
-    net.sgen['scaling'] = gen_scaling
-    net.gen['scaling'] = gen_scaling
-    net.load['scaling'] = load_scaling
-    net.storage['scaling'] = storage_scaling
-
-
-def set_system_constraints(net, voltage_band=None, max_loading=None):
-    # build_simbench_net.py:34-42
-    if voltage_band:
-        net.bus['max_vm_pu'] = 1 + voltage_band
-        net.bus['min_vm_pu'] = 1 - voltage_band
-    if max_loading:
-        net.line['max_loading_percent'] = max_loading
-        net.trafo['max_loading_percent'] = max_loading
-
-
-def repair_simbench_profiles(net, profiles):
-    # build_simbench_net.py:45-64: negative sgen power -> 0; drop constant units
-    sg = profiles[('sgen', 'p_mw')]
-    sg[sg < 0.0] = 0.0
-    for key in list(profiles.keys()):
-        df = profiles[key]
-        tbl = net[key[0]]
-        is_equal = df.max(axis=0) == df.min(axis=0)
-        tbl.drop(tbl[is_equal].index, inplace=True)
-        df.drop(columns=df.columns[is_equal], inplace=True)
-
-
-def set_constraints_from_profiles(net, profiles):
-    # build_simbench_net.py:67-97
-    for (unit_type, column), df in profiles.items():
-        tbl = net[unit_type]
-        if unit_type == 'storage':
-            max_power = np.maximum(df.max(axis=0).abs(), df.min(axis=0).abs())
-            tbl[f'max_max_{column}'] = max_power * tbl.scaling
-            tbl[f'min_min_{column}'] = -max_power * tbl.scaling
-        else:
-            tbl[f'max_max_{column}'] = df.max(axis=0) * tbl.scaling
-            tbl[f'min_min_{column}'] = df.min(axis=0) * tbl.scaling
-        tbl[f'mean_{column}'] = df.mean(axis=0)
-        tbl[f'std_dev_{column}'] = df.std(axis=0)
-    diff = profiles[('load', 'p_mw')].sum(axis=1) - profiles[('sgen', 'p_mw')].sum(axis=1)
-    net.ext_grid['max_max_p_mw'] = diff.max()
-    net.ext_grid['min_min_p_mw'] = diff.min()
-    net.ext_grid['mean_p_mw'] = diff.mean()
-    load_q = profiles[('load', 'q_mvar')].sum(axis=1)
-    net.ext_grid['max_max_q_mvar'] = load_q.max()
-    net.ext_grid['min_min_q_mvar'] = load_q.min()
-    net.ext_grid['mean_q_mvar'] = load_q.mean()
 
 
 def gens_to_fixed_sgens(net, profiles):
@@ -101,7 +30,14 @@ def gens_to_fixed_sgens(net, profiles):
     net.gen = net.gen.iloc[0:0]
     net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
     net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
-    set_constraints_from_profiles(net, profiles)
+    # limit / mean / std columns follow the profiles: recomputed by the reference's own function where the
+    # reference is at hand (recording a definition); a recorded definition already carries them
+    try:
+        from opfgym.simbench.build_simbench_net import set_constraints_from_profiles
+    except Exception:
+        return net, profiles
+    if 'scaling' in net.sgen.columns and 'scaling' in net.load.columns and 'scaling' in net.storage.columns:
+        set_constraints_from_profiles(net, profiles)
     return net, profiles
 
 

@@ -288,7 +288,7 @@ def main():
             checked = run_one(base, kw, rng)
             total += checked
             print(f'[{c}] ok   {base} checked={checked} {kw}')
-        except (NotImplementedError, KeyError) as e:
+        except (NotImplementedError, KeyError, ImportError) as e:
             print(f'[{c}] skip {base} {kw}: {e}')
         except AssertionError as e:
             bad += 1

@@ -1,0 +1,64 @@
+"""CPU: the recorded problem definitions (opfgym_amd/definitions/) — DATA written by
+tests/golden/make_definitions.py from the reference's own environment classes — load everywhere, and, where the
+reference is at hand (the build container), are reproduced bit for bit by that script and equal what
+`BatchedOpfEnv.from_reference` reads off the live reference objects."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from opfgym_amd import definition, envs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REFERENCE = os.path.isdir('/root/reference/opfgym')
+
+
+def test_every_recorded_definition_loads():
+    idx = json.load(open(os.path.join(definition.DEF_DIR, 'index.json')))
+    assert len(idx) >= 20
+    for key, name in idx.items():
+        d = definition.load(os.path.join(definition.DEF_DIR, name))
+        assert len(d.net.bus) > 0 and len(d.act_keys) > 0 and len(d.obs_keys) > 0, name
+        ref_path = json.loads(key)[0]
+        assert ref_path.startswith('opfgym.') and ref_path.rsplit('.', 1)[1] == d.class_name
+        for unit, col, idxs in d.act_keys + d.obs_keys + d.state_keys:
+            assert set(idxs) <= set(d.net[unit].index), (name, unit, col)
+        if d.profiles:
+            for (unit, col), df in d.profiles.items():
+                assert set(df.columns) <= set(d.net[unit].index) and df.shape[0] == 35136, (name, unit, col)
+
+
+def test_unrecorded_arguments_fail_loudly_without_the_reference():
+    if definition.reference_class('opfgym.envs.VoltageControl') is not None:
+        pytest.skip('the reference is importable here')
+    with pytest.raises(ImportError, match='no recorded definition'):
+        envs.VoltageControl(simbench_network_name='mv-small', cos_phi=0.5, batch_size=1, defer_device=True)
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason='needs /root/reference (build container only)')
+def test_recorded_definitions_are_reproduced_from_the_reference(tmp_path):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', OPFX_DEF_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, '-B', os.path.join(ROOT, 'tests', 'golden', 'make_definitions.py')],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    new = json.load(open(tmp_path / 'index.json'))
+    old = json.load(open(os.path.join(definition.DEF_DIR, 'index.json')))
+    assert new == old
+    for name in old.values():
+        a, b = np.load(tmp_path / name), np.load(os.path.join(definition.DEF_DIR, name))
+        assert set(a.files) == set(b.files), name
+        for k in a.files:
+            x, y = a[k], b[k]
+            same = np.array_equal(x, y, equal_nan=True) if x.dtype.kind == 'f' else np.array_equal(x, y)
+            assert same, (name, k)
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason='needs /root/reference (build container only)')
+def test_from_reference_reads_the_same_definition_off_live_reference_objects():
+    r = subprocess.run([sys.executable, '-B', os.path.join(ROOT, 'tests', 'golden', 'check_from_reference.py')],
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count('same definition') >= 10

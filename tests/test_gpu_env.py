@@ -408,8 +408,8 @@ def test_n_minus_one_on_switched_and_tapped_branches():
 
     class ReconfN1(SecurityConstrainedOpfEnv):
         def __init__(self, **kw):
-            self.controllable_switch_idxs = np.array((1, 3))
-            net, profiles = envs.NetworkReconfiguration._define_opf(self, 'hv-small-sw')
+            base = envs.NetworkReconfiguration(simbench_network_name='hv-small-sw', batch_size=1, defer_device=True)
+            net, profiles = base.definition.net, base.definition.profiles
             obs_keys = [('load', 'p_mw', net.load.index)]
             act_keys = [('switch', 'closed', net.switch.index[net.switch.controllable.to_numpy(bool)]),
                         ('trafo', 'tap_pos', net.trafo.index)]

@@ -7,7 +7,7 @@ import pandas as pd
 import pytest
 
 from opfgym_amd import constraints as pc, grids, net as ppn, reward as pr
-from opfgym_amd.simbench_build import (build_simbench_net, define_test_train_split,
+from opfgym_amd.simbench_build import (define_test_train_split,
                                        get_simbench_time_observation)
 from oracle import env_oracle as eo
 
@@ -211,12 +211,14 @@ def test_time_observation():
     assert t.shape == (2, 6) and np.isclose(t[0, 0], 1.0) and np.isclose(t[1, 2], 1.0)
 
 
-def test_build_simbench_net_columns():          # reference tests/test_simbench.py:15-76
-    net, prof = build_simbench_net('mv-small', gen_scaling=1.3, load_scaling=1.5, voltage_band=0.04,
-                                   max_loading=70)
+def test_build_simbench_net_columns():          # reference tests/test_simbench.py:15-76, on a recorded definition
+    from opfgym_amd import envs
+    env = envs.VoltageControl(simbench_network_name='mv-small', voltage_band=0.02, max_loading=40, batch_size=1,
+                              defer_device=True)
+    net, prof = env.net, env.profiles
     assert (net.sgen.scaling == 1.3).all() and (net.load.scaling == 1.5).all()
-    assert (net.bus.max_vm_pu == 1.04).all() and (net.bus.min_vm_pu == 0.96).all()
-    assert (net.line.max_loading_percent == 70).all() and (net.trafo.max_loading_percent == 70).all()
+    assert (net.bus.max_vm_pu == 1.02).all() and (net.bus.min_vm_pu == 0.98).all()
+    assert (net.line.max_loading_percent == 40).all() and (net.trafo.max_loading_percent == 40).all()
     assert np.allclose(net.load.max_max_p_mw, prof[('load', 'p_mw')].max() * 1.5)
     assert np.allclose(net.sgen.min_min_p_mw, prof[('sgen', 'p_mw')].min() * 1.3)
     assert (prof[('sgen', 'p_mw')].to_numpy() >= 0).all()
