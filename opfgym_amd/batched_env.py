@@ -1121,9 +1121,12 @@ class BatchedOpfEnv:
             self.current_simbench_step = None
         else:
             step = np.broadcast_to(np.asarray(step, dtype=np.int64), (B,))
-            n_steps = len(self.profiles[('load', 'q_mvar')]) if self.profiles else 1
-            if (step < 0).any() or (step >= n_steps).any():                # :335 (the reference's .loc raises KeyError)
-                raise KeyError(f"reset option 'step' outside the profile horizon [0, {n_steps})")
+            if self.uses_profiles:                                         # (without time series the step is not used)
+                n_steps = len(self.profiles[('load', 'q_mvar')])
+                if (step < 0).any() or (step >= n_steps).any():            # :335 (the reference's .loc raises KeyError)
+                    raise KeyError(f"reset option 'step' outside the profile horizon [0, {n_steps})")
+            else:
+                step = np.zeros(B, dtype=np.int64)
             self.current_simbench_step = step.copy()
             self.steps_dev.copy_(t.as_tensor(step.astype(np.int32)))
 
