@@ -102,6 +102,12 @@ typedef struct opfx_plan_info {
   /* register-resident lane programme (rounds of 64 work items); -1 = not built */
   int32_t lp_rounds_a, lp_rounds_h, lp_rounds_b, lp_rounds_c;
   int32_t n_full;            /* blocks [0,n_full) store 4 values, [n_full,n_blk) two (a,b of [[a,b],[-b,a]]) */
+  /* wave-team form of the factor/solve stream, [0]: teams of 2 wavefronts, [1]: of 4 */
+  int32_t team_rounds[2];    /* rounds each wavefront of a team walks per NR iteration            */
+  int32_t team_barriers[2];  /* workgroup barriers among them (groups that end with one)          */
+  int32_t n_groups;          /* independent groups of the stream (elimination levels of B and C)  */
+  int32_t team_kb[2];        /* rounds before the dense tail's register chain (= team_rounds without a tail) */
+  int32_t tail_m;            /* pivots of the dense tail (final levels with one pivot each), 0 = none */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
@@ -123,7 +129,10 @@ enum {
   OPFX_ARR_LP_A_ENT, OPFX_ARR_LP_A_DBLK, OPFX_ARR_LP_H_ENT, OPFX_ARR_LP_H_ROW,
   OPFX_ARR_LP_B, OPFX_ARR_LP_C,
   OPFX_ARR_BR_ISLAND,  /* [nbr] 1 = taking this branch out cuts some bus off every REF bus */
-  OPFX_ARR_ISL_PTR, OPFX_ARR_ISL_BUS   /* CSR [nbr+1] -> the buses that outage cuts off (they are de-energised) */
+  OPFX_ARR_ISL_PTR, OPFX_ARR_ISL_BUS,  /* CSR [nbr+1] -> the buses that outage cuts off (they are de-energised) */
+  OPFX_ARR_LP_TEAM2, OPFX_ARR_LP_TEAM4, /* wave-team streams [round][wave][64][4] */
+  OPFX_ARR_TAIL_BUS,                    /* [32] bus | diagonal block << 16 of the dense tail's pivots */
+  OPFX_ARR_TAIL_IDS                     /* [tail_m + 1][M] U-block ids inside the tail (0xFFFF none), M = tail_m rounded up to 8 */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };

@@ -26,7 +26,7 @@ OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, O
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
-          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS']
+          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS']
 DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y']
 
 _pd = C.POINTER(C.c_double)
@@ -48,7 +48,9 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'nb', 'nbr', 'nref', 'npv', 'npq', 'nnz_y', 'nnz_j', 'n_blk', 'n_fill', 'n_levels',
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
-        'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full')]
+        'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full',
+        'team_rounds_2', 'team_rounds_4', 'team_barriers_2', 'team_barriers_4', 'n_groups',
+        'team_kb_2', 'team_kb_4', 'tail_m')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

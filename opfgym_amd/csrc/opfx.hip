@@ -67,7 +67,10 @@ struct DevPlan {
   const int* lp_hrows;
   int n_hrows;
   const unsigned *lp_team2, *lp_team4;   // per-wave streams of the cooperative kernels (plan.h)
-  int team_rounds2, team_rounds4;
+  int tail_m, tail_n;                    // dense tail of the elimination, solved in registers (plan.cpp; 0: none); entries of tail_ids
+  const unsigned* tail_bus;              // [32] bus | diagonal block << 16 of tail pivot e
+  const unsigned short* tail_ids;        // [tail_m][M] id of U-block (row e, column s) at [e * M + s], M = tail_m rounded up to 8
+  int team_rounds2, team_rounds4, team_kb2, team_kb4;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
 };
@@ -256,6 +259,7 @@ struct Lds {
   int o2, o3;
   double* mod;               // per-instance branch modifiers (MOD_DOUBLES each), see mods_*
   unsigned short* dg;        // [nb] diagonal block of every bus (copied from the plan once per workgroup)
+  unsigned short* tl;        // [tail_m + 1][M] U-block ids of the dense tail (DevPlan::tail_ids; last row: none), likewise; 16-byte aligned
 };
 // Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
 // (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
@@ -504,7 +508,7 @@ __device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a1
 // that the reads of the NEXT round can be in flight while this round computes, whenever the plan marks the two
 // rounds as independent (ITEM_NEXT_INDEPENDENT: same elimination level / same back-substitution group).
 struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22; };
-constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;       // flags in word 3 of a round's items (plan.cpp)
+constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;   // flags in word 3 of a round's items (plan.cpp)
 template <bool PK>
 __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
@@ -561,6 +565,88 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
   const ItemRegs r = item_load<PK>(L, d);
   item_apply<PK>(L, d, r);
+}
+// Back substitution through the dense tail of the elimination (plan.cpp: the last m levels hold one pivot each
+// and their U-rows are full): a strictly serial chain.  As LDS groups it costs one round trip + one 2x2 inverse
+// per level with a handful of live lanes (13.7 % of the 306-bus step).  Here wavefront 0 runs it in registers
+// between the two parts of the team stream: lane e owns tail pivot e and keeps y_e and A_ee^-1; step s sends
+// x_s = A_ss^-1 y_s to the other lanes with v_readlane and the lanes e < s subtract U_es x_s.  The other
+// wavefronts wait at the barrier meanwhile, so what counts is the NUMBER of instructions wavefront 0 issues
+// (a lone wave issues in order), not the depth of the chain: per step four LDS reads (the lane's U-block ids
+// came in one read; tail blocks always hold four values, plan.cpp), x on every lane (only lane s's is used),
+// four readlanes, four FMAs, and a select with a compile-time lane mask instead of a branch.  Windows of
+// OPFX_TAIL_W steps, double buffered; compiler barriers keep the scheduler from hoisting ALL reads of the
+// unrolled chain (it spills).
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+struct TailBlk { double u11, u12, u21, u22; bool live; };
+template <int M>
+__device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, double& y0, double& y1,
+                                           double i11, double i12, double i21, double i22) {
+  // the lane's row of U-block ids: M 16-bit entries, entry s = block (row e, column s)
+  unsigned w[M / 2];
+  {
+    const uint4* tr = reinterpret_cast<const uint4*>(L.tl + row * M);
+#pragma unroll
+    for (int q = 0; q < M / 8; ++q) { const uint4 v = tr[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+  }
+  auto request = [&](int s) {
+    TailBlk t{0.0, 0.0, 0.0, 0.0, false};
+    if (s < 1) return t;                                   // (compile-time after unrolling)
+    const unsigned id = (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
+    t.live = id != 0xFFFFu;                                // (a tail that is not completely filled in)
+    const double* p = L.blk + (t.live ? id : 0u);
+    t.u11 = p[0]; t.u12 = p[L.bs]; t.u21 = p[L.o2]; t.u22 = p[L.o3];
+    return t;
+  };
+  auto apply = [&](const TailBlk& t, int s) {
+    if (s < 1) return;
+    const double x0 = readlane_f64(i11 * y0 + i12 * y1, s), x1 = readlane_f64(i21 * y0 + i22 * y1, s);
+    const double n0 = fma(-t.u11, x0, fma(-t.u12, x1, y0)), n1 = fma(-t.u21, x0, fma(-t.u22, x1, y1));
+    const bool upd = lane < s && t.live;                   // (rows s.. are final: a constant lane mask)
+    y0 = upd ? n0 : y0;
+    y1 = upd ? n1 : y1;
+  };
+#ifndef OPFX_TAIL_W
+#define OPFX_TAIL_W 2
+#endif
+  constexpr int W = OPFX_TAIL_W, NWIN = (M - 1 + W - 1) / W;      // steps M-1 .. 1 in windows of W
+  TailBlk b[2][W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) b[0][q] = request(M - 1 - q);
+#pragma unroll
+  for (int win = 0; win < NWIN; ++win) {
+    const int s0 = M - 1 - W * win;
+    if (win + 1 < NWIN) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) b[(win + 1) & 1][q] = request(s0 - W - q);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < W; ++q) apply(b[win & 1][q], s0 - q);
+    asm volatile("" ::: "memory");
+  }
+}
+// `tail`: bus | diagonal block << 16 of the lane's tail pivot (DevPlan::tail_bus, read once per solve).
+// The chain is instantiated for M = the next multiple of 8 >= tail_m; lanes >= tail_m carry y = 0 and an
+// id row of "none" (row tail_m of the table).
+__device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsigned tail) {
+  const bool mine = lane < m;
+  const int bus = mine ? (int)(tail & 0xFFFFu) : 0;
+  const double* p = L.blk + (mine ? tail >> 16 : 0u);  // (diagonal blocks always hold four values)
+  const double a11 = p[0], a12 = p[L.bs], a21 = p[L.o2], a22 = p[L.o3];
+  double y0 = L.rhs[bus], y1 = L.rq[bus];
+  const double rdet = mine ? fast_rcp(a11 * a22 - a12 * a21) : 0.0;
+  const double i11 = a22 * rdet, i12 = -a12 * rdet, i21 = -a21 * rdet, i22 = a11 * rdet;
+  const int row = mine ? lane : m;                       // (row m of the table: all "none")
+  if (m <= 8) tail_chain<8>(L, row, lane, y0, y1, i11, i12, i21, i22);
+  else if (m <= 16) tail_chain<16>(L, row, lane, y0, y1, i11, i12, i21, i22);
+  else if (m <= 24) tail_chain<24>(L, row, lane, y0, y1, i11, i12, i21, i22);
+  else tail_chain<32>(L, row, lane, y0, y1, i11, i12, i21, i22);
+  if (mine) { L.rhs[bus] = y0; L.rq[bus] = y1; }
 }
 // One round of a wave team's B/C stream.  (Issuing the NEXT round's reads before this round computes —
 // the plan marks independent rounds, ITEM_NEXT_INDEPENDENT — was tried and is slower: the compiler's wait-count
@@ -944,6 +1030,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   const int nb = P.nb;
   const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
   const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4;        // multiple of 4, >= 4
+  const int Kb = NW == 2 ? P.team_kb2 : P.team_kb4;               // rounds before the tail chain (= K without a tail)
   auto ld_desc = [&](int k) { return stream[(size_t)(k < K ? k : k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
   const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
   double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
@@ -952,6 +1039,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   bool conv = false;
   OPFX_STAMP_INIT();
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
+  const unsigned tail = P.tail_bus[lane & 31];     // the lane's pivot of the dense tail (tail_solve)
   // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
   const double* psp_g = L.psp; const double* qsp_g = L.qsp;
   const int r_first = wave < P.ra ? wave : 0;
@@ -1059,11 +1147,21 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     ++it;
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
-    for (int k = 0; k < K; k += 4) {
+    for (int k = 0; k < Kb; k += 4) {
       team_step<PK>(L, q0); q0 = ld_desc(k + 4);
       team_step<PK>(L, q1); q1 = ld_desc(k + 5);
       team_step<PK>(L, q2); q2 = ld_desc(k + 6);
       team_step<PK>(L, q3); q3 = ld_desc(k + 7);
+    }
+    if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
+      if (wave == 0) tail_solve(L, P.tail_m, lane, tail);
+      lds_barrier();
+      for (int k = Kb; k < K; k += 4) {
+        team_step<PK>(L, q0); q0 = ld_desc(k + 4);
+        team_step<PK>(L, q1); q1 = ld_desc(k + 5);
+        team_step<PK>(L, q2); q2 = ld_desc(k + 6);
+        team_step<PK>(L, q3); q3 = ld_desc(k + 7);
+      }
     }
     OPFX_STAMP(2);
     // ---- phase D ---------------------------------------------------------------------------------
@@ -1359,6 +1457,10 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   L.mod = L.acc + nacc;
   L.bt = reinterpret_cast<unsigned char*>(L.mod + MOD_DOUBLES * nmod);
   L.dg = reinterpret_cast<unsigned short*>(L.bt + ((nb + 1) & ~1));
+  {   // the tail table is read with 16-byte LDS loads
+    const size_t off = (size_t)(reinterpret_cast<char*>(L.dg + ((nb + 1) & ~1)) - reinterpret_cast<char*>(base));
+    L.tl = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(base) + ((off + 15) & ~(size_t)15));
+  }
   return L;
 }
 
@@ -1371,7 +1473,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
   const Lds L = carve<V2>(P, 0, nres_, smem, 8, 1);
-  if (V2) { for (int i = threadIdx.x; i < P.nb; i += blockDim.x) L.dg[i] = (unsigned short)P.diag_blk[i]; blk_sync<NW>(); }
+  if (V2) {
+    for (int i = threadIdx.x; i < P.nb; i += blockDim.x) L.dg[i] = (unsigned short)P.diag_blk[i];
+    for (int i = threadIdx.x; i < P.tail_n; i += blockDim.x) L.tl[i] = P.tail_ids[i];
+    blk_sync<NW>();
+  }
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
@@ -1492,7 +1598,11 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
-  if (V2) { for (int i = tid; i < nb; i += NT) L.dg[i] = (unsigned short)P.diag_blk[i]; blk_sync<NW>(); }
+  if (V2) {
+    for (int i = tid; i < nb; i += NT) L.dg[i] = (unsigned short)P.diag_blk[i];
+    for (int i = tid; i < P.tail_n; i += NT) L.tl[i] = P.tail_ids[i];
+    blk_sync<NW>();
+  }
   OPFX_STAMP_INIT();
   for (long long b = blockIdx.x; b < B; b += gridDim.x) {
     double* xr = io.x + b * E.nx;
@@ -2063,7 +2173,8 @@ size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc,
   const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)n_full + 1) & ~(size_t)1;
   size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 4 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
-  size_t bytes = d * sizeof(double) + (((size_t)p.nb + 1) & ~(size_t)1) + (v2 ? 2 * (size_t)p.nb : 0);      // + bus types, diagonal block ids
+  size_t bytes = d * sizeof(double) + (((size_t)p.nb + 1) & ~(size_t)1) +       // + bus types, diagonal block ids, tail table
+                 (v2 ? 2 * ((((size_t)p.nb + 1) & ~(size_t)1) + p.tail_ids.size()) + (p.tail_ids.empty() ? 0 : 16) : 0);
   return (bytes + 15) & ~(size_t)15;
 }
 
@@ -2171,6 +2282,10 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
   if (rc == OPFX_OK) rc = A.put(p->lp_team[1], &d.lp_team4);
   d.team_rounds2 = p->team_rounds[0]; d.team_rounds4 = p->team_rounds[1];
+  d.team_kb2 = p->team_kb[0]; d.team_kb4 = p->team_kb[1];
+  d.tail_m = p->tail_m; d.tail_n = (int)p->tail_ids.size();
+  if (rc == OPFX_OK) rc = A.put(p->tail_bus, &d.tail_bus);
+  if (rc == OPFX_OK) rc = A.put(p->tail_ids, &d.tail_ids);
   {
     void* ws = nullptr;
     const size_t n_ws = (size_t)c->n_cu * 16 * 2 * (size_t)p->nb;

@@ -67,6 +67,14 @@ struct BlockMap {
 //                             targets: they keep the shape [[a, b], [-b, a]] of dS/d(theta, ln|V|),
 //                             so the kernels store only (a, b) for them (a quarter of the LU
 //                             values of a radial grid: 26.2 -> 21.7 KB of LDS per 144-bus instance).
+// The dense tail of the elimination: the run of final levels that hold ONE pivot each (see build_lane_programs).
+int tail_length(const opfx_plan* p) {
+  const int nlev = p->n_levels();
+  int m = 0;
+  for (int lev = nlev - 1; lev >= 0 && p->lev_pptr[lev + 1] - p->lev_pptr[lev] == 1 && m < opfx_plan::TAIL_MAX; --lev) ++m;
+  return (m < 4 || getenv("OPFX_NO_TAIL")) ? 0 : m;
+}
+
 void renumber_blocks(opfx_plan* p) {
   const int32_t n = p->n_blk;
   std::vector<char> is_fill(n, 0), needs_full(n, 0);
@@ -74,6 +82,12 @@ void renumber_blocks(opfx_plan* p) {
   for (int32_t b = 0; b < n; ++b)
     if (p->blk_row[b] == p->blk_col[b] || p->bus_type[p->blk_row[b]] != OPFX_PQ) needs_full[b] = 1;
   for (int32_t tb : p->tgt_blk) if (tb >= 0) needs_full[tb] = 1;
+  {   // blocks inside the dense tail: the register chain reads them without the two-value case distinction
+    const int m = tail_length(p), nlev = p->n_levels();
+    std::vector<char> in_tail(p->nb, 0);
+    for (int e = 0; e < m; ++e) in_tail[p->piv_bus[p->lev_pptr[nlev - m + e]]] = 1;
+    for (int32_t b = 0; b < n; ++b) if (in_tail[p->blk_row[b]] && in_tail[p->blk_col[b]]) needs_full[b] = 1;
+  }
   if (getenv("OPFX_PLAN_NO_PACK")) std::fill(needs_full.begin(), needs_full.end(), 1);   // developer probe
   std::vector<int32_t> perm(n);
   int32_t next = 0;
@@ -245,6 +259,60 @@ void build_lane_programs(opfx_plan* p) {
   for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
     for (int r = p->lp_groups[g]; r + 1 < p->lp_groups[g + 1]; ++r)
       for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = 2u;
+  // ---- the dense tail ---------------------------------------------------------------------------
+  // A meshed grid ends in a chain of levels with ONE pivot each (the last separator fills in completely:
+  // 16 such levels on the 306-bus grid, 20 on the 372-bus one).  Their back substitution is a strictly serial
+  // chain of tiny groups — one LDS round trip and one 2x2 inverse per level with a handful of live lanes.  The
+  // wave teams run that chain in REGISTERS instead (opfx.hip: tail_solve): lane e holds y of tail pivot e and
+  // its diagonal block, x_s travels by v_readlane, the U-blocks are plain LDS reads that do not depend on the
+  // chain.  The plan hands over the tail pivots' buses and, per tail row, the ids of its U-blocks inside the
+  // tail; the U-terms of tail COLUMNS in rows outside the tail follow as one ordinary group.
+  const int tail_m = tail_length(p);
+  p->tail_m = tail_m;
+  constexpr int TAIL_MAX = opfx_plan::TAIL_MAX;
+  const int tail_M = (tail_m + 7) & ~7;                  // steps of the unrolled chain the kernels instantiate (8, 16, 24, 32)
+  p->tail_bus.assign(TAIL_MAX, 0u);
+  p->tail_ids.assign(tail_m > 0 ? (size_t)(tail_m + 1) * tail_M : 0, (uint16_t)NONE);      // (+ a row of "none" for the idle lanes)
+  std::vector<int> tail_pos(nb, -1);
+  for (int e = 0; e < tail_m; ++e) {
+    const int bus = p->piv_bus[p->lev_pptr[nlev - tail_m + e]];
+    p->tail_bus[e] = (uint32_t)bus | ((uint32_t)p->diag_blk[bus] << 16);
+    tail_pos[bus] = e;
+  }
+  for (int sx = 0; sx < tail_m; ++sx)
+    for (auto& kt : col_terms[p->tail_bus[sx] & 0xFFFFu])
+      if (tail_pos[kt[0]] >= 0) p->tail_ids[(size_t)tail_pos[kt[0]] * tail_M + sx] = (uint16_t)kt[1];
+  p->tail_ids32.assign(p->tail_ids.begin(), p->tail_ids.end());
+  // back-substitution rounds of the team streams: (register chain) [tail columns -> outside rows] [levels below the tail]
+  std::vector<uint32_t> tc;                               // rounds of 64 items x 4 words
+  std::vector<int32_t> tc_bounds{0};
+  auto tc_flush = [&]() {
+    for (size_t o = 0; o < items.size(); o += 64)
+      for (int lane = 0; lane < 64; ++lane) {
+        if (o + lane < items.size()) { tc.push_back(items[o + lane][0]); tc.push_back(items[o + lane][1]); }
+        else { tc.push_back(NONE | (NONE << 16)); tc.push_back(NONE | (NONE << 16)); }
+        tc.push_back(NONE | (NONE << 16)); tc.push_back(0u);
+      }
+    items.clear();
+    if ((int32_t)(tc.size() / 256) > tc_bounds.back()) tc_bounds.push_back((int32_t)(tc.size() / 256));
+  };
+  if (tail_m > 0) {
+    for (int sx = 0; sx < tail_m; ++sx) {
+      const int j = (int)(p->tail_bus[sx] & 0xFFFFu);
+      for (auto& kt : col_terms[j])
+        if (tail_pos[kt[0]] < 0)
+          items.push_back({(0x8000u | (uint32_t)kt[0]) | ((uint32_t)kt[1] << 16), (uint32_t)p->diag_blk[j] | ((uint32_t)j << 16)});
+    }
+    tc_flush();
+    for (int lev = nlev - tail_m - 1; lev >= 0; --lev) {
+      for (int q = p->lev_pptr[lev]; q < p->lev_pptr[lev + 1]; ++q) {
+        const int j = p->piv_bus[q];
+        for (auto& kt : col_terms[j])
+          items.push_back({(0x8000u | (uint32_t)kt[0]) | ((uint32_t)kt[1] << 16), (uint32_t)p->diag_blk[j] | ((uint32_t)j << 16)});
+      }
+      tc_flush();
+    }
+  }
   for (int t = 0; t < 2; ++t) {
     const int NW = t == 0 ? 2 : 4;
     std::vector<uint32_t>& out = p->lp_team[t];
@@ -254,28 +322,45 @@ void build_lane_programs(opfx_plan* p) {
         for (int l = 0; l < 64; ++l) { out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(flags); }
       ++K;
     };
-    // real groups (padding ranges dropped)
-    std::vector<std::pair<int, int>> groups;
+    // real groups (padding ranges dropped): (source, first round, end round); source 0 = lp_bc, 1 = tc.
+    // With a tail the stream has two parts, each padded to a multiple of 4 rounds: factorisation + forward
+    // substitution | back substitution below the tail; the kernels run the register chain between them
+    // (a workgroup barrier follows it), so the last round of the first part needs a barrier only if another
+    // wavefront than 0 took part in its group.
+    struct Group { int src, r0, r1; };
+    std::vector<Group> groups;
     for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g) {
       const int r0 = p->lp_groups[g], r1 = p->lp_groups[g + 1];
       const bool pad_group = (r0 >= p->rb && r1 <= p->rb_pad) || r0 >= p->rb_pad + p->rc;
       if (r0 == r1 || pad_group) continue;
-      groups.push_back({r0, r1});
+      if (tail_m > 0 && r0 >= p->rb_pad) continue;               // back substitution comes from `tc`
+      groups.push_back({0, r0, r1});
     }
+    const size_t n_first = groups.size();
+    if (tail_m > 0)
+      for (size_t g = 0; g + 1 < tc_bounds.size(); ++g) groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
+    p->team_kb[t] = -1;
     for (size_t g = 0; g < groups.size(); ++g) {
-      const int r0 = groups[g].first, r1 = groups[g].second;
+      const int r0 = groups[g].r0, r1 = groups[g].r1;
       const int per = (r1 - r0 + NW - 1) / NW;
       // A group of ONE round runs on wavefront 0 alone; when the next group is such a group too, the same
       // wavefront carries on and its LDS operations execute in issue order: no workgroup barrier between them
       // (the dense tail of a meshed grid is a long chain of one-round groups).
       const bool single = r1 - r0 == 1;
-      const bool next_single = g + 1 < groups.size() && groups[g + 1].second - groups[g + 1].first == 1;
+      if (tail_m > 0 && g == n_first) {                          // part boundary: the chain runs here
+        while (K % 4 || K < 4) empty_round(0u);
+        p->team_kb[t] = K;
+      }
+      const bool last_of_part = tail_m > 0 && g + 1 == n_first;  // (the chain runs on wavefront 0, like a one-round group)
+      const bool next_single = last_of_part || (g + 1 < groups.size() && groups[g + 1].r1 - groups[g + 1].r0 == 1);
+      const uint32_t* src = groups[g].src == 0 ? p->lp_bc.data() : tc.data();
       for (int j = 0; j < per; ++j) {
         const uint32_t flags = ((j == per - 1 && !(single && next_single)) ? 1u : 0u) | (j < per - 1 ? 2u : 0u);
+        p->team_barriers[t] += (int32_t)(flags & 1u);
         for (int w = 0; w < NW; ++w) {
           const int r = r0 + j * NW + w;
           for (int l = 0; l < 64; ++l) {
-            if (r < r1) for (int q = 0; q < 3; ++q) out.push_back(p->lp_bc[((size_t)r * 64 + l) * 4 + q]);
+            if (r < r1) for (int q = 0; q < 3; ++q) out.push_back(src[((size_t)r * 64 + l) * 4 + q]);
             else for (int q = 0; q < 3; ++q) out.push_back(NONE | (NONE << 16));
             out.push_back(flags);
           }
@@ -283,8 +368,14 @@ void build_lane_programs(opfx_plan* p) {
         ++K;
       }
     }
+    if (tail_m > 0 && p->team_kb[t] < 0) {                       // (no back-substitution group at all)
+      while (K % 4 || K < 4) empty_round(0u);
+      p->team_kb[t] = K;
+    }
     while (K % 4 || K < 4) empty_round(0u);
     p->team_rounds[t] = K;
+    if (tail_m == 0) p->team_kb[t] = K;
+    p->n_groups = (int32_t)groups.size();
   }
   p->lp_apk.assign((size_t)p->ra * 7 * 64 * 4, 0u);
   for (int r = 0; r < p->ra; ++r)
@@ -537,6 +628,10 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
     o->lds_doubles = 4 * nbe + 2 * bs + 2 * nfs;
   }
   o->lp_rounds_a = p->ra; o->lp_rounds_h = p->rh; o->lp_rounds_b = p->rb; o->lp_rounds_c = p->rc;
+  for (int t = 0; t < 2; ++t) { o->team_rounds[t] = p->team_rounds[t]; o->team_barriers[t] = p->team_barriers[t]; }
+  o->n_groups = p->n_groups;
+  o->team_kb[0] = p->team_kb[0]; o->team_kb[1] = p->team_kb[1];
+  o->tail_m = p->tail_m;
   return OPFX_OK;
 }
 
@@ -551,6 +646,10 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_H_ROW: v = u32(p->lp_h_row); break;
     case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
+    case OPFX_ARR_LP_TEAM2: v = u32(p->lp_team[0]); break;
+    case OPFX_ARR_LP_TEAM4: v = u32(p->lp_team[1]); break;
+    case OPFX_ARR_TAIL_BUS: v = u32(p->tail_bus); break;
+    case OPFX_ARR_TAIL_IDS: v = &p->tail_ids32; break;
     case OPFX_ARR_BR_ISLAND: v = &p->br_island; break;
     case OPFX_ARR_ISL_PTR: v = &p->isl_ptr; break;
     case OPFX_ARR_ISL_BUS: v = &p->isl_bus; break;

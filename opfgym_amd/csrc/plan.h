@@ -62,6 +62,15 @@ struct opfx_plan {
   // bit 0 = workgroup barrier after this round (end of a group that another wavefront continues).
   std::vector<uint32_t> lp_team[2];        // [0]: 2 waves, [1]: 4 waves
   int32_t team_rounds[2] = {0, 0};         // rounds per wave (multiples of 4)
+  int32_t team_barriers[2] = {0, 0};       // rounds that end with a workgroup barrier
+  int32_t team_kb[2] = {0, 0};             // rounds of the first part of the stream (the tail chain runs after it); = team_rounds without a tail
+  int32_t n_groups = 0;                    // independent groups of the B/C stream
+  // dense tail of the elimination (levels with one pivot each at the end), solved in registers by the wave teams
+  static constexpr int TAIL_MAX = 32;
+  int32_t tail_m = 0;                      // pivots in the tail (0: none / not worth it)
+  std::vector<uint32_t> tail_bus;          // [TAIL_MAX] bus | diagonal block << 16 of tail pivot e (elimination order, e = tail_m-1 last)
+  std::vector<int32_t> tail_ids32;         // (the same, widened: read-back for tests)
+  std::vector<uint16_t> tail_ids;          // [tail_m][M] id of U-block (row e, column s) at [e * M + s], 0xFFFF = none; M = tail_m rounded up to a multiple of 8
   std::vector<int32_t> lp_groups;          // round offsets into lp_bc: rounds of one group are mutually
                                            // independent (an elimination level / the back-substitution terms of a level)
   int32_t nnz_j = 0;

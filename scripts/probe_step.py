@@ -12,6 +12,8 @@ env = getattr(envs, cls)(batch_size=B, device='cuda:0', seed=0, **kw)
 rng = np.random.default_rng(1234)
 env.reset(options={'step': rng.choice(env.train_steps, B)})
 actions = torch.as_tensor(rng.random((B, env.n_actions)), device='cuda:0')
+if os.environ.get('OPFX_FIXED_IT'):
+    env.solve_opts.tol = 0.0; env.solve_opts.max_iter = int(os.environ['OPFX_FIXED_IT'])
 for _ in range(3):
     env.step(actions)
 io = env._io(actions, False)

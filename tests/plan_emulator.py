@@ -126,11 +126,15 @@ def emulate_newton(plan, p_sp, q_sp, tol=1e-8, max_iter=10, check_levels=True):
                 va[i] += np.pi
 
 
-def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
+def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0):
     """Walks the LANE PROGRAMME (plan.h lp_*: what kernel `newton2` executes) in
     numpy: ELL bus rows + overflow entries, flat update items accumulated per
     target, solve items with inline U-terms; relative-|V| unknowns and the
-    rectangular voltage update.  Returns (V, converged, iterations, norm)."""
+    rectangular voltage update.  Returns (V, converged, iterations, norm).
+    team = 2 | 4: factorisation and substitutions walk the WAVE-TEAM stream instead (what `newton2_coop`
+    executes: rounds dealt to the wavefronts, barrier flags, the dense tail's register chain between the two
+    parts of the stream), with a race check: between two workgroup barriers no wavefront may read a location
+    another wavefront adds to."""
     NONE = 0xFFFF
     case = plan.case
     info = plan.info
@@ -212,37 +216,40 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
             return v, False, it, nrm
         it += 1
         assert not np.isnan(blk).any()
-        for r in range(rb):
-            dblk_upd, drhs = {}, {}
-            for lane in range(64):
-                w0, w1 = int(lp_b[r, lane, 0]), int(lp_b[r, lane, 1])
-                tb = w0 & 0xFFFF
-                if tb == NONE:
-                    continue
-                w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
-                if tb & 0x8000:
-                    i = tb & 0x7FFF
-                    drhs[i] = drhs.get(i, 0) + w @ rhs[w1 >> 16]
-                else:
-                    dblk_upd[tb] = dblk_upd.get(tb, 0) + w @ blk[w1 >> 16]
-            for tb, d in dblk_upd.items():
-                blk[tb] -= d
-            for i, d in drhs.items():
-                rhs[i] -= d
-        for r in range(rc):                       # back substitution: the same item form, column by column
-            drhs = {}
-            for lane in range(64):
-                w0, w1 = int(lp_c[r, lane, 0]), int(lp_c[r, lane, 1])
-                tb = w0 & 0xFFFF
-                if tb == NONE:
-                    continue
-                assert tb & 0x8000
-                k = tb & 0x7FFF
-                w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
-                drhs[k] = drhs.get(k, 0) + w @ rhs[w1 >> 16]
-                assert (w1 >> 16) not in drhs          # a source of this round is final
-            for k, d in drhs.items():
-                rhs[k] -= d
+        if team:
+            _team_factor_solve(plan, team, blk, rhs, inv2)
+        else:
+            for r in range(rb):
+                dblk_upd, drhs = {}, {}
+                for lane in range(64):
+                    w0, w1 = int(lp_b[r, lane, 0]), int(lp_b[r, lane, 1])
+                    tb = w0 & 0xFFFF
+                    if tb == NONE:
+                        continue
+                    w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
+                    if tb & 0x8000:
+                        i = tb & 0x7FFF
+                        drhs[i] = drhs.get(i, 0) + w @ rhs[w1 >> 16]
+                    else:
+                        dblk_upd[tb] = dblk_upd.get(tb, 0) + w @ blk[w1 >> 16]
+                for tb, d in dblk_upd.items():
+                    blk[tb] -= d
+                for i, d in drhs.items():
+                    rhs[i] -= d
+            for r in range(rc):                       # back substitution: the same item form, column by column
+                drhs = {}
+                for lane in range(64):
+                    w0, w1 = int(lp_c[r, lane, 0]), int(lp_c[r, lane, 1])
+                    tb = w0 & 0xFFFF
+                    if tb == NONE:
+                        continue
+                    assert tb & 0x8000
+                    k = tb & 0x7FFF
+                    w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
+                    drhs[k] = drhs.get(k, 0) + w @ rhs[w1 >> 16]
+                    assert (w1 >> 16) not in drhs          # a source of this round is final
+                for k, d in drhs.items():
+                    rhs[k] -= d
         diag = plan.array('diag_blk')
         for i in range(nb):                       # x_i = A_ii^-1 y_i (phase D)
             if bt[i] != REF:
@@ -250,3 +257,82 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10):
         for i in range(nb):
             if bt[i] != REF:
                 v[i] = v[i] * (1.0 + rhs[i, 1]) * np.exp(1j * rhs[i, 0])
+
+
+def _team_factor_solve(plan, nw, blk, rhs, inv2):
+    """Phases B and C as a team of `nw` wavefronts walks them (csrc/plan.cpp lp_team, csrc/opfx.hip team_step /
+    tail_solve).  Rounds are executed in stream order, wavefront 0 first (one legal interleaving); the race check
+    makes sure every other interleaving between two barriers gives the same result up to the order of additions."""
+    NONE = 0xFFFF
+    info = plan.info
+    K, Kb, m = info[f'team_rounds_{nw}'], info[f'team_kb_{nw}'], info['tail_m']
+    stream = plan.array(f'lp_team{nw}').view(np.uint32).reshape(K, nw, 64, 4)
+    assert K % 4 == 0 and Kb % 4 == 0 and (m > 0 or Kb == K)
+    reads = [set() for _ in range(nw)]
+    adds = [set() for _ in range(nw)]
+
+    def barrier():
+        for w in range(nw):
+            for w2 in range(nw):
+                if w != w2:
+                    clash = reads[w] & adds[w2]
+                    assert not clash, f'wave {w} reads what wave {w2} adds to between two barriers: {sorted(clash)[:5]}'
+        for w in range(nw):
+            reads[w].clear()
+            adds[w].clear()
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            flags = set(int(f) for f in stream[k, :, :, 3].ravel())
+            assert len(flags) == 1                           # one flag word per round, the same for every wavefront
+            for w in range(nw):
+                upd_b, upd_r = {}, {}
+                for lane in range(64):
+                    w0, w1 = int(stream[k, w, lane, 0]), int(stream[k, w, lane, 1])
+                    tb = w0 & 0xFFFF
+                    if tb == NONE:
+                        continue
+                    ik, kk, kj = w0 >> 16, w1 & 0xFFFF, w1 >> 16
+                    mlt = blk[ik] @ inv2(blk[kk])
+                    reads[w].update((('b', ik), ('b', kk)))
+                    if tb & 0x8000:
+                        i = tb & 0x7FFF
+                        upd_r[i] = upd_r.get(i, 0) + mlt @ rhs[kj]
+                        reads[w].add(('r', kj))
+                        adds[w].add(('r', i))
+                    else:
+                        upd_b[tb] = upd_b.get(tb, 0) + mlt @ blk[kj]
+                        reads[w].add(('b', kj))
+                        adds[w].add(('b', tb))
+                    # an item never reads what an item of the same round adds to (one group = independent items)
+                for tb, d in upd_b.items():
+                    blk[tb] -= d
+                for i, d in upd_r.items():
+                    rhs[i] -= d
+            if flags.pop() & 1:
+                barrier()
+
+    run(0, Kb)
+    if m > 0:
+        # the register chain of wavefront 0: lane e owns tail pivot e; x_s travels to the lanes e < s
+        M = (m + 7) & ~7
+        tb_ = plan.array('tail_bus').view(np.uint32)
+        ids = plan.array('tail_ids').reshape(m + 1, M)
+        bus = [int(tb_[e] & 0xFFFF) for e in range(m)]
+        dblk = [int(tb_[e] >> 16) for e in range(m)]
+        assert (ids[m] == NONE).all()
+        y = [rhs[bus[e]].copy() for e in range(m)]
+        for e in range(m):
+            reads[0].update((('r', bus[e]), ('b', dblk[e])))
+        for s_ in range(m - 1, 0, -1):
+            x = inv2(blk[dblk[s_]]) @ y[s_]
+            for e in range(s_):
+                if ids[e, s_] != NONE:
+                    y[e] = y[e] - blk[ids[e, s_]] @ x
+                    reads[0].add(('b', int(ids[e, s_])))
+        for e in range(m):
+            rhs[bus[e]] = y[e]
+            adds[0].add(('r', bus[e]))
+        barrier()
+        run(Kb, K)
+    barrier()

@@ -69,6 +69,53 @@ def test_lane_programme_reproduces_oracle(built_lib, code):
     assert np.abs(v - ref['V']).max() < 1e-9          # both stop at ||F|| < 1e-8
 
 
+@pytest.mark.parametrize('code,team', [('hv-small', 2), ('hv-small', 4), ('1-HV-mixed--0-sw', 4), ('1-HV-mixed--0-sw', 2),
+                                       ('1-HV-urban--0-sw', 4), ('1-MV-urban--0-sw', 2)])
+def test_team_stream_reproduces_oracle(built_lib, code, team):
+    """The wave-team form of the factor/solve stream (kernel `newton2_coop`): rounds dealt to 2 or 4 wavefronts,
+    barriers only where the plan says so (none between consecutive one-round groups), the dense tail's back
+    substitution as a register chain of wavefront 0 between the two parts of the stream.  The emulation walks
+    exactly that and checks, between any two barriers, that no wavefront reads a location another one adds to —
+    the condition under which every interleaving the hardware may choose gives the same sums."""
+    net = grids.get_grid(code)[0]
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    p, q, *_ = bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = OracleSide(net, case).solve(p, q)
+    v, conv, it, nrm = emulate_newton_lane_program(plan, p, q, team=team)
+    assert conv and it == ref['iterations']
+    assert np.abs(v - ref['V']).max() < 1e-9
+
+
+def test_dense_tail_tables(built_lib):
+    """The tail the register chain works on: the final levels with one pivot each; its table names, for every
+    pair of tail pivots e < s, the U-block (row e, column s) — all of them four-value blocks."""
+    net = grids.get_grid('1-HV-mixed--0-sw')[0]
+    plan = capi.Plan(net_to_case(net))
+    P, info = load_plan(plan), plan.info
+    m = info['tail_m']
+    assert m == 16 and info['team_kb_4'] < info['team_rounds_4']
+    per_level = np.diff(P['lev_pptr'])
+    assert (per_level[-m:] == 1).all() and per_level[-m - 1] > 1
+    M = (m + 7) & ~7
+    tb = plan.array('tail_bus').view(np.uint32)
+    ids = plan.array('tail_ids').reshape(m + 1, M)
+    bus = (tb[:m] & 0xFFFF).astype(int)
+    assert bus.tolist() == P['piv_bus'][-m:].tolist()
+    assert ((tb[:m] >> 16).astype(int) == P['diag_blk'][bus]).all()
+    where = {(int(r), int(c)): b for b, (r, c) in enumerate(zip(P['blk_row'], P['blk_col']))}
+    for e in range(m):
+        for s in range(M):
+            if e < s < m:
+                assert ids[e, s] == where[(bus[e], bus[s])] and ids[e, s] < info['n_full']
+            else:
+                assert ids[e, s] == 0xFFFF
+    # without a tail (radial grid) the stream is one part
+    plan2 = capi.Plan(net_to_case(grids.get_grid('1-MV-urban--0-sw')[0]))
+    assert plan2.info['tail_m'] == 0 and plan2.info['team_kb_2'] == plan2.info['team_rounds_2']
+
+
 def test_plan_structure_invariants(built_lib):
     net, _ = grids.get_grid('1-HV-mixed--0-sw')
     case = net_to_case(net)
