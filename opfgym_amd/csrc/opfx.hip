@@ -1040,6 +1040,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   OPFX_STAMP_INIT();
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   const unsigned tail = P.tail_bus[lane & 31];     // the lane's pivot of the dense tail (tail_solve)
+  // overflow entries of rows longer than 4 (phase A): the row this thread zeroes and this wavefront's first round
+  const int hrow0 = tid < P.n_hrows ? P.lp_hrows[tid] : -1;
+  uint4 hy0 = make_uint4(0, 0, 0, 0), he0 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
+  if (wave < P.rh) { hy0 = hpk[(size_t)(wave * 2) * WAVE + lane]; he0 = hpk[(size_t)(wave * 2 + 1) * WAVE + lane]; }
   // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
   const double* psp_g = L.psp; const double* qsp_g = L.qsp;
   const int r_first = wave < P.ra ? wave : 0;
@@ -1048,12 +1052,16 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
   while (true) {
     // ---- phase A ------------------------------------------------------------------
-    for (int f = tid; f < P.nfill; f += NT) st_blk2<PK>(L, P.fill_blk[f], Blk{0.0, 0.0, 0.0, 0.0});
-    for (int h = tid; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
+    // (nothing in this prologue of the phase waits for global memory: fill blocks are one contiguous id range,
+    // the overflow rows and this wavefront's first overflow round were fetched once per solve)
+    for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+    if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
+    for (int h = tid + NT; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
     lds_barrier();
+    OPFX_STAMP(10);
     for (int h = wave; h < P.rh; h += NW) {
-      const uint4 hy = hpk[(size_t)(h * 2) * WAVE + lane];
-      const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+      const uint4 hy = h == wave ? hy0 : hpk[(size_t)(h * 2) * WAVE + lane];
+      const uint4 he = h == wave ? he0 : hpk[(size_t)(h * 2 + 1) * WAVE + lane];
       const unsigned ent = he.x;
       const unsigned j = ent & 0xFFFF;
       if (j != NONE) {
@@ -1075,6 +1083,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       }
     }
     lds_barrier();
+    OPFX_STAMP(11);
     double my = 0.0;
     for (int r = wave; r < P.ra; r += NW) {
       const ARound a = a_next;
@@ -1126,6 +1135,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         }
       }
     }
+    OPFX_STAMP(12);
     if (n_mod > 0) {
       lds_barrier();
       if (wave == 0) { dead_rows_patch<PK>(P, L, lane); wave_fence(); mods_apply(L, lane, n_mod); }
@@ -1140,7 +1150,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     nrm = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
-    OPFX_STAMP(12);
+    OPFX_STAMP(1);
     if (!(nrm == nrm)) { conv = false; break; }
     if (nrm < o.tol) { conv = true; break; }
     if (it >= o.max_iter) { conv = false; break; }
@@ -1153,9 +1163,11 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       team_step<PK>(L, q2); q2 = ld_desc(k + 6);
       team_step<PK>(L, q3); q3 = ld_desc(k + 7);
     }
+    OPFX_STAMP(2);
     if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
       if (wave == 0) tail_solve(L, P.tail_m, lane, tail);
       lds_barrier();
+      OPFX_STAMP(20);
       for (int k = Kb; k < K; k += 4) {
         team_step<PK>(L, q0); q0 = ld_desc(k + 4);
         team_step<PK>(L, q1); q1 = ld_desc(k + 5);
@@ -1163,7 +1175,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         team_step<PK>(L, q3); q3 = ld_desc(k + 7);
       }
     }
-    OPFX_STAMP(2);
+    OPFX_STAMP(3);
     // ---- phase D ---------------------------------------------------------------------------------
     for (int i = tid; i < nb; i += NT) {
       if (L.bt[i] == BT_REF) continue;
