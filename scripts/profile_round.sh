@@ -52,7 +52,7 @@ if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
                'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk,
                'FETCH_SIZE_launches': len(acc['FETCH_SIZE']), 'WRITE_SIZE_launches': len(acc['WRITE_SIZE']),
                'hbm_bytes_per_launch_raw': (fk + wk) * 1024, 'hbm_bytes_per_launch_fetch_x2': (2 * fk + wk) * 1024,
-               'note': 'gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); our reads are 8 B/lane, an uncalibrated width, so the true value lies between raw and fetch_x2 (bench.py reports fetch_x2). Includes register-spill scratch traffic.'},
+               'note': 'gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); our reads are 8 B/lane, an uncalibrated width, so the true value lies between raw and fetch_x2 (bench.py reports fetch_x2). The round-2 kernels use no scratch memory.'},
               open(out + '/pmc_summary.json', 'w'), indent=1)
 print(open(out + '/sq_counters.txt').read())
 print(open(out + '/kernel_stats.csv').read()[:1500] if st else 'no kernel stats')
