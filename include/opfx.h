@@ -172,6 +172,11 @@ typedef struct opfx_solve_opts {
   double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
   int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */
   int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits */
+  int32_t contingency_start; /* opfx_step, N-1 loop: 0 = every contingency solve starts from the base-case
+                              * solution (default; same fixed point, one iteration fewer), 1 = from the flat
+                              * start, as the reference does by calling pandapower anew
+                              * (security_constrained.py:53): identical iteration counts and identical
+                              * behaviour next to voltage collapse */
 } opfx_solve_opts;
 
 int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,

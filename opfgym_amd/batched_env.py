@@ -285,7 +285,8 @@ class BatchedOpfEnv:
                  objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
-                 defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False, **kwargs):
+                 defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False,
+                 contingency_start='base_case', **kwargs):
         from .objectives import QuadraticDeviation
         terms = objective_function if isinstance(objective_function, (list, tuple)) else \
             ([objective_function] if objective_function is not None else [])
@@ -378,7 +379,9 @@ class BatchedOpfEnv:
         for _, column, _ in self.n_minus_one_keys:
             assert column in ('in_service', 'closed')                      # security_constrained.py:34-35
         self.not_converged_penalty = not_converged_penalty
-        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)))
+        assert contingency_start in ('base_case', 'flat'), contingency_start
+        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)),
+                                         int(contingency_start == 'flat'))
         self.np_random = np.random.default_rng(seed)
 
         # ---- compile the grid --------------------------------------------------

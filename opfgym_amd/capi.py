@@ -57,7 +57,8 @@ class PlanInfo(C.Structure):
 
 
 class SolveOpts(C.Structure):
-    _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32)]
+    _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32),
+                ('contingency_start', C.c_int32)]
 
 
 class EnvDesc(C.Structure):

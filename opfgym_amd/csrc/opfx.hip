@@ -137,6 +137,7 @@ struct Opts {
   double tol;
   int max_iter;
   int enforce_q_lims;
+  int contingency_start;     // opfx_solve_opts::contingency_start
 };
 
 // ---------------------------------------------------------------------------
@@ -1805,9 +1806,10 @@ __global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const De
           L.vr[i] *= f; L.vi[i] *= f;
           if (!V2) L.vm[i] *= f;
         }
-        if (c > 0) {
+        if (c > 0 && o.contingency_start == 0) {
           // contingency cases start from the base-case solution (the reference restarts
-          // pandapower from scratch for each one; the converged result is the same)
+          // pandapower from scratch for each one; the converged result is the same;
+          // opfx_solve_opts::contingency_start = 1 does exactly what the reference does)
           const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
           for (int i = lane; i < nb; i += WAVE) { L.vr[i] = wv[i]; L.vi[i] = wv[nb + i]; }
         }
@@ -2333,7 +2335,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
   HIP_TRY(hipSetDevice(ctx->device));
-  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0};
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0};
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
   int n_full = ctx->plan.n_blk;
@@ -2584,7 +2586,7 @@ extern "C" void opfx_env_destroy(opfx_env* env) { delete env; }
 
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                    int32_t mode, void* stream) {
-  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1};
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1, opts ? opts->contingency_start : 0};
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
   const int team = pick_team(env->lds_bytes, env->ctx->v2);

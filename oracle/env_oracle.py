@@ -409,8 +409,11 @@ class EnvOracle:
         return np.asarray(self.objective_fn(self.net), float) if self.objective_fn else cost_vector(self.net)
 
     def solve(self):
+        """One `run_power_flow` (opf_env.py:646-662).  `solve_iterations` collects the Newton iterations of every
+        successful call since the last reset()/step() began (base case first, then the contingencies)."""
         try:
-            pf_oracle.runpp(self.net, enforce_q_lims=self.enforce_q_lims)
+            sol = pf_oracle.runpp(self.net, enforce_q_lims=self.enforce_q_lims)
+            self.solve_iterations.append(int(sol['iterations']))
             return True
         except pf_oracle.LoadflowNotConverged:
             return False
@@ -420,6 +423,7 @@ class EnvOracle:
         test_data for reset(options={'test': True}), opf_env.py:226)."""
         if not (self.carry_over and getattr(self, 'net', None) is not None):
             self.net = copy.deepcopy(self.base_net)
+        self.solve_iterations = []
         self.step_in_episode = 0
         self.current_step = step
         draws = iter(np.asarray(uniform, float))
@@ -460,6 +464,7 @@ class EnvOracle:
 
     def step(self, action):
         self.step_in_episode += 1
+        self.solve_iterations = []
         corr = apply_actions(self.net, self.act_keys, action, self.autoscale, self.diff_step)
         if not self.solve():
             return dict(converged=False)

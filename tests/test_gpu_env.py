@@ -202,6 +202,39 @@ def test_full_batch_hv_configs(name, B, n_check, team, monkeypatch):
     assert capi_team(env) == team
 
 
+def test_contingency_start_flat_reproduces_the_reference_iteration_for_iteration():
+    """N-1 loop, `contingency_start`: the reference calls pandapower anew for every contingency
+    (security_constrained.py:53), i.e. from the flat start; the kernel's default starts each contingency solve
+    from the base-case solution (same fixed point, fewer iterations).  'flat' does what the reference does: the
+    Newton iterations summed over the base case and all contingencies equal the oracle's count exactly, and both
+    modes give the same rewards, violations and observations."""
+    B = 24
+    rng = np.random.default_rng(5)
+    actions = rng.random((B, product_env('sc_hv_small', defer_device=True).n_actions))
+    results = {}
+    for mode in ('flat', 'base_case'):
+        env = product_env('sc_hv_small', batch_size=B, contingency_start=mode)
+        steps = np.random.default_rng(6).choice(env.train_steps, B)
+        env.reset(options={'step': steps})
+        obs, reward, term, trunc, info = env.step(actions)
+        results[mode] = dict(reward=_np(reward).copy(), viol=_np(info['violations']).copy(),
+                             total=_np(info['total_iterations']).copy(), base=_np(info['iterations']).copy(),
+                             conv=_np(info['converged']).copy())
+    orc = oracle_env('sc_hv_small', product_env('sc_hv_small', defer_device=True))
+    flat, warm = results['flat'], results['base_case']
+    assert flat['conv'].all() and warm['conv'].all()
+    assert np.allclose(flat['reward'], warm['reward'], rtol=0, atol=1e-7)
+    assert np.allclose(flat['viol'], warm['viol'], rtol=0, atol=1e-6)
+    assert (flat['base'] == warm['base']).all() and (warm['total'] <= flat['total']).all()
+    for k in range(0, B, 3):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert ref['converged']
+        assert orc.solve_iterations[0] == flat['base'][k]
+        assert sum(orc.solve_iterations) == flat['total'][k], (k, orc.solve_iterations, flat['total'][k])
+        assert abs(ref['reward'] - flat['reward'][k]) < 1e-7
+
+
 def capi_team(env):
     """wavefronts per instance the environment's kernels run with (LDS footprint -> team size, opfx.hip pick_team)"""
     import ctypes as C

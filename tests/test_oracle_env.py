@@ -136,3 +136,17 @@ def test_truncated_normal_transform_has_the_reference_distribution():
         ref = stats.truncnorm.rvs(lo[j], hi[j], mean[j], scale[j], n, random_state=np.random.default_rng(j))
         assert stats.ks_2samp(got[:, j], ref).pvalue > 1e-3
         assert (got[:, j] >= mean[j] + scale[j] * lo[j] - 1e-12).all() and (got[:, j] <= mean[j] + scale[j] * hi[j] + 1e-12).all()
+
+
+def test_oracle_counts_the_iterations_of_every_solve():
+    """`solve_iterations`: one entry per successful power flow of the step — the base case and each contingency of
+    security_constrained.py:44-66 (the GPU test of `contingency_start='flat'` compares its sum)."""
+    from env_cases import oracle_env, product_env
+    host = product_env('sc_hv_small', defer_device=True)
+    orc = oracle_env('sc_hv_small', host)
+    orc.reset(int(host.train_steps[3]))
+    assert len(orc.solve_iterations) <= 1                       # reset: at most the base case (opf_env.py:209-216)
+    ref = orc.step(np.full(host.n_actions, 0.5))
+    n_cont = sum(len(i) for _, _, i in host.n_minus_one_keys)
+    assert ref['converged'] and len(orc.solve_iterations) == 1 + n_cont
+    assert all(1 <= it <= 10 for it in orc.solve_iterations)
