@@ -1480,8 +1480,14 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
 // ---------------------------------------------------------------------------
 // pure power flow kernel (opfx_solve)
 // ---------------------------------------------------------------------------
+// Two wavefronts per SIMD (256 VGPRs each) is what LDS capacity allows anyway: 8 single-wave instances or 2 teams of
+// four per CU.  -DOPFX_MIN_WAVES_PER_SIMD=3 caps the kernels at 168 VGPRs: the build of the negative result in
+// profiles/r02_ab_three_waves_per_simd.txt (it spills, and the third wave slot stays empty).
+#ifndef OPFX_MIN_WAVES_PER_SIMD
+#define OPFX_MIN_WAVES_PER_SIMD 2
+#endif
 template <int V2, int NW>
-__global__ __launch_bounds__(WAVE * NW, 2) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
+__global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
@@ -1599,7 +1605,7 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
 template <int V2, int NW>
-__global__ __launch_bounds__(WAVE * NW, 2) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
+__global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
   // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
