@@ -248,14 +248,18 @@ def main():
         achieved = bm['B_step'] * B / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate
         # runs of this same script, see profiles/README.md) — not measurable in-process
-        traffic = None
+        traffic = traffic_raw = None
         pmc_file = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             ent = pmc.get(f'config{args.config}', pmc if args.config == 2 and 'hbm_bytes_per_launch_fetch_x2' in pmc else None)
             if ent and ent.get('batch', 8192) == B:
                 traffic = ent['hbm_bytes_per_launch_fetch_x2']
+                traffic_raw = ent['hbm_bytes_per_launch_raw']
         kernel_name = f'k_step<{"2" if env.plan.info["n_full"] < env.plan.info["n_blk"] else "1"}|1,{team.value}>'
+        # what the launch really has to read and write: the instance rows of the caller's buffers
+        buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
+                     'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
         out = {
             'metric': 'env.step()/s (batched NR power-flow solves/s) at batch 8192',
             'value': total_B * args.steps / elapsed,
@@ -280,8 +284,10 @@ def main():
                                          'instances_per_cu': per_cu.value}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                         'traffic_raw_counters': traffic_raw,
                          'algorithmic_bytes_per_launch': bm['B_step'] * B,
                          'compulsory_io_bytes_per_launch': bm['io_bytes'] * B,
+                         'buffer_io_bytes_per_launch': buffer_io,
                          'kernel': kernel_name, 'kernel_ms': kernel_ms,
                          'fp64_tflops_achieved': bm['fp64_flops_per_step'] * B / (kernel_ms * 1e-3) / 1e12,
                          'fp64_vector_peak_tflops': 78.6,
