@@ -1641,6 +1641,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       for (; q < nx; q += NT) xs[q] = xr[q];
     }
     blk_sync<NW>();       // staged row visible (one wave: compiler fence; team: all waves staged)
+    OPFX_STAMP(16);
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
     if (wave == 0) {
@@ -1697,6 +1698,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       corr = E.na > 0 ? wave_sum_dpp(corr) / E.na : 0.0;                                   // :488-489
     }
     blk_sync<NW>();       // NW > 1: row staged by all waves, set-points by wave 0
+    OPFX_STAMP(17);
     // (limits are read before any set-point of this step is written back: xs keeps the
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
@@ -1715,6 +1717,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       blk_sync<NW>();
       continue;
     }
+    OPFX_STAMP(18);
     double csum = 0.0;                       // this lane's share of the cost rows
     if (wave == 0) {
       // ---- bus injections (makeSbus): flat list, LDS accumulate ----------------------------------
@@ -1741,7 +1744,12 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
         wave_fence();
         for (int i = lane; i < nb; i += WAVE) { L.psp[i] = pacc[i]; L.qsp[i] = qacc[i]; }
       }
+      OPFX_STAMP(19);
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
+      // (Every phase of this prologue starts with descriptor loads and so with a memory round trip of its own,
+      // 17 k of the 135 k cycles of a 144-bus step in the cycle stamps.  Issuing each phase's first batch of loads
+      // one phase ahead shortened the prologue by 12 % and the kernel by nothing, 0.3027 vs 0.3003 ms: the second
+      // wavefront of the SIMD already fills those waits; what bounds the kernel is the instructions it issues.)
       for (int r0 = 0; r0 < E.ncost_pre; r0 += 2 * WAVE) {
         int meta[2], ps[2], qs[2], cb[2];
         double scl[2];

@@ -28,9 +28,9 @@ if os.environ.get('OPFX_STAMPS'):
     capi.lib().opfx_debug_read_stamps(env.ctx.handle, out)      # clear warm-up sums
     env.step(actions)
     capi.lib().opfx_debug_read_stamps(env.ctx.handle, out)
-    names = {0: 'prologue(actions+inject)', 1: ' A: mods + norm reduction', 2: 'NR phase B', 3: 'NR phase C', 4: 'NR phase D',
+    names = {0: ' prologue: cost rows (rest)', 1: ' A: mods + norm reduction', 2: 'NR phase B', 3: 'NR phase C', 4: 'NR phase D',
              5: 'solve_instance total(excl.)', 6: 'compute_results', 7: 'constraints', 8: 'objective+results out',
-             9: 'obs out', 20: ' team: tail chain + barrier', 10: ' A: desc prefetch + fill zero', 11: ' A: overflow entries', 12: ' A: bus rounds', 15: 'loop top/reward/outputs'}
+             9: 'obs out', 20: ' team: tail chain + barrier', 10: ' A: desc prefetch + fill zero', 11: ' A: overflow entries', 12: ' A: bus rounds', 15: 'loop top/reward/outputs', 16: ' prologue: stage row', 17: ' prologue: actions', 18: ' prologue: table obs', 19: ' prologue: injections'}
     tot = sum(out)
     n_inst = (B + 1535) // 1536
     for k in sorted(names):
