@@ -108,6 +108,7 @@ typedef struct opfx_plan_info {
   int32_t n_groups;          /* independent groups of the stream (elimination levels of B and C)  */
   int32_t team_kb[2];        /* rounds before the dense tail's register chain (= team_rounds without a tail) */
   int32_t tail_m;            /* pivots of the dense tail (final levels with one pivot each), 0 = none */
+  int32_t lp_ell_width;      /* off-diagonal Ybus entries per bus row in the row's own lane (LP_A_ENT: [ra][width][64]) */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block

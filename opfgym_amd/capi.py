@@ -50,7 +50,7 @@ class PlanInfo(C.Structure):
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
         'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full',
         'team_rounds_2', 'team_rounds_4', 'team_barriers_2', 'team_barriers_4', 'n_groups',
-        'team_kb_2', 'team_kb_4', 'tail_m')]
+        'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

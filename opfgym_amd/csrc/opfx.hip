@@ -678,22 +678,27 @@ __device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, do
   dvm = (a11 * y2 - a21 * y1) * rdet;
 }
 
-struct ARound { uint4 ent; double2 y[4]; double2 yd; unsigned dw; };
+// One bus round of phase A for one lane (plan.h lp_apk): KA off-diagonal entries of the lane's row, the row's
+// diagonal entry and its diagonal block.
+constexpr int KA = opfx_plan::KA;
+struct ARound { unsigned ent[KA]; double2 y[KA]; double2 yd; unsigned dw; };
 
 __device__ __forceinline__ ARound load_around(const DevPlan& P, int r, int lane) {
-  const uint4* q = reinterpret_cast<const uint4*>(P.lp_apk) + (size_t)r * 7 * WAVE + lane;
+  const uint4* q = reinterpret_cast<const uint4*>(P.lp_apk) + (size_t)r * opfx_plan::APK_VECS * WAVE + lane;
   ARound a;
-  a.ent = q[0];
+  const uint4 e = q[0];
+  const unsigned ew[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KA; ++k) {
+    a.ent[k] = ew[k];
     const uint4 w = q[(1 + k) * WAVE];
     a.y[k] = make_double2(__longlong_as_double(((long long)w.y << 32) | w.x),
                           __longlong_as_double(((long long)w.w << 32) | w.z));
   }
-  const uint4 w = q[5 * WAVE];
+  a.dw = e.w;
+  const uint4 w = q[(1 + KA) * WAVE];
   a.yd = make_double2(__longlong_as_double(((long long)w.y << 32) | w.x),
                       __longlong_as_double(((long long)w.w << 32) | w.z));
-  a.dw = q[6 * WAVE].x;
   return a;
 }
 
@@ -757,9 +762,9 @@ __device__ void dead_rows_patch(const DevPlan& P, const Lds& L, int lane) {
     const ARound a = load_around(P, r, lane);
     const int i = lane + WAVE * r;
     if (i >= P.nb || L.bt[i] != BT_DEAD) continue;
-    const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+    const unsigned (&ent)[KA] = a.ent;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) st_blk2<PK>(L, ent[k] >> 16, Blk{0.0, 0.0, 0.0, 0.0});
+    for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) st_blk2<PK>(L, ent[k] >> 16, Blk{0.0, 0.0, 0.0, 0.0});
     st_blk2<PK>(L, a.dw & 0xFFFF, Blk{1.0, 0.0, 0.0, 1.0});
     L.rhs[i] = 0.0; L.rq[i] = 0.0;
   }
@@ -848,7 +853,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     for (int f = fill_lo + lane; f < fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
     OPFX_STAMP(10);
     double my = 0.0;
-    // overflow entries of rows longer than 4: any row per lane, row sums accumulated in the
+    // overflow entries of rows longer than the ELL width: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
     if (P.rh > 0) {
       if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
@@ -892,11 +897,11 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         const double vri = L.vr[i], vii = L.vi[i];
         double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
         if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
-        const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
-        // branch-free over the 4 ELL slots (padding slots carry Y = 0 and read V_i): the four
+        const unsigned (&ent)[KA] = a.ent;
+        // branch-free over the ELL slots (padding slots carry Y = 0 and read V_i): the four
         // dependency chains interleave instead of being serialised by exec-mask branches
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KA; ++k) {
           const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
           const double g = a.y[k].x, b = a.y[k].y;
           const double vrj = L.vr[j], vij = L.vi[j];
@@ -911,7 +916,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         }
         if (t == BT_PV) {                                    // rare: skipped as a whole when the wave has no PV row
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
+          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
         if (t != BT_REF) {
           const double g = a.yd.x, b = a.yd.y;
@@ -1041,7 +1046,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   OPFX_STAMP_INIT();
   uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
   const unsigned tail = P.tail_bus[lane & 31];     // the lane's pivot of the dense tail (tail_solve)
-  // overflow entries of rows longer than 4 (phase A): the row this thread zeroes and this wavefront's first round
+  // overflow entries of rows longer than the ELL width (phase A): the row this thread zeroes and this wavefront's first round
   const int hrow0 = tid < P.n_hrows ? P.lp_hrows[tid] : -1;
   uint4 hy0 = make_uint4(0, 0, 0, 0), he0 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
   if (wave < P.rh) { hy0 = hpk[(size_t)(wave * 2) * WAVE + lane]; he0 = hpk[(size_t)(wave * 2 + 1) * WAVE + lane]; }
@@ -1101,9 +1106,9 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const double vri = L.vr[i], vii = L.vi[i];
         double sr = 0.0, si = 0.0;
         if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
-        const unsigned ent[4] = {a.ent.x, a.ent.y, a.ent.z, a.ent.w};
+        const unsigned (&ent)[KA] = a.ent;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < KA; ++k) {
           const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
           double g = a.y[k].x, b = a.y[k].y;
           const double vrj = L.vr[j], vij = L.vi[j];
@@ -1115,7 +1120,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         }
         if (t == BT_PV) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
+          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
         double g = a.yd.x, b = a.yd.y;
         const double v2 = vri * vri + vii * vii;

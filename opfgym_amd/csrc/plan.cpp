@@ -377,19 +377,21 @@ void build_lane_programs(opfx_plan* p) {
     if (tail_m == 0) p->team_kb[t] = K;
     p->n_groups = (int32_t)groups.size();
   }
-  p->lp_apk.assign((size_t)p->ra * 7 * 64 * 4, 0u);
+  static_assert(KA >= 1 && KA <= 3, "entries and the diagonal-block word share one 16-byte vector");
+  constexpr int NV = opfx_plan::APK_VECS;
+  p->lp_apk.assign((size_t)p->ra * NV * 64 * 4, 0u);
   for (int r = 0; r < p->ra; ++r)
     for (int l = 0; l < 64; ++l) {
-      auto at = [&](int v) { return (((size_t)r * 7 + v) * 64 + l) * 4; };
+      auto at = [&](int v) { return (((size_t)r * NV + v) * 64 + l) * 4; };
       for (int k = 0; k < KA; ++k) {
         const size_t o = ((size_t)r * KA + k) * 64 + l;
         p->lp_apk[at(0) + k] = p->lp_a_ent[o];
         put_d(p->lp_apk, at(1 + k), p->lp_a_y[o * 2]);
         put_d(p->lp_apk, at(1 + k) + 2, p->lp_a_y[o * 2 + 1]);
       }
-      put_d(p->lp_apk, at(5), p->lp_a_ydiag[((size_t)r * 64 + l) * 2]);
-      put_d(p->lp_apk, at(5) + 2, p->lp_a_ydiag[((size_t)r * 64 + l) * 2 + 1]);
-      p->lp_apk[at(6)] = p->lp_a_dblk[(size_t)r * 64 + l];
+      p->lp_apk[at(0) + 3] = p->lp_a_dblk[(size_t)r * 64 + l];
+      put_d(p->lp_apk, at(1 + KA), p->lp_a_ydiag[((size_t)r * 64 + l) * 2]);
+      put_d(p->lp_apk, at(1 + KA) + 2, p->lp_a_ydiag[((size_t)r * 64 + l) * 2 + 1]);
     }
   p->lp_hpk.assign((size_t)p->rh * 2 * 64 * 4, 0u);
   for (int h = 0; h < p->rh; ++h)
@@ -632,6 +634,7 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->n_groups = p->n_groups;
   o->team_kb[0] = p->team_kb[0]; o->team_kb[1] = p->team_kb[1];
   o->tail_m = p->tail_m;
+  o->lp_ell_width = opfx_plan::KA;
   return OPFX_OK;
 }
 

@@ -40,7 +40,15 @@ struct opfx_plan {
   // ---- lane programmes for the register-resident kernel (k_*2) ------------------
   // Every array is [round][lane] (64 lanes per round) so that a wave loads its
   // descriptors with one coalesced access per round, once per kernel.
-  static constexpr int KA = 4;             // ELL width: off-diagonal Ybus entries per bus row
+#ifndef OPFX_ELL_WIDTH
+#define OPFX_ELL_WIDTH 2
+#endif
+  // ELL width: off-diagonal Ybus entries per bus row held in the row's own lane; longer rows put the rest into the
+  // flat overflow list.  Padding slots cost a full entry evaluation each, and power grids are sparse (144-bus MV
+  // grid: 26/102/14/2 buses of degree 1/2/3/7; 306-bus HV: 131 of degree 1): width 4 evaluates 13 slot-rounds per
+  // pass of the 144-bus grid for 286 entries, width 2 seven (6 + one overflow round).
+  static constexpr int KA = OPFX_ELL_WIDTH;
+  static constexpr int APK_VECS = KA + 2;  // 16-byte vectors per (round, lane) of lp_apk
   int32_t ra = 0, rh = 0, rb = 0, rc = 0;  // rounds: bus rows, heavy-row overflow, factor/forward, backward
   int32_t rb_pad = 0, rc_pad = 0;          // rounds of the two parts of lp_bc (multiples of 4)
   std::vector<uint32_t> lp_a_ent;          // [ra][KA][64]  j | blk<<16   (0xFFFF = none)
@@ -54,7 +62,7 @@ struct opfx_plan {
   std::vector<uint32_t> lp_c;              // [rc][64][2]  (0x8000|k)|blk(k,j)<<16 , blk(j,j)|j<<16  (back substitution, same item form as lp_b)
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
   std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,-,0 (pad: empty items)
-  std::vector<uint32_t> lp_apk;            // [ra][7][64][4]  ent0..3 | y0 | y1 | y2 | y3 | ydiag | dblk,0,0,0
+  std::vector<uint32_t> lp_apk;            // [ra][KA+2][64][4]  ent0..ent(KA-1), dblk | y0 | .. | y(KA-1) | ydiag
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
   // cooperative kernels (2 or 4 wavefronts per instance): the rounds of each group dealt round-robin

@@ -141,9 +141,10 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
     nb = case.nb
     bt = case.bus_type
     ra, rh, rb, rc = (info[k] for k in ('lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c'))
-    a_ent = plan.array('lp_a_ent').view(np.uint32).reshape(ra, 4, 64)
+    ka = info['lp_ell_width']
+    a_ent = plan.array('lp_a_ent').view(np.uint32).reshape(ra, ka, 64)
     a_dblk = plan.array('lp_a_dblk').view(np.uint32).reshape(ra, 64)
-    a_y = plan.darray('lp_a_y').reshape(ra, 4, 64, 2)
+    a_y = plan.darray('lp_a_y').reshape(ra, ka, 64, 2)
     a_yd = plan.darray('lp_a_ydiag').reshape(ra, 64, 2)
     h_ent = plan.array('lp_h_ent').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
     h_row = plan.array('lp_h_row').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
@@ -185,7 +186,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
                     continue
                 t = bt[i]
                 s = soff[i] if (a_dblk[r, lane] >> 16) else 0j
-                for k in range(4):
+                for k in range(ka):
                     j = int(a_ent[r, k, lane] & 0xFFFF)
                     if j == NONE:
                         continue
