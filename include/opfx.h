@@ -314,6 +314,10 @@ typedef struct opfx_env_desc {
   const int32_t* xres_q;          /* [n_xres] column of the store or -1      */
   const double* xres_scale;       /* [n_xres] */
   const int32_t* xres_r;          /* [n_xres] third result index of OPFX_XRES_MAX3 rows (else unused); NULL = none */
+  /* Bus of the unit behind every OPFX_COST_UNIT row, -1 for the other kinds; NULL = none.  pandapower reports zero
+   * power for units on a de-energised bus (results_bus.py: set-point x `_is_elements`), so the cost rows of units on
+   * an island that a switch state or an outage has cut off vanish from the objective (objective.py:34-54). */
+  const int32_t* cost_bus;        /* [npoly+npwl] */
 } opfx_env_desc;
 
 int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);

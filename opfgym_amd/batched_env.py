@@ -820,19 +820,28 @@ class BatchedOpfEnv:
             sc = float(net[et]['scaling'].iloc[pos]) if 'scaling' in net[et].columns else 1.0
             if et == 'gen':
                 return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc
+            # (a unit on a bus that is not part of the compiled case — permanently de-energised — or out of
+            #  service reports zero power, results_bus.py: its row keeps the constant term only)
+            bus = c.bus_lookup.get(int(net[et]['bus'].iloc[pos]), -1)
+            if bus < 0 or ('in_service' in net[et].columns and not bool(net[et]['in_service'].iloc[pos])):
+                sc = 0.0
+            cost_bus_of_row.append(bus)
             return capi.COST_UNIT, st.slot(et, 'p_mw') + pos, st.slot(et, 'q_mvar') + pos, sc
         poly, pwl = net['poly_cost'], net['pwl_cost']
         if self.objective_terms or self.host_objective is not None:   # objective_function replaces get_pandapower_costs (opf_env.py:80-84)
             poly, pwl = poly.iloc[:0], pwl.iloc[:0]
-        ck, cp, cq, cs, coef, is_q = [], [], [], [], [], []
+        ck, cp, cq, cs, coef, is_q, cbus = [], [], [], [], [], [], []
+        cost_bus_of_row = []
         for _, row in poly.iterrows():
+            cost_bus_of_row.clear()
             k, pi, qi, sc = cost_source(row['et'], row['element'])
-            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc)
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(cost_bus_of_row[0] if cost_bus_of_row else -1)
             coef += [float(row[n]) for n in _POLY_COEF]
         nseg = min((len(p) for p in pwl['points']), default=0) if len(pwl) else 0      # defect D9
         for _, row in pwl.iterrows():
+            cost_bus_of_row.clear()
             k, pi, qi, sc = cost_source(row['et'], row['element'])
-            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc)
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(cost_bus_of_row[0] if cost_bus_of_row else -1)
             is_q.append(0 if row['power_type'] == 'p' else 1)
             for sgm in row['points'][:nseg]:
                 coef += [float(v) for v in sgm]
@@ -889,6 +898,7 @@ class BatchedOpfEnv:
         d.npoly, d.npwl, d.nseg = len(poly), len(pwl), nseg
         d.cost_kind, d.cost_pidx, d.cost_qidx = _keep(keep, ck, 'i'), _keep(keep, cp, 'i'), _keep(keep, cq, 'i')
         d.cost_scale, d.pwl_is_q, d.cost_coef = _keep(keep, cs, 'd'), _keep(keep, is_q, 'i'), _keep(keep, coef, 'd')
+        d.cost_bus = _keep(keep, cbus, 'i')
         d.nprice = len(price_slot)
         d.price_slot, d.price_coef = _keep(keep, price_slot, 'i'), _keep(keep, price_coef, 'i')
         d.nc = len(self.device_constraints)

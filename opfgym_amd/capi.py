@@ -95,7 +95,7 @@ class EnvDesc(C.Structure):
         ('vset_slot', _pi),
         ('n_qterm', C.c_int32), ('qterm_idx', _pi), ('qterm_target', _pd), ('qterm_weight', _pd),
         ('n_xres', C.c_int32), ('xres_kind', _pi), ('xres_p', _pi), ('xres_q', _pi), ('xres_scale', _pd),
-                ('xres_r', _pi)]
+                ('xres_r', _pi), ('cost_bus', _pi)]
 
 
 ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2

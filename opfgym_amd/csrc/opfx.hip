@@ -103,6 +103,7 @@ struct DevEnv {
   // cost rows in processing order: rows fed by table values/set-points first (ncost_pre), then
   // rows fed by the solve.  meta = kind | is_pwl<<4 | pwl_is_q<<5; sources: see src_val()
   const int *cost_meta, *cost_psrc, *cost_qsrc, *cost_cbase, *coef_xslot;
+  const int* cost_bus;       // [ncost_pre] bus of the unit behind a pre-solve cost row (-1: none), or nullptr
   const double *cost_scale, *cost_coef;
   const int2* con_pk;                              // {result index, constraint}
   const int* con_worst;
@@ -1935,8 +1936,25 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
           const int meta = as_global(E.cost_meta)[r], pi = as_global(E.cost_psrc)[r];
           double pw_, qv_;
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
-          else { pw_ = src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r]; qv_ = r_qg[pi]; }
+          else {                                               // generator: zero power on a de-energised bus (results_gen.py)
+            pw_ = L.bt[pi] == BT_DEAD ? 0.0 : src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r];
+            qv_ = r_qg[pi];
+          }
           csum += cost_row(E, xr, meta, as_global(E.cost_cbase)[r], pw_, qv_);
+        }
+        if (isl != 0 && E.cost_bus) {
+          // rare: this instance has a de-energised island.  Units on it report zero power (results_bus.py), so
+          // the rows the prologue evaluated from their set-points are replaced by rows at zero power — on the
+          // lane that added them, from the instance's row in global memory (the staged copy is gone)
+          for (int r = lane; r < E.ncost_pre; r += WAVE) {
+            const int bus = as_global(E.cost_bus)[r];
+            if (bus < 0 || L.bt[bus] != BT_DEAD) continue;
+            const int meta = as_global(E.cost_meta)[r], cbase = as_global(E.cost_cbase)[r];
+            const double scl_ = as_global(E.cost_scale)[r];
+            csum -= cost_row(E, xr, meta, cbase, src_val(xr, L.sp, as_global(E.cost_psrc)[r]) * scl_,
+                             src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * scl_);
+            csum += cost_row(E, xr, meta, cbase, 0.0, 0.0);
+          }
         }
         for (int k = lane; k < E.n_qterm; k += WAVE) {            // objective_function seam: w (result - target)^2
           const double dv = R[as_global(E.qterm_idx)[k]] - as_global(E.qterm_target)[k];
@@ -2469,7 +2487,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
       cx[d->price_coef[k]] = d->price_slot[k];
     }
     if (rc == OPFX_OK) rc = A.put(cx, &E.coef_xslot);
-    std::vector<int32_t> meta, ps, qs, cb;
+    std::vector<int32_t> meta, ps, qs, cb, cbus;
     std::vector<double> scl;
     for (int pass = 0; pass < 2; ++pass) {
       for (size_t r = 0; r < ncost; ++r) {
@@ -2480,7 +2498,12 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
         meta.push_back(kind | (pwl ? 16 : 0) | (pwl && d->pwl_is_q[w] ? 32 : 0));
         cb.push_back(pwl ? (int32_t)(d->npoly * 6 + w * d->nseg * 3) : (int32_t)(r * 6));
         scl.push_back(d->cost_scale[r]);
-        if (kind == OPFX_COST_UNIT) { ps.push_back(src_of(d->cost_pidx[r])); qs.push_back(src_of(d->cost_qidx[r])); }
+        if (kind == OPFX_COST_UNIT) {
+          ps.push_back(src_of(d->cost_pidx[r])); qs.push_back(src_of(d->cost_qidx[r]));
+          const int32_t bus = d->cost_bus ? d->cost_bus[r] : -1;
+          if (bus >= ctx->plan.nb) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: cost_bus out of range"); }
+          cbus.push_back(bus);
+        }
         else if (kind == OPFX_COST_GEN) { ps.push_back(d->cost_pidx[r]); qs.push_back(src_of(d->cost_qidx[r])); }   // gen: qidx = slot of p_mw
         else { ps.push_back(d->cost_pidx[r]); qs.push_back(NOSRC); }
       }
@@ -2491,6 +2514,8 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     if (rc == OPFX_OK) rc = A.put(qs, &E.cost_qsrc);
     if (rc == OPFX_OK) rc = A.put(cb, &E.cost_cbase);
     if (rc == OPFX_OK) rc = A.put(scl, &E.cost_scale);
+    E.cost_bus = nullptr;
+    if (d->cost_bus && rc == OPFX_OK) rc = A.put(cbus, &E.cost_bus);
   }
   const size_t ncel = d->nc ? d->con_ptr[d->nc] : 0;
   {

@@ -115,20 +115,32 @@ class BatchedPowerFlowSolver:
                 k = ordinal[case.bus_lookup[int(b)]]
                 pe[pos], qe[pos] = r['s_ref'][k, 0] * base, r['s_ref'][k, 1] * base
         net['res_ext_grid'] = pd.DataFrame({'p_mw': pe, 'q_mvar': qe}, index=eg.index)
+        # units outside the power flow (out of service, or on a de-energised bus): zero rows, as pandapower's
+        # `_is_elements` mask produces them (results_bus.py write_pq_results_to_element, results_gen.py)
+        bus_pos = {int(b): k for k, b in enumerate(net['bus'].index)}
+
+        def takes_part(df):
+            live = np.array([int(b) in case.bus_lookup and not np.isnan(vm[bus_pos[int(b)]]) for b in df['bus']], dtype=bool)
+            if 'in_service' in df.columns:
+                live &= df['in_service'].to_numpy(bool)
+            return live
         for tbl in ('load', 'sgen', 'storage'):
             df = net[tbl]
             sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns and len(df) else 1.0
-            net['res_' + tbl] = pd.DataFrame({'p_mw': df['p_mw'].to_numpy(float) * sc,
-                                              'q_mvar': df['q_mvar'].to_numpy(float) * sc}, index=df.index)
+            part = takes_part(df).astype(float) if len(df) else 1.0
+            net['res_' + tbl] = pd.DataFrame({'p_mw': df['p_mw'].to_numpy(float) * sc * part,
+                                              'q_mvar': df['q_mvar'].to_numpy(float) * sc * part}, index=df.index)
         gen = net['gen']
         sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns and len(gen) else 1.0
-        qg, vg = np.full(len(gen), np.nan), np.full(len(gen), np.nan)
-        for pos, b in enumerate(gen['bus'].to_numpy() if len(gen) else []):
-            if int(b) in case.bus_lookup:
-                i = case.bus_lookup[int(b)]
-                qg[pos], vg[pos] = r['q_gen'][i] * base, r['vm'][i]
-        net['res_gen'] = pd.DataFrame({'p_mw': gen['p_mw'].to_numpy(float) * sc if len(gen) else [],
-                                       'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
+        pg, qg, vg = np.zeros(len(gen)), np.zeros(len(gen)), np.zeros(len(gen))
+        if len(gen):
+            live = takes_part(gen)
+            pset = gen['p_mw'].to_numpy(float) * sc
+            for pos, b in enumerate(gen['bus'].to_numpy()):
+                if live[pos]:
+                    i = case.bus_lookup[int(b)]
+                    pg[pos], qg[pos], vg[pos] = pset[pos], r['q_gen'][i] * base, r['vm'][i]
+        net['res_gen'] = pd.DataFrame({'p_mw': pg, 'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
 
 
 _default = None

@@ -372,9 +372,15 @@ def write_results(net, ppc: PPC, sol):
     for table in ('line', 'trafo', 'trafo3w'):
         if table in net:
             net['res_' + table] = pd.DataFrame({'loading_percent': ld[table]}, index=net[table].index)
+    # Units that take no part in the power flow — out of service themselves, or on a bus that is out of service or
+    # cut off every slack (pandapower's `_is_elements`: `in_service` AND the bus in service, isolated buses counted as
+    # out of service) — get ZEROS in their result rows: pandapower fills `res_gen` from arrays of zeros for the
+    # in-service generators only (results_gen.py: p, q, vm_pu, va_degree) and multiplies the set-points of
+    # `res_load / res_sgen / res_storage` by that mask (results_bus.py: write_pq_results_to_element).  [3P, from the
+    # published source, unverified here.]
     eg, gen = net['ext_grid'], net['gen']
     pe, qe = np.full(len(eg), np.nan), np.full(len(eg), np.nan)
-    pg, qg, vg = np.full(len(gen), np.nan), np.full(len(gen), np.nan), np.full(len(gen), np.nan)
+    pg, qg, vg = np.zeros(len(gen)), np.zeros(len(gen)), np.zeros(len(gen))
     for g in range(len(ppc.g_bus)):
         live = ppc.g_status[g] > 0 and sol['supplied'][ppc.g_bus[g]]
         pos = int(ppc.g_pos[g])
@@ -388,9 +394,13 @@ def write_results(net, ppc: PPC, sol):
         net['res_gen'] = pd.DataFrame({'p_mw': pg, 'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
     else:
         net['res_gen'] = pd.DataFrame({'p_mw': [], 'q_mvar': [], 'vm_pu': []})
+    bus_alive = {int(b): bool(on[pos] and sol['supplied'][ppc.bus_lookup[int(b)]]) for pos, b in enumerate(net['bus'].index)}
     for tbl in ('load', 'sgen', 'storage'):
         df = net[tbl]
         sc = df['scaling'].to_numpy(float) if 'scaling' in df.columns and len(df) else 1.0
+        part = np.array([bus_alive.get(int(b), False) for b in df['bus']], dtype=float) if len(df) else 1.0
+        if len(df) and 'in_service' in df.columns:
+            part = part * df['in_service'].to_numpy(bool)
         net['res_' + tbl] = pd.DataFrame(
-            {'p_mw': df['p_mw'].to_numpy(float) * sc if len(df) else [],
-             'q_mvar': df['q_mvar'].to_numpy(float) * sc if len(df) else []}, index=df.index)
+            {'p_mw': df['p_mw'].to_numpy(float) * sc * part if len(df) else [],
+             'q_mvar': df['q_mvar'].to_numpy(float) * sc * part if len(df) else []}, index=df.index)

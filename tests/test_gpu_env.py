@@ -755,6 +755,44 @@ def test_several_open_switches_with_an_island():
     assert n_dead[0] > 0 and n_dead[1] == 0          # all open: an island; all closed: none
 
 
+def test_units_on_a_de_energised_island_cost_nothing():
+    """pandapower reports ZERO power for units that take no part in the power flow (`_is_elements`: out of service,
+    or their bus cut off every slack — results_bus.py / results_gen.py), so their cost rows vanish from the
+    objective (objective.py reads res_<unit>.p_mw).  NetworkReconfiguration with a price on every sgen: with all
+    controllable switches open a part of the grid is an island; the kernel corrects the cost rows it evaluated
+    before the solve (from the set-points) once the island is known."""
+    import copy
+    import pandas as pd
+    kw = dict(grid_seed=26)
+    defn = copy.deepcopy(product_env('reconf_hv_small_sw', defer_device=True, **kw).definition)
+    net = defn.net
+    pc = net['poly_cost']
+    rows = []
+    for k, idx in enumerate(net['sgen'].index):
+        r = dict(pc.iloc[0]); r.update(et='sgen', element=int(idx), cp1_eur_per_mw=0.5 + 0.1 * k, cp0_eur=0.0)
+        rows.append(r)
+    net['poly_cost'] = pd.concat([pc, pd.DataFrame(rows)], ignore_index=True)
+    B = 4
+    env = product_env('reconf_hv_small_sw', batch_size=B, definition=defn, **kw)
+    orc = oracle_env('reconf_hv_small_sw', product_env('reconf_hv_small_sw', defer_device=True, definition=defn, **kw))
+    steps = np.random.default_rng(3).choice(env.train_steps, B)
+    env.reset(options={'step': steps})
+    n_sw = len(env.act_keys[0][2])
+    actions = np.full((B, env.n_actions), 0.5)
+    actions[:, :n_sw] = [[0.0] * n_sw, [1.0] * n_sw, [0.0] + [1.0] * (n_sw - 1), [1.0] * (n_sw - 1) + [0.0]]
+    out = env.step(actions)
+    dead_sgens = []
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert ref['converged'] and bool(_np(out[4]['converged'])[k])
+        _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+        alive = ~np.isnan(orc.net['res_bus']['vm_pu'].loc[orc.net['sgen']['bus']].to_numpy())
+        assert (orc.net['res_sgen']['p_mw'].to_numpy()[~alive] == 0).all()
+        dead_sgens.append(int((~alive).sum()))
+    assert dead_sgens[0] > 0 and dead_sgens[1] == 0      # the island of the all-open row holds sgens with a price
+
+
 @pytest.mark.parametrize('name,kw', [('reconf_hv_small_sw', dict(grid_seed=26)), ('sc_hv_small', dict(add_res_obs=True)),
                                      ('mixed_lv', {})])
 def test_wave_reuse_with_per_instance_branch_states(name, kw):
