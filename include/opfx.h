@@ -133,7 +133,8 @@ enum {
   OPFX_ARR_ISL_PTR, OPFX_ARR_ISL_BUS,  /* CSR [nbr+1] -> the buses that outage cuts off (they are de-energised) */
   OPFX_ARR_LP_TEAM2, OPFX_ARR_LP_TEAM4, /* wave-team streams [round][wave][64][4] */
   OPFX_ARR_TAIL_BUS,                    /* [32] bus | diagonal block << 16 of the dense tail's pivots */
-  OPFX_ARR_TAIL_IDS                     /* [tail_m + 1][M] U-block ids inside the tail (0xFFFF none), M = tail_m rounded up to 8 */
+  OPFX_ARR_TAIL_IDS,                    /* [tail_m + 1][M] U-block ids inside the tail (0xFFFF none), M = tail_m rounded up to 8 */
+  OPFX_ARR_LP_B2                        /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };

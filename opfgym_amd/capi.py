@@ -26,7 +26,7 @@ OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, O
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
-          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS']
+          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2']
 DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y']
 
 _pd = C.POINTER(C.c_double)

@@ -509,9 +509,9 @@ __device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a1
 // The twelve values an item reads.  Loading (item_load) and using them (item_apply) are separate steps so
 // that the reads of the NEXT round can be in flight while this round computes, whenever the plan marks the two
 // rounds as independent (ITEM_NEXT_INDEPENDENT: same elimination level / same back-substitution group).
-struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22; };
+struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22, y1, y2; };
 constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;   // flags in word 3 of a round's items (plan.cpp)
-template <bool PK>
+template <bool PK, bool RIDERS>
 __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -528,9 +528,12 @@ __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   const double* c3p = rhs_t ? (L.rq + kj) : (L.blk + L.o2 + kjc);
   r.c11 = *c1p; r.c21 = *c3p;
   r.c12 = L.blk[L.bs + kjb]; r.c22 = L.blk[L.o3 + kjc];
+  // rider (plan.cpp): the item's multiplier also takes y_k to y_i — the forward substitution of the pair (i, k)
+  r.y1 = 0.0; r.y2 = 0.0;
+  if (RIDERS && (d.z >> 16) != NONE) { const unsigned k = d.z >> 16; r.y1 = L.rhs[k]; r.y2 = L.rq[k]; }
   return r;
 }
-template <bool PK>
+template <bool PK, bool RIDERS>
 __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const ItemRegs& r) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -561,12 +564,21 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
     lds_add(L.blk + L.bs + tb, m11 * c12 + m12 * c22);
     lds_add(L.blk + L.o3 + tb, m21 * c12 + m22 * c22);
   }
+  if (RIDERS && (d.z >> 16) != NONE) {
+    const unsigned i = d.z & 0xFFFF;
+    lds_add(L.rhs + i, m11 * r.y1 + m12 * r.y2);
+    lds_add(L.rq + i, m21 * r.y1 + m22 * r.y2);
+  }
 }
-template <bool PK>
+// RIDERS: the stream may carry forward-substitution riders (plan.cpp).  Only the single-wave kernels' stream does:
+// there a rider saves whole rounds (144-bus grid: 11 -> 8 rounds of factorisation, 0.286 -> 0.273 ms), whereas the
+// wave teams walk one round per wavefront through most levels either way and the two tests per item cost more
+// than the saved rounds give back (config 3: 1.967 -> 1.976 ms with riders, 2.06 ms with the tests but no riders).
+template <bool PK, bool RIDERS>
 __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
-  const ItemRegs r = item_load<PK>(L, d);
-  item_apply<PK>(L, d, r);
+  const ItemRegs r = item_load<PK, RIDERS>(L, d);
+  item_apply<PK, RIDERS>(L, d, r);
 }
 // Back substitution through the dense tail of the elimination (plan.cpp: the last m levels hold one pivot each
 // and their U-rows are full): a strictly serial chain.  As LDS groups it costs one round trip + one 2x2 inverse
@@ -657,7 +669,7 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
 template <bool PK>
 __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
-  item_factor<PK>(L, d);
+  item_factor<PK, false>(L, d);
   if (fl & ITEM_BARRIER) lds_barrier(); else wave_fence();        // (no barrier: the same wavefront carries on)
 }
 
@@ -970,17 +982,17 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     // Rounds of one level are independent; ordering is needed at level ends only, but on a
     // single wave the fence is free (the LDS executes a wave's operations in order).
     for (int r = 0; r < RB; r += 4) {
-      item_factor<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_factor<PK, true>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK, true>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK, true>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK, true>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(2);
     for (int r = RB; r < R; r += 4) {
-      item_factor<PK>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor<PK>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor<PK>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor<PK>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_factor<PK, false>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK, false>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK, false>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK, false>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
     OPFX_STAMP(3);
     // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----

@@ -169,32 +169,73 @@ void build_lane_programs(opfx_plan* p) {
   p->rh = (int32_t)(p->lp_h_ent.size() / 64);
   // ---- B ---------------------------------------------------------------------
   // per level: every (target, source) update term is one item; terms that share a
-  // target may sit in the same round (the kernel accumulates with LDS atomics);
-  // block targets first, rhs targets last, so that a round is mostly homogeneous.
+  // target may sit in the same round (the kernel accumulates with LDS atomics).
+  // The forward substitution rides along: the term  y_i -= A_ik A_kk^-1 y_k  needs the same multiplier as the
+  // block terms of the pair (i, k), and one of those always exists — the one on the diagonal block (i, i), because
+  // the pattern is symmetric (A_ki is there whenever A_ik is).  That item carries the pair (i, k) in its third
+  // word (lp_b2) and applies the multiplier to y_k as well: no separate right-hand-side items (1 of 7 items on
+  // the 306-bus grid, 1 of 4 on the radial 144-bus grid), no second evaluation of A_kk^-1 for them.
+  // Items with a rider first, so that a round is mostly homogeneous; right-hand-side terms that found no
+  // carrier (none on a symmetric pattern) would follow as items of their own.
+  // A rider lengthens its item (two more LDS reads, two more atomics), so it only pays where it saves a round:
+  // each stream — one wavefront, teams of two and of four — decides per level by the rounds a wavefront walks
+  // (`use_riders`); a level whose items fit one round per wavefront either way keeps separate items.
   const int nlev = p->n_levels();
   std::vector<int32_t> b_bounds{0}, c_bounds;
-  std::vector<std::array<uint32_t, 2>> items;
-  auto flush = [&]() {
-    for (size_t o = 0; o < items.size(); o += 64) {
-      for (int lane = 0; lane < 64; ++lane) {
-        if (o + lane < items.size()) { p->lp_b.push_back(items[o + lane][0]); p->lp_b.push_back(items[o + lane][1]); }
-        else { p->lp_b.push_back(NONE | (NONE << 16)); p->lp_b.push_back(0); }
-      }
-    }
-    items.clear();
-  };
+  struct Item3 { uint32_t w0, w1, w2; };
+  constexpr uint32_t NO_RIDER = NONE | (NONE << 16);
+  std::vector<std::vector<Item3>> lev_rider(nlev), lev_sep(nlev);
   for (int lev = 0; lev < nlev; ++lev) {
     const int t0 = p->lev_tptr[lev], t1 = p->lev_tptr[lev + 1];
-    for (int pass = 0; pass < 2; ++pass)
-      for (int t = t0; t < t1; ++t) {
-        const int tb = p->tgt_blk[t];
-        if ((tb >= 0) != (pass == 0)) continue;
-        const uint32_t tgt = tb >= 0 ? (uint32_t)tb : (0x8000u | (uint32_t)(-1 - tb));
-        for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s)
-          items.push_back({tgt | ((uint32_t)p->src_ik[s] << 16),
-                           (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16)});
+    // right-hand-side terms of the level by the block A_ik they multiply with: (i, k)
+    std::unordered_map<int32_t, std::pair<int32_t, int32_t>> rhs_of;
+    for (int t = t0; t < t1; ++t)
+      if (p->tgt_blk[t] < 0)
+        for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) rhs_of[p->src_ik[s]] = {-1 - p->tgt_blk[t], p->src_kj[s]};
+    std::vector<Item3> carriers, plain, rhs_items, rhs_left;
+    for (int t = t0; t < t1; ++t) {
+      const int tb = p->tgt_blk[t];
+      if (tb < 0) continue;
+      const bool diagonal = p->blk_row[tb] == p->blk_col[tb];
+      for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) {
+        const Item3 it{(uint32_t)tb | ((uint32_t)p->src_ik[s] << 16), (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16), NO_RIDER};
+        lev_sep[lev].push_back(it);
+        auto f = diagonal ? rhs_of.find(p->src_ik[s]) : rhs_of.end();
+        if (f != rhs_of.end() && f->second.first == p->blk_row[tb]) {
+          carriers.push_back({it.w0, it.w1, (uint32_t)f->second.first | ((uint32_t)f->second.second << 16)});
+          rhs_of.erase(f);
+        } else {
+          plain.push_back(it);
+        }
       }
-    flush();
+    }
+    for (int t = t0; t < t1; ++t) {
+      const int tb = p->tgt_blk[t];
+      if (tb >= 0) continue;
+      for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) {
+        const Item3 it{(0x8000u | (uint32_t)(-1 - tb)) | ((uint32_t)p->src_ik[s] << 16),
+                       (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16), NO_RIDER};
+        rhs_items.push_back(it);
+        if (rhs_of.count(p->src_ik[s])) rhs_left.push_back(it);          // (a term without a carrier)
+      }
+    }
+    lev_sep[lev].insert(lev_sep[lev].end(), rhs_items.begin(), rhs_items.end());       // block targets first, rhs targets last
+    lev_rider[lev] = carriers;                                                          // items with a rider first
+    lev_rider[lev].insert(lev_rider[lev].end(), plain.begin(), plain.end());
+    lev_rider[lev].insert(lev_rider[lev].end(), rhs_left.begin(), rhs_left.end());
+  }
+  auto rounds_of = [](size_t n) { return (int)((n + 63) / 64); };
+  auto use_riders = [&](int lev, int nw) {
+    const int with = (rounds_of(lev_rider[lev].size()) + nw - 1) / nw, without = (rounds_of(lev_sep[lev].size()) + nw - 1) / nw;
+    return with < without && !getenv("OPFX_NO_RIDERS");
+  };
+  for (int lev = 0; lev < nlev; ++lev) {
+    const std::vector<Item3>& its = use_riders(lev, 1) ? lev_rider[lev] : lev_sep[lev];
+    for (size_t o = 0; o < its.size(); o += 64)
+      for (int lane = 0; lane < 64; ++lane) {
+        if (o + lane < its.size()) { p->lp_b.push_back(its[o + lane].w0); p->lp_b.push_back(its[o + lane].w1); p->lp_b2.push_back(its[o + lane].w2); }
+        else { p->lp_b.push_back(NONE | (NONE << 16)); p->lp_b.push_back(0); p->lp_b2.push_back(NO_RIDER); }
+      }
     b_bounds.push_back((int32_t)(p->lp_b.size() / 128));
   }
   p->rb = (int32_t)(p->lp_b.size() / 128);
@@ -205,6 +246,7 @@ void build_lane_programs(opfx_plan* p) {
   // (j,j), source j).  One group of mutually independent items per level, walked from the last level to the
   // first; nothing is divided in place — the kernel's voltage update computes x_i = A_ii^-1 y_i for every
   // bus at the end.  (A row-oriented sweep needs a second group per level for pivots with many U-terms.)
+  std::vector<std::array<uint32_t, 2>> items;
   std::vector<std::vector<std::array<int32_t, 2>>> col_terms(nb);      // j -> (k, block (k,j))
   for (size_t q = 0; q + 1 < p->piv_uptr.size(); ++q)
     for (int u = p->piv_uptr[q]; u < p->piv_uptr[q + 1]; ++u)
@@ -248,6 +290,7 @@ void build_lane_programs(opfx_plan* p) {
     for (int l = 0; l < 64; ++l) {
       p->lp_bc[((size_t)r * 64 + l) * 4 + 0] = p->lp_b[((size_t)r * 64 + l) * 2];
       p->lp_bc[((size_t)r * 64 + l) * 4 + 1] = p->lp_b[((size_t)r * 64 + l) * 2 + 1];
+      p->lp_bc[((size_t)r * 64 + l) * 4 + 2] = p->lp_b2[(size_t)r * 64 + l];
     }
   for (int r = 0; r < p->rc; ++r)
     for (int l = 0; l < 64; ++l)
@@ -322,21 +365,38 @@ void build_lane_programs(opfx_plan* p) {
         for (int l = 0; l < 64; ++l) { out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(flags); }
       ++K;
     };
-    // real groups (padding ranges dropped): (source, first round, end round); source 0 = lp_bc, 1 = tc.
+    // real groups (padding ranges dropped): (source, first round, end round); source 0 = lp_bc, 1 = tc,
+    // 2 = tbk (this team's factorisation rounds).
     // With a tail the stream has two parts, each padded to a multiple of 4 rounds: factorisation + forward
     // substitution | back substitution below the tail; the kernels run the register chain between them
     // (a workgroup barrier follows it), so the last round of the first part needs a barrier only if another
     // wavefront than 0 took part in its group.
     struct Group { int src, r0, r1; };
     std::vector<Group> groups;
-    for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g) {
-      const int r0 = p->lp_groups[g], r1 = p->lp_groups[g + 1];
-      const bool pad_group = (r0 >= p->rb && r1 <= p->rb_pad) || r0 >= p->rb_pad + p->rc;
-      if (r0 == r1 || pad_group) continue;
-      if (tail_m > 0 && r0 >= p->rb_pad) continue;               // back substitution comes from `tc`
-      groups.push_back({0, r0, r1});
+    // factorisation + forward substitution: per level the item form that needs fewer rounds per wavefront of THIS
+    // team; items with a rider are dealt round-robin over the level's rounds so that no wavefront gets all of them
+    std::vector<uint32_t> tbk;
+    for (int lev = 0; lev < nlev; ++lev) {
+      const bool rid = false;          // (the team kernels' items take no riders, opfx.hip item_factor; `use_riders(lev, NW)` is how it was measured)
+      const std::vector<Item3>& its = rid ? lev_rider[lev] : lev_sep[lev];
+      const int nr = rounds_of(its.size());
+      if (nr == 0) continue;
+      const int first = (int)(tbk.size() / 256);
+      tbk.resize(tbk.size() + (size_t)nr * 256, NONE | (NONE << 16));
+      for (size_t q = 0; q < its.size(); ++q) {
+        const size_t r = rid ? q % nr : q / 64, l = rid ? q / nr : q % 64;
+        uint32_t* at = &tbk[((size_t)(first + r) * 64 + l) * 4];
+        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w2;
+      }
+      groups.push_back({2, first, first + nr});
     }
-    const size_t n_first = groups.size();
+    if (tail_m == 0)
+      for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g) {     // back substitution: the rounds of lp_bc
+        const int r0 = p->lp_groups[g], r1 = p->lp_groups[g + 1];
+        if (r0 == r1 || r0 < p->rb_pad || r0 >= p->rb_pad + p->rc) continue;
+        groups.push_back({0, r0, r1});
+      }
+    const size_t n_first = tail_m > 0 ? groups.size() : 0;
     if (tail_m > 0)
       for (size_t g = 0; g + 1 < tc_bounds.size(); ++g) groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
     p->team_kb[t] = -1;
@@ -353,7 +413,7 @@ void build_lane_programs(opfx_plan* p) {
       }
       const bool last_of_part = tail_m > 0 && g + 1 == n_first;  // (the chain runs on wavefront 0, like a one-round group)
       const bool next_single = last_of_part || (g + 1 < groups.size() && groups[g + 1].r1 - groups[g + 1].r0 == 1);
-      const uint32_t* src = groups[g].src == 0 ? p->lp_bc.data() : tc.data();
+      const uint32_t* src = groups[g].src == 0 ? p->lp_bc.data() : (groups[g].src == 1 ? tc.data() : tbk.data());
       for (int j = 0; j < per; ++j) {
         const uint32_t flags = ((j == per - 1 && !(single && next_single)) ? 1u : 0u) | (j < per - 1 ? 2u : 0u);
         p->team_barriers[t] += (int32_t)(flags & 1u);
@@ -648,6 +708,7 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_H_ENT: v = u32(p->lp_h_ent); break;
     case OPFX_ARR_LP_H_ROW: v = u32(p->lp_h_row); break;
     case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
+    case OPFX_ARR_LP_B2: v = u32(p->lp_b2); break;
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
     case OPFX_ARR_LP_TEAM2: v = u32(p->lp_team[0]); break;
     case OPFX_ARR_LP_TEAM4: v = u32(p->lp_team[1]); break;

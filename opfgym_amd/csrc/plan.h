@@ -59,9 +59,10 @@ struct opfx_plan {
   std::vector<uint32_t> lp_h_row;          // [rh]      bus whose overflow entries this round holds
   std::vector<double> lp_h_y;              // [rh][64][2]
   std::vector<uint32_t> lp_b;              // [rb][64][2]  tb|ik<<16 , kk|kj<<16
+  std::vector<uint32_t> lp_b2;             // [rb][64]     i|k<<16: the item also applies its multiplier to y_k -> y_i (0xFFFF|0xFFFF<<16: no)
   std::vector<uint32_t> lp_c;              // [rc][64][2]  (0x8000|k)|blk(k,j)<<16 , blk(j,j)|j<<16  (back substitution, same item form as lp_b)
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
-  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,-,0 (pad: empty items)
+  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,rider,flags (pad: empty items)
   std::vector<uint32_t> lp_apk;            // [ra][KA+2][64][4]  ent0..ent(KA-1), dblk | y0 | .. | y(KA-1) | ydiag
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)

@@ -150,6 +150,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
     h_row = plan.array('lp_h_row').view(np.uint32).reshape(rh, 64) if rh else np.zeros((0, 64), np.uint32)
     h_y = plan.darray('lp_h_y').reshape(rh, 64, 2) if rh else np.zeros((0, 64, 2))
     lp_b = plan.array('lp_b').view(np.uint32).reshape(rb, 64, 2)
+    lp_b2 = plan.array('lp_b2').view(np.uint32).reshape(rb, 64)      # riders: i | k << 16 (forward substitution of the pair)
     lp_c = plan.array('lp_c').view(np.uint32).reshape(rc, 64, 2)
     fill = plan.array('fill_blk')
     v = case.vm_set * np.exp(1j * case.va_set)
@@ -233,6 +234,10 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
                         drhs[i] = drhs.get(i, 0) + w @ rhs[w1 >> 16]
                     else:
                         dblk_upd[tb] = dblk_upd.get(tb, 0) + w @ blk[w1 >> 16]
+                    rider = int(lp_b2[r, lane])
+                    if (rider >> 16) != NONE:
+                        assert not tb & 0x8000
+                        drhs[rider & 0xFFFF] = drhs.get(rider & 0xFFFF, 0) + w @ rhs[rider >> 16]
                 for tb, d in dblk_upd.items():
                     blk[tb] -= d
                 for i, d in drhs.items():
@@ -305,6 +310,12 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2):
                         upd_b[tb] = upd_b.get(tb, 0) + mlt @ blk[kj]
                         reads[w].add(('b', kj))
                         adds[w].add(('b', tb))
+                    rider = int(stream[k, w, lane, 2])
+                    if (rider >> 16) != NONE:
+                        i2, k2 = rider & 0xFFFF, rider >> 16
+                        upd_r[i2] = upd_r.get(i2, 0) + mlt @ rhs[k2]
+                        reads[w].add(('r', k2))
+                        adds[w].add(('r', i2))
                     # an item never reads what an item of the same round adds to (one group = independent items)
                 for tb, d in upd_b.items():
                     blk[tb] -= d
