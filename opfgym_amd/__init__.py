@@ -3,8 +3,8 @@ reset()/step()/reward hot path.  Public names mirror the
 reference package (`opfgym/__init__.py:2-6`)."""
 from .reward import RewardFunction  # noqa: F401
 from .constraints import Constraint  # noqa: F401
-from .batched_env import (BatchedOpfEnv, MultiStageOpfEnv, SecurityConstrainedOpfEnv,  # noqa: F401
-                          StochasticObservation)
+from .batched_env import (BatchedOpfEnv, MultiStageOpfEnv, PowerFlowNotAvailable,  # noqa: F401
+                          SecurityConstrainedOpfEnv, StochasticObservation)
 from .solver_plugin import BatchedPowerFlowSolver, power_flow_solver  # noqa: F401
 
 OpfEnv = BatchedOpfEnv

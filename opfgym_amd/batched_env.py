@@ -270,6 +270,10 @@ def _keep(lst, arr, kind):
     return a.ctypes.data_as(capi._pd if kind == 'd' else capi._pi)
 
 
+class PowerFlowNotAvailable(Exception):
+    """opf_env.py:22"""
+
+
 class BatchedOpfEnv:
     """See module docstring.  Arguments as `OpfEnv.__init__` (opf_env.py:27-56)
     plus `batch_size`, `device` and, for the N-1 variant
@@ -317,6 +321,9 @@ class BatchedOpfEnv:
         # loops that keep what they were handed; costs one device copy per returned tensor and call)
         self.copy_outputs = bool(copy_outputs)
         self._state_valid = False
+        self.power_flow_available = False
+        self._objective_is_diff = False
+        self._last_host = None
         self.batch_size = int(batch_size)
         self.obs_keys = list(observation_keys)
         self.state_keys = list(state_keys) if state_keys else copy.copy(self.obs_keys)
@@ -1060,6 +1067,10 @@ class BatchedOpfEnv:
         return io
 
     def _launch_step(self, action, mode=0, with_initial_obj=False):
+        # (modes that run a power flow leave results behind: opf_env.py:659 power_flow_available)
+        self.power_flow_available = mode in (0, 1, 4, 5)
+        self._objective_is_diff = bool(with_initial_obj)
+        self._last_host = None
         io = self._io(action, with_initial_obj)
         with self.torch.cuda.device(self.device):
             capi.check(capi.lib().opfx_step(self._env_handle, self.B, C.byref(io), C.byref(self.solve_opts),
@@ -1090,6 +1101,7 @@ class BatchedOpfEnv:
             self.np_random = np.random.default_rng(seed)
             self._gen.manual_seed(int(seed))
         options = options or {}
+        self.power_flow_available = False                                  # opf_env.py:181 (a power flow of this reset sets it again)
         self._sample_and_initialise(options)
         if self.pf_for_obs and not bool(self.buf['converged'].all()):
             ok = self.buf['converged'].clone()
@@ -1249,6 +1261,7 @@ class BatchedOpfEnv:
         b = self.buf
         host = self._host_finisher.finish(0, self.initial_obj if self.diff_objective else None) \
             if self._host_finisher is not None else None
+        self._last_host = host
         info = {'valids': b['valids'] if host is None else host['valids'],
                 'violations': b['violations'] if host is None else host['violations'],
                 'unscaled_penalties': b['penalties'] if host is None else host['penalties'], 'cost': b['cost'],
@@ -1287,6 +1300,65 @@ class BatchedOpfEnv:
             tobs = get_simbench_time_observation(self.steps_dev.cpu().numpy())   # intended semantics (defect D1)
             parts = [t.as_tensor(tobs, dtype=t.float64, device=self.device)] + parts
         return t.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+
+    # ------------------------------------------------------------------ state / validity / objective
+    def _key_values(self, unit, col, idxs):
+        """`net[unit].loc[idxs, col]` for every instance, [B, len(idxs)]: a result column, a per-instance table
+        column of x, or a column that is the same for all instances."""
+        t = self.torch
+        idxs = np.asarray(list(idxs))
+        if unit.startswith('res_'):
+            rows = self.store.rows(unit[4:], idxs)
+            return self.result_table(unit[4:], col)[:, t.as_tensor(np.asarray(rows), device=self.device)]
+        rows = t.as_tensor(np.asarray(self.store.rows(unit, idxs)), device=self.device)
+        if (unit, col) in self.store.ranges:
+            return self.table_column(unit, col)[:, rows]
+        const = t.as_tensor(self.net[unit][col].to_numpy(dtype=float), dtype=t.float64, device=self.device)
+        return const[rows].expand(self.B, -1)
+
+    def get_state(self):
+        """opf_env.py:551-556 for the batch: the values behind `state_keys`, [B, n_state] — the full state of a
+        partially observable environment (`examples/partial_obs.py`)."""
+        t = self.torch
+        parts = []
+        for unit, col, idxs in self.state_keys:
+            seg = self._key_values(unit, col, idxs)
+            if self.bus_wise_obs and unit == 'load':                       # opf_env.py:535-536, 806-810
+                buses = self.net.load.iloc[np.asarray(list(idxs))].bus.to_numpy()
+                uniq, inv = np.unique(buses, return_inverse=True)
+                agg = t.zeros(seg.shape[0], len(uniq), dtype=seg.dtype, device=seg.device)
+                agg.index_add_(1, t.as_tensor(inv, device=seg.device), seg)
+                seg = agg
+            parts.append(seg)
+        return t.cat(parts, dim=1) if parts else t.zeros(self.B, 0, dtype=t.float64, device=self.device)
+
+    def run_power_flow(self):
+        """opf_env.py:646-662 for the batch: evaluate the CURRENT set-points (no action is applied) — power flow,
+        objective, violations.  Returns the converged flags, [B]."""
+        self._launch_step(self._center_action, mode=1)
+        if self._host_finisher is not None:
+            self._last_host = self._host_finisher.finish(1)
+        return self.buf['converged']
+
+    def ensure_power_flow_available(self):
+        if not self.power_flow_available:                                  # opf_env.py:682-684
+            raise PowerFlowNotAvailable('Please call `run_power_flow` first!')
+
+    def set_power_flow_unavailable(self):
+        self.power_flow_available = False                                  # opf_env.py:690-694
+
+    def is_state_valid(self):
+        """opf_env.py:613-618 for the batch: no constraint violated (and the power flow converged), [B] bool."""
+        self.ensure_power_flow_available()
+        valids = self._last_host['valids'] if self._last_host is not None else self.buf['valids'][:, :max(1, self.n_device_constraints)]
+        return valids.all(dim=1) & self.buf['converged']
+
+    def get_objective(self):
+        """opf_env.py:635-638 for the batch: the current value of the objective function, [B] (never the
+        difference to the initial objective, whatever `diff_objective` says)."""
+        self.ensure_power_flow_available()
+        obj = self.buf['objective']
+        return obj + self.initial_obj if self._objective_is_diff else obj
 
     # ------------------------------------------------------------------ helpers
     def get_current_actions(self, from_results_table=True):

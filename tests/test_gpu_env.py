@@ -235,6 +235,49 @@ def test_contingency_start_flat_reproduces_the_reference_iteration_for_iteration
         assert abs(ref['reward'] - flat['reward'][k]) < 1e-7
 
 
+def test_state_validity_and_objective_queries():
+    """`get_state`, `run_power_flow`, `is_state_valid`, `get_objective` (opf_env.py:551-556, 613-618, 635-638, 646-662)
+    for the batch, against the oracle environment: the state vector of a partially observable environment, the
+    guard that asks for a power flow first, validity = all constraints satisfied, the objective as a plain sum
+    even with `diff_objective`."""
+    import opfgym_amd
+    B = 12
+    env = product_env('partial_obs_lv', batch_size=B)
+    orc = oracle_env('partial_obs_lv', product_env('partial_obs_lv', defer_device=True))
+    rng = np.random.default_rng(8)
+    steps = rng.choice(env.train_steps, B)
+    env.reset(options={'step': steps})
+    if not env.pf_for_obs:
+        with pytest.raises(opfgym_amd.PowerFlowNotAvailable):
+            env.is_state_valid()
+    state0 = _np(env.get_state()).copy()
+    assert state0.shape == (B, sum(len(i) for _, _, i in env.state_keys))
+    assert state0.shape[1] > _np(env.reset(options={'step': steps})[0]).shape[1]      # partially observable: obs is a subset
+    conv = _np(env.run_power_flow())
+    assert conv.all() and env.power_flow_available
+    valid0, obj0 = _np(env.is_state_valid()).copy(), _np(env.get_objective()).copy()
+    actions = rng.random((B, env.n_actions))
+    out = env.step(actions)
+    valid1, obj1, state1 = _np(env.is_state_valid()), _np(env.get_objective()), _np(env.get_state())
+    assert (valid1 == _np(out[4]['valids']).all(axis=1)).all()
+    for k in range(0, B, 3):
+        orc.reset(int(steps[k]))
+        ref_state = np.concatenate([orc.net[u][c].loc[list(i)].to_numpy(float) for u, c, i in env.state_keys if not u.startswith('res_')])
+        n_tab = len(ref_state)
+        assert np.allclose(state0[k][:n_tab], ref_state, rtol=0, atol=1e-12)
+        ref = orc.step(actions[k])
+        assert np.isclose(obj1[k], ref['objective'], rtol=0, atol=1e-7)
+        assert bool(valid1[k]) == bool(np.all(ref['valids']))
+        ref_state1 = np.concatenate([orc.net[u][c].loc[list(i)].to_numpy(float) for u, c, i in env.state_keys])
+        assert np.allclose(state1[k], ref_state1, rtol=0, atol=1e-6, equal_nan=True)
+    # diff_objective: the step's objective entry is a difference, get_objective() is not
+    envd = product_env('vc_resobs_diff', batch_size=4)
+    envd.reset(options={'step': rng.choice(envd.train_steps, 4)})
+    a = rng.random((4, envd.n_actions))
+    o = envd.step(a)
+    assert np.allclose(_np(envd.get_objective()), _np(o[4]['objective']) + _np(envd.initial_obj), rtol=0, atol=1e-12)
+
+
 def capi_team(env):
     """wavefronts per instance the environment's kernels run with (LDS footprint -> team size, opfx.hip pick_team)"""
     import ctypes as C
