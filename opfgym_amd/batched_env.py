@@ -1140,7 +1140,7 @@ class BatchedOpfEnv:
             if self.uses_profiles:
                 # random draws are made on the device (torch generator): no host round trip per reset
                 pool = self._pools[key]
-                self.steps_dev.copy_(pool[t.randint(len(pool), (B,), generator=self._gen, device=dev)])
+                t.index_select(pool, 0, t.randint(len(pool), (B,), generator=self._gen, device=dev), out=self.steps_dev)
             else:
                 self.steps_dev.zero_()
             self.current_simbench_step = None
