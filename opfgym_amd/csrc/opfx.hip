@@ -1871,7 +1871,9 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       }
       double* R = L.blk;
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
-      compute_results<V2>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, io.results != nullptr || E.need_angle, NT);
+      // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
+      //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
+      compute_results<V2>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT);
       blk_sync<NW>();
       if (wave == 0) {
       for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
