@@ -175,6 +175,45 @@ def ieee14_ppc():
     return 100.0, bus, branch, gen, published
 
 
+def ieee30_ppc():
+    """IEEE 30-bus test system (PSTCA common-data-format case: 41 branches, four off-nominal taps, two bus
+    shunts, five PV buses; 0-based bus numbers) in pypower matrix form.  `published`: values of its solved load
+    flow as MATPOWER prints them for `case_ieee30` (no reactive limits enforced), quoted to the digits asserted —
+    only quantities known independently of this repository are listed, a subset of buses; a single wrong
+    parameter among the 41 branches would move every one of them."""
+    z = 0.0
+    loads = {2: (21.7, 12.7), 3: (2.4, 1.2), 4: (7.6, 1.6), 5: (94.2, 19.0), 7: (22.8, 10.9), 8: (30.0, 30.0), 10: (5.8, 2.0),
+             12: (11.2, 7.5), 14: (6.2, 1.6), 15: (8.2, 2.5), 16: (3.5, 1.8), 17: (9.0, 5.8), 18: (3.2, 0.9), 19: (9.5, 3.4),
+             20: (2.2, 0.7), 21: (17.5, 11.2), 23: (3.2, 1.6), 24: (8.7, 6.7), 26: (3.5, 2.3), 29: (2.4, 0.9), 30: (10.6, 1.9)}
+    gens = {1: (0.0, 1.060, 3), 2: (40.0, 1.043, 2), 5: (0.0, 1.010, 2), 8: (0.0, 1.010, 2), 11: (0.0, 1.082, 2), 13: (0.0, 1.071, 2)}
+    shunt = {10: 19.0, 24: 4.3}
+    bus = np.array([[i - 1, gens[i][2] if i in gens else 1, *loads.get(i, (0.0, 0.0)), z, shunt.get(i, 0.0), 1,
+                     gens[i][1] if i in gens else 1.0, 0.0, 132, 1, 1.1, 0.9] for i in range(1, 31)])
+    br = [  # from to r x b tap   (1-based as published)
+        (1, 2, 0.0192, 0.0575, 0.0528, 0), (1, 3, 0.0452, 0.1652, 0.0408, 0), (2, 4, 0.0570, 0.1737, 0.0368, 0),
+        (3, 4, 0.0132, 0.0379, 0.0084, 0), (2, 5, 0.0472, 0.1983, 0.0418, 0), (2, 6, 0.0581, 0.1763, 0.0374, 0),
+        (4, 6, 0.0119, 0.0414, 0.0090, 0), (5, 7, 0.0460, 0.1160, 0.0204, 0), (6, 7, 0.0267, 0.0820, 0.0170, 0),
+        (6, 8, 0.0120, 0.0420, 0.0090, 0), (6, 9, 0.0, 0.2080, 0.0, 0.978), (6, 10, 0.0, 0.5560, 0.0, 0.969),
+        (9, 11, 0.0, 0.2080, 0.0, 0), (9, 10, 0.0, 0.1100, 0.0, 0), (4, 12, 0.0, 0.2560, 0.0, 0.932),
+        (12, 13, 0.0, 0.1400, 0.0, 0), (12, 14, 0.1231, 0.2559, 0.0, 0), (12, 15, 0.0662, 0.1304, 0.0, 0),
+        (12, 16, 0.0945, 0.1987, 0.0, 0), (14, 15, 0.2210, 0.1997, 0.0, 0), (16, 17, 0.0524, 0.1923, 0.0, 0),
+        (15, 18, 0.1073, 0.2185, 0.0, 0), (18, 19, 0.0639, 0.1292, 0.0, 0), (19, 20, 0.0340, 0.0680, 0.0, 0),
+        (10, 20, 0.0936, 0.2090, 0.0, 0), (10, 17, 0.0324, 0.0845, 0.0, 0), (10, 21, 0.0348, 0.0749, 0.0, 0),
+        (10, 22, 0.0727, 0.1499, 0.0, 0), (21, 22, 0.0116, 0.0236, 0.0, 0), (15, 23, 0.1000, 0.2020, 0.0, 0),
+        (22, 24, 0.1150, 0.1790, 0.0, 0), (23, 24, 0.1320, 0.2700, 0.0, 0), (24, 25, 0.1885, 0.3292, 0.0, 0),
+        (25, 26, 0.2544, 0.3800, 0.0, 0), (25, 27, 0.1093, 0.2087, 0.0, 0), (28, 27, 0.0, 0.3960, 0.0, 0.968),
+        (27, 29, 0.2198, 0.4153, 0.0, 0), (27, 30, 0.3202, 0.6027, 0.0, 0), (29, 30, 0.2399, 0.4533, 0.0, 0),
+        (8, 28, 0.0636, 0.2000, 0.0428, 0), (6, 28, 0.0169, 0.0599, 0.0130, 0)]
+    branch = np.array([[f - 1, t - 1, r, x, b, 0, 0, 0, tap, 0, 1, -360, 360] for f, t, r, x, b, tap in br], dtype=float)
+    gen = np.array([[b - 1, pg, 0.0, 1e4, -1e4, vg, 100, 1] for b, (pg, vg, _) in gens.items()], dtype=float)
+    published = dict(
+        vm={2: 1.021, 3: 1.012, 6: 1.002, 29: 0.992}, vm_tol=6e-4,                 # buses 3, 4, 7, 30 (0-based keys)
+        va_deg={2: -7.53, 3: -9.28, 6: -12.86}, va_tol=7e-3,
+        p_slack_mw=260.95, losses_mw=17.55, s_tol=0.011,
+        qg_mvar={3: 37.22, 4: 16.18, 5: 10.63})                                    # generators at buses 8, 11, 13 (rows of `gen`)
+    return 100.0, bus, branch, gen, published
+
+
 def _ppc(base_kv, bus_rows, br_rows, gen_rows):
     """pypower matrices from compact rows: bus (type, Pd, Qd, Vm), branch (from, to, r, x, b; 1-based),
     gen (bus (1-based), Pg, Vg, Qmax, Qmin)."""

@@ -129,6 +129,34 @@ def test_ieee14_published_solution_on_the_gpu():
     assert abs(s_ref[0, 1] - pub['q_slack_mvar']) < 0.01
 
 
+def test_ieee30_published_solution_on_the_gpu():
+    """IEEE 30-bus case through `case_from_ppc` -> plan -> opfx_solve: the published numbers of
+    tests/helpers.ieee30_ppc on the kernel's result, and the whole voltage profile against the oracle's own
+    matrix route at 1e-9."""
+    import torch
+    from helpers import ieee30_ppc, oracle_ppc_solve
+    from opfgym_amd import capi
+    from opfgym_amd.ppci_io import case_from_ppc
+    base, bus, branch, gen, pub = ieee30_ppc()
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev))
+    assert bool(out['converged'][0]) and int(out['iterations'][0]) <= 5
+    vm, va = out['vm'][0].cpu().numpy(), np.degrees(out['va'][0].cpu().numpy())
+    for b, val in pub['vm'].items():
+        assert abs(vm[b] - val) < pub['vm_tol']
+    for b, val in pub['va_deg'].items():
+        assert abs(va[b] - val) < pub['va_tol']
+    s_ref = out['s_ref'][0].cpu().numpy() * base
+    assert abs(s_ref[0, 0] + gen[0, 1] - pub['p_slack_mw']) < pub['s_tol']
+    q_gen = out['q_gen'][0].cpu().numpy() * base
+    for g, val in pub['qg_mvar'].items():
+        assert abs(q_gen[int(gen[g, 0])] - val) < pub['s_tol']
+    ref = oracle_ppc_solve(base, bus, branch, gen)
+    assert np.abs(vm - np.abs(ref['V'])).max() < 1e-9 and np.abs(va - np.degrees(np.angle(ref['V']))).max() < 1e-7
+
+
 @pytest.mark.parametrize('name', ['gs4', 'ww6', 'sea5'])
 def test_published_textbook_solutions_on_the_gpu(name):
     """Three more published load flows (tests/helpers.published_cases) asserted on the kernel's result to

@@ -84,6 +84,25 @@ def test_ieee14_published_solution():
     assert abs(s.real.sum() - pub['losses_mw']) < 0.01
 
 
+def test_ieee30_published_solution():
+    """A larger public system: IEEE 30-bus (41 branches, four off-nominal taps, two shunts, five PV buses) against
+    numbers of its published load flow (tests/helpers.ieee30_ppc): slack generation, losses, generator reactive
+    outputs and a set of bus voltages, each to its printed precision."""
+    from helpers import ieee30_ppc, oracle_ppc_solve
+    base, bus, branch, gen, pub = ieee30_ppc()
+    sol = oracle_ppc_solve(base, bus, branch, gen)
+    v = sol['V']
+    assert sol['converged'] and sol['iterations'] <= 5
+    for b, val in pub['vm'].items():
+        assert abs(abs(v[b]) - val) < pub['vm_tol'], ('vm', b, abs(v[b]))
+    for b, val in pub['va_deg'].items():
+        assert abs(np.degrees(np.angle(v[b])) - val) < pub['va_tol'], ('va', b, np.degrees(np.angle(v[b])))
+    assert abs(sol['pg'][0] - pub['p_slack_mw']) < pub['s_tol']
+    assert abs(sol['pg'].sum() - bus[:, 2].sum() - pub['losses_mw']) < pub['s_tol']
+    for g, val in pub['qg_mvar'].items():
+        assert abs(sol['qg'][g] - val) < pub['s_tol'], ('qg', g, sol['qg'][g])
+
+
 @pytest.mark.parametrize('name', ['gs4', 'ww6', 'sea5'])
 def test_published_textbook_solutions(name):
     """Three more public systems whose solved load flow is printed in their textbooks (tests/helpers.py
