@@ -214,6 +214,21 @@ def ieee30_ppc():
     return 100.0, bus, branch, gen, published
 
 
+def dense_ppc(n, seed=0):
+    """A complete graph of `n` buses in pypower matrix form (every pair of buses joined by a line): the elimination
+    has no independent vertices at all, every level holds one pivot — the whole matrix is the "dense tail" of the
+    wave-team kernels (tail sizes up to and beyond their 32-pivot register chain)."""
+    rng = np.random.default_rng(seed)
+    z = 0.0
+    bus = np.array([[i, 3 if i == 0 else (2 if i in (3, 7) else 1), rng.uniform(1, 6), rng.uniform(0.2, 2), z, z, 1,
+                     1.02 if i in (0, 3, 7) else 1.0, 0.0, 110, 1, 1.1, 0.9] for i in range(n)])
+    pairs = [(f, t) for f in range(n) for t in range(f + 1, n)]
+    branch = np.array([[f, t, rng.uniform(0.02, 0.08), rng.uniform(0.1, 0.4), rng.uniform(0, 0.02), 0, 0, 0, 0, 0, 1, -360, 360]
+                       for f, t in pairs])
+    gen = np.array([[0, 0.0, 0.0, 1e4, -1e4, 1.02, 100, 1], [3, 12.0, 0.0, 1e4, -1e4, 1.02, 100, 1], [7, 9.0, 0.0, 1e4, -1e4, 1.02, 100, 1]])
+    return 100.0, bus, branch, gen
+
+
 def _ppc(base_kv, bus_rows, br_rows, gen_rows):
     """pypower matrices from compact rows: bus (type, Pd, Qd, Vm), branch (from, to, r, x, b; 1-based),
     gen (bus (1-based), Pg, Vg, Qmax, Qmin)."""

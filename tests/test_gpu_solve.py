@@ -157,6 +157,33 @@ def test_ieee30_published_solution_on_the_gpu():
     assert np.abs(vm - np.abs(ref['V'])).max() < 1e-9 and np.abs(va - np.degrees(np.angle(ref['V']))).max() < 1e-7
 
 
+@pytest.mark.parametrize('n,team', [(27, 4), (30, 2), (40, 4), (40, 1)])
+def test_complete_graph_on_the_gpu(n, team, monkeypatch):
+    """Complete graphs (every level one pivot): dense tails of 26, 29 and 32 (capped) pivots through the wave-team
+    kernels' register chain — its largest instantiations, which the random grids of the fuzz never reach —
+    and through the single-wave kernel, against the oracle."""
+    import torch
+    from helpers import dense_ppc, oracle_ppc_solve
+    from opfgym_amd import capi
+    from opfgym_amd.ppci_io import case_from_ppc
+    monkeypatch.setenv('OPFX_TEAM', str(team))
+    base, bus, branch, gen = dense_ppc(n)
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    B = 9
+    scale = np.linspace(0.6, 1.4, B)[:, None]
+    out = capi.solve(ctx, torch.tensor(p[None] * scale, device=dev), torch.tensor(q[None] * scale, device=dev))
+    assert bool(out['converged'].all())
+    vm, va = out['vm'].cpu().numpy(), out['va'].cpu().numpy()
+    for k in (0, 4, 8):
+        b2 = bus.copy(); b2[:, 2:4] *= scale[k, 0]
+        g2 = gen.copy(); g2[:, 1] *= scale[k, 0]
+        ref = oracle_ppc_solve(base, b2, branch, g2)
+        assert ref['converged'] and int(out['iterations'][k]) == ref['iterations']
+        assert np.abs(vm[k] - np.abs(ref['V'])).max() < 1e-9 and np.abs(va[k] - np.angle(ref['V'])).max() < 1e-9
+
+
 @pytest.mark.parametrize('name', ['gs4', 'ww6', 'sea5'])
 def test_published_textbook_solutions_on_the_gpu(name):
     """Three more published load flows (tests/helpers.published_cases) asserted on the kernel's result to

@@ -88,6 +88,23 @@ def test_team_stream_reproduces_oracle(built_lib, code, team):
     assert np.abs(v - ref['V']).max() < 1e-9
 
 
+@pytest.mark.parametrize('n,team', [(27, 4), (30, 2), (40, 4)])
+def test_team_stream_on_a_complete_graph(built_lib, n, team):
+    """Tails longer than the fuzz grids produce: a complete graph eliminates one pivot per level from the start, so
+    the register chain runs at its largest instantiation (25..32 pivots) and, beyond 32 pivots, shares the
+    back substitution with ordinary single-round groups."""
+    from helpers import dense_ppc, oracle_ppc_solve
+    from opfgym_amd.ppci_io import case_from_ppc
+    base, bus, branch, gen = dense_ppc(n)
+    case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
+    plan = capi.Plan(case)
+    assert plan.info['tail_m'] == min(n - 1, 32)                        # (the slack bus is no pivot)
+    ref = oracle_ppc_solve(base, bus, branch, gen)
+    v, conv, it, nrm = emulate_newton_lane_program(plan, p, q, team=team)
+    assert conv and ref['converged'] and it == ref['iterations']
+    assert np.abs(v - ref['V']).max() < 1e-9
+
+
 def test_dense_tail_tables(built_lib):
     """The tail the register chain works on: the final levels with one pivot each; its table names, for every
     pair of tail pivots e < s, the U-block (row e, column s) — all of them four-value blocks."""
