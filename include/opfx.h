@@ -449,6 +449,14 @@ typedef struct opfx_reset_io {
    * the stages of a multi-stage episode (multi_stage.py:49-56: only the sampled columns change, the
    * set-points of the last action stay) */
   int32_t keep_state;
+  /* optional: draw the time step of every instance inside the kernel instead of reading step_idx —
+   * a uniformly random entry of `step_pool` (the train / validation / test steps, opf_env.py:327-333) from a
+   * counter-based generator keyed by (rng_seed, instance), written to `step_out`.  Saves the two launches a
+   * host-side gather needs in front of every reset. */
+  const int32_t* step_pool;  /* [n_step_pool] or NULL = use step_idx */
+  int32_t n_step_pool;
+  uint64_t rng_seed;         /* change it for every reset */
+  int32_t* step_out;         /* [B] the steps drawn (may be NULL) */
 } opfx_reset_io;
 
 int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);

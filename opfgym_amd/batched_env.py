@@ -1134,13 +1134,14 @@ class BatchedOpfEnv:
         dev = self.device
         self.test = bool(options.get('test', False))
         step = options.get('step', None)
+        in_kernel_pool = None
         if step is None:                                                   # opf_env.py:327-333
             key = 'test' if (self.test and self.evaluate_on == 'test') else \
                 ('validation' if (self.test and self.evaluate_on == 'validation') else 'train')
             if self.uses_profiles:
-                # random draws are made on the device (torch generator): no host round trip per reset
-                pool = self._pools[key]
-                t.index_select(pool, 0, t.randint(len(pool), (B,), generator=self._gen, device=dev), out=self.steps_dev)
+                # the reset kernel draws the step itself (a counter-based generator keyed by a per-reset seed and
+                # the instance number): no launch of its own for the draw, no host round trip
+                in_kernel_pool = self._pools[key]
             else:
                 self.steps_dev.zero_()
             self.current_simbench_step = None
@@ -1173,6 +1174,10 @@ class BatchedOpfEnv:
             nrm_t = as_dev(nrm_t)
         rio = capi.ResetIO()
         rio.step_idx = self.steps_dev.data_ptr()
+        if in_kernel_pool is not None:
+            rio.step_pool, rio.n_step_pool = in_kernel_pool.data_ptr(), len(in_kernel_pool)
+            rio.rng_seed = int(self.np_random.integers(0, 2 ** 63 - 1))
+            rio.step_out = self.steps_dev.data_ptr()
         rio.noise = noise_t.data_ptr() if noise_t is not None else None
         rio.interp = interp_t.data_ptr() if interp_t is not None else None
         rio.uniform = uni_t.data_ptr() if uni_t is not None else None

@@ -131,7 +131,8 @@ class ResetIO(C.Structure):
     _fields_ = [('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
                 ('uniform', C.c_void_p), ('normal', C.c_void_p), ('normal_noise_factor', C.c_double),
                 ('x', C.c_void_p), ('mode', C.c_void_p), ('action', C.c_void_p), ('obs', C.c_void_p),
-                ('keep_state', C.c_int32)]
+                ('keep_state', C.c_int32), ('step_pool', C.c_void_p), ('n_step_pool', C.c_int32),
+                ('rng_seed', C.c_uint64), ('step_out', C.c_void_p)]
 
 
 _lib = None

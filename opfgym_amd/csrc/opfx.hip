@@ -2086,6 +2086,10 @@ struct ResetIO {
   const double* action;      // optional: initial action [B,na] (reset without power flow)
   double* obs;               // optional: table observation [B,nobs]
   int keep_state;            // start from the instance's current row instead of the template
+  const int* step_pool;      // optional: draw the step in the kernel (opfx_reset_io::step_pool)
+  int n_step_pool;
+  unsigned long long rng_seed;
+  int* step_out;
 };
 
 // One wavefront per instance; the row is built in LDS (template -> profile values -> vector-op
@@ -2103,7 +2107,19 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
   const double NaN = __builtin_nan("");
   for (long long b = w; b < B; b += nw) {
     double* xr = io.x + b * R.nx;
-    const int step = io.step_idx[b];
+    int step;
+    if (io.step_pool) {
+      // counter-based draw (splitmix64 finaliser of seed and instance number): uniform over the pool up to a
+      // bias of n / 2^64
+      unsigned long long h = io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1);
+      h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+      h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+      h ^= h >> 31;
+      step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
+      if (lane == 0 && io.step_out) io.step_out[b] = step;
+    } else {
+      step = io.step_idx[b];
+    }
     const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
     if (R.init_off >= 0 && !io.keep_state) for (int j = lane; j < R.nx; j += 64) row[j] = R.consts[R.init_off + j];
     else for (int j = lane; j < R.nx; j += 64) row[j] = xr[j];
@@ -2758,7 +2774,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
 
 extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream) {
   if (env && env->has_reset && io && B == 0) return OPFX_OK;               // empty batch (buffers may be null)
-  if (!env || !env->has_reset || !io || !io->step_idx || !io->x || B < 0) {
+  if (!env || !env->has_reset || !io || (!io->step_idx && !(io->step_pool && io->n_step_pool > 0)) || !io->x || B < 0) {
     opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
     return OPFX_ERR_INVALID;
   }
@@ -2776,7 +2792,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * 8);
   ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
-            io->action, io->obs, io->keep_state};
+            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
   hipLaunchKernelGGL(k_reset, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
                      (long long)B, row_doubles);
   HIP_TRY(hipGetLastError());

@@ -278,6 +278,34 @@ def test_state_validity_and_objective_queries():
     assert np.allclose(_np(envd.get_objective()), _np(o[4]['objective']) + _np(envd.initial_obj), rtol=0, atol=1e-12)
 
 
+def test_reset_draws_its_time_steps_in_the_kernel():
+    """Default reset (no 'step' option): every instance gets a uniformly random entry of the step pool of the data
+    split (opf_env.py:327-333), drawn inside the reset kernel.  All draws lie in the pool, they cover it evenly, two
+    resets differ, the same seed reproduces them, and `options={'test': True}` switches the pool."""
+    B = 32768
+    env = product_env('vc_mv_urban', batch_size=B)
+    env.reset(seed=11)
+    s1 = _np(env.steps_dev).copy()
+    env.reset()
+    s2 = _np(env.steps_dev).copy()
+    env.reset(seed=11)
+    s3 = _np(env.steps_dev).copy()
+    train = np.asarray(env.train_steps)
+    assert np.isin(s1, train).all() and np.isin(s2, train).all()
+    assert (s1 == s3).all() and (s1 != s2).mean() > 0.99
+    # evenly spread over the pool: bucket counts within 5 sigma of a uniform draw
+    pos = np.searchsorted(np.sort(train), s1)
+    counts = np.bincount(pos * 64 // len(train), minlength=64)
+    assert np.abs(counts - B / 64).max() < 5 * np.sqrt(B / 64)
+    # the observation belongs to the drawn step: replaying the steps explicitly gives the same rows
+    obs_a = _np(env.reset(seed=11)[0]).copy()
+    obs_b = _np(env.reset(options={'step': s1})[0])
+    assert np.array_equal(obs_a, obs_b)
+    env.reset(options={'test': True})
+    pool = np.asarray(env.validation_steps if env.evaluate_on == 'validation' else env.test_steps)
+    assert np.isin(_np(env.steps_dev), pool).all()
+
+
 def capi_team(env):
     """wavefronts per instance the environment's kernels run with (LDS footprint -> team size, opfx.hip pick_team)"""
     import ctypes as C
