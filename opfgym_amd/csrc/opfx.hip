@@ -815,6 +815,34 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   if (!pv) { lds_add(L.blk + blk_c(L, db, 2), dcr); lds_add(L.blk + blk_c(L, db, 3), 2.0 * dyi + dci); }
 }
 
+// The same correction from inside the bus round of phase A, by the lane that owns bus i (its row sums sr/si, its
+// diagonal term dyr/dyi, its own off-diagonal block): no pass of its own, no barriers, no second norm
+// reduction — 3.8 k of the 12 k cycles of a wave-team phase A on the N-1 workload.  Only without de-energised
+// buses (their identity rows are patched after the phase, dead_rows_patch); `t` = bus type of i.
+__device__ __forceinline__ void mods_inline(const Lds& L, int n_mod, int i, int t, double vri, double vii,
+                                            double& sr, double& si, double& dyr, double& dyi) {
+  for (int m = 0; m < n_mod; ++m) {
+    const int* id = mod_ids(L, m);
+    const int f = id[0], tt = id[1];
+    if (i != f && i != tt) continue;
+    const int e = i == tt ? 1 : 0;
+    const double* dy = mod_dy(L, m);
+    const int j = id[1 - e], ob = id[2 + e];
+    const double yii_g = dy[e ? 6 : 0], yii_b = dy[e ? 7 : 1], yij_g = dy[e ? 4 : 2], yij_b = dy[e ? 5 : 3];
+    const double vrj = L.vr[j], vij = L.vi[j];
+    const double tr = yij_g * vrj - yij_b * vij, ti = yij_g * vij + yij_b * vrj;
+    const double dcr = vri * tr + vii * ti, dci = vii * tr - vri * ti;      // V_i conj(dY_ij V_j)
+    const double v2 = vri * vri + vii * vii;
+    dyr += yii_g * v2; dyi -= yii_b * v2;                                    // conj(dY_ii)|V_i|^2
+    sr += dcr; si += dci;
+    if (ob >= 0 && t != BT_REF) {          // this lane stored the block earlier in this phase: plain read-modify-write
+      double* pa = L.blk + ob;
+      pa[0] += dci; pa[L.bs] += dcr;
+      if (t != BT_PV && ob < L.nfull) { pa[L.o2] -= dcr; pa[L.o3] += dci; }
+    }
+  }
+}
+
 // current injected at bus i by the modifiers: I_i += dY_ii V_i + dY_ij V_j
 __device__ __forceinline__ void mods_row_current(const Lds& L, int n_mod, int i, double& ir, double& ii) {
   for (int m = 0; m < n_mod; ++m) {
@@ -955,6 +983,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
         }
       }
     }
+    // (the wave teams fold the modifiers into the bus rounds, mods_inline; here, where the kernel's common case has
+    //  none, even the test for it in the bus round costs 1.5 % — measured — so they keep their own pass)
     if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
       wave_fence();
       dead_rows_patch<PK>(P, L, lane);
@@ -1041,7 +1071,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
 template <int NW, bool PK>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
-                             int* iters_out, double* nrm_out, double* piv_out) {
+                             int* iters_out, double* nrm_out, double* piv_out, bool inline_mods) {
   double piv = 1.0;
   constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
@@ -1135,9 +1165,11 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
 #pragma unroll
           for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
+        double dyr = 0.0, dyi = 0.0;
+        if (inline_mods && n_mod > 0) mods_inline(L, n_mod, i, t, vri, vii, sr, si, dyr, dyi);
         double g = a.yd.x, b = a.yd.y;
         const double v2 = vri * vri + vii * vii;
-        const double yr = g * v2, yi = -b * v2;
+        const double yr = g * v2 + dyr, yi = -b * v2 + dyi;
         if (t != BT_REF) {
           const double pc = sr + yr, qc = si + yi;
           const double fp = pc - p_sched;
@@ -1155,7 +1187,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       }
     }
     OPFX_STAMP(12);
-    if (n_mod > 0) {
+    if (n_mod > 0 && !inline_mods) {
       lds_barrier();
       if (wave == 0) { dead_rows_patch<PK>(P, L, lane); wave_fence(); mods_apply(L, lane, n_mod); }
       lds_barrier();
@@ -1322,7 +1354,8 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm, &pv_);
+    // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm, &pv_, isl_state == 0);
     else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm, &pv_) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     *min_piv = (pv_ == pv_) ? fmin(*min_piv, pv_) : *min_piv;
