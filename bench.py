@@ -100,6 +100,55 @@ def cpu_worker(scenario, budget_s, seed):
     print(json.dumps({'steps': n, 'cpu_s': t_step}))
 
 
+def cpu_check_worker(path):
+    """Checker leg: the oracle's base-case power flow for the instances described in `path` (steps, draws, actions
+    of the first instances of one GPU evaluation); prints their bus voltage magnitudes."""
+    from env_cases import oracle_env, product_env
+    from oracle import env_oracle
+    d = json.load(open(path))
+    host = product_env(d['scenario'], defer_device=True)
+    orc = oracle_env(d['scenario'], host)
+    out = []
+    for k in range(len(d['steps'])):
+        orc.reset(int(d['steps'][k]), np.asarray(d['uniform'][k], float) if d['uniform'] is not None else ())
+        env_oracle.apply_actions(orc.net, orc.act_keys, np.asarray(d['actions'][k], float), orc.autoscale, orc.diff_step)
+        ok = orc.solve()
+        vm = orc.net['res_bus']['vm_pu'].to_numpy(float) if ok else np.full(len(orc.net['bus']), np.nan)
+        out.append([None if v != v else float(v) for v in vm])
+    print(json.dumps({'vm': out}))
+
+
+def voltage_check(env, config, n_check):
+    """max |V| error of the GPU path against the CPU oracle on `n_check` instances of one fresh evaluation (the second
+    half of BASELINE.json's metric; pandapower itself is not installed, so the oracle stands in — as the checker)."""
+    import tempfile
+    rng = np.random.default_rng(99)
+    B = env.B
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    actions = rng.random((B, env.n_actions))
+    env.reset(options={'step': steps, 'uniform': uniform})
+    env.step(actions)
+    vm_gpu = env.result_table('bus', 'vm_pu')[:n_check].cpu().numpy()          # (result bank: the base case)
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as fh:
+        json.dump({'scenario': CONFIGS[config][4], 'steps': steps[:n_check].tolist(),
+                   'uniform': uniform[:n_check].tolist() if uniform is not None else None,
+                   'actions': actions[:n_check].tolist()}, fh)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-check', fh.name], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if not lines:
+            return None
+        vm_cpu = np.array([[np.nan if v is None else v for v in row] for row in json.loads(lines[-1])['vm']])
+    finally:
+        os.unlink(fh.name)
+    both = np.isfinite(vm_cpu) & np.isfinite(vm_gpu)
+    if not both.any() or (np.isfinite(vm_cpu) != np.isfinite(vm_gpu)).any():
+        return None
+    return float(np.abs(vm_cpu - vm_gpu)[both].max())
+
+
 def cpu_baseline(config, budget_s=10.0):
     scenario = CONFIGS[config][4]
     cores = os.cpu_count() or 1
@@ -156,9 +205,12 @@ def main():
     ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=10.0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-check', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker, args.cpu_budget, args.cpu_seed)
+    if args.cpu_check:
+        return cpu_check_worker(args.cpu_check)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(launch_ranks(args))           # nothing has touched a GPU in this process
 
@@ -298,6 +350,12 @@ def main():
         }
         # timed after the GPU work, in child processes (one, then one per host core)
         out['cpu_baseline'] = cpu_baseline(args.config) if (world == 1 and not args.no_cpu_baseline) else None
+        if out['cpu_baseline'] is not None:
+            n_check = 2 if args.config == 5 else 4
+            err = voltage_check(env, args.config, min(n_check, B))
+            out['config']['max_abs_v_err_pu'] = err
+            out['config']['max_abs_v_err_against'] = (f'CPU oracle (oracle/pf_oracle.py), base-case |V| of {min(n_check, B)} instances; '
+                                                      'pandapower is not installed here')
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
