@@ -62,3 +62,33 @@ def test_from_reference_reads_the_same_definition_off_live_reference_objects():
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count('same definition') >= 10
+
+
+def test_bench_checker_leg_reproduces_the_oracle(tmp_path):
+    """bench.py's `--cpu-check` child process (the checker behind `config.max_abs_v_err_pu`): the oracle's base-case
+    voltages for the instances a GPU evaluation hands over — here compared with running the oracle directly."""
+    import json
+    import subprocess
+    import sys
+    import os
+    import numpy as np
+    sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+    from env_cases import oracle_env, product_env
+    from oracle import env_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = product_env('maxren_lv', defer_device=True)
+    rng = np.random.default_rng(3)
+    d = {'scenario': 'maxren_lv', 'steps': rng.choice(host.train_steps, 2).tolist(), 'uniform': None,
+         'actions': rng.random((2, host.n_actions)).tolist()}
+    path = tmp_path / 'inputs.json'
+    path.write_text(json.dumps(d))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--cpu-check', str(path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    vm = np.array(json.loads(line)['vm'], dtype=float)
+    orc = oracle_env('maxren_lv', host)
+    for k in range(2):
+        orc.reset(int(d['steps'][k]))
+        env_oracle.apply_actions(orc.net, orc.act_keys, np.asarray(d['actions'][k]), orc.autoscale, orc.diff_step)
+        assert orc.solve()
+        assert np.allclose(vm[k], orc.net['res_bus']['vm_pu'].to_numpy(float), rtol=0, atol=0)
