@@ -737,7 +737,8 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_BLK_COL: v = &p->blk_col; break;
     default: opfx_set_error("opfx_plan_get_array: unknown array id"); return OPFX_ERR_INVALID;
   }
-  if (out) std::memcpy(out, v->data(), sizeof(int32_t) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  const int64_t n_copy = std::min<int64_t>(cap, (int64_t)v->size());
+  if (out && n_copy > 0) std::memcpy(out, v->data(), sizeof(int32_t) * (size_t)n_copy);      // (an empty vector's data() may be null)
   return (int64_t)v->size();
 }
 
@@ -757,6 +758,7 @@ extern "C" int64_t opfx_plan_get_darray(const opfx_plan* p, int which, double* o
     case OPFX_DARR_LP_H_Y: v = &p->lp_h_y; break;
     default: opfx_set_error("opfx_plan_get_darray: unknown array id"); return OPFX_ERR_INVALID;
   }
-  if (out) std::memcpy(out, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  const int64_t n_copy = std::min<int64_t>(cap, (int64_t)v->size());
+  if (out && n_copy > 0) std::memcpy(out, v->data(), sizeof(double) * (size_t)n_copy);
   return (int64_t)v->size();
 }
