@@ -2138,6 +2138,14 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
   const long long w = (long long)blockIdx.x * wpb + wib;
   const long long nw = (long long)gridDim.x * wpb;
   const double NaN = __builtin_nan("");
+  // observation segments: the same for every instance, read once per wavefront
+  int okind[8], osrc[8], odst[8], on[8];
+#pragma unroll
+  for (int sg = 0; sg < 8; ++sg) {
+    const bool have = io.obs && Ep && sg < Ep->n_oseg;
+    okind[sg] = have ? as_global(Ep->oseg_kind)[sg] : 0; osrc[sg] = have ? as_global(Ep->oseg_src)[sg] : 0;
+    odst[sg] = have ? as_global(Ep->oseg_dst)[sg] : 0; on[sg] = have ? as_global(Ep->oseg_n)[sg] : 0;
+  }
   for (long long b = w; b < B; b += nw) {
     double* xr = io.x + b * R.nx;
     int step;
@@ -2154,45 +2162,89 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
       step = io.step_idx[b];
     }
     const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-    if (R.init_off >= 0 && !io.keep_state) for (int j = lane; j < R.nx; j += 64) row[j] = R.consts[R.init_off + j];
-    else for (int j = lane; j < R.nx; j += 64) row[j] = xr[j];
+    // Every loop of this kernel is a chain of global-memory round trips (L2-resident descriptors, ~0.3 us each) with
+    // nothing else to hide them: four 64-column chunks at a time, all their loads — unconditional, clamped indices —
+    // requested before the first use, cut the round trips of a row from ~60 to ~20.
+    constexpr int U = 4;
+    {
+      const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
+      for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
+        double t[2 * U];
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
+      }
+    }
     wave_fence();
     for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
       const DevTable& T = R.tab[t];
       const double* rw = T.rel + (long long)step * T.n_types;
       const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
       const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
-      for (int j = lane; j < T.n_cols; j += 64) {
-        double v = rw[T.typ[j]] * T.peak[j];                                       // :343
-        if (interp) v = v * rr + (rw[T.n_types + T.typ[j]] * T.peak[j]) * (1.0 - rr);    // :347-349
-        if (io.noise) {
-          const double nz = io.noise[b * R.n_noise + T.noise_off + j];
-          if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz;   // :359-360
-          else v = v * nz;                                                          // :354-356
+      const int nc = T.n_cols;
+      const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
+      for (int j0 = lane; j0 < nc; j0 += 64 * U) {
+        int typ[U], slot[U];
+        double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
+          typ[u] = T.typ[jc]; slot[u] = T.slot[jc]; peak[u] = T.peak[jc]; lo[u] = T.col_min[jc]; hi[u] = T.col_max[jc];
+          nz[u] = nzp ? nzp[jc] : 1.0;
         }
-        v = fmin(fmax(v, T.col_min[j]), T.col_max[j]);                              // :364-369
-        row[T.slot[j]] = v;                                                         // :371-372
+#pragma unroll
+        for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double v = r0[u] * peak[u];                                                // :343
+          if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
+          if (nzp) {
+            if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
+            else v = v * nz[u];                                                      // :354-356
+          }
+          v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
+          if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
+        }
       }
     }
     wave_fence();
     for (int k = 0; k < R.n_ops; ++k) {
       if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
       const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
-      const double* c0 = R.op_c0[k] >= 0 ? R.consts + R.op_c0[k] : nullptr;
-      const double* c1 = R.op_c1[k] >= 0 ? R.consts + R.op_c1[k] : nullptr;
-      const double* c2 = R.op_c2[k] >= 0 ? R.consts + R.op_c2[k] : nullptr;
-      for (int j = lane; j < n; j += 64) {
-        double v;
-        if (code == OPFX_OP_SET_CONST) v = c0[j];
-        else if (code == OPFX_OP_AFFINE) v = row[a + j] * c0[j] + c1[j];
-        else if (code == OPFX_OP_SQRT_DIFF) { const double s = c0[j], pz = row[a + j]; v = sqrt(s * s - pz * pz); }
-        else if (code == OPFX_OP_NEG) v = -row[a + j];
-        else if (code == OPFX_OP_UNIFORM) { const double u = io.uniform[b * R.n_uniform + a + j]; v = (c0[j] + u * (c1[j] - c0[j])) / c2[j]; }
-        else if (code == OPFX_OP_NORMAL) v = c0[j] + c1[j] * io.normal[b * R.n_normal + a + j];
-        else if (code == OPFX_OP_CLIP) v = fmin(fmax(row[a + j], c0[j]), c1[j]);
-        else if (code == OPFX_OP_NORMINV) v = c0[j] + c1[j] * normcdfinv(row[a + j]);
-        else v = row[a + j] / c0[j];
-        row[dst + j] = v;
+      // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
+      const double* c0 = R.consts + (R.op_c0[k] >= 0 ? R.op_c0[k] : 0);
+      const double* c1 = R.consts + (R.op_c1[k] >= 0 ? R.op_c1[k] : 0);
+      const double* c2 = R.consts + (R.op_c2[k] >= 0 ? R.op_c2[k] : 0);
+      const bool has0 = R.op_c0[k] >= 0, has1 = R.op_c1[k] >= 0, has2 = R.op_c2[k] >= 0;
+      // per-instance draw of the op, if it has one (same chunked, unconditional access)
+      const double* draw = code == OPFX_OP_UNIFORM ? io.uniform + b * R.n_uniform + a
+                         : (code == OPFX_OP_NORMAL ? io.normal + b * R.n_normal + a : nullptr);
+      const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
+      for (int j0 = lane; j0 < n; j0 += 64 * U) {
+        double k0[U], k1[U], k2[U], dr[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
+          k0[u] = has0 ? c0[jc] : 0.0; k1[u] = has1 ? c1[jc] : 0.0; k2[u] = has2 ? c2[jc] : 0.0;
+          dr[u] = draw ? draw[jc] : 0.0;
+          rv[u] = reads_row ? row[a + jc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u;
+          double v;
+          if (code == OPFX_OP_SET_CONST) v = k0[u];
+          else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
+          else if (code == OPFX_OP_SQRT_DIFF) { const double s = k0[u], pz = rv[u]; v = sqrt(s * s - pz * pz); }
+          else if (code == OPFX_OP_NEG) v = -rv[u];
+          else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
+          else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
+          else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
+          else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
+          else v = rv[u] / k0[u];
+          if (j < n) row[dst + j] = v;
+        }
       }
       wave_fence();
     }
@@ -2201,31 +2253,40 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
       // table part of the observation (:218); result entries are NaN
       const DevEnv& E = *Ep;
       for (int k = lane; k < E.na; k += 64) {
-        const int slot = as_global(E.act_slot)[k];
+        // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
+        const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
+        const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
+        const int kind = as_global(E.act_kind)[k];
+        const bool clampa = (E.clamp_enabled & 2) != 0;
+        const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
+        const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
+        const double* act_row = io.action ? io.action + b * E.na : E.act_lo_const;      // (any readable row)
+        double a = act_row[k];
         double xv = row[slot];
         if (io.action) {
-          double a = io.action[b * E.na + k];
           a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
-          const int ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
-          const double lo = ls >= 0 ? row[ls] : as_global(E.act_lo_const)[k];
-          const double hi = hs >= 0 ? row[hs] : as_global(E.act_hi_const)[k];
+          const double lo = ls >= 0 ? row[ls] : loc;
+          const double hi = hs >= 0 ? row[hs] : hic;
           double spt = a * (hi - lo) + lo;                                              // :461
-          if (E.clamp_enabled & 2) {                                                    // :464-470 (autoscale off)
-            const int ch = as_global(E.clamp_hi_slot)[k], cl = as_global(E.clamp_lo_slot)[k];
-            if (ch > -2) { const double m = ch >= 0 ? row[ch] : as_global(E.clamp_hi_const)[k]; if (spt > m) spt = m; }
-            if (cl > -2) { const double m = cl >= 0 ? row[cl] : as_global(E.clamp_lo_const)[k]; if (spt < m) spt = m; }
+          if (clampa) {                                                                 // :464-470 (autoscale off)
+            if (ch > -2) { const double m = ch >= 0 ? row[ch] : chc; if (spt > m) spt = m; }
+            if (cl > -2) { const double m = cl >= 0 ? row[cl] : clc; if (spt < m) spt = m; }
           }
-          xv = spt / as_global(E.act_scaling)[k];                                       // :472-474
-          const int kind = as_global(E.act_kind)[k];
+          xv = spt / scal;                                                              // :472-474
           if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
         }
         sp[k] = xv;
+        if (E.na <= 64) {          // one chunk: the lane still knows its slot — (limits are read before any set-point is written)
+          wave_fence();
+          row[slot] = xv;
+        }
       }
-      wave_fence();          // (limits are read before any set-point is written into the row)
-      for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k];
+      wave_fence();
+      if (E.na > 64) { for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k]; }
       wave_fence();
       for (int sg = 0; sg < E.n_oseg; ++sg) {
-        const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
+        const int kind = sg < 8 ? okind[sg] : as_global(E.oseg_kind)[sg], src = sg < 8 ? osrc[sg] : as_global(E.oseg_src)[sg];
+        const int dst = sg < 8 ? odst[sg] : as_global(E.oseg_dst)[sg], n = sg < 8 ? on[sg] : as_global(E.oseg_n)[sg];
         for (int j = lane; j < n; j += 64)
           io.obs[b * E.nobs + dst + j] = kind == 1 ? NaN : (kind == 0 ? row[src + j] : sp[src + j]);
       }
