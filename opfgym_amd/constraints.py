@@ -75,74 +75,47 @@ class Constraint:
         return out[0], out[1]
 
 
-class VoltageConstraint(Constraint):
+# The reference's ready-made constraints (constraints.py:131-192) differ in four facts only, so they are rows of a
+# table here: name, table, bounded result column, what `autoscale_violation=True` stands for — a fixed factor
+# (:133-135, :144-146, :155-157, :164-172) or, for the slack exchange, nothing: `True` multiplies by one (defect D8) and a
+# falsy value turns into 1 / |sum of the mean exchange| (:179-182, :189-192) — and the limit columns whose presence
+# makes `create_default_constraints` add the constraint (:195-226).
+_READY_MADE = (
+    ('VoltageConstraint', 'bus', 'vm_pu', 20, None, ('max_vm_pu', 'min_vm_pu')),
+    ('LineOverloadConstraint', 'line', 'loading_percent', 1 / 30, None, ('max_loading_percent',)),
+    ('TrafoOverloadConstraint', 'trafo', 'loading_percent', 1 / 30, None, ('max_loading_percent',)),
+    ('Trafo3wOverloadConstraint', 'trafo3w', 'loading_percent', 1 / 30, None, ('max_loading_percent',)),
+    ('ExtGridActivePowerConstraint', 'ext_grid', 'p_mw', None, 'mean_p_mw', ('max_p_mw', 'min_p_mw')),
+    ('ExtGridReactivePowerConstraint', 'ext_grid', 'q_mvar', None, 'mean_q_mvar', ('max_q_mvar', 'min_q_mvar')),
+)
+
+
+def _ready_made(name, table, column, factor_for_true, mean_column, _limits):
     def __init__(self, autoscale_violation=True, **args):
-        if autoscale_violation is True:
-            autoscale_violation = 20                   # constraints.py:133-135
-        super().__init__('bus', 'vm_pu', autoscale_violation=autoscale_violation, **args)
-
-
-class LineOverloadConstraint(Constraint):
-    def __init__(self, autoscale_violation=True, **args):
-        if autoscale_violation is True:
-            autoscale_violation = 1 / 30               # constraints.py:144-146
-        super().__init__('line', 'loading_percent', autoscale_violation=autoscale_violation, **args)
-
-
-class TrafoOverloadConstraint(Constraint):
-    def __init__(self, autoscale_violation=True, **args):
-        if autoscale_violation is True:
-            autoscale_violation = 1 / 30               # constraints.py:155-157
-        super().__init__('trafo', 'loading_percent', autoscale_violation=autoscale_violation, **args)
-
-
-class Trafo3wOverloadConstraint(Constraint):
-    def __init__(self, autoscale_violation=True, **args):
-        if autoscale_violation is True:
-            autoscale_violation = 1 / 30               # constraints.py:164-172
-        super().__init__('trafo3w', 'loading_percent', autoscale_violation=autoscale_violation, **args)
-
-
-class ExtGridActivePowerConstraint(Constraint):
-    def __init__(self, **args):
-        super().__init__('ext_grid', 'p_mw', **args)
+        if factor_for_true is not None and autoscale_violation is True:
+            autoscale_violation = factor_for_true
+        Constraint.__init__(self, table, column, autoscale_violation=autoscale_violation, **args)
 
     def autoscale_factor(self, net) -> float:
-        if not self.autoscale_violation:               # constraints.py:179-182
-            self.autoscale_violation = 1 / abs(net.ext_grid['mean_p_mw'].sum())
-        return float(self.autoscale_violation)
+        if mean_column is not None and not self.autoscale_violation:
+            self.autoscale_violation = 1 / abs(net[table][mean_column].sum())
+        return Constraint.autoscale_factor(self, net)
+    return type(name, (Constraint,), {'__init__': __init__, 'autoscale_factor': autoscale_factor,
+                                      '__doc__': f'`opfgym.constraints.{name}`: {table}.{column} within its min_/max_ columns.'})
 
 
-class ExtGridReactivePowerConstraint(Constraint):
-    def __init__(self, **args):
-        super().__init__('ext_grid', 'q_mvar', **args)
-
-    def autoscale_factor(self, net) -> float:
-        if not self.autoscale_violation:               # constraints.py:189-192
-            self.autoscale_violation = 1 / abs(net.ext_grid['mean_q_mvar'].sum())
-        return float(self.autoscale_violation)
+for _row in _READY_MADE:
+    globals()[_row[0]] = _ready_made(*_row)
 
 
-def _defined(net, unit_type, column) -> bool:
-    # constraints.py:229-238
-    if unit_type not in net or column not in net[unit_type]:
+def _has_numbers(net, table, column) -> bool:
+    """A limit column counts when it exists and holds at least one finite number (constraints.py:229-238)."""
+    if table not in net or column not in net[table]:
         return False
-    return bool(np.isfinite(pd.to_numeric(net[unit_type][column], errors='coerce')).any())
+    return bool(np.isfinite(pd.to_numeric(net[table][column], errors='coerce')).any())
 
 
 def create_default_constraints(net, constraint_kwargs: dict) -> list:
-    """constraints.py:195-226."""
-    out = []
-    if _defined(net, 'bus', 'max_vm_pu') or _defined(net, 'bus', 'min_vm_pu'):
-        out.append(VoltageConstraint(**constraint_kwargs))
-    if _defined(net, 'line', 'max_loading_percent'):
-        out.append(LineOverloadConstraint(**constraint_kwargs))
-    if _defined(net, 'trafo', 'max_loading_percent'):
-        out.append(TrafoOverloadConstraint(**constraint_kwargs))
-    if _defined(net, 'trafo3w', 'max_loading_percent'):
-        out.append(Trafo3wOverloadConstraint(**constraint_kwargs))
-    if _defined(net, 'ext_grid', 'max_p_mw') or _defined(net, 'ext_grid', 'min_p_mw'):
-        out.append(ExtGridActivePowerConstraint(**constraint_kwargs))
-    if _defined(net, 'ext_grid', 'max_q_mvar') or _defined(net, 'ext_grid', 'min_q_mvar'):
-        out.append(ExtGridReactivePowerConstraint(**constraint_kwargs))
-    return out
+    """The ready-made constraints whose limit columns the net carries, in the reference's order (constraints.py:195-226)."""
+    return [globals()[name](**constraint_kwargs) for name, table, _, _, _, limits in _READY_MADE
+            if any(_has_numbers(net, table, col) for col in limits)]

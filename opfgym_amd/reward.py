@@ -1,135 +1,154 @@
-"""Reward-function parameter objects for the fused device evaluator.
+"""Reward parameters of the fused step kernel, behind the reference's class names.
 
-Host-side mirror of `/root/reference/opfgym/reward.py`: same class names and
-constructor parameters.  The reward itself is computed on the GPU at the end
-of `opfx_step` (csrc/opfx.hip, "reward" section) from these parameters; the
-`__call__` here is the same scalar formula for host-side use (reward.py:61-98).
-`estimate_reward_distribution` (reward.py:181-216) becomes ONE batched
-reset+step instead of 3000 sequential ones.
+The reward of a step is computed on the GPU (csrc/opfx.hip, reward epilogue of `k_step`) from eleven numbers:
+how the objective and the summed penalty are shifted for a valid / an invalid state, the two affine scalings, the
+mixing weight and the clip range.  The reference spreads them over a class hierarchy with one override per
+reward kind (`opfgym/reward.py`: Summation, Replacement, Parameterized, OnlyObjective); here ONE table row per
+kind says the same, the host-side formula (`RewardFunction.__call__`, used by the host fallback and by the tests)
+is the kernel's formula, and the public classes only carry the reference's constructor signatures.
+`estimate_reward_distribution` (reward.py:181-216) is ONE batched reset + step instead of 3000 sequential ones.
 """
 from __future__ import annotations
 
-import copy
-
 import numpy as np
 
+# reward kinds in the kernel's numbering (opfx_env_desc.reward_kind)
+SUMMATION, REPLACEMENT, PARAMETERIZED, ONLY_OBJECTIVE = 0, 1, 2, 3
 
-def calculate_normalization_params(std_objective, mean_objective, std_penalty, mean_penalty, **kw):
-    # reward.py:120-137
-    return {'objective_factor': 1 / std_objective, 'objective_bias': -mean_objective / std_objective,
-            'penalty_factor': 1 / std_penalty, 'penalty_bias': -mean_penalty / std_penalty}
+#: statistics -> (centre, half-width) of the affine map x -> (x - centre) / half-width, per scaling name and quantity
+#: (reward.py:120-178: normalization; min-max to [0, 1]; min-max to [-1, 1])
+_SCALERS = {
+    'normalization': lambda st, q: (st[f'mean_{q}'], st[f'std_{q}'], 0.0),
+    'minmax01': lambda st, q: (st[f'min_{q}'], st[f'max_{q}'] - st[f'min_{q}'], 0.0),
+    'minmax11': lambda st, q: (st[f'min_{q}'], (st[f'max_{q}'] - st[f'min_{q}']) / 2, 1.0),
+}
+_STATISTICS = {'normalization': ('mean', 'std'), 'minmax01': ('min', 'max'), 'minmax11': ('min', 'max')}
+_IDENTITY = {'penalty_factor': 1, 'penalty_bias': 0, 'objective_factor': 1, 'objective_bias': 0}
 
 
-def calculate_minmax01_params(min_objective, max_objective, min_penalty, max_penalty, **kw):
-    # reward.py:140-158
-    do, dp = max_objective - min_objective, max_penalty - min_penalty
-    return {'objective_factor': 1 / do, 'objective_bias': -(min_objective / do),
-            'penalty_factor': 1 / dp, 'penalty_bias': -(min_penalty / dp)}
-
-
-def calculate_minmax11_params(min_objective, max_objective, min_penalty, max_penalty, **kw):
-    # reward.py:161-178
-    do, dp = (max_objective - min_objective) / 2, (max_penalty - min_penalty) / 2
-    return {'objective_factor': 1 / do, 'objective_bias': -(min_objective / do + 1),
-            'penalty_factor': 1 / dp, 'penalty_bias': -(min_penalty / dp + 1)}
+def scaling_from_statistics(reward_scaling: str, stats: dict) -> dict:
+    """factor / bias of objective and penalty: x * factor + bias = (x - origin) / width - offset."""
+    if reward_scaling not in _SCALERS:
+        raise NotImplementedError('This reward scaling does not exist!')
+    out = {}
+    for quantity in ('objective', 'penalty'):
+        origin, width, offset = _SCALERS[reward_scaling](stats, quantity)
+        out[f'{quantity}_factor'] = 1 / width
+        out[f'{quantity}_bias'] = -(origin / width + offset) if offset else -(origin / width)
+    return out
 
 
 def select_reward_scaler(reward_scaling: str):
-    try:
-        return {'minmax11': calculate_minmax11_params, 'minmax01': calculate_minmax01_params,
-                'normalization': calculate_normalization_params}[reward_scaling]
-    except KeyError:
+    """The reference's entry point (reward.py:108-117): a function of the statistics, by scaling name."""
+    if reward_scaling not in _SCALERS:
         raise NotImplementedError('This reward scaling does not exist!')
+    return lambda **stats: scaling_from_statistics(reward_scaling, stats)
 
 
 def estimate_reward_distribution(env, num_samples: int = 3000, draws=None) -> dict:
-    """reward.py:181-216 as one batch: random states, random actions, one
-    power flow each; statistics of Σobjective and Σpenalty over converged rows.
-    `draws`: explicit inputs to replay (see BatchedOpfEnv.sample_objective_penalty)."""
-    objectives, penalties = env.sample_objective_penalty(num_samples, draws)
-    objectives = objectives[~np.isnan(objectives)]
-    penalties = penalties[~np.isnan(penalties)]
-    return {
-        'min_objective': objectives.min(), 'max_objective': objectives.max(),
-        'min_penalty': penalties.min(), 'max_penalty': penalties.max(),
-        'mean_objective': objectives.mean(), 'mean_penalty': penalties.mean(),
-        'std_objective': np.std(objectives), 'std_penalty': np.std(penalties),
-        'median_objective': np.median(objectives), 'median_penalty': np.median(penalties),
-        'mean_abs_objective': np.abs(objectives).mean(), 'mean_abs_penalty': np.abs(penalties).mean()}
+    """The twelve statistics of reward.py:198-216 over one batch of random states and random actions (one power
+    flow each; rows whose power flow failed are left out).  `draws`: explicit inputs to replay (see
+    BatchedOpfEnv.sample_objective_penalty)."""
+    samples = dict(zip(('objective', 'penalty'), env.sample_objective_penalty(num_samples, draws)))
+    stats = {}
+    for quantity, x in samples.items():
+        x = x[~np.isnan(x)]
+        for name, fn in (('min', np.min), ('max', np.max), ('mean', np.mean), ('std', np.std), ('median', np.median),
+                         ('mean_abs', lambda v: np.abs(v).mean())):
+            stats[f'{name}_{quantity}'] = fn(x)
+    return stats
 
 
 class RewardFunction:
-    KIND = 0
+    """penalty_weight, clip_range, reward_scaling, scaling_params: as `opfgym.RewardFunction` (reward.py:8-19).
+    KIND and the four shift parameters describe the reward kind:
+
+        objective' = objective + objective_bonus_valid        (valid state)    objective * invalid_objective_share  (invalid)
+        penalty'   = penalty + valid_reward_on_penalty        (valid state)    penalty - invalid_penalty            (invalid)
+    """
+    KIND = SUMMATION
 
     def __init__(self, penalty_weight: float = 0.5, clip_range=None, reward_scaling: str = None,
                  scaling_params: dict = None, env=None):
-        self.penalty_weight = penalty_weight
-        self.clip_range = clip_range
-        self.scaling_params = self.prepare_reward_scaling(reward_scaling, scaling_params, env)
-        self.valid_reward = 0.0
-        self.invalid_penalty = 0.0
-        self.invalid_objective_share = 1.0
+        self.penalty_weight, self.clip_range = penalty_weight, clip_range
+        self.scaling_params = self._scaling(reward_scaling, dict(scaling_params or {}), env)
+        self.valid_reward, self.invalid_penalty, self.invalid_objective_share = 0.0, 0.0, 1.0
 
-    def prepare_reward_scaling(self, reward_scaling, scaling_params, env) -> dict:
-        # reward.py:21-48
+    @staticmethod
+    def _scaling(reward_scaling, given, env) -> dict:
+        """reward.py:21-48: statistics the user gave win; missing ones are estimated on the environment; values the
+        user gave for factor / bias themselves win over everything; a constant penalty (std or range 0) is not scaled."""
         if not isinstance(reward_scaling, str):
-            return {'penalty_factor': 1, 'penalty_bias': 0, 'objective_factor': 1, 'objective_bias': 0}
-        scaling_params = scaling_params or {}
-        user = copy.copy(scaling_params)
-        scaler = select_reward_scaler(reward_scaling)
-        try:
-            scaling_params.update(scaler(**scaling_params))
-        except TypeError:
-            scaling_params = estimate_reward_distribution(env, **scaling_params)
-            scaling_params.update(scaler(**scaling_params))
-        scaling_params.update(user)
-        if np.isnan(scaling_params['penalty_bias']):
-            scaling_params['penalty_bias'] = 0
-        if np.isinf(scaling_params['penalty_factor']):
-            scaling_params['penalty_factor'] = 1
-        return scaling_params
+            return dict(_IDENTITY)
+        if reward_scaling not in _SCALERS:
+            raise NotImplementedError('This reward scaling does not exist!')
+        needed = [f'{s}_{q}' for s in _STATISTICS[reward_scaling] for q in ('objective', 'penalty')]
+        if all(k in given for k in needed):
+            params = dict(given)
+        else:
+            params = estimate_reward_distribution(env, **given)
+        params.update(scaling_from_statistics(reward_scaling, params))
+        params.update(given)
+        if np.isnan(params['penalty_bias']):
+            params['penalty_bias'] = 0
+        if np.isinf(params['penalty_factor']):
+            params['penalty_factor'] = 1
+        return params
 
-    # scalar host formulas (reward.py:61-98) -----------------------------------
+    # ---- the kernel's formula on host scalars --------------------------------------------------------
+    def _shifted(self, objective, penalty, valid):
+        kind = self.KIND
+        if kind == REPLACEMENT:
+            objective = objective + self.valid_reward if valid else 0.0
+        elif kind == PARAMETERIZED:
+            objective = objective if valid else objective * self.invalid_objective_share
+            penalty = penalty + self.valid_reward if valid else penalty - self.invalid_penalty
+        elif kind == ONLY_OBJECTIVE:
+            penalty = 0.0
+        return objective, penalty
+
     def __call__(self, objective, penalty, valid):
-        objective = self.adjust_objective(objective, valid)
-        penalty = self.adjust_penalty(penalty, valid)
-        objective = self.scale_objective(objective)
-        penalty = self.scale_penalty(penalty)
-        reward = self.compute_total_reward(objective, penalty)
-        if self.clip_range:
-            reward = self.clip_reward(reward)
-        return reward
-
-    def clip_reward(self, reward):
-        return float(np.clip(reward, self.clip_range[0], self.clip_range[1]))
-
-    def compute_total_reward(self, objective, penalty):
-        if self.penalty_weight is None:
-            return objective + penalty
-        return objective * (1 - self.penalty_weight) + penalty * self.penalty_weight
-
-    def scale_objective(self, objective):
-        return objective * self.scaling_params['objective_factor'] + self.scaling_params['objective_bias']
-
-    def scale_penalty(self, penalty):
-        return penalty * self.scaling_params['penalty_factor'] + self.scaling_params['penalty_bias']
-
-    def calculate_cost(self, penalty, valid):
-        return 0.0 if valid else abs(penalty * self.scaling_params['penalty_factor'])
-
-    def adjust_penalty(self, penalty, valid):
-        return penalty
+        objective, penalty = self._shifted(objective, penalty, valid)
+        reward = self.compute_total_reward(self.scale_objective(objective), self.scale_penalty(penalty))
+        return self.clip_reward(reward) if self.clip_range else reward
 
     def adjust_objective(self, objective, valid):
-        return objective
+        return self._shifted(objective, 0.0, valid)[0]
+
+    def adjust_penalty(self, penalty, valid):
+        return self._shifted(0.0, penalty, valid)[1]
+
+    def scale_objective(self, objective):
+        p = self.scaling_params
+        return objective * p['objective_factor'] + p['objective_bias']
+
+    def scale_penalty(self, penalty):
+        p = self.scaling_params
+        return penalty * p['penalty_factor'] + p['penalty_bias']
+
+    def compute_total_reward(self, objective, penalty):
+        w = self.penalty_weight
+        return objective + penalty if w is None else objective * (1 - w) + penalty * w
+
+    def clip_reward(self, reward):
+        lo, hi = self.clip_range
+        return float(min(max(reward, lo), hi))
+
+    def calculate_cost(self, penalty, valid):
+        """The scaled penalty of an invalid state as a cost (reward.py:100-104; Parameterized adds its offset, :335-339)."""
+        if valid:
+            return 0.0
+        cost = abs(penalty * self.scaling_params['penalty_factor'])
+        return cost + self.invalid_penalty if self.KIND == PARAMETERIZED else cost
 
 
 class Summation(RewardFunction):
-    KIND = 0
+    """reward.py:219-223"""
 
 
 class Replacement(RewardFunction):
-    KIND = 1
+    """reward.py:226-262: the objective only counts in valid states, plus a bonus."""
+    KIND = REPLACEMENT
 
     def __init__(self, valid_reward: float = 1.0, **kwargs):
         super().__init__(**kwargs)
@@ -139,12 +158,10 @@ class Replacement(RewardFunction):
                                       "reference as well; pass a number")
         self.valid_reward = valid_reward
 
-    def adjust_objective(self, objective, valid):
-        return objective + self.valid_reward if valid else 0.0
-
 
 class Parameterized(RewardFunction):
-    KIND = 2
+    """reward.py:265-339: bonus for valid, offset for invalid states, a share of the objective in invalid states."""
+    KIND = PARAMETERIZED
 
     def __init__(self, valid_reward: float = 0.0, invalid_penalty: float = 0.5,
                  invalid_objective_share: float = 1.0, **kwargs):
@@ -152,37 +169,25 @@ class Parameterized(RewardFunction):
         if isinstance(valid_reward, str) or isinstance(invalid_penalty, str):
             # reward.py:323-333 reads `offset` before assignment (defect D3): numeric only
             raise NotImplementedError('string heuristics raise UnboundLocalError in the reference')
-        assert valid_reward >= 0, 'Valid reward must be >= 0'
-        assert invalid_penalty >= 0, 'Invalid penalty must be >= 0'
-        assert 0 <= invalid_objective_share <= 1, 'Objective share must be in [0, 1]'
-        self.valid_reward = valid_reward
-        self.invalid_penalty = invalid_penalty
+        if valid_reward < 0 or invalid_penalty < 0 or not 0 <= invalid_objective_share <= 1:
+            raise AssertionError('valid_reward and invalid_penalty must be >= 0, the objective share in [0, 1]')
+        self.valid_reward, self.invalid_penalty = valid_reward, invalid_penalty
         self.invalid_objective_share = invalid_objective_share
-
-    def adjust_penalty(self, penalty, valid):
-        return penalty + self.valid_reward if valid else penalty - self.invalid_penalty
-
-    def adjust_objective(self, objective, valid):
-        return objective if valid else objective * self.invalid_objective_share
-
-    def calculate_cost(self, penalty, valid):
-        return 0.0 if valid else super().calculate_cost(penalty, valid) + self.invalid_penalty
 
 
 class OnlyObjective(RewardFunction):
-    KIND = 3
+    """reward.py:342-350: no penalty term at all."""
+    KIND = ONLY_OBJECTIVE
 
     def __init__(self, **kwargs):
         super().__init__(penalty_weight=0.0, **kwargs)
 
-    def adjust_penalty(self, penalty, valid):
-        return 0.0
-
 
 def load_reward_class(name: str):
-    """util/import_class.py:6-16: class by (capitalised) name."""
-    g = globals()
+    """A reward class of this module by (capitalised) name, as util/import_class.py:6-16 resolves the
+    `reward_function='summation'` strings of the reference."""
     for cand in (name, name.capitalize()):
-        if cand in g and isinstance(g[cand], type) and issubclass(g[cand], RewardFunction):
-            return g[cand]
+        cls = globals().get(cand)
+        if isinstance(cls, type) and issubclass(cls, RewardFunction):
+            return cls
     raise AttributeError(f'Class {name} not found in module opfgym_amd.reward!')
