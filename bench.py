@@ -239,12 +239,16 @@ def main():
     actions = torch.as_tensor(act_rng.random((B, env.n_actions)), device=device)
     gather = {'none': (), 'reward': ('reward',), 'obs': ('reward', 'obs')}[gather_mode]
 
+    # the gathers run behind the next step's kernel (opfgym_amd.dist.OverlappedGather): the full batch of step k is
+    # available while step k+1 is simulated, as a learner consumes it; the last one is collected after the loop
+    g_reward, g_obs = odist.OverlappedGather(world), odist.OverlappedGather(world)
+
     def one_step():
         obs, reward, term, trunc, info = env.step(actions)
         if world > 1 and gather:
-            odist.all_gather_rows(reward, world)
+            g_reward.submit(reward)
             if 'obs' in gather:
-                odist.all_gather_rows(obs, world)
+                g_obs.submit(obs)
         return info
 
     for _ in range(args.warmup):
@@ -255,6 +259,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         info = one_step()
+    if world > 1 and gather:                   # the last step's gather belongs to the timed region
+        g_reward.flush()
+        if 'obs' in gather:
+            g_obs.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -325,7 +333,7 @@ def main():
                                    f'({B} per GPU), {solves_per_step} NR solve(s) per step, step() only',
                        'baseline_config': args.config, 'batch_per_gpu': B, 'batch_total': total_B,
                        'parallelism': f'shard{world}',
-                       'collective': {'none': 'none', 'reward': 'all_gather(reward)', 'obs': 'all_gather(reward+obs)'}[gather_mode] if world > 1 else 'none',
+                       'collective': {'none': 'none', 'reward': 'all_gather(reward), overlapped with the next step', 'obs': 'all_gather(reward+obs), overlapped with the next step'}[gather_mode] if world > 1 else 'none',
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it_base,
                        'mean_nr_iterations_all_solves': mean_it_total, 'solves_per_step': solves_per_step,
                        'nr_solves_per_s': total_B * solves_per_step * args.steps / elapsed,

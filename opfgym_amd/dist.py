@@ -67,6 +67,55 @@ def all_gather_rows(local, world: int, sizes=None):
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], dim=0)
 
 
+class OverlappedGather:
+    """The per-step all-gather of one output (equal shards) WITHOUT stalling the producer: the local rows are
+    copied into one of two staging buffers and gathered asynchronously — on RCCL's own stream, behind the copy —
+    while the next step's kernel already runs; `submit` hands back the full-batch tensor of the PREVIOUS step
+    (complete by then), `flush` the last one.  A learner consumes step k's batch while step k+1 is simulated, which
+    is how the gather comes off the critical path (a blocking gather would add its latency to every step:
+    ~10 % at 0.27 ms per step)."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self._stage, self._out, self._work, self._k = [None, None], [None, None], [None, None], 0
+
+    def submit(self, local):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return local
+        if local.is_cuda and dist.get_backend() == 'gloo':        # (debugging aid: ranks sharing one GPU)
+            prev, self._last = getattr(self, '_last', None), all_gather_rows(local, self.world)
+            return prev
+        slot, other = self._k & 1, (self._k & 1) ^ 1
+        self._k += 1
+        if self._stage[slot] is None:
+            self._stage[slot] = torch.empty_like(local)
+            self._out[slot] = torch.empty((local.shape[0] * self.world,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                          device=local.device)
+        if self._work[slot] is not None:
+            self._work[slot].wait()                            # (two steps old: long finished)
+        self._stage[slot].copy_(local)
+        self._work[slot] = dist.all_gather_into_tensor(self._out[slot], self._stage[slot], async_op=True)
+        if self._work[other] is None:
+            return None
+        self._work[other].wait()
+        return self._out[other]
+
+    def flush(self):
+        """The full-batch tensor of the last submitted step."""
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return None
+        if getattr(self, '_last', None) is not None:
+            return self._last
+        slot = (self._k - 1) & 1
+        if self._k == 0 or self._work[slot] is None:
+            return None
+        self._work[slot].wait()
+        return self._out[slot]
+
+
 class ShardedBatch:
     """Wraps a per-rank environment factory: `total_batch` instances split over
     the ranks; `step()` returns the local shard's outputs plus, for the names in

@@ -135,3 +135,39 @@ def test_sharded_batch_reassembles_the_full_batch(total):
     assert np.array_equal(full['obs'], obs.numpy())
     assert np.array_equal(full['terminated'], term.double().numpy())
     assert np.array_equal(full['cost'], info['cost'].numpy())
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from opfgym_amd.dist import OverlappedGather
+    g = OverlappedGather(world)
+    buf = torch.zeros(5, dtype=torch.float64)          # a persistent output buffer, overwritten every "step"
+    got = []
+    for k in range(6):
+        buf.copy_(torch.arange(5, dtype=torch.float64) + 100 * k + 10 * rank)
+        prev = g.submit(buf)
+        got.append(None if prev is None else prev.clone())
+    got.append(g.flush().clone())
+    if rank == 0:
+        q.put([None if t is None else t.numpy() for t in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_returns_the_previous_step():
+    """`OverlappedGather`: step k's rows are gathered while step k+1 runs — `submit` returns the full batch of the
+    step before (None at first), `flush` the last one; the producer's buffer may be overwritten right after submit."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, 29655, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] is None
+    for k in range(6):
+        want = np.concatenate([np.arange(5) + 100 * k + 10 * r for r in range(2)]).astype(float)
+        assert np.array_equal(got[k + 1], want)
