@@ -823,32 +823,28 @@ class BatchedOpfEnv:
         def cost_source(et, element):
             pos = int(st.rows(et, [element])[0])
             if et == 'ext_grid':
-                return capi.COST_EXT_GRID, ref_ord[c.bus_lookup[int(net.ext_grid['bus'].iloc[pos])]], -1, 1.0
+                return capi.COST_EXT_GRID, ref_ord[c.bus_lookup[int(net.ext_grid['bus'].iloc[pos])]], -1, 1.0, -1
             sc = float(net[et]['scaling'].iloc[pos]) if 'scaling' in net[et].columns else 1.0
             if et == 'gen':
-                return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc
+                return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc, -1
             # (a unit on a bus that is not part of the compiled case — permanently de-energised — or out of
             #  service reports zero power, results_bus.py: its row keeps the constant term only)
             bus = c.bus_lookup.get(int(net[et]['bus'].iloc[pos]), -1)
             if bus < 0 or ('in_service' in net[et].columns and not bool(net[et]['in_service'].iloc[pos])):
                 sc = 0.0
-            cost_bus_of_row.append(bus)
-            return capi.COST_UNIT, st.slot(et, 'p_mw') + pos, st.slot(et, 'q_mvar') + pos, sc
+            return capi.COST_UNIT, st.slot(et, 'p_mw') + pos, st.slot(et, 'q_mvar') + pos, sc, bus
         poly, pwl = net['poly_cost'], net['pwl_cost']
         if self.objective_terms or self.host_objective is not None:   # objective_function replaces get_pandapower_costs (opf_env.py:80-84)
             poly, pwl = poly.iloc[:0], pwl.iloc[:0]
         ck, cp, cq, cs, coef, is_q, cbus = [], [], [], [], [], [], []
-        cost_bus_of_row = []
         for _, row in poly.iterrows():
-            cost_bus_of_row.clear()
-            k, pi, qi, sc = cost_source(row['et'], row['element'])
-            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(cost_bus_of_row[0] if cost_bus_of_row else -1)
+            k, pi, qi, sc, bus = cost_source(row['et'], row['element'])
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(bus)
             coef += [float(row[n]) for n in _POLY_COEF]
         nseg = min((len(p) for p in pwl['points']), default=0) if len(pwl) else 0      # defect D9
         for _, row in pwl.iterrows():
-            cost_bus_of_row.clear()
-            k, pi, qi, sc = cost_source(row['et'], row['element'])
-            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(cost_bus_of_row[0] if cost_bus_of_row else -1)
+            k, pi, qi, sc, bus = cost_source(row['et'], row['element'])
+            ck.append(k); cp.append(pi); cq.append(qi); cs.append(sc); cbus.append(bus)
             is_q.append(0 if row['power_type'] == 'p' else 1)
             for sgm in row['points'][:nseg]:
                 coef += [float(v) for v in sgm]
