@@ -149,12 +149,13 @@ def test_full_batch_voltage_control_properties():
 
 
 @pytest.mark.parametrize('name,B,n_check,team', [('eco_hv_mixed', 8192, 16, 4), ('sc_vc_hv_urban', 4096, 16, 4),
-                                                 ('eco_hv_mixed', 2048, 8, 2)])
-def test_full_batch_hv_configs(name, B, n_check, team, monkeypatch):
+                                                 ('eco_hv_mixed', 2048, 8, 2), ('qm_mv_urban', 65536, 12, 1)])
+def test_full_batch_configs(name, B, n_check, team, monkeypatch):
     """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
     (B = 8192, four wavefronts per instance; a smaller batch with teams of two forced through the
     developer switch OPFX_TEAM) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
-    contingency (B = 4096 x 251 solves, four wavefronts per instance).  All rows:
+    contingency (B = 4096 x 251 solves, four wavefronts per instance); BASELINE config 4 at its full size as well
+    (QMarket, 144 buses, B = 65536: every wavefront walks 32 instances).  All rows:
     size-independent properties; `n_check` rows spread over the batch: the full step against the oracle."""
     if team == 2:
         monkeypatch.setenv('OPFX_TEAM', '2')
