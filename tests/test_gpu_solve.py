@@ -215,38 +215,62 @@ def test_published_textbook_solutions_on_the_gpu(name):
             assert abs(out['q_gen'][i] * base - val) < pub['s_tol'], (g, out['q_gen'][i] * base)
 
 
+def _check_export_on_the_gpu(path):
+    """One exporter file through the HIP path: the matrix route (`ppci_io.load_exported_case` -> opfx_solve) and the
+    table route (batch-1 plug-in on the exported element tables) against the exported results."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'scripts'))
+    from export_pandapower_case import load_tables
+    from opfgym_amd import capi, power_flow_solver
+    from opfgym_amd.ppci_io import load_exported_case
+    dev = torch.device('cuda:0')
+    case, p, q, qmin, qmax, ref = load_exported_case(path)
+    ctx = capi.Context(capi.Plan(case), 0)
+    out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev),
+                     qg_min=torch.tensor(qmin, device=dev), qg_max=torch.tensor(qmax, device=dev), enforce_q_lims=True)
+    assert bool(out['converged'][0]), path
+    assert np.abs(out['vm'][0].cpu().numpy() - ref['vm']).max() < 1e-6, path
+    z = np.load(path, allow_pickle=False)
+    net = load_tables(z)
+    power_flow_solver(net, enforce_q_lims=True)
+    n_tables = 0
+    for key in z.files:
+        if key.startswith('out__'):
+            _, tbl, col = key.split('__')
+            tol = 1e-6 if col == 'vm_pu' else 1e-4
+            assert np.allclose(net[tbl][col].to_numpy(float), z[key], rtol=0, atol=tol, equal_nan=True), (path, key)
+            n_tables += 1
+    return n_tables
+
+
 def test_pandapower_export_fixtures_on_the_gpu():
     """fixtures/*.npz (pandapower's own matrices, tables and results; see fixtures/README.md): the HIP path
     against pandapower at 1e-6 p.u., through both the matrix route and the table route.  Skips while no
     export exists (pandapower is not installed in the build container)."""
     import glob
     import os
-    import sys
-    import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = sorted(glob.glob(os.path.join(root, 'fixtures', '*.npz')))
     if not files:
         pytest.skip('no pandapower exports under fixtures/')
-    sys.path.insert(0, os.path.join(root, 'scripts'))
-    from export_pandapower_case import load_tables
-    from opfgym_amd import capi, power_flow_solver
-    from opfgym_amd.ppci_io import load_exported_case
-    dev = torch.device('cuda:0')
     for path in files:
-        case, p, q, qmin, qmax, ref = load_exported_case(path)
-        ctx = capi.Context(capi.Plan(case), 0)
-        out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev),
-                         qg_min=torch.tensor(qmin, device=dev), qg_max=torch.tensor(qmax, device=dev), enforce_q_lims=True)
-        assert bool(out['converged'][0]), path
-        assert np.abs(out['vm'][0].cpu().numpy() - ref['vm']).max() < 1e-6, path
-        z = np.load(path, allow_pickle=False)
-        net = load_tables(z)
-        power_flow_solver(net, enforce_q_lims=True)
-        for key in z.files:
-            if key.startswith('out__'):
-                _, tbl, col = key.split('__')
-                tol = 1e-6 if col == 'vm_pu' else 1e-4
-                assert np.allclose(net[tbl][col].to_numpy(float), z[key], rtol=0, atol=tol, equal_nan=True), (path, key)
+        _check_export_on_the_gpu(path)
+
+
+@pytest.mark.parametrize('code', ['mv-small', 'hv-small-sw', 'mv-3w'])
+def test_export_checker_runs_on_a_synthetic_export_on_the_gpu(code, tmp_path):
+    """The GPU checker of real pandapower exports, exercised on a file in the exporter's format whose results are the
+    oracle's (tests/test_oracle_pf._synthetic_export): the first real file dropped into fixtures/ meets tested code —
+    and the HIP path agrees with the oracle through both routes on the way."""
+    from test_oracle_pf import _synthetic_export
+    from opfgym_amd import grids
+    net, _ = grids.get_grid(code)
+    path = tmp_path / f'{code}.npz'
+    _synthetic_export(net, str(path))
+    assert _check_export_on_the_gpu(str(path)) >= 3
 
 
 @pytest.mark.parametrize('seed', range(6))

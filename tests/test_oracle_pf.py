@@ -127,34 +127,86 @@ def _fixture_files():
     return sorted(glob.glob(os.path.join(root, 'fixtures', '*.npz')))
 
 
+def _check_export(path):
+    """One file of scripts/export_pandapower_case.py: (1) the solver on the exported pypower matrices against the
+    exported voltages, (2) the oracle's table converter + solver on the exported element tables against the
+    exported result tables (row P2)."""
+    import sys, os
+    from oracle import pd2ppc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    from export_pandapower_case import load_tables
+    z = np.load(path, allow_pickle=False)
+    ppc = pd2ppc.ppc_from_matrices(float(z['baseMVA']), z['bus'], z['branch'], z['gen'])
+    ppc.b = ppc.b - 1j * z['br_g']
+    sol = po.solve(ppc, enforce_q_lims=bool(z['enforce_q_lims']))
+    assert sol['converged'], path
+    assert np.abs(np.abs(sol['V']) - z['res_vm']).max() < 1e-6, path
+    assert np.abs(np.degrees(np.angle(sol['V'])) - z['res_va']).max() < 1e-5, path
+    net = load_tables(z)
+    po.runpp(net, enforce_q_lims=True)
+    n_tables = 0
+    for key in z.files:
+        if key.startswith('out__'):
+            _, tbl, col = key.split('__')
+            tol = 1e-6 if col in ('vm_pu',) else 1e-4
+            assert np.allclose(net[tbl][col].to_numpy(float), z[key], rtol=0, atol=tol, equal_nan=True), (path, key)
+            n_tables += 1
+    return n_tables
+
+
 def test_pandapower_export_fixtures():
     """The 1e-6 gate against pandapower proper: every fixtures/*.npz written by
     scripts/export_pandapower_case.py on a machine that has pandapower (element tables, ppci matrices and
     pandapower's own results).  None can be produced in this container, so the test skips while the
-    directory is empty.  Checked: (1) the solver on pandapower's own matrices, (2) the oracle's table
-    converter + solver on the element tables against pandapower's result tables (row P2)."""
-    import sys, os
-    from oracle import pd2ppc
+    directory is empty."""
     files = _fixture_files()
     if not files:
         pytest.skip('no pandapower exports under fixtures/ (pandapower is not installed here)')
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
-    from export_pandapower_case import load_tables
     for path in files:
-        z = np.load(path, allow_pickle=False)
-        ppc = pd2ppc.ppc_from_matrices(float(z['baseMVA']), z['bus'], z['branch'], z['gen'])
-        ppc.b = ppc.b - 1j * z['br_g']
-        sol = po.solve(ppc, enforce_q_lims=bool(z['enforce_q_lims']))
-        assert sol['converged'], path
-        assert np.abs(np.abs(sol['V']) - z['res_vm']).max() < 1e-6, path
-        assert np.abs(np.degrees(np.angle(sol['V'])) - z['res_va']).max() < 1e-5, path
-        net = load_tables(z)
-        po.runpp(net, enforce_q_lims=True)
-        for key in z.files:
-            if key.startswith('out__'):
-                _, tbl, col = key.split('__')
-                tol = 1e-6 if col in ('vm_pu',) else 1e-4
-                assert np.allclose(net[tbl][col].to_numpy(float), z[key], rtol=0, atol=tol, equal_nan=True), (path, key)
+        _check_export(path)
+
+
+def _synthetic_export(net, path):
+    """A file in the exporter's format whose "pandapower results" are the oracle's own — it pins nothing, it only
+    lets the checker of real exports run here (matrix route, table route, every `out__` column)."""
+    import sys, os
+    from oracle import pd2ppc
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    from export_pandapower_case import RESULTS, dump_tables
+    sol = po.runpp(net, enforce_q_lims=True)
+    ppc = sol['ppc']
+    on = np.flatnonzero(sol['supplied'])                   # (pandapower's ppci holds the energised buses only)
+    renum = {int(b): k for k, b in enumerate(on)}
+    keep_br = [k for k in range(ppc.nbr) if ppc.status[k] and ppc.f[k] in renum and ppc.t[k] in renum]
+    keep_g = [g for g in range(len(ppc.g_bus)) if ppc.g_status[g] and int(ppc.g_bus[g]) in renum]
+    z0 = np.zeros(len(on))
+    bus = np.column_stack([np.arange(len(on)), sol['bus_type'][on] if 'bus_type' in sol else ppc.bus_type[on], ppc.pd[on], ppc.qd[on],
+                           ppc.gs[on], ppc.bs[on], z0 + 1, ppc.vm[on], ppc.va[on], ppc.base_kv[on], z0 + 1, z0 + 2, z0])
+    bus[:, 1] = ppc.bus_type[on]
+    branch = np.array([[renum[int(ppc.f[k])], renum[int(ppc.t[k])], ppc.r[k], ppc.x[k], ppc.b[k].real, 0, 0, 0, ppc.tap[k],
+                        ppc.shift[k], 1, -360, 360] for k in keep_br], dtype=float)
+    gen = np.array([[renum[int(ppc.g_bus[g])], ppc.g_p[g], 0.0, ppc.g_qmax[g], ppc.g_qmin[g], ppc.g_vg[g], 100, 1] for g in keep_g], dtype=float)
+    v = sol['V'][on]
+    data = dict(baseMVA=np.array(ppc.base_mva), bus=bus, branch=branch, gen=gen, res_vm=np.abs(v), res_va=np.degrees(np.angle(v)),
+                br_g=np.array([-ppc.b[k].imag for k in keep_br]), enforce_q_lims=np.array(1))
+    data.update(dump_tables(net))
+    for tbl, cols in RESULTS:
+        if tbl in net and len(net[tbl]):
+            for col in cols:
+                if col in net[tbl].columns:
+                    data[f'out__{tbl}__{col}'] = net[tbl][col].to_numpy(dtype=float)
+    np.savez_compressed(path, **data)
+
+
+@pytest.mark.parametrize('code', ['mv-small', 'hv-small-sw', 'mv-3w'])
+def test_export_checker_runs_on_a_synthetic_export(code, tmp_path):
+    """The checker of real pandapower exports (`_check_export`) exercised end to end on a file in the exporter's
+    format (tables with taps, switches, a three-winding transformer; pypower matrices; result tables) — so that the
+    first real file a maintainer drops into fixtures/ meets tested code."""
+    net, _ = grids.get_grid(code)
+    path = tmp_path / f'{code}.npz'
+    _synthetic_export(net, str(path))
+    assert _check_export(str(path)) >= 3
 
 
 def test_export_table_round_trip():
