@@ -1,0 +1,46 @@
+"""The bench contract on the GPU box: `bench.py` prints ONE JSON line with the driver's keys, the roofline object and
+(unless switched off) the CPU baseline with the |V| check against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('config', [1, 2, 3])
+def test_bench_line_has_the_contract_keys(config):
+    d = _run('--config', str(config), '--steps', '4', '--warmup', '2', '--no-cpu-baseline')
+    assert set(d) == KEYS
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['higher_is_better'] is True
+    assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None and d['cpu_baseline'] is None
+    assert d['value'] > 0 and abs(d['value'] - d['config']['batch_total'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert d['config']['baseline_config'] == config and 'workload' in d['config'] and d['config']['converged_fraction'] > 0.99
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and r['unit'] == 'GB/s'
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * r['achieved']
+    bm = d['config']['byte_model']
+    assert abs(bm['B_step'] - (bm['io_bytes'] + bm['it'] * bm['bytes_per_iteration'])) < 1e-6
+
+
+def test_bench_default_line_carries_cpu_baseline_and_voltage_check():
+    d = _run('--config', '1', '--steps', '4', '--warmup', '2')
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and cb['all_cores']['cores'] >= 1
+    assert 'oracle' in cb['sample']
+    assert d['config']['max_abs_v_err_pu'] is not None and d['config']['max_abs_v_err_pu'] < 1e-9
