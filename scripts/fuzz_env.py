@@ -211,7 +211,12 @@ def run_one(base, kw, rng, B=8):
             # batched env keeps the fixed shape of its observation space: the common prefix is compared)
             go = got['obs'][k][:len(ref['obs'])] if base == 'multistage_lv' else got['obs'][k]
             assert np.allclose(go, ref['obs'], rtol=0, atol=R_TOL, equal_nan=True), ('obs', k, s_, np.abs(go - ref['obs']).max())
-            assert np.isclose(got['reward'][k], ref['reward'], rtol=REL, atol=R_TOL), ('reward', k, s_, got['reward'][k], ref['reward'])
+            # (with diff_objective the reward is the difference of two objectives: the solver tolerance enters
+            #  relative to THEIR size — a 9-bus case with generator costs of several thousand per hour — not to the
+            #  size of the difference)
+            big = abs(float(getattr(orc, 'initial_obj', 0.0) or 0.0)) if kw.get('diff_objective') else 0.0
+            assert abs(got['reward'][k] - ref['reward']) <= R_TOL + REL * max(abs(ref['reward']), big), \
+                ('reward', k, s_, got['reward'][k], ref['reward'])
             nc = len(ref['valids'])
             assert (got['valids'][k][:nc] == ref['valids']).all(), ('valids', k, s_)
             assert np.allclose(got['viol'][k][:nc], ref['violations'], rtol=REL, atol=R_TOL), ('violations', k, s_)
