@@ -128,6 +128,104 @@ def _col(df, name, default):
     return np.full(len(df), default)
 
 
+def _flags(df, name, default=False):
+    """Boolean column that may arrive as object dtype with None / NaN entries (a real pandapower table)."""
+    if name not in df.columns:
+        return np.full(len(df), default, dtype=bool)
+    return np.array([default if (v is None or v != v) else bool(v) for v in df[name].to_numpy()], dtype=bool)
+
+
+# pandapower element tables that take part in `runpp` and that this converter has no model for: a net that
+# fills one of them would be solved WITHOUT those elements — a silently different grid — so it is refused
+UNMODELLED_TABLES = ('ward', 'xward', 'impedance', 'dcline', 'motor', 'asymmetric_load', 'asymmetric_sgen',
+                     'svc', 'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc')
+
+
+def _count_nonzero(df, col):
+    if col not in df.columns:
+        return 0
+    v = pd_to_float(df[col].to_numpy())
+    return int(np.count_nonzero(np.nan_to_num(v)))
+
+
+def pd_to_float(values):
+    try:
+        return np.asarray(values, dtype=float)
+    except (TypeError, ValueError):
+        return np.array([np.nan if (v is None or isinstance(v, str)) else float(v) for v in values])
+
+
+def check_supported(net) -> None:
+    """Raise ValueError (naming the table / column) for net content that `pp.runpp` would model and this
+    converter does not (opf_env.py:703 hands the WHOLE net to pandapower): rows in `ward`, `xward`,
+    `impedance`, `dcline`, `motor`, the asymmetric / FACTS tables; voltage-dependent (ZIP) loads; switches
+    with an impedance; switches at three-winding transformers; generators acting as slack;
+    characteristic-dependent transformer impedances."""
+    def table(name):
+        try:
+            df = net[name]
+        except (KeyError, AttributeError):
+            return None
+        return df if hasattr(df, 'columns') and len(df) else None
+    for name in UNMODELLED_TABLES:
+        if table(name) is not None:
+            raise ValueError(f'net.{name} has {len(net[name])} row(s): this element type is not modelled by the '
+                             f'batched power flow (pandapower would include it)')
+    load = table('load')
+    if load is not None:
+        for col in ('const_z_percent', 'const_i_percent'):
+            if _count_nonzero(load, col):
+                raise ValueError(f'net.load.{col} is non-zero: voltage-dependent (ZIP) loads are not modelled')
+    sw = table('switch')
+    if sw is not None:
+        if _count_nonzero(sw, 'z_ohm'):
+            raise ValueError('net.switch.z_ohm is non-zero: switches with an impedance are not modelled')
+        if 'et' in sw.columns and any(str(v) == 't3' for v in sw['et']):
+            raise ValueError("net.switch: et='t3' (switches at three-winding transformers) is not modelled")
+    gen = table('gen')
+    if gen is not None and _flags(gen, 'slack').any():
+        raise ValueError('net.gen.slack is set: generators acting as slack are not modelled (use an ext_grid)')
+    for name in ('trafo', 'trafo3w'):
+        tr = table(name)
+        if tr is not None and _flags(tr, 'tap_dependent_impedance').any():
+            raise ValueError(f'net.{name}.tap_dependent_impedance is set: characteristic-dependent transformer '
+                             f'impedances are not modelled')
+    t3 = table('trafo3w')
+    if t3 is not None and _flags(t3, 'tap_at_star_point').any():
+        raise ValueError('net.trafo3w.tap_at_star_point is set: not modelled')
+    if t3 is not None and _count_nonzero(t3, 'tap_step_degree'):
+        raise ValueError('net.trafo3w.tap_step_degree is non-zero: not modelled for three-winding transformers')
+
+
+def tap_changer(side, tap_pos, tap_neutral, step_percent, step_degree, phase_shifter):
+    """pandapower `_calc_tap_from_dataframe` for one transformer: (factor on the rated voltage of the tap
+    side, additional phase shift in degree).  A ratio/asymmetrical tap changer moves the voltage phasor by
+    du = step_percent/100 * (pos - neutral) under the angle `step_degree`: |1 + du e^{j a}| and
+    arctan(+-du sin a / (1 + du cos a)) (+ on the hv side, - on the lv side); an ideal phase shifter
+    (`tap_phase_shifter`) only turns the angle, by `step_degree` per step or, given as `step_percent`,
+    by 2 asin(du / 2)."""
+    if side not in ('hv', 'lv') or not np.isfinite(tap_pos):
+        return 1.0, 0.0
+    direction = 1.0 if side == 'hv' else -1.0
+    diff = tap_pos - tap_neutral
+    deg = step_degree if np.isfinite(step_degree) else 0.0
+    pct = step_percent if np.isfinite(step_percent) else 0.0
+    if phase_shifter:
+        if deg != 0.0 and pct != 0.0:
+            raise ValueError('trafo: ideal phase shifter with both tap_step_degree and tap_step_percent')
+        if deg != 0.0:
+            return 1.0, direction * diff * deg
+        return 1.0, direction * 2.0 * np.degrees(np.arcsin(diff * pct / 100.0 / 2.0))
+    if not np.isfinite(step_percent):
+        return 1.0, 0.0
+    du = step_percent * diff / 100.0
+    if not np.isfinite(du):                  # (no neutral position given: pandapower applies no tap)
+        return 1.0, 0.0
+    a = np.radians(deg)
+    re, im = 1.0 + du * np.cos(a), du * np.sin(a)
+    return float(np.hypot(re, im)), float(np.degrees(np.arctan(direction * im / re)))
+
+
 def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     """Convert the element tables of `net` into a per-unit :class:`Case`.
 
@@ -147,6 +245,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         phase shift when voltage angles are calculated;
       * every in-service ext_grid bus is REF, every in-service gen bus PV.
     """
+    check_supported(net)
     base = float(net['sn_mva']) if 'sn_mva' in net else 1.0
     f_hz = float(net['f_hz']) if 'f_hz' in net else 50.0
     bus_df = net['bus']
@@ -225,6 +324,8 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         tap_pos = _col(tr, 'tap_pos', np.nan)
         tap_neutral = _col(tr, 'tap_neutral', np.nan)
         tap_step = _col(tr, 'tap_step_percent', np.nan)
+        tap_deg = _col(tr, 'tap_step_degree', np.nan)
+        phase_shifter = _flags(tr, 'tap_phase_shifter')
         shift = _col(tr, 'shift_degree', 0.0)
         for pos, idx in enumerate(tr.index):
             hb, lb = int(tr.at[idx, 'hv_bus']), int(tr.at[idx, 'lv_bus'])
@@ -237,14 +338,12 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             vn_hv, vn_lv = float(tr.at[idx, 'vn_hv_kv']), float(tr.at[idx, 'vn_lv_kv'])
             vt_hv, vt_lv = vn_hv, vn_lv
             side = tr.at[idx, 'tap_side'] if 'tap_side' in tr.columns else None
-            if isinstance(side, str) and not np.isnan(tap_pos[pos]) \
-                    and not np.isnan(tap_step[pos]):
-                neutral = 0.0 if np.isnan(tap_neutral[pos]) else tap_neutral[pos]
-                fac = 1.0 + (tap_pos[pos] - neutral) * tap_step[pos] / 100.0
-                if side == 'hv':
-                    vt_hv = vn_hv * fac
-                elif side == 'lv':
-                    vt_lv = vn_lv * fac
+            fac, tap_shift = tap_changer(side if isinstance(side, str) else '', tap_pos[pos], tap_neutral[pos],
+                                         tap_step[pos], tap_deg[pos], phase_shifter[pos])
+            if side == 'hv':
+                vt_hv = vn_hv * fac
+            elif side == 'lv':
+                vt_lv = vn_lv * fac
             vb_hv, vb_lv = vn[hb], vn[lb]
             # short-circuit impedance referred to the LV side, system base
             tap_lv = (vt_lv / vb_lv) ** 2 * base
@@ -274,7 +373,8 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             else:
                 r_pi, x_pi, bc = r_sc, x_sc, 0.0 + 0.0j
             ratio = (vt_hv / vb_hv) / (vt_lv / vb_lv)
-            sh = np.deg2rad(shift[pos]) if calc_angles else 0.0
+            # (shift_degree counts only when angles are calculated; the tap changer's own shift always does)
+            sh = np.deg2rad((shift[pos] if calc_angles else 0.0) + tap_shift)
             kf = base * (vn_hv / vb_hv) / sn * 100.0 / (par[pos] * dfac[pos])
             kt = base * (vn_lv / vb_lv) / sn * 100.0 / (par[pos] * dfac[pos])
             rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt, oside, 0))

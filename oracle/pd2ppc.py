@@ -101,7 +101,7 @@ def _get(df, col, default):
 def _flag(df, col, default=True):
     if col not in df.columns:
         return np.full(len(df), default, dtype=bool)
-    return np.array([bool(v) for v in df[col].to_numpy()], dtype=bool)
+    return np.array([default if (v is None or v != v) else bool(v) for v in df[col].to_numpy()], dtype=bool)
 
 
 class _Sets:
@@ -162,6 +162,8 @@ def _tap_voltages(vn_hv, vn_lv, shift_deg, tap_side, tap_pos, tap_neutral, tap_s
             if not np.isfinite(tap_step_percent[k]):
                 continue
             step = tap_step_percent[k] * diff[k] / 100.0
+            if not np.isfinite(step):            # `_replace_nan(tap_steps)`: no neutral position -> no tap change
+                step = 0.0
             ang = np.radians(tap_step_degree[k]) if np.isfinite(tap_step_degree[k]) else 0.0
             u1 = vn[k]
             du = u1 * step
@@ -230,7 +232,44 @@ def _trafo3w_as_two_winding(t3):
     return out
 
 
+def refuse_unmodelled(net):
+    """`pp.runpp` models every element table of the net; this restatement covers bus, line, trafo, trafo3w,
+    load, sgen, storage, gen, ext_grid, shunt and switch.  Anything else that is filled in would make the
+    oracle solve another grid than pandapower does, so it is an error, not a silent omission."""
+    def rows(name):
+        df = net[name] if name in net else None
+        return df if df is not None and hasattr(df, 'columns') and len(df) else None
+
+    def nonzero(df, col):
+        return col in df.columns and bool(np.any(_get(df, col, 0.0) != 0.0))
+    for name in ('ward', 'xward', 'impedance', 'dcline', 'motor', 'asymmetric_load', 'asymmetric_sgen', 'svc',
+                 'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc'):
+        if rows(name) is not None:
+            raise ValueError(f'oracle: element table {name!r} is not modelled')
+    ld = rows('load')
+    if ld is not None and (nonzero(ld, 'const_z_percent') or nonzero(ld, 'const_i_percent')):
+        raise ValueError('oracle: ZIP loads (load.const_z_percent / const_i_percent) are not modelled')
+    sw = rows('switch')
+    if sw is not None:
+        if nonzero(sw, 'z_ohm'):
+            raise ValueError('oracle: switch.z_ohm is not modelled')
+        if any(str(e) == 't3' for e in sw['et']):
+            raise ValueError("oracle: switch.et == 't3' is not modelled")
+    gn = rows('gen')
+    if gn is not None and _flag(gn, 'slack', False).any():
+        raise ValueError('oracle: gen.slack is not modelled')
+    for name in ('trafo', 'trafo3w'):
+        tr = rows(name)
+        if tr is not None and 'tap_dependent_impedance' in tr.columns and _flag(tr, 'tap_dependent_impedance', False).any():
+            raise ValueError(f'oracle: {name}.tap_dependent_impedance is not modelled')
+    t3 = rows('trafo3w')
+    if t3 is not None and ((('tap_at_star_point' in t3.columns) and _flag(t3, 'tap_at_star_point', False).any())
+                           or nonzero(t3, 'tap_step_degree')):
+        raise ValueError('oracle: trafo3w.tap_at_star_point / tap_step_degree are not modelled')
+
+
 def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> PPC:
+    refuse_unmodelled(net)
     base_mva = float(net['sn_mva']) if 'sn_mva' in net else 1.0
     f_hz = float(net['f_hz']) if 'f_hz' in net else 50.0
     bus_df = net['bus']
@@ -287,7 +326,7 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
         side = [s if isinstance(s, str) else '' for s in (tr['tap_side'] if 'tap_side' in tr.columns else [''] * len(tr))]
         vnh, vnl, sh = _tap_voltages(
             _get(tr, 'vn_hv_kv', np.nan), _get(tr, 'vn_lv_kv', np.nan), _get(tr, 'shift_degree', 0.0), side,
-            _get(tr, 'tap_pos', np.nan), _get(tr, 'tap_neutral', 0.0), _get(tr, 'tap_step_percent', np.nan),
+            _get(tr, 'tap_pos', np.nan), _get(tr, 'tap_neutral', np.nan), _get(tr, 'tap_step_percent', np.nan),
             _get(tr, 'tap_step_degree', np.nan), _flag(tr, 'tap_phase_shifter', False), calc_angles)
         par = _get(tr, 'parallel', 1.0)
         tr_r, tr_x, tr_b = _trafo_branch(base_mva, _get(tr, 'sn_mva', np.nan), _get(tr, 'vn_lv_kv', np.nan), vnl,

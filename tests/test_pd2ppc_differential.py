@@ -99,21 +99,34 @@ def _random_net(rng):
     for k in range(n_lv - 1):
         line(lv[k], lv[k + 1], 0.4)
 
-    def trafo(hb, lb, vh, vl, sn):
+    def trafo(hb, lb, vh, vl, sn, p_angle=0.3):
+        # tap changer kinds (pandapower `_calc_tap_from_dataframe`): ratio only (no / NaN / zero tap_step_degree),
+        # asymmetrical (tap_step_degree != 0), ideal phase shifter given in degree or in percent
+        kind = 'ratio' if rng.random() > p_angle else str(rng.choice(['cross', 'ideal_deg', 'ideal_pct']))
+        extra = {}
+        if kind == 'ratio':
+            extra = [{}, {'tap_step_degree': np.nan}, {'tap_step_degree': 0.0, 'tap_phase_shifter': False}][int(rng.integers(3))]
+        elif kind == 'cross':
+            extra = {'tap_step_degree': float(rng.choice([30.0, 60.0, 90.0, rng.uniform(-90.0, 90.0)])), 'tap_phase_shifter': False}
+        elif kind == 'ideal_deg':
+            extra = {'tap_step_degree': float(rng.uniform(-1.5, 1.5)), 'tap_phase_shifter': True}
         ppn.create_transformer_from_parameters(
             net, hb, lb, sn, vh * float(rng.choice([1.0, 1.0, rng.uniform(0.95, 1.05)])),
             vl * float(rng.choice([1.0, 1.0, rng.uniform(0.95, 1.05)])), float(rng.uniform(4.0, 18.0)),
             float(rng.uniform(0.2, 1.5)), float(rng.choice([0.0, rng.uniform(0.0, 60.0)])),
             float(rng.choice([0.0, rng.uniform(0.0, 0.5)])), shift_degree=float(rng.choice([0.0, 30.0, 150.0])),
             tap_side=[None, 'hv', 'lv'][int(rng.integers(3))], tap_neutral=float(rng.integers(-1, 2)),
-            tap_pos=float(rng.integers(-4, 5)), tap_step_percent=float(rng.uniform(0.5, 2.5)),
+            tap_pos=float(rng.integers(-4, 5)),
+            tap_step_percent=0.0 if kind == 'ideal_deg' else float(rng.uniform(0.5, 2.5)),
             parallel=int(rng.choice([1, 1, 2])), df=float(rng.choice([1.0, rng.uniform(0.6, 1.0)])),
-            in_service=bool(rng.random() > 0.1))
+            in_service=bool(rng.random() > 0.1), **extra)
+        if kind == 'ideal_pct':
+            net.trafo.loc[net.trafo.index[-1], 'tap_phase_shifter'] = True
     shift = float(rng.choice([0.0, 150.0]))
     for hb, lb in ((hv[1], mv[0]), (hv[3], mv[5])):
         trafo(hb, lb, 110.0, 20.0, float(rng.uniform(20.0, 63.0)))
     net.trafo.loc[net.trafo.index[:2], 'shift_degree'] = shift       # one vector group per voltage level
-    trafo(mv[7], lv[0], 20.0, 0.4, float(rng.uniform(0.25, 0.8)))
+    trafo(mv[7], lv[0], 20.0, 0.4, float(rng.uniform(0.25, 0.8)), p_angle=0.7)
     net.trafo.loc[net.trafo.index[2], 'shift_degree'] = 0.0          # (vector groups consistent around every loop)
     if rng.random() < 0.7:                 # a three-winding transformer 110 / 20 / 0.4 kV with random data
         sn_h = float(rng.uniform(20.0, 40.0))
