@@ -75,9 +75,71 @@ def byte_model(env, mean_it_per_solve, solves_per_step):
                 fp64_flops_per_step=flops)
 
 
+def lds_model(env, mean_it_per_solve, solves_per_step, team):
+    """LDS bytes one instance-step moves, counted from the compiled plan (8 B per active lane and access; an atomic
+    add counts once).  Per NR iteration: phase A (bus rounds: own V + ELL-width neighbours read, blocks / rhs
+    written; overflow entries), phases B + C (twelve reads + four or two atomic adds per live item, riders), phase D
+    (diagonal block + rhs + V read, V written), fill blocks zeroed; one more phase A per solve for the final mismatch.
+    Per step: the table row staged in LDS and read back by the prologue, the result bank written and read.
+    Cross-check: `instructions` (wave-level LDS instructions) against SQ_INSTS_LDS of profiles/*_sq_counters.txt."""
+    plan, info = env.plan, env.plan.info
+    nb, KA = info['nb'], info['lp_ell_width']
+    two_value = info['n_full'] < info['n_blk'] and env.kernel_info()['packed']
+    a_ent = plan.array('LP_A_ENT').astype(np.int64) & 0xFFFFFFFF
+    live_blk = int(((a_ent >> 16) != 0xFFFF).sum())
+    h_ent = plan.array('LP_H_ENT').astype(np.int64) & 0xFFFFFFFF
+    h_live = int(((h_ent & 0xFFFF) != 0xFFFF).sum())
+    vals_off = 2 if two_value else 4                      # values of a plain off-diagonal block
+    # phase A, per pass: reads (own vr, vi + KA neighbours) per bus, bus type byte ignored
+    a_reads = nb * (2 + 2 * KA) + h_live * 4
+    a_writes = live_blk * vals_off + h_live * vals_off + 2 * h_live + nb * (4 + 2) + len(plan.array('LP_H_ROW')) * 2
+    a_instr = info['lp_rounds_a'] * (2 + 2 * KA + KA * vals_off + 6) + info['lp_rounds_h'] * (4 + vals_off + 2)
+    if team == 1:
+        items = plan.array('LP_B').astype(np.int64).reshape(-1, 2) & 0xFFFFFFFF
+        riders = plan.array('LP_B2').astype(np.int64) & 0xFFFFFFFF
+        itc = plan.array('LP_C').astype(np.int64).reshape(-1, 2) & 0xFFFFFFFF
+        live_b, live_c = (items[:, 0] & 0xFFFF) != 0xFFFF, (itc[:, 0] & 0xFFFF) != 0xFFFF
+        rhs_b = live_b & ((items[:, 0] & 0x8000) != 0)
+        n_rider = int(((riders >> 16) != 0xFFFF).sum())
+        n_items, n_rhs = int(live_b.sum() + live_c.sum()), int(rhs_b.sum() + live_c.sum())
+        rounds = info['lp_rounds_b'] + info['lp_rounds_c']
+    else:
+        tm = plan.array('LP_TEAM4' if team == 4 else 'LP_TEAM2').astype(np.int64).reshape(-1, 4) & 0xFFFFFFFF
+        live = (tm[:, 0] & 0xFFFF) != 0xFFFF
+        n_items, n_rhs, n_rider = int(live.sum()), int((live & ((tm[:, 0] & 0x8000) != 0)).sum()), 0
+        rounds = info[f'team_rounds_{team}'] * team
+    bc_reads = 12 * n_items + 2 * n_rider
+    bc_writes = 4 * (n_items - n_rhs) + 2 * n_rhs + 2 * n_rider
+    bc_instr = rounds * (12 + 4) + (info['lp_rounds_b'] * 4 if team == 1 else 0)
+    n_free = nb - info['nref']
+    d_reads, d_writes = n_free * 8, n_free * 2
+    d_instr = info['lp_rounds_a'] * 11
+    fill_w = info['n_fill'] * vals_off
+    per_it = 8 * (a_reads + a_writes + bc_reads + bc_writes + d_reads + d_writes + fill_w)
+    per_pass_a = 8 * (a_reads + a_writes + fill_w)
+    nres = env.n_results
+    per_step = 8 * (2 * env.nx + 2 * env.n_actions + 2 * env.n_inj + solves_per_step * (2 * nres + 4 * nb + 6 * info['nbr']))
+    it_step = mean_it_per_solve * solves_per_step
+    total = it_step * per_it + solves_per_step * per_pass_a + per_step
+    instr_it = a_instr + bc_instr + d_instr + (info['n_fill'] * vals_off + 63) // 64
+    instr = it_step * instr_it + solves_per_step * a_instr + (2 * env.nx + 2 * env.n_inj + solves_per_step * (2 * nres + 4 * nb + 6 * info['nbr'])) / 64.0
+    return dict(bytes_per_iteration=per_it, bytes_per_step=total, items_per_iteration=n_items, riders=n_rider,
+                rounds_bc=rounds, lds_wave_instructions_per_step=instr)
+
+
+def measured_counters(config, B):
+    """Counter means of the committed rocprofv3 passes for this configuration (profiles/pmc_latest.json, written by
+    scripts/profile_round.sh: HBM bytes and SQ counters cannot be read in-process), or {} when the batch differs."""
+    pmc_file = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    if not os.path.exists(pmc_file):
+        return {}
+    ent = json.load(open(pmc_file)).get(f'config{config}')
+    return ent if ent and ent.get('batch', 8192) == B else {}
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (numpy/SciPy restatement of the reference path: pandas tables + SuperLU
-# Newton) on this box's host cores, in worker processes (one, then one per host core up to 32)
+# Newton) on this box's host cores, in worker processes (one, then one per host core)
 # ---------------------------------------------------------------------------------------------------
 def cpu_worker(scenario, budget_s, seed):
     """One core: env.step() of the oracle environment for `budget_s` seconds; prints one JSON line."""
@@ -168,7 +230,15 @@ def cpu_baseline(config, budget_s=float(os.environ.get('OPFX_BENCH_CPU_BUDGET', 
         return res
     one = run(1)
     rate1 = one[0]['steps'] / one[0]['cpu_s'] if one else float('nan')
-    n_many = min(cores, 32)          # (every worker is a Python process with pandas + SciPy: bounded memory)
+    # one worker per host core (P = os.cpu_count()); every worker is a Python process with pandas + SciPy
+    # (~0.3 GB resident): bounded by the memory that is free, and by OPFX_BENCH_CPU_PROCS for tests
+    n_many = cores
+    try:
+        import psutil
+        n_many = max(1, min(n_many, int(psutil.virtual_memory().available / 0.6e9)))
+    except Exception:
+        pass
+    n_many = int(os.environ.get('OPFX_BENCH_CPU_PROCS', n_many))
     many = run(n_many) if n_many > 1 else one
     rate_p = sum(r['steps'] / r['cpu_s'] for r in many) if many else float('nan')
     return dict(value=rate1, unit='env.step()/s', cores=1, kind='port',
@@ -176,7 +246,8 @@ def cpu_baseline(config, budget_s=float(os.environ.get('OPFX_BENCH_CPU_BUDGET', 
                 sample=f'{one[0]["steps"] if one else 0} instance-steps of {CONFIGS[config][0]} (scenario {scenario}) with '
                        f'the numpy+SciPy oracle (oracle/env_oracle.py + pf_oracle.py), step() only, '
                        f'{one[0]["cpu_s"] if one else 0:.1f} s of CPU work on one core; then {len(many)} independent '
-                       f'processes, one per host core; pandapower itself is not installed')
+                       f'processes on the {cores} host cores ({"one per core" if len(many) == cores else "fewer than cores: bounded by free memory / OPFX_BENCH_CPU_PROCS"}); '
+                       f'pandapower itself is not installed')
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -241,7 +312,10 @@ def main():
 
     # the gathers run behind the next step's kernel (opfgym_amd.dist.OverlappedGather): the full batch of step k is
     # available while step k+1 is simulated, as a learner consumes it; the last one is collected after the loop
-    g_reward, g_obs = odist.OverlappedGather(world), odist.OverlappedGather(world)
+    # (strong-scaling configs on a world size that does not divide the batch give ragged shards: padded and trimmed)
+    sizes = [odist.shard_bounds(total_B, r, world)[1] - odist.shard_bounds(total_B, r, world)[0] for r in range(world)] \
+        if (args.batch is None and scaling == 'strong') else None
+    g_reward, g_obs = odist.OverlappedGather(world, sizes), odist.OverlappedGather(world, sizes)
 
     def one_step():
         obs, reward, term, trunc, info = env.step(actions)
@@ -256,9 +330,14 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    # HIP events on the launch stream (torch's current stream: capi._stream()) around the SAME timed region: the device
+    # time of the K back-to-back launches, from which the kernel's average duration is taken
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         info = one_step()
+    ev1.record()
     if world > 1 and gather:                   # the last step's gather belongs to the timed region
         g_reward.flush()
         if 'obs' in gather:
@@ -267,6 +346,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64,
                           device=device if dist.get_backend() == 'nccl' else 'cpu')
@@ -278,7 +358,7 @@ def main():
     mean_it_base = float(info['iterations'].double().mean().item())
     min_pivot = float(info['min_pivot'].min().item())
 
-    # kernel duration: HIP events on the launch stream around back-to-back launches
+    # cross-check: the C ABI's own helper (hipEvents around `reps` launches with nothing else on the stream)
     io = env._io(actions, False)
     ms = capi.C.c_float()
     reps = max(5, min(args.steps, 50))
@@ -286,7 +366,7 @@ def main():
         capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io),
                                               capi.C.byref(env.solve_opts), reps,
                                               capi._stream(), capi.C.byref(ms)), 'opfx_time_steps')
-    kernel_ms = ms.value / reps
+    kernel_ms_helper = ms.value / reps
 
     # the cycle of a single-step benchmark environment: reset (device-side sampling) + step
     n_cyc = max(3, min(args.steps, 20))
@@ -302,21 +382,47 @@ def main():
     cycle_ms = (time.perf_counter() - t1) / n_cyc * 1e3
 
     if rank == 0:
-        team, lds, per_cu = capi.C.c_int32(), capi.C.c_int64(), capi.C.c_int32()
-        capi.check(capi.lib().opfx_env_get_info(env._env_handle, capi.C.byref(team), capi.C.byref(lds), capi.C.byref(per_cu)))
+        ki = env.kernel_info()
+        team = ki['waves_per_instance']
         bm = byte_model(env, mean_it_total / solves_per_step, solves_per_step)
-        achieved = bm['B_step'] * B / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate
-        # runs of this same script, see profiles/README.md) — not measurable in-process
-        traffic = traffic_raw = None
-        pmc_file = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-        if os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            ent = pmc.get(f'config{args.config}', pmc if args.config == 2 and 'hbm_bytes_per_launch_fetch_x2' in pmc else None)
-            if ent and ent.get('batch', 8192) == B:
-                traffic = ent['hbm_bytes_per_launch_fetch_x2']
-                traffic_raw = ent['hbm_bytes_per_launch_raw']
-        kernel_name = f'k_step<{"2" if env.plan.info["n_full"] < env.plan.info["n_blk"] else "1"}|1,{team.value}>'
+        lm = lds_model(env, mean_it_total / solves_per_step, solves_per_step, team)
+        kernel_s = kernel_ms * 1e-3
+        props = torch.cuda.get_device_properties(device)
+        n_cu = int(props.multi_processor_count)
+        n_simd, n_xcd = 4 * n_cu, 8
+        algorithmic = bm['B_step'] * B / kernel_s / 1e9              # GB/s, SURVEY §8d model
+        # ---- what the committed rocprofv3 passes of this configuration measured (profiles/pmc_latest.json) ----
+        pm = measured_counters(args.config, B)
+        sq = pm.get('sq', {})
+        traffic, traffic_raw = pm.get('hbm_bytes_per_launch_fetch_x2'), pm.get('hbm_bytes_per_launch_raw')
+        cycles = sq['GRBM_GUI_ACTIVE'] / n_xcd if 'GRBM_GUI_ACTIVE' in sq else None      # kernel duration in GPU clocks
+        fr = {}
+        if traffic is not None:
+            # HBM: measured bytes of the profiled launch / its own duration (the profile's, so both from one run)
+            prof_s = pm.get('kernel_avg_ns', kernel_ms * 1e6) * 1e-9
+            fr['hbm'] = dict(achieved=traffic / prof_s / 1e9, peak=8000.0, unit='GB/s')
+        if cycles:
+            # SQ_ACTIVE_INST_VALU counts in units of 4 cycles (quad-cycles), per SIMD; SQ_LDS_IDX_ACTIVE in LDS-array
+            # cycles, per CU (MI355X_MICROARCH.md, LDS section; VERDICT r02 recomputation)
+            fr['valu_issue'] = dict(achieved=sq['SQ_ACTIVE_INST_VALU'] * 4 / (n_simd * cycles), peak=1.0,
+                                    unit='fraction of SIMD cycles with a vector instruction in issue')
+            fr['lds_array'] = dict(achieved=sq['SQ_LDS_IDX_ACTIVE'] / (n_cu * cycles), peak=1.0,
+                                   unit='fraction of LDS-array cycles busy',
+                                   bank_conflict_share=sq.get('SQ_LDS_BANK_CONFLICT', 0.0) / sq['SQ_LDS_IDX_ACTIVE'])
+        for v in fr.values():
+            v['frac'] = v['achieved'] / v['peak']
+        # LDS bytes from the plan (live) against the guide's aggregate ds_read_b64 rate
+        lds_rate = lm['bytes_per_step'] * B / kernel_s / 1e12
+        fr['lds_bytes'] = dict(achieved=lds_rate, peak=150.0, unit='TB/s', frac=lds_rate / 150.0,
+                               bytes_per_launch=lm['bytes_per_step'] * B,
+                               wave_instructions_per_launch_model=lm['lds_wave_instructions_per_step'] * B,
+                               wave_instructions_per_launch_measured=sq.get('SQ_INSTS_LDS'))
+        fp64 = bm['fp64_flops_per_step'] * B / kernel_s / 1e12
+        fr['fp64_vector'] = dict(achieved=fp64, peak=78.6, unit='TFLOP/s', frac=fp64 / 78.6)
+        # the binding resource: the largest fraction of its own peak (none of them can exceed 1)
+        cand = {k: v['frac'] for k, v in fr.items()}
+        bound = max(cand, key=cand.get)
+        kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}>'
         # what the launch really has to read and write: the instance rows of the caller's buffers
         buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
                      'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
@@ -339,22 +445,31 @@ def main():
                        'nr_solves_per_s': total_B * solves_per_step * args.steps / elapsed,
                        'reset_plus_step_ms': cycle_ms, 'episodes_per_s_reset_plus_step': B * world / (cycle_ms * 1e-3),
                        'min_relative_pivot': min_pivot,
-                       'tolerance_pu': env.solve_opts.tol, 'byte_model': bm,
-                       'kernel_launch': {'waves_per_instance': team.value, 'lds_bytes_per_instance': lds.value,
-                                         'instances_per_cu': per_cu.value}},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
-                         'traffic_raw_counters': traffic_raw,
-                         'algorithmic_bytes_per_launch': bm['B_step'] * B,
-                         'compulsory_io_bytes_per_launch': bm['io_bytes'] * B,
-                         'buffer_io_bytes_per_launch': buffer_io,
-                         'kernel': kernel_name, 'kernel_ms': kernel_ms,
-                         'fp64_tflops_achieved': bm['fp64_flops_per_step'] * B / (kernel_ms * 1e-3) / 1e12,
-                         'fp64_vector_peak_tflops': 78.6,
-                         'note': 'achieved = SURVEY §8d algorithmic bytes (state streamed through memory once per NR '
-                                 'phase) x instances per launch / kernel time; the kernel keeps that state in LDS, so '
-                                 'real HBM traffic is ~ io_bytes per instance (`traffic`); what bounds the kernel is a '
-                                 'wave\'s own issue / LDS-return rate (profiles/*_sq_counters.txt, DESIGN.md)'},
+                       'tolerance_pu': env.solve_opts.tol, 'byte_model': bm, 'lds_model': lm,
+                       'kernel_launch': {k: ki[k] for k in ('waves_per_instance', 'lds_bytes_per_instance', 'instances_per_cu')},
+                       'device': {'compute_units': n_cu, 'simds': n_simd}},
+            'roofline': {
+                'bound': bound, 'achieved': fr[bound]['achieved'], 'peak': fr[bound]['peak'], 'unit': fr[bound]['unit'],
+                'frac': fr[bound]['frac'],
+                'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_raw_counters': traffic_raw,
+                'kernel': kernel_name, 'kernel_ms': kernel_ms, 'kernel_ms_source': 'HIP events on the launch stream around the timed region / steps',
+                'kernel_ms_back_to_back_helper': kernel_ms_helper,
+                'resources': fr,
+                'hbm_measured_frac': fr['hbm']['frac'] if 'hbm' in fr else None,
+                # SURVEY §8d's figure, kept with unchanged arithmetic: the bytes a memory-streaming Newton solver would
+                # move, divided by this kernel's time.  It is NOT a fraction of anything this kernel saturates (the
+                # iteration state lives in LDS) and may exceed 1
+                'algorithmic_equiv': {'achieved': algorithmic, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algorithmic / 8000.0,
+                                      'algorithmic_bytes_per_launch': bm['B_step'] * B,
+                                      'compulsory_io_bytes_per_launch': bm['io_bytes'] * B},
+                'buffer_io_bytes_per_launch': buffer_io,
+                'counters_from': pm.get('tag'),
+                'note': 'bound = the resource with the largest fraction of its own peak.  hbm / valu_issue / lds_array come '
+                        'from the committed rocprofv3 passes of this configuration (profiles/pmc_latest.json <- '
+                        'scripts/profile_round.sh; recompute from profiles/<tag>_sq_counters.txt: VALU = '
+                        'SQ_ACTIVE_INST_VALU*4 / (SIMDs * GRBM_GUI_ACTIVE/8), LDS = SQ_LDS_IDX_ACTIVE / (CUs * '
+                        'GRBM_GUI_ACTIVE/8)); lds_bytes, fp64_vector and algorithmic_equiv are computed live from the plan '
+                        'and this run\'s kernel time'},
         }
         # timed after the GPU work, in child processes (one, then one per host core)
         out['cpu_baseline'] = cpu_baseline(args.config) if (world == 1 and not args.no_cpu_baseline) else None

@@ -394,10 +394,13 @@ typedef struct opfx_profile_desc {
  *   OPFX_OP_DIV         x[dst] = x[a] / c0                        (load_shedding.py:137)
  *   OPFX_OP_NORMINV     x[dst] = c0 + c1*Phi^-1(x[a])   (truncated normal by inverse CDF, opf_env.py:306-309:
  *                       x[a] holds a probability drawn uniformly between Phi(lower) and Phi(upper))
+ *   OPFX_OP_TRUNCNORM   x[dst] = ppf of the standard normal truncated to [c0, c1] at the probability x[a] — what
+ *                       scipy.stats.truncnorm.ppf(x[a], c0, c1) returns, evaluated in log space so that bounds far
+ *                       out in one tail (the reference passes raw MW values as standardised bounds) stay finite
  */
 enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
        OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6,
-       OPFX_OP_DIV = 7, OPFX_OP_NORMINV = 8 };
+       OPFX_OP_DIV = 7, OPFX_OP_NORMINV = 8, OPFX_OP_TRUNCNORM = 9 };
 typedef struct opfx_reset_desc {
   int32_t n_tables;
   const opfx_profile_desc* tables;
@@ -473,6 +476,12 @@ int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
  * (0 until the first opfx_step has queried the occupancy).  Any out pointer may be NULL. */
 int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
                       int32_t* instances_per_cu);
+
+/* Block storage the environment's kernels run with (report/diagnostics): LU blocks in all, and how many of them
+ * are stored with four values (the rest keep the two values (a, b) of [[a, b], [-b, a]], see opfx_plan_info.n_full;
+ * equal to n_blk when the two-value form is not used: it is chosen only where the LDS it saves lets a CU hold more
+ * instances).  Any out pointer may be NULL. */
+int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t* n_four_value);
 
 #ifdef __cplusplus
 }

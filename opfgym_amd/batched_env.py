@@ -151,14 +151,16 @@ def _truncated_normal(ops, table, col, idxs, mean, scale, a, b):
     scipy reads its first two arguments as STANDARDISED bounds, so what the reference samples is
     mean + scale * Z with Z standard normal truncated to [min_values, max_values] (the raw numbers; defect
     D14, reproduced).  scipy draws from its own generator, which cannot be replayed; here Z comes from the
-    instance's uniform draw u by inverse CDF: Phi^-1(Phi(a) + u (Phi(b) - Phi(a)))."""
-    import math
-    phi = np.vectorize(lambda x_: 0.5 * math.erfc(-x_ / math.sqrt(2.0)))
-    pa, pb = phi(np.asarray(a, dtype=float)), phi(np.asarray(b, dtype=float))
-    ops.uniform(table, col, idxs, pa, pb, 1.0)                 # the probability, into the column itself
+    instance's uniform draw u by the inverse CDF scipy itself applies to its uniforms, `truncnorm.ppf(u, a, b)`,
+    as a device op that works in log space (OPFX_OP_TRUNCNORM): bounds like [10, 200] — every unit above ~8 MW —
+    lie so far in the upper tail that Phi(a) == Phi(b) == 1.0 in double precision, and the plain
+    Phi^-1(Phi(a) + u (Phi(b) - Phi(a))) returns +inf there."""
+    n = len(np.asarray(a, dtype=float))
+    ops.uniform(table, col, idxs, np.zeros(n), np.ones(n), 1.0)      # u itself, into the column
     rows = ops.store.rows(table, idxs)
     dst = ops._all(table, col, rows, True)
-    ops._emit(capi.OP_NORMINV, dst, dst, c0=mean, c1=scale)
+    ops._emit(capi.OP_TRUNCNORM, dst, dst, c0=np.asarray(a, dtype=float), c1=np.asarray(b, dtype=float))
+    ops._emit(capi.OP_AFFINE, dst, dst, c0=np.asarray(scale, dtype=float), c1=np.asarray(mean, dtype=float))
 
 
 def _normal_and_clip(ops, table, col, idxs, mean, std, lo, hi):
@@ -441,13 +443,17 @@ class BatchedOpfEnv:
         kind = type('FromReference' + type(ref_env).__name__, (base,),
                     {'_sampling_ops': (lambda self, ops: sampling_ops(self, ops)) if sampling_ops else base._sampling_ops})
         rf = ref_env.reward_function
-        prf = reward_mod.load_reward_class(type(rf).__name__)(**({} if type(rf).__name__ == 'OnlyObjective' else
-                                                              {'penalty_weight': rf.penalty_weight}))
-        prf.clip_range = getattr(rf, 'clip_range', None)
-        prf.scaling_params = dict(rf.scaling_params)
-        for attr in ('valid_reward', 'invalid_penalty', 'invalid_objective_share'):
-            if hasattr(rf, attr):
-                setattr(prf, attr, getattr(rf, attr))
+        if type(rf).__name__ in ('Summation', 'Replacement', 'Parameterized', 'OnlyObjective') \
+                and type(rf).__module__.startswith('opfgym.'):
+            prf = reward_mod.load_reward_class(type(rf).__name__)(**({} if type(rf).__name__ == 'OnlyObjective' else
+                                                                  {'penalty_weight': rf.penalty_weight}))
+            prf.clip_range = getattr(rf, 'clip_range', None)
+            prf.scaling_params = dict(rf.scaling_params)
+            for attr in ('valid_reward', 'invalid_penalty', 'invalid_objective_share'):
+                if hasattr(rf, attr):
+                    setattr(prf, attr, getattr(rf, attr))
+        else:
+            prf = rf          # a user's own reward class: evaluated on the host with the object itself (reward.SEAMS)
         cons = []
         for c_ in ref_env.constraints:
             twin = getattr(constraints_mod, type(c_).__name__, None)
@@ -888,6 +894,7 @@ class BatchedOpfEnv:
         d.nx = st.n
         d.pinj_ptr, d.pinj_slot, d.pinj_coef = _keep(keep, pp_, 'i'), _keep(keep, ps_, 'i'), _keep(keep, pc_, 'd')
         d.qinj_ptr, d.qinj_slot, d.qinj_coef = _keep(keep, qp_, 'i'), _keep(keep, qs_, 'i'), _keep(keep, qc_, 'd')
+        self.n_inj = int(len(ps_) + len(qs_))
         d.qg_min, d.qg_max = _keep(keep, qg_lo, 'd'), _keep(keep, qg_hi, 'd')
         d.na = na
         d.act_slot, d.act_scaling = _keep(keep, a_slot, 'i'), _keep(keep, a_sc, 'd')
@@ -910,7 +917,13 @@ class BatchedOpfEnv:
         d.con_autoscale, d.con_penalty_factor = _keep(keep, c_as, 'd'), _keep(keep, c_pf, 'd')
         d.con_penalty_power, d.con_count_penalty = _keep(keep, c_pp, 'd'), _keep(keep, c_cp, 'd')
         d.con_worst_case = _keep(keep, c_wc, 'i')
-        rf = self.reward_function
+        # a reward object that overrides one of the reference's extension points (adjust_objective, ...) or is not one
+        # of this package's classes cannot be expressed as kernel parameters: the kernel then computes a plain
+        # summation (unused) and the host finishes the reward with the user's object (host_fallback.py)
+        self.host_reward = not reward_mod.runs_on_device(self.reward_function)
+        if self.host_reward:
+            reward_mod.check_host_reward(self.reward_function)
+        rf = reward_mod.Summation() if self.host_reward else self.reward_function
         d.reward_kind = rf.KIND
         d.penalty_weight = np.nan if rf.penalty_weight is None else float(rf.penalty_weight)
         d.clip_lo, d.clip_hi = (np.nan, np.nan) if not rf.clip_range else map(float, rf.clip_range)
@@ -973,7 +986,7 @@ class BatchedOpfEnv:
         self.n_constraints = len(self.constraints)
         self.n_device_constraints = len(self.device_constraints)
         self._host_finisher = None
-        if self.host_mode:
+        if self.host_mode or self.host_reward:
             from .host_fallback import HostFinisher
             self._host_finisher = HostFinisher(self, self.host_objective, self._host_constraints, self._constraint_order)
         self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses) + len(self._xres)
@@ -1218,7 +1231,7 @@ class BatchedOpfEnv:
         if self.pf_for_obs:                                                # :209-216
             self._launch_step(act, mode=4, with_initial_obj=False)
             if self._host_finisher is not None:
-                self._host_finisher.finish(4)
+                self._last_host = self._host_finisher.finish(4)
             self.initial_obj.copy_(self.buf['objective'])
 
     def _profile_draws(self, data_distr, options, as_dev):
@@ -1351,7 +1364,9 @@ class BatchedOpfEnv:
     def is_state_valid(self):
         """opf_env.py:613-618 for the batch: no constraint violated (and the power flow converged), [B] bool."""
         self.ensure_power_flow_available()
-        valids = self._last_host['valids'] if self._last_host is not None else self.buf['valids'][:, :max(1, self.n_device_constraints)]
+        # (no constraints at all: an empty all() is True, as in the reference)
+        valids = self._last_host['valids'][:, :self.n_constraints] if self._last_host is not None \
+            else self.buf['valids'][:, :self.n_device_constraints]
         return valids.all(dim=1) & self.buf['converged']
 
     def get_objective(self):
@@ -1442,6 +1457,15 @@ class BatchedOpfEnv:
         finally:
             self.B, self.x, self.buf, self.initial_obj, self.step_count, self.steps_dev, self._center_action = old
         return obj, pen
+
+    def kernel_info(self) -> dict:
+        """Launch configuration of the fused step kernel (report / diagnostics): wavefronts per instance, LDS bytes per
+        instance, instances resident per CU (0 before the first step) and whether the two-value block storage is used."""
+        team, lds, per_cu, nblk, nfour = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(capi.lib().opfx_env_get_info(self._env_handle, C.byref(team), C.byref(lds), C.byref(per_cu)), 'opfx_env_get_info')
+        capi.check(capi.lib().opfx_env_get_storage(self._env_handle, C.byref(nblk), C.byref(nfour)), 'opfx_env_get_storage')
+        return dict(waves_per_instance=team.value, lds_bytes_per_instance=lds.value, instances_per_cu=per_cu.value,
+                    packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value)
 
     def close(self):
         if self._env_handle is not None:

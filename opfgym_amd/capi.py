@@ -21,7 +21,7 @@ PQ, PV, REF = 1, 2, 3
 SRC_X, SRC_RESULT = 0, 1
 COST_UNIT, COST_EXT_GRID, COST_GEN = 0, 1, 2
 REWARD_SUMMATION, REWARD_REPLACEMENT, REWARD_PARAMETERIZED, REWARD_ONLY_OBJECTIVE = 0, 1, 2, 3
-OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, OP_DIV, OP_NORMINV = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, OP_DIV, OP_NORMINV, OP_TRUNCNORM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
@@ -140,7 +140,7 @@ _lib = None
 EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_plan_get_array',
            'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
-           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info']
+           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info', 'opfx_env_get_storage']
 
 
 def lib():
@@ -183,6 +183,7 @@ def lib():
     L.opfx_time_steps.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32,
                                   vp, C.POINTER(C.c_float)]
     L.opfx_env_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.opfx_env_get_storage.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _lib = L
     return L
 

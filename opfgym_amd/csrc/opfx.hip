@@ -2125,6 +2125,38 @@ struct ResetIO {
   int* step_out;
 };
 
+// Standard normal truncated to [a, b], by inverse CDF of a uniform draw u — what scipy.stats.truncnorm.ppf(u, a, b)
+// computes, in log space so that bounds far out in a tail work (opf_env.py:306-309 hands scipy the raw MW bounds as
+// STANDARDISED ones, defect D14: a unit between 50 and 300 MW is "50 to 300 sigma"; Phi(50) == 1.0 in double).
+//   log Phi(t): erfcx form in the lower tail;  a > 0: mirrored problem (-b, -a), 1 - u, result negated;
+//   log P = log Phi(b) + log(r + u (1 - r)),  r = Phi(a) / Phi(b);  z = (log Phi)^-1(log P): normcdfinv where P is
+//   representable (through 1 - P next to 1), Newton on log Phi below that (d/dz log Phi = phi / Phi = sqrt(2/pi) / erfcx(-z / sqrt 2)).
+__device__ double log_ndtr(double t) {
+  const double s = t * 0.70710678118654752440;
+  return t < 0.0 ? log(0.5 * erfcx(-s)) - s * s : log1p(-0.5 * erfc(s));
+}
+__device__ double ndtri_log(double lp) {
+  if (lp > -0.69314718055994531) return -normcdfinv(-expm1(lp));
+  if (lp > -600.0) return normcdfinv(exp(lp));
+  double z = -sqrt(-2.0 * lp);
+  for (int k = 0; k < 6; ++k) {
+    const double f = log_ndtr(z) - lp;
+    const double d = 0.79788456080286535588 / erfcx(-z * 0.70710678118654752440);
+    z -= f / d;
+  }
+  return z;
+}
+__device__ double truncnorm_ppf(double u, double a, double b) {
+  const bool flip = a > 0.0;
+  const double lo = flip ? -b : a, hi = flip ? -a : b;
+  const double q = flip ? 1.0 - u : u;
+  const double lhi = log_ndtr(hi);
+  const double r = exp(log_ndtr(lo) - lhi);
+  double z = ndtri_log(lhi + log(r + q * (1.0 - r)));
+  z = fmin(fmax(z, lo), hi);
+  return flip ? -z : z;
+}
+
 // One wavefront per instance; the row is built in LDS (template -> profile values -> vector-op
 // programme -> optionally the initial action and the table observation, opf_env.py:201-207,218)
 // and leaves with one coalesced store: the intermediate values never make a round trip through
@@ -2242,6 +2274,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
           else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
           else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
           else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
+          else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
           else v = rv[u] / k0[u];
           if (j < n) row[dst + j] = v;
         }
@@ -2820,6 +2853,13 @@ extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instanc
   if (waves_per_instance) *waves_per_instance = pick_team(env->lds_bytes, env->ctx->v2);
   if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
   if (instances_per_cu) *instances_per_cu = env->per_cu;
+  return OPFX_OK;
+}
+
+extern "C" int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t* n_four_value) {
+  if (!env) { opfx_set_error("opfx_env_get_storage: null environment"); return OPFX_ERR_INVALID; }
+  if (n_blk) *n_blk = env->ctx->plan.n_blk;
+  if (n_four_value) *n_four_value = env->ctx->v2 ? env->n_full : env->ctx->plan.n_blk;
   return OPFX_OK;
 }
 

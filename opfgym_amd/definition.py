@@ -3,16 +3,18 @@
 What an OPF environment IS — which units are controllable, their limit columns, the cost tables, the
 action / observation / state keys — is written down once, in the reference's environment classes
 (`opfgym/envs/*.py`, `opfgym/examples/*.py`: `_define_opf` and the key lists of `__init__`).  This package does
-not restate that code.  A batched environment gets its definition in one of two ways:
+not restate that code line by line.  A batched environment gets its definition in one of three ways:
 
   * from a LIVE reference environment: `BatchedOpfEnv.from_reference(ref_env, ...)` / `extract(ref_env)` read
     the constructed object (`ref_env.net`, `.act_keys`, `.obs_keys`, `.state_keys`, `.profiles`, ...);
     `resolve()` builds that object itself when `opfgym` (with pandapower and simbench) is importable;
+  * from the NATIVE builder (`opfgym_amd/native_definition.py`): the benchmark classes as rule tables run by one
+    interpreter, parameterised by the constructor arguments, on the synthetic stand-in grids — the fallback when
+    `opfgym` is not importable (the GPU box);
   * from a recorded definition: a small `.npz` holding exactly that data (element tables, key lists, the
     surviving profile columns), written by `tests/golden/make_definitions.py` from the reference's own classes.
-    The files under `opfgym_amd/definitions/` cover the synthetic stand-in grids of the BASELINE
-    configurations and of the test scenarios, so the package works where the reference is not installed
-    (the GPU box).
+    The files under `opfgym_amd/definitions/` are (a) the regression fixtures the native builder is tested against
+    and (b) the definitions of the reference's EXAMPLE classes, which have no native recipe.
 
 Only what genuinely has to be re-expressed for the device stays in `envs.py`: the per-reset `_sampling` tails
 as vector ops of the reset kernel.
@@ -245,12 +247,18 @@ def resolve(ref_path: str, class_kwargs: dict, grid_seed=0, prepare=None) -> Def
     if cls is not None:
         from . import simbench_build
         return build_from_reference(cls, class_kwargs, getattr(simbench_build, prepare) if prepare else None)
+    from . import native_definition, simbench_build
+    if native_definition.has_recipe(ref_path) and not os.environ.get('OPFX_RECORDED_DEFINITIONS'):
+        # the native, parameterised builder (rule tables of opfgym_amd/native_definition.py): any constructor
+        # arguments, on the synthetic stand-in grids.  (OPFX_RECORDED_DEFINITIONS=1: the recorded files instead.)
+        return native_definition.build(ref_path, class_kwargs, grid_seed,
+                                       getattr(simbench_build, prepare) if prepare else None)
     key = request_key(ref_path, class_kwargs, grid_seed, prepare)
     idx = _index()
     if key not in idx:
         raise ImportError(
-            f'{ref_path}({class_kwargs}) is defined by the reference package `opfgym`, which is not importable here, '
-            f'and no recorded definition exists for these arguments (opfgym_amd/definitions/index.json).  Install '
-            f'opfgym, or record one with tests/golden/make_definitions.py, or build the environment from your own '
-            f'net and keys with BatchedOpfEnv(net, action_keys, observation_keys, ...).')
+            f'{ref_path}({class_kwargs}) is defined by the reference package `opfgym`, which is not importable here; '
+            f'it has no native recipe (opfgym_amd/native_definition.py) and no recorded definition for these arguments '
+            f'(opfgym_amd/definitions/index.json).  Install opfgym, or record one with tests/golden/make_definitions.py, '
+            f'or build the environment from your own net and keys with BatchedOpfEnv(net, action_keys, observation_keys, ...).')
     return load(os.path.join(DEF_DIR, idx[key]))

@@ -68,16 +68,44 @@ def all_gather_rows(local, world: int, sizes=None):
 
 
 class OverlappedGather:
-    """The per-step all-gather of one output (equal shards) WITHOUT stalling the producer: the local rows are
-    copied into one of two staging buffers and gathered asynchronously — on RCCL's own stream, behind the copy —
-    while the next step's kernel already runs; `submit` hands back the full-batch tensor of the PREVIOUS step
-    (complete by then), `flush` the last one.  A learner consumes step k's batch while step k+1 is simulated, which
-    is how the gather comes off the critical path (a blocking gather would add its latency to every step:
-    ~10 % at 0.27 ms per step)."""
+    """The per-step all-gather of one output WITHOUT stalling the producer: the local rows are copied into one of
+    two staging buffers and gathered asynchronously — on RCCL's own stream, behind the copy — while the next step's
+    kernel already runs; `submit` hands back the full-batch tensor of the PREVIOUS step (complete by then), `flush`
+    the last one.  A learner consumes step k's batch while step k+1 is simulated, which is how the gather comes off
+    the critical path (a blocking gather would add its latency to every step: ~10 % at 0.27 ms per step).
 
-    def __init__(self, world: int):
-        self.world = world
+    `sizes`: rows per rank when the shards are ragged (`shard_bounds` with a batch the world size does not divide,
+    e.g. 65 536 instances on 3, 6 or 7 GPUs): every rank then stages a shard padded to the largest one — the
+    collective needs equal counts — and the padding rows are cut out on hand-over.
+
+    LIFETIME of what `submit` / `flush` return: with equal shards it is one of the two persistent gather buffers and
+    is overwritten by the submit after next (use it before, or pass `clone=True`); with ragged shards it is a fresh
+    tensor (the trim copies)."""
+
+    def __init__(self, world: int, sizes=None, clone: bool = False):
+        self.world, self.clone = world, clone
+        self.sizes = None if sizes is None or len(set(sizes)) == 1 else [int(v) for v in sizes]
+        if self.sizes is not None and len(self.sizes) != world:
+            raise ValueError(f'OverlappedGather: {len(self.sizes)} shard sizes for a world of {world}')
         self._stage, self._out, self._work, self._k = [None, None], [None, None], [None, None], 0
+
+    def _rows(self, local):
+        import torch.distributed as dist
+        if self.sizes is None:
+            return local.shape[0]
+        mine = self.sizes[dist.get_rank()]
+        if local.shape[0] != mine:
+            raise ValueError(f'OverlappedGather: rank {dist.get_rank()} submitted {local.shape[0]} rows, its shard has {mine}')
+        return max(self.sizes)
+
+    def _hand_over(self, out):
+        import torch
+        if out is None:
+            return None
+        if self.sizes is not None:
+            m = max(self.sizes)
+            return torch.cat([out[r * m:r * m + self.sizes[r]] for r in range(self.world)], dim=0)
+        return out.clone() if self.clone else out
 
     def submit(self, local):
         import torch
@@ -85,22 +113,23 @@ class OverlappedGather:
         if self.world == 1 or not dist.is_initialized():
             return local
         if local.is_cuda and dist.get_backend() == 'gloo':        # (debugging aid: ranks sharing one GPU)
-            prev, self._last = getattr(self, '_last', None), all_gather_rows(local, self.world)
+            prev, self._last = getattr(self, '_last', None), all_gather_rows(local, self.world, self.sizes)
             return prev
         slot, other = self._k & 1, (self._k & 1) ^ 1
         self._k += 1
+        m = self._rows(local)
         if self._stage[slot] is None:
-            self._stage[slot] = torch.empty_like(local)
-            self._out[slot] = torch.empty((local.shape[0] * self.world,) + tuple(local.shape[1:]), dtype=local.dtype,
+            self._stage[slot] = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            self._out[slot] = torch.empty((m * self.world,) + tuple(local.shape[1:]), dtype=local.dtype,
                                           device=local.device)
         if self._work[slot] is not None:
             self._work[slot].wait()                            # (two steps old: long finished)
-        self._stage[slot].copy_(local)
+        self._stage[slot][:local.shape[0]].copy_(local)
         self._work[slot] = dist.all_gather_into_tensor(self._out[slot], self._stage[slot], async_op=True)
         if self._work[other] is None:
             return None
         self._work[other].wait()
-        return self._out[other]
+        return self._hand_over(self._out[other])
 
     def flush(self):
         """The full-batch tensor of the last submitted step."""
@@ -113,7 +142,7 @@ class OverlappedGather:
         if self._k == 0 or self._work[slot] is None:
             return None
         self._work[slot].wait()
-        return self._out[slot]
+        return self._hand_over(self._out[slot])
 
 
 class ShardedBatch:

@@ -4,8 +4,10 @@ The PROBLEM DEFINITIONS of these environments — which units are controllable, 
 action / observation / state keys — are the reference's: `opfgym/envs/*.py` and `opfgym/examples/*.py`.
 They are not restated here.  Each class names the reference class it stands for (`REFERENCE`) and obtains the
 definition through `opfgym_amd.definition.resolve`: from the live reference class when `opfgym` is importable,
-otherwise from the recorded definition for exactly these constructor arguments
-(`opfgym_amd/definitions/`, written by `tests/golden/make_definitions.py` from the reference's own classes).
+otherwise from the native, parameterised rule tables of `opfgym_amd/native_definition.py` (the benchmark classes; any
+constructor arguments) or, for the example classes, from the recorded definition for exactly these arguments
+(`opfgym_amd/definitions/`, written by `tests/golden/make_definitions.py` from the reference's own classes — also the
+regression fixtures of the native builder).
 
 What this file does hold is what cannot be taken over as data: the constructor signatures (the API a user of
 the reference expects) and the per-reset `_sampling` tails of the reference classes re-expressed as vector ops

@@ -108,7 +108,9 @@ class RewardFunction:
         return objective, penalty
 
     def __call__(self, objective, penalty, valid):
-        objective, penalty = self._shifted(objective, penalty, valid)
+        # through the two extension points of the reference (reward.py:61-66: its abstract `adjust_objective` /
+        # `adjust_penalty`), so that a user subclass overriding them is honoured on the host path
+        objective, penalty = self.adjust_objective(objective, valid), self.adjust_penalty(penalty, valid)
         reward = self.compute_total_reward(self.scale_objective(objective), self.scale_penalty(penalty))
         return self.clip_reward(reward) if self.clip_range else reward
 
@@ -181,6 +183,29 @@ class OnlyObjective(RewardFunction):
 
     def __init__(self, **kwargs):
         super().__init__(penalty_weight=0.0, **kwargs)
+
+
+#: the methods a user may override (reward.py:61-104).  The fused kernel evaluates the four built-in kinds from their
+#: parameters; a reward object that overrides any of these — or that is not a `RewardFunction` of this module at
+#: all, e.g. a subclass of the reference's abstract class — is evaluated on the HOST after the launch
+#: (opfgym_amd/host_fallback.py), from the objective / penalties / validity the kernel computed.
+SEAMS = ('__call__', 'adjust_objective', 'adjust_penalty', 'scale_objective', 'scale_penalty', 'compute_total_reward',
+         'clip_reward', 'calculate_cost', '_shifted')
+
+
+def runs_on_device(rf) -> bool:
+    """True when `rf` is fully described by KIND + its parameters (what opfx_env_desc.reward_* carries)."""
+    if not isinstance(rf, RewardFunction) or rf.KIND not in (SUMMATION, REPLACEMENT, PARAMETERIZED, ONLY_OBJECTIVE):
+        return False
+    return all(getattr(type(rf), m) is getattr(RewardFunction, m) for m in SEAMS)
+
+
+def check_host_reward(rf) -> None:
+    """What the host path needs of a foreign reward object (the reference's interface, reward.py:61-104)."""
+    missing = [m for m in ('__call__', 'calculate_cost') if not callable(getattr(rf, m, None))]
+    if missing:
+        raise TypeError(f'reward_function {type(rf).__name__}: needs {missing} (the interface of opfgym.RewardFunction: '
+                        f'__call__(objective, penalty, valid) and calculate_cost(penalty, valid))')
 
 
 def load_reward_class(name: str):

@@ -31,11 +31,11 @@ def gens_to_fixed_sgens(net, profiles):
     net.sgen['bus'] = net.sgen['bus'].astype(np.int64)
     net.sgen['in_service'] = net.sgen['in_service'].astype(bool)
     # limit / mean / std columns follow the profiles: recomputed by the reference's own function where the
-    # reference is at hand (recording a definition); a recorded definition already carries them
+    # reference is at hand (recording a definition), by the native grid preparation otherwise
     try:
         from opfgym.simbench.build_simbench_net import set_constraints_from_profiles
     except Exception:
-        return net, profiles
+        from .native_definition import ranges_from_profiles as set_constraints_from_profiles
     if 'scaling' in net.sgen.columns and 'scaling' in net.load.columns and 'scaling' in net.storage.columns:
         set_constraints_from_profiles(net, profiles)
     return net, profiles

@@ -45,9 +45,22 @@ with open(out + '/sq_counters.txt', 'w') as fh:
     for k in sorted(mean):
         if k not in ('FETCH_SIZE', 'WRITE_SIZE'):
             fh.write('%-28s %16.0f  (n=%d)\n' % (k, mean[k], len(acc[k])))
+avg_ns, calls = None, None
+if st:
+    for r in csv.DictReader(open(st[0])):
+        if 'k_step' in r.get('Name', ''):
+            avg_ns, calls = float(r['AverageNs']), int(r['Calls'])
+batch = None
+try:
+    line = [ln for ln in open(out + '/trace.log') if ln.startswith('{')][-1]
+    batch = json.loads(line)['config']['batch_per_gpu']
+except Exception:
+    pass
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     fk, wk = mean['FETCH_SIZE'], mean['WRITE_SIZE']
-    json.dump({'kernel': name, 'tag': tag, 'config': int(cfg),
+    json.dump({'kernel': name, 'tag': tag, 'config': int(cfg), 'batch': batch,
+               'kernel_avg_ns': avg_ns, 'kernel_calls': calls,
+               'sq': {k: v for k, v in mean.items() if k not in ('FETCH_SIZE', 'WRITE_SIZE')},
                'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --config %s --steps %s --warmup 2 --no-cpu-baseline (one pass per counter)' % (cfg, psteps),
                'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk,
                'FETCH_SIZE_launches': len(acc['FETCH_SIZE']), 'WRITE_SIZE_launches': len(acc['WRITE_SIZE']),

@@ -34,8 +34,10 @@ def test_every_recorded_definition_loads():
 def test_unrecorded_arguments_fail_loudly_without_the_reference():
     if definition.reference_class('opfgym.envs.VoltageControl') is not None:
         pytest.skip('the reference is importable here')
+    # (classes with a native recipe — the five benchmark environments — build for any arguments,
+    #  tests/test_native_definition.py; the example classes exist as recorded definitions only)
     with pytest.raises(ImportError, match='no recorded definition'):
-        envs.VoltageControl(simbench_network_name='mv-small', cos_phi=0.5, batch_size=1, defer_device=True)
+        envs.MultiStageOpf(simbench_network_name='mv-small', batch_size=1, defer_device=True)
 
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason='needs /root/reference (build container only)')

@@ -171,3 +171,46 @@ def test_overlapped_gather_returns_the_previous_step():
     for k in range(6):
         want = np.concatenate([np.arange(5) + 100 * k + 10 * r for r in range(2)]).astype(float)
         assert np.array_equal(got[k + 1], want)
+
+
+def _ragged_overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from opfgym_amd.dist import OverlappedGather, shard_bounds
+    total = 7                                             # 7 rows over 2 ranks: shards of 4 and 3
+    sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    lo, hi = shard_bounds(total, rank, world)
+    g = OverlappedGather(world, sizes)
+    got = []
+    for k in range(4):
+        local = (torch.arange(lo, hi, dtype=torch.float64) + 100 * k).reshape(-1, 1).repeat(1, 2)
+        got.append(g.submit(local))
+    got.append(g.flush())
+    bad = None
+    try:
+        g.submit(torch.zeros(sizes[rank] + 1, 2, dtype=torch.float64))
+    except ValueError as e:
+        bad = str(e)
+    if rank == 0:
+        q.put(([None if t is None else t.numpy() for t in got], bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_with_ragged_shards():
+    """a batch the world size does not divide (bench.py's strong-scaling configs on 3, 6 or 7 GPUs) gives
+    shards of different sizes; the overlapped gather pads to the largest shard and trims on hand-over instead of
+    issuing a collective with mismatched counts."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_overlap_worker, args=(r, 2, 29657, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, bad = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] is None and bad is not None and 'shard has' in bad
+    for k in range(4):
+        want = (np.arange(7.0) + 100 * k).reshape(-1, 1).repeat(2, axis=1)
+        assert got[k + 1].shape == (7, 2) and np.array_equal(got[k + 1], want)

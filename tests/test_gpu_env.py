@@ -352,6 +352,53 @@ def test_truncated_normal_sampling_matches_the_oracle_transform():
     assert (np.abs(x.var(axis=0) - v)[ok] < 0.15 * v[ok] + 1e-12).all()
 
 
+def test_truncated_normal_with_bounds_far_in_a_tail():
+    """the reference hands scipy the raw MW bounds as standardised ones (D14), so a unit between 10 and
+    200 MW is truncated "between 10 and 200 sigma", where Phi(a) == Phi(b) == 1.0 in double precision.  scipy samples
+    such a tail in log space and returns finite values in [a, b]; so must the device op (it used to return +inf and
+    the reset raised after 20 retries).  Bounds in both tails, across zero, one-sided wide, and beyond 38 sigma."""
+    from scipy import stats
+    from opfgym_amd import envs, native_definition
+    defn = native_definition.build('opfgym.envs.VoltageControl', dict(simbench_network_name='mv-small'))
+    ld = defn.net.load
+    n = len(ld)
+    rng = np.random.default_rng(17)
+    kinds = [(10.0, 200.0), (50.0, 300.0), (-300.0, -50.0), (0.0, 1.5), (-2.0, 3.0), (-40.0, -9.0), (8.5, 8.6), (0.3, 120.0)]
+    lo = np.array([kinds[i % len(kinds)][0] for i in range(n)])
+    hi = np.array([kinds[i % len(kinds)][1] for i in range(n)])
+    sc = ld.scaling.to_numpy(float)
+    ld['min_min_p_mw'], ld['max_max_p_mw'] = lo * sc, hi * sc
+    ld['mean_p_mw'] = rng.uniform(-1.0, 1.0, n)
+    kw = dict(definition=defn, simbench_network_name='mv-small', train_data='normal_around_mean',
+              test_data='normal_around_mean', sampling_params=dict(relative_std=0.01, truncated=True))
+    B = 256
+    env = envs.VoltageControl(batch_size=B, device='cuda:0', seed=3, **kw)
+    u = rng.random((B, env.n_uniform))
+    u[0, :] = 0.0
+    u[1, :] = 1.0 - 2.0 ** -53
+    u[2, :] = 1e-300
+    env.reset(options={'uniform': u})
+    unit, col, idxs = next(k for k in env.state_keys if k[0] == 'load' and k[1] == 'p_mw')
+    rows = env.store.rows(unit, idxs)
+    x = _np(env.table_column('load', 'p_mw'))[:, rows]
+    # which uniform column feeds which load row: the ops are emitted per state key in order
+    first = 0
+    for un, cl, ix in env.state_keys:
+        if (un, cl) == ('load', 'p_mw'):
+            break
+        if 'res_' not in un and 'poly_cost' not in un:
+            first += len(ix)
+    uu = u[:, first:first + len(rows)]
+    scale = 0.01 * (hi - lo) ** 2
+    ref = stats.truncnorm.ppf(uu, lo[None, rows], hi[None, rows], ld['mean_p_mw'].to_numpy(float)[None, rows], scale[None, rows])
+    assert np.isfinite(x).all()
+    z = (x - ld['mean_p_mw'].to_numpy(float)[None, rows]) / scale[None, rows]
+    assert (z >= lo[None, rows] - 1e-9).all() and (z <= hi[None, rows] + 1e-9).all()
+    ok = np.isfinite(ref)
+    assert ok.mean() > 0.95
+    assert np.allclose(x[ok], ref[ok], rtol=1e-9, atol=1e-9), np.abs(x - ref)[ok].max()
+
+
 def test_host_fallback_for_python_callables():
     """Arbitrary Python callables in the problem definition (opf_env.py:80-84 `objective_function(net)`,
     constraints.py:62-65 value callables, or an object with `get_violation_metrics(net)`) are evaluated on
@@ -406,6 +453,61 @@ def test_host_fallback_for_python_callables():
         for k in variants['device']:
             assert np.allclose(variants['device'][k], variants[name][k], rtol=0, atol=1e-10, equal_nan=True), (name, k)
     assert (variants['device']['violations'][:, -1] > 0).any(), 'the custom constraint must bind for the test to mean something'
+
+
+def test_custom_reward_classes_run_through_their_own_methods():
+    """`adjust_objective` / `adjust_penalty` are the reference's extension points (reward.py:106-112,
+    abstract there).  A user subclass that overrides them — or a foreign object with the reference's interface — must
+    not be silently evaluated as Summation by the kernel: the reward is finished on the host with the user's object;
+    the built-in kinds stay in the kernel and give the same numbers as their host formula."""
+    from opfgym_amd import envs, reward as rw
+
+    class Harsh(rw.Summation):                           # overrides an extension point
+        def adjust_penalty(self, penalty, valid):
+            return penalty if valid else 3.0 * penalty - 1.0
+
+    class Foreign:                                       # not a class of this package at all (reference interface)
+        penalty_weight, clip_range = 0.25, None
+        scaling_params = {'penalty_factor': 1, 'penalty_bias': 0, 'objective_factor': 1, 'objective_bias': 0}
+
+        def __call__(self, objective, penalty, valid):
+            return 0.75 * objective + 0.25 * (penalty - (0.0 if valid else 2.0))
+
+        def calculate_cost(self, penalty, valid):
+            return 0.0 if valid else abs(penalty) + 2.0
+    assert rw.runs_on_device(rw.Parameterized()) and not rw.runs_on_device(Harsh()) and not rw.runs_on_device(Foreign())
+    B = 48
+    kw = dict(simbench_network_name='mv-small', voltage_band=0.02, max_loading=40, batch_size=B, device='cuda:0', seed=5)
+    base = envs.VoltageControl(**kw)
+    assert not base.host_reward
+    rng = np.random.default_rng(8)
+    steps, act = rng.choice(base.train_steps, B), rng.random((B, base.n_actions))
+    base.reset(options={'step': steps})
+    _, r0, _, _, i0 = base.step(act)
+    obj, pen, valid = _np(i0['objective']).copy(), _np(i0['unscaled_penalties']).sum(axis=1), _np(i0['valids']).all(axis=1)
+    assert (~valid).any(), 'the scenario must produce invalid rows (the overrides act on those)'
+    assert np.allclose(_np(r0), [rw.Summation()(o, p, v) for o, p, v in zip(obj, pen, valid)], rtol=0, atol=1e-12)
+    for rf in (Harsh(), Foreign()):
+        env = envs.VoltageControl(reward_function=rf, **kw)
+        assert env.host_reward
+        env.reset(options={'step': steps})
+        _, r, _, _, info = env.step(act)
+        assert np.allclose(_np(r), [rf(o, p, v) for o, p, v in zip(obj, pen, valid)], rtol=0, atol=1e-12)
+        assert np.allclose(_np(info['cost']), [rf.calculate_cost(p, v) for p, v in zip(pen, valid)], rtol=0, atol=1e-12)
+        assert not np.allclose(_np(r), _np(r0))
+        assert np.array_equal(_np(env.is_state_valid()), valid)
+    with pytest.raises(TypeError, match='calculate_cost'):
+        envs.VoltageControl(reward_function=object(), **kw)
+
+
+def test_is_state_valid_without_any_constraint():
+    """no constraints at all -> an empty all() is True (opf_env.py:613-618), not a column the kernel never writes."""
+    from opfgym_amd import envs
+    env = envs.VoltageControl(simbench_network_name='mv-small', batch_size=6, device='cuda:0', seed=1, custom_constraints=[])
+    assert env.n_constraints == 0
+    env.reset()
+    env.step(np.full((6, env.n_actions), 0.5))
+    assert bool(env.is_state_valid().all())
 
 
 @pytest.mark.parametrize('name', list(EPISODE_STEPS))
