@@ -132,6 +132,11 @@ struct StepIO {
   int* total_iterations;
   double* min_pivot;
   int mode;
+  // autoreset (opfx_step_io.autoreset_seed != 0): the reset of the finished episode runs in the step's epilogue
+  const struct DevReset* ar_R;       // reset programme of the environment (device copy)
+  const struct ResetIO* ar_io;       // its inputs as registered with opfx_env_set_autoreset (device copy)
+  unsigned long long ar_seed;        // per-call seed of the in-kernel draws (0 = no autoreset)
+  double* final_obs;                 // [B,nobs] or NULL: the observation of the finished episode
 };
 
 struct Opts {
@@ -1615,6 +1620,267 @@ __device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
   return __longlong_as_double(((long long)hi << 32) | lo);
 }
 
+// ---------------------------------------------------------------------------
+// reset kernel: SimBench state sampling (opf_env.py:317-372) + `_sampling` tails
+// ---------------------------------------------------------------------------
+struct DevTable {
+  int n_steps, n_types, n_cols, noise_off;
+  const double *rel, *peak, *col_min, *col_max;
+  const int *typ, *slot;
+};
+constexpr int MAX_TABLES = 8;
+struct DevReset {
+  int n_tables, n_ops, n_uniform, n_normal, n_noise, nx, init_off;
+  DevTable tab[MAX_TABLES];
+  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2, *op_mode;
+  const double* consts;
+};
+
+struct ResetIO {
+  const int* step_idx;
+  const double *noise, *interp, *uniform, *normal;
+  double normal_noise_factor;
+  double* x;
+  const int* mode;
+  const double* action;      // optional: initial action [B,na] (reset without power flow)
+  double* obs;               // optional: table observation [B,nobs]
+  int keep_state;            // start from the instance's current row instead of the template
+  const int* step_pool;      // optional: draw the step in the kernel (opfx_reset_io::step_pool)
+  int n_step_pool;
+  unsigned long long rng_seed;
+  int* step_out;
+};
+
+// Standard normal truncated to [a, b], by inverse CDF of a uniform draw u — what scipy.stats.truncnorm.ppf(u, a, b)
+// computes, in log space so that bounds far out in a tail work (opf_env.py:306-309 hands scipy the raw MW bounds as
+// STANDARDISED ones, defect D14: a unit between 50 and 300 MW is "50 to 300 sigma"; Phi(50) == 1.0 in double).
+//   log Phi(t): erfcx form in the lower tail;  a > 0: mirrored problem (-b, -a), 1 - u, result negated;
+//   log P = log Phi(b) + log(r + u (1 - r)),  r = Phi(a) / Phi(b);  z = (log Phi)^-1(log P): normcdfinv where P is
+//   representable (through 1 - P next to 1), Newton on log Phi below that (d/dz log Phi = phi / Phi = sqrt(2/pi) / erfcx(-z / sqrt 2)).
+__device__ __forceinline__ double log_ndtr(double t) {
+  const double s = t * 0.70710678118654752440;
+  return t < 0.0 ? log(0.5 * erfcx(-s)) - s * s : log1p(-0.5 * erfc(s));
+}
+__device__ __forceinline__ double ndtri_log(double lp) {
+  if (lp > -0.69314718055994531) return -normcdfinv(-expm1(lp));
+  if (lp > -600.0) return normcdfinv(exp(lp));
+  double z = -sqrt(-2.0 * lp);
+  for (int k = 0; k < 6; ++k) {
+    const double f = log_ndtr(z) - lp;
+    const double d = 0.79788456080286535588 / erfcx(-z * 0.70710678118654752440);
+    z -= f / d;
+  }
+  return z;
+}
+__device__ __forceinline__ double truncnorm_ppf(double u, double a, double b) {
+  const bool flip = a > 0.0;
+  const double lo = flip ? -b : a, hi = flip ? -a : b;
+  const double q = flip ? 1.0 - u : u;
+  const double lhi = log_ndtr(hi);
+  const double r = exp(log_ndtr(lo) - lhi);
+  double z = ndtri_log(lhi + log(r + q * (1.0 - r)));
+  z = fmin(fmax(z, lo), hi);
+  return flip ? -z : z;
+}
+
+// Counter-based random numbers for draws made inside the kernels (splitmix64 finaliser): value j of instance b under a
+// per-reset seed; nothing to store, reproducible from the seed the caller drew from ITS generator.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long h) {
+  h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+  h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+  return h ^ (h >> 31);
+}
+__device__ __forceinline__ unsigned long long draw_bits(unsigned long long seed, long long b, unsigned stream) {
+  return mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1)) + 0xD6E8FEB86659FD93ull * (unsigned long long)(stream + 1));
+}
+__device__ __forceinline__ double draw_uniform(unsigned long long seed, long long b, unsigned stream) {     // [0, 1)
+  return (double)(draw_bits(seed, b, stream) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double draw_normal(unsigned long long seed, long long b, unsigned stream) {      // Box-Muller
+  const double u1 = 1.0 - draw_uniform(seed, b, 2u * stream + 0x40000000u), u2 = draw_uniform(seed, b, 2u * stream + 0x40000001u);
+  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+// The reset of ONE instance by one wavefront: the row is built in LDS (`row`: nx doubles, `sp`: na doubles) — template
+// -> profile values -> vector-op programme -> optionally the initial action and the table observation
+// (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make a round trip
+// through memory.  Called by k_reset (a launch of its own) and by k_step's epilogue (opfx_step_io.autoreset_seed:
+// the reset of a finished single-step episode inside the launch of its step).
+// U: 64-column chunks whose loads are requested together (k_reset: 4 — nothing else hides its round trips; inside
+// k_step: 1 — the CU's other instances do, and four chunks' worth of registers on top of the step's own would spill).
+template <bool CACHED, int U>
+__device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b, int lane,
+                          double* const row, double* const sp, const int (&okind)[8], const int (&osrc)[8],
+                          const int (&odst)[8], const int (&on)[8]) {
+  const double NaN = __builtin_nan("");
+  {
+    double* xr = io.x + b * R.nx;
+    int step;
+    if (io.step_pool) {
+      // counter-based draw: uniform over the pool up to a bias of n / 2^64
+      const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1));
+      step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
+      if (lane == 0 && io.step_out) io.step_out[b] = step;
+    } else {
+      step = io.step_idx[b];
+    }
+    const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
+    // Every loop of this kernel is a chain of global-memory round trips (L2-resident descriptors, ~0.3 us each) with
+    // nothing else to hide them: four 64-column chunks at a time, all their loads — unconditional, clamped indices —
+    // requested before the first use, cut the round trips of a row from ~60 to ~20.
+    {
+      const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
+      for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
+        double t[2 * U];
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
+      }
+    }
+    wave_fence();
+    for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
+      const DevTable& T = R.tab[t];
+      const double* rw = T.rel + (long long)step * T.n_types;
+      const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
+      const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
+      const int nc = T.n_cols;
+      const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
+      for (int j0 = lane; j0 < nc; j0 += 64 * U) {
+        int typ[U], slot[U];
+        double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
+          typ[u] = T.typ[jc]; slot[u] = T.slot[jc]; peak[u] = T.peak[jc]; lo[u] = T.col_min[jc]; hi[u] = T.col_max[jc];
+          nz[u] = nzp ? nzp[jc] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          double v = r0[u] * peak[u];                                                // :343
+          if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
+          if (nzp) {
+            if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
+            else v = v * nz[u];                                                      // :354-356
+          }
+          v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
+          if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
+        }
+      }
+    }
+    wave_fence();
+    for (int k = 0; k < R.n_ops; ++k) {
+      if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
+      const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
+      // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
+      const double* c0 = R.consts + (R.op_c0[k] >= 0 ? R.op_c0[k] : 0);
+      const double* c1 = R.consts + (R.op_c1[k] >= 0 ? R.op_c1[k] : 0);
+      const double* c2 = R.consts + (R.op_c2[k] >= 0 ? R.op_c2[k] : 0);
+      const bool has0 = R.op_c0[k] >= 0, has1 = R.op_c1[k] >= 0, has2 = R.op_c2[k] >= 0;
+      // per-instance draw of the op, if it has one (same chunked, unconditional access)
+      // (no draw array given: the kernel draws them itself from the per-reset seed, see draw_uniform)
+      const double* draw = (code == OPFX_OP_UNIFORM && io.uniform) ? io.uniform + b * R.n_uniform + a
+                         : ((code == OPFX_OP_NORMAL && io.normal) ? io.normal + b * R.n_normal + a : nullptr);
+      const bool own_u = code == OPFX_OP_UNIFORM && !io.uniform, own_n = code == OPFX_OP_NORMAL && !io.normal;
+      const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
+      for (int j0 = lane; j0 < n; j0 += 64 * U) {
+        double k0[U], k1[U], k2[U], dr[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
+          k0[u] = has0 ? c0[jc] : 0.0; k1[u] = has1 ? c1[jc] : 0.0; k2[u] = has2 ? c2[jc] : 0.0;
+          dr[u] = draw ? draw[jc] : (own_u ? draw_uniform(io.rng_seed, b, (unsigned)(a + jc)) : (own_n ? draw_normal(io.rng_seed, b, (unsigned)(a + jc)) : 0.0));
+          rv[u] = reads_row ? row[a + jc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + 64 * u;
+          double v;
+          if (code == OPFX_OP_SET_CONST) v = k0[u];
+          else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
+          else if (code == OPFX_OP_SQRT_DIFF) { const double s = k0[u], pz = rv[u]; v = sqrt(s * s - pz * pz); }
+          else if (code == OPFX_OP_NEG) v = -rv[u];
+          else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
+          else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
+          else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
+          else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
+          else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
+          else v = rv[u] / k0[u];
+          if (j < n) row[dst + j] = v;
+        }
+      }
+      wave_fence();
+    }
+    if (io.obs && Ep) {
+      // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
+      // table part of the observation (:218); result entries are NaN
+      const DevEnv& E = *Ep;
+      for (int k = lane; k < E.na; k += 64) {
+        // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
+        const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
+        const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
+        const int kind = as_global(E.act_kind)[k];
+        const bool clampa = (E.clamp_enabled & 2) != 0;
+        const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
+        const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
+        const double* act_row = io.action ? io.action + b * E.na : E.act_lo_const;      // (any readable row)
+        double a = act_row[k];
+        double xv = row[slot];
+        if (io.action) {
+          a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
+          const double lo = ls >= 0 ? row[ls] : loc;
+          const double hi = hs >= 0 ? row[hs] : hic;
+          double spt = a * (hi - lo) + lo;                                              // :461
+          if (clampa) {                                                                 // :464-470 (autoscale off)
+            if (ch > -2) { const double m = ch >= 0 ? row[ch] : chc; if (spt > m) spt = m; }
+            if (cl > -2) { const double m = cl >= 0 ? row[cl] : clc; if (spt < m) spt = m; }
+          }
+          xv = spt / scal;                                                              // :472-474
+          if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
+        }
+        sp[k] = xv;
+        if (E.na <= 64) {          // one chunk: the lane still knows its slot — (limits are read before any set-point is written)
+          wave_fence();
+          row[slot] = xv;
+        }
+      }
+      wave_fence();
+      if (E.na > 64) { for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k]; }
+      wave_fence();
+      for (int sg = 0; sg < E.n_oseg; ++sg) {
+        const bool c = CACHED && sg < 8;
+        const int kind = c ? okind[sg & 7] : as_global(E.oseg_kind)[sg], src = c ? osrc[sg & 7] : as_global(E.oseg_src)[sg];
+        const int dst = c ? odst[sg & 7] : as_global(E.oseg_dst)[sg], n = c ? on[sg & 7] : as_global(E.oseg_n)[sg];
+        for (int j = lane; j < n; j += 64)
+          io.obs[b * E.nobs + dst + j] = kind == 1 ? NaN : (kind == 0 ? row[src + j] : sp[src + j]);
+      }
+    }
+    for (int j = lane; j < R.nx; j += 64) xr[j] = row[j];
+    wave_fence();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
+                                               int row_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  double* const row = smem + (size_t)wib * row_doubles;
+  double* const sp = row + ((R.nx + 1) & ~1);
+  const long long w = (long long)blockIdx.x * wpb + wib;
+  const long long nw = (long long)gridDim.x * wpb;
+  // observation segments: the same for every instance, the first eight read once per wavefront
+  int okind[8], osrc[8], odst[8], on[8];
+#pragma unroll
+  for (int sg = 0; sg < 8; ++sg) {
+    const bool have = io.obs && Ep && sg < Ep->n_oseg;
+    okind[sg] = have ? as_global(Ep->oseg_kind)[sg] : 0; osrc[sg] = have ? as_global(Ep->oseg_src)[sg] : 0;
+    odst[sg] = have ? as_global(Ep->oseg_dst)[sg] : 0; on[sg] = have ? as_global(Ep->oseg_n)[sg] : 0;
+  }
+  for (long long b = w; b < B; b += nw) reset_row<true, 4>(R, Ep, io, b, lane, row, sp, okind, osrc, odst, on);
+}
+
 // cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
 // constants or sampled prices living in the instance's table row `xc`
 __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, int meta, int cbase, double pw_, double qv_) {
@@ -1668,6 +1934,12 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
+  // autoreset: the observation buffer receives the first observation of the NEXT episode (written by reset_row in the
+  // epilogue); the step's own — last — observation goes to final_obs, or nowhere
+  // (single-wave kernels only: the grids of the wave teams spend milliseconds per step, a reset's 0.06 ms does not
+  //  matter there, and the extra code costs their register allocation a few spills — opfx_step refuses it for them)
+  const bool autoreset = NW == 1 && io.ar_seed != 0;
+  double* const obs_step = autoreset ? io.final_obs : io.obs;
   if (V2) {
     for (int i = tid; i < nb; i += NT) L.dg[i] = (unsigned short)P.diag_blk[i];
     for (int i = tid; i < P.tail_n; i += NT) L.tl[i] = P.tail_ids[i];
@@ -1753,14 +2025,14 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     // (limits are read before any set-point of this step is written back: xs keeps the
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
-    if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+    if (wave == 0 && obs_step) for (int sg = 0; sg < E.n_oseg; ++sg) {
       const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
       if (kind == 1) {
-        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = NaN;
+        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = NaN;
         continue;
       }
       const double* from = (kind == 0 ? xs : L.sp) + src;
-      for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = from[j];
+      for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = from[j];
     }
     if (io.mode == 2 || io.mode == 3) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
@@ -2013,10 +2285,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       }
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
-      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+      if (obs_step) for (int sg = 0; sg < E.n_oseg; ++sg) {
         if (as_global(E.oseg_kind)[sg] != 1) continue;
         const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
-        for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = R[src + j];
+        for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = R[src + j];
       }
       }
       blk_sync<NW>();
@@ -2027,7 +2299,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
       __builtin_amdgcn_s_waitcnt(0);      // the table observations written above are overwritten
-      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
+      if (obs_step) for (int k = lane; k < E.nobs; k += WAVE) obs_step[b * E.nobs + k] = NaN;
       if (lane < E.nc) {
         if (io.valids) io.valids[b * E.nc + lane] = 0;
         if (io.violations) io.violations[b * E.nc + lane] = 1.0;
@@ -2089,243 +2361,24 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       if (io.total_iterations) io.total_iterations[b] = iters_all;
       if (io.min_pivot) io.min_pivot[b] = min_piv;
     }
+    if (NW == 1 && autoreset) {
+      // Single-step episodes end with every step (opf_env.py:406-414): this row starts its next episode here — a new
+      // time step, profile values, the `_sampling` tail, the initial action, the first observation — built in the
+      // staging area (free again) and stored over the row.  One launch per reset + step cycle: the reset's chain of
+      // L2 round trips hides behind the Newton phases of the CU's other instances.
+      wave_fence();
+      __builtin_amdgcn_s_waitcnt(0);            // (the set-points this step wrote into the row are overwritten)
+      // (pointers laundered through an empty asm: everything read through them is loop-invariant, and the compiler
+      //  would otherwise hoist ~60 values out of the instance loop and keep them alive across the Newton phases)
+      const ResetIO* aio = io.ar_io; const DevReset* aR = io.ar_R; const DevEnv* aE = Ep;
+      asm volatile("" : "+s"(aio), "+s"(aR), "+s"(aE));
+      ResetIO rio = *aio;
+      rio.rng_seed = io.ar_seed;
+      const int none[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      reset_row<false, 1>(*aR, aE, rio, b, lane, xs, L.sp, none, none, none, none);
+    }
     }
     blk_sync<NW>();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// reset kernel: SimBench state sampling (opf_env.py:317-372) + `_sampling` tails
-// ---------------------------------------------------------------------------
-struct DevTable {
-  int n_steps, n_types, n_cols, noise_off;
-  const double *rel, *peak, *col_min, *col_max;
-  const int *typ, *slot;
-};
-constexpr int MAX_TABLES = 8;
-struct DevReset {
-  int n_tables, n_ops, n_uniform, n_normal, n_noise, nx, init_off;
-  DevTable tab[MAX_TABLES];
-  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2, *op_mode;
-  const double* consts;
-};
-
-struct ResetIO {
-  const int* step_idx;
-  const double *noise, *interp, *uniform, *normal;
-  double normal_noise_factor;
-  double* x;
-  const int* mode;
-  const double* action;      // optional: initial action [B,na] (reset without power flow)
-  double* obs;               // optional: table observation [B,nobs]
-  int keep_state;            // start from the instance's current row instead of the template
-  const int* step_pool;      // optional: draw the step in the kernel (opfx_reset_io::step_pool)
-  int n_step_pool;
-  unsigned long long rng_seed;
-  int* step_out;
-};
-
-// Standard normal truncated to [a, b], by inverse CDF of a uniform draw u — what scipy.stats.truncnorm.ppf(u, a, b)
-// computes, in log space so that bounds far out in a tail work (opf_env.py:306-309 hands scipy the raw MW bounds as
-// STANDARDISED ones, defect D14: a unit between 50 and 300 MW is "50 to 300 sigma"; Phi(50) == 1.0 in double).
-//   log Phi(t): erfcx form in the lower tail;  a > 0: mirrored problem (-b, -a), 1 - u, result negated;
-//   log P = log Phi(b) + log(r + u (1 - r)),  r = Phi(a) / Phi(b);  z = (log Phi)^-1(log P): normcdfinv where P is
-//   representable (through 1 - P next to 1), Newton on log Phi below that (d/dz log Phi = phi / Phi = sqrt(2/pi) / erfcx(-z / sqrt 2)).
-__device__ double log_ndtr(double t) {
-  const double s = t * 0.70710678118654752440;
-  return t < 0.0 ? log(0.5 * erfcx(-s)) - s * s : log1p(-0.5 * erfc(s));
-}
-__device__ double ndtri_log(double lp) {
-  if (lp > -0.69314718055994531) return -normcdfinv(-expm1(lp));
-  if (lp > -600.0) return normcdfinv(exp(lp));
-  double z = -sqrt(-2.0 * lp);
-  for (int k = 0; k < 6; ++k) {
-    const double f = log_ndtr(z) - lp;
-    const double d = 0.79788456080286535588 / erfcx(-z * 0.70710678118654752440);
-    z -= f / d;
-  }
-  return z;
-}
-__device__ double truncnorm_ppf(double u, double a, double b) {
-  const bool flip = a > 0.0;
-  const double lo = flip ? -b : a, hi = flip ? -a : b;
-  const double q = flip ? 1.0 - u : u;
-  const double lhi = log_ndtr(hi);
-  const double r = exp(log_ndtr(lo) - lhi);
-  double z = ndtri_log(lhi + log(r + q * (1.0 - r)));
-  z = fmin(fmax(z, lo), hi);
-  return flip ? -z : z;
-}
-
-// One wavefront per instance; the row is built in LDS (template -> profile values -> vector-op
-// programme -> optionally the initial action and the table observation, opf_env.py:201-207,218)
-// and leaves with one coalesced store: the intermediate values never make a round trip through
-// memory and the reset of an environment whose observation needs no power flow is ONE launch.
-__global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
-                                               int row_doubles) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  double* const row = smem + (size_t)wib * row_doubles;
-  double* const sp = row + ((R.nx + 1) & ~1);
-  const long long w = (long long)blockIdx.x * wpb + wib;
-  const long long nw = (long long)gridDim.x * wpb;
-  const double NaN = __builtin_nan("");
-  // observation segments: the same for every instance, read once per wavefront
-  int okind[8], osrc[8], odst[8], on[8];
-#pragma unroll
-  for (int sg = 0; sg < 8; ++sg) {
-    const bool have = io.obs && Ep && sg < Ep->n_oseg;
-    okind[sg] = have ? as_global(Ep->oseg_kind)[sg] : 0; osrc[sg] = have ? as_global(Ep->oseg_src)[sg] : 0;
-    odst[sg] = have ? as_global(Ep->oseg_dst)[sg] : 0; on[sg] = have ? as_global(Ep->oseg_n)[sg] : 0;
-  }
-  for (long long b = w; b < B; b += nw) {
-    double* xr = io.x + b * R.nx;
-    int step;
-    if (io.step_pool) {
-      // counter-based draw (splitmix64 finaliser of seed and instance number): uniform over the pool up to a
-      // bias of n / 2^64
-      unsigned long long h = io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1);
-      h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
-      h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
-      h ^= h >> 31;
-      step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
-      if (lane == 0 && io.step_out) io.step_out[b] = step;
-    } else {
-      step = io.step_idx[b];
-    }
-    const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-    // Every loop of this kernel is a chain of global-memory round trips (L2-resident descriptors, ~0.3 us each) with
-    // nothing else to hide them: four 64-column chunks at a time, all their loads — unconditional, clamped indices —
-    // requested before the first use, cut the round trips of a row from ~60 to ~20.
-    constexpr int U = 4;
-    {
-      const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
-      for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
-        double t[2 * U];
-#pragma unroll
-        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
-#pragma unroll
-        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
-      }
-    }
-    wave_fence();
-    for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
-      const DevTable& T = R.tab[t];
-      const double* rw = T.rel + (long long)step * T.n_types;
-      const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
-      const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
-      const int nc = T.n_cols;
-      const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
-      for (int j0 = lane; j0 < nc; j0 += 64 * U) {
-        int typ[U], slot[U];
-        double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
-          typ[u] = T.typ[jc]; slot[u] = T.slot[jc]; peak[u] = T.peak[jc]; lo[u] = T.col_min[jc]; hi[u] = T.col_max[jc];
-          nz[u] = nzp ? nzp[jc] : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          double v = r0[u] * peak[u];                                                // :343
-          if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
-          if (nzp) {
-            if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
-            else v = v * nz[u];                                                      // :354-356
-          }
-          v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
-          if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
-        }
-      }
-    }
-    wave_fence();
-    for (int k = 0; k < R.n_ops; ++k) {
-      if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
-      const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
-      // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
-      const double* c0 = R.consts + (R.op_c0[k] >= 0 ? R.op_c0[k] : 0);
-      const double* c1 = R.consts + (R.op_c1[k] >= 0 ? R.op_c1[k] : 0);
-      const double* c2 = R.consts + (R.op_c2[k] >= 0 ? R.op_c2[k] : 0);
-      const bool has0 = R.op_c0[k] >= 0, has1 = R.op_c1[k] >= 0, has2 = R.op_c2[k] >= 0;
-      // per-instance draw of the op, if it has one (same chunked, unconditional access)
-      const double* draw = code == OPFX_OP_UNIFORM ? io.uniform + b * R.n_uniform + a
-                         : (code == OPFX_OP_NORMAL ? io.normal + b * R.n_normal + a : nullptr);
-      const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
-      for (int j0 = lane; j0 < n; j0 += 64 * U) {
-        double k0[U], k1[U], k2[U], dr[U], rv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
-          k0[u] = has0 ? c0[jc] : 0.0; k1[u] = has1 ? c1[jc] : 0.0; k2[u] = has2 ? c2[jc] : 0.0;
-          dr[u] = draw ? draw[jc] : 0.0;
-          rv[u] = reads_row ? row[a + jc] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u;
-          double v;
-          if (code == OPFX_OP_SET_CONST) v = k0[u];
-          else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
-          else if (code == OPFX_OP_SQRT_DIFF) { const double s = k0[u], pz = rv[u]; v = sqrt(s * s - pz * pz); }
-          else if (code == OPFX_OP_NEG) v = -rv[u];
-          else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
-          else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
-          else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
-          else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
-          else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
-          else v = rv[u] / k0[u];
-          if (j < n) row[dst + j] = v;
-        }
-      }
-      wave_fence();
-    }
-    if (io.obs && Ep) {
-      // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
-      // table part of the observation (:218); result entries are NaN
-      const DevEnv& E = *Ep;
-      for (int k = lane; k < E.na; k += 64) {
-        // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
-        const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
-        const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
-        const int kind = as_global(E.act_kind)[k];
-        const bool clampa = (E.clamp_enabled & 2) != 0;
-        const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
-        const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
-        const double* act_row = io.action ? io.action + b * E.na : E.act_lo_const;      // (any readable row)
-        double a = act_row[k];
-        double xv = row[slot];
-        if (io.action) {
-          a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
-          const double lo = ls >= 0 ? row[ls] : loc;
-          const double hi = hs >= 0 ? row[hs] : hic;
-          double spt = a * (hi - lo) + lo;                                              // :461
-          if (clampa) {                                                                 // :464-470 (autoscale off)
-            if (ch > -2) { const double m = ch >= 0 ? row[ch] : chc; if (spt > m) spt = m; }
-            if (cl > -2) { const double m = cl >= 0 ? row[cl] : clc; if (spt < m) spt = m; }
-          }
-          xv = spt / scal;                                                              // :472-474
-          if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
-        }
-        sp[k] = xv;
-        if (E.na <= 64) {          // one chunk: the lane still knows its slot — (limits are read before any set-point is written)
-          wave_fence();
-          row[slot] = xv;
-        }
-      }
-      wave_fence();
-      if (E.na > 64) { for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k]; }
-      wave_fence();
-      for (int sg = 0; sg < E.n_oseg; ++sg) {
-        const int kind = sg < 8 ? okind[sg] : as_global(E.oseg_kind)[sg], src = sg < 8 ? osrc[sg] : as_global(E.oseg_src)[sg];
-        const int dst = sg < 8 ? odst[sg] : as_global(E.oseg_dst)[sg], n = sg < 8 ? on[sg] : as_global(E.oseg_n)[sg];
-        for (int j = lane; j < n; j += 64)
-          io.obs[b * E.nobs + dst + j] = kind == 1 ? NaN : (kind == 0 ? row[src + j] : sp[src + j]);
-      }
-    }
-    for (int j = lane; j < R.nx; j += 64) xr[j] = row[j];
-    wave_fence();
   }
 }
 
@@ -2368,6 +2421,9 @@ struct opfx_env {
   const DevEnv* d_de = nullptr;
   DevReset dr{};
   bool has_reset = false;
+  const DevReset* d_dr = nullptr;      // device copy (autoreset inside opfx_step)
+  ResetIO* d_ar = nullptr;             // device copy of the registered autoreset inputs
+  bool has_autoreset = false;
   DevArena arena;
   size_t lds_bytes = 0;
   int per_cu = 0;
@@ -2808,6 +2864,15 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
+  s.ar_R = nullptr; s.ar_io = nullptr; s.ar_seed = 0; s.final_obs = nullptr;
+  if (io->autoreset_seed != 0) {
+    if (!env->has_autoreset || mode != 0 || env->de.steps_per_episode != 1 || team != 1) {
+      opfx_set_error("opfx_step: autoreset needs opfx_env_set_autoreset, mode 0, single-step episodes and a grid that runs "
+                     "on the single-wave kernel (opfx_env_get_info: waves_per_instance == 1)");
+      return OPFX_ERR_INVALID;
+    }
+    s.ar_R = env->d_dr; s.ar_io = env->d_ar; s.ar_seed = (unsigned long long)io->autoreset_seed; s.final_obs = io->final_obs;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
@@ -2901,8 +2966,39 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   PUTN(op_c2, d->op_c2, d->n_ops); PUTN(consts, d->consts, d->n_consts);
   if (d->op_mode) { PUTN(op_mode, d->op_mode, d->n_ops); }
 #undef PUTN
+  if (rc == OPFX_OK) rc = A.put(&env->dr, 1, &env->d_dr);
   if (rc != OPFX_OK) return rc;
   env->has_reset = true;
+  env->has_autoreset = false;
+  return OPFX_OK;
+}
+
+static int check_reset_io(const opfx_env* env, const opfx_reset_io* io, const char* who) {
+  if (!io->step_idx && !(io->step_pool && io->n_step_pool > 0)) { opfx_set_error(std::string(who) + ": step_idx or step_pool required"); return OPFX_ERR_INVALID; }
+  if (!io->x) { opfx_set_error(std::string(who) + ": x required"); return OPFX_ERR_INVALID; }
+  return OPFX_OK;
+}
+
+extern "C" int opfx_env_set_autoreset(opfx_env* env, const opfx_reset_io* io) {
+  if (!env) { opfx_set_error("opfx_env_set_autoreset: null environment"); return OPFX_ERR_INVALID; }
+  if (!io) { env->has_autoreset = false; return OPFX_OK; }
+  if (!env->has_reset) { opfx_set_error("opfx_env_set_autoreset: opfx_env_set_reset not called"); return OPFX_ERR_INVALID; }
+  int rc = check_reset_io(env, io, "opfx_env_set_autoreset");
+  if (rc != OPFX_OK) return rc;
+  if (!io->obs) { opfx_set_error("opfx_env_set_autoreset: obs required (the first observation of the next episode)"); return OPFX_ERR_INVALID; }
+  if ((size_t)(((env->dr.nx + 1) & ~1)) > (size_t)(2 * ((env->ctx->plan.nb + 1) & ~1) + env->de.nblk_d)) {
+    opfx_set_error("opfx_env_set_autoreset: table row does not fit the staging area"); return OPFX_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
+            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
+  if (!env->d_ar) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(ResetIO)));
+    env->arena.ptrs.push_back(d);
+    env->d_ar = static_cast<ResetIO*>(d);
+  }
+  HIP_TRY(hipMemcpy(env->d_ar, &r, sizeof(ResetIO), hipMemcpyHostToDevice));
+  env->has_autoreset = true;
   return OPFX_OK;
 }
 
@@ -2912,8 +3008,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
     opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
     return OPFX_ERR_INVALID;
   }
-  if (env->dr.n_uniform > 0 && !io->uniform) { opfx_set_error("opfx_reset: uniform draws required"); return OPFX_ERR_INVALID; }
-  if (env->dr.n_normal > 0 && !io->normal) { opfx_set_error("opfx_reset: normal draws required"); return OPFX_ERR_INVALID; }
+  // (uniform / normal == NULL with draws to make: the kernel draws them itself from rng_seed, see opfx_reset_io)
   if (B == 0) return OPFX_OK;
   HIP_TRY(hipSetDevice(env->ctx->device));
   const int na = env->de.na, nx = env->dr.nx;
