@@ -278,6 +278,9 @@ def main():
     ap.add_argument('--gather', choices=('none', 'reward', 'obs'), default=None,
                     help='per-step RCCL all-gather of the rewards (and observations) on every rank; '
                          'default: reward when N > 1')
+    ap.add_argument('--dump-reward', default=None, help='rank 0 saves the rewards of the last timed step here (.npy): the '
+                    'all-gathered full batch for N > 1 with --gather reward, the local batch for N = 1')
+    ap.add_argument('--as-rank', type=int, default=None, help='(N = 1) use the seeds rank R of a multi-GPU run uses')
     ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=10.0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
@@ -308,10 +311,14 @@ def main():
         lo, hi = odist.shard_bounds(batch_cfg, rank, world)
         B = hi - lo
     total_B = B * world if (args.batch is not None or scaling == 'weak') else batch_cfg
-    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=rank, **kw)
-    rng = np.random.default_rng(1234 + rank)
-    env.reset(options={'step': rng.choice(env.train_steps, B)})
-    act_rng = np.random.default_rng(4321 + rank)
+    seed_rank = rank if args.as_rank is None else args.as_rank
+    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=seed_rank, **kw)
+    rng = np.random.default_rng(1234 + seed_rank)
+    reset_options = {'step': rng.choice(env.train_steps, B)}
+    if env.n_uniform:                       # (explicit draws: a run is then a function of the rank's seed alone)
+        reset_options['uniform'] = rng.random((B, env.n_uniform))
+    env.reset(options=reset_options)
+    act_rng = np.random.default_rng(4321 + seed_rank)
     actions = torch.as_tensor(act_rng.random((B, env.n_actions)), device=device)
     gather = {'none': (), 'reward': ('reward',), 'obs': ('reward', 'obs')}[gather_mode]
 
@@ -343,14 +350,17 @@ def main():
     for _ in range(args.steps):
         info = one_step()
     ev1.record()
+    last_reward = None
     if world > 1 and gather:                   # the last step's gather belongs to the timed region
-        g_reward.flush()
+        last_reward = g_reward.flush()
         if 'obs' in gather:
             g_obs.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if args.dump_reward and rank == 0:
+        np.save(args.dump_reward, (last_reward if last_reward is not None else env.buf['reward']).cpu().numpy())
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64,
@@ -384,21 +394,7 @@ def main():
         env.reset()
         env.step(actions)
     torch.cuda.synchronize()
-    cycle_two_ms = (time.perf_counter() - t1) / n_cyc * 1e3
-    # the same cycle as ONE launch: the reset of the finished episode runs in the epilogue of the step's kernel
-    # (opfx_step_io.autoreset_seed; single-step episodes on the single-wave kernel), as a same-step-autoreset vector
-    # environment calls it; the finished episodes' last observation is not written (nobody bootstraps from it)
-    cycle_ms, cycle_mode = cycle_two_ms, 'two launches (opfx_reset, opfx_step)'
-    if env.can_fuse_autoreset:
-        for _ in range(2):
-            env.step(actions, autoreset=True, want_final_obs=False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_cyc):
-            env.step(actions, autoreset=True, want_final_obs=False)
-        torch.cuda.synchronize()
-        cycle_ms, cycle_mode = (time.perf_counter() - t1) / n_cyc * 1e3, 'one launch (reset in the step kernel\'s epilogue)'
-        env.reset()
+    cycle_ms = (time.perf_counter() - t1) / n_cyc * 1e3
 
     if rank == 0:
         ki = env.kernel_info()
@@ -462,8 +458,7 @@ def main():
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it_base,
                        'mean_nr_iterations_all_solves': mean_it_total, 'solves_per_step': solves_per_step,
                        'nr_solves_per_s': total_B * solves_per_step * args.steps / elapsed,
-                       'reset_plus_step_ms': cycle_ms, 'reset_plus_step_mode': cycle_mode,
-                       'reset_plus_step_two_launches_ms': cycle_two_ms,
+                       'reset_plus_step_ms': cycle_ms,
                        'episodes_per_s_reset_plus_step': B * world / (cycle_ms * 1e-3),
                        'min_relative_pivot': min_pivot,
                        'tolerance_pu': env.solve_opts.tol, 'byte_model': bm, 'lds_model': lm,

@@ -348,14 +348,6 @@ typedef struct opfx_step_io {
   double* max_mismatch;      /* [B]                                          */
   int32_t* total_iterations; /* [B]  NR iterations summed over the base case and every contingency solve */
   double* min_pivot;         /* [B]  smallest relative 2x2 pivot of all solves of the step, see opfx_solve */
-  /* Autoreset inside the step's launch (single-step episodes, opf_env.py:406-414: every step ends its episode and
-   * the next call is `reset()`, opf_env.py:177-220; gymnasium's vector environments do that reset inside `step()`,
-   * "same-step" mode).  autoreset_seed != 0: after its outputs are written every instance starts its next episode
-   * in the same launch — with the inputs registered by opfx_env_set_autoreset and this seed for the draws the kernel
-   * makes itself: x gets the new row, the registered `obs` buffer the first observation of the new episode, and the
-   * last observation of the finished one goes to final_obs (NULL: not wanted) instead of `obs`.  Mode 0 only. */
-  uint64_t autoreset_seed;
-  double* final_obs;         /* [B,nobs] or NULL */
 } opfx_step_io;
 
 /* One env.step() for B instances: apply actions → injections → NR → results →
@@ -472,10 +464,6 @@ typedef struct opfx_reset_io {
 } opfx_reset_io;
 
 int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream);
-
-/* Registers the reset inputs opfx_step uses when its io carries autoreset_seed != 0 (pointers as for opfx_reset, copied;
- * `obs` is required, rng_seed is ignored: the seed comes with every step).  io == NULL switches it off. */
-int opfx_env_set_autoreset(opfx_env* env, const opfx_reset_io* io);
 
 /* Timing helper for bench.py: runs `reps` back-to-back opfx_step launches on
  * `stream` between two hipEvents recorded on that stream and returns the

@@ -1073,18 +1073,14 @@ class BatchedOpfEnv:
         io.outage = None
         for name, buf in self.buf.items():
             setattr(io, name, buf.data_ptr())
-        io.autoreset_seed, io.final_obs = 0, None
         return io
 
-    def _launch_step(self, action, mode=0, with_initial_obj=False, autoreset_seed=0, final_obs=None):
+    def _launch_step(self, action, mode=0, with_initial_obj=False):
         # (modes that run a power flow leave results behind: opf_env.py:659 power_flow_available)
         self.power_flow_available = mode in (0, 1, 4, 5)
         self._objective_is_diff = bool(with_initial_obj)
         self._last_host = None
         io = self._io(action, with_initial_obj)
-        if autoreset_seed:
-            io.autoreset_seed = int(autoreset_seed)
-            io.final_obs = final_obs.data_ptr() if final_obs is not None else None
         with self.torch.cuda.device(self.device):
             capi.check(capi.lib().opfx_step(self._env_handle, self.B, C.byref(io), C.byref(self.solve_opts),
                                             mode, capi._stream()), 'opfx_step')
@@ -1258,15 +1254,9 @@ class BatchedOpfEnv:
             interp_t = t.rand(B, len(self.tables), generator=self._gen, device=dev, dtype=t.float64)   # :348
         return noise_t, interp_t, (float(nf) if normal_noise else 0.0)
 
-    def step(self, action, autoreset=False, want_final_obs=True):
+    def step(self, action):
         """opf_env.py:374-419 for the whole batch: (obs, reward, terminated,
         truncated, info) as torch tensors on the device.
-
-        autoreset=True (only where `can_fuse_autoreset`): the single-step episode that this step ends is followed by
-        the next `reset()` INSIDE the same kernel launch (opfx_step_io.autoreset_seed): the returned observation is
-        the first one of the new episodes — what `reset()` would return —, the last observation of the finished ones
-        is `info['final_obs']` (not produced with want_final_obs=False), and the environment is left exactly as after
-        `step()` followed by `reset()`.  This is gymnasium's same-step autoreset of a vector environment as one launch.
 
         LIFETIME: the returned tensors are the environment's persistent output buffers (or views of them) —
         the next `reset()` / `step()` overwrites them in place.  A rollout loop that keeps them across calls
@@ -1277,8 +1267,6 @@ class BatchedOpfEnv:
             assert not bool(t.isnan(action).any())                         # :382
         if self.steps_per_episode != 1:
             self.step_count += 1
-        if autoreset:
-            return self._step_and_reset(action, want_final_obs)
         self._launch_step(action, mode=0, with_initial_obj=self.diff_objective)
         b = self.buf
         host = self._host_finisher.finish(0, self.initial_obj if self.diff_objective else None) \
@@ -1293,55 +1281,6 @@ class BatchedOpfEnv:
         out = (self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info)
         if self.copy_outputs:
             out = tuple(v.clone() for v in out[:4]) + ({k: (v.clone() if self.torch.is_tensor(v) else v) for k, v in info.items()},)
-        return out
-
-    @property
-    def can_fuse_autoreset(self) -> bool:
-        """A reset that needs nothing but the kernel's own draws, right after every step: single-step episodes
-        (opf_env.py:406-414) sampled from the profile rows without noise or interpolation, an observation that needs no
-        power flow and no host-side post-processing (time / mean / bus-wise entries), the centred initial action, a grid
-        on the single-wave kernel, no host-side callables."""
-        return bool(self.steps_per_episode == 1 and self.uses_profiles and not self.per_source and not self.mixed
-                    and self.noise_factor == 0.0 and not self.interpolate_steps and not self.pf_for_obs
-                    and self.initial_action != 'random' and not self.carry_over_state and self._host_finisher is None
-                    and not (self.add_time_obs or self.add_mean_obs or self.bus_wise_obs)
-                    and type(self).step is BatchedOpfEnv.step and self._env_handle is not None
-                    and self.kernel_info()['waves_per_instance'] == 1)
-
-    def _step_and_reset(self, action, want_final_obs):
-        if not self.can_fuse_autoreset:
-            raise NotImplementedError('this environment cannot reset inside the step launch (see can_fuse_autoreset); '
-                                      'call step() and reset() separately')
-        t = self.torch
-        if getattr(self, '_autoreset_B', None) != self.B:          # register the reset's inputs once per buffer set
-            rio = capi.ResetIO()
-            pool = self._pools['train']                            # (as reset() without options: opf_env.py:327-333)
-            rio.step_idx = self.steps_dev.data_ptr()
-            rio.step_pool, rio.n_step_pool, rio.step_out = pool.data_ptr(), len(pool), self.steps_dev.data_ptr()
-            rio.x, rio.keep_state = self.x.data_ptr(), 0
-            rio.action, rio.obs = self._center_action.data_ptr(), self.buf['obs'].data_ptr()
-            rio.noise = rio.interp = rio.uniform = rio.normal = rio.mode = None
-            rio.normal_noise_factor = 0.0
-            capi.check(capi.lib().opfx_env_set_autoreset(self._env_handle, C.byref(rio)), 'opfx_env_set_autoreset')
-            self._final_obs = t.zeros_like(self.buf['obs'])
-            self._autoreset_B = self.B
-        seed = int(self.np_random.integers(1, 2 ** 63 - 1))        # the draw reset() would make next
-        self._launch_step(action, mode=0, with_initial_obj=False, autoreset_seed=seed,
-                          final_obs=self._final_obs if want_final_obs else None)
-        # the environment is now where reset() leaves it
-        self.power_flow_available = False
-        self.test = False
-        self.current_simbench_step = None
-        self._state_valid = True
-        b = self.buf
-        info = {'valids': b['valids'], 'violations': b['violations'], 'unscaled_penalties': b['penalties'], 'cost': b['cost'],
-                'converged': b['converged'], 'iterations': b['iterations'], 'max_mismatch': b['max_mismatch'],
-                'objective': b['objective'], 'total_iterations': b['total_iterations'], 'min_pivot': b['min_pivot']}
-        if want_final_obs:
-            info['final_obs'] = self._final_obs[:, :self.n_obs_raw]
-        out = (self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info)
-        if self.copy_outputs:
-            out = tuple(v.clone() for v in out[:4]) + ({k: (v.clone() if t.is_tensor(v) else v) for k, v in info.items()},)
         return out
 
     def _finish_obs(self):

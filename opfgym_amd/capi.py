@@ -110,8 +110,7 @@ class StepIO(C.Structure):
                 ('penalties', C.c_void_p), ('cost', C.c_void_p), ('objective', C.c_void_p),
                 ('results', C.c_void_p), ('mean_correction', C.c_void_p),
                 ('converged', C.c_void_p), ('iterations', C.c_void_p), ('max_mismatch', C.c_void_p),
-                ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p),
-                ('autoreset_seed', C.c_uint64), ('final_obs', C.c_void_p)]
+                ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p)]
 
 
 class ProfileDesc(C.Structure):
@@ -141,7 +140,7 @@ _lib = None
 EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_plan_get_array',
            'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
-           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info', 'opfx_env_get_storage', 'opfx_env_set_autoreset']
+           'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info', 'opfx_env_get_storage']
 
 
 def lib():
@@ -181,7 +180,6 @@ def lib():
     L.opfx_step.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32, vp]
     L.opfx_env_set_reset.argtypes = [vp, C.POINTER(ResetDesc)]
     L.opfx_reset.argtypes = [vp, C.c_int64, C.POINTER(ResetIO), vp]
-    L.opfx_env_set_autoreset.argtypes = [vp, C.POINTER(ResetIO)]
     L.opfx_time_steps.argtypes = [vp, C.c_int64, C.POINTER(StepIO), C.POINTER(SolveOpts), C.c_int32,
                                   vp, C.POINTER(C.c_float)]
     L.opfx_env_get_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]

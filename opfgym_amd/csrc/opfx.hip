@@ -132,11 +132,6 @@ struct StepIO {
   int* total_iterations;
   double* min_pivot;
   int mode;
-  // autoreset (opfx_step_io.autoreset_seed != 0): the reset of the finished episode runs in the step's epilogue
-  const struct DevReset* ar_R;       // reset programme of the environment (device copy)
-  const struct ResetIO* ar_io;       // its inputs as registered with opfx_env_set_autoreset (device copy)
-  unsigned long long ar_seed;        // per-call seed of the in-kernel draws (0 = no autoreset)
-  double* final_obs;                 // [B,nobs] or NULL: the observation of the finished episode
 };
 
 struct Opts {
@@ -1701,165 +1696,220 @@ __device__ __forceinline__ double draw_normal(unsigned long long seed, long long
   return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
+// ---- where a reset reads what is the same for every instance -----------------------------------------------------
+// Everything but the profile rows themselves — the row template and the constants of the vector ops, the per-column
+// descriptors of the profile tables, the op list, the action and observation descriptors — is reached through a
+// source policy.  SrcGlobal reads it from global memory (L2-resident).  Round 3 also tried an image of it in LDS, copied
+// once per persistent workgroup, so that a row's chain of ~20 L2 round trips shrinks to the time step, the profile
+// values and the stores: 64.9 us per reset of 8192 instances against 56.8 us for this form — the image leaves room for
+// 13 rows per CU instead of 16 and the rows no longer divide evenly over the wavefronts (profiles/r03_reset_experiments.txt);
+// removed again.
+enum { OPF_CODE = 0, OPF_DST, OPF_A, OPF_N, OPF_C0, OPF_C1, OPF_C2, OPF_MODE, OPF_FIELDS };
+enum { AI_SLOT = 0, AI_LO_SLOT, AI_HI_SLOT, AI_KIND, AI_CLAMP_LO_SLOT, AI_CLAMP_HI_SLOT, AI_FIELDS };
+enum { AD_LO = 0, AD_HI, AD_SCALING, AD_CLAMP_LO, AD_CLAMP_HI, AD_FIELDS };
+enum { OS_KIND = 0, OS_SRC, OS_DST, OS_N, OS_FIELDS };
+struct EnvScalars { int na, nobs, n_oseg, clamp_enabled; };
+
+struct SrcGlobal {
+  const DevReset& R;
+  const DevEnv* E;
+  __device__ __forceinline__ EnvScalars env() const { return E ? EnvScalars{E->na, E->nobs, E->n_oseg, E->clamp_enabled} : EnvScalars{0, 0, 0, 0}; }
+  __device__ __forceinline__ double cst(int off) const { return R.consts[off]; }
+  __device__ __forceinline__ int t_typ(int t, int j) const { return R.tab[t].typ[j]; }
+  __device__ __forceinline__ int t_slot(int t, int j) const { return R.tab[t].slot[j]; }
+  __device__ __forceinline__ double t_peak(int t, int j) const { return R.tab[t].peak[j]; }
+  __device__ __forceinline__ double t_lo(int t, int j) const { return R.tab[t].col_min[j]; }
+  __device__ __forceinline__ double t_hi(int t, int j) const { return R.tab[t].col_max[j]; }
+  __device__ __forceinline__ int op(int f, int k) const {
+    const int* const* tabs[OPF_FIELDS] = {&R.op_code, &R.op_dst, &R.op_a, &R.op_n, &R.op_c0, &R.op_c1, &R.op_c2, &R.op_mode};
+    return (*tabs[f])[k];
+  }
+  __device__ __forceinline__ bool has_op_mode() const { return R.op_mode != nullptr; }
+  __device__ __forceinline__ int ai(int f, int k) const {
+    const int* p = f == AI_SLOT ? E->act_slot : f == AI_LO_SLOT ? E->act_lo_slot : f == AI_HI_SLOT ? E->act_hi_slot
+                 : f == AI_KIND ? E->act_kind : f == AI_CLAMP_LO_SLOT ? E->clamp_lo_slot : E->clamp_hi_slot;
+    return as_global(p)[k];
+  }
+  __device__ __forceinline__ double ad(int f, int k) const {
+    const double* p = f == AD_LO ? E->act_lo_const : f == AD_HI ? E->act_hi_const : f == AD_SCALING ? E->act_scaling
+                    : f == AD_CLAMP_LO ? E->clamp_lo_const : E->clamp_hi_const;
+    return as_global(p)[k];
+  }
+  __device__ __forceinline__ int os(int f, int sg) const {
+    const int* p = f == OS_KIND ? E->oseg_kind : f == OS_SRC ? E->oseg_src : f == OS_DST ? E->oseg_dst : E->oseg_n;
+    return as_global(p)[sg];
+  }
+};
+
 // The reset of ONE instance by one wavefront: the row is built in LDS (`row`: nx doubles, `sp`: na doubles) — template
 // -> profile values -> vector-op programme -> optionally the initial action and the table observation
 // (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make a round trip
-// through memory.  Called by k_reset (a launch of its own) and by k_step's epilogue (opfx_step_io.autoreset_seed:
-// the reset of a finished single-step episode inside the launch of its step).
-// U: 64-column chunks whose loads are requested together (k_reset: 4 — nothing else hides its round trips; inside
-// k_step: 1 — the CU's other instances do, and four chunks' worth of registers on top of the step's own would spill).
-template <bool CACHED, int U>
-__device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b, int lane,
-                          double* const row, double* const sp, const int (&okind)[8], const int (&osrc)[8],
-                          const int (&odst)[8], const int (&on)[8]) {
+// through memory.  U: 64-column chunks whose loads are requested together (nothing else hides the round trips).
+// (Round 3 also ran this function in the epilogue of the step kernel, the reset of a finished single-step episode
+// inside the launch of its step: bit-identical rows, but 404.6 us per launch against 270.3 + 56.8 us for the two
+// launches — the step kernel's throughput is waves / latency per instance, and the reset's chain of round trips adds
+// its whole latency to every instance; profiles/r03_reset_experiments.txt.  Removed again.)
+template <class SRC, int U>
+__device__ __forceinline__ void reset_row(const SRC& S, const DevReset& R, const ResetIO& io, long long b, int lane,
+                                          double* const row, double* const sp) {
   const double NaN = __builtin_nan("");
-  {
-    double* xr = io.x + b * R.nx;
-    int step;
-    if (io.step_pool) {
-      // counter-based draw: uniform over the pool up to a bias of n / 2^64
-      const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1));
-      step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
-      if (lane == 0 && io.step_out) io.step_out[b] = step;
-    } else {
-      step = io.step_idx[b];
+  double* xr = io.x + b * R.nx;
+  int step;
+  if (io.step_pool) {
+    // counter-based draw: uniform over the pool up to a bias of n / 2^64
+    const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1));
+    step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
+    if (lane == 0 && io.step_out) io.step_out[b] = step;
+  } else {
+    step = io.step_idx[b];
+  }
+  const int mode = (io.mode && S.has_op_mode()) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
+  // start of the row: the table template, or the instance's own row (keep_state) — two loops, so that each reads from
+  // ONE address space (a select between an LDS and a global address would make every load a flat one)
+  if (R.init_off >= 0 && !io.keep_state) {
+    for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
+      double t[2 * U];
+#pragma unroll
+      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = S.cst(R.init_off + (j < R.nx ? j : R.nx - 1)); }
+#pragma unroll
+      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
     }
-    const int mode = (io.mode && R.op_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-    // Every loop of this kernel is a chain of global-memory round trips (L2-resident descriptors, ~0.3 us each) with
-    // nothing else to hide them: four 64-column chunks at a time, all their loads — unconditional, clamped indices —
-    // requested before the first use, cut the round trips of a row from ~60 to ~20.
-    {
-      const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
-      for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
-        double t[2 * U];
+  } else {
+    for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
+      double t[2 * U];
 #pragma unroll
-        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
+      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = xr[j < R.nx ? j : R.nx - 1]; }
 #pragma unroll
-        for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
+      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
+    }
+  }
+  wave_fence();
+  for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
+    const DevTable& T = R.tab[t];
+    const double* rw = T.rel + (long long)step * T.n_types;
+    const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
+    const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
+    const int nc = T.n_cols;
+    const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
+    for (int j0 = lane; j0 < nc; j0 += 64 * U) {
+      int typ[U], slot[U];
+      double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
+        typ[u] = S.t_typ(t, jc); slot[u] = S.t_slot(t, jc); peak[u] = S.t_peak(t, jc); lo[u] = S.t_lo(t, jc); hi[u] = S.t_hi(t, jc);
+        nz[u] = nzp ? nzp[jc] : 1.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        double v = r0[u] * peak[u];                                                // :343
+        if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
+        if (nzp) {
+          if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
+          else v = v * nz[u];                                                      // :354-356
+        }
+        v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
+        if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
       }
     }
-    wave_fence();
-    for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
-      const DevTable& T = R.tab[t];
-      const double* rw = T.rel + (long long)step * T.n_types;
-      const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
-      const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
-      const int nc = T.n_cols;
-      const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
-      for (int j0 = lane; j0 < nc; j0 += 64 * U) {
-        int typ[U], slot[U];
-        double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
+  }
+  wave_fence();
+  for (int k = 0; k < R.n_ops; ++k) {
+    if (mode >= 0 && !((S.op(OPF_MODE, k) >> mode) & 1)) continue;
+    const int code = S.op(OPF_CODE, k), dst = S.op(OPF_DST, k), a = S.op(OPF_A, k), n = S.op(OPF_N, k);
+    const int o0 = S.op(OPF_C0, k), o1 = S.op(OPF_C1, k), o2 = S.op(OPF_C2, k);
+    // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
+    const bool has0 = o0 >= 0, has1 = o1 >= 0, has2 = o2 >= 0;
+    const int b0 = has0 ? o0 : 0, b1 = has1 ? o1 : 0, b2 = has2 ? o2 : 0;
+    // per-instance draw of the op, if it has one (same chunked, unconditional access); no draw array given: the
+    // kernel draws them itself from the per-reset seed, see draw_uniform
+    const double* draw = (code == OPFX_OP_UNIFORM && io.uniform) ? io.uniform + b * R.n_uniform + a
+                       : ((code == OPFX_OP_NORMAL && io.normal) ? io.normal + b * R.n_normal + a : nullptr);
+    const bool own_u = code == OPFX_OP_UNIFORM && !io.uniform, own_n = code == OPFX_OP_NORMAL && !io.normal;
+    const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
+    for (int j0 = lane; j0 < n; j0 += 64 * U) {
+      double k0[U], k1[U], k2[U], dr[U], rv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
-          typ[u] = T.typ[jc]; slot[u] = T.slot[jc]; peak[u] = T.peak[jc]; lo[u] = T.col_min[jc]; hi[u] = T.col_max[jc];
-          nz[u] = nzp ? nzp[jc] : 1.0;
-        }
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
+        k0[u] = has0 ? S.cst(b0 + jc) : 0.0; k1[u] = has1 ? S.cst(b1 + jc) : 0.0; k2[u] = has2 ? S.cst(b2 + jc) : 0.0;
+        dr[u] = draw ? draw[jc] : (own_u ? draw_uniform(io.rng_seed, b, (unsigned)(a + jc)) : (own_n ? draw_normal(io.rng_seed, b, (unsigned)(a + jc)) : 0.0));
+        rv[u] = reads_row ? row[a + jc] : 0.0;
+      }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          double v = r0[u] * peak[u];                                                // :343
-          if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
-          if (nzp) {
-            if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
-            else v = v * nz[u];                                                      // :354-356
-          }
-          v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
-          if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
-        }
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + 64 * u;
+        double v;
+        if (code == OPFX_OP_SET_CONST) v = k0[u];
+        else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
+        else if (code == OPFX_OP_SQRT_DIFF) { const double s_ = k0[u], pz = rv[u]; v = sqrt(s_ * s_ - pz * pz); }
+        else if (code == OPFX_OP_NEG) v = -rv[u];
+        else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
+        else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
+        else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
+        else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
+        else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
+        else v = rv[u] / k0[u];
+        if (j < n) row[dst + j] = v;
       }
     }
-    wave_fence();
-    for (int k = 0; k < R.n_ops; ++k) {
-      if (mode >= 0 && !((R.op_mode[k] >> mode) & 1)) continue;
-      const int code = R.op_code[k], dst = R.op_dst[k], a = R.op_a[k], n = R.op_n[k];
-      // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
-      const double* c0 = R.consts + (R.op_c0[k] >= 0 ? R.op_c0[k] : 0);
-      const double* c1 = R.consts + (R.op_c1[k] >= 0 ? R.op_c1[k] : 0);
-      const double* c2 = R.consts + (R.op_c2[k] >= 0 ? R.op_c2[k] : 0);
-      const bool has0 = R.op_c0[k] >= 0, has1 = R.op_c1[k] >= 0, has2 = R.op_c2[k] >= 0;
-      // per-instance draw of the op, if it has one (same chunked, unconditional access)
-      // (no draw array given: the kernel draws them itself from the per-reset seed, see draw_uniform)
-      const double* draw = (code == OPFX_OP_UNIFORM && io.uniform) ? io.uniform + b * R.n_uniform + a
-                         : ((code == OPFX_OP_NORMAL && io.normal) ? io.normal + b * R.n_normal + a : nullptr);
-      const bool own_u = code == OPFX_OP_UNIFORM && !io.uniform, own_n = code == OPFX_OP_NORMAL && !io.normal;
-      const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
-      for (int j0 = lane; j0 < n; j0 += 64 * U) {
-        double k0[U], k1[U], k2[U], dr[U], rv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
-          k0[u] = has0 ? c0[jc] : 0.0; k1[u] = has1 ? c1[jc] : 0.0; k2[u] = has2 ? c2[jc] : 0.0;
-          dr[u] = draw ? draw[jc] : (own_u ? draw_uniform(io.rng_seed, b, (unsigned)(a + jc)) : (own_n ? draw_normal(io.rng_seed, b, (unsigned)(a + jc)) : 0.0));
-          rv[u] = reads_row ? row[a + jc] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * u;
-          double v;
-          if (code == OPFX_OP_SET_CONST) v = k0[u];
-          else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
-          else if (code == OPFX_OP_SQRT_DIFF) { const double s = k0[u], pz = rv[u]; v = sqrt(s * s - pz * pz); }
-          else if (code == OPFX_OP_NEG) v = -rv[u];
-          else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
-          else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
-          else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
-          else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
-          else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
-          else v = rv[u] / k0[u];
-          if (j < n) row[dst + j] = v;
-        }
-      }
-      wave_fence();
-    }
-    if (io.obs && Ep) {
-      // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
-      // table part of the observation (:218); result entries are NaN
-      const DevEnv& E = *Ep;
-      for (int k = lane; k < E.na; k += 64) {
-        // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
-        const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
-        const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
-        const int kind = as_global(E.act_kind)[k];
-        const bool clampa = (E.clamp_enabled & 2) != 0;
-        const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
-        const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
-        const double* act_row = io.action ? io.action + b * E.na : E.act_lo_const;      // (any readable row)
-        double a = act_row[k];
-        double xv = row[slot];
-        if (io.action) {
-          a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
-          const double lo = ls >= 0 ? row[ls] : loc;
-          const double hi = hs >= 0 ? row[hs] : hic;
-          double spt = a * (hi - lo) + lo;                                              // :461
-          if (clampa) {                                                                 // :464-470 (autoscale off)
-            if (ch > -2) { const double m = ch >= 0 ? row[ch] : chc; if (spt > m) spt = m; }
-            if (cl > -2) { const double m = cl >= 0 ? row[cl] : clc; if (spt < m) spt = m; }
-          }
-          xv = spt / scal;                                                              // :472-474
-          if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
-        }
-        sp[k] = xv;
-        if (E.na <= 64) {          // one chunk: the lane still knows its slot — (limits are read before any set-point is written)
-          wave_fence();
-          row[slot] = xv;
-        }
-      }
-      wave_fence();
-      if (E.na > 64) { for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k]; }
-      wave_fence();
-      for (int sg = 0; sg < E.n_oseg; ++sg) {
-        const bool c = CACHED && sg < 8;
-        const int kind = c ? okind[sg & 7] : as_global(E.oseg_kind)[sg], src = c ? osrc[sg & 7] : as_global(E.oseg_src)[sg];
-        const int dst = c ? odst[sg & 7] : as_global(E.oseg_dst)[sg], n = c ? on[sg & 7] : as_global(E.oseg_n)[sg];
-        for (int j = lane; j < n; j += 64)
-          io.obs[b * E.nobs + dst + j] = kind == 1 ? NaN : (kind == 0 ? row[src + j] : sp[src + j]);
-      }
-    }
-    for (int j = lane; j < R.nx; j += 64) xr[j] = row[j];
     wave_fence();
   }
+  const EnvScalars es = S.env();
+  if (io.obs) {
+    // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
+    // table part of the observation (:218); result entries are NaN
+    for (int k = lane; k < es.na; k += 64) {
+      // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
+      const int slot = S.ai(AI_SLOT, k), ls = S.ai(AI_LO_SLOT, k), hs = S.ai(AI_HI_SLOT, k), kind = S.ai(AI_KIND, k);
+      const double loc = S.ad(AD_LO, k), hic = S.ad(AD_HI, k), scal = S.ad(AD_SCALING, k);
+      const bool clampa = (es.clamp_enabled & 2) != 0;
+      const int ch = clampa ? S.ai(AI_CLAMP_HI_SLOT, k) : -2, cl = clampa ? S.ai(AI_CLAMP_LO_SLOT, k) : -2;
+      const double chc = clampa ? S.ad(AD_CLAMP_HI, k) : 0.0, clc = clampa ? S.ad(AD_CLAMP_LO, k) : 0.0;
+      double a = io.action ? io.action[b * es.na + k] : 0.0;
+      double xv = row[slot];
+      if (io.action) {
+        a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
+        const double lo = ls >= 0 ? row[ls] : loc;
+        const double hi = hs >= 0 ? row[hs] : hic;
+        double spt = a * (hi - lo) + lo;                                              // :461
+        if (clampa) {                                                                 // :464-470 (autoscale off)
+          if (ch > -2) { const double m = ch >= 0 ? row[ch] : chc; if (spt > m) spt = m; }
+          if (cl > -2) { const double m = cl >= 0 ? row[cl] : clc; if (spt < m) spt = m; }
+        }
+        xv = spt / scal;                                                              // :472-474
+        if (kind != OPFX_ACT_CONTINUOUS) { xv = rint(xv); if (kind == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0; }
+      }
+      sp[k] = xv;
+    }
+    // (limits are read before any set-point is written: all set-points first, then their slots)
+    wave_fence();
+    for (int k = lane; k < es.na; k += 64) row[S.ai(AI_SLOT, k)] = sp[k];
+    wave_fence();
+    for (int sg = 0; sg < es.n_oseg; ++sg) {
+      const int kind = S.os(OS_KIND, sg), src = S.os(OS_SRC, sg), dst = S.os(OS_DST, sg), n = S.os(OS_N, sg);
+      // (LDS reads of several chunks before their stores: one LDS round trip per group instead of one per chunk)
+      double* const out = io.obs + b * es.nobs + dst;
+      const double* const from = (kind == 2 ? sp : row) + src;
+      for (int j0 = lane; j0 < n; j0 += 64 * U) {
+        double t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int j = j0 + 64 * u; t[u] = kind == 1 ? NaN : from[j < n ? j : n - 1]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int j = j0 + 64 * u; if (j < n) out[j] = t[u]; }
+      }
+    }
+  }
+  for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
+    double t[2 * U];
+#pragma unroll
+    for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = row[j < R.nx ? j : R.nx - 1]; }
+#pragma unroll
+    for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) xr[j] = t[u]; }
+  }
+  wave_fence();
 }
 
 __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
@@ -1870,15 +1920,9 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
   double* const sp = row + ((R.nx + 1) & ~1);
   const long long w = (long long)blockIdx.x * wpb + wib;
   const long long nw = (long long)gridDim.x * wpb;
-  // observation segments: the same for every instance, the first eight read once per wavefront
-  int okind[8], osrc[8], odst[8], on[8];
-#pragma unroll
-  for (int sg = 0; sg < 8; ++sg) {
-    const bool have = io.obs && Ep && sg < Ep->n_oseg;
-    okind[sg] = have ? as_global(Ep->oseg_kind)[sg] : 0; osrc[sg] = have ? as_global(Ep->oseg_src)[sg] : 0;
-    odst[sg] = have ? as_global(Ep->oseg_dst)[sg] : 0; on[sg] = have ? as_global(Ep->oseg_n)[sg] : 0;
-  }
-  for (long long b = w; b < B; b += nw) reset_row<true, 4>(R, Ep, io, b, lane, row, sp, okind, osrc, odst, on);
+  if (!Ep) io.obs = nullptr;
+  const SrcGlobal S{R, Ep};
+  for (long long b = w; b < B; b += nw) reset_row<SrcGlobal, 4>(S, R, io, b, lane, row, sp);
 }
 
 // cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
@@ -1934,12 +1978,6 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
-  // autoreset: the observation buffer receives the first observation of the NEXT episode (written by reset_row in the
-  // epilogue); the step's own — last — observation goes to final_obs, or nowhere
-  // (single-wave kernels only: the grids of the wave teams spend milliseconds per step, a reset's 0.06 ms does not
-  //  matter there, and the extra code costs their register allocation a few spills — opfx_step refuses it for them)
-  const bool autoreset = NW == 1 && io.ar_seed != 0;
-  double* const obs_step = autoreset ? io.final_obs : io.obs;
   if (V2) {
     for (int i = tid; i < nb; i += NT) L.dg[i] = (unsigned short)P.diag_blk[i];
     for (int i = tid; i < P.tail_n; i += NT) L.tl[i] = P.tail_ids[i];
@@ -2025,14 +2063,14 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     // (limits are read before any set-point of this step is written back: xs keeps the
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
-    if (wave == 0 && obs_step) for (int sg = 0; sg < E.n_oseg; ++sg) {
+    if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
       const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
       if (kind == 1) {
-        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = NaN;
+        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = NaN;
         continue;
       }
       const double* from = (kind == 0 ? xs : L.sp) + src;
-      for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = from[j];
+      for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = from[j];
     }
     if (io.mode == 2 || io.mode == 3) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
@@ -2285,10 +2323,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       }
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
-      if (obs_step) for (int sg = 0; sg < E.n_oseg; ++sg) {
+      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         if (as_global(E.oseg_kind)[sg] != 1) continue;
         const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
-        for (int j = lane; j < n; j += WAVE) obs_step[b * E.nobs + dst + j] = R[src + j];
+        for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = R[src + j];
       }
       }
       blk_sync<NW>();
@@ -2299,7 +2337,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
       __builtin_amdgcn_s_waitcnt(0);      // the table observations written above are overwritten
-      if (obs_step) for (int k = lane; k < E.nobs; k += WAVE) obs_step[b * E.nobs + k] = NaN;
+      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
       if (lane < E.nc) {
         if (io.valids) io.valids[b * E.nc + lane] = 0;
         if (io.violations) io.violations[b * E.nc + lane] = 1.0;
@@ -2361,22 +2399,6 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       if (io.total_iterations) io.total_iterations[b] = iters_all;
       if (io.min_pivot) io.min_pivot[b] = min_piv;
     }
-    if (NW == 1 && autoreset) {
-      // Single-step episodes end with every step (opf_env.py:406-414): this row starts its next episode here — a new
-      // time step, profile values, the `_sampling` tail, the initial action, the first observation — built in the
-      // staging area (free again) and stored over the row.  One launch per reset + step cycle: the reset's chain of
-      // L2 round trips hides behind the Newton phases of the CU's other instances.
-      wave_fence();
-      __builtin_amdgcn_s_waitcnt(0);            // (the set-points this step wrote into the row are overwritten)
-      // (pointers laundered through an empty asm: everything read through them is loop-invariant, and the compiler
-      //  would otherwise hoist ~60 values out of the instance loop and keep them alive across the Newton phases)
-      const ResetIO* aio = io.ar_io; const DevReset* aR = io.ar_R; const DevEnv* aE = Ep;
-      asm volatile("" : "+s"(aio), "+s"(aR), "+s"(aE));
-      ResetIO rio = *aio;
-      rio.rng_seed = io.ar_seed;
-      const int none[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      reset_row<false, 1>(*aR, aE, rio, b, lane, xs, L.sp, none, none, none, none);
-    }
     }
     blk_sync<NW>();
   }
@@ -2421,9 +2443,7 @@ struct opfx_env {
   const DevEnv* d_de = nullptr;
   DevReset dr{};
   bool has_reset = false;
-  const DevReset* d_dr = nullptr;      // device copy (autoreset inside opfx_step)
-  ResetIO* d_ar = nullptr;             // device copy of the registered autoreset inputs
-  bool has_autoreset = false;
+
   DevArena arena;
   size_t lds_bytes = 0;
   int per_cu = 0;
@@ -2864,15 +2884,6 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
-  s.ar_R = nullptr; s.ar_io = nullptr; s.ar_seed = 0; s.final_obs = nullptr;
-  if (io->autoreset_seed != 0) {
-    if (!env->has_autoreset || mode != 0 || env->de.steps_per_episode != 1 || team != 1) {
-      opfx_set_error("opfx_step: autoreset needs opfx_env_set_autoreset, mode 0, single-step episodes and a grid that runs "
-                     "on the single-wave kernel (opfx_env_get_info: waves_per_instance == 1)");
-      return OPFX_ERR_INVALID;
-    }
-    s.ar_R = env->d_dr; s.ar_io = env->d_ar; s.ar_seed = (unsigned long long)io->autoreset_seed; s.final_obs = io->final_obs;
-  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
@@ -2966,39 +2977,8 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   PUTN(op_c2, d->op_c2, d->n_ops); PUTN(consts, d->consts, d->n_consts);
   if (d->op_mode) { PUTN(op_mode, d->op_mode, d->n_ops); }
 #undef PUTN
-  if (rc == OPFX_OK) rc = A.put(&env->dr, 1, &env->d_dr);
   if (rc != OPFX_OK) return rc;
   env->has_reset = true;
-  env->has_autoreset = false;
-  return OPFX_OK;
-}
-
-static int check_reset_io(const opfx_env* env, const opfx_reset_io* io, const char* who) {
-  if (!io->step_idx && !(io->step_pool && io->n_step_pool > 0)) { opfx_set_error(std::string(who) + ": step_idx or step_pool required"); return OPFX_ERR_INVALID; }
-  if (!io->x) { opfx_set_error(std::string(who) + ": x required"); return OPFX_ERR_INVALID; }
-  return OPFX_OK;
-}
-
-extern "C" int opfx_env_set_autoreset(opfx_env* env, const opfx_reset_io* io) {
-  if (!env) { opfx_set_error("opfx_env_set_autoreset: null environment"); return OPFX_ERR_INVALID; }
-  if (!io) { env->has_autoreset = false; return OPFX_OK; }
-  if (!env->has_reset) { opfx_set_error("opfx_env_set_autoreset: opfx_env_set_reset not called"); return OPFX_ERR_INVALID; }
-  int rc = check_reset_io(env, io, "opfx_env_set_autoreset");
-  if (rc != OPFX_OK) return rc;
-  if (!io->obs) { opfx_set_error("opfx_env_set_autoreset: obs required (the first observation of the next episode)"); return OPFX_ERR_INVALID; }
-  if ((size_t)(((env->dr.nx + 1) & ~1)) > (size_t)(2 * ((env->ctx->plan.nb + 1) & ~1) + env->de.nblk_d)) {
-    opfx_set_error("opfx_env_set_autoreset: table row does not fit the staging area"); return OPFX_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(env->ctx->device));
-  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
-            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
-  if (!env->d_ar) {
-    void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(ResetIO)));
-    env->arena.ptrs.push_back(d);
-    env->d_ar = static_cast<ResetIO*>(d);
-  }
-  HIP_TRY(hipMemcpy(env->d_ar, &r, sizeof(ResetIO), hipMemcpyHostToDevice));
-  env->has_autoreset = true;
   return OPFX_OK;
 }
 
@@ -3015,13 +2995,13 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   const int row_doubles = ((nx + 1) & ~1) + ((na + 1) & ~1);
   const size_t row_bytes = (size_t)row_doubles * sizeof(double);
   if (row_bytes > 160 * 1024) { opfx_set_error("opfx_reset: table row does not fit the LDS"); return OPFX_ERR_TOO_LARGE; }
+  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
+            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
   const int wpb = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
   const size_t lds = wpb * row_bytes;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * 8);
-  ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
-            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
   hipLaunchKernelGGL(k_reset, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
                      (long long)B, row_doubles);
   HIP_TRY(hipGetLastError());

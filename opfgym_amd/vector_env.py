@@ -26,8 +26,8 @@ class OpfVectorEnv:
           `step()` call; the returned observation is the first one of the new episode and the
           last one of the old episode is in `info['final_obs']` (rows flagged by `info['_final_obs']`).
           With the single-step benchmark environments one call is therefore one full
-          reset + step cycle for the whole batch: ONE kernel launch where the environment can reset inside the
-          step's launch (`can_fuse_autoreset`; `fused=False` forces the two-launch form), two otherwise.
+          reset + step cycle for the whole batch: two kernel launches (running the reset inside the step's launch
+          was built and measured in round 3 and is slower, DESIGN.md §4 k_reset).
       'next_step' — the reset happens in the NEXT `step()` call, whose action is ignored for
           those rows (reward 0, not terminated).
       'disabled' — the caller resets.
@@ -36,13 +36,9 @@ class OpfVectorEnv:
     the host instead).
     """
 
-    def __init__(self, env, autoreset_mode='same_step', as_numpy=False, fused=True, want_final_obs=True):
-        """fused: use the in-launch reset where the environment allows it (`BatchedOpfEnv.can_fuse_autoreset`);
-        want_final_obs=False skips writing the finished episodes' last observation (nobody bootstraps from the last
-        state of a single-step episode) and saves its HBM traffic."""
+    def __init__(self, env, autoreset_mode='same_step', as_numpy=False):
         assert autoreset_mode in ('same_step', 'next_step', 'disabled')
         self.env = env
-        self.fused, self.want_final_obs = bool(fused), bool(want_final_obs)
         self.num_envs = env.B
         self.autoreset_mode = autoreset_mode
         self.as_numpy = as_numpy
@@ -109,16 +105,6 @@ class OpfVectorEnv:
             self._pending = done
             return self._out(obs), self._out(reward), self._out(term), self._out(trunc), \
                 {k: self._out(v) for k, v in info.items()}
-        if self.autoreset_mode == 'same_step' and self.fused and env.can_fuse_autoreset:
-            # single-step episodes on the single-wave kernel: the reset runs in the epilogue of the step's launch
-            # (opfx_step_io.autoreset_seed) — ONE launch per reset + step cycle of the whole batch
-            obs, reward, term, trunc, info = env.step(actions, autoreset=True, want_final_obs=self.want_final_obs)
-            info = dict(info)
-            if 'final_obs' in info:
-                info['final_obs'] = self._out(info['final_obs'])
-            info['_final_obs'] = self._out(term)
-            return self._out(obs), self._out(reward), self._out(term), self._out(trunc), \
-                {k: (self._out(v) if k != 'final_obs' else v) for k, v in info.items()}
         obs, reward, term, trunc, info = env.step(actions)
         info = dict(info)
         if self.autoreset_mode == 'same_step' and env.steps_per_episode == 1:
@@ -156,7 +142,7 @@ class OpfVectorEnv:
 
 def make_vec(env_id, num_envs, **kwargs):
     """`gymnasium.make_vec`-like constructor: make_vec('VoltageControl-v0', 8192, device='cuda:0')."""
-    vec_kw = {k: kwargs.pop(k) for k in ('autoreset_mode', 'as_numpy', 'fused', 'want_final_obs') if k in kwargs}
+    vec_kw = {k: kwargs.pop(k) for k in ('autoreset_mode', 'as_numpy') if k in kwargs}
     cls = getattr(_envs, ENV_IDS[env_id])
     return OpfVectorEnv(cls(batch_size=num_envs, **kwargs), **vec_kw)
 

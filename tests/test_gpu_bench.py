@@ -57,3 +57,32 @@ def test_bench_default_line_carries_cpu_baseline_and_voltage_check():
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and cb['all_cores']['cores'] >= 1
     assert 'oracle' in cb['sample']
     assert d['config']['max_abs_v_err_pu'] is not None and d['config']['max_abs_v_err_pu'] < 1e-9
+
+
+def test_two_ranks_on_the_one_gpu_run_the_multi_gpu_path_end_to_end(tmp_path):
+    """The path the driver calls on an 8-GPU node — self-launch of the ranks, strong sharding of a BASELINE batch,
+    the overlapped all-gather of the rewards — run once on hardware: two ranks sharing GPU 0 (OPFX_BENCH_SHARE_GPU,
+    gloo staging through the host).  Rank 0's gathered rewards must be the concatenation of what each shard computes
+    on its own in a single-process run with that rank's seeds.  No scaling number is read off this."""
+    import numpy as np
+    env = dict(os.environ, OPFX_BENCH_SHARE_GPU='1', OPFX_DIST_BACKEND='gloo', OPFX_BENCH_CPU_BUDGET='1')
+    full = tmp_path / 'full.npy'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', '4', '--batch', '4096',
+                        '--steps', '3', '--warmup', '1', '--dump-reward', str(full)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['batch_total'] == 8192 and d['config']['batch_per_gpu'] == 4096
+    assert d['config']['parallelism'] == 'shard2' and 'all_gather(reward)' in d['config']['collective']
+    assert d['cpu_baseline'] is None and d['value'] > 0
+    got = np.load(full)
+    assert got.shape == (8192,) and np.isfinite(got).all()
+    for rank in (0, 1):
+        part = tmp_path / f'part{rank}.npy'
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--config', '4', '--batch', '4096',
+                            '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--as-rank', str(rank), '--dump-reward', str(part)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=os.environ.copy())
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert np.array_equal(np.load(part), got[rank * 4096:(rank + 1) * 4096]), rank
