@@ -81,6 +81,10 @@ typedef struct opfx_case {
   const double* br_y;        /* [nbr*8] yff.re,yff.im,yft.re,yft.im,ytf.re,ytf.im,ytt.re,ytt.im */
   const double* br_kf;       /* [nbr] loading_percent = max(|If|*kf, |It|*kt) */
   const double* br_kt;       /* [nbr]                                        */
+  /* optional, for opfx_solve_opts.init = OPFX_INIT_DC (pypower makeBdc): per branch b = 1 / (x * |tap|) in p.u. (0
+   * for a branch that couples nothing) and its phase-shift injection b * (-shift [rad]); NULL: no DC start */
+  const double* br_bdc;      /* [nbr] */
+  const double* br_pfinj;    /* [nbr] */
 } opfx_case;
 
 typedef struct opfx_plan opfx_plan;   /* host-side compiled structure        */
@@ -109,6 +113,7 @@ typedef struct opfx_plan_info {
   int32_t team_kb[2];        /* rounds before the dense tail's register chain (= team_rounds without a tail) */
   int32_t tail_m;            /* pivots of the dense tail (final levels with one pivot each), 0 = none */
   int32_t lp_ell_width;      /* off-diagonal Ybus entries per bus row in the row's own lane (LP_A_ENT: [ra][width][64]) */
+  int32_t has_dc;            /* 1 = the case carried br_bdc / br_pfinj: opfx_solve_opts.init = OPFX_INIT_DC is available */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
@@ -137,7 +142,10 @@ enum {
   OPFX_ARR_LP_B2                        /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
-enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y };
+enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y,
+       OPFX_DARR_LP_DC,   /* [ra][width + 2][64]: B'_ij of the row's ELL entries, B'_ii, and the constant part of the DC
+                           * right-hand side of bus i (phase-shift injections + shunt conductance + B'_i,ref theta_ref) */
+       OPFX_DARR_LP_H_DC  /* [rh][64]: B'_ij of the overflow entries */ };
 int64_t opfx_plan_get_darray(const opfx_plan* p, int which, double* out, int64_t cap);
 int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* out, int64_t cap);
 /* Ybus values in the plan's CSR order: out_g/out_b [nnz_y]. */
@@ -170,10 +178,18 @@ void opfx_version(int* major, int* minor, int* patch);
  * security_constrained.py:44-66.
  * B = 0 (an empty batch) is a no-op that returns OPFX_OK for opfx_solve, opfx_step and
  * opfx_reset alike; the batch buffers may then be NULL. */
+enum { OPFX_INIT_FLAT = 0, OPFX_INIT_DC = 1 };
 typedef struct opfx_solve_opts {
   double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
   int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */
   int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits */
+  int32_t init;              /* start of the base-case Newton iteration: OPFX_INIT_FLAT (0, default): |V| = 1 (set-points at
+                              * PV / REF buses), angles = the slack angle carried through the transformer phase shifts;
+                              * OPFX_INIT_DC (1): angles from a DC power flow B' theta = P first (pandapower init='dc',
+                              * its 'auto' choice whenever voltage angles are calculated, i.e. for grids fed above 70 kV):
+                              * one linear solve through the same block-LU schedule.  Same fixed point, other iteration
+                              * counts.  Applies to solves on the compiled topology (no outage / switch / tap modifier:
+                              * those start flat). */
   int32_t contingency_start; /* opfx_step, N-1 loop: 0 = every contingency solve starts from the base-case
                               * solution (default; same fixed point, one iteration fewer), 1 = from the flat
                               * start, as the reference does by calling pandapower anew

@@ -292,7 +292,7 @@ class BatchedOpfEnv:
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
                  defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False,
-                 contingency_start='base_case', **kwargs):
+                 contingency_start='base_case', init='flat', **kwargs):
         from .objectives import QuadraticDeviation
         terms = objective_function if isinstance(objective_function, (list, tuple)) else \
             ([objective_function] if objective_function is not None else [])
@@ -389,13 +389,20 @@ class BatchedOpfEnv:
             assert column in ('in_service', 'closed')                      # security_constrained.py:34-35
         self.not_converged_penalty = not_converged_penalty
         assert contingency_start in ('base_case', 'flat'), contingency_start
-        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)),
+        # init: start of the Newton iteration — 'flat' (default), 'dc' (pandapower's init='dc': angles from a DC power
+        # flow first), 'auto' (pandapower's default: 'dc' when voltage angles are calculated, i.e. grids fed above 70 kV)
+        assert init in ('flat', 'dc', 'auto'), init
+        self.init = init
+        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)), 0,
                                          int(contingency_start == 'flat'))
         self.np_random = np.random.default_rng(seed)
 
         # ---- compile the grid --------------------------------------------------
         self.case = _case_all_branches_in(net, self.act_keys)
         self.plan = capi.Plan(self.case)
+        if self.init == 'auto':
+            self.init = 'dc' if self.case.meta.get('calc_angles') else 'flat'
+        self.solve_opts.init = capi.INIT[self.init]
         self.store = ColumnStore(net)
         for tbl in ('load', 'sgen', 'storage'):
             self.store.slot(tbl, 'p_mw')

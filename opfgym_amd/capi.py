@@ -27,7 +27,7 @@ ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BL
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
           'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2']
-DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y']
+DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y', 'LP_DC', 'LP_H_DC']
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -41,7 +41,8 @@ class OpfxError(RuntimeError):
 class CaseStruct(C.Structure):
     _fields_ = [('nb', C.c_int32), ('nbr', C.c_int32), ('base_mva', C.c_double),
                 ('bus_type', _pi), ('vm_set', _pd), ('va_set', _pd), ('gs', _pd), ('bs', _pd),
-                ('br_f', _pi), ('br_t', _pi), ('br_y', _pd), ('br_kf', _pd), ('br_kt', _pd)]
+                ('br_f', _pi), ('br_t', _pi), ('br_y', _pd), ('br_kf', _pd), ('br_kt', _pd),
+                ('br_bdc', _pd), ('br_pfinj', _pd)]
 
 
 class PlanInfo(C.Structure):
@@ -50,7 +51,7 @@ class PlanInfo(C.Structure):
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
         'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full',
         'team_rounds_2', 'team_rounds_4', 'team_barriers_2', 'team_barriers_4', 'n_groups',
-        'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width')]
+        'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width', 'has_dc')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -58,7 +59,10 @@ class PlanInfo(C.Structure):
 
 class SolveOpts(C.Structure):
     _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32),
-                ('contingency_start', C.c_int32)]
+                ('init', C.c_int32), ('contingency_start', C.c_int32)]
+
+
+INIT = {'flat': 0, 'dc': 1}
 
 
 class EnvDesc(C.Structure):
@@ -224,6 +228,11 @@ class Plan:
         ya, yp = _d(y)
         keep.append(ya)
         cs.br_y = yp
+        if getattr(case, 'bdc', None) is not None and getattr(case, 'pfinj', None) is not None:
+            for name, arr in (('br_bdc', case.bdc), ('br_pfinj', case.pfinj)):
+                a, p = _d(np.nan_to_num(np.asarray(arr, dtype=float)))
+                keep.append(a)
+                setattr(cs, name, p)
         self.branch_y = ya
         h = C.c_void_p()
         check(lib().opfx_plan_create(C.byref(cs), C.byref(h)), 'opfx_plan_create')
@@ -298,7 +307,7 @@ def _stream():
 
 
 def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, tol=1e-8,
-          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref', 'q_gen')):
+          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref', 'q_gen'), init='flat'):
     """Batched power flow on torch CUDA tensors p_inj/q_inj [B, nb] (p.u.)."""
     import torch
     assert p_inj.is_cuda and p_inj.dtype == torch.float64 and p_inj.shape == q_inj.shape
@@ -321,7 +330,7 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
     out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
     out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
     out['min_pivot'] = torch.empty(B, dtype=torch.float64, device=dev)
-    opts = SolveOpts(float(tol), int(max_iter), int(bool(enforce_q_lims)))
+    opts = SolveOpts(float(tol), int(max_iter), int(bool(enforce_q_lims)), INIT[init], 0)
     with torch.cuda.device(dev):
         check(lib().opfx_solve(
             ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),

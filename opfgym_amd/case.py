@@ -47,6 +47,9 @@ class Case:
     br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo
     br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w
     br_side: np.ndarray = None    # int32 [nbr]  trafo3w: 0 hv, 1 mv, 2 lv winding of its star equivalent (else 0)
+    # DC model of the branches (pypower makeBdc; for opfx_solve_opts.init = OPFX_INIT_DC)
+    bdc: np.ndarray = None        # f64 [nbr]  1 / (x * ratio), 0 for a branch that couples nothing (open-ended)
+    pfinj: np.ndarray = None      # f64 [nbr]  bdc * (-shift in rad)
     # lookups back to the net
     bus_lookup: dict = field(default_factory=dict)   # net bus index -> case bus
     ref_elems: np.ndarray = None  # positional ext_grid rows per REF bus order
@@ -547,8 +550,20 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         br_kind=np.array([r[7] for r in rows], dtype=np.int32),
         br_elem=np.array([r[8] for r in rows], dtype=np.int32),
         br_side=np.array([r[12] for r in rows], dtype=np.int32),
+        bdc=_bdc(rows)[0], pfinj=_bdc(rows)[1],
         bus_lookup=bus_lookup, ref_elems=np.array(ref_elems, dtype=np.int32),
         meta={'calc_angles': calc_angles})
+
+
+def _bdc(rows):
+    """pypower `makeBdc` per branch: b = 1 / x, divided by the off-nominal ratio; phase-shift injection b * (-shift)."""
+    x = np.array([r[3] for r in rows], dtype=float)
+    ratio = np.array([r[5] for r in rows], dtype=float)
+    shift = np.array([r[6] for r in rows], dtype=float)
+    coupled = np.array([r[11] == 0 for r in rows], dtype=bool)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        b = np.where(coupled, 1.0 / x / ratio, 0.0)
+    return b, b * (-shift)
 
 
 def _propagate_angles(nb, f, t, shift, bus_type, va_set):

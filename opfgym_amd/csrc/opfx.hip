@@ -71,6 +71,7 @@ struct DevPlan {
   const unsigned* tail_bus;              // [32] bus | diagonal block << 16 of tail pivot e
   const unsigned short* tail_ids;        // [tail_m][M] id of U-block (row e, column s) at [e * M + s], M = tail_m rounded up to 8
   int team_rounds2, team_rounds4, team_kb2, team_kb4;
+  const double *lp_dc, *lp_hdc;          // DC start (plan.h): B' on the Ybus pattern + constant right-hand side; nullptr: none
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
 };
@@ -139,6 +140,7 @@ struct Opts {
   int max_iter;
   int enforce_q_lims;
   int contingency_start;     // opfx_solve_opts::contingency_start
+  int init;                  // opfx_solve_opts::init
 };
 
 // ---------------------------------------------------------------------------
@@ -1264,6 +1266,94 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   return conv;
 }
 
+// ---- DC start (opfx_solve_opts.init = OPFX_INIT_DC; pandapower init='dc', pypower dcpf) -----------------------------
+// theta of the free buses from B' theta = P - (phase-shift injections + Gs + B'_ref theta_ref), |V| as in the flat start.
+// B' has the Ybus pattern, so the solve runs through the Newton schedule itself: every block becomes [[B'_ij, 0], [0,
+// B'_ij]] (which the two-value storage (a, b) -> [[a, b], [-b, a]] represents exactly), the right-hand side (P_i - c_i, 0);
+// phases B and C as in an iteration; then V_i = |V_i| e^{j x_i}.  One linear solve before the first iteration, in a code
+// region of its own: the Newton loops keep their register allocation.
+template <bool PK>
+__device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int first, int stride, int lane) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const int nb = P.nb;
+  for (int r = first; r < P.ra; r += stride) {
+    const ARound a = load_around(P, r, lane);
+    const double* dc = P.lp_dc + (size_t)r * (KA + 2) * WAVE + lane;
+    double bij[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) bij[k] = dc[k * WAVE];
+    const double bii = dc[KA * WAVE], cst = dc[(KA + 1) * WAVE];
+    const int i = lane + WAVE * r;
+    if (i >= nb) continue;
+    const double p_sched = L.psp[i];
+    if (L.bt[i] == BT_REF) continue;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const unsigned bid = a.ent[k] >> 16;
+      if (bid != NONE) st_blk2<PK>(L, bid, Blk{bij[k], 0.0, 0.0, bij[k]});
+    }
+    st_blk2<PK>(L, a.dw & 0xFFFF, Blk{bii, 0.0, 0.0, bii});
+    L.rhs[i] = p_sched - cst;
+    L.rq[i] = 0.0;
+  }
+}
+template <bool PK>
+__device__ __forceinline__ void dc_overflow(const DevPlan& P, const Lds& L, int first, int stride, int lane) {
+  constexpr unsigned NONE = 0xFFFFu;
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
+  for (int h = first; h < P.rh; h += stride) {
+    const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+    const double b = P.lp_hdc[(size_t)h * WAVE + lane];
+    const unsigned bid = he.x >> 16;
+    if ((he.x & 0xFFFF) != NONE && bid != NONE) st_blk2<PK>(L, bid, Blk{b, 0.0, 0.0, b});
+  }
+}
+__device__ __forceinline__ void dc_update(const Lds& L, int nb, int first, int stride) {
+  for (int i = first; i < nb; i += stride) {
+    if (L.bt[i] == BT_REF) continue;
+    double th, dv, piv = 1.0;
+    solve_pivot(L, i, th, dv, piv);
+    const double vr = L.vr[i], vi = L.vi[i];
+    const double vm = sqrt(vr * vr + vi * vi);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    L.vr[i] = vm * cs;
+    L.vi[i] = vm * sn;
+  }
+}
+template <bool PK>
+__device__ void dc_start(const DevPlan& P, const Lds& L, int lane) {
+  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc) + lane;
+  const int RB = P.rb, R = P.rb + P.rc;
+  for (int f = P.fill_lo + lane; f < P.fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+  dc_overflow<PK>(P, L, 0, 1, lane);
+  dc_rows<PK>(P, L, 0, 1, lane);
+  wave_fence();
+  for (int r = 0; r < RB; ++r) { item_factor<PK, true>(L, stream[(size_t)r * WAVE]); wave_fence(); }
+  for (int r = RB; r < R; ++r) { item_factor<PK, false>(L, stream[(size_t)r * WAVE]); wave_fence(); }
+  dc_update(L, P.nb, lane, WAVE);
+  wave_fence();
+}
+template <int NW, bool PK>
+__device__ void dc_start_coop(const DevPlan& P, const Lds& L) {
+  constexpr int NT = WAVE * NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
+  const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4, Kb = NW == 2 ? P.team_kb2 : P.team_kb4;
+  for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+  dc_overflow<PK>(P, L, wave, NW, lane);
+  dc_rows<PK>(P, L, wave, NW, lane);
+  lds_barrier();
+  for (int k = 0; k < Kb; ++k) team_step<PK>(L, stream[(size_t)k * (NW * WAVE)]);
+  if (P.tail_m > 0) {
+    if (wave == 0) tail_solve(L, P.tail_m, lane, P.tail_bus[lane & 31]);
+    lds_barrier();
+    for (int k = Kb; k < K; ++k) team_step<PK>(L, stream[(size_t)k * (NW * WAVE)]);
+  }
+  dc_update(L, P.nb, tid, NT);
+  lds_barrier();
+}
+
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
 // A bus that an earlier solve of this instance pinned at a reactive limit gets
 // its generator share removed from q_sp again (L.bt must hold valid codes).
@@ -1339,7 +1429,10 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
   wave_fence();
 }
 
-template <int V2, int NW>
+// DC: compiled with the DC start (opfx_solve_opts.init).  A template parameter, i.e. kernels of their own: with the DC
+// code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
+// in the wave teams) although the region runs once per solve.
+template <int V2, int NW, bool DC = false>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
                                int isl_state = 0) {
@@ -1351,6 +1444,11 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   if (isl_state == 2) { *iters = 1; *nrm = __builtin_nan(""); return false; }
   int total = 0;
   bool conv = false;
+  // DC start: on the compiled topology only (a modifier changes B' as well; such solves start flat), V2 kernels
+  if (DC && V2 && o.init == OPFX_INIT_DC && P.lp_dc != nullptr && n_mod == 0 && isl_state == 0) {
+    if (NW > 1) dc_start_coop<NW, V2 == 2>(P, L);
+    else dc_start<V2 == 2>(P, L, lane);
+  }
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
@@ -1537,7 +1635,7 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
 #ifndef OPFX_MIN_WAVES_PER_SIMD
 #define OPFX_MIN_WAVES_PER_SIMD 2
 #endif
-template <int V2, int NW>
+template <int V2, int NW, bool DC = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1565,7 +1663,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     blk_sync<NW>();
     int iters; double nrm;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
-    const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
+    const bool conv = solve_instance<V2, NW, DC>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
     blk_sync<NW>();
     if (wave == 0) {
       double* R = L.blk;
@@ -1965,7 +2063,7 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <int V2, int NW>
+template <int V2, int NW, bool DC = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
@@ -2192,7 +2290,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
+      const bool conv = solve_instance<V2, NW, DC>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
@@ -2430,6 +2528,7 @@ struct opfx_ctx {
   int device = 0;
   int n_cu = 0;
   int solve_per_cu = 0;
+  int solve_per_cu_dc = 0;
   opfx_plan plan;     // host copy
   DevPlan dp{};
   const DevPlan* d_dp = nullptr;   // device copy of dp (kernels take it by pointer)
@@ -2447,6 +2546,7 @@ struct opfx_env {
   DevArena arena;
   size_t lds_bytes = 0;
   int per_cu = 0;
+  int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
   int n_full = 0;        // four-value blocks this environment's kernels run with (choose_block_storage)
 };
 
@@ -2562,6 +2662,8 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   }
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
+  d.lp_dc = nullptr; d.lp_hdc = nullptr;
+  if (!p->lp_dc.empty()) { PUT(lp_dc, lp_dc); PUT(lp_hdc, lp_hdc); }
   d.n_hrows = (int)p->lp_hrows.size();
   if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
   if (rc == OPFX_OK) rc = A.put(p->lp_team[1], &d.lp_team4);
@@ -2605,7 +2707,8 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
   HIP_TRY(hipSetDevice(ctx->device));
-  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0};
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0, opts ? opts->init : 0};
+  if (o.init == OPFX_INIT_DC && !ctx->dp.lp_dc) { opfx_set_error("opfx_solve: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
   int n_full = ctx->plan.n_blk;
@@ -2620,6 +2723,14 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                      : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
   int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
+  if (o.init == OPFX_INIT_DC && ctx->v2) {           // the kernels compiled with the DC start (same launch geometry)
+    kern = packed ? (team == 4 ? k_solve<2, 4, true> : (team == 2 ? k_solve<2, 2, true> : k_solve<2, 1, true>))
+                  : (team == 4 ? k_solve<1, 4, true> : (team == 2 ? k_solve<1, 2, true> : k_solve<1, 1, true>));
+    int per_cu_dc = ctx->solve_per_cu_dc;
+    rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
+    ctx->solve_per_cu_dc = per_cu_dc;
+    if (rc != OPFX_OK) return rc;
+  }
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot};
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
@@ -2863,7 +2974,9 @@ extern "C" void opfx_env_destroy(opfx_env* env) { delete env; }
 
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                    int32_t mode, void* stream) {
-  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1, opts ? opts->contingency_start : 0};
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1, opts ? opts->contingency_start : 0,
+         opts ? opts->init : 0};
+  if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
   const int team = pick_team(env->lds_bytes, env->ctx->v2);
@@ -2875,6 +2988,14 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
                      : (team == 4 ? k_step<1, 4> : (team == 2 ? k_step<1, 2> : k_step<1, 1>));
   int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
+  if (o.init == OPFX_INIT_DC && env->ctx->v2) {      // the kernels compiled with the DC start (same launch geometry)
+    kern = packed ? (team == 4 ? k_step<2, 4, true> : (team == 2 ? k_step<2, 2, true> : k_step<2, 1, true>))
+                  : (team == 4 ? k_step<1, 4, true> : (team == 2 ? k_step<1, 2, true> : k_step<1, 1, true>));
+    int per_cu_dc = env->per_cu_dc;
+    rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
+    env->per_cu_dc = per_cu_dc;
+    if (rc != OPFX_OK) return rc;
+  }
   StepIO s{};
   s.x = io->x; s.action = io->action; s.initial_obj = io->initial_obj;
   s.step_in_episode = io->step_in_episode; s.outage = io->outage;

@@ -167,6 +167,41 @@ void build_lane_programs(opfx_plan* p) {
     p->lp_h_y.push_back(0.0);
   }
   p->rh = (int32_t)(p->lp_h_ent.size() / 64);
+  // ---- DC start: B' = Cft' diag(b) Cft on the same pattern (pypower makeBdc), the constant part of the right-hand
+  // side per bus: Pbusinj (phase shifters) + Gs + sum over REF columns of B'_ir theta_r --------------------------------
+  if (!p->br_bdc.empty()) {
+    std::vector<std::map<int32_t, double>> bdc(nb);
+    std::vector<double> cst(nb, 0.0);
+    for (int32_t k = 0; k < p->nbr; ++k) {
+      const double b = p->br_bdc[k];
+      if (b == 0.0) continue;
+      const int32_t f = p->br_f[k], t = p->br_t[k];
+      bdc[f][f] += b; bdc[t][t] += b; bdc[f][t] -= b; bdc[t][f] -= b;
+      cst[f] += p->br_pfinj[k]; cst[t] -= p->br_pfinj[k];
+    }
+    for (int i = 0; i < nb; ++i) {
+      for (auto& kv : bdc[i]) if (p->bus_type[kv.first] == OPFX_REF && kv.first != i) cst[i] += kv.second * p->va_set[kv.first];
+    }
+    for (int i = 0; i < nb; ++i) cst[i] += p->gs_copy.empty() ? 0.0 : p->gs_copy[i];
+    p->lp_dc.assign((size_t)p->ra * (KA + 2) * 64, 0.0);
+    p->lp_hdc.assign((size_t)p->rh * 64, 0.0);
+    auto val = [&](int i, int j) { auto it = bdc[i].find(j); return it == bdc[i].end() ? 0.0 : it->second; };
+    for (int i = 0; i < nb; ++i) {
+      const int r = i / 64, lane = i % 64;
+      for (int k = 0; k < KA; ++k) {
+        const uint32_t ent = p->lp_a_ent[((size_t)r * KA + k) * 64 + lane];
+        const int j = (int)(ent & 0xFFFF);
+        p->lp_dc[((size_t)r * (KA + 2) + k) * 64 + lane] = j == i ? 0.0 : val(i, j);
+      }
+      p->lp_dc[((size_t)r * (KA + 2) + KA) * 64 + lane] = val(i, i);
+      p->lp_dc[((size_t)r * (KA + 2) + KA + 1) * 64 + lane] = cst[i];
+    }
+    for (size_t q = 0; q < p->lp_h_ent.size(); ++q) {
+      const uint32_t ent = p->lp_h_ent[q];
+      if ((ent & 0xFFFF) == NONE) continue;
+      p->lp_hdc[q] = val((int)p->lp_h_row[q], (int)(ent & 0xFFFF));
+    }
+  }
   // ---- B ---------------------------------------------------------------------
   // per level: every (target, source) update term is one item; terms that share a
   // target may sit in the same round (the kernel accumulates with LDS atomics).
@@ -485,6 +520,7 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
   p->br_kf.assign(nbr, 0.0); p->br_kt.assign(nbr, 0.0);
   if (c->br_kf) p->br_kf.assign(c->br_kf, c->br_kf + nbr);
   if (c->br_kt) p->br_kt.assign(c->br_kt, c->br_kt + nbr);
+  if (c->br_bdc && c->br_pfinj) { p->br_bdc.assign(c->br_bdc, c->br_bdc + nbr); p->br_pfinj.assign(c->br_pfinj, c->br_pfinj + nbr); }
   p->ref_ord.assign(nb, -1);
   for (int32_t i = 0; i < nb; ++i) {
     int32_t t = p->bus_type[i];
@@ -505,6 +541,7 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
   std::vector<std::map<int32_t, std::pair<double, double>>> rows(nb);
   for (int32_t i = 0; i < nb; ++i)
     rows[i][i] = {c->gs ? c->gs[i] : 0.0, c->bs ? c->bs[i] : 0.0};
+  if (c->gs) p->gs_copy.assign(c->gs, c->gs + nb);
   // a branch without coupling terms (open-ended in the net itself: a shunt at its connected end, case.py
   // open_ended_stamps) adds to the diagonal only: no structural (f,t) entry, no edge for connectivity
   std::vector<char> coupled(nbr, 1);
@@ -695,6 +732,7 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->team_kb[0] = p->team_kb[0]; o->team_kb[1] = p->team_kb[1];
   o->tail_m = p->tail_m;
   o->lp_ell_width = opfx_plan::KA;
+  o->has_dc = p->lp_dc.empty() ? 0 : 1;
   return OPFX_OK;
 }
 
@@ -756,6 +794,8 @@ extern "C" int64_t opfx_plan_get_darray(const opfx_plan* p, int which, double* o
     case OPFX_DARR_LP_A_Y: v = &p->lp_a_y; break;
     case OPFX_DARR_LP_A_YDIAG: v = &p->lp_a_ydiag; break;
     case OPFX_DARR_LP_H_Y: v = &p->lp_h_y; break;
+    case OPFX_DARR_LP_DC: v = &p->lp_dc; break;
+    case OPFX_DARR_LP_H_DC: v = &p->lp_hdc; break;
     default: opfx_set_error("opfx_plan_get_darray: unknown array id"); return OPFX_ERR_INVALID;
   }
   const int64_t n_copy = std::min<int64_t>(cap, (int64_t)v->size());

@@ -14,6 +14,8 @@ struct opfx_plan {
   std::vector<double> vm_set, va_set;
   std::vector<int32_t> br_f, br_t;
   std::vector<double> br_y, br_kf, br_kt;
+  std::vector<double> br_bdc, br_pfinj;  // DC model of the branches (empty: none given)
+  std::vector<double> gs_copy;           // [nb] bus shunt conductance, p.u. (DC right-hand side)
   std::vector<int32_t> ref_bus;        // REF buses, increasing order
   std::vector<int32_t> ref_ord;        // [nb] ordinal among REF buses or -1
   // Ybus block CSR (all buses, diagonal included, columns sorted)
@@ -66,6 +68,9 @@ struct opfx_plan {
   std::vector<uint32_t> lp_apk;            // [ra][KA+2][64][4]  ent0..ent(KA-1), dblk | y0 | .. | y(KA-1) | ydiag
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
+  // DC start (opfx_solve_opts.init = OPFX_INIT_DC): B' on the Ybus pattern, laid out like lp_a_y / lp_h_y
+  std::vector<double> lp_dc;               // [ra][KA+2][64]  B'_ij (ELL slots), B'_ii, constant part of the right-hand side
+  std::vector<double> lp_hdc;              // [rh][64]        B'_ij of the overflow entries
   // cooperative kernels (2 or 4 wavefronts per instance): the rounds of each group dealt round-robin
   // to the waves and laid out per wave, [round][wave][64][4]; word 3 of an item carries flags:
   // bit 0 = workgroup barrier after this round (end of a group that another wavefront continues).

@@ -58,16 +58,24 @@ class BatchedPowerFlowSolver:
         return ctx
 
     def __call__(self, net, enforce_q_lims=True, **kwargs):
+        """Keyword arguments as `pp.runpp` where they apply: `calculate_voltage_angles`, `init` ('flat' — the default
+        here —, 'dc', or pandapower's own default 'auto': 'dc' when voltage angles are calculated)."""
         import torch
         case = net_to_case(net, kwargs.get('calculate_voltage_angles', 'auto'))
+        init = kwargs.get('init', 'flat')
+        if init == 'auto':
+            init = 'dc' if case.meta.get('calc_angles') else 'flat'
+        if init not in ('flat', 'dc'):
+            raise NotImplementedError(f"init={init!r}: 'flat', 'dc' or 'auto' (no 'results' start)")
         ctx = self._context(case)
         base = case.base_mva
         p, q, qmin, qmax = bus_injections(net, case)
         dev = torch.device(self.device)
         as_t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
         out = capi.solve(ctx, as_t(p[None] / base), as_t(q[None] / base), qg_min=as_t(qmin / base),
-                         qg_max=as_t(qmax / base), tol=self.tol, max_iter=self.max_it,
+                         qg_max=as_t(qmax / base), tol=self.tol, max_iter=self.max_it, init=init,
                          enforce_q_lims=bool(enforce_q_lims) and case.bus_type.tolist().count(2) > 0)
+        self.last_iterations = int(out['iterations'][0])
         if not bool(out['converged'][0]):
             raise _not_converged_exception()('batched Newton-Raphson did not converge')
         self._write_results(net, case, {k: v[0].cpu().numpy() for k, v in out.items()}, p, q)

@@ -12,5 +12,5 @@ cd $root
 for v in "" _global; do
   f=$(find $out/reset_$tag$v -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $out/reset_$tag${v}_kernel_stats.csv && grep -E "k_reset|k_step" $out/reset_$tag${v}_kernel_stats.csv | cut -c1-60,150-400
-  grep '^{' $out/reset_$tag$v.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('cycle', c['reset_plus_step_ms'], c['reset_plus_step_mode'], 'two launches', c['reset_plus_step_two_launches_ms'], 'step', d['ms_per_step'])"
+  grep '^{' $out/reset_$tag$v.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('cycle', c['reset_plus_step_ms'], 'step', d['ms_per_step'])"
 done

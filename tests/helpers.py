@@ -56,7 +56,7 @@ class OracleSide:
         assert (self.br_map >= 0).all()
         self.ref = np.flatnonzero(case.bus_type == 3)
 
-    def solve(self, p, q, outage=-1, qg_min=None, qg_max=None, enforce_q_lims=False, tol=1e-8, max_it=10):
+    def solve(self, p, q, outage=-1, qg_min=None, qg_max=None, enforce_q_lims=False, tol=1e-8, max_it=10, init='flat'):
         """One instance: bus injections p, q [nb] (p.u., product order; generator active power included
         in p) -> results in product order."""
         ppc, case = copy.copy(self.ppc), self.case
@@ -78,7 +78,7 @@ class OracleSide:
         if outage is not None and outage >= 0:
             status = ppc.status.copy()
             status[self.br_map[outage]] = 0
-        sol = po.solve(ppc, enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it, status=status)
+        sol = po.solve(ppc, enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it, status=status, init=init)
         v = sol['V'][self.bus_map]
         ld = po.loading_percent(ppc, self.net, sol['V'], sol['status'])
         loading = np.array([ld[('line', 'trafo', 'trafo3w')[int(kd)]][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])   # (trafo3w: the transformer's value on each of its three windings)

@@ -500,6 +500,31 @@ def test_custom_reward_classes_run_through_their_own_methods():
         envs.VoltageControl(reward_function=object(), **kw)
 
 
+def test_env_option_init_dc_and_auto():
+    """BatchedOpfEnv(init=...): 'dc' starts every base-case solve from the DC angles, 'auto' picks it where pandapower
+    would (voltage angles calculated: grids fed above 70 kV); rewards / observations / validity as with the flat start."""
+    from opfgym_amd import envs
+    B = 32
+    rng = np.random.default_rng(12)
+    for cls, code in (('EcoDispatch', 'hv-small'), ('VoltageControl', '1-MV-urban--0-sw')):
+        ref = getattr(envs, cls)(simbench_network_name=code, batch_size=B, device='cuda:0', seed=2)
+        steps, act = rng.choice(ref.train_steps, B), rng.random((B, ref.n_actions))
+        uni = rng.random((B, ref.n_uniform)) if ref.n_uniform else None
+        ref.reset(options={'step': steps, 'uniform': uni})
+        _, r0, _, _, i0 = ref.step(act)
+        for init in ('dc', 'auto'):
+            env = getattr(envs, cls)(simbench_network_name=code, batch_size=B, device='cuda:0', seed=2, init=init)
+            assert env.init == 'dc' and env.solve_opts.init == 1     # (both stand-in grids are fed from 110 kV or above)
+            env.reset(options={'step': steps, 'uniform': uni})
+            _, r1, _, _, i1 = env.step(act)
+            assert bool(i1['converged'].all())
+            assert np.allclose(_np(r0), _np(r1), rtol=0, atol=1e-7) and np.array_equal(_np(i0['valids']), _np(i1['valids']))
+            assert np.abs(_np(env.result_table('bus', 'vm_pu')) - _np(ref.result_table('bus', 'vm_pu'))).max() < 1e-8
+    lv = envs.MaxRenewable(simbench_network_name='1-LV-rural1--0-sw', min_sgen_power=0.005, min_storage_power=0.005,
+                           batch_size=2, device='cuda:0', init='auto')
+    assert lv.init == 'flat'                                        # 20 kV slack: no angle calculation, flat start
+
+
 def test_is_state_valid_without_any_constraint():
     """no constraints at all -> an empty all() is True (opf_env.py:613-618), not a column the kernel never writes."""
     from opfgym_amd import envs

@@ -439,3 +439,48 @@ def test_first_generation_kernel_still_correct():
                         '-q', '-x', '-k', 'matches_oracle or q_lims or outage_axis'], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('code,B', [('1-HV-mixed--0-sw', 24), ('1-HV-urban--0-sw', 16), ('hv-small', 64), ('1-MV-urban--0-sw', 64),
+                                    ('mv-3w', 32)])
+def test_dc_start_reproduces_the_oracle_iteration_for_iteration(code, B):
+    """opfx_solve_opts.init = OPFX_INIT_DC (pandapower init='dc', its 'auto' choice for grids fed above 70 kV): angles
+    from B' theta = P first — one linear solve through the Newton schedule —, then Newton.  Same fixed point as the
+    flat start and, instance for instance, the iteration count of the oracle started the same way (single-wave kernels
+    and wave teams)."""
+    import torch
+    from helpers import OracleSide
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = grids.get_grid(code)
+    case = net_to_case(net)
+    ctx = capi.Context(capi.Plan(case), 0)
+    p, q = random_injections(net, case, B, seed=31, lo=0.3, hi=1.3)
+    dev = torch.device('cuda:0')
+    out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), init='dc').items()}
+    flat = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
+    side = OracleSide(net, case)
+    ref_it, ref_flat = np.zeros(B, int), np.zeros(B, int)
+    for b in range(B):
+        r = side.solve(p[b], q[b], init='dc')
+        assert r['converged'] and out['converged'][b]
+        ref_it[b] = r['iterations']
+        ref_flat[b] = side.solve(p[b], q[b])['iterations']
+        assert np.abs(out['vm'][b] - r['vm']).max() < TOL_V
+        assert np.abs(np.angle(np.exp(1j * (out['va'][b] - r['va'])))).max() < TOL_V
+    assert np.array_equal(out['iterations'], ref_it), (out['iterations'], ref_it)
+    assert np.array_equal(flat['iterations'], ref_flat)
+    assert np.abs(out['vm'] - flat['vm']).max() < 1e-8 and np.abs(out['loading'] - flat['loading']).max() < 1e-5
+
+
+def test_dc_start_needs_the_dc_model_of_the_branches():
+    import torch
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = grids.get_grid('hv-small')
+    case = net_to_case(net)
+    case.bdc = None
+    ctx = capi.Context(capi.Plan(case), 0)
+    z = torch.zeros(2, case.nb, dtype=torch.float64, device='cuda:0')
+    with pytest.raises(capi.OpfxError, match='OPFX_INIT_DC'):
+        capi.solve(ctx, z, z, init='dc')

@@ -193,3 +193,43 @@ def test_islanding_outages_flagged():
         island = plan.array('br_island')
         assert len(island) == case.nbr
         assert set(np.flatnonzero(island == 0).tolist()) == set(non_bridge_branches(case).tolist())
+
+
+@pytest.mark.parametrize('code', ['hv-small', '1-HV-mixed--0-sw', '1-MV-urban--0-sw', 'mv-3w', 'hv-small-sw'])
+def test_dc_start_arrays_are_the_dc_power_flow_of_the_oracle(code, built_lib):
+    """opfx_solve_opts.init = OPFX_INIT_DC: the plan lays B' (pypower makeBdc) out on the Ybus pattern next to the constant
+    part of the DC right-hand side; reassembled from the descriptor arrays and solved densely it gives the angles of the
+    oracle's DC start (oracle/pf_oracle.py:_dc_angles, its own branch table)."""
+    from helpers import OracleSide
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import bus_injections, net_to_case
+    from oracle import pf_oracle as po
+    net, _ = grids.get_grid(code)
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    assert plan.info['has_dc'] == 1
+    ka, ra, nb = plan.info['lp_ell_width'], plan.info['lp_rounds_a'], case.nb
+    dc = plan.darray('LP_DC').reshape(ra, ka + 2, 64)
+    ent = (plan.array('LP_A_ENT').astype(np.int64) & 0xFFFFFFFF).reshape(ra, ka, 64)
+    hdc, hent = plan.darray('LP_H_DC'), plan.array('LP_H_ENT').astype(np.int64) & 0xFFFFFFFF
+    hrow = plan.array('LP_H_ROW').astype(np.int64) & 0xFFFFFFFF
+    b, cst = np.zeros((nb, nb)), np.zeros(nb)
+    for i in range(nb):
+        r, lane = divmod(i, 64)
+        for k in range(ka):
+            j = int(ent[r, k, lane] & 0xFFFF)
+            if j != i:
+                b[i, j] += dc[r, k, lane]
+        b[i, i], cst[i] = dc[r, ka, lane], dc[r, ka + 1, lane]
+    for q in range(len(hent)):
+        if (hent[q] & 0xFFFF) != 0xFFFF:
+            b[int(hrow[q]), int(hent[q] & 0xFFFF)] += hdc[q]
+    assert np.allclose(b, b.T, rtol=0, atol=1e-12) and np.allclose(b.sum(axis=1), 0, rtol=0, atol=1e-9 * np.abs(b).max())
+    p, *_ = bus_injections(net, case)
+    ref, free = np.flatnonzero(case.bus_type == 3), np.flatnonzero(case.bus_type != 3)
+    theta = np.zeros(nb)
+    theta[ref] = case.va_set[ref]
+    theta[free] = np.linalg.solve(b[np.ix_(free, free)], (p / case.base_mva - cst)[free])
+    side = OracleSide(net, case)
+    v0 = po.start_voltage(side.ppc, 'dc')[side.bus_map]
+    assert np.abs(np.angle(v0 * np.exp(-1j * theta))).max() < 1e-10
