@@ -11,7 +11,9 @@
 //     of an elimination level (numeric 2x2-block LU + forward substitution),
 //     over the pivots of a level (back substitution), and reduce the mismatch
 //     inf-norm / constraint sums with cross-lane shuffles;
-//   * no inter-workgroup communication, no atomics, deterministic results.
+//   * no inter-workgroup communication and no global atomics; update terms that share a target meet in LDS
+//     atomics (ds_add_f64): one wavefront issues them in a fixed order, so the single-wave kernels are
+//     bit-reproducible; the wave teams (large grids) are reproducible to rounding only.
 //
 // Replaces: pypower `newtonpf` (P4), the q-limit outer loop
 // (P5), `pfsoln`/result extraction (P6) and, in MODE_ENV, OpfEnv._apply_actions
@@ -522,7 +524,7 @@ __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   const bool rhs_t = live && (tb & 0x8000u) != 0;
   ItemRegs r;
   ld_blk_raw<PK>(L, ik, r.i11, r.i12, r.i21, r.i22);
-  ld_blk_raw<PK>(L, kk, r.k11, r.k12, r.k21, r.k22);
+  ld_blk_raw<false>(L, kk, r.k11, r.k12, r.k21, r.k22);        // (a pivot's diagonal block always holds four values, plan.cpp)
   // third operand C: A_kj, or the column (y_k ; .) of the right-hand side
   const unsigned kjb = rhs_t ? 0u : kj;                                  // (any valid block for the unused reads)
   const unsigned kjc = (!PK || kjb < (unsigned)L.nfull) ? kjb : 0u;
@@ -544,9 +546,8 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
   const bool rhs_t = (tb & 0x8000u) != 0;
   Blk bi{r.i11, r.i12, r.i21, r.i22}, bk{r.k11, r.k12, r.k21, r.k22};
   if (PK) {
-    const bool fi = ik < (unsigned)L.nfull, fk = kk < (unsigned)L.nfull;
+    const bool fi = ik < (unsigned)L.nfull;
     bi.a21 = fi ? r.i21 : -r.i12; bi.a22 = fi ? r.i22 : r.i11;
-    bk.a21 = fk ? r.k21 : -r.k12; bk.a22 = fk ? r.k22 : r.k11;
   }
   const bool fj = !PK || rhs_t || kj < (unsigned)L.nfull;
   const double c11 = r.c11, c12 = r.c12;
@@ -581,6 +582,22 @@ __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
   const ItemRegs r = item_load<PK, RIDERS>(L, d);
   item_apply<PK, RIDERS>(L, d, r);
+}
+// Two consecutive rounds of one wavefront.  When the plan marks the second as independent of the first (same group)
+// all LDS reads of both are requested first.
+template <bool PK, bool RIDERS>
+__device__ __forceinline__ void item_pair(const Lds& L, const uint4 da, const uint4 db) {
+  const unsigned fl = __builtin_amdgcn_readfirstlane(da.w);
+  if (fl & ITEM_NEXT_INDEPENDENT) {
+    const ItemRegs ra = item_load<PK, RIDERS>(L, da);
+    const ItemRegs rb = item_load<PK, RIDERS>(L, db);
+    item_apply<PK, RIDERS>(L, da, ra);
+    item_apply<PK, RIDERS>(L, db, rb);
+    wave_fence();
+  } else {
+    item_factor<PK, RIDERS>(L, da); wave_fence();
+    item_factor<PK, RIDERS>(L, db); wave_fence();
+  }
 }
 // Back substitution through the dense tail of the elimination (plan.cpp: the last m levels hold one pivot each
 // and their U-rows are full): a strictly serial chain.  As LDS groups it costs one round trip + one 2x2 inverse
@@ -675,6 +692,22 @@ __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   if (fl & ITEM_BARRIER) lds_barrier(); else wave_fence();        // (no barrier: the same wavefront carries on)
 }
 
+#ifdef OPFX_PAIR_ROUNDS
+template <bool PK>
+__device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const uint4 db) {
+  const unsigned fa = __builtin_amdgcn_readfirstlane(da.w), fb = __builtin_amdgcn_readfirstlane(db.w);
+  if ((fa & ITEM_NEXT_INDEPENDENT) && !(fa & ITEM_BARRIER)) {
+    const ItemRegs ra = item_load<PK, false>(L, da);
+    const ItemRegs rb = item_load<PK, false>(L, db);
+    item_apply<PK, false>(L, da, ra);
+    item_apply<PK, false>(L, db, rb);
+    if (fb & ITEM_BARRIER) lds_barrier(); else wave_fence();
+  } else {
+    team_step<PK>(L, da);
+    team_step<PK>(L, db);
+  }
+}
+#endif
 // Phase D of the lane-programme kernels: after the back-substitution items y_i of bus i holds its
 // right-hand side with every U-term removed; x_i = A_ii^-1 y_i, then V_i <- V_i (1 + d|V|/|V|) e^{j dth}.
 // `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
@@ -1013,6 +1046,19 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     // ---- phase B: block LU + forward substitution; phase C: back substitution ---------------
     // Rounds of one level are independent; ordering is needed at level ends only, but on a
     // single wave the fence is free (the LDS executes a wave's operations in order).
+#ifdef OPFX_PAIR_ROUNDS
+    // Two rounds of one elimination level (the plan's ITEM_NEXT_INDEPENDENT flag) as one step: the LDS reads of both
+    // are requested before either computes, so the second round's round trip hides behind the first round's arithmetic.
+    for (int r = 0; r < RB; r += 4) {
+      item_pair<PK, true>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
+      item_pair<PK, true>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
+    }
+    OPFX_STAMP(2);
+    for (int r = RB; r < R; r += 4) {
+      item_pair<PK, false>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
+      item_pair<PK, false>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
+    }
+#else
     for (int r = 0; r < RB; r += 4) {
       item_factor<PK, true>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
       item_factor<PK, true>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
@@ -1026,6 +1072,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       item_factor<PK, false>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
       item_factor<PK, false>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
+#endif
     OPFX_STAMP(3);
     // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
     for (int i = lane; i < nb; i += WAVE) {
@@ -1210,23 +1257,37 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     ++it;
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
+#ifdef OPFX_PAIR_ROUNDS
+    for (int k = 0; k < Kb; k += 4) {
+      team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
+      team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
+    }
+#else
     for (int k = 0; k < Kb; k += 4) {
       team_step<PK>(L, q0); q0 = ld_desc(k + 4);
       team_step<PK>(L, q1); q1 = ld_desc(k + 5);
       team_step<PK>(L, q2); q2 = ld_desc(k + 6);
       team_step<PK>(L, q3); q3 = ld_desc(k + 7);
     }
+#endif
     OPFX_STAMP(2);
     if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
       if (wave == 0) tail_solve(L, P.tail_m, lane, tail);
       lds_barrier();
       OPFX_STAMP(20);
+#ifdef OPFX_PAIR_ROUNDS
+      for (int k = Kb; k < K; k += 4) {
+        team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
+        team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
+      }
+#else
       for (int k = Kb; k < K; k += 4) {
         team_step<PK>(L, q0); q0 = ld_desc(k + 4);
         team_step<PK>(L, q1); q1 = ld_desc(k + 5);
         team_step<PK>(L, q2); q2 = ld_desc(k + 6);
         team_step<PK>(L, q3); q3 = ld_desc(k + 7);
       }
+#endif
     }
     OPFX_STAMP(3);
     // ---- phase D ---------------------------------------------------------------------------------
