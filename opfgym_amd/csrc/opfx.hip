@@ -74,6 +74,8 @@ struct DevPlan {
   const unsigned short* tail_ids;        // [tail_m][M] id of U-block (row e, column s) at [e * M + s], M = tail_m rounded up to 8
   int team_rounds2, team_rounds4, team_kb2, team_kb4;
   const double *lp_dc, *lp_hdc;          // DC start (plan.h): B' on the Ybus pattern + constant right-hand side; nullptr: none
+  double* blk_mem;           // memory-resident kernels: [resident workgroups][blk_mem_stride] LU block values
+  long long blk_mem_stride;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
 };
@@ -253,6 +255,9 @@ constexpr int BT_DEAD = 6;
 // rectangular form only (no |V|/angle arrays) to fit 6 instances per CU.
 struct Lds {
   double *vr, *vi, *vm, *va, *psp, *qsp, *rhs, *blk, *sp, *acc;
+  double* stage;             // LDS area behind rq: the LU block values live here (blk == stage) unless the grid is too large
+                             // for that (memory-resident kernels: blk points into a per-workgroup row of global memory); outside
+                             // the solve it holds the rest of the staged table row and the result bank
   unsigned char* bt;
   // second-generation kernels: structure-of-arrays images.  rhs = P-row values [nb], rq =
   // Q-row values [nb]; block component c of block id at blk[c * bs + id].  A wave's 64-bit
@@ -468,10 +473,10 @@ __device__ __forceinline__ double fast_rcp1(double x) {
   return r;
 }
 __device__ __forceinline__ void lds_sub(double* p, double v) {
-  __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void lds_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #ifdef OPFX_ENABLE_STAMPS
@@ -503,6 +508,16 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// MEM: the memory-resident form of the wave-team kernels (grids whose LU blocks do not fit the LDS: they live in a
+// per-workgroup row of global memory, L2-resident).  Group ends then also wait for the vector-memory operations, and a
+// wavefront that carries on alone waits for its own block updates before it reads them back.
+template <bool MEM>
+__device__ __forceinline__ void team_sync() { if (MEM) __syncthreads(); else lds_barrier(); }
+template <bool MEM>
+__device__ __forceinline__ void mem_fence() {
+  if (MEM) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  wave_fence();
 }
 template <bool PK>
 __device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a11, double& a12, double& x21, double& x22) {
@@ -685,11 +700,11 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
 // the plan marks independent rounds, ITEM_NEXT_INDEPENDENT — was tried and is slower: the compiler's wait-count
 // insertion treats loads that are pending across the loop's back edge conservatively and drains the LDS queue,
 // lgkmcnt(0), at the first use, so the early reads only lengthen that wait: config 3 2.27 -> 2.66 ms.)
-template <bool PK>
+template <bool PK, bool MEM = false>
 __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
   item_factor<PK, false>(L, d);
-  if (fl & ITEM_BARRIER) lds_barrier(); else wave_fence();        // (no barrier: the same wavefront carries on)
+  if (fl & ITEM_BARRIER) team_sync<MEM>(); else mem_fence<MEM>();  // (no barrier: the same wavefront carries on)
 }
 
 #ifdef OPFX_PAIR_ROUNDS
@@ -1118,7 +1133,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // ---------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
-template <int NW, bool PK>
+template <int NW, bool PK, bool MEM = false>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
                              int* iters_out, double* nrm_out, double* piv_out, bool inline_mods) {
   double piv = 1.0;
@@ -1155,7 +1170,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
     if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
     for (int h = tid + NT; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
-    lds_barrier();
+    team_sync<MEM>();
     OPFX_STAMP(10);
     for (int h = wave; h < P.rh; h += NW) {
       const uint4 hy = h == wave ? hy0 : hpk[(size_t)(h * 2) * WAVE + lane];
@@ -1180,7 +1195,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         lds_add(&L.rq[i], ci);
       }
     }
-    lds_barrier();
+    team_sync<MEM>();
     OPFX_STAMP(11);
     double my = 0.0;
     for (int r = wave; r < P.ra; r += NW) {
@@ -1237,16 +1252,16 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
     OPFX_STAMP(12);
     if (n_mod > 0 && !inline_mods) {
-      lds_barrier();
-      if (wave == 0) { dead_rows_patch<PK>(P, L, lane); wave_fence(); mods_apply(L, lane, n_mod); }
-      lds_barrier();
+      team_sync<MEM>();
+      if (wave == 0) { dead_rows_patch<PK>(P, L, lane); mem_fence<MEM>(); mods_apply(L, lane, n_mod); }
+      team_sync<MEM>();
       my = 0.0;
       for (int i = tid; i < nb; i += NT)
         if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
     }
     my = wave_max_dpp(my);
     if (lane == 0) xw[wave] = my;
-    lds_barrier();
+    team_sync<MEM>();
     nrm = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
@@ -1264,16 +1279,16 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
 #else
     for (int k = 0; k < Kb; k += 4) {
-      team_step<PK>(L, q0); q0 = ld_desc(k + 4);
-      team_step<PK>(L, q1); q1 = ld_desc(k + 5);
-      team_step<PK>(L, q2); q2 = ld_desc(k + 6);
-      team_step<PK>(L, q3); q3 = ld_desc(k + 7);
+      team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
+      team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
+      team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
+      team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
     }
 #endif
     OPFX_STAMP(2);
     if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
       if (wave == 0) tail_solve(L, P.tail_m, lane, tail);
-      lds_barrier();
+      team_sync<MEM>();
       OPFX_STAMP(20);
 #ifdef OPFX_PAIR_ROUNDS
       for (int k = Kb; k < K; k += 4) {
@@ -1282,10 +1297,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       }
 #else
       for (int k = Kb; k < K; k += 4) {
-        team_step<PK>(L, q0); q0 = ld_desc(k + 4);
-        team_step<PK>(L, q1); q1 = ld_desc(k + 5);
-        team_step<PK>(L, q2); q2 = ld_desc(k + 6);
-        team_step<PK>(L, q3); q3 = ld_desc(k + 7);
+        team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
+        team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
+        team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
+        team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
       }
 #endif
     }
@@ -1310,17 +1325,17 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       L.vr[i] = (vr * cs - vi * sn) * sc;
       L.vi[i] = (vr * sn + vi * cs) * sc;
     }
-    lds_barrier();
+    team_sync<MEM>();
     OPFX_STAMP(4);
   }
-  lds_barrier();          // xw (aliases the constraint accumulators) is free again
+  team_sync<MEM>();          // xw (aliases the constraint accumulators) is free again
   piv = wave_min_dpp(piv);
   if (lane == 0) xw[wave] = piv;
-  lds_barrier();
+  team_sync<MEM>();
   piv = xw[0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) piv = nn_min(piv, xw[w]);
-  lds_barrier();
+  team_sync<MEM>();
   *iters_out = it;
   *nrm_out = nrm;
   *piv_out = piv;
@@ -1493,7 +1508,7 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 // DC: compiled with the DC start (opfx_solve_opts.init).  A template parameter, i.e. kernels of their own: with the DC
 // code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
 // in the wave teams) although the region runs once per solve.
-template <int V2, int NW, bool DC = false>
+template <int V2, int NW, bool DC = false, bool MEM = false>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
                                int isl_state = 0) {
@@ -1514,7 +1529,7 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
     int it;
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
     // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2>(P, L, o, n_mod, &it, nrm, &pv_, isl_state == 0);
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM>(P, L, o, n_mod, &it, nrm, &pv_, isl_state == 0);
     else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm, &pv_) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     *min_piv = (pv_ == pv_) ? fmin(*min_piv, pv_) : *min_piv;
@@ -1651,7 +1666,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   }
 }
 
-template <int V2>
+template <int V2, bool MEM = false>
 __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc, int nmod) {
   Lds L;
   const int nb = P.nb;
@@ -1668,14 +1683,15 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
     L.psp = P.pq + (size_t)blockIdx.x * 2 * nbe; L.qsp = L.psp + nbe; L.rhs = nxt;
   } else { L.psp = nxt; L.qsp = L.psp + nbe; L.rhs = L.qsp + nbe; }
   L.rq = L.rhs + nbe;
-  L.blk = L.rhs + 2 * nbe;
+  L.stage = L.rhs + 2 * nbe;
+  L.blk = MEM ? P.blk_mem + (size_t)blockIdx.x * P.blk_mem_stride : L.stage;
   L.bs = (P.nblk + 1) & ~1;
   L.nfull = V2 ? P.nfull : P.nblk;
   const int nfs = (L.nfull + 1) & ~1;
   L.o2 = 2 * L.bs; L.o3 = 2 * L.bs + nfs;
   const int nval = V2 ? 2 * L.bs + 2 * nfs : 4 * L.bs;      // (first-generation kernel: 32-byte records)
-  const int nblk_d = nval > nres ? nval : nres;
-  L.sp = L.blk + ((nblk_d + 1) & ~1);
+  const int nblk_d = (!MEM && nval > nres) ? nval : nres;
+  L.sp = L.stage + ((nblk_d + 1) & ~1);
   L.acc = L.sp + na;
   L.mod = L.acc + nacc;
   L.bt = reinterpret_cast<unsigned char*>(L.mod + MOD_DOUBLES * nmod);
@@ -1696,12 +1712,12 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
 #ifndef OPFX_MIN_WAVES_PER_SIMD
 #define OPFX_MIN_WAVES_PER_SIMD 2
 #endif
-template <int V2, int NW, bool DC = false>
+template <int V2, int NW, bool DC = false, bool MEM = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nres_ = 3 * P.nb + P.nbr + 2 * P.nref;
-  const Lds L = carve<V2>(P, 0, nres_, smem, 8, 1);
+  const Lds L = carve<V2, MEM>(P, 0, nres_, smem, 8, 1);
   if (V2) {
     for (int i = threadIdx.x; i < P.nb; i += blockDim.x) L.dg[i] = (unsigned short)P.diag_blk[i];
     for (int i = threadIdx.x; i < P.tail_n; i += blockDim.x) L.tl[i] = P.tail_ids[i];
@@ -1724,10 +1740,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     blk_sync<NW>();
     int iters; double nrm;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
-    const bool conv = solve_instance<V2, NW, DC>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
+    const bool conv = solve_instance<V2, NW, DC, MEM>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
     blk_sync<NW>();
     if (wave == 0) {
-      double* R = L.blk;
+      double* R = L.stage;
       compute_results<V2>(P, L, lane, out_br, n_mod, io.qg_min, io.qg_max, R, false, io.va != nullptr);
       sec_sync<NW>();
       const int nb = P.nb, nbr = P.nbr, nref = P.nref;
@@ -2124,7 +2140,7 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <int V2, int NW, bool DC = false>
+template <int V2, int NW, bool DC = false, bool MEM = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
@@ -2133,7 +2149,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Lds L = carve<V2>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8, E.max_mod);
+  const Lds L = carve<V2, MEM>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8, E.max_mod);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
@@ -2351,7 +2367,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW, DC>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
+      const bool conv = solve_instance<V2, NW, DC, MEM>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
@@ -2371,7 +2387,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
         pen_acc += E.not_converged_penalty;
         continue;
       }
-      double* R = L.blk;
+      double* R = L.stage;
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
@@ -2590,6 +2606,9 @@ struct opfx_ctx {
   int n_cu = 0;
   int solve_per_cu = 0;
   int solve_per_cu_dc = 0;
+  int solve_per_cu_mem = 0;
+  double* blk_mem = nullptr;           // memory-resident kernels: LU block values, one row per resident workgroup
+  size_t blk_mem_rows = 0;
   opfx_plan plan;     // host copy
   DevPlan dp{};
   const DevPlan* d_dp = nullptr;   // device copy of dp (kernels take it by pointer)
@@ -2608,15 +2627,17 @@ struct opfx_env {
   size_t lds_bytes = 0;
   int per_cu = 0;
   int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
+  bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
   int n_full = 0;        // four-value blocks this environment's kernels run with (choose_block_storage)
 };
 
 namespace {
 
-size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod, int n_full) {
+size_t solver_lds_bytes(const opfx_plan& p, int na, int nres, bool v2, int nacc, int nmod, int n_full, bool mem = false) {
   const size_t nbe = ((size_t)p.nb + 1) & ~(size_t)1;
   const size_t bs = ((size_t)p.n_blk + 1) & ~(size_t)1, nfs = ((size_t)n_full + 1) & ~(size_t)1;
-  size_t blk = (std::max<size_t>(v2 ? 2 * bs + 2 * nfs : 4 * bs, (size_t)nres) + 1) & ~(size_t)1;
+  // (memory-resident kernels: the block values are in global memory, the area only stages the table row / result bank)
+  size_t blk = (std::max<size_t>(mem ? 0 : (v2 ? 2 * bs + 2 * nfs : 4 * bs), (size_t)nres) + 1) & ~(size_t)1;
   size_t d = (v2 ? 4 : 8) * nbe + blk + (size_t)na + (size_t)nacc + (size_t)12 * nmod;
   size_t bytes = d * sizeof(double) + (((size_t)p.nb + 1) & ~(size_t)1) +       // + bus types, diagonal block ids, tail table
                  (v2 ? 2 * ((((size_t)p.nb + 1) & ~(size_t)1) + p.tail_ids.size()) + (p.tail_ids.empty() ? 0 : 16) : 0);
@@ -2685,6 +2706,25 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
 
 }  // namespace
 
+// Memory-resident form (grids past the LDS): block values of every resident workgroup in one row of global memory.
+static bool wants_mem(size_t lds_resident, bool v2) {
+  return v2 && (lds_resident > 160 * 1024 || getenv("OPFX_FORCE_MEM") != nullptr);    // (env var: developer / test switch)
+}
+static size_t blk_mem_stride(const opfx_plan& p) { return 4 * ((((size_t)p.n_blk + 1) & ~(size_t)1)); }
+static int ensure_blk_mem(opfx_ctx* ctx, int rows) {
+  if ((size_t)rows <= ctx->blk_mem_rows) return OPFX_OK;
+  void* d = nullptr;
+  const size_t bytes = (size_t)rows * blk_mem_stride(ctx->plan) * sizeof(double);
+  if (hipMalloc(&d, bytes) != hipSuccess) {
+    opfx_set_error("hipMalloc(block values of the memory-resident kernel, " + std::to_string(bytes >> 20) + " MiB) failed");
+    return OPFX_ERR_HIP;
+  }
+  ctx->arena.ptrs.push_back(d);          // (an earlier, smaller buffer stays with the arena until the context goes)
+  ctx->blk_mem = static_cast<double*>(d);
+  ctx->blk_mem_rows = (size_t)rows;
+  return OPFX_OK;
+}
+
 extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   if (!p || !out) { opfx_set_error("opfx_ctx_create: null argument"); return OPFX_ERR_INVALID; }
   int n_dev = 0;
@@ -2724,6 +2764,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   d.lp_dc = nullptr; d.lp_hdc = nullptr;
+  d.blk_mem = nullptr; d.blk_mem_stride = 0;
   if (!p->lp_dc.empty()) { PUT(lp_dc, lp_dc); PUT(lp_hdc, lp_hdc); }
   d.n_hrows = (int)p->lp_hrows.size();
   if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
@@ -2775,6 +2816,24 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   int n_full = ctx->plan.n_blk;
   size_t lds = choose_block_storage(ctx->plan, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
   DevPlan dp = ctx->dp;
+  if (wants_mem(lds, ctx->v2)) {
+    // the LU blocks do not fit the LDS beside the state vectors: wave team of four, four-value blocks in global memory
+    n_full = ctx->plan.n_blk;
+    lds = solver_lds_bytes(ctx->plan, 0, nres, true, 8, 1, n_full, true);
+    dp.nfull = n_full;
+    int grid = 0;
+    auto kern = k_solve<1, 4, false, true>;
+    int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu_mem, WAVE * 4);
+    if (rc != OPFX_OK) return rc;
+    rc = ensure_blk_mem(ctx, ctx->solve_per_cu_mem * ctx->n_cu);
+    if (rc != OPFX_OK) return rc;
+    dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
+    if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
+    SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
+    HIP_TRY(hipGetLastError());
+    return OPFX_OK;
+  }
   dp.nfull = n_full;
   int grid = 0;
   const int team = pick_team(lds, ctx->v2);
@@ -3027,6 +3086,11 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
   e->lds_bytes = choose_block_storage(p, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod, nf); }, &e->n_full);
+  if (wants_mem(e->lds_bytes, ctx->v2)) {
+    e->mem = true;
+    e->n_full = p.n_blk;
+    e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, true, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod, e->n_full, true);
+  }
   *out = e;
   return OPFX_OK;
 }
@@ -3040,15 +3104,22 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  const int team = pick_team(env->lds_bytes, env->ctx->v2);
+  const int team = env->mem ? 4 : pick_team(env->lds_bytes, env->ctx->v2);
   DevPlan dp = env->ctx->dp;
   dp.nfull = env->n_full;
   const bool packed = env->n_full < env->ctx->plan.n_blk;
   auto kern = !env->ctx->v2 ? k_step<0, 1>
             : packed ? (team == 4 ? k_step<2, 4> : (team == 2 ? k_step<2, 2> : k_step<2, 1>))
                      : (team == 4 ? k_step<1, 4> : (team == 2 ? k_step<1, 2> : k_step<1, 1>));
+  if (env->mem) kern = k_step<1, 4, false, true>;
   int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
+  if (env->mem) {
+    rc = ensure_blk_mem(env->ctx, env->per_cu * env->ctx->n_cu);
+    if (rc != OPFX_OK) return rc;
+    dp.blk_mem = env->ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(env->ctx->plan);
+    if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
+  }
   if (o.init == OPFX_INIT_DC && env->ctx->v2) {      // the kernels compiled with the DC start (same launch geometry)
     kern = packed ? (team == 4 ? k_step<2, 4, true> : (team == 2 ? k_step<2, 2, true> : k_step<2, 1, true>))
                   : (team == 4 ? k_step<1, 4, true> : (team == 2 ? k_step<1, 2, true> : k_step<1, 1, true>));
@@ -3108,7 +3179,7 @@ extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
 extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
                                  int32_t* instances_per_cu) {
   if (!env) { opfx_set_error("opfx_env_get_info: null environment"); return OPFX_ERR_INVALID; }
-  if (waves_per_instance) *waves_per_instance = pick_team(env->lds_bytes, env->ctx->v2);
+  if (waves_per_instance) *waves_per_instance = env->mem ? 4 : pick_team(env->lds_bytes, env->ctx->v2);
   if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
   if (instances_per_cu) *instances_per_cu = env->per_cu;
   return OPFX_OK;

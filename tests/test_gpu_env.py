@@ -525,6 +525,24 @@ def test_env_option_init_dc_and_auto():
     assert lv.init == 'flat'                                        # 20 kV slack: no angle calculation, flat start
 
 
+@pytest.mark.parametrize('name', ['eco_hv_small', 'sc_hv_small', 'vc_mv_small', 'reconf_hv_small_sw'])
+def test_env_on_the_memory_resident_kernel_matches_the_golden(name, monkeypatch):
+    """The fused step on the memory-resident form of the team kernel (OPFX_FORCE_MEM: block values in global memory)
+    replays golden scenarios of the reference — q-limits, N-1 contingencies, switch / tap modifiers included."""
+    monkeypatch.setenv('OPFX_FORCE_MEM', '1')
+    g = golden(name)
+    n = len(g['step'])
+    env = product_env(name, batch_size=n)
+    assert env.kernel_info()['waves_per_instance'] == 4
+    env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None})
+    out = env.step(g['action'])
+    assert _np(out[4]['converged']).all()
+    n1 = bool(env.n_minus_one_keys)
+    for k in range(n):
+        ref = {key: g[key][k] for key in g if g[key].ndim and len(g[key]) == n and not key.startswith('fail_')}
+        _check_step(env, out, ref, k, n1)
+
+
 def test_is_state_valid_without_any_constraint():
     """no constraints at all -> an empty all() is True (opf_env.py:613-618), not a column the kernel never writes."""
     from opfgym_amd import envs

@@ -484,3 +484,62 @@ def test_dc_start_needs_the_dc_model_of_the_branches():
     z = torch.zeros(2, case.nb, dtype=torch.float64, device='cuda:0')
     with pytest.raises(capi.OpfxError, match='OPFX_INIT_DC'):
         capi.solve(ctx, z, z, init='dc')
+
+
+@pytest.mark.parametrize('code,B', [('1-HV-mixed--0-sw', 40), ('hv-small', 64), ('1-MV-urban--0-sw', 64), ('mv-3w', 32)])
+def test_memory_resident_kernel_matches_the_oracle_on_grids_that_also_fit_the_lds(code, B, monkeypatch):
+    """The memory-resident form of the wave-team kernel (LU block values in a per-workgroup row of global memory,
+    state vectors in LDS; chosen when a grid's blocks do not fit the LDS) forced on grids the LDS-resident kernels
+    also run (OPFX_FORCE_MEM): same voltages, loadings, slack power and iteration counts, outages included."""
+    monkeypatch.setenv('OPFX_FORCE_MEM', '1')
+    net, case, p, q, out = _run(code, B, seed=41)
+    ref = oracle_batch(net, case, p, q)
+    assert ref['converged'].all() and out['converged'].astype(bool).all()
+    assert np.abs(out['vm'] - ref['vm']).max() < TOL_V
+    assert np.abs(np.angle(np.exp(1j * (out['va'] - ref['va'])))).max() < TOL_V
+    assert np.abs(out['loading'] - ref['loading']).max() < 1e-6
+    assert np.abs(out['s_ref'] - ref['s_ref']).max() < 1e-8
+    assert (np.abs(out['iterations'] - ref['iterations']) <= 1).all() and (out['max_mismatch'] < 1e-8).all()
+    # one branch out of service per instance (modifier path of the team kernel)
+    import torch
+    from helpers import non_bridge_branches
+    from opfgym_amd import capi
+    cand = non_bridge_branches(case)
+    outage = np.random.default_rng(5).choice(cand, B).astype(np.int32)
+    ctx = capi.Context(capi.Plan(case), 0)
+    dev = torch.device('cuda:0')
+    o2 = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev),
+                                                     outage=torch.tensor(outage, device=dev)).items()}
+    r2 = oracle_batch(net, case, p, q, outage=outage)
+    both = r2['converged'] & o2['converged'].astype(bool)
+    assert both.sum() >= B // 2 and (r2['converged'] == o2['converged'].astype(bool)).all()
+    assert np.abs(o2['vm'] - r2['vm'])[both].max() < TOL_V
+
+
+def test_a_grid_past_the_lds_runs_on_the_memory_resident_kernel():
+    """1 000 buses, 8 788 LU blocks = 276 KB of block values: more than a CU's LDS.  The reference has no such limit
+    (opf_env.py:703 hands any net to pandapower); OPFX_ERR_TOO_LARGE is gone: the solve runs with the blocks in
+    global memory, against the oracle on a handful of instances."""
+    import torch
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = grids.synthetic_hv(5, nb=1000, n_ext=2, n_gen=10)
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    assert plan.info['lds_doubles'] * 8 > 160 * 1024 and plan.info['n_blk'] < 32768
+    ctx = capi.Context(plan, 0)
+    B = 6
+    p, q = random_injections(net, case, B, seed=3, lo=0.5, hi=1.0)
+    dev = torch.device('cuda:0')
+    out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
+    ref = oracle_batch(net, case, p, q)
+    assert ref['converged'].all() and out['converged'].astype(bool).all()
+    assert np.abs(out['vm'] - ref['vm']).max() < TOL_V
+    assert np.abs(np.angle(np.exp(1j * (out['va'] - ref['va'])))).max() < TOL_V
+    assert np.abs(out['loading'] - ref['loading']).max() < 1e-6
+    assert (np.abs(out['iterations'] - ref['iterations']) <= 1).all()
+    # a batch larger than the resident workgroups: every row solved, same iteration counts for equal inputs
+    big = capi.solve(ctx, torch.tensor(np.repeat(p, 200, axis=0), device=dev), torch.tensor(np.repeat(q, 200, axis=0), device=dev))
+    assert bool(big['converged'].all())
+    assert np.array_equal(big['iterations'].cpu().numpy().reshape(B, 200), np.repeat(out['iterations'][:, None], 200, axis=1))
+    assert np.abs(big['vm'].cpu().numpy().reshape(B, 200, -1) - out['vm'][:, None, :]).max() < 1e-11
