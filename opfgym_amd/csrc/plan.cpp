@@ -108,6 +108,78 @@ void renumber_blocks(opfx_plan* p) {
   std::sort(p->fill_blk.begin(), p->fill_blk.end());
 }
 
+// LDS bank conflicts of the B/C items.  A wave's 64-bit LDS access is served in two groups of 32 lanes over 32
+// eight-byte banks, and every operand array of the kernels is indexed by an id, so within one access the bank of a lane
+// is (array base + id) mod 32: two lanes of a group collide when their ids differ but agree mod 32 (equal ids are a
+// broadcast).  The items of one group of the stream (an elimination level, the back-substitution terms of a level) are
+// mutually independent, so which round and which half-wave runs which item is free: every item goes, in stream order,
+// to the half-round where it adds the fewest extra LDS cycles over its accesses (A_ik, A_kk, A_kj or y_k, the target's
+// atomics, a rider's y_k / y_i; a group of 32 lanes takes as many cycles as its busiest bank holds addresses).
+// `base`: n_rounds x 64 items x 4 words, in place; word 3 (flags) stays with its round.  OPFX_PLAN_NO_BANK=1 keeps the
+// plan's own order.
+void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
+  constexpr uint32_t NONE = 0xFFFFu;
+  struct It { uint32_t w[3]; int id[6]; int wt[6]; };
+  std::vector<It> live;
+  for (int l = 0; l < 64 * n_rounds; ++l) {
+    const uint32_t* w = base + 4 * l;
+    if ((w[0] & 0xFFFF) == NONE) continue;
+    It it{};
+    for (int q = 0; q < 3; ++q) it.w[q] = w[q];
+    const uint32_t tb = w[0] & 0xFFFF, ik = w[0] >> 16, kk = w[1] & 0xFFFF, kj = w[1] >> 16;
+    const bool rhs_t = (tb & 0x8000u) != 0;
+    // access classes: 0 blocks read through ik, 1 through kk, 2 through kj (block) / 3 (right-hand side), 4 target
+    // atomics on blocks / 5 on the right-hand side (weights: LDS instructions of that access; atomics count double)
+    for (int c = 0; c < 6; ++c) { it.id[c] = -1; it.wt[c] = 0; }
+    it.id[0] = (int)ik; it.wt[0] = (int)ik < n_full ? 4 : 2;
+    it.id[1] = (int)kk; it.wt[1] = 4;
+    if (rhs_t) { it.id[3] = (int)kj; it.wt[3] = 2; it.id[5] = (int)(tb & 0x7FFF); it.wt[5] = 4; }
+    else { it.id[2] = (int)kj; it.wt[2] = (int)kj < n_full ? 4 : 2; it.id[4] = (int)tb; it.wt[4] = 8; }
+    if ((w[2] >> 16) != NONE) { it.id[3] = (int)(w[2] >> 16); it.wt[3] += 2; if (it.id[5] < 0) { it.id[5] = (int)(w[2] & 0xFFFF); it.wt[5] = 4; } }
+    live.push_back(it);
+  }
+  const int n = (int)live.size(), nbin = 2 * n_rounds;
+  if (n < 2) return;
+  // rounds actually needed stay as they are: the items fill the first ceil(n / 64) rounds (a round that is empty in
+  // the plan's order stays empty: padding)
+  const int used_rounds = (n + 63) / 64, used_bins = 2 * used_rounds;
+  struct Banks { std::array<std::vector<int>, 32> ids; int worst = 0; };
+  std::vector<std::array<Banks, 6>> tab(used_bins);
+  std::vector<int> cnt(used_bins, 0), bin_of(n, 0);
+  auto price = [&](int h, const It& it) {
+    int c_ = 0;
+    for (int c = 0; c < 6; ++c) {
+      if (it.id[c] < 0) continue;
+      const auto& v = tab[h][c].ids[it.id[c] & 31];
+      if (std::find(v.begin(), v.end(), it.id[c]) != v.end()) continue;            // (same address: a broadcast)
+      if ((int)v.size() + 1 > std::max(tab[h][c].worst, 1)) c_ += it.wt[c];
+    }
+    return c_;
+  };
+  for (int q = 0; q < n; ++q) {
+    int best = -1, best_cost = 0;
+    for (int h = 0; h < used_bins; ++h) {
+      if (cnt[h] >= 32) continue;
+      const int c = 64 * price(h, live[q]) + cnt[h];          // (ties: the emptier half-round)
+      if (best < 0 || c < best_cost) { best = h; best_cost = c; }
+    }
+    bin_of[q] = best; ++cnt[best];
+    for (int c = 0; c < 6; ++c) {
+      if (live[q].id[c] < 0) continue;
+      auto& v = tab[best][c].ids[live[q].id[c] & 31];
+      if (std::find(v.begin(), v.end(), live[q].id[c]) == v.end()) { v.push_back(live[q].id[c]); tab[best][c].worst = std::max(tab[best][c].worst, (int)v.size()); }
+    }
+  }
+  (void)nbin;
+  for (int l = 0; l < 64 * n_rounds; ++l) { uint32_t* w = base + 4 * l; w[0] = NONE | (NONE << 16); w[1] = NONE | (NONE << 16); w[2] = NONE | (NONE << 16); }
+  std::vector<int> at(used_bins);
+  for (int h = 0; h < used_bins; ++h) at[h] = (h / 2) * 64 + (h & 1) * 32;
+  for (int q = 0; q < n; ++q) {
+    uint32_t* w = base + 4 * (at[bin_of[q]]++);
+    for (int k = 0; k < 3; ++k) w[k] = live[q].w[k];
+  }
+}
+
 void build_lane_programs(opfx_plan* p) {
   constexpr int KA = opfx_plan::KA;
   constexpr uint32_t NONE = 0xFFFFu;
@@ -337,6 +409,11 @@ void build_lane_programs(opfx_plan* p) {
   for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
     for (int r = p->lp_groups[g]; r + 1 < p->lp_groups[g + 1]; ++r)
       for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = 2u;
+  const bool spread = !getenv("OPFX_PLAN_NO_BANK");
+  if (spread)
+    for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
+      if (p->lp_groups[g + 1] > p->lp_groups[g])
+        spread_over_banks(&p->lp_bc[(size_t)p->lp_groups[g] * 256], p->lp_groups[g + 1] - p->lp_groups[g], p->n_full);
   // ---- the dense tail ---------------------------------------------------------------------------
   // A meshed grid ends in a chain of levels with ONE pivot each (the last separator fills in completely:
   // 16 such levels on the 306-bus grid, 20 on the 372-bus one).  Their back substitution is a strictly serial
@@ -423,6 +500,7 @@ void build_lane_programs(opfx_plan* p) {
         uint32_t* at = &tbk[((size_t)(first + r) * 64 + l) * 4];
         at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w2;
       }
+      if (spread) spread_over_banks(&tbk[(size_t)first * 256], nr, p->n_full);
       groups.push_back({2, first, first + nr});
     }
     if (tail_m == 0)
@@ -433,7 +511,10 @@ void build_lane_programs(opfx_plan* p) {
       }
     const size_t n_first = tail_m > 0 ? groups.size() : 0;
     if (tail_m > 0)
-      for (size_t g = 0; g + 1 < tc_bounds.size(); ++g) groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
+      for (size_t g = 0; g + 1 < tc_bounds.size(); ++g) {
+        if (spread && t == 0) spread_over_banks(&tc[(size_t)tc_bounds[g] * 256], tc_bounds[g + 1] - tc_bounds[g], p->n_full);
+        groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
+      }
     p->team_kb[t] = -1;
     for (size_t g = 0; g < groups.size(); ++g) {
       const int r0 = groups[g].r0, r1 = groups[g].r1;
