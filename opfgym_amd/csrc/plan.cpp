@@ -156,19 +156,45 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
     }
     return c_;
   };
-  for (int q = 0; q < n; ++q) {
+  auto put = [&](int h, const It& it) {
+    for (int c = 0; c < 6; ++c) {
+      if (it.id[c] < 0) continue;
+      auto& v = tab[h][c].ids[it.id[c] & 31];
+      if (std::find(v.begin(), v.end(), it.id[c]) == v.end()) { v.push_back(it.id[c]); tab[h][c].worst = std::max(tab[h][c].worst, (int)v.size()); }
+    }
+  };
+  auto rebuild = [&](int h, int skip) {          // the tables of half-round h without item `skip`
+    for (int c = 0; c < 6; ++c) { for (auto& v : tab[h][c].ids) v.clear(); tab[h][c].worst = 0; }
+    for (int q = 0; q < n; ++q) if (bin_of[q] == h && q != skip) put(h, live[q]);
+  };
+  auto choose = [&](const It& it) {
     int best = -1, best_cost = 0;
     for (int h = 0; h < used_bins; ++h) {
       if (cnt[h] >= 32) continue;
-      const int c = 64 * price(h, live[q]) + cnt[h];          // (ties: the emptier half-round)
+      const int c = 64 * price(h, it) + cnt[h];              // (ties: the emptier half-round)
       if (best < 0 || c < best_cost) { best = h; best_cost = c; }
     }
-    bin_of[q] = best; ++cnt[best];
-    for (int c = 0; c < 6; ++c) {
-      if (live[q].id[c] < 0) continue;
-      auto& v = tab[best][c].ids[live[q].id[c] & 31];
-      if (std::find(v.begin(), v.end(), live[q].id[c]) == v.end()) { v.push_back(live[q].id[c]); tab[best][c].worst = std::max(tab[best][c].worst, (int)v.size()); }
+    return best;
+  };
+  std::fill(bin_of.begin(), bin_of.end(), -1);
+  for (int q = 0; q < n; ++q) { const int h = choose(live[q]); bin_of[q] = h; ++cnt[h]; put(h, live[q]); }
+  // local search: take an item that sits on a busiest bank of its half-round out and place it again
+  for (int pass = 0; pass < 1; ++pass) {
+    bool moved = false;
+    for (int q = 0; q < n; ++q) {
+      const int h0 = bin_of[q];
+      bool hot = false;
+      for (int c = 0; c < 6 && !hot; ++c)
+        if (live[q].id[c] >= 0 && tab[h0][c].worst > 1 && (int)tab[h0][c].ids[live[q].id[c] & 31].size() == tab[h0][c].worst) hot = true;
+      if (!hot) continue;
+      rebuild(h0, q); --cnt[h0]; bin_of[q] = -1;
+      const int before = 64 * price(h0, live[q]) + cnt[h0];
+      int h1 = choose(live[q]);
+      if (64 * price(h1, live[q]) + cnt[h1] >= before) h1 = h0;
+      bin_of[q] = h1; ++cnt[h1]; put(h1, live[q]);
+      moved = moved || h1 != h0;
     }
+    if (!moved) break;
   }
   (void)nbin;
   for (int l = 0; l < 64 * n_rounds; ++l) { uint32_t* w = base + 4 * l; w[0] = NONE | (NONE << 16); w[1] = NONE | (NONE << 16); w[2] = NONE | (NONE << 16); }
