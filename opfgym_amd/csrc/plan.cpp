@@ -151,7 +151,8 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
     for (int c = 0; c < 6; ++c) {
       if (it.id[c] < 0) continue;
       const auto& v = tab[h][c].ids[it.id[c] & 31];
-      if (std::find(v.begin(), v.end(), it.id[c]) != v.end()) continue;            // (same address: a broadcast)
+      // (reads of one address are a broadcast; atomic adds on one address are serialised like any other conflict)
+      if (c < 4 && std::find(v.begin(), v.end(), it.id[c]) != v.end()) continue;
       if ((int)v.size() + 1 > std::max(tab[h][c].worst, 1)) c_ += it.wt[c];
     }
     return c_;
@@ -160,7 +161,7 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
     for (int c = 0; c < 6; ++c) {
       if (it.id[c] < 0) continue;
       auto& v = tab[h][c].ids[it.id[c] & 31];
-      if (std::find(v.begin(), v.end(), it.id[c]) == v.end()) { v.push_back(it.id[c]); tab[h][c].worst = std::max(tab[h][c].worst, (int)v.size()); }
+      if (c >= 4 || std::find(v.begin(), v.end(), it.id[c]) == v.end()) { v.push_back(it.id[c]); tab[h][c].worst = std::max(tab[h][c].worst, (int)v.size()); }
     }
   };
   auto rebuild = [&](int h, int skip) {          // the tables of half-round h without item `skip`
