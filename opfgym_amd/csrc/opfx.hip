@@ -1793,17 +1793,34 @@ __device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
 // ---------------------------------------------------------------------------
 // reset kernel: SimBench state sampling (opf_env.py:317-372) + `_sampling` tails
 // ---------------------------------------------------------------------------
-struct DevTable {
-  int n_steps, n_types, n_cols, noise_off;
-  const double *rel, *peak, *col_min, *col_max;
-  const int *typ, *slot;
-};
+// What a reset executes, FLATTENED at opfx_env_set_reset time into per-element lists so that a row needs few
+// dependent global-memory round trips (a round trip costs ~0.8 us with 16 waves per CU queueing on the L2, and a row is
+// a chain of them: in-kernel stamps of round 3 — template 3, two per profile table, two per vector op (its scalar
+// descriptor, then its constants), one per observation segment = 24 for the 144-bus VoltageControl row, 19 us):
+//   * profile columns of ALL tables as one list (table data per column: relative-profile base, types per step, ...):
+//     descriptors in one round trip, profile values in a second;
+//   * the vector ops as STAGES of mutually independent elements (an element = one (op, j): code, destination, source,
+//     its three constants): all ops that do not depend on one another run in one pass, e.g. VoltageControl's tail
+//     {max_p, min_p, q := 0} | {max_q} | {min_q} is 3 round trips instead of 10;
+//   * the observation as one element list (source kind | index).
 constexpr int MAX_TABLES = 8;
 struct DevReset {
-  int n_tables, n_ops, n_uniform, n_normal, n_noise, nx, init_off;
-  DevTable tab[MAX_TABLES];
-  const int *op_code, *op_dst, *op_a, *op_n, *op_c0, *op_c1, *op_c2, *op_mode;
-  const double* consts;
+  int n_tables, n_uniform, n_normal, n_noise, nx, init_off, has_mode;
+  int n_steps[MAX_TABLES];                 // (interpolation guard per table)
+  // profile columns, all tables
+  int n_tcols;
+  const double* const* tc_rel;             // [n_tcols] relative profiles of the column's table ([n_steps, n_types])
+  const int *tc_nt, *tc_tab, *tc_typ, *tc_slot;      // types per step, table number, type, destination slot
+  const double *tc_peak, *tc_lo, *tc_hi;
+  // op elements by stage
+  int n_stages;
+  const int* st_ptr;                       // [n_stages + 1]
+  const int *el_code, *el_dst, *el_src;    // code | source mask << 8; destination slot; source slot or draw number
+  const double *el_k0, *el_k1, *el_k2;
+  const double* consts;                    // row template at init_off
+  // observation elements (environments whose observation needs no power flow)
+  int n_oel;
+  const int* oe_src;                       // kind << 28 | index: 0 row, 1 NaN (result entry), 2 action set-point
 };
 
 struct ResetIO {
@@ -1819,6 +1836,7 @@ struct ResetIO {
   int n_step_pool;
   unsigned long long rng_seed;
   int* step_out;
+  unsigned long long* stamps;   // developer probe (stamps build): per-phase cycle sums of wavefront 0 of workgroup 0
 };
 
 // Standard normal truncated to [a, b], by inverse CDF of a uniform draw u — what scipy.stats.truncnorm.ppf(u, a, b)
@@ -1871,63 +1889,52 @@ __device__ __forceinline__ double draw_normal(unsigned long long seed, long long
   return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
-// ---- where a reset reads what is the same for every instance -----------------------------------------------------
-// Everything but the profile rows themselves — the row template and the constants of the vector ops, the per-column
-// descriptors of the profile tables, the op list, the action and observation descriptors — is reached through a
-// source policy.  SrcGlobal reads it from global memory (L2-resident).  Round 3 also tried an image of it in LDS, copied
-// once per persistent workgroup, so that a row's chain of ~20 L2 round trips shrinks to the time step, the profile
-// values and the stores: 64.9 us per reset of 8192 instances against 56.8 us for this form — the image leaves room for
-// 13 rows per CU instead of 16 and the rows no longer divide evenly over the wavefronts (profiles/r03_reset_experiments.txt);
-// removed again.
-enum { OPF_CODE = 0, OPF_DST, OPF_A, OPF_N, OPF_C0, OPF_C1, OPF_C2, OPF_MODE, OPF_FIELDS };
-enum { AI_SLOT = 0, AI_LO_SLOT, AI_HI_SLOT, AI_KIND, AI_CLAMP_LO_SLOT, AI_CLAMP_HI_SLOT, AI_FIELDS };
-enum { AD_LO = 0, AD_HI, AD_SCALING, AD_CLAMP_LO, AD_CLAMP_HI, AD_FIELDS };
-enum { OS_KIND = 0, OS_SRC, OS_DST, OS_N, OS_FIELDS };
-struct EnvScalars { int na, nobs, n_oseg, clamp_enabled; };
+#ifdef OPFX_ENABLE_STAMPS
+#define RSTAMP(slot)                                                                          \
+  do {                                                                                        \
+    if (io.stamps && blockIdx.x == 0 && threadIdx.x < 64) {                                   \
+      const unsigned long long now__ = __builtin_readcyclecounter();                          \
+      if (threadIdx.x == 0) io.stamps[slot] += now__ - rt_last__;                              \
+      rt_last__ = __builtin_readcyclecounter();                                               \
+    }                                                                                         \
+  } while (0)
+#else
+#define RSTAMP(slot) do { } while (0)
+#endif
 
-struct SrcGlobal {
-  const DevReset& R;
-  const DevEnv* E;
-  __device__ __forceinline__ EnvScalars env() const { return E ? EnvScalars{E->na, E->nobs, E->n_oseg, E->clamp_enabled} : EnvScalars{0, 0, 0, 0}; }
-  __device__ __forceinline__ double cst(int off) const { return R.consts[off]; }
-  __device__ __forceinline__ int t_typ(int t, int j) const { return R.tab[t].typ[j]; }
-  __device__ __forceinline__ int t_slot(int t, int j) const { return R.tab[t].slot[j]; }
-  __device__ __forceinline__ double t_peak(int t, int j) const { return R.tab[t].peak[j]; }
-  __device__ __forceinline__ double t_lo(int t, int j) const { return R.tab[t].col_min[j]; }
-  __device__ __forceinline__ double t_hi(int t, int j) const { return R.tab[t].col_max[j]; }
-  __device__ __forceinline__ int op(int f, int k) const {
-    const int* const* tabs[OPF_FIELDS] = {&R.op_code, &R.op_dst, &R.op_a, &R.op_n, &R.op_c0, &R.op_c1, &R.op_c2, &R.op_mode};
-    return (*tabs[f])[k];
+// One vector-op element (include/opfx.h OPFX_OP_*): rv = the source value of the row (or 0), dr = its draw (or 0)
+__device__ __forceinline__ double op_value(int code, double rv, double dr, double k0, double k1, double k2) {
+  switch (code) {
+    case OPFX_OP_SET_CONST: return k0;
+    case OPFX_OP_AFFINE: return rv * k0 + k1;
+    case OPFX_OP_SQRT_DIFF: return sqrt(k0 * k0 - rv * rv);
+    case OPFX_OP_NEG: return -rv;
+    case OPFX_OP_UNIFORM: return (k0 + dr * (k1 - k0)) / k2;
+    case OPFX_OP_NORMAL: return k0 + k1 * dr;
+    case OPFX_OP_CLIP: return fmin(fmax(rv, k0), k1);
+    case OPFX_OP_NORMINV: return k0 + k1 * normcdfinv(rv);
+    case OPFX_OP_TRUNCNORM: return truncnorm_ppf(rv, k0, k1);
+    default: return rv / k0;                 // OPFX_OP_DIV
   }
-  __device__ __forceinline__ bool has_op_mode() const { return R.op_mode != nullptr; }
-  __device__ __forceinline__ int ai(int f, int k) const {
-    const int* p = f == AI_SLOT ? E->act_slot : f == AI_LO_SLOT ? E->act_lo_slot : f == AI_HI_SLOT ? E->act_hi_slot
-                 : f == AI_KIND ? E->act_kind : f == AI_CLAMP_LO_SLOT ? E->clamp_lo_slot : E->clamp_hi_slot;
-    return as_global(p)[k];
-  }
-  __device__ __forceinline__ double ad(int f, int k) const {
-    const double* p = f == AD_LO ? E->act_lo_const : f == AD_HI ? E->act_hi_const : f == AD_SCALING ? E->act_scaling
-                    : f == AD_CLAMP_LO ? E->clamp_lo_const : E->clamp_hi_const;
-    return as_global(p)[k];
-  }
-  __device__ __forceinline__ int os(int f, int sg) const {
-    const int* p = f == OS_KIND ? E->oseg_kind : f == OS_SRC ? E->oseg_src : f == OS_DST ? E->oseg_dst : E->oseg_n;
-    return as_global(p)[sg];
-  }
-};
+}
 
 // The reset of ONE instance by one wavefront: the row is built in LDS (`row`: nx doubles, `sp`: na doubles) — template
-// -> profile values -> vector-op programme -> optionally the initial action and the table observation
+// -> profile values -> vector-op stages -> optionally the initial action and the table observation
 // (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make a round trip
-// through memory.  U: 64-column chunks whose loads are requested together (nothing else hides the round trips).
-// (Round 3 also ran this function in the epilogue of the step kernel, the reset of a finished single-step episode
-// inside the launch of its step: bit-identical rows, but 404.6 us per launch against 270.3 + 56.8 us for the two
-// launches — the step kernel's throughput is waves / latency per instance, and the reset's chain of round trips adds
-// its whole latency to every instance; profiles/r03_reset_experiments.txt.  Removed again.)
-template <class SRC, int U>
-__device__ __forceinline__ void reset_row(const SRC& S, const DevReset& R, const ResetIO& io, long long b, int lane,
+// through memory.  Every pass requests the loads of up to U 64-element chunks before the first use.
+// (Round 3 also ran the reset in the epilogue of the step kernel — bit-identical rows, 404.6 us per launch against
+// 270.3 + 56.8 us for two launches: the step kernel's throughput is waves / latency per instance and the reset's chain of
+// round trips adds its whole latency to every instance — and with its descriptors in an LDS image per persistent
+// workgroup — 64.9 vs 56.8 us: 13 rows per CU instead of 16.  profiles/r03_reset_experiments.txt.  Both removed.)
+// U: chunks per round trip of the element passes (profile columns, op elements); UC: of the plain copies (template,
+// observation, store) — sized so that the kernel stays at 128 VGPRs: 16 rows in flight per CU, as many as the LDS holds.
+template <int U, int UC>
+__device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b, int lane,
                                           double* const row, double* const sp) {
   const double NaN = __builtin_nan("");
+#ifdef OPFX_ENABLE_STAMPS
+  unsigned long long rt_last__ = __builtin_readcyclecounter();
+#endif
   double* xr = io.x + b * R.nx;
   int step;
   if (io.step_pool) {
@@ -1938,112 +1945,101 @@ __device__ __forceinline__ void reset_row(const SRC& S, const DevReset& R, const
   } else {
     step = io.step_idx[b];
   }
-  const int mode = (io.mode && S.has_op_mode()) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
-  // start of the row: the table template, or the instance's own row (keep_state) — two loops, so that each reads from
-  // ONE address space (a select between an LDS and a global address would make every load a flat one)
-  if (R.init_off >= 0 && !io.keep_state) {
-    for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
-      double t[2 * U];
+  const int mode = (io.mode && R.has_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
+  RSTAMP(0);
+  // ---- the row template (or the instance's own row: keep_state), 2U chunks per round trip ----------------------
+  {
+    const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
+    for (int j0 = lane; j0 < R.nx; j0 += 64 * UC) {
+      double t[UC];
 #pragma unroll
-      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = S.cst(R.init_off + (j < R.nx ? j : R.nx - 1)); }
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
 #pragma unroll
-      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
-    }
-  } else {
-    for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
-      double t[2 * U];
-#pragma unroll
-      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = xr[j < R.nx ? j : R.nx - 1]; }
-#pragma unroll
-      for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
     }
   }
   wave_fence();
-  for (int t = 0; t < (mode <= 0 ? R.n_tables : 0); ++t) {
-    const DevTable& T = R.tab[t];
-    const double* rw = T.rel + (long long)step * T.n_types;
-    const bool interp = io.interp != nullptr && step < T.n_steps - 1;                // :345
-    const double rr = interp ? io.interp[b * R.n_tables + t] : 0.0;
-    const int nc = T.n_cols;
-    const double* nzp = io.noise ? io.noise + b * R.n_noise + T.noise_off : nullptr;
-    for (int j0 = lane; j0 < nc; j0 += 64 * U) {
-      int typ[U], slot[U];
-      double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U];
+  RSTAMP(1);
+  // ---- profile values of every table (opf_env.py:339-372) -------------------------------------------------------
+  const int n_tc = mode <= 0 ? R.n_tcols : 0;
+  for (int e0 = lane; e0 < n_tc; e0 += 64 * U) {
+    const double* rel[U];
+    int nt[U], tab[U], typ[U], slot[U];
+    double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U], rr[U];
+    bool itp[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = j0 + 64 * u, jc = j < nc ? j : nc - 1;
-        typ[u] = S.t_typ(t, jc); slot[u] = S.t_slot(t, jc); peak[u] = S.t_peak(t, jc); lo[u] = S.t_lo(t, jc); hi[u] = S.t_hi(t, jc);
-        nz[u] = nzp ? nzp[jc] : 1.0;
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 64 * u, ec = e < n_tc ? e : n_tc - 1;
+      rel[u] = R.tc_rel[ec]; nt[u] = R.tc_nt[ec]; tab[u] = R.tc_tab[ec]; typ[u] = R.tc_typ[ec]; slot[u] = R.tc_slot[ec];
+      peak[u] = R.tc_peak[ec]; lo[u] = R.tc_lo[ec]; hi[u] = R.tc_hi[ec];
+      nz[u] = io.noise ? io.noise[b * R.n_noise + ec] : 1.0;              // (noise columns are numbered like the list)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      itp[u] = io.interp != nullptr && step < R.n_steps[tab[u]] - 1;                      // :345
+      const double* rw = rel[u] + (long long)step * nt[u];
+      r0[u] = rw[typ[u]];
+      r1[u] = itp[u] ? rw[nt[u] + typ[u]] : 0.0;
+      rr[u] = itp[u] ? io.interp[b * R.n_tables + tab[u]] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double v = r0[u] * peak[u];                                                // :343
+      if (itp[u]) v = v * rr[u] + (r1[u] * peak[u]) * (1.0 - rr[u]);             // :347-349
+      if (io.noise) {
+        if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
+        else v = v * nz[u];                                                      // :354-356
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) { r0[u] = rw[typ[u]]; r1[u] = interp ? rw[T.n_types + typ[u]] : 0.0; }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        double v = r0[u] * peak[u];                                                // :343
-        if (interp) v = v * rr + (r1[u] * peak[u]) * (1.0 - rr);                   // :347-349
-        if (nzp) {
-          if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
-          else v = v * nz[u];                                                      // :354-356
-        }
-        v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
-        if (j0 + 64 * u < nc) row[slot[u]] = v;                                    // :371-372
-      }
+      v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
+      if (e0 + 64 * u < n_tc) row[slot[u]] = v;                                  // :371-372
     }
   }
   wave_fence();
-  for (int k = 0; k < R.n_ops; ++k) {
-    if (mode >= 0 && !((S.op(OPF_MODE, k) >> mode) & 1)) continue;
-    const int code = S.op(OPF_CODE, k), dst = S.op(OPF_DST, k), a = S.op(OPF_A, k), n = S.op(OPF_N, k);
-    const int o0 = S.op(OPF_C0, k), o1 = S.op(OPF_C1, k), o2 = S.op(OPF_C2, k);
-    // (an absent constant vector reads the start of the constant pool: the loads stay unconditional)
-    const bool has0 = o0 >= 0, has1 = o1 >= 0, has2 = o2 >= 0;
-    const int b0 = has0 ? o0 : 0, b1 = has1 ? o1 : 0, b2 = has2 ? o2 : 0;
-    // per-instance draw of the op, if it has one (same chunked, unconditional access); no draw array given: the
-    // kernel draws them itself from the per-reset seed, see draw_uniform
-    const double* draw = (code == OPFX_OP_UNIFORM && io.uniform) ? io.uniform + b * R.n_uniform + a
-                       : ((code == OPFX_OP_NORMAL && io.normal) ? io.normal + b * R.n_normal + a : nullptr);
-    const bool own_u = code == OPFX_OP_UNIFORM && !io.uniform, own_n = code == OPFX_OP_NORMAL && !io.normal;
-    const bool reads_row = code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL;
-    for (int j0 = lane; j0 < n; j0 += 64 * U) {
+  RSTAMP(2);
+  // ---- the `_sampling` tail: stages of mutually independent op elements -------------------------------------------
+  for (int sgi = 0; sgi < R.n_stages; ++sgi) {
+    const int s0 = R.st_ptr[sgi], s1 = R.st_ptr[sgi + 1];
+    for (int e0 = s0 + lane; e0 < s1; e0 += 64 * U) {
+      int cm[U], dst[U], src[U];
       double k0[U], k1[U], k2[U], dr[U], rv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = j0 + 64 * u, jc = j < n ? j : n - 1;
-        k0[u] = has0 ? S.cst(b0 + jc) : 0.0; k1[u] = has1 ? S.cst(b1 + jc) : 0.0; k2[u] = has2 ? S.cst(b2 + jc) : 0.0;
-        dr[u] = draw ? draw[jc] : (own_u ? draw_uniform(io.rng_seed, b, (unsigned)(a + jc)) : (own_n ? draw_normal(io.rng_seed, b, (unsigned)(a + jc)) : 0.0));
-        rv[u] = reads_row ? row[a + jc] : 0.0;
+        const int e = e0 + 64 * u, ec = e < s1 ? e : s1 - 1;
+        cm[u] = R.el_code[ec]; dst[u] = R.el_dst[ec]; src[u] = R.el_src[ec];
+        k0[u] = R.el_k0[ec]; k1[u] = R.el_k1[ec]; k2[u] = R.el_k2[ec];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = j0 + 64 * u;
-        double v;
-        if (code == OPFX_OP_SET_CONST) v = k0[u];
-        else if (code == OPFX_OP_AFFINE) v = rv[u] * k0[u] + k1[u];
-        else if (code == OPFX_OP_SQRT_DIFF) { const double s_ = k0[u], pz = rv[u]; v = sqrt(s_ * s_ - pz * pz); }
-        else if (code == OPFX_OP_NEG) v = -rv[u];
-        else if (code == OPFX_OP_UNIFORM) v = (k0[u] + dr[u] * (k1[u] - k0[u])) / k2[u];
-        else if (code == OPFX_OP_NORMAL) v = k0[u] + k1[u] * dr[u];
-        else if (code == OPFX_OP_CLIP) v = fmin(fmax(rv[u], k0[u]), k1[u]);
-        else if (code == OPFX_OP_NORMINV) v = k0[u] + k1[u] * normcdfinv(rv[u]);
-        else if (code == OPFX_OP_TRUNCNORM) v = truncnorm_ppf(rv[u], k0[u], k1[u]);
-        else v = rv[u] / k0[u];
-        if (j < n) row[dst + j] = v;
+        const int code = cm[u] & 0xFF;
+        const bool is_u = code == OPFX_OP_UNIFORM, is_n = code == OPFX_OP_NORMAL;
+        // the element's draw: from the caller's array, or made here from the per-reset seed (draw_uniform)
+        dr[u] = is_u ? (io.uniform ? io.uniform[b * R.n_uniform + src[u]] : draw_uniform(io.rng_seed, b, (unsigned)src[u]))
+              : (is_n ? (io.normal ? io.normal[b * R.n_normal + src[u]] : draw_normal(io.rng_seed, b, (unsigned)src[u])) : 0.0);
+        rv[u] = (is_u || is_n || code == OPFX_OP_SET_CONST) ? 0.0 : row[src[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool on = e0 + 64 * u < s1 && (mode < 0 || ((cm[u] >> (8 + mode)) & 1));
+        const double v = op_value(cm[u] & 0xFF, rv[u], dr[u], k0[u], k1[u], k2[u]);
+        if (on) row[dst[u]] = v;
       }
     }
     wave_fence();
   }
-  const EnvScalars es = S.env();
-  if (io.obs) {
+  RSTAMP(3);
+  if (io.obs && Ep) {
     // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
     // table part of the observation (:218); result entries are NaN
-    for (int k = lane; k < es.na; k += 64) {
+    const DevEnv& E = *Ep;
+    for (int k = lane; k < E.na; k += 64) {
       // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
-      const int slot = S.ai(AI_SLOT, k), ls = S.ai(AI_LO_SLOT, k), hs = S.ai(AI_HI_SLOT, k), kind = S.ai(AI_KIND, k);
-      const double loc = S.ad(AD_LO, k), hic = S.ad(AD_HI, k), scal = S.ad(AD_SCALING, k);
-      const bool clampa = (es.clamp_enabled & 2) != 0;
-      const int ch = clampa ? S.ai(AI_CLAMP_HI_SLOT, k) : -2, cl = clampa ? S.ai(AI_CLAMP_LO_SLOT, k) : -2;
-      const double chc = clampa ? S.ad(AD_CLAMP_HI, k) : 0.0, clc = clampa ? S.ad(AD_CLAMP_LO, k) : 0.0;
-      double a = io.action ? io.action[b * es.na + k] : 0.0;
+      const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
+      const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
+      const int kind = as_global(E.act_kind)[k];
+      const bool clampa = (E.clamp_enabled & 2) != 0;
+      const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
+      const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
+      double a = io.action ? io.action[b * E.na + k] : 0.0;
       double xv = row[slot];
       if (io.action) {
         a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
@@ -2061,33 +2057,37 @@ __device__ __forceinline__ void reset_row(const SRC& S, const DevReset& R, const
     }
     // (limits are read before any set-point is written: all set-points first, then their slots)
     wave_fence();
-    for (int k = lane; k < es.na; k += 64) row[S.ai(AI_SLOT, k)] = sp[k];
+    for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k];
     wave_fence();
-    for (int sg = 0; sg < es.n_oseg; ++sg) {
-      const int kind = S.os(OS_KIND, sg), src = S.os(OS_SRC, sg), dst = S.os(OS_DST, sg), n = S.os(OS_N, sg);
-      // (LDS reads of several chunks before their stores: one LDS round trip per group instead of one per chunk)
-      double* const out = io.obs + b * es.nobs + dst;
-      const double* const from = (kind == 2 ? sp : row) + src;
-      for (int j0 = lane; j0 < n; j0 += 64 * U) {
-        double t[U];
+    RSTAMP(4);
+    double* const out = io.obs + b * E.nobs;
+    for (int e0 = lane; e0 < R.n_oel; e0 += 64 * UC) {
+      int w[UC];
+      double v[UC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int j = j0 + 64 * u; t[u] = kind == 1 ? NaN : from[j < n ? j : n - 1]; }
+      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = R.oe_src[e < R.n_oel ? e : R.n_oel - 1]; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int j = j0 + 64 * u; if (j < n) out[j] = t[u]; }
-      }
+      for (int u = 0; u < UC; ++u) { const int kind = w[u] >> 28, idx = w[u] & 0x0FFFFFFF; v[u] = kind == 1 ? NaN : (kind == 0 ? row[idx] : sp[idx]); }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; if (e < R.n_oel) out[e] = v[u]; }
     }
   }
-  for (int j0 = lane; j0 < R.nx; j0 += 64 * 2 * U) {
-    double t[2 * U];
+  RSTAMP(5);
+  for (int j0 = lane; j0 < R.nx; j0 += 64 * UC) {
+    double t[UC];
 #pragma unroll
-    for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; t[u] = row[j < R.nx ? j : R.nx - 1]; }
+    for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = row[j < R.nx ? j : R.nx - 1]; }
 #pragma unroll
-    for (int u = 0; u < 2 * U; ++u) { const int j = j0 + 64 * u; if (j < R.nx) xr[j] = t[u]; }
+    for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < R.nx) xr[j] = t[u]; }
   }
   wave_fence();
+#ifdef OPFX_ENABLE_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  RSTAMP(6);
 }
 
-__global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
+__global__ __launch_bounds__(256, 4) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
                                                int row_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -2095,9 +2095,7 @@ __global__ __launch_bounds__(256) void k_reset(DevReset R, const DevEnv* __restr
   double* const sp = row + ((R.nx + 1) & ~1);
   const long long w = (long long)blockIdx.x * wpb + wib;
   const long long nw = (long long)gridDim.x * wpb;
-  if (!Ep) io.obs = nullptr;
-  const SrcGlobal S{R, Ep};
-  for (long long b = w; b < B; b += nw) reset_row<SrcGlobal, 4>(S, R, io, b, lane, row, sp);
+  for (long long b = w; b < B; b += nw) reset_row<4, 18>(R, Ep, io, b, lane, row, sp);
 }
 
 // cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
@@ -2628,6 +2626,7 @@ struct opfx_env {
   int per_cu = 0;
   int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
   bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
+  std::vector<int32_t> h_oseg[4];      // observation segments (kind, source, destination, length): host copy for the reset's element list
   int n_full = 0;        // four-value blocks this environment's kernels run with (choose_block_storage)
 };
 
@@ -3011,6 +3010,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
       else { sk.push_back(kind); ss.push_back(src); sd.push_back(k); sn.push_back(1); }
     }
     E.n_oseg = (int)sk.size();
+    e->h_oseg[0] = sk; e->h_oseg[1] = ss; e->h_oseg[2] = sd; e->h_oseg[3] = sn;
     if (rc == OPFX_OK) rc = A.put(sk, &E.oseg_kind);
     if (rc == OPFX_OK) rc = A.put(ss, &E.oseg_src);
     if (rc == OPFX_OK) rc = A.put(sd, &E.oseg_dst);
@@ -3201,35 +3201,101 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   DevReset& R = env->dr;
   DevArena& A = env->arena;
   R = DevReset{};
-  R.n_tables = d->n_tables; R.n_ops = d->n_ops; R.n_uniform = d->n_uniform; R.nx = env->de.nx;
+  R.n_tables = d->n_tables; R.n_uniform = d->n_uniform; R.nx = env->de.nx;
   R.init_off = d->init_off;
   R.n_normal = d->n_normal;
+  R.has_mode = d->op_mode != nullptr;
   if (d->init_off >= 0 && d->init_off + R.nx > d->n_consts) { opfx_set_error("opfx_env_set_reset: init template out of range"); return OPFX_ERR_INVALID; }
-  int rc = OPFX_OK, noise_off = 0;
-  for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
-    const opfx_profile_desc& T = d->tables[t];
-    DevTable& D = R.tab[t];
-    D.n_steps = T.n_steps; D.n_types = T.n_types; D.n_cols = T.n_cols; D.noise_off = noise_off;
-    noise_off += T.n_cols;
-    for (int j = 0; j < T.n_cols; ++j)
-      if (T.slot[j] < 0 || T.slot[j] >= R.nx || T.typ[j] < 0 || T.typ[j] >= T.n_types) {
-        opfx_set_error("opfx_env_set_reset: profile slot/type out of range");
-        return OPFX_ERR_INVALID;
+  int rc = OPFX_OK;
+  // ---- profile columns of all tables as one list --------------------------------------------------------------
+  {
+    std::vector<const double*> rel;
+    std::vector<int32_t> nt, tab, typ, slot;
+    std::vector<double> peak, lo, hi;
+    for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
+      const opfx_profile_desc& T = d->tables[t];
+      R.n_steps[t] = T.n_steps;
+      for (int j = 0; j < T.n_cols; ++j)
+        if (T.slot[j] < 0 || T.slot[j] >= R.nx || T.typ[j] < 0 || T.typ[j] >= T.n_types) {
+          opfx_set_error("opfx_env_set_reset: profile slot/type out of range");
+          return OPFX_ERR_INVALID;
+        }
+      const double* d_rel = nullptr;
+      rc = A.put(T.rel, (size_t)T.n_steps * T.n_types, &d_rel);
+      for (int j = 0; j < T.n_cols; ++j) {
+        rel.push_back(d_rel); nt.push_back(T.n_types); tab.push_back(t); typ.push_back(T.typ[j]); slot.push_back(T.slot[j]);
+        peak.push_back(T.peak[j]); lo.push_back(T.col_min[j]); hi.push_back(T.col_max[j]);
       }
-    rc = A.put(T.rel, (size_t)T.n_steps * T.n_types, &D.rel);
-    if (rc == OPFX_OK) rc = A.put(T.peak, (size_t)T.n_cols, &D.peak);
-    if (rc == OPFX_OK) rc = A.put(T.col_min, (size_t)T.n_cols, &D.col_min);
-    if (rc == OPFX_OK) rc = A.put(T.col_max, (size_t)T.n_cols, &D.col_max);
-    if (rc == OPFX_OK) rc = A.put(T.typ, (size_t)T.n_cols, &D.typ);
-    if (rc == OPFX_OK) rc = A.put(T.slot, (size_t)T.n_cols, &D.slot);
+    }
+    R.n_tcols = (int)rel.size();
+    R.n_noise = R.n_tcols;
+    if (rc == OPFX_OK) rc = A.put(rel, &R.tc_rel);
+    if (rc == OPFX_OK) rc = A.put(nt, &R.tc_nt);
+    if (rc == OPFX_OK) rc = A.put(tab, &R.tc_tab);
+    if (rc == OPFX_OK) rc = A.put(typ, &R.tc_typ);
+    if (rc == OPFX_OK) rc = A.put(slot, &R.tc_slot);
+    if (rc == OPFX_OK) rc = A.put(peak, &R.tc_peak);
+    if (rc == OPFX_OK) rc = A.put(lo, &R.tc_lo);
+    if (rc == OPFX_OK) rc = A.put(hi, &R.tc_hi);
   }
-  R.n_noise = noise_off;
-#define PUTN(field, ptr, n) if (rc == OPFX_OK) rc = A.put(ptr, (size_t)(n), &R.field)
-  PUTN(op_code, d->op_code, d->n_ops); PUTN(op_dst, d->op_dst, d->n_ops); PUTN(op_a, d->op_a, d->n_ops);
-  PUTN(op_n, d->op_n, d->n_ops); PUTN(op_c0, d->op_c0, d->n_ops); PUTN(op_c1, d->op_c1, d->n_ops);
-  PUTN(op_c2, d->op_c2, d->n_ops); PUTN(consts, d->consts, d->n_consts);
-  if (d->op_mode) { PUTN(op_mode, d->op_mode, d->n_ops); }
-#undef PUTN
+  // ---- vector ops -> stages of mutually independent elements -------------------------------------------------------
+  {
+    const int n_ops = d->n_ops;
+    auto reads_row = [](int code) { return code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL; };
+    auto overlap = [](int a0, int an, int b0, int bn) { return an > 0 && bn > 0 && a0 < b0 + bn && b0 < a0 + an; };
+    std::vector<int> stage(n_ops, 0);
+    int n_stages = 0;
+    for (int k = 0; k < n_ops; ++k) {
+      if (d->op_dst[k] < 0 || d->op_n[k] < 0 || d->op_dst[k] + d->op_n[k] > R.nx ||
+          (reads_row(d->op_code[k]) && (d->op_a[k] < 0 || d->op_a[k] + d->op_n[k] > R.nx))) {
+        opfx_set_error("opfx_env_set_reset: op range out of the row"); return OPFX_ERR_INVALID;
+      }
+      const int rk = reads_row(d->op_code[k]) ? d->op_n[k] : 0;
+      for (int j = 0; j < k; ++j) {
+        const int rj = reads_row(d->op_code[j]) ? d->op_n[j] : 0;
+        const bool dep = overlap(d->op_dst[j], d->op_n[j], d->op_a[k], rk)            // reads what j writes
+                      || overlap(d->op_dst[j], d->op_n[j], d->op_dst[k], d->op_n[k])   // writes what j writes
+                      || overlap(d->op_a[j], rj, d->op_dst[k], d->op_n[k]);            // writes what j reads
+        if (dep) stage[k] = std::max(stage[k], stage[j] + 1);
+      }
+      n_stages = std::max(n_stages, stage[k] + 1);
+    }
+    std::vector<int32_t> ptr{0}, code, dst, src;
+    std::vector<double> k0, k1, k2;
+    for (int sg = 0; sg < n_stages; ++sg) {
+      for (int k = 0; k < n_ops; ++k) {
+        if (stage[k] != sg) continue;
+        const int mask = d->op_mode ? (d->op_mode[k] & 7) : 7;
+        for (int j = 0; j < d->op_n[k]; ++j) {
+          code.push_back(d->op_code[k] | (mask << 8));
+          dst.push_back(d->op_dst[k] + j);
+          src.push_back(d->op_a[k] + j);
+          k0.push_back(d->op_c0[k] >= 0 ? d->consts[d->op_c0[k] + j] : 0.0);
+          k1.push_back(d->op_c1[k] >= 0 ? d->consts[d->op_c1[k] + j] : 0.0);
+          k2.push_back(d->op_c2[k] >= 0 ? d->consts[d->op_c2[k] + j] : 0.0);
+        }
+      }
+      ptr.push_back((int32_t)code.size());
+    }
+    R.n_stages = n_stages;
+    if (rc == OPFX_OK) rc = A.put(ptr, &R.st_ptr);
+    if (rc == OPFX_OK) rc = A.put(code, &R.el_code);
+    if (rc == OPFX_OK) rc = A.put(dst, &R.el_dst);
+    if (rc == OPFX_OK) rc = A.put(src, &R.el_src);
+    if (rc == OPFX_OK) rc = A.put(k0, &R.el_k0);
+    if (rc == OPFX_OK) rc = A.put(k1, &R.el_k1);
+    if (rc == OPFX_OK) rc = A.put(k2, &R.el_k2);
+    if (rc == OPFX_OK) rc = A.put(d->consts, (size_t)d->n_consts, &R.consts);
+  }
+  // ---- observation elements ---------------------------------------------------------------------------------------
+  {
+    std::vector<int32_t> oe((size_t)env->de.nobs, 1 << 28);
+    for (size_t sg = 0; sg < env->h_oseg[0].size(); ++sg)
+      for (int j = 0; j < env->h_oseg[3][sg]; ++j)
+        oe[(size_t)env->h_oseg[2][sg] + j] = (env->h_oseg[0][sg] << 28) | ((env->h_oseg[1][sg] + j) & 0x0FFFFFFF);
+    R.n_oel = (int)oe.size();
+    if (rc == OPFX_OK) rc = A.put(oe, &R.oe_src);
+  }
   if (rc != OPFX_OK) return rc;
   env->has_reset = true;
   return OPFX_OK;
@@ -3249,7 +3315,8 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   const size_t row_bytes = (size_t)row_doubles * sizeof(double);
   if (row_bytes > 160 * 1024) { opfx_set_error("opfx_reset: table row does not fit the LDS"); return OPFX_ERR_TOO_LARGE; }
   ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
-            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out};
+            io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out,
+            env->ctx->dp.stamps};
   const int wpb = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
   const size_t lds = wpb * row_bytes;
   if (lds > 64 * 1024)
