@@ -466,7 +466,14 @@ def synthetic_mv_3w(seed: int = 0):
     return net, prof
 
 
+def synthetic_hv_large(seed: int = 0):
+    """1 000-bus meshed HV grid (not a BASELINE config): its 8 788 LU blocks do not fit a CU's LDS — the workload of the
+    memory-resident kernel."""
+    return synthetic_hv(seed + 5, nb=1000, n_ext=2, n_gen=10, name='syn-hv-large')
+
+
 GRIDS = {
+    'hv-large': synthetic_hv_large,
     '1-LV-rural1--0-sw': synthetic_lv_rural1,
     '1-MV-urban--0-sw': synthetic_mv_urban,
     '1-HV-mixed--0-sw': synthetic_hv_mixed,

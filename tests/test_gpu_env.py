@@ -543,6 +543,35 @@ def test_env_on_the_memory_resident_kernel_matches_the_golden(name, monkeypatch)
         _check_step(env, out, ref, k, n1)
 
 
+def test_environment_on_a_grid_past_the_lds(monkeypatch):
+    """EcoDispatch on the 1 000-bus stand-in grid (`hv-large`: 8 788 LU blocks, more than a CU's LDS holds): the native
+    definition builder constructs the problem, the fused step runs on the memory-resident form of the wave-team kernel
+    (q-limits of the PV generators included) and matches the oracle environment instance for instance."""
+    import env_cases
+    monkeypatch.setitem(env_cases.SCENARIOS, 'eco_hv_large', ('EcoDispatch', dict(simbench_network_name='hv-large'), 4, 3))
+    B = 4
+    env = product_env('eco_hv_large', batch_size=B)
+    ki = env.kernel_info()
+    assert ki['waves_per_instance'] == 4 and env.plan.info['lds_doubles'] * 8 > 160 * 1024
+    orc = oracle_env('eco_hv_large', product_env('eco_hv_large', defer_device=True))
+    rng = np.random.default_rng(4)
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform))
+    actions = rng.random((B, env.n_actions)) * 0.6 + 0.2
+    obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    out = env.step(actions)
+    n_ok = 0
+    for k in range(B):
+        ob = orc.reset(int(steps[k]), uniform[k])
+        assert np.allclose(_np(obs0)[k], ob, rtol=0, atol=R_TOL)
+        ref = orc.step(actions[k])
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+            n_ok += 1
+    assert n_ok >= 2
+
+
 def test_is_state_valid_without_any_constraint():
     """no constraints at all -> an empty all() is True (opf_env.py:613-618), not a column the kernel never writes."""
     from opfgym_amd import envs

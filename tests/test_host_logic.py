@@ -239,3 +239,35 @@ def test_vector_env_ids_mirror_reference_registration():
         assert vector_env.register() is True
     except ImportError:
         assert vector_env.register() is False
+
+
+def test_reward_extension_points_are_honoured_on_the_host():
+    """reward.py:61-112: `adjust_objective` / `adjust_penalty` are the reference's (abstract) extension points.  The host
+    formula goes through them, and a reward object that overrides any of the seams — or is no class of this package —
+    is reported as not expressible in the kernel's parameters (`runs_on_device`), so that the environment finishes its
+    reward on the host instead of evaluating a plain summation."""
+    from opfgym_amd import reward as rw
+
+    class Harsh(rw.Summation):
+        def adjust_penalty(self, penalty, valid):
+            return penalty if valid else 3.0 * penalty - 1.0
+
+    class Scaled(rw.Replacement):
+        def scale_objective(self, objective):
+            return 2.0 * objective
+
+    class Foreign:
+        def __call__(self, objective, penalty, valid):
+            return objective
+
+        def calculate_cost(self, penalty, valid):
+            return 0.0
+    for cls in (rw.Summation, rw.Replacement, rw.Parameterized, rw.OnlyObjective):
+        assert rw.runs_on_device(cls())
+    assert not rw.runs_on_device(Harsh()) and not rw.runs_on_device(Scaled()) and not rw.runs_on_device(Foreign())
+    assert Harsh()(1.0, -2.0, False) == 0.5 * 1.0 + 0.5 * (3.0 * -2.0 - 1.0)
+    assert Harsh()(1.0, -2.0, True) == rw.Summation()(1.0, -2.0, True)
+    assert Scaled(valid_reward=1.0)(1.0, 0.0, True) == 0.5 * 2.0 * (1.0 + 1.0)
+    rw.check_host_reward(Foreign())
+    with pytest.raises(TypeError, match='calculate_cost'):
+        rw.check_host_reward(object())
