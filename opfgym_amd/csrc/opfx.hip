@@ -1793,31 +1793,40 @@ __device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
 // ---------------------------------------------------------------------------
 // reset kernel: SimBench state sampling (opf_env.py:317-372) + `_sampling` tails
 // ---------------------------------------------------------------------------
-// What a reset executes, FLATTENED at opfx_env_set_reset time into per-element lists so that a row needs few
-// dependent global-memory round trips (a round trip costs ~0.8 us with 16 waves per CU queueing on the L2, and a row is
-// a chain of them: in-kernel stamps of round 3 — template 3, two per profile table, two per vector op (its scalar
-// descriptor, then its constants), one per observation segment = 24 for the 144-bus VoltageControl row, 19 us):
-//   * profile columns of ALL tables as one list (table data per column: relative-profile base, types per step, ...):
-//     descriptors in one round trip, profile values in a second;
-//   * the vector ops as STAGES of mutually independent elements (an element = one (op, j): code, destination, source,
-//     its three constants): all ops that do not depend on one another run in one pass, e.g. VoltageControl's tail
-//     {max_p, min_p, q := 0} | {max_q} | {min_q} is 3 round trips instead of 10;
+// What a reset executes, compiled at opfx_env_set_reset time into CHUNKS of up to 64 consecutive elements whose
+// structure is the same for every lane — a run of columns of one profile table, or 64 elements of one vector op —
+// so that everything but the per-element data is WAVE-UNIFORM: a chunk's descriptor (32 bytes) comes through the scalar
+// cache into SGPRs, the op code is a scalar branch (only the code that runs is executed, and once), destination /
+// source / constant addresses are a scalar base + the lane, and the per-element data (types, peaks, limits, constants)
+// are coalesced loads.  The element-list form of this (round 3, first half: one descriptor record per element and lane)
+// spent 1 687 vector instructions and 217 vector loads on a 1 082-column row, 100 per 64 outputs, nearly all of it
+// decoding per-lane descriptors that are equal across the rows; the kernel was bound by exactly that.
+//   * profile chunks: columns [e0, e0 + n) of the list of all profile columns, all of one table;
+//   * op chunks by STAGE: an op is cut into chunks; ops that do not depend on one another share a stage (one pass, one
+//     LDS fence), e.g. VoltageControl's tail {max_p, min_p, q := 0} | {max_q} | {min_q}; within a stage the chunks whose
+//     code needs a long function (inverse normal CDF, truncated normal, in-kernel normal draws) come last and run in a
+//     loop of their own, so that the common loop stays small and is unrolled over several chunks;
 //   * the observation as one element list (source kind | index).
 constexpr int MAX_TABLES = 8;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// profile chunk words: 0-1 address of the table's relative profiles ([n_steps, n_types]), 2 first column number e0,
+//   3 columns n (1..64), 4 types per step, 5 steps of the table, 6 table number
+// op chunk words: 0 code | mode mask << 8 | OCH_* flags << 16, 1 elements n (1..64), 2 first destination slot,
+//   3 first source slot or first draw number, 4-6 offsets of the element constants k0 / k1 / k2 in `consts` (-1: none, 0.0)
+constexpr int OCH_READS_ROW = 1 << 16, OCH_LONG = 2 << 16;
 struct DevReset {
   int n_tables, n_uniform, n_normal, n_noise, nx, init_off, has_mode;
-  int n_steps[MAX_TABLES];                 // (interpolation guard per table)
-  // profile columns, all tables
-  int n_tcols;
-  const double* const* tc_rel;             // [n_tcols] relative profiles of the column's table ([n_steps, n_types])
-  const int *tc_nt, *tc_tab, *tc_typ, *tc_slot;      // types per step, table number, type, destination slot
+  int skip_template;                       // every slot of the row is written by a profile column or an op (and no per-instance modes)
+  // profile columns, all tables: per-column data by column number; chunks of columns of one table
+  int n_tcols, n_pch;
+  const i32x8* pch;
+  const int *tc_typ, *tc_slot;             // type, destination slot
   const double *tc_peak, *tc_lo, *tc_hi;
-  // op elements by stage
+  // op chunks by stage
   int n_stages;
-  const int* st_ptr;                       // [n_stages + 1]
-  const int *el_code, *el_dst, *el_src;    // code | source mask << 8; destination slot; source slot or draw number
-  const double *el_k0, *el_k1, *el_k2;
-  const double* consts;                    // row template at init_off
+  const int* st_ptr;                       // [2 * n_stages + 1]: stage s = chunks [st_ptr[2s], st_ptr[2s+2]), the long ones from st_ptr[2s+1] on
+  const i32x8* och;
+  const double* consts;                    // row template at init_off; element constants of the ops
   // observation elements (environments whose observation needs no power flow)
   int n_oel;
   const int* oe_src;                       // kind << 28 | index: 0 row, 1 NaN (result entry), 2 action set-point
@@ -1902,7 +1911,9 @@ __device__ __forceinline__ double draw_normal(unsigned long long seed, long long
 #define RSTAMP(slot) do { } while (0)
 #endif
 
-// One vector-op element (include/opfx.h OPFX_OP_*): rv = the source value of the row (or 0), dr = its draw (or 0)
+// One vector-op element (include/opfx.h OPFX_OP_*): rv = the source value of the row (or 0), dr = its draw (or 0).
+// `code` is wave-uniform (a chunk holds elements of one op).  LONG: with the codes that need a long function.
+template <bool LONG>
 __device__ __forceinline__ double op_value(int code, double rv, double dr, double k0, double k1, double k2) {
   switch (code) {
     case OPFX_OP_SET_CONST: return k0;
@@ -1912,22 +1923,116 @@ __device__ __forceinline__ double op_value(int code, double rv, double dr, doubl
     case OPFX_OP_UNIFORM: return (k0 + dr * (k1 - k0)) / k2;
     case OPFX_OP_NORMAL: return k0 + k1 * dr;
     case OPFX_OP_CLIP: return fmin(fmax(rv, k0), k1);
-    case OPFX_OP_NORMINV: return k0 + k1 * normcdfinv(rv);
-    case OPFX_OP_TRUNCNORM: return truncnorm_ppf(rv, k0, k1);
+    case OPFX_OP_NORMINV: return LONG ? k0 + k1 * normcdfinv(rv) : 0.0;
+    case OPFX_OP_TRUNCNORM: return LONG ? truncnorm_ppf(rv, k0, k1) : 0.0;
     default: return rv / k0;                 // OPFX_OP_DIV
   }
 }
 
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
+  return (const __attribute__((address_space(4))) T*)p;
+}
+// element `idx` of an array whose base is wave-uniform: the byte offset as an unsigned 32-bit value, which is the form
+// the hardware addresses as scalar base + vector offset (no 64-bit address arithmetic per lane); arrays < 4 GiB
+template <class T>
+__device__ __forceinline__ T ld_at(const T* base, unsigned idx) {
+  typedef const __attribute__((address_space(1))) char* gbytes;
+  return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>(as_global(base)) + idx * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ void st_at(T* base, unsigned idx, T v) {
+  typedef __attribute__((address_space(1))) char* gbytes;
+  *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>((__attribute__((address_space(1))) T*)base) + idx * (unsigned)sizeof(T)) = v;
+}
+// a chunk descriptor through the scalar cache (`c` is wave-uniform)
+__device__ __forceinline__ i32x8 ld_chunk(const i32x8* base, int c) { return as_const(base)[c]; }
+
+// The loads of one op chunk / its arithmetic and store, apart, so that the loads of several chunks are requested
+// before the first value is used.
+struct OpRegs { double k0, k1, k2, rv, dr; };
+template <bool LONG>
+__device__ __forceinline__ OpRegs op_chunk_load(const DevReset& R, const ResetIO& io, long long b, int lane, const i32x8 ch,
+                                                const double* row) {
+  const int code = ch[0] & 0xFF, n = ch[1], src0 = ch[3];
+  const int lc = lane < n ? lane : n - 1;
+  OpRegs r{0.0, 0.0, 0.0, 0.0, 0.0};
+  if (ch[4] >= 0) r.k0 = ld_at(R.consts, (unsigned)(ch[4] + lc));
+  if (ch[5] >= 0) r.k1 = ld_at(R.consts, (unsigned)(ch[5] + lc));
+  if (ch[6] >= 0) r.k2 = ld_at(R.consts, (unsigned)(ch[6] + lc));
+  if (ch[0] & OCH_READS_ROW) r.rv = row[src0 + lc];
+  // the element's draw: from the caller's array, or made here from the per-reset seed
+  if (code == OPFX_OP_UNIFORM)
+    r.dr = io.uniform ? ld_at(io.uniform + b * R.n_uniform, (unsigned)(src0 + lc)) : draw_uniform(io.rng_seed, b, (unsigned)(src0 + lc));
+  if (LONG && code == OPFX_OP_NORMAL)
+    r.dr = io.normal ? ld_at(io.normal + b * R.n_normal, (unsigned)(src0 + lc)) : draw_normal(io.rng_seed, b, (unsigned)(src0 + lc));
+  return r;
+}
+template <bool LONG>
+__device__ __forceinline__ void op_chunk_apply(int lane, const i32x8 ch, const OpRegs& r, double* row) {
+  const double v = op_value<LONG>(ch[0] & 0xFF, r.rv, r.dr, r.k0, r.k1, r.k2);
+  if (lane < ch[1]) row[ch[2] + lane] = v;
+}
+
+// rows move between memory and the LDS two columns per lane where the row allows it (even column count: every row
+// of the batch starts on a 16-byte boundary), UC chunks per round trip
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <int UC>
+__device__ __forceinline__ void row_copy_in(double* row, const double* src, int nx, int lane) {
+  if ((nx & 1) == 0 && (reinterpret_cast<size_t>(src) & 15) == 0) {
+    const int n2 = nx >> 1;
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(src);
+    f64x2* r2 = reinterpret_cast<f64x2*>(row);
+    for (int j0 = lane; j0 < n2; j0 += 64 * UC) {
+      f64x2 t[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = ld_at(s2, (unsigned)(j < n2 ? j : n2 - 1)); }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < n2) r2[j] = t[u]; }
+    }
+  } else {
+    for (int j0 = lane; j0 < nx; j0 += 64 * UC) {
+      double t[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = ld_at(src, (unsigned)(j < nx ? j : nx - 1)); }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < nx) row[j] = t[u]; }
+    }
+  }
+}
+template <int UC>
+__device__ __forceinline__ void row_copy_out(double* dst, const double* row, int nx, int lane) {
+  if ((nx & 1) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+    const int n2 = nx >> 1;
+    f64x2* d2 = reinterpret_cast<f64x2*>(dst);
+    const f64x2* r2 = reinterpret_cast<const f64x2*>(row);
+    for (int j0 = lane; j0 < n2; j0 += 64 * UC) {
+      f64x2 t[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = r2[j < n2 ? j : n2 - 1]; }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < n2) st_at(d2, (unsigned)j, t[u]); }
+    }
+  } else {
+    for (int j0 = lane; j0 < nx; j0 += 64 * UC) {
+      double t[UC];
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = row[j < nx ? j : nx - 1]; }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < nx) st_at(dst, (unsigned)j, t[u]); }
+    }
+  }
+}
+
 // The reset of ONE instance by one wavefront: the row is built in LDS (`row`: nx doubles, `sp`: na doubles) — template
-// -> profile values -> vector-op stages -> optionally the initial action and the table observation
-// (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make a round trip
-// through memory.  Every pass requests the loads of up to U 64-element chunks before the first use.
+// (unless every column is written anyway) -> profile values -> vector-op stages -> optionally the initial action and the
+// table observation (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make
+// a round trip through memory.  `b` is wave-uniform (k_reset), and so is everything read from the chunk descriptors.
 // (Round 3 also ran the reset in the epilogue of the step kernel — bit-identical rows, 404.6 us per launch against
 // 270.3 + 56.8 us for two launches: the step kernel's throughput is waves / latency per instance and the reset's chain of
 // round trips adds its whole latency to every instance — and with its descriptors in an LDS image per persistent
 // workgroup — 64.9 vs 56.8 us: 13 rows per CU instead of 16.  profiles/r03_reset_experiments.txt.  Both removed.)
-// U: chunks per round trip of the element passes (profile columns, op elements); UC: of the plain copies (template,
-// observation, store) — sized so that the kernel stays at 128 VGPRs: 16 rows in flight per CU, as many as the LDS holds.
+// U: chunks per round trip of the chunk passes; UC: of the plain copies.
 template <int U, int UC>
 __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b, int lane,
                                           double* const row, double* const sp) {
@@ -1940,89 +2045,88 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
   if (io.step_pool) {
     // counter-based draw: uniform over the pool up to a bias of n / 2^64
     const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1));
-    step = io.step_pool[(int)(h % (unsigned long long)io.n_step_pool)];
+    step = as_const(io.step_pool)[(int)(h % (unsigned long long)io.n_step_pool)];
     if (lane == 0 && io.step_out) io.step_out[b] = step;
   } else {
-    step = io.step_idx[b];
+    step = as_const(io.step_idx)[b];
   }
-  const int mode = (io.mode && R.has_mode) ? io.mode[b] : -1;     // data source of this instance ('mixed'), -1: none
+  const int mode = (io.mode && R.has_mode) ? as_const(io.mode)[b] : -1;     // data source of this instance ('mixed'), -1: none
   RSTAMP(0);
-  // ---- the row template (or the instance's own row: keep_state), 2U chunks per round trip ----------------------
-  {
+  // ---- the row template (or the instance's own row: keep_state) ---------------------------------------------------
+  if (!R.skip_template || io.keep_state) {
     const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
-    for (int j0 = lane; j0 < R.nx; j0 += 64 * UC) {
-      double t[UC];
-#pragma unroll
-      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = src[j < R.nx ? j : R.nx - 1]; }
-#pragma unroll
-      for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < R.nx) row[j] = t[u]; }
-    }
+    row_copy_in<UC>(row, src, R.nx, lane);
+    wave_fence();
   }
-  wave_fence();
   RSTAMP(1);
   // ---- profile values of every table (opf_env.py:339-372) -------------------------------------------------------
-  const int n_tc = mode <= 0 ? R.n_tcols : 0;
-  for (int e0 = lane; e0 < n_tc; e0 += 64 * U) {
-    const double* rel[U];
-    int nt[U], tab[U], typ[U], slot[U];
+  const int n_pc = mode <= 0 ? R.n_pch : 0;
+  for (int c0 = 0; c0 < n_pc; c0 += U) {
+    i32x8 ch[U];
+    int typ[U], slot[U];
     double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U], rr[U];
-    bool itp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = e0 + 64 * u, ec = e < n_tc ? e : n_tc - 1;
-      rel[u] = R.tc_rel[ec]; nt[u] = R.tc_nt[ec]; tab[u] = R.tc_tab[ec]; typ[u] = R.tc_typ[ec]; slot[u] = R.tc_slot[ec];
-      peak[u] = R.tc_peak[ec]; lo[u] = R.tc_lo[ec]; hi[u] = R.tc_hi[ec];
-      nz[u] = io.noise ? io.noise[b * R.n_noise + ec] : 1.0;              // (noise columns are numbered like the list)
+      ch[u] = ld_chunk(R.pch, c0 + u < n_pc ? c0 + u : n_pc - 1);
+      if (c0 + u >= n_pc) ch[u][3] = 0;                                    // (past the end: no live lane)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      itp[u] = io.interp != nullptr && step < R.n_steps[tab[u]] - 1;                      // :345
-      const double* rw = rel[u] + (long long)step * nt[u];
-      r0[u] = rw[typ[u]];
-      r1[u] = itp[u] ? rw[nt[u] + typ[u]] : 0.0;
-      rr[u] = itp[u] ? io.interp[b * R.n_tables + tab[u]] : 0.0;
+      const int n = ch[u][3], e = ch[u][2] + (lane < n ? lane : (n > 0 ? n - 1 : 0));
+      typ[u] = 0; slot[u] = 0; peak[u] = 0.0; lo[u] = 0.0; hi[u] = 0.0; nz[u] = 1.0;
+      if (n == 0) continue;
+      typ[u] = ld_at(R.tc_typ, (unsigned)e); slot[u] = ld_at(R.tc_slot, (unsigned)e);
+      peak[u] = ld_at(R.tc_peak, (unsigned)e); lo[u] = ld_at(R.tc_lo, (unsigned)e); hi[u] = ld_at(R.tc_hi, (unsigned)e);
+      nz[u] = io.noise ? ld_at(io.noise + b * R.n_noise, (unsigned)e) : 1.0;         // (noise columns are numbered like the list)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      const double* rel = reinterpret_cast<const double*>(((unsigned long long)(unsigned)ch[u][1] << 32) | (unsigned)ch[u][0]);
+      const int nt = ch[u][4];
+      const bool itp = io.interp != nullptr && step < ch[u][5] - 1;                          // :345
+      const double* rw = rel + (long long)step * nt;
+      r0[u] = 0.0; r1[u] = 0.0; rr[u] = 0.0;
+      if (ch[u][3] == 0) continue;
+      r0[u] = ld_at(rw, (unsigned)typ[u]);
+      if (itp) { r1[u] = ld_at(rw, (unsigned)(nt + typ[u])); rr[u] = as_global(io.interp)[b * R.n_tables + ch[u][6]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool itp = io.interp != nullptr && step < ch[u][5] - 1;
       double v = r0[u] * peak[u];                                                // :343
-      if (itp[u]) v = v * rr[u] + (r1[u] * peak[u]) * (1.0 - rr[u]);             // :347-349
+      if (itp) v = v * rr[u] + (r1[u] * peak[u]) * (1.0 - rr[u]);                // :347-349
       if (io.noise) {
         if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
         else v = v * nz[u];                                                      // :354-356
       }
       v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
-      if (e0 + 64 * u < n_tc) row[slot[u]] = v;                                  // :371-372
+      if (lane < ch[u][3]) row[slot[u]] = v;                                     // :371-372
     }
   }
   wave_fence();
   RSTAMP(2);
-  // ---- the `_sampling` tail: stages of mutually independent op elements -------------------------------------------
+  // ---- the `_sampling` tail: stages of mutually independent op chunks ----------------------------------------------
   for (int sgi = 0; sgi < R.n_stages; ++sgi) {
-    const int s0 = R.st_ptr[sgi], s1 = R.st_ptr[sgi + 1];
-    for (int e0 = s0 + lane; e0 < s1; e0 += 64 * U) {
-      int cm[U], dst[U], src[U];
-      double k0[U], k1[U], k2[U], dr[U], rv[U];
+    const int s0 = as_const(R.st_ptr)[2 * sgi], sl = as_const(R.st_ptr)[2 * sgi + 1], s1 = as_const(R.st_ptr)[2 * sgi + 2];
+    for (int c0 = s0; c0 < sl; c0 += U) {
+      i32x8 ch[U];
+      OpRegs r[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = e0 + 64 * u, ec = e < s1 ? e : s1 - 1;
-        cm[u] = R.el_code[ec]; dst[u] = R.el_dst[ec]; src[u] = R.el_src[ec];
-        k0[u] = R.el_k0[ec]; k1[u] = R.el_k1[ec]; k2[u] = R.el_k2[ec];
+        ch[u] = ld_chunk(R.och, c0 + u < sl ? c0 + u : sl - 1);
+        // past the end, or an op this instance's data source does not run: no live lane
+        if (c0 + u >= sl || (mode >= 0 && !((ch[u][0] >> (8 + mode)) & 1))) ch[u][1] = 0;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int code = cm[u] & 0xFF;
-        const bool is_u = code == OPFX_OP_UNIFORM, is_n = code == OPFX_OP_NORMAL;
-        // the element's draw: from the caller's array, or made here from the per-reset seed (draw_uniform)
-        dr[u] = is_u ? (io.uniform ? io.uniform[b * R.n_uniform + src[u]] : draw_uniform(io.rng_seed, b, (unsigned)src[u]))
-              : (is_n ? (io.normal ? io.normal[b * R.n_normal + src[u]] : draw_normal(io.rng_seed, b, (unsigned)src[u])) : 0.0);
-        rv[u] = (is_u || is_n || code == OPFX_OP_SET_CONST) ? 0.0 : row[src[u]];
-      }
+      for (int u = 0; u < U; ++u) if (ch[u][1] > 0) r[u] = op_chunk_load<false>(R, io, b, lane, ch[u], row);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool on = e0 + 64 * u < s1 && (mode < 0 || ((cm[u] >> (8 + mode)) & 1));
-        const double v = op_value(cm[u] & 0xFF, rv[u], dr[u], k0[u], k1[u], k2[u]);
-        if (on) row[dst[u]] = v;
-      }
+      for (int u = 0; u < U; ++u) if (ch[u][1] > 0) op_chunk_apply<false>(lane, ch[u], r[u], row);
+    }
+    for (int c = sl; c < s1; ++c) {
+      const i32x8 ch = ld_chunk(R.och, c);
+      if (mode >= 0 && !((ch[0] >> (8 + mode)) & 1)) continue;
+      const OpRegs r = op_chunk_load<true>(R, io, b, lane, ch, row);
+      op_chunk_apply<true>(lane, ch, r, row);
     }
     wave_fence();
   }
@@ -2065,7 +2169,7 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
       int w[UC];
       double v[UC];
 #pragma unroll
-      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = R.oe_src[e < R.n_oel ? e : R.n_oel - 1]; }
+      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = as_global(R.oe_src)[e < R.n_oel ? e : R.n_oel - 1]; }
 #pragma unroll
       for (int u = 0; u < UC; ++u) { const int kind = w[u] >> 28, idx = w[u] & 0x0FFFFFFF; v[u] = kind == 1 ? NaN : (kind == 0 ? row[idx] : sp[idx]); }
 #pragma unroll
@@ -2073,13 +2177,7 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
     }
   }
   RSTAMP(5);
-  for (int j0 = lane; j0 < R.nx; j0 += 64 * UC) {
-    double t[UC];
-#pragma unroll
-    for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; t[u] = row[j < R.nx ? j : R.nx - 1]; }
-#pragma unroll
-    for (int u = 0; u < UC; ++u) { const int j = j0 + 64 * u; if (j < R.nx) xr[j] = t[u]; }
-  }
+  row_copy_out<UC>(xr, row, R.nx, lane);
   wave_fence();
 #ifdef OPFX_ENABLE_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
@@ -2090,12 +2188,13 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
 __global__ __launch_bounds__(256, 4) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
                                                int row_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // (the row number is wave-uniform: scalar addressing)
   double* const row = smem + (size_t)wib * row_doubles;
   double* const sp = row + ((R.nx + 1) & ~1);
   const long long w = (long long)blockIdx.x * wpb + wib;
   const long long nw = (long long)gridDim.x * wpb;
-  for (long long b = w; b < B; b += nw) reset_row<4, 18>(R, Ep, io, b, lane, row, sp);
+  for (long long b = w; b < B; b += nw) reset_row<4, 9>(R, Ep, io, b, lane, row, sp);
 }
 
 // cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
@@ -3207,14 +3306,13 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   R.has_mode = d->op_mode != nullptr;
   if (d->init_off >= 0 && d->init_off + R.nx > d->n_consts) { opfx_set_error("opfx_env_set_reset: init template out of range"); return OPFX_ERR_INVALID; }
   int rc = OPFX_OK;
-  // ---- profile columns of all tables as one list --------------------------------------------------------------
+  // ---- profile columns of all tables as one list, chunks of up to 64 columns of one table ------------------------
+  std::vector<char> covered((size_t)R.nx, 0);
   {
-    std::vector<const double*> rel;
-    std::vector<int32_t> nt, tab, typ, slot;
+    std::vector<int32_t> typ, slot, pch;
     std::vector<double> peak, lo, hi;
     for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
       const opfx_profile_desc& T = d->tables[t];
-      R.n_steps[t] = T.n_steps;
       for (int j = 0; j < T.n_cols; ++j)
         if (T.slot[j] < 0 || T.slot[j] >= R.nx || T.typ[j] < 0 || T.typ[j] >= T.n_types) {
           opfx_set_error("opfx_env_set_reset: profile slot/type out of range");
@@ -3222,26 +3320,35 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
         }
       const double* d_rel = nullptr;
       rc = A.put(T.rel, (size_t)T.n_steps * T.n_types, &d_rel);
+      const unsigned long long addr = (unsigned long long)reinterpret_cast<uintptr_t>(d_rel);
+      for (int j0 = 0; j0 < T.n_cols; j0 += 64) {
+        const int32_t words[8] = {(int32_t)(uint32_t)(addr & 0xFFFFFFFFull), (int32_t)(uint32_t)(addr >> 32), (int32_t)typ.size() + j0,
+                                  std::min(64, T.n_cols - j0), T.n_types, T.n_steps, t, 0};
+        pch.insert(pch.end(), words, words + 8);
+      }
+      // (the chunk's first column number was computed before this table's columns were appended)
       for (int j = 0; j < T.n_cols; ++j) {
-        rel.push_back(d_rel); nt.push_back(T.n_types); tab.push_back(t); typ.push_back(T.typ[j]); slot.push_back(T.slot[j]);
+        typ.push_back(T.typ[j]); slot.push_back(T.slot[j]); covered[(size_t)T.slot[j]] = 1;
         peak.push_back(T.peak[j]); lo.push_back(T.col_min[j]); hi.push_back(T.col_max[j]);
       }
     }
-    R.n_tcols = (int)rel.size();
+    R.n_tcols = (int)typ.size();
     R.n_noise = R.n_tcols;
-    if (rc == OPFX_OK) rc = A.put(rel, &R.tc_rel);
-    if (rc == OPFX_OK) rc = A.put(nt, &R.tc_nt);
-    if (rc == OPFX_OK) rc = A.put(tab, &R.tc_tab);
+    R.n_pch = (int)(pch.size() / 8);
+    const int32_t* d_pch = nullptr;
+    if (rc == OPFX_OK) rc = A.put(pch, &d_pch);
+    R.pch = reinterpret_cast<const i32x8*>(d_pch);
     if (rc == OPFX_OK) rc = A.put(typ, &R.tc_typ);
     if (rc == OPFX_OK) rc = A.put(slot, &R.tc_slot);
     if (rc == OPFX_OK) rc = A.put(peak, &R.tc_peak);
     if (rc == OPFX_OK) rc = A.put(lo, &R.tc_lo);
     if (rc == OPFX_OK) rc = A.put(hi, &R.tc_hi);
   }
-  // ---- vector ops -> stages of mutually independent elements -------------------------------------------------------
+  // ---- vector ops -> stages of mutually independent ops, cut into chunks of up to 64 elements ----------------------
   {
     const int n_ops = d->n_ops;
     auto reads_row = [](int code) { return code != OPFX_OP_SET_CONST && code != OPFX_OP_UNIFORM && code != OPFX_OP_NORMAL; };
+    auto is_long = [](int code) { return code == OPFX_OP_NORMINV || code == OPFX_OP_TRUNCNORM || code == OPFX_OP_NORMAL; };
     auto overlap = [](int a0, int an, int b0, int bn) { return an > 0 && bn > 0 && a0 < b0 + bn && b0 < a0 + an; };
     std::vector<int> stage(n_ops, 0);
     int n_stages = 0;
@@ -3249,6 +3356,10 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
       if (d->op_dst[k] < 0 || d->op_n[k] < 0 || d->op_dst[k] + d->op_n[k] > R.nx ||
           (reads_row(d->op_code[k]) && (d->op_a[k] < 0 || d->op_a[k] + d->op_n[k] > R.nx))) {
         opfx_set_error("opfx_env_set_reset: op range out of the row"); return OPFX_ERR_INVALID;
+      }
+      for (int q = 0; q < 3; ++q) {
+        const int32_t off = q == 0 ? d->op_c0[k] : (q == 1 ? d->op_c1[k] : d->op_c2[k]);
+        if (off >= 0 && off + d->op_n[k] > d->n_consts) { opfx_set_error("opfx_env_set_reset: op constants out of range"); return OPFX_ERR_INVALID; }
       }
       const int rk = reads_row(d->op_code[k]) ? d->op_n[k] : 0;
       for (int j = 0; j < k; ++j) {
@@ -3259,34 +3370,36 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
         if (dep) stage[k] = std::max(stage[k], stage[j] + 1);
       }
       n_stages = std::max(n_stages, stage[k] + 1);
+      for (int j = 0; j < d->op_n[k]; ++j) covered[(size_t)d->op_dst[k] + j] = 1;
     }
-    std::vector<int32_t> ptr{0}, code, dst, src;
-    std::vector<double> k0, k1, k2;
+    std::vector<int32_t> ptr{0}, och;
     for (int sg = 0; sg < n_stages; ++sg) {
-      for (int k = 0; k < n_ops; ++k) {
-        if (stage[k] != sg) continue;
-        const int mask = d->op_mode ? (d->op_mode[k] & 7) : 7;
-        for (int j = 0; j < d->op_n[k]; ++j) {
-          code.push_back(d->op_code[k] | (mask << 8));
-          dst.push_back(d->op_dst[k] + j);
-          src.push_back(d->op_a[k] + j);
-          k0.push_back(d->op_c0[k] >= 0 ? d->consts[d->op_c0[k] + j] : 0.0);
-          k1.push_back(d->op_c1[k] >= 0 ? d->consts[d->op_c1[k] + j] : 0.0);
-          k2.push_back(d->op_c2[k] >= 0 ? d->consts[d->op_c2[k] + j] : 0.0);
+      for (int pass = 0; pass < 2; ++pass) {               // the chunks with a long function last
+        for (int k = 0; k < n_ops; ++k) {
+          if (stage[k] != sg || (int)is_long(d->op_code[k]) != pass) continue;
+          const int mask = d->op_mode ? (d->op_mode[k] & 7) : 7;
+          for (int j0 = 0; j0 < d->op_n[k]; j0 += 64) {
+            const int32_t words[8] = {d->op_code[k] | (mask << 8) | (reads_row(d->op_code[k]) ? OCH_READS_ROW : 0) | (pass ? OCH_LONG : 0),
+                                      std::min(64, d->op_n[k] - j0), d->op_dst[k] + j0, d->op_a[k] + j0,
+                                      d->op_c0[k] >= 0 ? d->op_c0[k] + j0 : -1, d->op_c1[k] >= 0 ? d->op_c1[k] + j0 : -1,
+                                      d->op_c2[k] >= 0 ? d->op_c2[k] + j0 : -1, 0};
+            och.insert(och.end(), words, words + 8);
+          }
         }
+        ptr.push_back((int32_t)(och.size() / 8));
       }
-      ptr.push_back((int32_t)code.size());
     }
     R.n_stages = n_stages;
+    if (och.empty()) och.assign(8, 0);
+    const int32_t* d_och = nullptr;
     if (rc == OPFX_OK) rc = A.put(ptr, &R.st_ptr);
-    if (rc == OPFX_OK) rc = A.put(code, &R.el_code);
-    if (rc == OPFX_OK) rc = A.put(dst, &R.el_dst);
-    if (rc == OPFX_OK) rc = A.put(src, &R.el_src);
-    if (rc == OPFX_OK) rc = A.put(k0, &R.el_k0);
-    if (rc == OPFX_OK) rc = A.put(k1, &R.el_k1);
-    if (rc == OPFX_OK) rc = A.put(k2, &R.el_k2);
+    if (rc == OPFX_OK) rc = A.put(och, &d_och);
+    R.och = reinterpret_cast<const i32x8*>(d_och);
     if (rc == OPFX_OK) rc = A.put(d->consts, (size_t)d->n_consts, &R.consts);
   }
+  // the row template is not needed where every column is written anyway (per-instance data sources: an op may be
+  // skipped, so no)
+  R.skip_template = !R.has_mode && std::all_of(covered.begin(), covered.end(), [](char c) { return c != 0; });
   // ---- observation elements ---------------------------------------------------------------------------------------
   {
     std::vector<int32_t> oe((size_t)env->de.nobs, 1 << 28);
