@@ -1807,7 +1807,7 @@ __device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
 //     code needs a long function (inverse normal CDF, truncated normal, in-kernel normal draws) come last and run in a
 //     loop of their own, so that the common loop stays small and is unrolled over several chunks;
 //   * the observation as one element list (source kind | index).
-constexpr int MAX_TABLES = 8;
+constexpr int MAX_TABLES = 8, MAX_STAGES = 12;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 // profile chunk words: 0-1 address of the table's relative profiles ([n_steps, n_types]), 2 first column number e0,
 //   3 columns n (1..64), 4 types per step, 5 steps of the table, 6 table number
@@ -1824,7 +1824,8 @@ struct DevReset {
   const double *tc_peak, *tc_lo, *tc_hi;
   // op chunks by stage
   int n_stages;
-  const int* st_ptr;                       // [2 * n_stages + 1]: stage s = chunks [st_ptr[2s], st_ptr[2s+2]), the long ones from st_ptr[2s+1] on
+  unsigned st_barrier;                     // bit s: stage s starts with a workgroup barrier (teams of wavefronts)
+  int st_ptr[2 * MAX_STAGES + 1];          // stage s = chunks [st_ptr[2s], st_ptr[2s+2]), the long ones from st_ptr[2s+1] on
   const i32x8* och;
   const double* consts;                    // row template at init_off; element constants of the ops
   // observation elements (environments whose observation needs no power flow)
@@ -1907,8 +1908,10 @@ __device__ __forceinline__ double draw_normal(unsigned long long seed, long long
       rt_last__ = __builtin_readcyclecounter();                                               \
     }                                                                                         \
   } while (0)
+#define RSTAMPD(slot) do { __builtin_amdgcn_s_waitcnt(0); RSTAMP(slot); } while (0)
 #else
 #define RSTAMP(slot) do { } while (0)
+#define RSTAMPD(slot) do { } while (0)
 #endif
 
 // One vector-op element (include/opfx.h OPFX_OP_*): rv = the source value of the row (or 0), dr = its draw (or 0).
@@ -1947,32 +1950,6 @@ __device__ __forceinline__ void st_at(T* base, unsigned idx, T v) {
 }
 // a chunk descriptor through the scalar cache (`c` is wave-uniform)
 __device__ __forceinline__ i32x8 ld_chunk(const i32x8* base, int c) { return as_const(base)[c]; }
-
-// The loads of one op chunk / its arithmetic and store, apart, so that the loads of several chunks are requested
-// before the first value is used.
-struct OpRegs { double k0, k1, k2, rv, dr; };
-template <bool LONG>
-__device__ __forceinline__ OpRegs op_chunk_load(const DevReset& R, const ResetIO& io, long long b, int lane, const i32x8 ch,
-                                                const double* row) {
-  const int code = ch[0] & 0xFF, n = ch[1], src0 = ch[3];
-  const int lc = lane < n ? lane : n - 1;
-  OpRegs r{0.0, 0.0, 0.0, 0.0, 0.0};
-  if (ch[4] >= 0) r.k0 = ld_at(R.consts, (unsigned)(ch[4] + lc));
-  if (ch[5] >= 0) r.k1 = ld_at(R.consts, (unsigned)(ch[5] + lc));
-  if (ch[6] >= 0) r.k2 = ld_at(R.consts, (unsigned)(ch[6] + lc));
-  if (ch[0] & OCH_READS_ROW) r.rv = row[src0 + lc];
-  // the element's draw: from the caller's array, or made here from the per-reset seed
-  if (code == OPFX_OP_UNIFORM)
-    r.dr = io.uniform ? ld_at(io.uniform + b * R.n_uniform, (unsigned)(src0 + lc)) : draw_uniform(io.rng_seed, b, (unsigned)(src0 + lc));
-  if (LONG && code == OPFX_OP_NORMAL)
-    r.dr = io.normal ? ld_at(io.normal + b * R.n_normal, (unsigned)(src0 + lc)) : draw_normal(io.rng_seed, b, (unsigned)(src0 + lc));
-  return r;
-}
-template <bool LONG>
-__device__ __forceinline__ void op_chunk_apply(int lane, const i32x8 ch, const OpRegs& r, double* row) {
-  const double v = op_value<LONG>(ch[0] & 0xFF, r.rv, r.dr, r.k0, r.k1, r.k2);
-  if (lane < ch[1]) row[ch[2] + lane] = v;
-}
 
 // rows move between memory and the LDS two columns per lane where the row allows it (even column count: every row
 // of the batch starts on a 16-byte boundary), UC chunks per round trip
@@ -2024,114 +2001,291 @@ __device__ __forceinline__ void row_copy_out(double* dst, const double* row, int
   }
 }
 
-// The reset of ONE instance by one wavefront: the row is built in LDS (`row`: nx doubles, `sp`: na doubles) — template
-// (unless every column is written anyway) -> profile values -> vector-op stages -> optionally the initial action and the
-// table observation (opf_env.py:201-207,218) — and leaves with one coalesced store: the intermediate values never make
-// a round trip through memory.  `b` is wave-uniform (k_reset), and so is everything read from the chunk descriptors.
+// The reset of NR instances by one workgroup of NR wavefronts.  The rows are built in LDS (`rows`: NR x (nx + na)
+// doubles) — template (unless every column is written anyway) -> profile values -> vector-op stages -> optionally the
+// initial action and the table observation (opf_env.py:201-207,218) — and leave with one coalesced store each: the
+// intermediate values never make a round trip through memory.
+// The CHUNKS of a pass are dealt over the wavefronts and a wavefront applies its chunk to ALL NR rows: the chunk's
+// descriptor and per-element data (types, peaks, limits, op constants — equal for every row) are fetched once per NR
+// rows, and a row's chain of dependent round trips shrinks with it (one wavefront per row walked 9 profile chunks and 15
+// op chunks of the 144-bus VoltageControl row in 12 round trips; a team of four walks them in 7).  Passes are separated
+// by LDS-only workgroup barriers.  Template, initial action, observation and the final store are per row: wavefront w
+// owns row w.
 // (Round 3 also ran the reset in the epilogue of the step kernel — bit-identical rows, 404.6 us per launch against
 // 270.3 + 56.8 us for two launches: the step kernel's throughput is waves / latency per instance and the reset's chain of
 // round trips adds its whole latency to every instance — and with its descriptors in an LDS image per persistent
 // workgroup — 64.9 vs 56.8 us: 13 rows per CU instead of 16.  profiles/r03_reset_experiments.txt.  Both removed.)
-// U: chunks per round trip of the chunk passes; UC: of the plain copies.
-template <int U, int UC>
-__device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b, int lane,
-                                          double* const row, double* const sp) {
+// U: chunks of one wavefront per round trip; UC: 64-element pieces per round trip of the plain copies.
+template <int NR, int U, int UC, bool FULL>
+__device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __restrict__ Ep, const ResetIO& io, long long b0, long long B,
+                                           int lane, int wib, double* const rows, int row_doubles) {
+  // Wave-uniform decisions below are kept out of the per-(chunk, row) code where they would be scalar BRANCHES (a taken
+  // branch costs a wavefront ~20 cycles, and a first version with a decision tree per chunk and row spent two thirds
+  // of its cycles in them): dead chunks / rows / ops read valid addresses and store under an empty lane mask.
   const double NaN = __builtin_nan("");
 #ifdef OPFX_ENABLE_STAMPS
   unsigned long long rt_last__ = __builtin_readcyclecounter();
 #endif
-  double* xr = io.x + b * R.nx;
-  int step;
-  if (io.step_pool) {
-    // counter-based draw: uniform over the pool up to a bias of n / 2^64
-    const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1));
-    step = as_const(io.step_pool)[(int)(h % (unsigned long long)io.n_step_pool)];
-    if (lane == 0 && io.step_out) io.step_out[b] = step;
-  } else {
-    step = as_const(io.step_idx)[b];
+  const int nxe = (R.nx + 1) & ~1;
+  double* const row = rows + (size_t)wib * row_doubles;                  // this wavefront's own row
+  double* const sp = row + nxe;
+  int* const shared = reinterpret_cast<int*>(rows + (size_t)NR * row_doubles);   // [NR] time steps, [NR] data sources
+  const long long bw = b0 + wib;
+  const bool mine = bw < B;
+  const long long bwc = mine ? bw : B - 1;
+  double* xr = io.x + bwc * R.nx;
+  int step[NR], mode[NR];
+  bool live[NR];
+  // What does not depend on the rows is requested AHEAD of where it is used: the descriptors and per-column data of this
+  // wavefront's first profile chunks before the time steps are known, and those of the first chunks of op stage s + 1
+  // while stage s computes — a row's chain of dependent round trips is what the kernel's time consists of.
+  struct PfRegs { i32x8 ch[U]; int typ[U], slot[U]; double peak[U], lo[U], hi[U]; };
+  auto pf_load = [&](int c0, PfRegs& q) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + NR * u;
+      q.ch[u] = ld_chunk(R.pch, c < R.n_pch ? c : (R.n_pch > 0 ? R.n_pch - 1 : 0));
+      q.ch[u][3] = c < R.n_pch ? q.ch[u][3] : 0;                            // (past the end: no live lane)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = q.ch[u][3], e = q.ch[u][2] + (lane < n ? lane : (n > 0 ? n - 1 : 0));
+      q.typ[u] = ld_at(R.tc_typ, (unsigned)e); q.slot[u] = ld_at(R.tc_slot, (unsigned)e);
+      q.peak[u] = ld_at(R.tc_peak, (unsigned)e); q.lo[u] = ld_at(R.tc_lo, (unsigned)e); q.hi[u] = ld_at(R.tc_hi, (unsigned)e);
+    }
+  };
+  PfRegs pf;
+  if (R.n_pch > 0) pf_load(wib, pf);
+  {
+    int my_step;
+    if (io.step_pool) {
+      // counter-based draw: entry floor(h n / 2^64) of the pool (a multiply-high instead of a 64-bit division), uniform
+      // up to a bias of n / 2^64
+      const unsigned long long h = mix64(io.rng_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(bwc + 1));
+      my_step = as_const(io.step_pool)[(int)__umul64hi(h, (unsigned long long)io.n_step_pool)];
+      if (lane == 0 && mine && io.step_out) io.step_out[bw] = my_step;
+    } else {
+      my_step = as_const(io.step_idx)[bwc];
+    }
+    const int my_mode = (FULL && io.mode && R.has_mode) ? as_const(io.mode)[bwc] : -1;    // data source of this instance ('mixed'), -1: none
+    if (NR == 1) { step[0] = my_step; mode[0] = my_mode; live[0] = mine; }
+    else if (lane == 0) { shared[wib] = my_step; shared[NR + wib] = my_mode; }
   }
-  const int mode = (io.mode && R.has_mode) ? as_const(io.mode)[b] : -1;     // data source of this instance ('mixed'), -1: none
   RSTAMP(0);
   // ---- the row template (or the instance's own row: keep_state) ---------------------------------------------------
-  if (!R.skip_template || io.keep_state) {
+  if ((!R.skip_template || io.keep_state) && mine) {
     const double* src = (R.init_off >= 0 && !io.keep_state) ? R.consts + R.init_off : xr;
     row_copy_in<UC>(row, src, R.nx, lane);
-    wave_fence();
+  }
+  if (NR > 1) {
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      step[r] = __builtin_amdgcn_readfirstlane(shared[r]);
+      mode[r] = __builtin_amdgcn_readfirstlane(shared[NR + r]);
+      live[r] = b0 + r < B;
+    }
   }
   RSTAMP(1);
   // ---- profile values of every table (opf_env.py:339-372) -------------------------------------------------------
-  const int n_pc = mode <= 0 ? R.n_pch : 0;
-  for (int c0 = 0; c0 < n_pc; c0 += U) {
-    i32x8 ch[U];
-    int typ[U], slot[U];
-    double peak[U], lo[U], hi[U], nz[U], r0[U], r1[U], rr[U];
+  // FULL: the kernel with interpolation between time steps, noise on the profile values or per-instance data sources (all
+  // rare: kernels of their own, so that the plain one neither carries their registers nor evaluates them under a mask)
+  const bool any_itp = FULL && io.interp != nullptr, any_noise = FULL && io.noise != nullptr;
+  for (int c0 = wib; c0 < R.n_pch; c0 += NR * U) {
+    if (c0 != wib) pf_load(c0, pf);
+    const i32x8 (&ch)[U] = pf.ch;
+    const int (&typ)[U] = pf.typ; const int (&slot)[U] = pf.slot;
+    const double (&peak)[U] = pf.peak; const double (&lo)[U] = pf.lo; const double (&hi)[U] = pf.hi;
+    double r0[U][NR], r1[FULL ? U : 1][FULL ? NR : 1], rr[FULL ? U : 1][FULL ? NR : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      ch[u] = ld_chunk(R.pch, c0 + u < n_pc ? c0 + u : n_pc - 1);
-      if (c0 + u >= n_pc) ch[u][3] = 0;                                    // (past the end: no live lane)
+      const double* rel = reinterpret_cast<const double*>(((unsigned long long)(unsigned)ch[u][1] << 32) | (unsigned)ch[u][0]);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) r0[u][r] = ld_at(rel + (long long)step[r] * ch[u][4], (unsigned)typ[u]);
+    }
+    if (FULL && any_itp) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double* rel = reinterpret_cast<const double*>(((unsigned long long)(unsigned)ch[u][1] << 32) | (unsigned)ch[u][0]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const bool itp = step[r] < ch[u][5] - 1;                                   // :345 (the last step has no successor)
+          r1[FULL ? u : 0][FULL ? r : 0] = ld_at(rel + (long long)step[r] * ch[u][4], (unsigned)((itp ? ch[u][4] : 0) + typ[u]));
+          rr[FULL ? u : 0][FULL ? r : 0] = as_const(io.interp)[(live[r] ? b0 + r : B - 1) * R.n_tables + ch[u][6]];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = ch[u][3], e = ch[u][2] + (lane < n ? lane : (n > 0 ? n - 1 : 0));
-      typ[u] = 0; slot[u] = 0; peak[u] = 0.0; lo[u] = 0.0; hi[u] = 0.0; nz[u] = 1.0;
-      if (n == 0) continue;
-      typ[u] = ld_at(R.tc_typ, (unsigned)e); slot[u] = ld_at(R.tc_slot, (unsigned)e);
-      peak[u] = ld_at(R.tc_peak, (unsigned)e); lo[u] = ld_at(R.tc_lo, (unsigned)e); hi[u] = ld_at(R.tc_hi, (unsigned)e);
-      nz[u] = io.noise ? ld_at(io.noise + b * R.n_noise, (unsigned)e) : 1.0;         // (noise columns are numbered like the list)
-    }
+      double v[NR];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const double* rel = reinterpret_cast<const double*>(((unsigned long long)(unsigned)ch[u][1] << 32) | (unsigned)ch[u][0]);
-      const int nt = ch[u][4];
-      const bool itp = io.interp != nullptr && step < ch[u][5] - 1;                          // :345
-      const double* rw = rel + (long long)step * nt;
-      r0[u] = 0.0; r1[u] = 0.0; rr[u] = 0.0;
-      if (ch[u][3] == 0) continue;
-      r0[u] = ld_at(rw, (unsigned)typ[u]);
-      if (itp) { r1[u] = ld_at(rw, (unsigned)(nt + typ[u])); rr[u] = as_global(io.interp)[b * R.n_tables + ch[u][6]]; }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool itp = io.interp != nullptr && step < ch[u][5] - 1;
-      double v = r0[u] * peak[u];                                                // :343
-      if (itp) v = v * rr[u] + (r1[u] * peak[u]) * (1.0 - rr[u]);                // :347-349
-      if (io.noise) {
-        if (io.normal_noise_factor > 0.0) v = v + fabs(v) * io.normal_noise_factor * nz[u];   // :359-360
-        else v = v * nz[u];                                                      // :354-356
+      for (int r = 0; r < NR; ++r) {
+        v[r] = r0[u][r] * peak[u];                                                 // :343
+        if (FULL && any_itp) {                                                     // :347-349
+          const double rr_ = rr[FULL ? u : 0][FULL ? r : 0];
+          const double w = v[r] * rr_ + (r1[FULL ? u : 0][FULL ? r : 0] * peak[u]) * (1.0 - rr_);
+          v[r] = step[r] < ch[u][5] - 1 ? w : v[r];
+        }
+        if (FULL && any_noise) {
+          const double nz = ld_at(io.noise + (live[r] ? b0 + r : B - 1) * R.n_noise, (unsigned)e);   // (noise columns are numbered like the list)
+          if (io.normal_noise_factor > 0.0) v[r] = v[r] + fabs(v[r]) * io.normal_noise_factor * nz;   // :359-360
+          else v[r] = v[r] * nz;                                                   // :354-356
+        }
+        v[r] = fmin(fmax(v[r], lo[u]), hi[u]);                                     // :364-369
       }
-      v = fmin(fmax(v, lo[u]), hi[u]);                                           // :364-369
-      if (lane < ch[u][3]) row[slot[u]] = v;                                     // :371-372
+      // (rows past the end of the batch are computed like the last one and never leave the LDS)
+      if (FULL) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if (lane < (mode[r] <= 0 ? n : 0)) rows[(size_t)r * row_doubles + slot[u]] = v[r];
+      } else if (lane < n) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rows[(size_t)r * row_doubles + slot[u]] = v[r];           // :371-372
+      }
     }
   }
-  wave_fence();
   RSTAMP(2);
   // ---- the `_sampling` tail: stages of mutually independent op chunks ----------------------------------------------
-  for (int sgi = 0; sgi < R.n_stages; ++sgi) {
-    const int s0 = as_const(R.st_ptr)[2 * sgi], sl = as_const(R.st_ptr)[2 * sgi + 1], s1 = as_const(R.st_ptr)[2 * sgi + 2];
-    for (int c0 = s0; c0 < sl; c0 += U) {
-      i32x8 ch[U];
-      OpRegs r[U];
+  struct OpRegs { i32x8 ch[U]; double k0[U], k1[U], k2[U]; };
+  auto op_load = [&](int c0, int sl, OpRegs& q) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ch[u] = ld_chunk(R.och, c0 + u < sl ? c0 + u : sl - 1);
-        // past the end, or an op this instance's data source does not run: no live lane
-        if (c0 + u >= sl || (mode >= 0 && !((ch[u][0] >> (8 + mode)) & 1))) ch[u][1] = 0;
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + NR * u;
+      q.ch[u] = ld_chunk(R.och, c < sl ? c : (sl > 0 ? sl - 1 : 0));
+      q.ch[u][1] = c < sl ? q.ch[u][1] : 0;                                 // (past the end: no live lane)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = q.ch[u][1], lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
+      // (an op without a constant points at a block of zeros, opfx_env_set_reset)
+      q.k0[u] = ld_at(R.consts, (unsigned)(q.ch[u][4] + lc));
+      q.k1[u] = ld_at(R.consts, (unsigned)(q.ch[u][5] + lc));
+      q.k2[u] = ld_at(R.consts, (unsigned)(q.ch[u][6] + lc));
+    }
+  };
+  auto op_apply = [&](const OpRegs& q) {
+    double rv[U][NR];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = q.ch[u][1], lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
+      const int src = (q.ch[u][0] & OCH_READS_ROW) ? q.ch[u][3] + lc : 0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) rv[u][r] = rows[(size_t)r * row_doubles + src];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = q.ch[u][1], code = q.ch[u][0] & 0xFF, lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
+      const double k0 = q.k0[u], k1 = q.k1[u], k2 = q.k2[u];
+      double v[NR];
+      // ONE dispatch on the op code per chunk, the rows inside it (OP_CASE: an empty volatile asm keeps each case a
+      // branch target whatever the optimiser thinks of the cost of the other cases' division and square root)
+#define OP_CASE() asm volatile("" ::: "memory")
+      switch (code) {
+        case OPFX_OP_AFFINE:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = rv[u][r] * k0 + k1;
+          break;
+        case OPFX_OP_SET_CONST:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = k0;
+          break;
+        case OPFX_OP_UNIFORM:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            // the element's draw: from the caller's array, or made here from the per-reset seed
+            const long long b = live[r] ? b0 + r : B - 1;
+            const double dr = io.uniform ? ld_at(io.uniform + b * R.n_uniform, (unsigned)(q.ch[u][3] + lc))
+                                         : draw_uniform(io.rng_seed, b, (unsigned)(q.ch[u][3] + lc));
+            v[r] = op_value<false>(OPFX_OP_UNIFORM, 0.0, dr, k0, k1, k2);
+          }
+          break;
+        case OPFX_OP_SQRT_DIFF:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = op_value<false>(OPFX_OP_SQRT_DIFF, rv[u][r], 0.0, k0, k1, k2);
+          break;
+        case OPFX_OP_NEG:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = -rv[u][r];
+          break;
+        case OPFX_OP_CLIP:
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = op_value<false>(OPFX_OP_CLIP, rv[u][r], 0.0, k0, k1, k2);
+          break;
+        default:                                           // OPFX_OP_DIV (the codes with long functions are not in this loop)
+          OP_CASE();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) v[r] = op_value<false>(OPFX_OP_DIV, rv[u][r], 0.0, k0, k1, k2);
       }
+#undef OP_CASE
+      if (FULL) {
+        // (an op this instance's data source does not run stores nothing)
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (ch[u][1] > 0) r[u] = op_chunk_load<false>(R, io, b, lane, ch[u], row);
+        for (int r = 0; r < NR; ++r)
+          if (lane < ((mode[r] < 0 || ((q.ch[u][0] >> (8 + mode[r])) & 1)) ? n : 0)) rows[(size_t)r * row_doubles + q.ch[u][2] + lane] = v[r];
+      } else if (lane < n) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) if (ch[u][1] > 0) op_chunk_apply<false>(lane, ch[u], r[u], row);
+        for (int r = 0; r < NR; ++r) rows[(size_t)r * row_doubles + q.ch[u][2] + lane] = v[r];
+      }
     }
-    for (int c = sl; c < s1; ++c) {
+  };
+  OpRegs pre;
+  if (R.n_stages > 0) op_load(R.st_ptr[0] + wib, R.st_ptr[1], pre);
+  for (int sgi = 0; sgi < R.n_stages; ++sgi) {
+    const int s0 = R.st_ptr[2 * sgi], sl = R.st_ptr[2 * sgi + 1], s1 = R.st_ptr[2 * sgi + 2];
+    RSTAMPD(8);
+    // (a stage whose ops depend on earlier ones chunk by chunk only — chunk i on chunk i, which the same wavefront ran,
+    //  the stage lists being padded to whole rounds of the wavefronts — needs no barrier: the LDS keeps a wavefront's order)
+    if (NR > 1 && ((R.st_barrier >> sgi) & 1)) lds_barrier(); else wave_fence();
+    RSTAMPD(9);
+    OpRegs cur = pre;
+    if (sgi + 1 < R.n_stages) op_load(R.st_ptr[2 * sgi + 2] + wib, R.st_ptr[2 * sgi + 3], pre);
+    RSTAMPD(10);
+    op_apply(cur);
+    RSTAMPD(11);
+    for (int c0 = s0 + wib + NR * U; c0 < sl; c0 += NR * U) {
+      op_load(c0, sl, cur);
+      op_apply(cur);
+    }
+    for (int c = sl + wib; c < s1; c += NR) {
       const i32x8 ch = ld_chunk(R.och, c);
-      if (mode >= 0 && !((ch[0] >> (8 + mode)) & 1)) continue;
-      const OpRegs r = op_chunk_load<true>(R, io, b, lane, ch, row);
-      op_chunk_apply<true>(lane, ch, r, row);
+      const int n = ch[1], code = ch[0] & 0xFF, lc = lane < n ? lane : n - 1;
+      const double k0 = ld_at(R.consts, (unsigned)(ch[4] + lc)), k1 = ld_at(R.consts, (unsigned)(ch[5] + lc)),
+                   k2 = ld_at(R.consts, (unsigned)(ch[6] + lc));
+      for (int r = 0; r < NR; ++r) {
+        const long long b = b0 + r;
+        if (b >= B) break;
+        int md = -1;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) if (q == r) md = mode[q];
+        if (md >= 0 && !((ch[0] >> (8 + md)) & 1)) continue;
+        const double rv = (ch[0] & OCH_READS_ROW) ? rows[(size_t)r * row_doubles + ch[3] + lc] : 0.0;
+        double dr = 0.0;
+        if (code == OPFX_OP_UNIFORM)
+          dr = io.uniform ? ld_at(io.uniform + b * R.n_uniform, (unsigned)(ch[3] + lc)) : draw_uniform(io.rng_seed, b, (unsigned)(ch[3] + lc));
+        if (code == OPFX_OP_NORMAL)
+          dr = io.normal ? ld_at(io.normal + b * R.n_normal, (unsigned)(ch[3] + lc)) : draw_normal(io.rng_seed, b, (unsigned)(ch[3] + lc));
+        const double v = op_value<true>(code, rv, dr, k0, k1, k2);
+        if (lane < n) rows[(size_t)r * row_doubles + ch[2] + lane] = v;
+      }
     }
-    wave_fence();
   }
+  // the first observation descriptors are on their way while the last stage finishes
+  int ow[UC];
+  const bool with_obs = io.obs && Ep;
+  if (with_obs) {
+#pragma unroll
+    for (int u = 0; u < UC; ++u) { const int e = lane + 64 * u; ow[u] = ld_at(R.oe_src, (unsigned)(e < R.n_oel ? e : R.n_oel - 1)); }
+  }
+  if (NR > 1) lds_barrier(); else wave_fence();
   RSTAMP(3);
-  if (io.obs && Ep) {
+  if (!mine) return;
+  if (with_obs) {
     // reset without power flow: initial action as ABSOLUTE set-points (opf_env.py:207), then the
     // table part of the observation (:218); result entries are NaN
     const DevEnv& E = *Ep;
@@ -2143,7 +2297,7 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
       const bool clampa = (E.clamp_enabled & 2) != 0;
       const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
       const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
-      double a = io.action ? io.action[b * E.na + k] : 0.0;
+      double a = io.action ? io.action[bw * E.na + k] : 0.0;
       double xv = row[slot];
       if (io.action) {
         a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
@@ -2164,12 +2318,12 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
     for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k];
     wave_fence();
     RSTAMP(4);
-    double* const out = io.obs + b * E.nobs;
+    double* const out = io.obs + bw * E.nobs;
     for (int e0 = lane; e0 < R.n_oel; e0 += 64 * UC) {
       int w[UC];
       double v[UC];
 #pragma unroll
-      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = as_global(R.oe_src)[e < R.n_oel ? e : R.n_oel - 1]; }
+      for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = e0 == lane ? ow[u] : ld_at(R.oe_src, (unsigned)(e < R.n_oel ? e : R.n_oel - 1)); }
 #pragma unroll
       for (int u = 0; u < UC; ++u) { const int kind = w[u] >> 28, idx = w[u] & 0x0FFFFFFF; v[u] = kind == 1 ? NaN : (kind == 0 ? row[idx] : sp[idx]); }
 #pragma unroll
@@ -2185,16 +2339,16 @@ __device__ __forceinline__ void reset_row(const DevReset& R, const DevEnv* __res
   RSTAMP(6);
 }
 
-__global__ __launch_bounds__(256, 4) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B,
-                                               int row_doubles) {
+// NR: wavefronts per workgroup = rows per workgroup (as many as the LDS takes next to three more workgroups)
+template <int NR, bool FULL>
+__global__ __launch_bounds__(64 * NR, NR == 1 ? 2 : 4) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B, int row_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // (the row number is wave-uniform: scalar addressing)
-  double* const row = smem + (size_t)wib * row_doubles;
-  double* const sp = row + ((R.nx + 1) & ~1);
-  const long long w = (long long)blockIdx.x * wpb + wib;
-  const long long nw = (long long)gridDim.x * wpb;
-  for (long long b = w; b < B; b += nw) reset_row<4, 9>(R, Ep, io, b, lane, row, sp);
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // (wave-uniform: scalar addressing)
+  for (long long b0 = (long long)blockIdx.x * NR; b0 < B; b0 += (long long)gridDim.x * NR) {
+    reset_rows<NR, NR == 2 ? 4 : (NR == 4 && FULL ? 2 : 3), (NR == 1 || FULL) ? 6 : 9, FULL>(R, Ep, io, b0, B, lane, wib, smem, row_doubles);
+    if (NR > 1) lds_barrier();            // (the next rows are written by all wavefronts)
+  }
 }
 
 // cost of one cost row (objective.py:34-77) given its active/reactive power; coefficients are
@@ -3291,6 +3445,12 @@ extern "C" int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t
   return OPFX_OK;
 }
 
+// wavefronts (= rows) per workgroup of the reset kernel: as many as leave room for four workgroups per CU
+static int reset_team(const opfx_env* env) {
+  const size_t row_bytes = (size_t)(((env->de.nx + 1) & ~1) + ((env->de.na + 1) & ~1)) * sizeof(double);
+  return 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
+}
+
 extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   if (!env || !d || d->n_tables < 0 || d->n_tables > MAX_TABLES) {
     opfx_set_error("opfx_env_set_reset: bad argument (at most 8 profile tables)");
@@ -3373,29 +3533,55 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
       for (int j = 0; j < d->op_n[k]; ++j) covered[(size_t)d->op_dst[k] + j] = 1;
     }
     std::vector<int32_t> ptr{0}, och;
+    const int32_t zero_off = d->n_consts;                 // 64 zeros behind the caller's constants: "no constant" (0.0)
+    // Wavefront w of a team of `team` runs entries w, w + team, ... of a stage's list.  Each op's chunks are padded to a
+    // whole number of rounds (empty chunks), so chunk i of EVERY op runs on wavefront i mod team; a dependency that pairs
+    // chunk i with chunk i (the later op starts where the earlier one's range starts) then stays inside one wavefront and
+    // its stage needs no workgroup barrier.
+    const int team = reset_team(env);
+    R.st_barrier = 1u;                                     // (stage 0 follows the profile pass: always)
+    for (int k = 0; k < n_ops; ++k) {
+      const int rk = reads_row(d->op_code[k]) ? d->op_n[k] : 0;
+      for (int j = 0; j < k; ++j) {
+        if (stage[j] == stage[k]) continue;
+        const int rj = reads_row(d->op_code[j]) ? d->op_n[j] : 0;
+        const bool raw = overlap(d->op_dst[j], d->op_n[j], d->op_a[k], rk), waw = overlap(d->op_dst[j], d->op_n[j], d->op_dst[k], d->op_n[k]),
+                   war = overlap(d->op_a[j], rj, d->op_dst[k], d->op_n[k]);
+        const bool aligned = (!raw || d->op_a[k] == d->op_dst[j]) && (!waw || d->op_dst[k] == d->op_dst[j]) && (!war || d->op_dst[k] == d->op_a[j]);
+        if ((raw || waw || war) && !aligned) R.st_barrier |= 1u << stage[k];
+      }
+    }
     for (int sg = 0; sg < n_stages; ++sg) {
       for (int pass = 0; pass < 2; ++pass) {               // the chunks with a long function last
         for (int k = 0; k < n_ops; ++k) {
           if (stage[k] != sg || (int)is_long(d->op_code[k]) != pass) continue;
           const int mask = d->op_mode ? (d->op_mode[k] & 7) : 7;
+          const int n_chunks = (d->op_n[k] + 63) / 64, n_padded = (n_chunks + team - 1) / team * team;
           for (int j0 = 0; j0 < d->op_n[k]; j0 += 64) {
             const int32_t words[8] = {d->op_code[k] | (mask << 8) | (reads_row(d->op_code[k]) ? OCH_READS_ROW : 0) | (pass ? OCH_LONG : 0),
                                       std::min(64, d->op_n[k] - j0), d->op_dst[k] + j0, d->op_a[k] + j0,
-                                      d->op_c0[k] >= 0 ? d->op_c0[k] + j0 : -1, d->op_c1[k] >= 0 ? d->op_c1[k] + j0 : -1,
-                                      d->op_c2[k] >= 0 ? d->op_c2[k] + j0 : -1, 0};
+                                      d->op_c0[k] >= 0 ? d->op_c0[k] + j0 : zero_off, d->op_c1[k] >= 0 ? d->op_c1[k] + j0 : zero_off,
+                                      d->op_c2[k] >= 0 ? d->op_c2[k] + j0 : zero_off, 0};
+            och.insert(och.end(), words, words + 8);
+          }
+          for (int q = n_chunks; q < n_padded; ++q) {      // empty chunks (no element; valid addresses)
+            const int32_t words[8] = {OPFX_OP_SET_CONST, 0, 0, 0, zero_off, zero_off, zero_off, 0};
             och.insert(och.end(), words, words + 8);
           }
         }
         ptr.push_back((int32_t)(och.size() / 8));
       }
     }
+    if (n_stages > MAX_STAGES) { opfx_set_error("opfx_env_set_reset: more than 12 dependent stages of vector ops"); return OPFX_ERR_INVALID; }
     R.n_stages = n_stages;
+    for (size_t q = 0; q < ptr.size(); ++q) R.st_ptr[q] = ptr[q];
     if (och.empty()) och.assign(8, 0);
     const int32_t* d_och = nullptr;
-    if (rc == OPFX_OK) rc = A.put(ptr, &R.st_ptr);
     if (rc == OPFX_OK) rc = A.put(och, &d_och);
     R.och = reinterpret_cast<const i32x8*>(d_och);
-    if (rc == OPFX_OK) rc = A.put(d->consts, (size_t)d->n_consts, &R.consts);
+    std::vector<double> cz(d->consts, d->consts + d->n_consts);
+    cz.resize(cz.size() + 64, 0.0);
+    if (rc == OPFX_OK) rc = A.put(cz, &R.consts);
   }
   // the row template is not needed where every column is written anyway (per-instance data sources: an op may be
   // skipped, so no)
@@ -3430,13 +3616,24 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
             io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out,
             env->ctx->dp.stamps};
-  const int wpb = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
-  const size_t lds = wpb * row_bytes;
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
-                     (long long)B, row_doubles);
+  const int wpb = reset_team(env);
+  const size_t lds = wpb * row_bytes + 2 * wpb * sizeof(int32_t);       // rows; time steps and data sources of the rows
+  auto launch = [&](auto kernel) -> int {
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // as many workgroups as are resident at once (LDS / registers); each walks its share of the batch
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, lds));
+    static const int mult = getenv("OPFX_RESET_GRID_MULT") ? atoi(getenv("OPFX_RESET_GRID_MULT")) : 1;
+    const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * std::max(per_cu, 1) * mult);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
+                       (long long)B, row_doubles);
+    return OPFX_OK;
+  };
+  const bool full = io->interp != nullptr || io->noise != nullptr || (io->mode != nullptr && env->dr.has_mode);
+  const int lrc = full ? (wpb == 4 ? launch(k_reset<4, true>) : (wpb == 2 ? launch(k_reset<2, true>) : launch(k_reset<1, true>)))
+                       : (wpb == 4 ? launch(k_reset<4, false>) : (wpb == 2 ? launch(k_reset<2, false>) : launch(k_reset<1, false>)));
+  if (lrc != OPFX_OK) return lrc;
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }

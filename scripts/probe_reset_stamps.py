@@ -24,4 +24,7 @@ names = ['time step', 'template', 'profile tables', 'vector ops', 'initial actio
 tot = sum(out[:7])
 for k, nm in enumerate(names):
     print(f'  {nm:22s} {out[k] // n:9d} cycles per reset  {100 * out[k] / tot:5.1f}%')
+for k, nm in ((8, 'ops: stage pointers'), (9, 'ops: barrier'), (10, 'ops: chunk descriptors + constants (drained)'), (11, 'ops: LDS reads, arithmetic, LDS writes (drained)')):
+    if out[k]:
+        print(f'    {nm:48s} {out[k] // n:9d} cycles per reset')
 print(f'  total {tot // n} cycles per reset for the rows of wavefront 0 of workgroup 0 (nx={env.nx}, na={env.n_actions}, n_ops={len(env.ops.ops)}, tables={len(env.tables)})')
