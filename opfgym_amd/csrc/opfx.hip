@@ -2868,6 +2868,7 @@ struct opfx_ctx {
 };
 
 struct opfx_env {
+  int reset_team = 1;                  // wavefronts (= rows) per workgroup of the reset kernel (opfx_env_set_reset)
   opfx_ctx* ctx = nullptr;
   DevEnv de{};
   const DevEnv* d_de = nullptr;
@@ -3446,9 +3447,12 @@ extern "C" int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t
 }
 
 // wavefronts (= rows) per workgroup of the reset kernel: as many as leave room for four workgroups per CU
+// (OPFX_RESET_TEAM=1|2|4, read when the reset programme is set: the smaller teams on a row that would not need them — tests)
 static int reset_team(const opfx_env* env) {
   const size_t row_bytes = (size_t)(((env->de.nx + 1) & ~1) + ((env->de.na + 1) & ~1)) * sizeof(double);
-  return 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
+  int team = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
+  if (const char* e = getenv("OPFX_RESET_TEAM")) { const int t = atoi(e); if ((t == 1 || t == 2 || t == 4) && t < team) team = t; }
+  return team;
 }
 
 extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
@@ -3538,7 +3542,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
     // whole number of rounds (empty chunks), so chunk i of EVERY op runs on wavefront i mod team; a dependency that pairs
     // chunk i with chunk i (the later op starts where the earlier one's range starts) then stays inside one wavefront and
     // its stage needs no workgroup barrier.
-    const int team = reset_team(env);
+    const int team = env->reset_team = reset_team(env);
     R.st_barrier = 1u;                                     // (stage 0 follows the profile pass: always)
     for (int k = 0; k < n_ops; ++k) {
       const int rk = reads_row(d->op_code[k]) ? d->op_n[k] : 0;
@@ -3616,7 +3620,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   ResetIO r{io->step_idx, io->noise, io->interp, io->uniform, io->normal, io->normal_noise_factor, io->x, io->mode,
             io->action, io->obs, io->keep_state, io->step_pool, io->n_step_pool, (unsigned long long)io->rng_seed, io->step_out,
             env->ctx->dp.stamps};
-  const int wpb = reset_team(env);
+  const int wpb = env->reset_team;
   const size_t lds = wpb * row_bytes + 2 * wpb * sizeof(int32_t);       // rows; time steps and data sources of the rows
   auto launch = [&](auto kernel) -> int {
     if (lds > 64 * 1024)

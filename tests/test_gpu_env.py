@@ -92,6 +92,38 @@ def test_env_matches_reference_golden(name):
         assert not _np(info['valids']).any()
 
 
+@pytest.mark.parametrize('team', [1, 2])
+@pytest.mark.parametrize('name', ['vc_mv_small', 'vc_mixed_simbench', 'vc_mixed_uniform', 'vc_noisy', 'vc_normal_noise', 'vc_interpolate', 'qm_mv_small', 'eco_hv_small', 'loadshed_mv_small'])
+def test_reset_kernel_teams_of_one_and_two_wavefronts(name, team, monkeypatch):
+    """The reset kernel runs as teams of 4, 2 or 1 wavefronts (= rows per workgroup) depending on the size of the table
+    row; the grids of the goldens all take teams of four.  The smaller teams are forced here (OPFX_RESET_TEAM) and must
+    reproduce the reference's sampled tables and reset observation, on batches that are no multiple of the team."""
+    if name not in SINGLE_STEP:
+        pytest.skip(f'no golden {name}')
+    monkeypatch.setenv('OPFX_RESET_TEAM', str(team))
+    g = golden(name)
+    n = len(g['step'])
+    env = product_env(name, batch_size=n)
+    noise = None
+    if noise_factors(name, g['noise'][0]) is not None:
+        noise = np.stack([noise_factors(name, g['noise'][k]) for k in range(n)])
+    extra = {k: g[k] for k in ('interp', 'normal') if k in g and g[k].shape[1]}
+    if mixed_modes(name, g) is not None:
+        extra.pop('interp')
+        extra['mode'] = mixed_modes(name, g)
+    obs0, _ = env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None,
+                                 'noise': noise, **extra})
+    checked = 0
+    for key in g:
+        if key.startswith('tab__'):
+            _, tbl, col = key.split('__')
+            if (tbl, col) in env.store.ranges:
+                assert np.allclose(_np(env.table_column(tbl, col)), g[key], rtol=0, atol=TAB_TOL), key
+                checked += 1
+    assert checked > 0
+    assert np.allclose(_np(obs0), g['obs_reset'], rtol=0, atol=R_TOL)
+
+
 @pytest.mark.parametrize('name,B', [('vc_mv_small', 48), ('qm_mv_small', 32), ('eco_hv_small', 24),
                                     ('sc_hv_small', 12), ('vc_resobs_diff', 16), ('reconf_hv_small_sw', 32),
                                     ('mixed_lv', 32)])
