@@ -1830,7 +1830,7 @@ struct DevReset {
   const double* consts;                    // row template at init_off; element constants of the ops
   // observation elements (environments whose observation needs no power flow)
   int n_oel;
-  const int* oe_src;                       // kind << 28 | index: 0 row, 1 NaN (result entry), 2 action set-point
+  const int* oe_src;                       // position in the LDS image of the instance (table row, then the action set-points), -1: NaN (result entry)
 };
 
 struct ResetIO {
@@ -2050,6 +2050,8 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = q.ch[u][3], e = q.ch[u][2] + (lane < n ? lane : (n > 0 ? n - 1 : 0));
+      q.typ[u] = 0; q.slot[u] = 0; q.peak[u] = 0.0; q.lo[u] = 0.0; q.hi[u] = 0.0;
+      if (u > 0 && n == 0) continue;                       // (a slot past the end costs one scalar branch, not its instructions)
       q.typ[u] = ld_at(R.tc_typ, (unsigned)e); q.slot[u] = ld_at(R.tc_slot, (unsigned)e);
       q.peak[u] = ld_at(R.tc_peak, (unsigned)e); q.lo[u] = ld_at(R.tc_lo, (unsigned)e); q.hi[u] = ld_at(R.tc_hi, (unsigned)e);
     }
@@ -2101,6 +2103,9 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
     for (int u = 0; u < U; ++u) {
       const double* rel = reinterpret_cast<const double*>(((unsigned long long)(unsigned)ch[u][1] << 32) | (unsigned)ch[u][0]);
 #pragma unroll
+      for (int r = 0; r < NR; ++r) r0[u][r] = 0.0;
+      if (u > 0 && ch[u][3] == 0) continue;
+#pragma unroll
       for (int r = 0; r < NR; ++r) r0[u][r] = ld_at(rel + (long long)step[r] * ch[u][4], (unsigned)typ[u]);
     }
     if (FULL && any_itp) {
@@ -2118,6 +2123,7 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = ch[u][3], e = ch[u][2] + (lane < n ? lane : (n > 0 ? n - 1 : 0));
+      if (u > 0 && n == 0) continue;
       double v[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -2157,6 +2163,8 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = q.ch[u][1], lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
+      q.k0[u] = 0.0; q.k1[u] = 0.0; q.k2[u] = 0.0;
+      if (u > 0 && n == 0) continue;                       // (a slot past the end costs one scalar branch, not its instructions)
       // (an op without a constant points at a block of zeros, opfx_env_set_reset)
       q.k0[u] = ld_at(R.consts, (unsigned)(q.ch[u][4] + lc));
       q.k1[u] = ld_at(R.consts, (unsigned)(q.ch[u][5] + lc));
@@ -2170,11 +2178,15 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
       const int n = q.ch[u][1], lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
       const int src = (q.ch[u][0] & OCH_READS_ROW) ? q.ch[u][3] + lc : 0;
 #pragma unroll
+      for (int r = 0; r < NR; ++r) rv[u][r] = 0.0;
+      if (u > 0 && n == 0) continue;
+#pragma unroll
       for (int r = 0; r < NR; ++r) rv[u][r] = rows[(size_t)r * row_doubles + src];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = q.ch[u][1], code = q.ch[u][0] & 0xFF, lc = lane < n ? lane : (n > 0 ? n - 1 : 0);
+      if (u > 0 && n == 0) continue;
       const double k0 = q.k0[u], k1 = q.k1[u], k2 = q.k2[u];
       double v[NR];
       // ONE dispatch on the op code per chunk, the rows inside it (OP_CASE: an empty volatile asm keeps each case a
@@ -2291,13 +2303,14 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
     const DevEnv& E = *Ep;
     for (int k = lane; k < E.na; k += 64) {
       // (descriptors and the action first, unconditionally, then the arithmetic: one memory round trip)
-      const int slot = as_global(E.act_slot)[k], ls = as_global(E.act_lo_slot)[k], hs = as_global(E.act_hi_slot)[k];
-      const double loc = as_global(E.act_lo_const)[k], hic = as_global(E.act_hi_const)[k], scal = as_global(E.act_scaling)[k];
-      const int kind = as_global(E.act_kind)[k];
+      const unsigned ku = (unsigned)k;
+      const int slot = ld_at(E.act_slot, ku), ls = ld_at(E.act_lo_slot, ku), hs = ld_at(E.act_hi_slot, ku);
+      const double loc = ld_at(E.act_lo_const, ku), hic = ld_at(E.act_hi_const, ku), scal = ld_at(E.act_scaling, ku);
+      const int kind = ld_at(E.act_kind, ku);
       const bool clampa = (E.clamp_enabled & 2) != 0;
-      const int ch = clampa ? as_global(E.clamp_hi_slot)[k] : -2, cl = clampa ? as_global(E.clamp_lo_slot)[k] : -2;
-      const double chc = clampa ? as_global(E.clamp_hi_const)[k] : 0.0, clc = clampa ? as_global(E.clamp_lo_const)[k] : 0.0;
-      double a = io.action ? io.action[bw * E.na + k] : 0.0;
+      const int ch = clampa ? ld_at(E.clamp_hi_slot, ku) : -2, cl = clampa ? ld_at(E.clamp_lo_slot, ku) : -2;
+      const double chc = clampa ? ld_at(E.clamp_hi_const, ku) : 0.0, clc = clampa ? ld_at(E.clamp_lo_const, ku) : 0.0;
+      double a = io.action ? ld_at(io.action + bw * E.na, ku) : 0.0;
       double xv = row[slot];
       if (io.action) {
         a = (a != a) ? a : fmin(fmax(a, 0.0), 1.0);                                  // :429
@@ -2315,7 +2328,7 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
     }
     // (limits are read before any set-point is written: all set-points first, then their slots)
     wave_fence();
-    for (int k = lane; k < E.na; k += 64) row[as_global(E.act_slot)[k]] = sp[k];
+    for (int k = lane; k < E.na; k += 64) row[ld_at(E.act_slot, (unsigned)k)] = sp[k];
     wave_fence();
     RSTAMP(4);
     double* const out = io.obs + bw * E.nobs;
@@ -2325,7 +2338,7 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
 #pragma unroll
       for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; w[u] = e0 == lane ? ow[u] : ld_at(R.oe_src, (unsigned)(e < R.n_oel ? e : R.n_oel - 1)); }
 #pragma unroll
-      for (int u = 0; u < UC; ++u) { const int kind = w[u] >> 28, idx = w[u] & 0x0FFFFFFF; v[u] = kind == 1 ? NaN : (kind == 0 ? row[idx] : sp[idx]); }
+      for (int u = 0; u < UC; ++u) v[u] = w[u] < 0 ? NaN : row[w[u]];        // (set-points live behind the row: sp = row + nxe)
 #pragma unroll
       for (int u = 0; u < UC; ++u) { const int e = e0 + 64 * u; if (e < R.n_oel) out[e] = v[u]; }
     }
@@ -3592,10 +3605,13 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
   R.skip_template = !R.has_mode && std::all_of(covered.begin(), covered.end(), [](char c) { return c != 0; });
   // ---- observation elements ---------------------------------------------------------------------------------------
   {
-    std::vector<int32_t> oe((size_t)env->de.nobs, 1 << 28);
+    std::vector<int32_t> oe((size_t)env->de.nobs, -1);
+    const int nxe = (R.nx + 1) & ~1;
     for (size_t sg = 0; sg < env->h_oseg[0].size(); ++sg)
-      for (int j = 0; j < env->h_oseg[3][sg]; ++j)
-        oe[(size_t)env->h_oseg[2][sg] + j] = (env->h_oseg[0][sg] << 28) | ((env->h_oseg[1][sg] + j) & 0x0FFFFFFF);
+      for (int j = 0; j < env->h_oseg[3][sg]; ++j) {
+        const int kind = env->h_oseg[0][sg], idx = env->h_oseg[1][sg] + j;      // 0 row, 1 result entry, 2 action set-point
+        oe[(size_t)env->h_oseg[2][sg] + j] = kind == 0 ? idx : (kind == 2 ? nxe + idx : -1);
+      }
     R.n_oel = (int)oe.size();
     if (rc == OPFX_OK) rc = A.put(oe, &R.oe_src);
   }
