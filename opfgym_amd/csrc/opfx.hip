@@ -2882,6 +2882,7 @@ struct opfx_ctx {
 
 struct opfx_env {
   int reset_team = 1;                  // wavefronts (= rows) per workgroup of the reset kernel (opfx_env_set_reset)
+  int reset_per_cu[2] = {0, 0};        // resident workgroups per CU of the plain / full reset kernel (cached)
   opfx_ctx* ctx = nullptr;
   DevEnv de{};
   const DevEnv* d_de = nullptr;
@@ -3556,6 +3557,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
     // chunk i with chunk i (the later op starts where the earlier one's range starts) then stays inside one wavefront and
     // its stage needs no workgroup barrier.
     const int team = env->reset_team = reset_team(env);
+    env->reset_per_cu[0] = env->reset_per_cu[1] = 0;
     R.st_barrier = 1u;                                     // (stage 0 follows the profile pass: always)
     for (int k = 0; k < n_ops; ++k) {
       const int rk = reads_row(d->op_code[k]) ? d->op_n[k] : 0;
@@ -3638,19 +3640,18 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
             env->ctx->dp.stamps};
   const int wpb = env->reset_team;
   const size_t lds = wpb * row_bytes + 2 * wpb * sizeof(int32_t);       // rows; time steps and data sources of the rows
+  const bool full = io->interp != nullptr || io->noise != nullptr || (io->mode != nullptr && env->dr.has_mode);
   auto launch = [&](auto kernel) -> int {
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // as many workgroups as are resident at once (LDS / registers); each walks its share of the batch
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, lds));
-    static const int mult = getenv("OPFX_RESET_GRID_MULT") ? atoi(getenv("OPFX_RESET_GRID_MULT")) : 1;
-    const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * std::max(per_cu, 1) * mult);
+    int& per_cu = env->reset_per_cu[full ? 1 : 0];
+    if (per_cu <= 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, lds));
+    const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * std::max(per_cu, 1));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
                        (long long)B, row_doubles);
     return OPFX_OK;
   };
-  const bool full = io->interp != nullptr || io->noise != nullptr || (io->mode != nullptr && env->dr.has_mode);
   const int lrc = full ? (wpb == 4 ? launch(k_reset<4, true>) : (wpb == 2 ? launch(k_reset<2, true>) : launch(k_reset<1, true>)))
                        : (wpb == 4 ? launch(k_reset<4, false>) : (wpb == 2 ? launch(k_reset<2, false>) : launch(k_reset<1, false>)));
   if (lrc != OPFX_OK) return lrc;
