@@ -78,6 +78,7 @@ struct DevPlan {
   long long blk_mem_stride;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
+  int* queue;                // work queue of the step kernel: instances handed out beyond the first one per workgroup
 };
 
 struct DevEnv {
@@ -123,6 +124,7 @@ struct SolveIO {
   unsigned char* converged;
   int* iterations;
   double* min_pivot;
+  int queued;                // as StepIO::queued
 };
 
 struct StepIO {
@@ -137,6 +139,7 @@ struct StepIO {
   int* total_iterations;
   double* min_pivot;
   int mode;
+  int queued;                // instances beyond a workgroup's first come from the context's work queue (many per workgroup)
 };
 
 struct Opts {
@@ -1666,6 +1669,8 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   }
 }
 
+// accumulator doubles of the env kernels: five per constraint group (at least 8) + two for the work queue's hand-over
+__host__ __device__ constexpr int env_nacc(int nc) { return (5 * nc > 8 ? 5 * nc : 8) + 2; }
 template <int V2, bool MEM = false>
 __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double* base, int nacc, int nmod) {
   Lds L;
@@ -1703,6 +1708,19 @@ __device__ __forceinline__ Lds carve(const DevPlan& P, int na, int nres, double*
   return L;
 }
 
+// The next instance of a workgroup of the solve / step kernels: gridDim.x + the queue value thread 0 fetched after the solve
+// (handed to the other wavefronts of a team through LDS), or the fixed stride; doubles as the end-of-instance barrier.
+template <int NW>
+__device__ __forceinline__ long long next_instance(double* slot, long long b, bool queued, int nxt_v) {
+  if (!queued) { blk_sync<NW>(); return b + gridDim.x; }
+  int* const queue_slot = reinterpret_cast<int*>(slot);
+  if (threadIdx.x == 0) *queue_slot = nxt_v;
+  blk_sync<NW>();                                     // (all wavefronts are through with the instance; the value is there)
+  const long long n = (long long)gridDim.x + __builtin_amdgcn_readfirstlane(*queue_slot);
+  blk_sync<NW>();                                     // (read by everyone before thread 0 writes the next one)
+  return n;
+}
+
 // ---------------------------------------------------------------------------
 // pure power flow kernel (opfx_solve)
 // ---------------------------------------------------------------------------
@@ -1723,7 +1741,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     for (int i = threadIdx.x; i < P.tail_n; i += blockDim.x) L.tl[i] = P.tail_ids[i];
     blk_sync<NW>();
   }
-  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+  for (long long b = blockIdx.x; b < B;) {
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
         L.psp[i] = io.p_inj[b * P.nb + i];
@@ -1742,6 +1760,8 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     double min_piv = V2 ? 1.0 : __builtin_nan("");
     const bool conv = solve_instance<V2, NW, DC, MEM>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
     blk_sync<NW>();
+    int nxt_v = 0;                            // (work queue, see k_step)
+    if (io.queued && threadIdx.x == 0) nxt_v = __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave == 0) {
       double* R = L.stage;
       compute_results<V2>(P, L, lane, out_br, n_mod, io.qg_min, io.qg_max, R, false, io.va != nullptr);
@@ -1762,7 +1782,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
         if (io.min_pivot) io.min_pivot[b] = min_piv;
       }
     }
-    blk_sync<NW>();
+    b = next_instance<NW>(L.acc + 6, b, io.queued != 0, nxt_v);
   }
 }
 
@@ -2413,7 +2433,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Lds L = carve<V2, MEM>(P, E.na, E.nblk_d, smem, 5 * E.nc > 8 ? 5 * E.nc : 8, E.max_mod);
+  const Lds L = carve<V2, MEM>(P, E.na, E.nblk_d, smem, env_nacc(E.nc), E.max_mod);
   const int nb = P.nb;
   const double NaN = __builtin_nan("");
   double* const xs = L.rhs;                  // staged table row: [rhs | LU blocks] are free outside the solve
@@ -2423,7 +2443,16 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     blk_sync<NW>();
   }
   OPFX_STAMP_INIT();
-  for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+  // With many instances per workgroup (opfx_step decides: eight or more) the instances beyond a workgroup's first come
+  // from a QUEUE (an atomic counter in the context): instances differ in their Newton iteration count, and with a fixed
+  // share per workgroup the launch ends with the unluckiest one (65 536 instances of config 4: 34.5 mean instance times
+  // on the slowest of 2 048 wavefronts against a mean load of 32.0; a queue brings that to 32.6).  The next index is
+  // fetched after the solve, so that the round trip hides behind the instance's epilogue — not earlier: a claim made an
+  // instance ahead is a static assignment again (measured at four instances per wavefront: +12 %).  opfx_step zeroes the
+  // counter in front of such a launch (launches on one context are serialised by the caller).  With few
+  // instances per workgroup a queue cannot help (four jobs per worker: the greedy makespan equals the static one) and
+  // the shares stay fixed.
+  for (long long b = blockIdx.x; b < B;) {
     double* xr = io.x + b * E.nx;
     const bool apply = io.mode != 1 && io.mode != 3;
     OPFX_STAMP(15);
@@ -2514,7 +2543,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     if (io.mode == 2 || io.mode == 3) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
       if (tid == 0 && io.mean_correction) io.mean_correction[b] = corr;
-      blk_sync<NW>();
+      b = next_instance<NW>(L.acc + env_nacc(E.nc) - 2, b, io.queued != 0, io.queued && tid == 0 ? __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
       continue;
     }
     OPFX_STAMP(18);
@@ -2771,6 +2800,8 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       blk_sync<NW>();
     }
     OPFX_STAMP(9);
+    int nxt_v = 0;                            // (the queue's answer arrives while the reward and the flags are written)
+    if (io.queued && tid == 0) nxt_v = __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- reward (opf_env.py:515-530, reward.py:61-98) --------------------------
     if (wave == 0) {
     if (!conv0) {
@@ -2839,7 +2870,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       if (io.min_pivot) io.min_pivot[b] = min_piv;
     }
     }
-    blk_sync<NW>();
+    b = next_instance<NW>(L.acc + env_nacc(E.nc) - 2, b, io.queued != 0, nxt_v);
   }
 }
 
@@ -2928,6 +2959,14 @@ size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
   if (const char* ov = getenv("OPFX_PACKED")) use_packed = atoi(ov) != 0 && packed <= 160 * 1024;     // developer probe
   *n_full_out = use_packed ? p.n_full : p.n_blk;
   return use_packed ? packed : full;
+}
+
+// Instances from the context's work queue instead of fixed shares: with eight or more instances per workgroup
+// (measured: −5.3 % at 32 per wavefront, −3.5 % at 16 and −3.4 % at 8 per team of four, +2.8 % at 4 per wavefront;
+// profiles/r03_ab_queue.txt).  OPFX_QUEUE=0|1 forces the choice (A/B runs).
+int use_queue(long long B, int grid) {
+  static const char* force = getenv("OPFX_QUEUE");
+  return force ? atoi(force) != 0 : B >= 8LL * grid;
 }
 
 int pick_team(size_t lds, bool v2) {
@@ -3052,6 +3091,10 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
     if (hipMalloc(&pq, (size_t)c->n_cu * 16 * 2 * nbe * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(P/Q scratch) failed"); return OPFX_ERR_HIP; }
     A.ptrs.push_back(pq);
     d.pq = static_cast<double*>(pq);
+    void* qu = nullptr;
+    if (hipMalloc(&qu, 2 * sizeof(int)) != hipSuccess || hipMemset(qu, 0, 2 * sizeof(int)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(work queue) failed"); return OPFX_ERR_HIP; }
+    A.ptrs.push_back(qu);
+    d.queue = static_cast<int*>(qu);
   }
   {
     std::vector<double> vr0(p->nb), vi0(p->nb);
@@ -3096,7 +3139,8 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     if (rc != OPFX_OK) return rc;
     dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
-    SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot};
+    SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
+    if ((io.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
     HIP_TRY(hipGetLastError());
     return OPFX_OK;
@@ -3118,7 +3162,8 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     ctx->solve_per_cu_dc = per_cu_dc;
     if (rc != OPFX_OK) return rc;
   }
-  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot};
+  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
+  if ((io.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
@@ -3353,11 +3398,11 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
   }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = choose_block_storage(p, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod, nf); }, &e->n_full);
+  e->lds_bytes = choose_block_storage(p, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, env_nacc(d->nc), E.max_mod, nf); }, &e->n_full);
   if (wants_mem(e->lds_bytes, ctx->v2)) {
     e->mem = true;
     e->n_full = p.n_blk;
-    e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, true, 5 * d->nc > 8 ? 5 * d->nc : 8, E.max_mod, e->n_full, true);
+    e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, true, env_nacc(d->nc), E.max_mod, e->n_full, true);
   }
   *out = e;
   return OPFX_OK;
@@ -3405,6 +3450,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
+  if ((s.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(env->ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
