@@ -38,7 +38,9 @@
  *     NULL = default stream) and is asynchronous; non-convergence is DATA
  *     (converged[B], iterations[B], max_mismatch[B]), never an error code.
  *   - one context per device; calls on one context are serialised by the
- *     caller; no hidden global state.
+ *     caller — in stream order too: launches of one context must not overlap
+ *     on the device (they share its scratch rows and its work queue); no
+ *     hidden global state.
  */
 #ifndef OPFX_H
 #define OPFX_H
