@@ -2965,7 +2965,7 @@ size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
 // (measured: −5.3 % at 32 per wavefront, −3.5 % at 16 and −3.4 % at 8 per team of four, +2.8 % at 4 per wavefront;
 // profiles/r03_ab_queue.txt).  OPFX_QUEUE=0|1 forces the choice (A/B runs).
 int use_queue(long long B, int grid) {
-  static const char* force = getenv("OPFX_QUEUE");
+  const char* force = getenv("OPFX_QUEUE");
   return force ? atoi(force) != 0 : B >= 8LL * grid;
 }
 

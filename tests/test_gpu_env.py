@@ -92,6 +92,29 @@ def test_env_matches_reference_golden(name):
         assert not _np(info['valids']).any()
 
 
+@pytest.mark.parametrize('name,B', [('vc_mv_urban', 8192), ('eco_hv_small', 6000)])
+def test_work_queue_and_fixed_shares_give_the_same_rows(name, B, monkeypatch):
+    """Batches of eight or more instances per workgroup are handed out through a work queue (opfx.hip: use_queue), smaller
+    ones in fixed shares.  Which workgroup solves an instance must not matter: the same reset and actions under both
+    policies (OPFX_QUEUE forces one) give the same rows — bit for bit on the single-wavefront kernel, whose arithmetic
+    does not depend on the workgroup."""
+    import torch
+    outs = []
+    for q in ('0', '1'):
+        monkeypatch.setenv('OPFX_QUEUE', q)
+        env = product_env(name, batch_size=B)
+        rng = np.random.default_rng(3)
+        env.reset(seed=11)
+        a = rng.random((B, env.n_actions))
+        obs, rew, term, trunc, info = env.step(a)
+        torch.cuda.synchronize()
+        outs.append((_np(obs).copy(), _np(rew).copy(), _np(info['iterations']).copy(), _np(info['converged']).copy()))
+        env.close()
+    (o0, r0, i0, c0), (o1, r1, i1, c1) = outs
+    assert c0.all() and np.array_equal(c0, c1) and np.array_equal(i0, i1)
+    assert np.array_equal(r0, r1, equal_nan=True) and np.array_equal(o0, o1, equal_nan=True)
+
+
 @pytest.mark.parametrize('team', [1, 2])
 @pytest.mark.parametrize('name', ['vc_mv_small', 'vc_mixed_simbench', 'vc_mixed_uniform', 'vc_noisy', 'vc_normal_noise', 'vc_interpolate', 'qm_mv_small', 'eco_hv_small', 'loadshed_mv_small'])
 def test_reset_kernel_teams_of_one_and_two_wavefronts(name, team, monkeypatch):
