@@ -277,22 +277,34 @@ struct Lds {
 };
 // Off-diagonal Jacobian blocks of PQ rows that no update targets keep the shape [[a, b], [-b, a]]
 // (dS/dtheta = -j c, dS/dln|V| = c): the plan numbers them last and only (a, b) is stored.
-__device__ __forceinline__ int blk_c(const Lds& L, int id, int c) { return id + (c == 0 ? 0 : c == 1 ? L.bs : c == 2 ? L.o2 : L.o3); }
+// Where the four values of block `id` live in L.blk (element indices).  Default: one array per component (above).
+// -DOPFX_PAIR_LAYOUT (probe): the rows of a block as 16-byte pairs — (a11, a12) at 2 id, (a21, a22) at o2 + 2 id — so
+// that a row is ONE address and one two-value LDS access.
+#ifdef OPFX_PAIR_LAYOUT
+__device__ __forceinline__ int bx11(const Lds&, int id) { return 2 * id; }
+__device__ __forceinline__ int bx12(const Lds&, int id) { return 2 * id + 1; }
+__device__ __forceinline__ int bx21(const Lds& L, int id) { return L.o2 + 2 * id; }
+__device__ __forceinline__ int bx22(const Lds& L, int id) { return L.o2 + 2 * id + 1; }
+#else
+__device__ __forceinline__ int bx11(const Lds&, int id) { return id; }
+__device__ __forceinline__ int bx12(const Lds& L, int id) { return L.bs + id; }
+__device__ __forceinline__ int bx21(const Lds& L, int id) { return L.o2 + id; }
+__device__ __forceinline__ int bx22(const Lds& L, int id) { return L.o3 + id; }
+#endif
+__device__ __forceinline__ int blk_c(const Lds& L, int id, int c) { return c == 0 ? bx11(L, id) : c == 1 ? bx12(L, id) : c == 2 ? bx21(L, id) : bx22(L, id); }
 template <bool PK>
 __device__ __forceinline__ Blk ld_blk2(const Lds& L, int id) {
-  const double* p = L.blk + id;
-  Blk b{p[0], p[L.bs], 0.0, 0.0};
-  if (!PK || id < L.nfull) { b.a21 = p[L.o2]; b.a22 = p[L.o3]; }
+  Blk b{L.blk[bx11(L, id)], L.blk[bx12(L, id)], 0.0, 0.0};
+  if (!PK || id < L.nfull) { b.a21 = L.blk[bx21(L, id)]; b.a22 = L.blk[bx22(L, id)]; }
   else { b.a21 = -b.a12; b.a22 = b.a11; }
   return b;
 }
 // second row of a block of a PV bus row (always a four-value block): the Q equation is replaced by d|V| = 0
-__device__ __forceinline__ void blk_zero_row2(const Lds& L, int id) { L.blk[id + L.o2] = 0.0; L.blk[id + L.o3] = 0.0; }
+__device__ __forceinline__ void blk_zero_row2(const Lds& L, int id) { L.blk[bx21(L, id)] = 0.0; L.blk[bx22(L, id)] = 0.0; }
 template <bool PK>
 __device__ __forceinline__ void st_blk2(const Lds& L, int id, const Blk& b) {
-  double* p = L.blk + id;
-  p[0] = b.a11; p[L.bs] = b.a12;
-  if (!PK || id < L.nfull) { p[L.o2] = b.a21; p[L.o3] = b.a22; }
+  L.blk[bx11(L, id)] = b.a11; L.blk[bx12(L, id)] = b.a12;
+  if (!PK || id < L.nfull) { L.blk[bx21(L, id)] = b.a21; L.blk[bx22(L, id)] = b.a22; }
 }
 // Newton-Raphson on the instance in LDS.  Returns converged; *iters, *nrm out.
 __device__ bool newton(const DevPlan& P, const Lds& L, const Opts& o, int lane,
@@ -524,9 +536,8 @@ __device__ __forceinline__ void mem_fence() {
 }
 template <bool PK>
 __device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a11, double& a12, double& x21, double& x22) {
-  const double* p = L.blk + id;
   const unsigned idc = (!PK || id < (unsigned)L.nfull) ? id : 0u;
-  a11 = p[0]; a12 = p[L.bs]; x21 = L.blk[L.o2 + idc]; x22 = L.blk[L.o3 + idc];
+  a11 = L.blk[bx11(L, id)]; a12 = L.blk[bx12(L, id)]; x21 = L.blk[bx21(L, idc)]; x22 = L.blk[bx22(L, idc)];
 }
 // The twelve values an item reads.  Loading (item_load) and using them (item_apply) are separate steps so
 // that the reads of the NEXT round can be in flight while this round computes, whenever the plan marks the two
@@ -546,10 +557,10 @@ __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   // third operand C: A_kj, or the column (y_k ; .) of the right-hand side
   const unsigned kjb = rhs_t ? 0u : kj;                                  // (any valid block for the unused reads)
   const unsigned kjc = (!PK || kjb < (unsigned)L.nfull) ? kjb : 0u;
-  const double* c1p = rhs_t ? (L.rhs + kj) : (L.blk + kj);
-  const double* c3p = rhs_t ? (L.rq + kj) : (L.blk + L.o2 + kjc);
+  const double* c1p = rhs_t ? (L.rhs + kj) : (L.blk + bx11(L, kj));
+  const double* c3p = rhs_t ? (L.rq + kj) : (L.blk + bx21(L, kjc));
   r.c11 = *c1p; r.c21 = *c3p;
-  r.c12 = L.blk[L.bs + kjb]; r.c22 = L.blk[L.o3 + kjc];
+  r.c12 = L.blk[bx12(L, kjb)]; r.c22 = L.blk[bx22(L, kjc)];
   // rider (plan.cpp): the item's multiplier also takes y_k to y_i — the forward substitution of the pair (i, k)
   r.y1 = 0.0; r.y2 = 0.0;
   if (RIDERS && (d.z >> 16) != NONE) { const unsigned k = d.z >> 16; r.y1 = L.rhs[k]; r.y2 = L.rq[k]; }
@@ -577,13 +588,13 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
   const double m21 = (bi.a21 * bk.a22 - bi.a22 * bk.a21) * nrdet;
   const double m22 = (bi.a22 * bk.a11 - bi.a21 * bk.a12) * nrdet;
   const unsigned ti = tb & 0x7FFF;
-  double* t1p = rhs_t ? (L.rhs + ti) : (L.blk + tb);
-  double* t3p = rhs_t ? (L.rq + ti) : (L.blk + L.o2 + tb);
+  double* t1p = rhs_t ? (L.rhs + ti) : (L.blk + bx11(L, tb));
+  double* t3p = rhs_t ? (L.rq + ti) : (L.blk + bx21(L, tb));
   lds_add(t1p, m11 * c11 + m12 * c21);
   lds_add(t3p, m21 * c11 + m22 * c21);
   if (!rhs_t) {
-    lds_add(L.blk + L.bs + tb, m11 * c12 + m12 * c22);
-    lds_add(L.blk + L.o3 + tb, m21 * c12 + m22 * c22);
+    lds_add(L.blk + bx12(L, tb), m11 * c12 + m12 * c22);
+    lds_add(L.blk + bx22(L, tb), m21 * c12 + m22 * c22);
   }
   if (RIDERS && (d.z >> 16) != NONE) {
     const unsigned i = d.z & 0xFFFF;
@@ -649,8 +660,8 @@ __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, doub
     if (s < 1) return t;                                   // (compile-time after unrolling)
     const unsigned id = (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
     t.live = id != 0xFFFFu;                                // (a tail that is not completely filled in)
-    const double* p = L.blk + (t.live ? id : 0u);
-    t.u11 = p[0]; t.u12 = p[L.bs]; t.u21 = p[L.o2]; t.u22 = p[L.o3];
+    const int ib = t.live ? (int)id : 0;
+    t.u11 = L.blk[bx11(L, ib)]; t.u12 = L.blk[bx12(L, ib)]; t.u21 = L.blk[bx21(L, ib)]; t.u22 = L.blk[bx22(L, ib)];
     return t;
   };
   auto apply = [&](const TailBlk& t, int s) {
@@ -687,8 +698,8 @@ __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, doub
 __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsigned tail) {
   const bool mine = lane < m;
   const int bus = mine ? (int)(tail & 0xFFFFu) : 0;
-  const double* p = L.blk + (mine ? tail >> 16 : 0u);  // (diagonal blocks always hold four values)
-  const double a11 = p[0], a12 = p[L.bs], a21 = p[L.o2], a22 = p[L.o3];
+  const int ib = mine ? (int)(tail >> 16) : 0;         // (diagonal blocks always hold four values)
+  const double a11 = L.blk[bx11(L, ib)], a12 = L.blk[bx12(L, ib)], a21 = L.blk[bx21(L, ib)], a22 = L.blk[bx22(L, ib)];
   double y0 = L.rhs[bus], y1 = L.rq[bus];
   const double rdet = mine ? fast_rcp(a11 * a22 - a12 * a21) : 0.0;
   const double i11 = a22 * rdet, i12 = -a12 * rdet, i21 = -a21 * rdet, i22 = a11 * rdet;
@@ -733,8 +744,8 @@ __device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const ui
 // static pivoting inside the blocks has broken down, SURVEY §7 hard part 2).
 __device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, double& dvm, double& piv) {
   const int db = L.dg[i];
-  const double* p = L.blk + db;                       // (diagonal blocks always hold four values)
-  const double a11 = p[0], a12 = p[L.bs], a21 = p[L.o2], a22 = p[L.o3];
+  // (diagonal blocks always hold four values)
+  const double a11 = L.blk[bx11(L, db)], a12 = L.blk[bx12(L, db)], a21 = L.blk[bx21(L, db)], a22 = L.blk[bx22(L, db)];
   const double y1 = L.rhs[i], y2 = L.rq[i];
   const double p1 = a11 * a22, p2 = a12 * a21;
   const double det = p1 - p2;
@@ -889,9 +900,8 @@ __device__ __forceinline__ void mods_inline(const Lds& L, int n_mod, int i, int 
     dyr += yii_g * v2; dyi -= yii_b * v2;                                    // conj(dY_ii)|V_i|^2
     sr += dcr; si += dci;
     if (ob >= 0 && t != BT_REF) {          // this lane stored the block earlier in this phase: plain read-modify-write
-      double* pa = L.blk + ob;
-      pa[0] += dci; pa[L.bs] += dcr;
-      if (t != BT_PV && ob < L.nfull) { pa[L.o2] -= dcr; pa[L.o3] += dci; }
+      L.blk[bx11(L, ob)] += dci; L.blk[bx12(L, ob)] += dcr;
+      if (t != BT_PV && ob < L.nfull) { L.blk[bx21(L, ob)] -= dcr; L.blk[bx22(L, ob)] += dci; }
     }
   }
 }
