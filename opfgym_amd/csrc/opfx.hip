@@ -2462,7 +2462,18 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   // counter in front of such a launch (launches on one context are serialised by the caller).  With few
   // instances per workgroup a queue cannot help (four jobs per worker: the greedy makespan equals the static one) and
   // the shares stay fixed.
+#ifdef OPFX_ENABLE_STAMPS
+  const double t_start__ = (double)wall_clock64();
+#endif
+  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD)
   for (long long b = blockIdx.x; b < B;) {
+    if (NW == 1 && io.mode >= 0) {
+      // The SIMD's arbiter serves the OLDER of two ready wavefronts first: of the two single-wave instances that share a
+      // SIMD one ran 6 % ahead of the other through the whole launch (per-workgroup busy times, scripts/probe_finish_times.py)
+      // and the launch ended with the slower ones.  The two take the higher user priority in turns, instance by instance.
+      if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      ++turn;
+    }
     double* xr = io.x + b * E.nx;
     const bool apply = io.mode != 1 && io.mode != 3;
     OPFX_STAMP(15);
@@ -2881,6 +2892,13 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     }
     }
     b = next_instance<NW>(L.acc + env_nacc(E.nc) - 2, b, io.queued != 0, nxt_v);
+#ifdef OPFX_ENABLE_STAMPS
+    if (P.stamps && tid == 0 && E.n_cont == 0) {      // developer probe: when each workgroup finished what (its warm row is free)
+      double* w = P.warm + (size_t)blockIdx.x * 2 * nb;
+      if (w[1] == 0.0) { w[3] = t_start__; w[4] = (double)__builtin_amdgcn_s_getreg(63492); w[5] = (double)__builtin_amdgcn_s_getreg(63508); }   // HW_ID, XCC_ID
+      w[0] = (double)wall_clock64(); w[1] += 1.0; w[2] += (double)iters0;
+    }
+#endif
   }
 }
 
@@ -3712,6 +3730,21 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
                        : (wpb == 4 ? launch(k_reset<4, false>) : (wpb == 2 ? launch(k_reset<2, false>) : launch(k_reset<1, false>)));
   if (lrc != OPFX_OK) return lrc;
   HIP_TRY(hipGetLastError());
+  return OPFX_OK;
+}
+
+// developer probe (stamps build, not part of the ABI header): per workgroup of the last step launches — wall clock
+// (100 MHz) at its last instance, instances and Newton iterations it processed since the last read, wall clock at its
+// start, HW_ID and XCC_ID registers (six doubles per workgroup); clears them
+extern "C" int opfx_debug_read_finish(opfx_ctx* ctx, double* out3, int n_wg) {
+  if (!ctx || !ctx->dp.warm) return OPFX_ERR_INVALID;
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t stride = 2 * (size_t)ctx->plan.nb;
+  std::vector<double> row(3);
+  for (int g = 0; g < n_wg; ++g) {
+    HIP_TRY(hipMemcpy(out3 + 6 * g, ctx->dp.warm + g * stride, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->dp.warm + g * stride, 0, 6 * sizeof(double)));
+  }
   return OPFX_OK;
 }
 
