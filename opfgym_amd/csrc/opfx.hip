@@ -1751,7 +1751,9 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     for (int i = threadIdx.x; i < P.tail_n; i += blockDim.x) L.tl[i] = P.tail_ids[i];
     blk_sync<NW>();
   }
+  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD; see k_step)
   for (long long b = blockIdx.x; b < B;) {
+    if (NW == 1) { if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); ++turn; }
     if (wave == 0) {
       for (int i = lane; i < P.nb; i += WAVE) {
         L.psp[i] = io.p_inj[b * P.nb + i];
@@ -2467,7 +2469,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
 #endif
   int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD)
   for (long long b = blockIdx.x; b < B;) {
-    if (NW == 1 && io.mode >= 0) {
+    if (NW == 1) {
       // The SIMD's arbiter serves the OLDER of two ready wavefronts first: of the two single-wave instances that share a
       // SIMD one ran 6 % ahead of the other through the whole launch (per-workgroup busy times, scripts/probe_finish_times.py)
       // and the launch ended with the slower ones.  The two take the higher user priority in turns, instance by instance.
