@@ -2474,7 +2474,15 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
   const double t_start__ = (double)wall_clock64();
 #endif
   int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD)
+  if (NW > 1) {       // the two teams of a CU in turns as well (the slot parity of wavefront 0 stands for its team):
+                      // -3.0 % on config 3 with fixed shares, nothing on top of the work queue
+    if (tid == 0) L.acc[0] = (double)(__builtin_amdgcn_s_getreg(63492) & 1u);
+    __syncthreads();
+    turn = (int)L.acc[0];
+    __syncthreads();
+  }
   for (long long b = blockIdx.x; b < B;) {
+    if (NW > 1) { if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); ++turn; }
     if (NW == 1) {
       // The SIMD's arbiter serves the OLDER of two ready wavefronts first: of the two single-wave instances that share a
       // SIMD one ran 6 % ahead of the other through the whole launch (per-workgroup busy times, scripts/probe_finish_times.py)
