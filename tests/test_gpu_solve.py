@@ -43,6 +43,27 @@ def test_solve_matches_oracle(code, B):
     assert (out['max_mismatch'] < 1e-8).all()
 
 
+@pytest.mark.parametrize('code,B', [('1-HV-mixed--0-sw', 48), ('1-HV-urban--0-sw', 32)])
+def test_the_answer_does_not_depend_on_the_elimination_order(code, B, monkeypatch):
+    """`opfx_plan_create` picks one of 16 elimination orders for the grids of the wave-team kernels (plan.cpp).  Another
+    order means other block numbers, levels and rounding — and the same power flow: the first order (OPFX_PLAN_SEARCH=0),
+    the searched one and a pinned third one agree to rounding, with the same iteration counts."""
+    runs = []
+    for env in ({'OPFX_PLAN_SEARCH': '0'}, {}, {'OPFX_PLAN_SEED': '7', 'OPFX_PLAN_DCAP_SLACK': '3'}):
+        for k in ('OPFX_PLAN_SEARCH', 'OPFX_PLAN_SEED', 'OPFX_PLAN_DCAP_SLACK'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs.append(_run(code, B, seed=5)[4])
+    a = runs[0]
+    assert a['converged'].astype(bool).all()
+    for b in runs[1:]:
+        assert b['converged'].astype(bool).all()
+        assert np.abs(a['vm'] - b['vm']).max() < 1e-12 and np.abs(np.angle(np.exp(1j * (a['va'] - b['va'])))).max() < 1e-12
+        assert np.abs(a['loading'] - b['loading']).max() < 1e-8
+        assert (a['iterations'] == b['iterations']).all()
+
+
 def test_full_batch_properties():
     """B = 8192 (BASELINE config 2 size): every instance converges and the
     solution satisfies the power-flow equations — checked for all rows through
