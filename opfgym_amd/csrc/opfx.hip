@@ -52,6 +52,10 @@ constexpr int MODE_ENV = 1;
 // ---------------------------------------------------------------------------
 // device-resident plan
 // ---------------------------------------------------------------------------
+// s_getreg operands (size - 1) << 11 | offset << 6 | register: all 32 bits of HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8],
+// shader array [12], shader engine [15:13]) and of XCC_ID
+constexpr int GETREG_HW_ID = (31 << 11) | 4, GETREG_XCC_ID = (31 << 11) | 20;
+
 struct DevPlan {
   int nb, nbr, nref, nblk, nlev, nfill, npv;
   int nfull;                 // blocks [0, nfull) are stored with four values (per launch: choose_block_storage)
@@ -1751,7 +1755,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     for (int i = threadIdx.x; i < P.tail_n; i += blockDim.x) L.tl[i] = P.tail_ids[i];
     blk_sync<NW>();
   }
-  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD; see k_step)
+  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(GETREG_HW_ID) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD; see k_step)
   for (long long b = blockIdx.x; b < B;) {
     if (NW == 1) { if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); ++turn; }
     if (wave == 0) {
@@ -2393,7 +2397,7 @@ __global__ __launch_bounds__(64 * NR, NR == 1 ? 2 : 4) void k_reset(DevReset R, 
   // (the four wavefronts that share a SIMD — of four workgroups — rotate through the user priority levels, one step per
   //  set of rows: the arbiter's oldest-first rule otherwise lets the workgroups finish in the order of their age and the
   //  launch end with the youngest; 16 384 rows 57.9 -> 54.4 us, 8 192: 33.3 -> 32.9; see k_step)
-  int turn = (int)(__builtin_amdgcn_s_getreg(63492) & 3u);     // HW_ID: the wave slot on its SIMD
+  int turn = (int)(__builtin_amdgcn_s_getreg(GETREG_HW_ID) & 3u);     // HW_ID: the wave slot on its SIMD
   for (long long b0 = (long long)blockIdx.x * NR; b0 < B; b0 += (long long)gridDim.x * NR) {
     switch (turn++ & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
                           case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); }
@@ -2473,10 +2477,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
 #ifdef OPFX_ENABLE_STAMPS
   const double t_start__ = (double)wall_clock64();
 #endif
-  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(63492) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD)
+  int turn = NW == 1 ? (int)(__builtin_amdgcn_s_getreg(GETREG_HW_ID) & 1u) : 0;     // (HW_ID: the wave slot on its SIMD)
   if (NW > 1) {       // the two teams of a CU in turns as well (the slot parity of wavefront 0 stands for its team):
                       // -3.0 % on config 3 with fixed shares, nothing on top of the work queue
-    if (tid == 0) L.acc[0] = (double)(__builtin_amdgcn_s_getreg(63492) & 1u);
+    if (tid == 0) L.acc[0] = (double)(__builtin_amdgcn_s_getreg(GETREG_HW_ID) & 1u);
     __syncthreads();
     turn = (int)L.acc[0];
     __syncthreads();
@@ -2911,7 +2915,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
 #ifdef OPFX_ENABLE_STAMPS
     if (P.stamps && tid == 0 && E.n_cont == 0) {      // developer probe: when each workgroup finished what (its warm row is free)
       double* w = P.warm + (size_t)blockIdx.x * 2 * nb;
-      if (w[1] == 0.0) { w[3] = t_start__; w[4] = (double)__builtin_amdgcn_s_getreg(63492); w[5] = (double)__builtin_amdgcn_s_getreg(63508); }   // HW_ID, XCC_ID
+      if (w[1] == 0.0) { w[3] = t_start__; w[4] = (double)__builtin_amdgcn_s_getreg(GETREG_HW_ID); w[5] = (double)__builtin_amdgcn_s_getreg(GETREG_XCC_ID); }   // HW_ID, XCC_ID
       w[0] = (double)wall_clock64(); w[1] += 1.0; w[2] += (double)iters0;
     }
 #endif
