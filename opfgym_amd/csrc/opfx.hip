@@ -3009,12 +3009,13 @@ size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
   return use_packed ? packed : full;
 }
 
-// Instances from the context's work queue instead of fixed shares: with eight or more instances per workgroup
-// (measured: −5.3 % at 32 per wavefront, −3.5 % at 16 and −3.4 % at 8 per team of four, +2.8 % at 4 per wavefront;
-// profiles/r03_ab_queue.txt).  OPFX_QUEUE=0|1 forces the choice (A/B runs).
-int use_queue(long long B, int grid) {
+// Instances from the context's work queue instead of fixed shares: from 12 instances per single-wave workgroup on,
+// from 8 per wave team.  Measured against fixed shares WITH the priority turns of the kernels (profiles/r03_ab_queue.txt):
+// single wave +4 % / +2 % / 0 / -1.5 % / -2.5 % / -4 % at 5 / 8 / 12 / 16 / 24 / 32 instances per wavefront; teams of four
+// -0.4 % at 8, -0.9 % at 16 per team.  OPFX_QUEUE=0|1 forces the choice (A/B runs).
+int use_queue(long long B, int grid, int team) {
   const char* force = getenv("OPFX_QUEUE");
-  return force ? atoi(force) != 0 : B >= 8LL * grid;
+  return force ? atoi(force) != 0 : B >= (team > 1 ? 8LL : 12LL) * grid;
 }
 
 int pick_team(size_t lds, bool v2) {
@@ -3188,7 +3189,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
     SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
-    if ((io.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    if ((io.queued = use_queue(B, grid, 4))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
     HIP_TRY(hipGetLastError());
     return OPFX_OK;
@@ -3211,7 +3212,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     if (rc != OPFX_OK) return rc;
   }
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
-  if ((io.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+  if ((io.queued = use_queue(B, grid, team))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
@@ -3498,7 +3499,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
-  if ((s.queued = use_queue(B, grid))) HIP_TRY(hipMemsetAsync(env->ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+  if ((s.queued = use_queue(B, grid, team))) HIP_TRY(hipMemsetAsync(env->ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
