@@ -39,21 +39,36 @@
  *     (converged[B], iterations[B], max_mismatch[B]), never an error code.
  *   - one context per device; calls on one context are serialised by the
  *     caller — in stream order too: launches of one context must not overlap
- *     on the device (they share its scratch rows and its work queue); no
- *     hidden global state.
+ *     on the device (they share its scratch rows); no hidden global state:
+ *     the library reads no environment variable (developer switches travel in
+ *     an explicit struct, include/opfx_debug.h).
+ *   - VERSIONING.  Every struct that crosses the boundary starts with
+ *     `uint32_t struct_size`, which the CALLER sets to sizeof(the struct) of the
+ *     header it was compiled against (OPFX_INIT(x) does it).  The library
+ *     refuses a size it does not know (OPFX_ERR_INVALID with text) instead of
+ *     reading past the caller's struct; new members are only ever APPENDED, and
+ *     a struct that is shorter than the library's but not shorter than the
+ *     first layout of this major.minor series is accepted with the missing
+ *     members zero (= their documented defaults).  opfx_version() reports the
+ *     library's version; bindings compare major and minor on load
+ *     (opfgym_amd/capi.py does).
  */
 #ifndef OPFX_H
 #define OPFX_H
 
 #include <stdint.h>
+#include <string.h>   /* memset (OPFX_INIT) */
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 #define OPFX_VERSION_MAJOR 0
-#define OPFX_VERSION_MINOR 1
+#define OPFX_VERSION_MINOR 2      /* 0.2: struct_size in every struct, developer switches out of the environment */
 #define OPFX_VERSION_PATCH 0
+
+/* zero a struct of this header and stamp its size: opfx_solve_opts o; OPFX_INIT(o); o.tol = 1e-8; ... */
+#define OPFX_INIT(x) do { memset(&(x), 0, sizeof(x)); (x).struct_size = (uint32_t)sizeof(x); } while (0)
 
 typedef enum opfx_status {
   OPFX_OK = 0,
@@ -70,6 +85,7 @@ enum { OPFX_PQ = 1, OPFX_PV = 2, OPFX_REF = 3 };
  * Mirrors the pypower/pandapower `ppci` the reference builds inside runpp
  * (SURVEY §8a rows P2/P3). */
 typedef struct opfx_case {
+  uint32_t struct_size;      /* = sizeof(opfx_case), see VERSIONING above    */
   int32_t nb;                /* buses                                        */
   int32_t nbr;               /* branches (lines + transformers), in service  */
   double base_mva;
@@ -94,6 +110,7 @@ typedef struct opfx_ctx opfx_ctx;     /* plan resident on one GPU            */
 typedef struct opfx_env opfx_env;     /* environment evaluator on a context  */
 
 typedef struct opfx_plan_info {
+  uint32_t struct_size;      /* set by the caller BEFORE opfx_plan_get_info: the library fills that many bytes */
   int32_t nb, nbr, nref, npv, npq;
   int32_t nnz_y;             /* Ybus block entries (incl. diagonal)          */
   int32_t nnz_j;             /* scalar Jacobian non-zeros, pypower layout    */
@@ -182,6 +199,8 @@ void opfx_version(int* major, int* minor, int* patch);
  * opfx_reset alike; the batch buffers may then be NULL. */
 enum { OPFX_INIT_FLAT = 0, OPFX_INIT_DC = 1 };
 typedef struct opfx_solve_opts {
+  uint32_t struct_size;      /* = sizeof(opfx_solve_opts)                    */
+  int32_t reserved0;         /* (alignment) 0                                */
   double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
   int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */
   int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits */
@@ -228,6 +247,7 @@ enum { OPFX_ACT_CONTINUOUS = 0, OPFX_ACT_INTEGER = 1 /* np.round */, OPFX_ACT_BO
 enum { OPFX_XRES_P = 0, OPFX_XRES_S = 1, OPFX_XRES_MAX3 = 2 };
 
 typedef struct opfx_env_desc {
+  uint32_t struct_size;      /* = sizeof(opfx_env_desc)                      */
   int32_t nx;                /* columns of the per-instance store           */
   /* bus injections: P_i = sum coef*x[slot] over p-list of bus i (p.u.) */
   const int32_t* pinj_ptr;   /* [nb+1] */
@@ -343,6 +363,8 @@ int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);
 void opfx_env_destroy(opfx_env* env);
 
 typedef struct opfx_step_io {
+  uint32_t struct_size;      /* = sizeof(opfx_step_io)                       */
+  uint32_t reserved0;        /* (alignment) 0                                */
   /* inputs */
   double* x;                 /* [B,nx] in/out: action set-points are written back */
   const double* action;      /* [B,na] in [0,1] (clipped inside, opf_env.py:429)  */
@@ -388,6 +410,7 @@ int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io,
  * table is rel[:, typ[j]] * peak[j]; per-column min/max are precomputed once
  * (defect D10 of the reference recomputes them on every reset). */
 typedef struct opfx_profile_desc {
+  uint32_t struct_size;      /* = sizeof(opfx_profile_desc): also the stride of opfx_reset_desc.tables */
   int32_t n_steps, n_types, n_cols;
   const double* rel;         /* [n_steps, n_types] row-major                 */
   const int32_t* typ;        /* [n_cols] */
@@ -420,6 +443,7 @@ enum { OPFX_OP_SET_CONST = 0, OPFX_OP_AFFINE = 1, OPFX_OP_SQRT_DIFF = 2,
        OPFX_OP_NEG = 3, OPFX_OP_UNIFORM = 4, OPFX_OP_NORMAL = 5, OPFX_OP_CLIP = 6,
        OPFX_OP_DIV = 7, OPFX_OP_NORMINV = 8, OPFX_OP_TRUNCNORM = 9 };
 typedef struct opfx_reset_desc {
+  uint32_t struct_size;      /* = sizeof(opfx_reset_desc)                    */
   int32_t n_tables;
   const opfx_profile_desc* tables;
   int32_t n_ops;
@@ -452,6 +476,8 @@ int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d);
  *       instance b is a function of (rng_seed, b, j) only — which saves the caller a launch per reset.
  * Fills x [B,nx]. */
 typedef struct opfx_reset_io {
+  uint32_t struct_size;      /* = sizeof(opfx_reset_io)                      */
+  uint32_t reserved0;        /* (alignment) 0                                */
   const int32_t* step_idx;
   const double* noise;
   const double* interp;

@@ -393,7 +393,7 @@ class BatchedOpfEnv:
         # flow first), 'auto' (pandapower's default: 'dc' when voltage angles are calculated, i.e. grids fed above 70 kV)
         assert init in ('flat', 'dc', 'auto'), init
         self.init = init
-        self.solve_opts = capi.SolveOpts(float(tolerance), int(max_iteration), int(bool(enforce_q_lims)), 0,
+        self.solve_opts = capi.SolveOpts(tolerance, max_iteration, int(bool(enforce_q_lims)), 0,
                                          int(contingency_start == 'flat'))
         self.np_random = np.random.default_rng(seed)
 
@@ -401,7 +401,8 @@ class BatchedOpfEnv:
         self.case = _case_all_branches_in(net, self.act_keys)
         self.plan = capi.Plan(self.case)
         if self.init == 'auto':
-            self.init = 'dc' if self.case.meta.get('calc_angles') else 'flat'
+            # (a case whose DC model is not finite — a zero-reactance branch — carries no B': 'auto' then stays flat)
+            self.init = 'dc' if self.case.meta.get('calc_angles') and self.plan.info['has_dc'] else 'flat'
         self.solve_opts.init = capi.INIT[self.init]
         self.store = ColumnStore(net)
         for tbl in ('load', 'sgen', 'storage'):
@@ -1013,6 +1014,7 @@ class BatchedOpfEnv:
         tabs = (capi.ProfileDesc * max(1, len(self.tables)))()
         self.n_noise = 0
         for k, t in enumerate(self.tables):
+            tabs[k].struct_size = capi.C.sizeof(capi.ProfileDesc)
             tabs[k].n_steps, tabs[k].n_types = t['rel'].shape
             tabs[k].n_cols = len(t['typ'])
             tabs[k].rel, tabs[k].typ = _keep(keep, t['rel'], 'd'), _keep(keep, t['typ'], 'i')

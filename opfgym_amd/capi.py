@@ -38,15 +38,26 @@ class OpfxError(RuntimeError):
     pass
 
 
-class CaseStruct(C.Structure):
-    _fields_ = [('nb', C.c_int32), ('nbr', C.c_int32), ('base_mva', C.c_double),
+# the version of include/opfx.h these ctypes structs were written for; lib() refuses a library of another major.minor
+ABI_VERSION = (0, 2)
+
+
+class Sized(C.Structure):
+    """A struct of include/opfx.h: first member `struct_size`, stamped on construction (opfx.h, VERSIONING)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class CaseStruct(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('nb', C.c_int32), ('nbr', C.c_int32), ('base_mva', C.c_double),
                 ('bus_type', _pi), ('vm_set', _pd), ('va_set', _pd), ('gs', _pd), ('bs', _pd),
                 ('br_f', _pi), ('br_t', _pi), ('br_y', _pd), ('br_kf', _pd), ('br_kt', _pd),
                 ('br_bdc', _pd), ('br_pfinj', _pd)]
 
 
-class PlanInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+class PlanInfo(Sized):
+    _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in (
         'nb', 'nbr', 'nref', 'npv', 'npq', 'nnz_y', 'nnz_j', 'n_blk', 'n_fill', 'n_levels',
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
         'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full',
@@ -54,20 +65,24 @@ class PlanInfo(C.Structure):
         'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width', 'has_dc')]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_size'}
 
 
-class SolveOpts(C.Structure):
-    _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32),
+class SolveOpts(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('reserved0', C.c_int32),
+                ('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32),
                 ('init', C.c_int32), ('contingency_start', C.c_int32)]
+
+    def __init__(self, tol=1e-8, max_iter=10, enforce_q_lims=0, init=0, contingency_start=0):
+        super().__init__(0, float(tol), int(max_iter), int(enforce_q_lims), int(init), int(contingency_start))
 
 
 INIT = {'flat': 0, 'dc': 1}
 
 
-class EnvDesc(C.Structure):
+class EnvDesc(Sized):
     _fields_ = [
-        ('nx', C.c_int32),
+        ('struct_size', C.c_uint32), ('nx', C.c_int32),
         ('pinj_ptr', _pi), ('pinj_slot', _pi), ('pinj_coef', _pd),
         ('qinj_ptr', _pi), ('qinj_slot', _pi), ('qinj_coef', _pd),
         ('qg_min', _pd), ('qg_max', _pd),
@@ -106,8 +121,8 @@ ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2
 XRES_P, XRES_S, XRES_MAX3 = 0, 1, 2
 
 
-class StepIO(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('action', C.c_void_p), ('initial_obj', C.c_void_p),
+class StepIO(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('reserved0', C.c_uint32), ('x', C.c_void_p), ('action', C.c_void_p), ('initial_obj', C.c_void_p),
                 ('step_in_episode', C.c_void_p), ('outage', C.c_void_p),
                 ('obs', C.c_void_p), ('reward', C.c_void_p), ('terminated', C.c_void_p),
                 ('truncated', C.c_void_p), ('valids', C.c_void_p), ('violations', C.c_void_p),
@@ -117,26 +132,65 @@ class StepIO(C.Structure):
                 ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p)]
 
 
-class ProfileDesc(C.Structure):
-    _fields_ = [('n_steps', C.c_int32), ('n_types', C.c_int32), ('n_cols', C.c_int32),
+class ProfileDesc(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('n_steps', C.c_int32), ('n_types', C.c_int32), ('n_cols', C.c_int32),
                 ('rel', _pd), ('typ', _pi), ('peak', _pd), ('slot', _pi),
                 ('col_min', _pd), ('col_max', _pd)]
 
 
-class ResetDesc(C.Structure):
-    _fields_ = [('n_tables', C.c_int32), ('tables', C.POINTER(ProfileDesc)),
+class ResetDesc(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('n_tables', C.c_int32), ('tables', C.POINTER(ProfileDesc)),
                 ('n_ops', C.c_int32), ('op_code', _pi), ('op_dst', _pi), ('op_a', _pi),
                 ('op_n', _pi), ('op_c0', _pi), ('op_c1', _pi), ('op_c2', _pi),
                 ('n_consts', C.c_int32), ('consts', _pd), ('n_uniform', C.c_int32),
                 ('init_off', C.c_int32), ('n_normal', C.c_int32), ('op_mode', _pi)]
 
 
-class ResetIO(C.Structure):
-    _fields_ = [('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
+class ResetIO(Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('reserved0', C.c_uint32), ('step_idx', C.c_void_p), ('noise', C.c_void_p), ('interp', C.c_void_p),
                 ('uniform', C.c_void_p), ('normal', C.c_void_p), ('normal_noise_factor', C.c_double),
                 ('x', C.c_void_p), ('mode', C.c_void_p), ('action', C.c_void_p), ('obs', C.c_void_p),
                 ('keep_state', C.c_int32), ('step_pool', C.c_void_p), ('n_step_pool', C.c_int32),
                 ('rng_seed', C.c_uint64), ('step_out', C.c_void_p)]
+
+
+class DebugOpts(Sized):
+    """include/opfx_debug.h: developer switches, handed explicitly to the *_debug constructors (0 = library default)."""
+    _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in (
+        'plan_search', 'plan_dcap_slack', 'plan_seed', 'plan_no_bank', 'plan_no_pack', 'plan_no_riders', 'plan_no_tail',
+        'plan_ordering', 'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
+        'reset_team')]
+
+    def any(self):
+        return any(getattr(self, n) for n, _ in self._fields_ if n != 'struct_size')
+
+
+def debug_from_env(environ=None) -> DebugOpts:
+    """Developer switches of THIS binding's test / A-B harness: OPFX_* variables of the Python process, read when a
+    Plan / Context is constructed without an explicit `debug=` and turned into the explicit struct the library takes
+    (the C library itself reads no environment variable).  Tri-state switches: '1' on, '0' off, unset = automatic."""
+    e = os.environ if environ is None else environ
+    d = DebugOpts()
+
+    def flag(name):
+        return 1 if e.get(name) not in (None, '', '0') else 0
+
+    def tri(name):
+        return 0 if e.get(name) in (None, '') else (1 if int(e[name]) != 0 else -1)
+    if e.get('OPFX_PLAN_SEARCH') not in (None, ''):
+        d.plan_search = int(e['OPFX_PLAN_SEARCH']) or -1
+    d.plan_dcap_slack = int(e.get('OPFX_PLAN_DCAP_SLACK') or 0)
+    d.plan_seed = int(e.get('OPFX_PLAN_SEED') or 0)
+    d.plan_ordering = int(e.get('OPFX_PLAN_ORDERING') or 0)
+    d.plan_no_bank, d.plan_no_pack = flag('OPFX_PLAN_NO_BANK'), flag('OPFX_PLAN_NO_PACK')
+    d.plan_no_riders, d.plan_no_tail = flag('OPFX_NO_RIDERS'), flag('OPFX_NO_TAIL')
+    d.team = int(e.get('OPFX_TEAM') or 0)
+    d.queue, d.packed = tri('OPFX_QUEUE'), tri('OPFX_PACKED')
+    d.force_mem, d.kernel_v1 = flag('OPFX_FORCE_MEM'), flag('OPFX_KERNEL_V1')
+    d.waves_per_cu = int(e.get('OPFX_WAVES_PER_CU') or 0)
+    d.verbose, d.stamps = flag('OPFX_VERBOSE'), flag('OPFX_STAMPS')
+    d.reset_team = int(e.get('OPFX_RESET_TEAM') or 0)
+    return d
 
 
 _lib = None
@@ -145,6 +199,8 @@ EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_
            'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
            'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info', 'opfx_env_get_storage']
+# include/opfx_debug.h (developer entry points, not part of the boundary)
+DEBUG_EXPORTS = ['opfx_plan_create_debug', 'opfx_ctx_create_debug', 'opfx_debug_read_stamps', 'opfx_debug_read_finish']
 
 
 def lib():
@@ -163,6 +219,15 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.opfx_last_error.restype = C.c_char_p
+    L.opfx_version.argtypes = [C.POINTER(C.c_int)] * 3
+    L.opfx_version.restype = None
+    v = [C.c_int(), C.c_int(), C.c_int()]
+    L.opfx_version(*[C.byref(x) for x in v])
+    if (v[0].value, v[1].value) != ABI_VERSION:
+        raise OpfxError(f'{LIB_PATH} is libopfx {v[0].value}.{v[1].value}.{v[2].value}, this binding was written for '
+                        f'{ABI_VERSION[0]}.{ABI_VERSION[1]}.x (struct layouts differ): rebuild it with __graft_entry__.build()')
+    L.opfx_plan_create_debug.argtypes = [C.POINTER(CaseStruct), C.POINTER(DebugOpts), C.POINTER(vp)]
+    L.opfx_ctx_create_debug.argtypes = [vp, C.c_int, C.POINTER(DebugOpts), C.POINTER(vp)]
     L.opfx_plan_create.argtypes = [C.POINTER(CaseStruct), C.POINTER(vp)]
     L.opfx_plan_destroy.argtypes = [vp]
     L.opfx_plan_destroy.restype = None
@@ -175,8 +240,6 @@ def lib():
     L.opfx_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.opfx_ctx_destroy.argtypes = [vp]
     L.opfx_ctx_destroy.restype = None
-    L.opfx_version.argtypes = [C.POINTER(C.c_int)] * 3
-    L.opfx_version.restype = None
     L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 10
     L.opfx_env_create.argtypes = [vp, C.POINTER(EnvDesc), C.POINTER(vp)]
     L.opfx_env_destroy.argtypes = [vp]
@@ -211,8 +274,9 @@ def _i(a):
 class Plan:
     """Host-side compiled grid plan (opfx_plan)."""
 
-    def __init__(self, case):
+    def __init__(self, case, debug: DebugOpts = None):
         self.case = case
+        self.debug = debug if debug is not None else debug_from_env()
         keep = []
         cs = CaseStruct()
         cs.nb, cs.nbr, cs.base_mva = case.nb, case.nbr, float(case.base_mva)
@@ -228,14 +292,21 @@ class Plan:
         ya, yp = _d(y)
         keep.append(ya)
         cs.br_y = yp
-        if getattr(case, 'bdc', None) is not None and getattr(case, 'pfinj', None) is not None:
+        # (a zero-reactance branch has no finite 1/x: such a case gets no DC start — `has_dc` 0, init='auto' stays flat —
+        #  instead of a B' with 1.8e308 in it)
+        if getattr(case, 'bdc', None) is not None and getattr(case, 'pfinj', None) is not None \
+                and np.isfinite(np.asarray(case.bdc, dtype=float)).all() and np.isfinite(np.asarray(case.pfinj, dtype=float)).all():
             for name, arr in (('br_bdc', case.bdc), ('br_pfinj', case.pfinj)):
-                a, p = _d(np.nan_to_num(np.asarray(arr, dtype=float)))
+                a, p = _d(np.asarray(arr, dtype=float))
                 keep.append(a)
                 setattr(cs, name, p)
         self.branch_y = ya
+        self.case_struct, self._keep = cs, keep
         h = C.c_void_p()
-        check(lib().opfx_plan_create(C.byref(cs), C.byref(h)), 'opfx_plan_create')
+        if self.debug.any():
+            check(lib().opfx_plan_create_debug(C.byref(cs), C.byref(self.debug), C.byref(h)), 'opfx_plan_create_debug')
+        else:
+            check(lib().opfx_plan_create(C.byref(cs), C.byref(h)), 'opfx_plan_create')
         self.handle = h
         info = PlanInfo()
         check(lib().opfx_plan_get_info(h, C.byref(info)), 'opfx_plan_get_info')
@@ -277,11 +348,15 @@ class Plan:
 class Context:
     """Plan resident on one GPU (opfx_ctx)."""
 
-    def __init__(self, plan: Plan, device: int = 0):
+    def __init__(self, plan: Plan, device: int = 0, debug: DebugOpts = None):
         self.plan = plan
         self.device = device
+        self.debug = debug if debug is not None else debug_from_env()
         h = C.c_void_p()
-        check(lib().opfx_ctx_create(plan.handle, int(device), C.byref(h)), 'opfx_ctx_create')
+        if self.debug.any():
+            check(lib().opfx_ctx_create_debug(plan.handle, int(device), C.byref(self.debug), C.byref(h)), 'opfx_ctx_create_debug')
+        else:
+            check(lib().opfx_ctx_create(plan.handle, int(device), C.byref(h)), 'opfx_ctx_create')
         self.handle = h
 
     def __del__(self):
@@ -330,7 +405,7 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
     out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
     out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
     out['min_pivot'] = torch.empty(B, dtype=torch.float64, device=dev)
-    opts = SolveOpts(float(tol), int(max_iter), int(bool(enforce_q_lims)), INIT[init], 0)
+    opts = SolveOpts(tol, max_iter, int(bool(enforce_q_lims)), INIT[init], 0)
     with torch.cuda.device(dev):
         check(lib().opfx_solve(
             ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "opfx.h"
+#include "opfx_debug.h"
 #include "plan.h"
 
 #define HIP_TRY(expr)                                                         \
@@ -68,7 +69,7 @@ struct DevPlan {
   const double *vm_set, *va_set, *vr0, *vi0, *y_g, *y_b, *br_y, *br_kf, *br_kt;
   // lane programme (plan.h)
   int ra, rh, rb, rc;
-  unsigned long long* stamps; // developer probe (OPFX_STAMPS): per-phase cycle sums of workgroup 0
+  unsigned long long* stamps; // developer probe (opfx_debug_opts.stamps): per-phase cycle sums of workgroup 0
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
   const int* lp_hrows;
   int n_hrows;
@@ -2945,6 +2946,7 @@ struct DevArena {
 }  // namespace
 
 struct opfx_ctx {
+  opfx_debug_opts dbg{};               // developer switches (include/opfx_debug.h); all zero: the library's own choices
   int device = 0;
   int n_cu = 0;
   int solve_per_cu = 0;
@@ -2973,6 +2975,7 @@ struct opfx_env {
   int per_cu = 0;
   int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
   bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
+  int* queue = nullptr;  // this environment's own work-queue counter (two environments of a context do not share one)
   std::vector<int32_t> h_oseg[4];      // observation segments (kind, source, destination, length): host copy for the reset's element list
   int n_full = 0;        // four-value blocks this environment's kernels run with (choose_block_storage)
 };
@@ -3001,10 +3004,10 @@ int instances_per_cu(size_t lds) {
 // branch per block read; it is used only when the LDS it saves lets a CU hold more instances.
 // Returns the LDS bytes per instance and the number of four-value blocks to run with.
 template <typename F>
-size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
+size_t choose_block_storage(const opfx_plan& p, const opfx_debug_opts& dbg, F lds_for, int* n_full_out) {
   const size_t full = lds_for(p.n_blk), packed = lds_for(p.n_full);
   bool use_packed = packed <= 160 * 1024 && (full > 160 * 1024 || instances_per_cu(packed) > instances_per_cu(full));
-  if (const char* ov = getenv("OPFX_PACKED")) use_packed = atoi(ov) != 0 && packed <= 160 * 1024;     // developer probe
+  if (dbg.packed) use_packed = dbg.packed > 0 && packed <= 160 * 1024;     // developer probe
   *n_full_out = use_packed ? p.n_full : p.n_blk;
   return use_packed ? packed : full;
 }
@@ -3012,15 +3015,14 @@ size_t choose_block_storage(const opfx_plan& p, F lds_for, int* n_full_out) {
 // Instances from the context's work queue instead of fixed shares: from 12 instances per single-wave workgroup on,
 // from 8 per wave team.  Measured against fixed shares WITH the priority turns of the kernels (profiles/r03_ab_queue.txt):
 // single wave +4 % / +2 % / 0 / -1.5 % / -2.5 % / -4 % at 5 / 8 / 12 / 16 / 24 / 32 instances per wavefront; teams of four
-// -0.4 % at 8, -0.9 % at 16 per team.  OPFX_QUEUE=0|1 forces the choice (A/B runs).
-int use_queue(long long B, int grid, int team) {
-  const char* force = getenv("OPFX_QUEUE");
-  return force ? atoi(force) != 0 : B >= (team > 1 ? 8LL : 12LL) * grid;
+// -0.4 % at 8, -0.9 % at 16 per team.  opfx_debug_opts.queue forces the choice (A/B runs).
+int use_queue(const opfx_debug_opts& dbg, long long B, int grid, int team) {
+  return dbg.queue ? dbg.queue > 0 : B >= (team > 1 ? 8LL : 12LL) * grid;
 }
 
-int pick_team(size_t lds, bool v2) {
+int pick_team(const opfx_debug_opts& dbg, size_t lds, bool v2) {
   if (!v2) return 1;
-  if (const char* ov = getenv("OPFX_TEAM")) { const int t = atoi(ov); if (t == 1 || t == 2 || t == 4) return t; }
+  if (dbg.team == 1 || dbg.team == 2 || dbg.team == 4) return dbg.team;
   const size_t granule = 1024;
   const int inst = (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
   if (inst <= 2) return 4;
@@ -3029,7 +3031,7 @@ int pick_team(size_t lds, bool v2) {
 }
 
 template <typename K>
-int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int* per_cu_cache, int threads = WAVE) {
+int launch_geometry(const opfx_debug_opts& dbg, K kernel, size_t lds, int n_cu, long long B, int* grid, int* per_cu_cache, int threads = WAVE) {
   if (*per_cu_cache > 0) {
     *grid = (int)std::max<long long>(1, std::min<long long>((long long)*per_cu_cache * n_cu, B));
     return OPFX_OK;
@@ -3051,8 +3053,8 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
   }
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;       // the per-workgroup scratch rows (warm start, scheduled P/Q) are sized for 16 per CU
-  if (const char* ov = getenv("OPFX_WAVES_PER_CU")) per_cu = atoi(ov);     // developer override
-  if (getenv("OPFX_VERBOSE")) fprintf(stderr, "[opfx] lds=%zu B/instance, resident waves per CU=%d, CUs=%d\n", lds, per_cu, n_cu);
+  if (dbg.waves_per_cu > 0) per_cu = dbg.waves_per_cu;     // developer override
+  if (dbg.verbose) fprintf(stderr, "[opfx] lds=%zu B/instance, resident waves per CU=%d, CUs=%d\n", lds, per_cu, n_cu);
   *per_cu_cache = per_cu;
   long long g = (long long)per_cu * n_cu;
   *grid = (int)std::max<long long>(1, std::min<long long>(g, B));
@@ -3062,8 +3064,8 @@ int launch_geometry(K kernel, size_t lds, int n_cu, long long B, int* grid, int*
 }  // namespace
 
 // Memory-resident form (grids past the LDS): block values of every resident workgroup in one row of global memory.
-static bool wants_mem(size_t lds_resident, bool v2) {
-  return v2 && (lds_resident > 160 * 1024 || getenv("OPFX_FORCE_MEM") != nullptr);    // (env var: developer / test switch)
+static bool wants_mem(const opfx_debug_opts& dbg, size_t lds_resident, bool v2) {
+  return v2 && (lds_resident > 160 * 1024 || dbg.force_mem != 0);    // (force_mem: developer / test switch)
 }
 static size_t blk_mem_stride(const opfx_plan& p) { return 4 * ((((size_t)p.n_blk + 1) & ~(size_t)1)); }
 static int ensure_blk_mem(opfx_ctx* ctx, int rows) {
@@ -3080,8 +3082,12 @@ static int ensure_blk_mem(opfx_ctx* ctx, int rows) {
   return OPFX_OK;
 }
 
-extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
+extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) { return opfx_ctx_create_debug(p, device, nullptr, out); }
+
+extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_debug_opts* dbg_in, opfx_ctx** out) {
   if (!p || !out) { opfx_set_error("opfx_ctx_create: null argument"); return OPFX_ERR_INVALID; }
+  opfx_debug_opts dbg{};
+  if (dbg_in) { const int rc_ = opfx_take(dbg_in, &dbg, "opfx_ctx_create_debug(opfx_debug_opts)"); if (rc_ != OPFX_OK) return rc_; }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
     opfx_set_error("opfx_ctx_create: no HIP device available");
@@ -3092,6 +3098,7 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   auto* c = new opfx_ctx();
+  c->dbg = dbg;
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   c->plan = *p;
@@ -3112,11 +3119,11 @@ extern "C" int opfx_ctx_create(const opfx_plan* p, int device, opfx_ctx** out) {
   d.fill_lo = p->n_full - (int)p->fill_blk.size();
   d.ra = p->ra; d.rh = p->rh; d.rb = p->rb_pad; d.rc = p->rc_pad;      // device: padded round counts of lp_bc
   d.stamps = nullptr;
-  if (getenv("OPFX_STAMPS")) {
+  if (dbg.stamps) {
     void* st = nullptr;
     if (hipMalloc(&st, 32 * sizeof(unsigned long long)) == hipSuccess) { (void)hipMemset(st, 0, 32 * sizeof(unsigned long long)); A.ptrs.push_back(st); d.stamps = static_cast<unsigned long long*>(st); }
   }
-  c->v2 = p->rb >= 0 && !getenv("OPFX_KERNEL_V1");   // env var: developer switch to the first-generation kernel
+  c->v2 = p->rb >= 0 && !dbg.kernel_v1;   // (kernel_v1: developer switch to the first-generation kernel)
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   d.lp_dc = nullptr; d.lp_hdc = nullptr;
   d.blk_mem = nullptr; d.blk_mem_stride = 0;
@@ -3167,60 +3174,65 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                           double* max_mismatch, double* min_pivot, void* stream) {
   if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
+  opfx_solve_opts so;
+  if (opts) { const int rc_ = opfx_take(opts, &so, "opfx_solve(opfx_solve_opts)"); if (rc_ != OPFX_OK) return rc_; opts = &so; }
   HIP_TRY(hipSetDevice(ctx->device));
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0, opts ? opts->init : 0};
   if (o.init == OPFX_INIT_DC && !ctx->dp.lp_dc) { opfx_set_error("opfx_solve: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
   int n_full = ctx->plan.n_blk;
-  size_t lds = choose_block_storage(ctx->plan, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
+  size_t lds = choose_block_storage(ctx->plan, ctx->dbg, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
   DevPlan dp = ctx->dp;
-  if (wants_mem(lds, ctx->v2)) {
+  if (wants_mem(ctx->dbg, lds, ctx->v2)) {
     // the LU blocks do not fit the LDS beside the state vectors: wave team of four, four-value blocks in global memory
     n_full = ctx->plan.n_blk;
     lds = solver_lds_bytes(ctx->plan, 0, nres, true, 8, 1, n_full, true);
     dp.nfull = n_full;
     int grid = 0;
     auto kern = k_solve<1, 4, false, true>;
-    int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu_mem, WAVE * 4);
+    int rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu_mem, WAVE * 4);
     if (rc != OPFX_OK) return rc;
     rc = ensure_blk_mem(ctx, ctx->solve_per_cu_mem * ctx->n_cu);
     if (rc != OPFX_OK) return rc;
     dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
     SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
-    if ((io.queued = use_queue(B, grid, 4))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    if ((io.queued = use_queue(ctx->dbg, B, grid, 4))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
     HIP_TRY(hipGetLastError());
     return OPFX_OK;
   }
   dp.nfull = n_full;
   int grid = 0;
-  const int team = pick_team(lds, ctx->v2);
+  const int team = pick_team(ctx->dbg, lds, ctx->v2);
   const bool packed = n_full < ctx->plan.n_blk;
   auto kern = !ctx->v2 ? k_solve<0, 1>
             : packed ? (team == 4 ? k_solve<2, 4> : (team == 2 ? k_solve<2, 2> : k_solve<2, 1>))
                      : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
-  int rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
+  int rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   if (o.init == OPFX_INIT_DC && ctx->v2) {           // the kernels compiled with the DC start (same launch geometry)
     kern = packed ? (team == 4 ? k_solve<2, 4, true> : (team == 2 ? k_solve<2, 2, true> : k_solve<2, 1, true>))
                   : (team == 4 ? k_solve<1, 4, true> : (team == 2 ? k_solve<1, 2, true> : k_solve<1, 1, true>));
     int per_cu_dc = ctx->solve_per_cu_dc;
-    rc = launch_geometry(kern, lds, ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
+    rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
     ctx->solve_per_cu_dc = per_cu_dc;
     if (rc != OPFX_OK) return rc;
   }
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
-  if ((io.queued = use_queue(B, grid, team))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+  if ((io.queued = use_queue(ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
   HIP_TRY(hipGetLastError());
   return OPFX_OK;
 }
 
-extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out) {
-  if (!ctx || !d || !out) { opfx_set_error("opfx_env_create: null argument"); return OPFX_ERR_INVALID; }
+extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_env** out) {
+  if (!ctx || !d_in || !out) { opfx_set_error("opfx_env_create: null argument"); return OPFX_ERR_INVALID; }
+  opfx_env_desc desc;
+  { const int rc_ = opfx_take(d_in, &desc, "opfx_env_create(opfx_env_desc)"); if (rc_ != OPFX_OK) return rc_; }
+  const opfx_env_desc* const d = &desc;
   HIP_TRY(hipSetDevice(ctx->device));
   const opfx_plan& p = ctx->plan;
   const int nb = p.nb;
@@ -3446,9 +3458,10 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env**
     E.nblk_d = std::max(E.nres, d->nx - 2 * nbe);
   }
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
+  if (rc == OPFX_OK) { const int zero[2] = {0, 0}; const int* q = nullptr; rc = A.put(zero, 2, &q); e->queue = const_cast<int*>(q); }
   if (rc != OPFX_OK) { delete e; return rc; }
-  e->lds_bytes = choose_block_storage(p, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, env_nacc(d->nc), E.max_mod, nf); }, &e->n_full);
-  if (wants_mem(e->lds_bytes, ctx->v2)) {
+  e->lds_bytes = choose_block_storage(p, ctx->dbg, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, env_nacc(d->nc), E.max_mod, nf); }, &e->n_full);
+  if (wants_mem(ctx->dbg, e->lds_bytes, ctx->v2)) {
     e->mem = true;
     e->n_full = p.n_blk;
     e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, true, env_nacc(d->nc), E.max_mod, e->n_full, true);
@@ -3466,7 +3479,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  const int team = env->mem ? 4 : pick_team(env->lds_bytes, env->ctx->v2);
+  const int team = env->mem ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2);
   DevPlan dp = env->ctx->dp;
   dp.nfull = env->n_full;
   const bool packed = env->n_full < env->ctx->plan.n_blk;
@@ -3474,7 +3487,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
             : packed ? (team == 4 ? k_step<2, 4> : (team == 2 ? k_step<2, 2> : k_step<2, 1>))
                      : (team == 4 ? k_step<1, 4> : (team == 2 ? k_step<1, 2> : k_step<1, 1>));
   if (env->mem) kern = k_step<1, 4, false, true>;
-  int rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
+  int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   if (env->mem) {
     rc = ensure_blk_mem(env->ctx, env->per_cu * env->ctx->n_cu);
@@ -3486,7 +3499,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     kern = packed ? (team == 4 ? k_step<2, 4, true> : (team == 2 ? k_step<2, 2, true> : k_step<2, 1, true>))
                   : (team == 4 ? k_step<1, 4, true> : (team == 2 ? k_step<1, 2, true> : k_step<1, 1, true>));
     int per_cu_dc = env->per_cu_dc;
-    rc = launch_geometry(kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
+    rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
     env->per_cu_dc = per_cu_dc;
     if (rc != OPFX_OK) return rc;
   }
@@ -3499,7 +3512,8 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
-  if ((s.queued = use_queue(B, grid, team))) HIP_TRY(hipMemsetAsync(env->ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+  dp.queue = env->queue;
+  if ((s.queued = use_queue(env->ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(env->queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
                      dp, env->d_de, s, o, (long long)B);
   HIP_TRY(hipGetLastError());
@@ -3508,6 +3522,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
 
 extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                          int32_t mode, void* stream) {
+  opfx_step_io sio;
+  opfx_solve_opts so;
+  if (io) { const int rc_ = opfx_take(io, &sio, "opfx_step(opfx_step_io)"); if (rc_ != OPFX_OK) return rc_; io = &sio; }
+  if (opts) { const int rc_ = opfx_take(opts, &so, "opfx_step(opfx_solve_opts)"); if (rc_ != OPFX_OK) return rc_; opts = &so; }
   if (env && io && B == 0 && mode >= 0 && mode <= 5) return OPFX_OK;       // empty batch (buffers may be null)
   if (!env || !io || !io->x || B < 0 || mode < 0 || mode > 5 || ((mode == 0 || mode == 2 || mode == 4 || mode == 5) && env->de.na > 0 && !io->action)) {
     opfx_set_error("opfx_step: bad argument");
@@ -3519,6 +3537,10 @@ extern "C" int opfx_step(opfx_env* env, int64_t B, const opfx_step_io* io, const
 
 extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                                int32_t reps, void* stream, float* elapsed_ms) {
+  opfx_step_io sio;
+  opfx_solve_opts so;
+  if (io) { const int rc_ = opfx_take(io, &sio, "opfx_time_steps(opfx_step_io)"); if (rc_ != OPFX_OK) return rc_; io = &sio; }
+  if (opts) { const int rc_ = opfx_take(opts, &so, "opfx_time_steps(opfx_solve_opts)"); if (rc_ != OPFX_OK) return rc_; opts = &so; }
   if (!env || !io || !io->x || B <= 0 || reps <= 0 || !elapsed_ms) {
     opfx_set_error("opfx_time_steps: bad argument");
     return OPFX_ERR_INVALID;
@@ -3542,7 +3564,7 @@ extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
 extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
                                  int32_t* instances_per_cu) {
   if (!env) { opfx_set_error("opfx_env_get_info: null environment"); return OPFX_ERR_INVALID; }
-  if (waves_per_instance) *waves_per_instance = env->mem ? 4 : pick_team(env->lds_bytes, env->ctx->v2);
+  if (waves_per_instance) *waves_per_instance = env->mem ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2);
   if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
   if (instances_per_cu) *instances_per_cu = env->per_cu;
   return OPFX_OK;
@@ -3556,18 +3578,29 @@ extern "C" int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t
 }
 
 // wavefronts (= rows) per workgroup of the reset kernel: as many as leave room for four workgroups per CU
-// (OPFX_RESET_TEAM=1|2|4, read when the reset programme is set: the smaller teams on a row that would not need them — tests)
+// (opfx_debug_opts.reset_team = 1|2|4: the smaller teams on a row that would not need them — tests)
 static int reset_team(const opfx_env* env) {
   const size_t row_bytes = (size_t)(((env->de.nx + 1) & ~1) + ((env->de.na + 1) & ~1)) * sizeof(double);
   int team = 4 * row_bytes <= 64 * 1024 ? 4 : (2 * row_bytes <= 64 * 1024 ? 2 : 1);
-  if (const char* e = getenv("OPFX_RESET_TEAM")) { const int t = atoi(e); if ((t == 1 || t == 2 || t == 4) && t < team) team = t; }
+  { const int t = env->ctx->dbg.reset_team; if ((t == 1 || t == 2 || t == 4) && t < team) team = t; }
   return team;
 }
 
-extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
+extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d_in) {
+  opfx_reset_desc desc;
+  if (d_in) { const int rc_ = opfx_take(d_in, &desc, "opfx_env_set_reset(opfx_reset_desc)"); if (rc_ != OPFX_OK) return rc_; }
+  const opfx_reset_desc* const d = d_in ? &desc : nullptr;
   if (!env || !d || d->n_tables < 0 || d->n_tables > MAX_TABLES) {
     opfx_set_error("opfx_env_set_reset: bad argument (at most 8 profile tables)");
     return OPFX_ERR_INVALID;
+  }
+  // the profile tables: an array of versioned structs whose stride is the struct_size of its elements
+  std::vector<opfx_profile_desc> tables((size_t)d->n_tables);
+  for (int t = 0; t < d->n_tables; ++t) {
+    const uint32_t stride = d->tables ? d->tables[0].struct_size : 0;
+    const auto* src = reinterpret_cast<const opfx_profile_desc*>(reinterpret_cast<const char*>(d->tables) + (size_t)t * stride);
+    const int rc_ = opfx_take(d->tables ? src : nullptr, &tables[(size_t)t], "opfx_env_set_reset(opfx_profile_desc)");
+    if (rc_ != OPFX_OK) return rc_;
   }
   HIP_TRY(hipSetDevice(env->ctx->device));
   DevReset& R = env->dr;
@@ -3585,7 +3618,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
     std::vector<int32_t> typ, slot, pch;
     std::vector<double> peak, lo, hi;
     for (int t = 0; t < d->n_tables && rc == OPFX_OK; ++t) {
-      const opfx_profile_desc& T = d->tables[t];
+      const opfx_profile_desc& T = tables[(size_t)t];
       for (int j = 0; j < T.n_cols; ++j)
         if (T.slot[j] < 0 || T.slot[j] >= R.nx || T.typ[j] < 0 || T.typ[j] >= T.n_types) {
           opfx_set_error("opfx_env_set_reset: profile slot/type out of range");
@@ -3645,6 +3678,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
       n_stages = std::max(n_stages, stage[k] + 1);
       for (int j = 0; j < d->op_n[k]; ++j) covered[(size_t)d->op_dst[k] + j] = 1;
     }
+    if (n_stages > MAX_STAGES) { opfx_set_error("opfx_env_set_reset: more than 12 dependent stages of vector ops"); return OPFX_ERR_INVALID; }
     std::vector<int32_t> ptr{0}, och;
     const int32_t zero_off = d->n_consts;                 // 64 zeros behind the caller's constants: "no constant" (0.0)
     // Wavefront w of a team of `team` runs entries w, w + team, ... of a stage's list.  Each op's chunks are padded to a
@@ -3686,7 +3720,6 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
         ptr.push_back((int32_t)(och.size() / 8));
       }
     }
-    if (n_stages > MAX_STAGES) { opfx_set_error("opfx_env_set_reset: more than 12 dependent stages of vector ops"); return OPFX_ERR_INVALID; }
     R.n_stages = n_stages;
     for (size_t q = 0; q < ptr.size(); ++q) R.st_ptr[q] = ptr[q];
     if (och.empty()) och.assign(8, 0);
@@ -3718,6 +3751,8 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d) {
 }
 
 extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, void* stream) {
+  opfx_reset_io rio;
+  if (io) { const int rc_ = opfx_take(io, &rio, "opfx_reset(opfx_reset_io)"); if (rc_ != OPFX_OK) return rc_; io = &rio; }
   if (env && env->has_reset && io && B == 0) return OPFX_OK;               // empty batch (buffers may be null)
   if (!env || !env->has_reset || !io || (!io->step_idx && !(io->step_pool && io->n_step_pool > 0)) || !io->x || B < 0) {
     opfx_set_error("opfx_reset: bad argument or opfx_env_set_reset not called");
@@ -3754,7 +3789,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
   return OPFX_OK;
 }
 
-// developer probe (stamps build, not part of the ABI header): per workgroup of the last step launches — wall clock
+// developer probe (stamps build; declared in include/opfx_debug.h, not in the ABI header): per workgroup of the last step launches — wall clock
 // (100 MHz) at its last instance, instances and Newton iterations it processed since the last read, wall clock at its
 // start, HW_ID and XCC_ID registers (six doubles per workgroup); clears them
 extern "C" int opfx_debug_read_finish(opfx_ctx* ctx, double* out3, int n_wg) {
@@ -3769,7 +3804,7 @@ extern "C" int opfx_debug_read_finish(opfx_ctx* ctx, double* out3, int n_wg) {
   return OPFX_OK;
 }
 
-// developer probe (not part of the ABI header): copies and clears the OPFX_STAMPS cycle sums
+// developer probe (include/opfx_debug.h): copies and clears the cycle sums of a context created with opfx_debug_opts.stamps
 extern "C" int opfx_debug_read_stamps(opfx_ctx* ctx, unsigned long long* out32) {
   if (!ctx || !ctx->dp.stamps) return OPFX_ERR_INVALID;
   HIP_TRY(hipDeviceSynchronize());

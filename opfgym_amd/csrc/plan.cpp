@@ -72,7 +72,7 @@ int tail_length(const opfx_plan* p) {
   const int nlev = p->n_levels();
   int m = 0;
   for (int lev = nlev - 1; lev >= 0 && p->lev_pptr[lev + 1] - p->lev_pptr[lev] == 1 && m < opfx_plan::TAIL_MAX; --lev) ++m;
-  return (m < 4 || getenv("OPFX_NO_TAIL")) ? 0 : m;
+  return (m < 4 || p->dbg.plan_no_tail) ? 0 : m;
 }
 
 void renumber_blocks(opfx_plan* p) {
@@ -88,7 +88,7 @@ void renumber_blocks(opfx_plan* p) {
     for (int e = 0; e < m; ++e) in_tail[p->piv_bus[p->lev_pptr[nlev - m + e]]] = 1;
     for (int32_t b = 0; b < n; ++b) if (in_tail[p->blk_row[b]] && in_tail[p->blk_col[b]]) needs_full[b] = 1;
   }
-  if (getenv("OPFX_PLAN_NO_PACK")) std::fill(needs_full.begin(), needs_full.end(), 1);   // developer probe
+  if (p->dbg.plan_no_pack) std::fill(needs_full.begin(), needs_full.end(), 1);   // developer probe
   std::vector<int32_t> perm(n);
   int32_t next = 0;
   for (int32_t b = 0; b < n; ++b) if (!is_fill[b] && needs_full[b]) perm[b] = next++;
@@ -115,7 +115,7 @@ void renumber_blocks(opfx_plan* p) {
 // mutually independent, so which round and which half-wave runs which item is free: every item goes, in stream order,
 // to the half-round where it adds the fewest extra LDS cycles over its accesses (A_ik, A_kk, A_kj or y_k, the target's
 // atomics, a rider's y_k / y_i; a group of 32 lanes takes as many cycles as its busiest bank holds addresses).
-// `base`: n_rounds x 64 items x 4 words, in place; word 3 (flags) stays with its round.  OPFX_PLAN_NO_BANK=1 keeps the
+// `base`: n_rounds x 64 items x 4 words, in place; word 3 (flags) stays with its round.  opfx_debug_opts.plan_no_bank keeps the
 // plan's own order.
 void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
   constexpr uint32_t NONE = 0xFFFFu;
@@ -361,7 +361,7 @@ void build_lane_programs(opfx_plan* p) {
   auto rounds_of = [](size_t n) { return (int)((n + 63) / 64); };
   auto use_riders = [&](int lev, int nw) {
     const int with = (rounds_of(lev_rider[lev].size()) + nw - 1) / nw, without = (rounds_of(lev_sep[lev].size()) + nw - 1) / nw;
-    return with < without && !getenv("OPFX_NO_RIDERS");
+    return with < without && !p->dbg.plan_no_riders;
   };
   for (int lev = 0; lev < nlev; ++lev) {
     const std::vector<Item3>& its = use_riders(lev, 1) ? lev_rider[lev] : lev_sep[lev];
@@ -436,7 +436,7 @@ void build_lane_programs(opfx_plan* p) {
   for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
     for (int r = p->lp_groups[g]; r + 1 < p->lp_groups[g + 1]; ++r)
       for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = 2u;
-  const bool spread = !getenv("OPFX_PLAN_NO_BANK");
+  const bool spread = !p->dbg.plan_no_bank;
   if (spread)
     for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
       if (p->lp_groups[g + 1] > p->lp_groups[g])
@@ -613,7 +613,7 @@ void build_lane_programs(opfx_plan* p) {
 // degree <= dmin + slack; `tie_seed` = order of candidates of equal degree (0: by bus number, else by a seeded hash).
 struct PlanKnobs { int slack = 2; unsigned tie_seed = 0; };
 
-static int plan_build(const opfx_case* c, const PlanKnobs& knobs, opfx_plan** out) {
+static int plan_build(const opfx_case* c, const PlanKnobs& knobs, const opfx_debug_opts& dbg, opfx_plan** out) {
   if (!c || !out) { opfx_set_error("opfx_plan_create: null argument"); return OPFX_ERR_INVALID; }
   if (c->nb <= 0 || c->nbr < 0 || !c->bus_type || !c->vm_set || !c->va_set ||
       (c->nbr > 0 && (!c->br_f || !c->br_t || !c->br_y))) {
@@ -622,6 +622,7 @@ static int plan_build(const opfx_case* c, const PlanKnobs& knobs, opfx_plan** ou
   }
   const int32_t nb = c->nb, nbr = c->nbr;
   auto* p = new opfx_plan();
+  p->dbg = dbg;
   p->nb = nb; p->nbr = nbr; p->base_mva = c->base_mva;
   p->bus_type.assign(c->bus_type, c->bus_type + nb);
   p->vm_set.assign(c->vm_set, c->vm_set + nb);
@@ -839,27 +840,32 @@ static double plan_cost(const opfx_plan* p) {
 // The elimination order decides how many rounds and barriers an iteration takes, and on meshed grids the outcome of the
 // minimum-degree heuristic moves by 5-10 % with the way it breaks ties (306-bus HV grid: 48 to 56 rounds per wavefront
 // over 24 tie-breaking rules).  A plan is compiled once per grid and runs millions of times: for grids of the wave-team
-// kernels several rules are tried and the cheapest plan is kept (OPFX_PLAN_SEARCH = number of extra plans, default 15,
-// 0 = the first rule only; OPFX_PLAN_DCAP_SLACK / OPFX_PLAN_SEED pin one rule).  Radial MV / LV grids are item-bound, not
+// kernels several rules are tried and the cheapest plan is kept (15 extra plans by default).  Radial MV / LV grids are item-bound, not
 // level-bound, and every rule gives the same round count: no search below 200 buses; above 800 (a plan takes most of a
-// second to build) only on request.
-extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
-  PlanKnobs base;
-  const bool pinned = getenv("OPFX_PLAN_DCAP_SLACK") || getenv("OPFX_PLAN_SEED");
-  if (const char* e = getenv("OPFX_PLAN_DCAP_SLACK")) base.slack = atoi(e);
-  if (const char* e = getenv("OPFX_PLAN_SEED")) base.tie_seed = (unsigned)atoi(e);
-  opfx_plan* best = nullptr;
-  int rc = plan_build(c, base, &best);
+// second to build) only on request (opfx_debug_opts.plan_search / plan_dcap_slack / plan_seed, include/opfx_debug.h).
+extern "C" int opfx_plan_create_debug(const opfx_case* c_in, const opfx_debug_opts* dbg_in, opfx_plan** out) {
+  opfx_case cs;
+  int rc = opfx_take(c_in, &cs, "opfx_plan_create(opfx_case)");
   if (rc != OPFX_OK) return rc;
-  const int n_search = getenv("OPFX_PLAN_SEARCH") ? atoi(getenv("OPFX_PLAN_SEARCH")) : 15;
-  if (!pinned && best->nb >= 200 && (best->nb <= 800 || getenv("OPFX_PLAN_SEARCH")) && n_search > 0) {
+  const opfx_case* c = &cs;
+  opfx_debug_opts dbg{};
+  if (dbg_in && (rc = opfx_take(dbg_in, &dbg, "opfx_plan_create_debug(opfx_debug_opts)")) != OPFX_OK) return rc;
+  PlanKnobs base;
+  const bool pinned = dbg.plan_dcap_slack > 0 || dbg.plan_seed > 0;
+  if (dbg.plan_dcap_slack > 0) base.slack = dbg.plan_dcap_slack;
+  if (dbg.plan_seed > 0) base.tie_seed = (unsigned)dbg.plan_seed;
+  opfx_plan* best = nullptr;
+  rc = plan_build(c, base, dbg, &best);
+  if (rc != OPFX_OK) return rc;
+  const int n_search = dbg.plan_search > 0 ? dbg.plan_search : (dbg.plan_search < 0 ? 0 : 15);
+  if (!pinned && best->nb >= 200 && (best->nb <= 800 || dbg.plan_search > 0) && n_search > 0) {
     double best_cost = plan_cost(best);
     for (int t = 0; t < n_search; ++t) {
       PlanKnobs k;
       k.slack = 2 + (t & 1);                       // slack 2 and 3 in turn
       k.tie_seed = (unsigned)(t / 2 + (k.slack == 2 ? 1 : 0));   // (slack 2 / seed 0 is the base plan)
       opfx_plan* q = nullptr;
-      if (plan_build(c, k, &q) != OPFX_OK) continue;
+      if (plan_build(c, k, dbg, &q) != OPFX_OK) continue;
       const double cost = plan_cost(q);
       if (cost < best_cost) { delete best; best = q; best_cost = cost; } else delete q;
     }
@@ -868,10 +874,20 @@ extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) {
   return OPFX_OK;
 }
 
+extern "C" int opfx_plan_create(const opfx_case* c, opfx_plan** out) { return opfx_plan_create_debug(c, nullptr, out); }
+
 extern "C" void opfx_plan_destroy(opfx_plan* p) { delete p; }
 
 extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   if (!p || !o) { opfx_set_error("opfx_plan_get_info: null argument"); return OPFX_ERR_INVALID; }
+  opfx_plan_info* const caller = o;
+  const uint32_t caller_size = caller->struct_size;
+  if (caller_size < sizeof(uint32_t) || caller_size > sizeof(opfx_plan_info)) {
+    opfx_set_error("opfx_plan_get_info: set opfx_plan_info.struct_size = sizeof(opfx_plan_info) before the call (got " + std::to_string(caller_size) + ")");
+    return OPFX_ERR_INVALID;
+  }
+  opfx_plan_info full{};
+  o = &full;
   o->nb = p->nb; o->nbr = p->nbr; o->nref = p->nref; o->npv = p->npv; o->npq = p->npq;
   o->nnz_y = (int32_t)p->y_col.size();
   o->nnz_j = p->nnz_j;
@@ -896,6 +912,8 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->tail_m = p->tail_m;
   o->lp_ell_width = opfx_plan::KA;
   o->has_dc = p->lp_dc.empty() ? 0 : 1;
+  full.struct_size = caller_size;
+  std::memcpy(caller, &full, caller_size);          // (a caller built against an older, shorter layout gets its prefix)
   return OPFX_OK;
 }
 

@@ -5,8 +5,10 @@
 #include <vector>
 
 #include "opfx.h"
+#include "opfx_debug.h"
 
 struct opfx_plan {
+  opfx_debug_opts dbg{};               // developer switches this plan was built with (all zero: the defaults)
   int32_t nb = 0, nbr = 0, nref = 0, npv = 0, npq = 0;
   double base_mva = 1.0;
   // case copy
@@ -93,3 +95,24 @@ struct opfx_plan {
 };
 
 void opfx_set_error(const std::string& msg);
+
+// Versioned structs (include/opfx.h, VERSIONING): copy the caller's struct into a zeroed one of THIS library's layout.
+// Accepted sizes: [min_size, sizeof(T)] — members are only ever appended, a shorter struct of the same series leaves the
+// new ones zero (their defaults); anything else is a caller built against another header and is refused.
+#include <cstring>
+template <class T>
+inline int opfx_take(const T* in, T* out, const char* what, size_t min_size = sizeof(T)) {
+  std::memset(static_cast<void*>(out), 0, sizeof(T));
+  if (!in) { opfx_set_error(std::string(what) + ": null struct"); return OPFX_ERR_INVALID; }
+  const uint32_t sz = in->struct_size;
+  if (sz < min_size || sz > sizeof(T)) {
+    opfx_set_error(std::string(what) + ": struct_size " + std::to_string(sz) + " is not a layout of libopfx " +
+                   std::to_string(OPFX_VERSION_MAJOR) + "." + std::to_string(OPFX_VERSION_MINOR) + " (expected " +
+                   (min_size == sizeof(T) ? std::to_string(sizeof(T)) : std::to_string(min_size) + " .. " + std::to_string(sizeof(T))) +
+                   " bytes: set struct_size = sizeof(struct), OPFX_INIT, and build against this library's include/opfx.h)");
+    return OPFX_ERR_INVALID;
+  }
+  std::memcpy(static_cast<void*>(out), in, sz);
+  out->struct_size = (uint32_t)sizeof(T);
+  return OPFX_OK;
+}

@@ -63,11 +63,11 @@ class BatchedPowerFlowSolver:
         import torch
         case = net_to_case(net, kwargs.get('calculate_voltage_angles', 'auto'))
         init = kwargs.get('init', 'flat')
-        if init == 'auto':
-            init = 'dc' if case.meta.get('calc_angles') else 'flat'
-        if init not in ('flat', 'dc'):
+        if init not in ('flat', 'dc', 'auto'):
             raise NotImplementedError(f"init={init!r}: 'flat', 'dc' or 'auto' (no 'results' start)")
         ctx = self._context(case)
+        if init == 'auto':       # (no DC model — a zero-reactance branch has no finite 1/x —: flat, as for grids below 70 kV)
+            init = 'dc' if case.meta.get('calc_angles') and ctx.plan.info['has_dc'] else 'flat'
         base = case.base_mva
         p, q, qmin, qmax = bus_injections(net, case)
         dev = torch.device(self.device)

@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc_example  # noqa: E402
 import opfgym.security_constrained as ref_sc  # noqa: E402
-from scenarios import E12_SCENARIOS, EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED  # noqa: E402
+from scenarios import E12_SCENARIOS, EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED, VALID_ROWS  # noqa: E402
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
 import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
@@ -172,9 +172,26 @@ def run(name):
         rec.setdefault(key, []).append(np.array(val, copy=True))
     k = -1
     done = 0
+    # fixtures with a quota of all-valid rows (scenarios.VALID_ROWS): candidates are recorded until both kinds are full
+    want_valid, levels = VALID_ROWS.get(name, (None, ()))
+    have = {True: 0, False: 0}
     while done < n:
         k += 1
         step = int(rng.choice(pool))
+        found = None
+        if want_valid is not None and have[True] < want_valid and (k % 2 == 1 or have[False] >= n - want_valid):
+            # look for an all-valid state along one scalar action level (see scenarios.VALID_ROWS); every trial is the
+            # reference's own reset + step with this candidate's seed, so the recorded draws are those of the last reset
+            u = rng.random(env.action_space.shape[0])
+            for level in levels:
+                env.reset(seed=seed * 100 + k, options={'step': step})
+                a = np.clip(level + 0.1 * (u - 0.5), 0.0, 1.0)
+                info = env.step(a)[4]
+                if 'cost' in info and bool(np.all(info['valids'])):
+                    found = a
+                    break
+            if found is None:
+                continue
         obs0, _ = env.reset(seed=seed * 100 + k, options={'step': step})
         log = env.np_random.log
         uni = [u.ravel() for kind, u in log if kind == 'uniform']
@@ -184,7 +201,7 @@ def run(name):
         normal_noise = (kwargs.get('sampling_params') or {}).get('noise_distribution') == 'normal'
         if normal_noise:                # the noise of _set_simbench_state is drawn with normal()
             noise, normal = normal, []
-        action = rng.random(env.action_space.shape[0])
+        action = rng.random(env.action_space.shape[0]) if found is None else found
         if k == 0:
             action = np.clip(action * 1.6 - 0.3, -0.2, 1.2)        # exercise the [0,1] clipping
         snap = snapshot(env.net)
@@ -199,6 +216,11 @@ def run(name):
             push('fail_interp', np.concatenate(interp) if interp else np.zeros(0))
             push('fail_normal', np.concatenate(normal) if normal else np.zeros(0))
             continue
+        if want_valid is not None:
+            kind = bool(np.all(info['valids']))
+            if have[kind] >= (want_valid if kind else n - want_valid):
+                continue                                           # this kind is full: the candidate is not recorded
+            have[kind] += 1
         done += 1
         push('step', step)
         push('uniform', np.concatenate(uni) if uni else np.zeros(0))

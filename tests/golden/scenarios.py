@@ -5,9 +5,9 @@ tests (run this repo's oracle / GPU path on the same inputs)."""
 # name -> (environment class name, constructor kwargs, number of samples, seed)
 SCENARIOS = {
     'vc_mv_small': ('VoltageControl', dict(simbench_network_name='mv-small'), 6, 1),
-    'vc_mv_urban': ('VoltageControl', dict(simbench_network_name='1-MV-urban--0-sw'), 4, 2),
+    'vc_mv_urban': ('VoltageControl', dict(simbench_network_name='1-MV-urban--0-sw'), 16, 2),
     'qm_mv_small': ('QMarket', dict(simbench_network_name='mv-small'), 6, 3),
-    'qm_mv_urban': ('QMarket', dict(simbench_network_name='1-MV-urban--0-sw'), 3, 4),
+    'qm_mv_urban': ('QMarket', dict(simbench_network_name='1-MV-urban--0-sw'), 16, 4),
     'eco_hv_small': ('EcoDispatch', dict(simbench_network_name='hv-small'), 6, 5),
     'maxren_lv': ('MaxRenewable', dict(simbench_network_name='1-LV-rural1--0-sw',
                                        min_sgen_power=0.005, min_storage_power=0.005), 6, 6),
@@ -17,13 +17,13 @@ SCENARIOS = {
     # option coverage on the small MV grid
     'vc_replacement': ('VoltageControl', dict(
         simbench_network_name='mv-small', reward_function='replacement',
-        reward_function_params=dict(valid_reward=0.7, penalty_weight=0.3, clip_range=(-1.5, 1.0))), 4, 8),
+        reward_function_params=dict(valid_reward=0.7, penalty_weight=0.3, clip_range=(-1.5, 1.0))), 8, 8),
     'vc_parameterized': ('VoltageControl', dict(
         simbench_network_name='mv-small', reward_function='parameterized',
         reward_function_params=dict(valid_reward=0.4, invalid_penalty=0.2, invalid_objective_share=0.5,
                                     penalty_weight=None),
         constraint_params=dict(penalty_factor=2.0, penalty_power=1.5, violation_count_penalty=0.1,
-                               only_worst_case_violations=True)), 4, 9),
+                               only_worst_case_violations=True)), 8, 9),
     'vc_resobs_diff': ('VoltageControl', dict(
         simbench_network_name='mv-small', add_res_obs=True, diff_objective=True, add_act_obs=True,
         add_mean_obs=True, clipped_action_penalty=0.5), 4, 10),
@@ -92,12 +92,34 @@ SCENARIOS.update({
     # BASELINE configs 3 and 5 on their own grids: EcoDispatch on the 306-bus meshed HV
     # stand-in (wave teams of two), N-1 VoltageControl on the 372-bus stand-in with every non-islanding
     # line as contingency (250 of them; wave teams of four)
-    'eco_hv_mixed': ('EcoDispatch', dict(simbench_network_name='1-HV-mixed--0-sw'), 4, 31),
+    'eco_hv_mixed': ('EcoDispatch', dict(simbench_network_name='1-HV-mixed--0-sw'), 16, 31),
     # a grid with a three-winding transformer: Trafo3wOverloadConstraint among the defaults (constraints.py:164-172,210)
     'vc_mv_3w': ('VoltageControl', dict(simbench_network_name='mv-3w'), 5, 33),
     'sc_vc_hv_urban': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
                                                                  n_minus_one_lines='all'), 2, 32),
+    # the same N-1 problem with a reactive exchange band an HV grid can meet (the reference's default of +-0.5 Mvar is an
+    # MV figure: on the 372-bus grid no action keeps all 251 cases inside it): valid AND invalid states of config 5's kind
+    'sc_vc_hv_urban_wide': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
+                                                                      n_minus_one_lines='all', max_q_exchange=150.0), 4, 34),
 })
+
+# Fixtures that must hold all-valid AND invalid states (the reward classes' `valid` branch, reward.py:246-252,254-305,
+# needs reference-generated rows of both kinds): name -> (all-valid rows among the n samples, action levels searched).
+# Random actions practically never give a valid state (the ext-grid band is narrow), so the generator looks for one
+# along ONE scalar: the action level a = clip(level + 0.1 (u - 0.5)), u the sample's own uniform draw — the first level
+# of the list whose step the reference itself reports as all-valid is recorded; a candidate without one is dropped.
+def _levels(lo, hi, step):
+    return [round(lo + step * k, 6) for k in range(int(round((hi - lo) / step)) + 1)]
+
+
+VALID_ROWS = {
+    'vc_mv_urban': (8, _levels(0.40, 0.70, 0.005)),
+    'qm_mv_urban': (8, _levels(0.40, 0.70, 0.005)),
+    'eco_hv_mixed': (8, _levels(0.0, 1.0, 0.0125)),
+    'vc_replacement': (4, _levels(0.30, 0.70, 0.01)),
+    'vc_parameterized': (4, _levels(0.30, 0.70, 0.01)),
+    'sc_vc_hv_urban_wide': (2, [0.5, 0.49, 0.51]),
+}
 
 # E12 (`estimate_reward_distribution`, reward.py:181-216): fixture name -> (scenario whose environment is sampled, samples)
 E12_SCENARIOS = {'e12_vc_mv_small': ('vc_mv_small', 64), 'e12_sc_hv_small': ('sc_hv_small', 24),

@@ -25,7 +25,96 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(built_lib, name), name
     ver = [capi.C.c_int() for _ in range(3)]
     built_lib.opfx_version(*[capi.C.byref(v) for v in ver])
-    assert (ver[0].value, ver[1].value) == (0, 1)
+    assert (ver[0].value, ver[1].value) == capi.ABI_VERSION == (0, 2)
+    # the header and the library agree on the version; the developer entry points live in a header of their own
+    assert re.search(r'#define OPFX_VERSION_MAJOR (\d+)', header).group(1) == str(ver[0].value)
+    assert re.search(r'#define OPFX_VERSION_MINOR (\d+)', header).group(1) == str(ver[1].value)
+    dbg = open(os.path.join(ROOT, 'include', 'opfx_debug.h')).read()
+    declared_dbg = set(re.findall(r'^int (opfx_[a-z_]+)\s*\(', dbg, re.M))
+    assert declared_dbg == set(capi.DEBUG_EXPORTS)
+    for name in declared_dbg:
+        assert hasattr(built_lib, name), name
+    # nothing else is exported, and the library reads no environment variable (opfx.h: "no hidden global state")
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ' T ' in ln and ln.split()[-1].startswith('opfx_')}
+    assert exported == declared | declared_dbg, exported ^ (declared | declared_dbg)
+    undefined = subprocess.run(['nm', '-D', '--undefined-only', capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in undefined
+    for src in ('opfx.hip', 'plan.cpp'):
+        assert 'getenv' not in open(os.path.join(ROOT, 'opfgym_amd', 'csrc', src)).read(), src
+
+
+def test_structs_carry_their_size_and_a_wrong_size_is_refused(built_lib):
+    """include/opfx.h, VERSIONING: every struct that crosses the boundary starts with `struct_size`; a binding built
+    against another header (a shorter or longer struct) gets OPFX_ERR_INVALID with text instead of a library that reads
+    past the end of the caller's struct (`init` was inserted into the middle of opfx_solve_opts)."""
+    C = capi.C
+    header = open(os.path.join(ROOT, 'include', 'opfx.h')).read()
+    for name in ('opfx_case', 'opfx_plan_info', 'opfx_solve_opts', 'opfx_env_desc', 'opfx_step_io', 'opfx_profile_desc',
+                 'opfx_reset_desc', 'opfx_reset_io'):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), header, re.S).group(1)
+        first = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(('/*', '*'))][0]
+        assert first.startswith('uint32_t struct_size;'), (name, first)
+    for cls in (capi.CaseStruct, capi.PlanInfo, capi.SolveOpts, capi.EnvDesc, capi.StepIO, capi.ProfileDesc, capi.ResetDesc,
+                capi.ResetIO, capi.DebugOpts):
+        assert cls._fields_[0][0] == 'struct_size' and cls().struct_size == C.sizeof(cls)
+    # the ctypes layouts equal the C compiler's: sizeof of every struct through a tiny C program
+    import subprocess, tempfile
+    names = ['opfx_case', 'opfx_plan_info', 'opfx_solve_opts', 'opfx_env_desc', 'opfx_step_io', 'opfx_profile_desc',
+             'opfx_reset_desc', 'opfx_reset_io', 'opfx_debug_opts']
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, 's.c')
+        open(src, 'w').write('#include <stdio.h>\n#include "opfx_debug.h"\nint main(void) {' +
+                             ''.join(f'printf("%zu\\n", sizeof({n}));' for n in names) + 'return 0; }\n')
+        subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), src, '-o',
+                        os.path.join(td, 's')], check=True)
+        sizes = [int(x) for x in subprocess.run([os.path.join(td, 's')], capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(c) for c in (capi.CaseStruct, capi.PlanInfo, capi.SolveOpts, capi.EnvDesc, capi.StepIO,
+                                          capi.ProfileDesc, capi.ResetDesc, capi.ResetIO, capi.DebugOpts)]
+    # a case with a wrong size: refused, with the expected size in the text
+    case = net_to_case(grids.two_bus())
+    plan = capi.Plan(case)                                   # (the right size works)
+    cs = capi.CaseStruct()
+    cs.nb, cs.nbr = 2, 1
+    h = C.c_void_p()
+    for wrong in (0, C.sizeof(capi.CaseStruct) - 16, C.sizeof(capi.CaseStruct) + 8):
+        cs.struct_size = wrong
+        assert built_lib.opfx_plan_create(C.byref(cs), C.byref(h)) == -1
+        msg = built_lib.opfx_last_error().decode()
+        assert 'struct_size' in msg and str(C.sizeof(capi.CaseStruct)) in msg, msg
+    info = capi.PlanInfo()
+    info.struct_size = C.sizeof(capi.PlanInfo) + 4
+    assert built_lib.opfx_plan_get_info(plan.handle, C.byref(info)) == -1
+    # an out-struct of an older, shorter layout gets its prefix only (members are appended, never inserted)
+    info = capi.PlanInfo()
+    info.struct_size = 6 * 4
+    info.nnz_y = -7
+    assert built_lib.opfx_plan_get_info(plan.handle, C.byref(info)) == 0
+    assert (info.nb, info.nbr, info.nref, info.npq) == (2, 1, 1, 1) and info.nnz_y == -7
+    dbg = capi.DebugOpts()
+    dbg.struct_size = 8
+    assert built_lib.opfx_plan_create_debug(C.byref(capi.Plan(case).case_struct), C.byref(dbg), C.byref(h)) == -1
+    assert 'opfx_debug_opts' in built_lib.opfx_last_error().decode()
+
+
+def test_developer_switches_travel_in_an_explicit_struct(built_lib, monkeypatch):
+    """include/opfx_debug.h: what used to be OPFX_* environment variables of the LIBRARY is a struct handed to the *_debug
+    constructors; the binding fills it from its own process environment (debug_from_env) or takes it explicitly."""
+    case = net_to_case(grids.get_grid('1-HV-mixed--0-sw')[0])
+    default = capi.Plan(case).info
+    d = capi.DebugOpts()
+    d.plan_search = -1
+    first = capi.Plan(case, debug=d).info
+    monkeypatch.setenv('OPFX_PLAN_SEARCH', '0')
+    assert capi.debug_from_env().plan_search == -1 and capi.Plan(case).info == first
+    monkeypatch.delenv('OPFX_PLAN_SEARCH')
+    d = capi.DebugOpts()
+    d.plan_no_tail = 1
+    assert capi.Plan(case, debug=d).info['tail_m'] == 0 and default['tail_m'] > 0
+    assert not capi.debug_from_env({}).any()
+    e = capi.debug_from_env({'OPFX_TEAM': '2', 'OPFX_QUEUE': '0', 'OPFX_FORCE_MEM': '1', 'OPFX_PACKED': '1'})
+    assert (e.team, e.queue, e.force_mem, e.packed) == (2, -1, 1, 1)
 
 
 def test_bad_arguments_return_status_not_exceptions(built_lib):
