@@ -267,20 +267,200 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
 
 
+def source_sha16():
+    """Hash of the sources the kernels are built from: profiles/pmc_latest.json records it with the counters, and counters
+    taken from another state of the sources are not mixed into a line."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h', 'include/opfx.h'):
+        h.update(open(os.path.join(ROOT, rel), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def percentile(v, q):
+    return float(np.percentile(np.asarray(v, float), q))
+
+
+def timed_windows(one_step, steps, windows, world, device, flush=None):
+    """`windows` timed regions of exactly `steps` steps each, every one bracketed by a barrier + synchronize on both sides,
+    the elapsed time of a window = max over ranks; HIP events on the launch stream around the same regions.  Returns
+    (wall seconds per window, device milliseconds per window, the last step's info, what `flush` returned last)."""
+    import torch
+    import torch.distributed as dist
+    wall, dev_ms, info, tail = [], [], None, None
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            info = one_step()
+        ev1.record()
+        if flush is not None:                  # (the last step's gather belongs to the timed region)
+            tail = flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        wall.append(el)
+        dev_ms.append(ev0.elapsed_time(ev1))
+    return wall, dev_ms, info, tail
+
+
+def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, device):
+    """The resources that could bound the step kernel, each as achieved / its own peak (DESIGN.md §4 Roofline)."""
+    import torch
+    ki = env.kernel_info()
+    team = ki['waves_per_instance']
+    bm = byte_model(env, mean_it_total / solves_per_step, solves_per_step)
+    lm = lds_model(env, mean_it_total / solves_per_step, solves_per_step, team)
+    kernel_s = kernel_ms * 1e-3
+    props = torch.cuda.get_device_properties(device)
+    n_cu = int(props.multi_processor_count)
+    n_simd, n_xcd = 4 * n_cu, 8
+    algorithmic = bm['B_step'] * B / kernel_s / 1e9              # GB/s, SURVEY §8d model
+    # ---- what the committed rocprofv3 passes of this configuration measured (profiles/pmc_latest.json) ----
+    pm = measured_counters(config, B)
+    stale = bool(pm) and pm.get('source_sha16') != source_sha16()
+    if stale:                                  # counters of another state of the sources: not mixed into this line
+        pm = {}
+    sq = pm.get('sq', {})
+    traffic, traffic_raw = pm.get('hbm_bytes_per_launch_fetch_x2'), pm.get('hbm_bytes_per_launch_raw')
+    cycles = sq['GRBM_GUI_ACTIVE'] / n_xcd if 'GRBM_GUI_ACTIVE' in sq else None      # kernel duration in GPU clocks
+    fr = {}
+    if traffic is not None:
+        # HBM: measured bytes of the profiled launch / its own duration (the profile's, so both from one run)
+        prof_s = pm.get('kernel_avg_ns', kernel_ms * 1e6) * 1e-9
+        fr['hbm'] = dict(achieved=traffic / prof_s / 1e9, peak=8000.0, unit='GB/s')
+    if cycles:
+        # SQ_ACTIVE_INST_VALU counts in units of 4 cycles (quad-cycles), per SIMD; SQ_LDS_IDX_ACTIVE in LDS-array
+        # cycles, per CU (MI355X_MICROARCH.md, LDS section; VERDICT r02 recomputation)
+        fr['valu_issue'] = dict(achieved=sq['SQ_ACTIVE_INST_VALU'] * 4 / (n_simd * cycles), peak=1.0,
+                                unit='fraction of SIMD cycles with a vector instruction in issue')
+        fr['lds_array'] = dict(achieved=sq['SQ_LDS_IDX_ACTIVE'] / (n_cu * cycles), peak=1.0,
+                               unit='fraction of LDS-array cycles busy',
+                               bank_conflict_share=sq.get('SQ_LDS_BANK_CONFLICT', 0.0) / sq['SQ_LDS_IDX_ACTIVE'])
+    for v in fr.values():
+        v['frac'] = v['achieved'] / v['peak']
+    # LDS bytes from the plan (live) against the guide's aggregate ds_read_b64 rate
+    lds_rate = lm['bytes_per_step'] * B / kernel_s / 1e12
+    fr['lds_bytes'] = dict(achieved=lds_rate, peak=150.0, unit='TB/s', frac=lds_rate / 150.0,
+                           bytes_per_launch=lm['bytes_per_step'] * B,
+                           wave_instructions_per_launch_model=lm['lds_wave_instructions_per_step'] * B,
+                           wave_instructions_per_launch_measured=sq.get('SQ_INSTS_LDS'))
+    fp64 = bm['fp64_flops_per_step'] * B / kernel_s / 1e12
+    fr['fp64_vector'] = dict(achieved=fp64, peak=78.6, unit='TFLOP/s', frac=fp64 / 78.6)
+    if 'valu_issue' in fr:
+        # what share of the cycles the vector ALU is busy is FP64 arithmetic of the algorithm (the rest: addresses,
+        # descriptor unpacking, selects, LDS plumbing — DESIGN.md §4 "What the VALU cycles are")
+        fr['fp64_useful_of_valu_busy'] = dict(achieved=fr['fp64_vector']['frac'] / fr['valu_issue']['frac'], peak=1.0,
+                                              unit='fp64_vector.frac / valu_issue.frac', frac=fr['fp64_vector']['frac'] / fr['valu_issue']['frac'])
+    # the binding resource: the largest fraction of its own peak (none of them can exceed 1)
+    cand = {k: v['frac'] for k, v in fr.items() if k != 'fp64_useful_of_valu_busy'}
+    bound = max(cand, key=cand.get)
+    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}>'
+    # what the launch really has to read and write: the instance rows of the caller's buffers
+    buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
+                 'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
+    roof = {
+        'bound': bound, 'achieved': fr[bound]['achieved'], 'peak': fr[bound]['peak'], 'unit': fr[bound]['unit'],
+        'frac': fr[bound]['frac'],
+        'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_raw_counters': traffic_raw,
+        'kernel': kernel_name, 'kernel_ms': kernel_ms,
+        'kernel_ms_source': 'HIP events on the launch stream around the timed window (median window) / steps: device time of '
+                            'the Python step loop, host gaps between launches included',
+        'resources': fr,
+        'hbm_measured_frac': fr['hbm']['frac'] if 'hbm' in fr else None,
+        # SURVEY §8d's figure, kept with unchanged arithmetic: the bytes a memory-streaming Newton solver would
+        # move, divided by this kernel's time.  It is NOT a fraction of anything this kernel saturates (the
+        # iteration state lives in LDS) and may exceed 1
+        'algorithmic_equiv': {'achieved': algorithmic, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algorithmic / 8000.0,
+                              'algorithmic_bytes_per_launch': bm['B_step'] * B,
+                              'compulsory_io_bytes_per_launch': bm['io_bytes'] * B},
+        'buffer_io_bytes_per_launch': buffer_io,
+        'counters_from': pm.get('tag'), 'counters_source_sha16': pm.get('source_sha16'), 'source_sha16': source_sha16(),
+        'counters_dropped_as_stale': stale,
+        'hbm_target_note': 'north_star asks for >= 40 % of the HBM roofline: structurally n/a for this design — the Newton '
+                           'state is LDS-resident, HBM carries inputs + outputs only (hbm_measured_frac); the binding '
+                           'resource and its fraction are what `bound` / `frac` report',
+        'note': 'bound = the resource with the largest fraction of its own peak.  hbm / valu_issue / lds_array come '
+                'from the committed rocprofv3 passes of this configuration (profiles/pmc_latest.json <- '
+                'scripts/profile_round.sh, taken from sources with the same source_sha16; recompute from '
+                'profiles/<tag>_sq_counters.txt: VALU = SQ_ACTIVE_INST_VALU*4 / (SIMDs * GRBM_GUI_ACTIVE/8), LDS = '
+                'SQ_LDS_IDX_ACTIVE / (CUs * GRBM_GUI_ACTIVE/8)); lds_bytes, fp64_vector and algorithmic_equiv are computed '
+                'live from the plan and this run\'s kernel time'}
+    return roof, bm, lm, ki, n_cu, n_simd
+
+
+def also_config(config, device, steps, warmup):
+    """One of the other BASELINE configurations, measured briefly on this GPU after the headline: the
+    driver's one line then carries all five."""
+    import torch
+    from opfgym_amd import envs
+    cls_name, kw, B, scaling, _ = CONFIGS[config]
+    t_build = time.perf_counter()
+    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=0, **kw)
+    rng = np.random.default_rng(1234)
+    opts = {'step': rng.choice(env.train_steps, B)}
+    if env.n_uniform:
+        opts['uniform'] = rng.random((B, env.n_uniform))
+    env.reset(options=opts)
+    actions = torch.as_tensor(np.random.default_rng(4321).random((B, env.n_actions)), device=device)
+    t_build = time.perf_counter() - t_build
+    for _ in range(warmup):
+        env.step(actions)
+    wall, dev_ms, info, _ = timed_windows(lambda: env.step(actions)[4], steps, 1, 1, device)
+    solves_per_step = 1 + len(env.contingencies)
+    mean_it_total = float(info['total_iterations'].double().mean().item())
+    kernel_ms = dev_ms[0] / steps
+    roof, bm, lm, ki, _, _ = roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, device)
+    n_check = 8 if config == 5 else 64
+    err = voltage_check(env, config, min(n_check, B))
+    out = {'workload': f'{cls_name}, {kw["simbench_network_name"]} stand-in ({bm["nb"]} buses), batch={B}, '
+                       f'{solves_per_step} NR solve(s) per step',
+           'value': B * steps / wall[0], 'unit': 'env.step()/s', 'steps': steps, 'warmup': warmup,
+           'ms_per_step': wall[0] / steps * 1e3, 'kernel_ms': kernel_ms, 'kernel': roof['kernel'],
+           'nr_solves_per_s': B * solves_per_step * steps / wall[0],
+           'converged_fraction': float(info['converged'].double().mean().item()),
+           'mean_nr_iterations': float(info['iterations'].double().mean().item()),
+           'mean_nr_iterations_all_solves': mean_it_total,
+           'roofline': {'bound': roof['bound'], 'frac': roof['frac'], 'counters_from': roof['counters_from'],
+                        'algorithmic_equiv_frac': roof['algorithmic_equiv']['frac'],
+                        'fractions': {k: v['frac'] for k, v in roof['resources'].items()}},
+           'max_abs_v_err_pu': err, 'max_abs_v_err_instances': min(n_check, B), 'env_build_s': t_build}
+    env.close()
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each; value = the median window')
     ap.add_argument('--batch', type=int, default=None, help='instances per GPU (default: the configuration\'s)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--reuse-tol', type=float, default=0.0, help='opfx_solve_opts.jacobian_reuse_tol: chord steps once the mismatch is '
+                    'below this (0 = full Newton, the headline and the reference\'s algorithm)')
+    ap.add_argument('--init', choices=('flat', 'dc', 'auto'), default='flat', help="start of the Newton iteration (pandapower's `init`; "
+                    "'auto' = pandapower's own default: 'dc' on grids fed above 70 kV); the headline runs the flat start")
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='GPU measurement only (also skips the `also` block and the |V| check)')
+    ap.add_argument('--no-also', action='store_true', help='do not measure the other BASELINE configurations after the headline')
     ap.add_argument('--gather', choices=('none', 'reward', 'obs'), default=None,
                     help='per-step RCCL all-gather of the rewards (and observations) on every rank; '
                          'default: reward when N > 1')
     ap.add_argument('--dump-reward', default=None, help='rank 0 saves the rewards of the last timed step here (.npy): the '
                     'all-gathered full batch for N > 1 with --gather reward, the local batch for N = 1')
     ap.add_argument('--as-rank', type=int, default=None, help='(N = 1) use the seeds rank R of a multi-GPU run uses')
+    ap.add_argument('--of-world', type=int, default=None, help='(N = 1, with --as-rank) take the shard rank R of a world of this size owns')
     ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=10.0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
@@ -303,16 +483,21 @@ def main():
     device = f'cuda:{local_rank}'
     cls_name, kw, batch_cfg, scaling, _ = CONFIGS[args.config]
     gather_mode = args.gather or ('reward' if world > 1 else 'none')
-    if args.batch is not None:
-        B = args.batch
-    elif scaling == 'weak':
-        B = batch_cfg
-    else:                                          # strong: the configuration's total, whole instances per rank
-        lo, hi = odist.shard_bounds(batch_cfg, rank, world)
-        B = hi - lo
-    total_B = B * world if (args.batch is not None or scaling == 'weak') else batch_cfg
     seed_rank = rank if args.as_rank is None else args.as_rank
-    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=seed_rank, **kw)
+    # --batch N: N instances per GPU (weak scaling), whatever the configuration; without it the configuration's own batch —
+    # per GPU for the weak ones, as a TOTAL sharded over the ranks for the strong ones (whole instances per rank; a world
+    # size that does not divide it gives ragged shards).  --as-rank R --of-world W (single process): the shard rank R of a
+    # world of W ranks owns, with its seeds — what the multi-GPU tests compare the gathered batch against.
+    strong_total = batch_cfg if (args.batch is None and scaling == 'strong') else None
+    if strong_total is not None:
+        w_, r_ = (args.of_world, seed_rank) if (world == 1 and args.of_world) else (world, rank)
+        lo, hi = odist.shard_bounds(strong_total, r_, w_)
+        B = hi - lo
+        total_B = strong_total if world > 1 else B
+    else:
+        B = args.batch if args.batch is not None else batch_cfg
+        total_B = B * world
+    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=seed_rank, init=args.init, jacobian_reuse_tol=args.reuse_tol, **kw)
     rng = np.random.default_rng(1234 + seed_rank)
     reset_options = {'step': rng.choice(env.train_steps, B)}
     if env.n_uniform:                       # (explicit draws: a run is then a function of the rank's seed alone)
@@ -325,8 +510,8 @@ def main():
     # the gathers run behind the next step's kernel (opfgym_amd.dist.OverlappedGather): the full batch of step k is
     # available while step k+1 is simulated, as a learner consumes it; the last one is collected after the loop
     # (strong-scaling configs on a world size that does not divide the batch give ragged shards: padded and trimmed)
-    sizes = [odist.shard_bounds(total_B, r, world)[1] - odist.shard_bounds(total_B, r, world)[0] for r in range(world)] \
-        if (args.batch is None and scaling == 'strong') else None
+    sizes = [odist.shard_bounds(strong_total, r, world)[1] - odist.shard_bounds(strong_total, r, world)[0] for r in range(world)] \
+        if strong_total is not None else None
     g_reward, g_obs = odist.OverlappedGather(world, sizes), odist.OverlappedGather(world, sizes)
 
     def one_step():
@@ -337,36 +522,24 @@ def main():
                 g_obs.submit(obs)
         return info
 
-    for _ in range(args.warmup):
-        info = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # HIP events on the launch stream (torch's current stream: capi._stream()) around the SAME timed region: the device
-    # time of the K back-to-back launches, from which the kernel's average duration is taken
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        info = one_step()
-    ev1.record()
-    last_reward = None
-    if world > 1 and gather:                   # the last step's gather belongs to the timed region
-        last_reward = g_reward.flush()
+    def flush():
+        last = g_reward.flush()
         if 'obs' in gather:
             g_obs.flush()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        return last
+
+    for _ in range(args.warmup):
+        info = one_step()
+    # `windows` windows of EXACTLY --steps steps, each bracketed by a barrier + synchronize on both sides and reduced to
+    # the max over ranks; the reported time is the MEDIAN window (a 5 ms region is otherwise one sample), p10 / p90 beside it
+    wall, dev_ms, info, last_reward = timed_windows(one_step, args.steps, max(1, args.windows), world, device,
+                                                    flush if (world > 1 and gather) else None)
+    order = np.argsort(wall)
+    mid = int(order[len(order) // 2])
+    elapsed = wall[mid]
+    kernel_ms = dev_ms[mid] / args.steps
     if args.dump_reward and rank == 0:
         np.save(args.dump_reward, (last_reward if last_reward is not None else env.buf['reward']).cpu().numpy())
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64,
-                          device=device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     conv = float(info['converged'].double().mean().item())
     solves_per_step = 1 + len(env.contingencies)
     mean_it_total = float(info['total_iterations'].double().mean().item())
@@ -397,63 +570,27 @@ def main():
     cycle_ms = (time.perf_counter() - t1) / n_cyc * 1e3
 
     if rank == 0:
-        ki = env.kernel_info()
-        team = ki['waves_per_instance']
-        bm = byte_model(env, mean_it_total / solves_per_step, solves_per_step)
-        lm = lds_model(env, mean_it_total / solves_per_step, solves_per_step, team)
-        kernel_s = kernel_ms * 1e-3
-        props = torch.cuda.get_device_properties(device)
-        n_cu = int(props.multi_processor_count)
-        n_simd, n_xcd = 4 * n_cu, 8
-        algorithmic = bm['B_step'] * B / kernel_s / 1e9              # GB/s, SURVEY §8d model
-        # ---- what the committed rocprofv3 passes of this configuration measured (profiles/pmc_latest.json) ----
-        pm = measured_counters(args.config, B)
-        sq = pm.get('sq', {})
-        traffic, traffic_raw = pm.get('hbm_bytes_per_launch_fetch_x2'), pm.get('hbm_bytes_per_launch_raw')
-        cycles = sq['GRBM_GUI_ACTIVE'] / n_xcd if 'GRBM_GUI_ACTIVE' in sq else None      # kernel duration in GPU clocks
-        fr = {}
-        if traffic is not None:
-            # HBM: measured bytes of the profiled launch / its own duration (the profile's, so both from one run)
-            prof_s = pm.get('kernel_avg_ns', kernel_ms * 1e6) * 1e-9
-            fr['hbm'] = dict(achieved=traffic / prof_s / 1e9, peak=8000.0, unit='GB/s')
-        if cycles:
-            # SQ_ACTIVE_INST_VALU counts in units of 4 cycles (quad-cycles), per SIMD; SQ_LDS_IDX_ACTIVE in LDS-array
-            # cycles, per CU (MI355X_MICROARCH.md, LDS section; VERDICT r02 recomputation)
-            fr['valu_issue'] = dict(achieved=sq['SQ_ACTIVE_INST_VALU'] * 4 / (n_simd * cycles), peak=1.0,
-                                    unit='fraction of SIMD cycles with a vector instruction in issue')
-            fr['lds_array'] = dict(achieved=sq['SQ_LDS_IDX_ACTIVE'] / (n_cu * cycles), peak=1.0,
-                                   unit='fraction of LDS-array cycles busy',
-                                   bank_conflict_share=sq.get('SQ_LDS_BANK_CONFLICT', 0.0) / sq['SQ_LDS_IDX_ACTIVE'])
-        for v in fr.values():
-            v['frac'] = v['achieved'] / v['peak']
-        # LDS bytes from the plan (live) against the guide's aggregate ds_read_b64 rate
-        lds_rate = lm['bytes_per_step'] * B / kernel_s / 1e12
-        fr['lds_bytes'] = dict(achieved=lds_rate, peak=150.0, unit='TB/s', frac=lds_rate / 150.0,
-                               bytes_per_launch=lm['bytes_per_step'] * B,
-                               wave_instructions_per_launch_model=lm['lds_wave_instructions_per_step'] * B,
-                               wave_instructions_per_launch_measured=sq.get('SQ_INSTS_LDS'))
-        fp64 = bm['fp64_flops_per_step'] * B / kernel_s / 1e12
-        fr['fp64_vector'] = dict(achieved=fp64, peak=78.6, unit='TFLOP/s', frac=fp64 / 78.6)
-        # the binding resource: the largest fraction of its own peak (none of them can exceed 1)
-        cand = {k: v['frac'] for k, v in fr.items()}
-        bound = max(cand, key=cand.get)
-        kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}>'
-        # what the launch really has to read and write: the instance rows of the caller's buffers
-        buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
-                     'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
+        roof, bm, lm, ki, n_cu, n_simd = roofline_of(env, args.config, B, kernel_ms, mean_it_total, solves_per_step, device)
+        roof['kernel_ms_back_to_back_helper'] = kernel_ms_helper
+        per_step_ms = [w / args.steps * 1e3 for w in wall]
         out = {
             'metric': 'env.step()/s (batched NR power-flow solves/s) at batch 8192',
             'value': total_B * args.steps / elapsed,
             'unit': 'env.step()/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': scaling if args.batch is None else 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong_total is not None else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
+            'timing': {'windows': len(wall), 'steps_per_window': args.steps, 'reported': 'median window',
+                       'ms_per_step_windows': per_step_ms, 'ms_per_step_p10': percentile(per_step_ms, 10),
+                       'ms_per_step_p90': percentile(per_step_ms, 90), 'ms_per_step_min': min(per_step_ms)},
             'config': {'workload': f'BASELINE config {args.config}: {cls_name} env, synthetic stand-in for SimBench '
                                    f'{kw["simbench_network_name"]} ({bm["nb"]} buses), batch={total_B} '
                                    f'({B} per GPU), {solves_per_step} NR solve(s) per step, step() only',
                        'baseline_config': args.config, 'batch_per_gpu': B, 'batch_total': total_B,
-                       'parallelism': f'shard{world}',
+                       'parallelism': f'shard{world}', 'newton_variant': 'full Newton (a Jacobian factorisation per iteration)' if not args.reuse_tol else
+                                         f'Shamanskii / chord steps below a mismatch of {args.reuse_tol:g} (jacobian_reuse_tol; opt-in, NOT the reference\'s algorithm)',
+                       'newton_start': env.init,
                        'collective': {'none': 'none', 'reward': 'all_gather(reward), overlapped with the next step', 'obs': 'all_gather(reward+obs), overlapped with the next step'}[gather_mode] if world > 1 else 'none',
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it_base,
                        'mean_nr_iterations_all_solves': mean_it_total, 'solves_per_step': solves_per_step,
@@ -464,37 +601,31 @@ def main():
                        'tolerance_pu': env.solve_opts.tol, 'byte_model': bm, 'lds_model': lm,
                        'kernel_launch': {k: ki[k] for k in ('waves_per_instance', 'lds_bytes_per_instance', 'instances_per_cu')},
                        'device': {'compute_units': n_cu, 'simds': n_simd}},
-            'roofline': {
-                'bound': bound, 'achieved': fr[bound]['achieved'], 'peak': fr[bound]['peak'], 'unit': fr[bound]['unit'],
-                'frac': fr[bound]['frac'],
-                'traffic': traffic, 'traffic_unit': 'bytes per launch', 'traffic_raw_counters': traffic_raw,
-                'kernel': kernel_name, 'kernel_ms': kernel_ms, 'kernel_ms_source': 'HIP events on the launch stream around the timed region / steps',
-                'kernel_ms_back_to_back_helper': kernel_ms_helper,
-                'resources': fr,
-                'hbm_measured_frac': fr['hbm']['frac'] if 'hbm' in fr else None,
-                # SURVEY §8d's figure, kept with unchanged arithmetic: the bytes a memory-streaming Newton solver would
-                # move, divided by this kernel's time.  It is NOT a fraction of anything this kernel saturates (the
-                # iteration state lives in LDS) and may exceed 1
-                'algorithmic_equiv': {'achieved': algorithmic, 'peak': 8000.0, 'unit': 'GB/s', 'frac': algorithmic / 8000.0,
-                                      'algorithmic_bytes_per_launch': bm['B_step'] * B,
-                                      'compulsory_io_bytes_per_launch': bm['io_bytes'] * B},
-                'buffer_io_bytes_per_launch': buffer_io,
-                'counters_from': pm.get('tag'),
-                'note': 'bound = the resource with the largest fraction of its own peak.  hbm / valu_issue / lds_array come '
-                        'from the committed rocprofv3 passes of this configuration (profiles/pmc_latest.json <- '
-                        'scripts/profile_round.sh; recompute from profiles/<tag>_sq_counters.txt: VALU = '
-                        'SQ_ACTIVE_INST_VALU*4 / (SIMDs * GRBM_GUI_ACTIVE/8), LDS = SQ_LDS_IDX_ACTIVE / (CUs * '
-                        'GRBM_GUI_ACTIVE/8)); lds_bytes, fp64_vector and algorithmic_equiv are computed live from the plan '
-                        'and this run\'s kernel time'},
+            'roofline': roof,
         }
-        # timed after the GPU work, in child processes (one, then one per host core)
-        out['cpu_baseline'] = cpu_baseline(args.config) if (world == 1 and not args.no_cpu_baseline) else None
-        if out['cpu_baseline'] is not None:
-            n_check = 2 if args.config == 5 else 4
-            err = voltage_check(env, args.config, min(n_check, B))
-            out['config']['max_abs_v_err_pu'] = err
-            out['config']['max_abs_v_err_against'] = (f'CPU oracle (oracle/pf_oracle.py), base-case |V| of {min(n_check, B)} instances; '
+        full = world == 1 and not args.no_cpu_baseline
+        if full:
+            # the second half of BASELINE.json's metric, on 64 instances (8 for the N-1 configuration: 251 solves each)
+            n_check = min(8 if args.config == 5 else 64, B)
+            out['config']['max_abs_v_err_pu'] = voltage_check(env, args.config, n_check)
+            out['config']['max_abs_v_err_against'] = (f'CPU oracle (oracle/pf_oracle.py), base-case |V| of {n_check} instances; '
                                                       'pandapower is not installed here')
+        if full and not args.no_also and args.batch is None and args.as_rank is None:
+            # the other BASELINE configurations on this GPU, briefly (>= 5 steps; the N-1 configuration 3), after the
+            # headline measurement and before the CPU baseline
+            env.close()
+            del env
+            torch.cuda.empty_cache()
+            out['also'] = {}
+            for c in sorted(CONFIGS):
+                if c == args.config:
+                    continue
+                try:
+                    out['also'][f'config{c}'] = also_config(c, device, 3 if c == 5 else (20 if c == 1 else 5), 1 if c == 5 else 2)
+                except Exception as exc:           # (a failure here must not cost the headline line)
+                    out['also'][f'config{c}'] = {'error': f'{type(exc).__name__}: {exc}'}
+        # timed after the GPU work, in child processes (one, then one per host core)
+        out['cpu_baseline'] = cpu_baseline(args.config) if full else None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -103,6 +103,12 @@ typedef struct opfx_case {
    * for a branch that couples nothing) and its phase-shift injection b * (-shift [rad]); NULL: no DC start */
   const double* br_bdc;      /* [nbr] */
   const double* br_pfinj;    /* [nbr] */
+  /* optional [nb] flags (NULL: none): buses to eliminate AFTER all others.  The block LU pivots statically — a fixed
+   * elimination order, the 2x2 diagonal block of each bus as its pivot — where pandapower's SuperLU pivots partially; a
+   * bus whose own diagonal block is (numerically) singular at its turn breaks the factorisation although the Jacobian is
+   * regular (min_pivot ~ 0, min_pivot_bus names it).  Eliminated last, the same bus meets a diagonal block that carries
+   * the Schur complement of everything else: the rescue plan of `on_pivot_breakdown='resolve'` (opfgym_amd/batched_env.py). */
+  const int32_t* elim_last;
 } opfx_case;
 
 typedef struct opfx_plan opfx_plan;   /* host-side compiled structure        */
@@ -133,6 +139,14 @@ typedef struct opfx_plan_info {
   int32_t tail_m;            /* pivots of the dense tail (final levels with one pivot each), 0 = none */
   int32_t lp_ell_width;      /* off-diagonal Ybus entries per bus row in the row's own lane (LP_A_ENT: [ra][width][64]) */
   int32_t has_dc;            /* 1 = the case carried br_bdc / br_pfinj: opfx_solve_opts.init = OPFX_INIT_DC is available */
+  /* chord steps (opfx_solve_opts.jacobian_reuse_tol): rounds of the forward substitution alone (one wavefront), and the
+   * rounds / barriers per wavefront of a team's chord iteration (forward + back substitution, no factorisation) */
+  int32_t lp_rounds_f;
+  int32_t team_rounds_chord[2];
+  int32_t team_barriers_chord[2];
+  int32_t team_kb_chord[2];  /* rounds of the chord stream before the tail chain (as team_kb) */
+  int32_t lp_rounds_f_pad;   /* lp_rounds_f padded to the multiple of four the stream OPFX_ARR_LP_BCC is laid out with; its
+                              * back-substitution part follows with lp_rounds_c padded likewise */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
@@ -158,7 +172,9 @@ enum {
   OPFX_ARR_LP_TEAM2, OPFX_ARR_LP_TEAM4, /* wave-team streams [round][wave][64][4] */
   OPFX_ARR_TAIL_BUS,                    /* [32] bus | diagonal block << 16 of the dense tail's pivots */
   OPFX_ARR_TAIL_IDS,                    /* [tail_m + 1][M] U-block ids inside the tail (0xFFFF none), M = tail_m rounded up to 8 */
-  OPFX_ARR_LP_B2                        /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
+  OPFX_ARR_LP_B2,                       /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
+  OPFX_ARR_LP_BCC,                      /* chord stream of the single-wave kernels: [rf_pad + rc_pad][64][4] */
+  OPFX_ARR_LP_TEAMC2, OPFX_ARR_LP_TEAMC4 /* chord streams of the wave teams, laid out like OPFX_ARR_LP_TEAM2 / 4 */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y,
@@ -188,7 +204,8 @@ void opfx_version(int* major, int* minor, int* patch);
  * |det| / (|a11 a22| + |a12 a21|) of the 2x2 diagonal block each bus is eliminated
  * with (1 = no cancellation; towards 0 the static pivoting inside the blocks is
  * breaking down and a "not converged" may be numerical, not physical; NaN from the
- * first-generation fallback kernel, which does not monitor it).
+ * first-generation fallback kernel, which does not monitor it).  min_pivot_bus [B]: the bus that pivot belongs
+ * to (-1: none recorded) — where a breakdown of the static pivoting sits, see opfx_case.elim_last.
  * q_inj at a PV bus is the reactive injection of everything EXCEPT the voltage-
  * controlling generator there (so Qgen = Qcalc - q_inj); qg_min/qg_max [nb]
  * p.u. (NULL = unlimited) are the generator capability used by enforce_q_lims.
@@ -216,6 +233,13 @@ typedef struct opfx_solve_opts {
                               * start, as the reference does by calling pandapower anew
                               * (security_constrained.py:53): identical iteration counts and identical
                               * behaviour next to voltage collapse */
+  double jacobian_reuse_tol; /* 0 (default): full Newton, a Jacobian factorisation in every iteration — what pandapower does.
+                              * theta > 0 (Shamanskii / chord steps): once the mismatch norm of an iteration is below theta,
+                              * the LATER iterations of that solve keep its factorisation — mismatch, forward and back
+                              * substitution only, no Jacobian, no block LU — for as long as each such step cuts the norm
+                              * at least tenfold (else the next iteration factorises again).  Same fixed point and same
+                              * tolerance test; the iterates differ from full Newton's after the switch, so iteration
+                              * counts and the last digits of V may differ from pandapower's.  Sensible: 1e-3 ... 1e-1 */
 } opfx_solve_opts;
 
 int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,
@@ -223,7 +247,7 @@ int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_in
                const int32_t* outage, const opfx_solve_opts* opts,
                double* vm, double* va, double* loading, double* s_ref, double* q_gen,
                uint8_t* converged, int32_t* iterations, double* max_mismatch,
-               double* min_pivot, void* stream);
+               double* min_pivot, int32_t* min_pivot_bus, void* stream);
 
 /* ---- environment evaluation ------------------------------------------------
  * Per-instance state lives in one row-major column store x[B,nx] owned by the
@@ -388,6 +412,7 @@ typedef struct opfx_step_io {
   double* max_mismatch;      /* [B]                                          */
   int32_t* total_iterations; /* [B]  NR iterations summed over the base case and every contingency solve */
   double* min_pivot;         /* [B]  smallest relative 2x2 pivot of all solves of the step, see opfx_solve */
+  int32_t* min_pivot_bus;    /* [B]  the bus it belongs to (-1: none), see opfx_solve */
 } opfx_step_io;
 
 /* One env.step() for B instances: apply actions → injections → NR → results →

@@ -34,8 +34,6 @@ typedef struct opfx_debug_opts {
   int32_t plan_no_pack;      /* 1: every block keeps four values                                                */
   int32_t plan_no_riders;    /* 1: forward-substitution terms as items of their own                             */
   int32_t plan_no_tail;      /* 1: no register chain for the dense tail                                         */
-  int32_t plan_ordering;     /* 0: default (minimum degree, searched); 1: minimum degree only; 2: nested
-                              * dissection only (experiment of round 4)                          */
   /* ---- context (opfx_ctx_create_debug): kept by the context, read by everything created on it -------------- */
   int32_t team;              /* 1 / 2 / 4: wavefronts per instance                                              */
   int32_t queue;             /* 1: work queue always, -1: fixed shares always                                   */

@@ -292,8 +292,25 @@ class BatchedOpfEnv:
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
                  defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False,
-                 contingency_start='base_case', init='flat', **kwargs):
+                 contingency_start='base_case', init='flat', jacobian_reuse_tol=0.0, resample_failed_resets=True,
+                 on_pivot_breakdown='ignore', **kwargs):
         from .objectives import QuadraticDeviation
+        # on_pivot_breakdown: the block LU pivots statically (fixed elimination order, the 2x2 diagonal block of a bus as its
+        # pivot), pandapower's SuperLU partially.  'ignore' (default): a row whose factorisation broke down is a failed row
+        # like any other (`converged` 0; `min_pivot` ~ 0 and `min_pivot_bus` say why).  'resolve': such rows — not
+        # converged AND min_pivot < 1e-8 — are solved once more ON THE GPU with a rescue plan that eliminates the
+        # offending buses last (opfx_case.elim_last), where their diagonal blocks carry the Schur complement of the rest;
+        # costs one host synchronisation per step (the count of such rows) and nothing else while there are none
+        assert on_pivot_breakdown in ('ignore', 'resolve'), on_pivot_breakdown
+        self.on_pivot_breakdown = on_pivot_breakdown
+        self.pivot_rescues = 0                 # rows re-solved / recovered so far (diagnostics)
+        self.pivot_rescues_recovered = 0
+        self._rescue_envs = {}
+        # resample_failed_resets (environments whose reset runs a power flow, opf_env.py:209-214): True re-samples the rows
+        # whose power flow failed, which needs the convergence flags on the HOST after every reset (one stream
+        # synchronisation per reset); False leaves such rows as they are (NaN observation, `converged` 0 in the buffers)
+        # and keeps reset() asynchronous
+        self.resample_failed_resets = bool(resample_failed_resets)
         terms = objective_function if isinstance(objective_function, (list, tuple)) else \
             ([objective_function] if objective_function is not None else [])
         if power_flow_solver is not None:
@@ -393,8 +410,13 @@ class BatchedOpfEnv:
         # flow first), 'auto' (pandapower's default: 'dc' when voltage angles are calculated, i.e. grids fed above 70 kV)
         assert init in ('flat', 'dc', 'auto'), init
         self.init = init
+        # jacobian_reuse_tol (default 0: full Newton, what pandapower does): once an iteration's mismatch is below it, the
+        # later iterations of that solve keep its factorisation (chord steps; opfx_solve_opts.jacobian_reuse_tol) — same
+        # fixed point and tolerance, cheaper iterations; iteration counts may then differ from pandapower's
+        assert jacobian_reuse_tol >= 0.0
+        self.jacobian_reuse_tol = float(jacobian_reuse_tol)
         self.solve_opts = capi.SolveOpts(tolerance, max_iteration, int(bool(enforce_q_lims)), 0,
-                                         int(contingency_start == 'flat'))
+                                         int(contingency_start == 'flat'), self.jacobian_reuse_tol)
         self.np_random = np.random.default_rng(seed)
 
         # ---- compile the grid --------------------------------------------------
@@ -990,6 +1012,8 @@ class BatchedOpfEnv:
         h = C.c_void_p()
         capi.check(capi.lib().opfx_env_create(self.ctx.handle, C.byref(d), C.byref(h)), 'opfx_env_create')
         self._env_handle = h
+        self._env_desc, self._env_desc_keep = d, keep        # (the rescue environments of on_pivot_breakdown reuse them)
+        self._rescue_envs = {}
         self.n_obs_raw = len(oidx)
         self.n_constraints = len(self.constraints)
         self.n_device_constraints = len(self.device_constraints)
@@ -1061,7 +1085,8 @@ class BatchedOpfEnv:
             objective=t.zeros(B, **f64), results=t.zeros(B, self.n_results, **f64),
             mean_correction=t.zeros(B, **f64), converged=t.zeros(B, **u8),
             iterations=t.zeros(B, dtype=t.int32, device=dev), max_mismatch=t.zeros(B, **f64),
-            total_iterations=t.zeros(B, dtype=t.int32, device=dev), min_pivot=t.zeros(B, **f64))
+            total_iterations=t.zeros(B, dtype=t.int32, device=dev), min_pivot=t.zeros(B, **f64),
+            min_pivot_bus=t.zeros(B, dtype=t.int32, device=dev))
         self.initial_obj = t.zeros(B, **f64)
         self.step_count = t.zeros(B, dtype=t.int32, device=dev)
         self.steps_dev = t.zeros(B, dtype=t.int32, device=dev)
@@ -1090,9 +1115,55 @@ class BatchedOpfEnv:
         self._objective_is_diff = bool(with_initial_obj)
         self._last_host = None
         io = self._io(action, with_initial_obj)
+        resolve = self.on_pivot_breakdown == 'resolve' and mode in (0, 1, 4, 5)
+        # (incremental actions are applied to the row in place: the rescue starts from the row as it was)
+        x_before = self.x.clone() if resolve and self.diff_action_step_size and mode == 0 else None
         with self.torch.cuda.device(self.device):
             capi.check(capi.lib().opfx_step(self._env_handle, self.B, C.byref(io), C.byref(self.solve_opts),
                                             mode, capi._stream()), 'opfx_step')
+        if resolve:
+            self._rescue_pivot_breakdown(action, mode, with_initial_obj, x_before)
+
+    PIVOT_BREAKDOWN = 1e-8
+
+    def _rescue_pivot_breakdown(self, action, mode, with_initial_obj, x_before):
+        """Rows whose factorisation broke down (not converged, min_pivot < 1e-8) once more, on a plan that eliminates the
+        buses named by `min_pivot_bus` last (see `on_pivot_breakdown`): gathered into a compact batch, stepped by a second
+        environment object on that plan (same descriptor), scattered back.  GPU only — there is no CPU fallback."""
+        t, b = self.torch, self.buf
+        bad = (~b['converged']) & (b['min_pivot'] < self.PIVOT_BREAKDOWN) & (b['min_pivot_bus'] >= 0)
+        if not bool(bad.any()):                                            # (the one host synchronisation of this option)
+            return
+        idx = bad.nonzero().flatten()
+        buses = tuple(sorted(set(b['min_pivot_bus'][idx].cpu().tolist())))
+        if buses not in self._rescue_envs:
+            plan = capi.Plan(self.case, elim_last=buses)
+            ctx = capi.Context(plan, self.device.index or 0)
+            h = C.c_void_p()
+            capi.check(capi.lib().opfx_env_create(ctx.handle, C.byref(self._env_desc), C.byref(h)), 'opfx_env_create (rescue plan)')
+            self._rescue_envs[buses] = (plan, ctx, h)
+        _, _, handle = self._rescue_envs[buses]
+        n = int(idx.numel())
+        x2 = (x_before if x_before is not None else self.x)[idx].contiguous()
+        tmp = {name: buf[idx].contiguous() for name, buf in b.items()}
+        io = capi.StepIO()
+        io.x = x2.data_ptr()
+        act2 = action[idx].contiguous() if action is not None else None
+        io.action = act2.data_ptr() if act2 is not None else None
+        init2 = self.initial_obj[idx].contiguous() if with_initial_obj else None
+        io.initial_obj = init2.data_ptr() if init2 is not None else None
+        cnt2 = self.step_count[idx].contiguous() if self.steps_per_episode != 1 else None
+        io.step_in_episode = cnt2.data_ptr() if cnt2 is not None else None
+        io.outage = None
+        for name, buf in tmp.items():
+            setattr(io, name, buf.data_ptr())
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_step(handle, n, C.byref(io), C.byref(self.solve_opts), mode, capi._stream()), 'opfx_step (rescue plan)')
+        self.x[idx] = x2
+        for name, buf in tmp.items():
+            b[name][idx] = buf
+        self.pivot_rescues += n
+        self.pivot_rescues_recovered += int(tmp['converged'].sum().item())
 
     def _as_action(self, action):
         t = self.torch
@@ -1121,7 +1192,7 @@ class BatchedOpfEnv:
         options = options or {}
         self.power_flow_available = False                                  # opf_env.py:181 (a power flow of this reset sets it again)
         self._sample_and_initialise(options)
-        if self.pf_for_obs and not bool(self.buf['converged'].all()):
+        if self.pf_for_obs and self.resample_failed_resets and not bool(self.buf['converged'].all()):
             ok = self.buf['converged'].clone()
             state = lambda: [self.x, self.steps_dev, self.initial_obj] + \
                 ([self.sampling_mode] if self.per_source else []) + list(self.buf.values())
@@ -1286,7 +1357,7 @@ class BatchedOpfEnv:
                 'unscaled_penalties': b['penalties'] if host is None else host['penalties'], 'cost': b['cost'],
                 'converged': b['converged'], 'iterations': b['iterations'],
                 'max_mismatch': b['max_mismatch'], 'objective': b['objective'],
-                'total_iterations': b['total_iterations'], 'min_pivot': b['min_pivot']}
+                'total_iterations': b['total_iterations'], 'min_pivot': b['min_pivot'], 'min_pivot_bus': b['min_pivot_bus']}
         out = (self._finish_obs(), b['reward'], b['terminated'], b['truncated'], info)
         if self.copy_outputs:
             out = tuple(v.clone() for v in out[:4]) + ({k: (v.clone() if self.torch.is_tensor(v) else v) for k, v in info.items()},)
@@ -1473,6 +1544,9 @@ class BatchedOpfEnv:
                     packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value)
 
     def close(self):
+        for _, _, h in getattr(self, '_rescue_envs', {}).values():
+            capi.lib().opfx_env_destroy(h)
+        self._rescue_envs = {}
         if self._env_handle is not None:
             capi.lib().opfx_env_destroy(self._env_handle)
             self._env_handle = None

@@ -26,7 +26,8 @@ OP_SET_CONST, OP_AFFINE, OP_SQRT_DIFF, OP_NEG, OP_UNIFORM, OP_NORMAL, OP_CLIP, O
 ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BLK',
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
-          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2']
+          'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2',
+          'LP_BCC', 'LP_TEAMC2', 'LP_TEAMC4']
 DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y', 'LP_DC', 'LP_H_DC']
 
 _pd = C.POINTER(C.c_double)
@@ -53,7 +54,7 @@ class CaseStruct(Sized):
     _fields_ = [('struct_size', C.c_uint32), ('nb', C.c_int32), ('nbr', C.c_int32), ('base_mva', C.c_double),
                 ('bus_type', _pi), ('vm_set', _pd), ('va_set', _pd), ('gs', _pd), ('bs', _pd),
                 ('br_f', _pi), ('br_t', _pi), ('br_y', _pd), ('br_kf', _pd), ('br_kt', _pd),
-                ('br_bdc', _pd), ('br_pfinj', _pd)]
+                ('br_bdc', _pd), ('br_pfinj', _pd), ('elim_last', _pi)]
 
 
 class PlanInfo(Sized):
@@ -62,7 +63,9 @@ class PlanInfo(Sized):
         'n_targets', 'n_sources', 'n_uterms', 'max_level_width', 'lds_doubles',
         'lp_rounds_a', 'lp_rounds_h', 'lp_rounds_b', 'lp_rounds_c', 'n_full',
         'team_rounds_2', 'team_rounds_4', 'team_barriers_2', 'team_barriers_4', 'n_groups',
-        'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width', 'has_dc')]
+        'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width', 'has_dc', 'lp_rounds_f', 'team_rounds_chord_2',
+        'team_rounds_chord_4', 'team_barriers_chord_2', 'team_barriers_chord_4', 'team_kb_chord_2', 'team_kb_chord_4',
+        'lp_rounds_f_pad')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_size'}
@@ -71,10 +74,11 @@ class PlanInfo(Sized):
 class SolveOpts(Sized):
     _fields_ = [('struct_size', C.c_uint32), ('reserved0', C.c_int32),
                 ('tol', C.c_double), ('max_iter', C.c_int32), ('enforce_q_lims', C.c_int32),
-                ('init', C.c_int32), ('contingency_start', C.c_int32)]
+                ('init', C.c_int32), ('contingency_start', C.c_int32), ('jacobian_reuse_tol', C.c_double)]
 
-    def __init__(self, tol=1e-8, max_iter=10, enforce_q_lims=0, init=0, contingency_start=0):
-        super().__init__(0, float(tol), int(max_iter), int(enforce_q_lims), int(init), int(contingency_start))
+    def __init__(self, tol=1e-8, max_iter=10, enforce_q_lims=0, init=0, contingency_start=0, jacobian_reuse_tol=0.0):
+        super().__init__(0, float(tol), int(max_iter), int(enforce_q_lims), int(init), int(contingency_start),
+                         float(jacobian_reuse_tol))
 
 
 INIT = {'flat': 0, 'dc': 1}
@@ -129,7 +133,7 @@ class StepIO(Sized):
                 ('penalties', C.c_void_p), ('cost', C.c_void_p), ('objective', C.c_void_p),
                 ('results', C.c_void_p), ('mean_correction', C.c_void_p),
                 ('converged', C.c_void_p), ('iterations', C.c_void_p), ('max_mismatch', C.c_void_p),
-                ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p)]
+                ('total_iterations', C.c_void_p), ('min_pivot', C.c_void_p), ('min_pivot_bus', C.c_void_p)]
 
 
 class ProfileDesc(Sized):
@@ -158,7 +162,7 @@ class DebugOpts(Sized):
     """include/opfx_debug.h: developer switches, handed explicitly to the *_debug constructors (0 = library default)."""
     _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in (
         'plan_search', 'plan_dcap_slack', 'plan_seed', 'plan_no_bank', 'plan_no_pack', 'plan_no_riders', 'plan_no_tail',
-        'plan_ordering', 'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
+        'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
         'reset_team')]
 
     def any(self):
@@ -181,7 +185,6 @@ def debug_from_env(environ=None) -> DebugOpts:
         d.plan_search = int(e['OPFX_PLAN_SEARCH']) or -1
     d.plan_dcap_slack = int(e.get('OPFX_PLAN_DCAP_SLACK') or 0)
     d.plan_seed = int(e.get('OPFX_PLAN_SEED') or 0)
-    d.plan_ordering = int(e.get('OPFX_PLAN_ORDERING') or 0)
     d.plan_no_bank, d.plan_no_pack = flag('OPFX_PLAN_NO_BANK'), flag('OPFX_PLAN_NO_PACK')
     d.plan_no_riders, d.plan_no_tail = flag('OPFX_NO_RIDERS'), flag('OPFX_NO_TAIL')
     d.team = int(e.get('OPFX_TEAM') or 0)
@@ -240,7 +243,7 @@ def lib():
     L.opfx_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.opfx_ctx_destroy.argtypes = [vp]
     L.opfx_ctx_destroy.restype = None
-    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 10
+    L.opfx_solve.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.POINTER(SolveOpts)] + [vp] * 11
     L.opfx_env_create.argtypes = [vp, C.POINTER(EnvDesc), C.POINTER(vp)]
     L.opfx_env_destroy.argtypes = [vp]
     L.opfx_env_destroy.restype = None
@@ -274,8 +277,11 @@ def _i(a):
 class Plan:
     """Host-side compiled grid plan (opfx_plan)."""
 
-    def __init__(self, case, debug: DebugOpts = None):
+    def __init__(self, case, debug: DebugOpts = None, elim_last=None):
+        """elim_last: bus indices (of the case) to eliminate after all others — the rescue ordering for a breakdown of
+        the static pivoting at those buses (opfx_case.elim_last, `min_pivot_bus`)."""
         self.case = case
+        self.elim_last = None if elim_last is None else sorted(int(b) for b in elim_last)
         self.debug = debug if debug is not None else debug_from_env()
         keep = []
         cs = CaseStruct()
@@ -300,6 +306,12 @@ class Plan:
                 a, p = _d(np.asarray(arr, dtype=float))
                 keep.append(a)
                 setattr(cs, name, p)
+        if self.elim_last:
+            flags = np.zeros(case.nb, dtype=np.int32)
+            flags[self.elim_last] = 1
+            a, p = _i(flags)
+            keep.append(a)
+            cs.elim_last = p
         self.branch_y = ya
         self.case_struct, self._keep = cs, keep
         h = C.c_void_p()
@@ -382,7 +394,8 @@ def _stream():
 
 
 def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, tol=1e-8,
-          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref', 'q_gen'), init='flat'):
+          max_iter=10, enforce_q_lims=False, want=('vm', 'va', 'loading', 's_ref', 'q_gen'), init='flat',
+          jacobian_reuse_tol=0.0):
     """Batched power flow on torch CUDA tensors p_inj/q_inj [B, nb] (p.u.)."""
     import torch
     assert p_inj.is_cuda and p_inj.dtype == torch.float64 and p_inj.shape == q_inj.shape
@@ -405,11 +418,13 @@ def solve(ctx: Context, p_inj, q_inj, *, qg_min=None, qg_max=None, outage=None, 
     out['iterations'] = torch.empty(B, dtype=torch.int32, device=dev)
     out['max_mismatch'] = torch.empty(B, dtype=torch.float64, device=dev)
     out['min_pivot'] = torch.empty(B, dtype=torch.float64, device=dev)
-    opts = SolveOpts(tol, max_iter, int(bool(enforce_q_lims)), INIT[init], 0)
+    out['min_pivot_bus'] = torch.empty(B, dtype=torch.int32, device=dev)
+    opts = SolveOpts(tol, max_iter, int(bool(enforce_q_lims)), INIT[init], 0, jacobian_reuse_tol)
     with torch.cuda.device(dev):
         check(lib().opfx_solve(
             ctx.handle, B, _ptr(p_inj.contiguous()), _ptr(q_inj.contiguous()), _ptr(qg_min), _ptr(qg_max),
             _ptr(outage), C.byref(opts), _ptr(out.get('vm')), _ptr(out.get('va')),
             _ptr(out.get('loading')), _ptr(out.get('s_ref')), _ptr(out.get('q_gen')), _ptr(out['converged']),
-            _ptr(out['iterations']), _ptr(out['max_mismatch']), _ptr(out['min_pivot']), _stream()), 'opfx_solve')
+            _ptr(out['iterations']), _ptr(out['max_mismatch']), _ptr(out['min_pivot']), _ptr(out['min_pivot_bus']),
+            _stream()), 'opfx_solve')
     return out

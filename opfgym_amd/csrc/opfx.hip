@@ -71,6 +71,8 @@ struct DevPlan {
   int ra, rh, rb, rc;
   unsigned long long* stamps; // developer probe (opfx_debug_opts.stamps): per-phase cycle sums of workgroup 0
   const unsigned *lp_bc, *lp_apk, *lp_hpk;
+  const unsigned* lp_bcc;                // chord stream (plan.h): [rf rounds forward substitution | rc rounds back substitution]
+  int rf;                                // its forward part, padded rounds
   const int* lp_hrows;
   int n_hrows;
   const unsigned *lp_team2, *lp_team4;   // per-wave streams of the cooperative kernels (plan.h)
@@ -78,6 +80,8 @@ struct DevPlan {
   const unsigned* tail_bus;              // [32] bus | diagonal block << 16 of tail pivot e
   const unsigned short* tail_ids;        // [tail_m][M] id of U-block (row e, column s) at [e * M + s], M = tail_m rounded up to 8
   int team_rounds2, team_rounds4, team_kb2, team_kb4;
+  const unsigned *lp_teamc2, *lp_teamc4; // chord streams of the teams
+  int team_roundsc2, team_roundsc4, team_kbc2, team_kbc4;
   const double *lp_dc, *lp_hdc;          // DC start (plan.h): B' on the Ybus pattern + constant right-hand side; nullptr: none
   double* blk_mem;           // memory-resident kernels: [resident workgroups][blk_mem_stride] LU block values
   long long blk_mem_stride;
@@ -129,6 +133,7 @@ struct SolveIO {
   unsigned char* converged;
   int* iterations;
   double* min_pivot;
+  int* min_pivot_bus;
   int queued;                // as StepIO::queued
 };
 
@@ -143,6 +148,7 @@ struct StepIO {
   int* iterations;
   int* total_iterations;
   double* min_pivot;
+  int* min_pivot_bus;
   int mode;
   int queued;                // instances beyond a workgroup's first come from the context's work queue (many per workgroup)
 };
@@ -153,6 +159,7 @@ struct Opts {
   int enforce_q_lims;
   int contingency_start;     // opfx_solve_opts::contingency_start
   int init;                  // opfx_solve_opts::init
+  double reuse_tol;          // opfx_solve_opts::jacobian_reuse_tol (kernels instantiated with CHORD)
 };
 
 // ---------------------------------------------------------------------------
@@ -241,6 +248,47 @@ __device__ __forceinline__ void wave_fence() {
 // __syncthreads() would drain every prefetched global load and every store (s_waitcnt vmcnt(0)).
 template <int NW> __device__ __forceinline__ void blk_sync() { if (NW == 1) wave_fence(); else __syncthreads(); }
 template <int NW> __device__ __forceinline__ void sec_sync() { wave_fence(); }
+
+// Pointers read out of a descriptor that itself lives in memory are generic to the compiler
+// (flat_load: counted on vmcnt AND lgkmcnt, serialising them with the LDS traffic); all of
+// ours are hipMalloc'ed, so say so.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+  return (const __attribute__((address_space(1))) T*)p;
+}
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
+  return (const __attribute__((address_space(4))) T*)p;
+}
+// element `idx` of an array whose base is wave-uniform: the byte offset as an unsigned 32-bit value, which is the form
+// the hardware addresses as scalar base + vector offset (no 64-bit address arithmetic per lane); arrays < 4 GiB
+template <class T>
+__device__ __forceinline__ T ld_at(const T* base, unsigned idx) {
+  typedef const __attribute__((address_space(1))) char* gbytes;
+  return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>(as_global(base)) + idx * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ void st_at(T* base, unsigned idx, T v) {
+  typedef __attribute__((address_space(1))) char* gbytes;
+  *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>((__attribute__((address_space(1))) T*)base) + idx * (unsigned)sizeof(T)) = v;
+}
+
+// A wave-uniform pointer made OPAQUE to the optimiser (two v_readfirstlane): the per-instance row pointer `array + b * n` of
+// an output array.  Without it the compiler re-associates (array + b n) + lane into (array + lane) + b n, hoists the first
+// sum — a 64-bit per-lane value — out of the instance loop and keeps it in two VGPRs through every Newton loop (the wave
+// teams' DC kernels spilled exactly those, round 4); with it the store is scalar base + 32-bit lane offset (st_at).
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// A loop index made opaque (an empty asm on its register): loop strength reduction otherwise turns `base[i]`, i = lane +
+// 64 k, into a 64-bit POINTER induction variable whose start value base + 8 lane is invariant in the instance loop, gets
+// hoisted to the kernel's entry and occupies two VGPRs through every Newton loop.  With an opaque index the access stays
+// scalar base + 32-bit offset (st_at / ld_at), one shift per element in loops that run once per instance.
+__device__ __forceinline__ unsigned opaque(unsigned i) { asm volatile("" : "+v"(i)); return i; }
 
 struct Blk { double a11, a12, a21, a22; };
 __device__ __forceinline__ Blk ld_blk(const double* blk, int id) {
@@ -649,10 +697,15 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | lo);
 }
+// FWD (kernels compiled with chord steps): the same chain run FORWARD first — the forward substitution through the tail,
+// y_e -= L_es A_ss^-1 y_s for e > s, steps s = 0 .. m-2 — when `fwd` says so (a chord iteration: the factorisation items
+// that carry the tail's forward substitution in an ordinary iteration are not walked).  The L-blocks' ids are the LOWER
+// triangle of the same table (plan.cpp: entry [e][s], e > s, = block (row e, column s)); the backward steps mask the
+// rows e >= s out before they form an address, so what they read is what they read without the lower triangle.
 struct TailBlk { double u11, u12, u21, u22; bool live; };
-template <int M>
+template <int M, bool FWD>
 __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, double& y0, double& y1,
-                                           double i11, double i12, double i21, double i22) {
+                                           double i11, double i12, double i21, double i22, bool fwd) {
   // the lane's row of U-block ids: M 16-bit entries, entry s = block (row e, column s)
   unsigned w[M / 2];
   {
@@ -660,11 +713,42 @@ __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, doub
 #pragma unroll
     for (int q = 0; q < M / 8; ++q) { const uint4 v = tr[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
   }
+#ifndef OPFX_TAIL_W
+#define OPFX_TAIL_W 2
+#endif
+  constexpr int W = OPFX_TAIL_W;
+  if (FWD && fwd) {
+    auto request_f = [&](int s) {
+      TailBlk t{0.0, 0.0, 0.0, 0.0, false};
+      if (s > M - 2) return t;                             // (compile-time after unrolling)
+      const unsigned id = (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
+      t.live = lane > s && id != 0xFFFFu;
+      const int ib = t.live ? (int)id : 0;
+      t.u11 = L.blk[bx11(L, ib)]; t.u12 = L.blk[bx12(L, ib)]; t.u21 = L.blk[bx21(L, ib)]; t.u22 = L.blk[bx22(L, ib)];
+      return t;
+    };
+    auto apply_f = [&](const TailBlk& t, int s) {
+      if (s > M - 2) return;
+      const double x0 = readlane_f64(i11 * y0 + i12 * y1, s), x1 = readlane_f64(i21 * y0 + i22 * y1, s);
+      const double n0 = fma(-t.u11, x0, fma(-t.u12, x1, y0)), n1 = fma(-t.u21, x0, fma(-t.u22, x1, y1));
+      y0 = t.live ? n0 : y0;
+      y1 = t.live ? n1 : y1;
+    };
+    // (one step at a time, no double buffering: this direction runs in chord iterations only, and the wave-team step
+    //  kernels have no registers to spare for a second window)
+#pragma unroll
+    for (int s = 0; s < M - 1; ++s) {
+      const TailBlk t = request_f(s);
+      asm volatile("" ::: "memory");
+      apply_f(t, s);
+      asm volatile("" ::: "memory");
+    }
+  }
   auto request = [&](int s) {
     TailBlk t{0.0, 0.0, 0.0, 0.0, false};
     if (s < 1) return t;                                   // (compile-time after unrolling)
     const unsigned id = (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
-    t.live = id != 0xFFFFu;                                // (a tail that is not completely filled in)
+    t.live = lane < s && id != 0xFFFFu;                    // (rows s.. are final; a tail that is not completely filled in)
     const int ib = t.live ? (int)id : 0;
     t.u11 = L.blk[bx11(L, ib)]; t.u12 = L.blk[bx12(L, ib)]; t.u21 = L.blk[bx21(L, ib)]; t.u22 = L.blk[bx22(L, ib)];
     return t;
@@ -673,14 +757,10 @@ __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, doub
     if (s < 1) return;
     const double x0 = readlane_f64(i11 * y0 + i12 * y1, s), x1 = readlane_f64(i21 * y0 + i22 * y1, s);
     const double n0 = fma(-t.u11, x0, fma(-t.u12, x1, y0)), n1 = fma(-t.u21, x0, fma(-t.u22, x1, y1));
-    const bool upd = lane < s && t.live;                   // (rows s.. are final: a constant lane mask)
-    y0 = upd ? n0 : y0;
-    y1 = upd ? n1 : y1;
+    y0 = t.live ? n0 : y0;
+    y1 = t.live ? n1 : y1;
   };
-#ifndef OPFX_TAIL_W
-#define OPFX_TAIL_W 2
-#endif
-  constexpr int W = OPFX_TAIL_W, NWIN = (M - 1 + W - 1) / W;      // steps M-1 .. 1 in windows of W
+  constexpr int NWIN = (M - 1 + W - 1) / W;                // steps M-1 .. 1 in windows of W
   TailBlk b[2][W];
 #pragma unroll
   for (int q = 0; q < W; ++q) b[0][q] = request(M - 1 - q);
@@ -700,7 +780,8 @@ __device__ __forceinline__ void tail_chain(const Lds& L, int row, int lane, doub
 // `tail`: bus | diagonal block << 16 of the lane's tail pivot (DevPlan::tail_bus, read once per solve).
 // The chain is instantiated for M = the next multiple of 8 >= tail_m; lanes >= tail_m carry y = 0 and an
 // id row of "none" (row tail_m of the table).
-__device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsigned tail) {
+template <bool FWD = false>
+__device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsigned tail, bool fwd = false) {
   const bool mine = lane < m;
   const int bus = mine ? (int)(tail & 0xFFFFu) : 0;
   const int ib = mine ? (int)(tail >> 16) : 0;         // (diagonal blocks always hold four values)
@@ -709,10 +790,10 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
   const double rdet = mine ? fast_rcp(a11 * a22 - a12 * a21) : 0.0;
   const double i11 = a22 * rdet, i12 = -a12 * rdet, i21 = -a21 * rdet, i22 = a11 * rdet;
   const int row = mine ? lane : m;                       // (row m of the table: all "none")
-  if (m <= 8) tail_chain<8>(L, row, lane, y0, y1, i11, i12, i21, i22);
-  else if (m <= 16) tail_chain<16>(L, row, lane, y0, y1, i11, i12, i21, i22);
-  else if (m <= 24) tail_chain<24>(L, row, lane, y0, y1, i11, i12, i21, i22);
-  else tail_chain<32>(L, row, lane, y0, y1, i11, i12, i21, i22);
+  if (m <= 8) tail_chain<8, FWD>(L, row, lane, y0, y1, i11, i12, i21, i22, fwd);
+  else if (m <= 16) tail_chain<16, FWD>(L, row, lane, y0, y1, i11, i12, i21, i22, fwd);
+  else if (m <= 24) tail_chain<24, FWD>(L, row, lane, y0, y1, i11, i12, i21, i22, fwd);
+  else tail_chain<32, FWD>(L, row, lane, y0, y1, i11, i12, i21, i22, fwd);
   if (mine) { L.rhs[bus] = y0; L.rq[bus] = y1; }
 }
 // One round of a wave team's B/C stream.  (Issuing the NEXT round's reads before this round computes —
@@ -747,7 +828,8 @@ __device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const ui
 // `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
 // diagonal block the bus is solved with (1 = no cancellation, -> 0 = the block is numerically singular:
 // static pivoting inside the blocks has broken down, SURVEY §7 hard part 2).
-__device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, double& dvm, double& piv) {
+// `pbus`: the bus that holds this lane's smallest pivot (where a breakdown sits: opfx_step_io.min_pivot_bus).
+__device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, double& dvm, double& piv, int& pbus) {
   const int db = L.dg[i];
   // (diagonal blocks always hold four values)
   const double a11 = L.blk[bx11(L, db)], a12 = L.blk[bx12(L, db)], a21 = L.blk[bx21(L, db)], a22 = L.blk[bx22(L, db)];
@@ -755,7 +837,11 @@ __device__ __forceinline__ void solve_pivot(const Lds& L, int i, double& dth, do
   const double p1 = a11 * a22, p2 = a12 * a21;
   const double det = p1 - p2;
   const double rdet = fast_rcp(det);
-  piv = nn_min(piv, fabs(det) * __builtin_amdgcn_rcp(fabs(p1) + fabs(p2)));
+  // (an exactly singular block with vanishing products is 0 / 0: that is a pivot of zero, not "no information")
+  const double den = fabs(p1) + fabs(p2);
+  const double ratio = den == 0.0 ? 0.0 : fabs(det) * __builtin_amdgcn_rcp(den);
+  pbus = ratio < piv ? i : pbus;
+  piv = nn_min(piv, ratio);
   dth = (a22 * y1 - a12 * y2) * rdet;
   dvm = (a11 * y2 - a21 * y1) * rdet;
 }
@@ -828,8 +914,9 @@ __device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane
 // De-energised buses (mark_island): their rows become identity rows — off-diagonal blocks 0,
 // diagonal block I, right-hand side 0.  Runs after phase A in the modifier path only (an island
 // always comes with the modifier of the branch that cut it off), re-reading the row descriptors.
+// jac = false (a chord iteration: the blocks hold the factorisation of an earlier iteration): right-hand sides only.
 template <bool PK>
-__device__ void dead_rows_patch(const DevPlan& P, const Lds& L, int lane) {
+__device__ void dead_rows_patch(const DevPlan& P, const Lds& L, int lane, bool jac = true) {
   constexpr unsigned NONE = 0xFFFFu;
   bool any = false;
   for (int i = lane; i < P.nb; i += WAVE) any = any || L.bt[i] == BT_DEAD;
@@ -838,22 +925,24 @@ __device__ void dead_rows_patch(const DevPlan& P, const Lds& L, int lane) {
   for (int h = 0; h < P.rh; ++h) {
     const uint4 he = hpk[(size_t)(h * 2 + 1) * WAVE];
     const unsigned bid = he.x >> 16;
-    if ((he.x & 0xFFFF) != NONE && bid != NONE && L.bt[he.y] == BT_DEAD) st_blk2<PK>(L, bid, Blk{0.0, 0.0, 0.0, 0.0});
+    if (jac && (he.x & 0xFFFF) != NONE && bid != NONE && L.bt[he.y] == BT_DEAD) st_blk2<PK>(L, bid, Blk{0.0, 0.0, 0.0, 0.0});
   }
   for (int r = 0; r < P.ra; ++r) {
     const ARound a = load_around(P, r, lane);
     const int i = lane + WAVE * r;
     if (i >= P.nb || L.bt[i] != BT_DEAD) continue;
     const unsigned (&ent)[KA] = a.ent;
+    if (jac) {
 #pragma unroll
-    for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) st_blk2<PK>(L, ent[k] >> 16, Blk{0.0, 0.0, 0.0, 0.0});
-    st_blk2<PK>(L, a.dw & 0xFFFF, Blk{1.0, 0.0, 0.0, 1.0});
+      for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) st_blk2<PK>(L, ent[k] >> 16, Blk{0.0, 0.0, 0.0, 0.0});
+      st_blk2<PK>(L, a.dw & 0xFFFF, Blk{1.0, 0.0, 0.0, 1.0});
+    }
     L.rhs[i] = 0.0; L.rq[i] = 0.0;
   }
 }
 
 // lanes 0 .. 2*n_mod-1: end e = lane & 1 of modifier lane >> 1
-__device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
+__device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod, bool jac = true) {
   if (lane >= 2 * n_mod) return;
   const int m = lane >> 1, e = lane & 1;
   const double* dy = mod_dy(L, m);
@@ -875,6 +964,7 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
   const bool pv = t == BT_PV;
   lds_add(&L.rhs[i], -(dcr + dyr));        // rhs = -F
   if (!pv) lds_add(&L.rq[i], -(dci + dyi));
+  if (!jac) return;                        // (chord iteration: the mismatch only)
   if (ob >= 0) {                           // dS_i/dth_j = -j c, dS_i/dln|V_j| = c
     lds_add(L.blk + blk_c(L, ob, 0), dci); lds_add(L.blk + blk_c(L, ob, 1), dcr);
     if (!pv && ob < L.nfull) { lds_add(L.blk + blk_c(L, ob, 2), -dcr); lds_add(L.blk + blk_c(L, ob, 3), dci); }   // (two-value blocks: implied)
@@ -889,7 +979,7 @@ __device__ __forceinline__ void mods_apply(const Lds& L, int lane, int n_mod) {
 // reduction — 3.8 k of the 12 k cycles of a wave-team phase A on the N-1 workload.  Only without de-energised
 // buses (their identity rows are patched after the phase, dead_rows_patch); `t` = bus type of i.
 __device__ __forceinline__ void mods_inline(const Lds& L, int n_mod, int i, int t, double vri, double vii,
-                                            double& sr, double& si, double& dyr, double& dyi) {
+                                            double& sr, double& si, double& dyr, double& dyi, bool jac = true) {
   for (int m = 0; m < n_mod; ++m) {
     const int* id = mod_ids(L, m);
     const int f = id[0], tt = id[1];
@@ -904,7 +994,7 @@ __device__ __forceinline__ void mods_inline(const Lds& L, int n_mod, int i, int 
     const double v2 = vri * vri + vii * vii;
     dyr += yii_g * v2; dyi -= yii_b * v2;                                    // conj(dY_ii)|V_i|^2
     sr += dcr; si += dci;
-    if (ob >= 0 && t != BT_REF) {          // this lane stored the block earlier in this phase: plain read-modify-write
+    if (jac && ob >= 0 && t != BT_REF) {   // this lane stored the block earlier in this phase: plain read-modify-write
       L.blk[bx11(L, ob)] += dci; L.blk[bx12(L, ob)] += dcr;
       if (t != BT_PV && ob < L.nfull) { L.blk[bx21(L, ob)] -= dcr; L.blk[bx22(L, ob)] += dci; }
     }
@@ -928,444 +1018,24 @@ __device__ __forceinline__ void mods_row_current(const Lds& L, int n_mod, int i,
   }
 }
 
-template <bool PK>
-__device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
-                        int* iters_out, double* nrm_out, double* piv_out) {
-  double piv = 1.0;
-  constexpr unsigned NONE = 0xFFFFu;
-  const int nb = P.nb;
-  // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
-  // that the compiler's wait-count insertion sees a fixed number of loads in flight and
-  // waits for the oldest only (a conditional load anywhere in these loops degrades every
-  // wait to vmcnt(0), i.e. one exposed L2 round trip per round).
-  const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc) + lane;
-  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk) + lane;
-  const int RB = P.rb, R = P.rb + P.rc;                  // padded round counts (multiples of 4, R >= 4)
-  auto ld_desc = [&](int r) { return stream[(size_t)(r < R ? r : r - R) * WAVE]; };
-  const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
-  const int fill_lo = P.fill_lo;                           // fill blocks: ids [fill_lo, fill_lo + nfill) (plan.cpp)
-
-  int it = 0;
-  double nrm = 0.0;
-  bool conv = false;
-  OPFX_STAMP_INIT();
-  ARound cur = load_around(P, 0, lane);
-  // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
-  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
-  double pcur = psp_g[lane < nb ? lane : nb - 1], qcur = qsp_g[lane < nb ? lane : nb - 1];
-  uint4 hy = make_uint4(0, 0, 0, 0), he = make_uint4(NONE | (NONE << 16), 0, 0, 0);
-  if (P.rh > 0) { hy = hpk[0]; he = hpk[WAVE]; }
-  // rounds 0..3 of phases B/C; re-loaded by the tail of phase C for the next iteration
-  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
-  while (true) {
-    // ---- phase A -----------------------------------------------------------------
-    for (int f = fill_lo + lane; f < fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
-    OPFX_STAMP(10);
-    double my = 0.0;
-    // overflow entries of rows longer than the ELL width: any row per lane, row sums accumulated in the
-    // rhs slots of those rows (zeroed first) with LDS atomics
-    if (P.rh > 0) {
-      if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
-      for (int h = lane + WAVE; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
-      wave_fence();
-      for (int h = 0; h < P.rh; ++h) {
-        const uint4 cy = hy, ce = he;
-        const int hn = h + 1 < P.rh ? h + 1 : 0;           // next round (or round 0 of the next iteration)
-        hy = hpk[(size_t)(hn * 2) * WAVE]; he = hpk[(size_t)(hn * 2 + 1) * WAVE];
-        const unsigned ent = ce.x;
-        const unsigned j = ent & 0xFFFF;
-        if (j != NONE) {
-          const int i = ce.y;
-          const double g = __longlong_as_double(((long long)cy.y << 32) | cy.x);
-          const double b = __longlong_as_double(((long long)cy.w << 32) | cy.z);
-          const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
-          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
-          const unsigned bid = ent >> 16;
-          const int t = L.bt[i];
-          if (bid != NONE) { st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci}); if (t == BT_PV) blk_zero_row2(L, bid); }
-          lds_add(&L.rhs[i], cr);
-          lds_add(&L.rq[i], ci);
-        }
-      }
-      wave_fence();
-    }
-    OPFX_STAMP(11);
-    for (int r = 0; r < P.ra; ++r) {
-      const ARound a = cur;
-      const double p_sched = pcur, q_sched = qcur;
-      {
-        const int rn = r + 1 < P.ra ? r + 1 : 0;                 // next round (or round 0 of the next iteration)
-        cur = load_around(P, rn, lane);
-        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
-        pcur = psp_g[in_]; qcur = qsp_g[in_];
-      }
-      const int i = lane + WAVE * r;
-      if (i < nb) {
-        const int t = L.bt[i];
-        const double vri = L.vr[i], vii = L.vi[i];
-        double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
-        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
-        const unsigned (&ent)[KA] = a.ent;
-        // branch-free over the ELL slots (padding slots carry Y = 0 and read V_i): the four
-        // dependency chains interleave instead of being serialised by exec-mask branches
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
-          const double g = a.y[k].x, b = a.y[k].y;
-          const double vrj = L.vr[j], vij = L.vi[j];
-          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
-          sr += cr; si += ci;
-          const unsigned bid = ent[k] >> 16;
-          if (bid != NONE) {                                 // (rows and columns of REF buses have no blocks)
-            // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c ; PV rows are patched after the loop
-            st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});
-          }
-        }
-        if (t == BT_PV) {                                    // rare: skipped as a whole when the wave has no PV row
-#pragma unroll
-          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
-        }
-        if (t != BT_REF) {
-          const double g = a.yd.x, b = a.yd.y;
-          const double v2 = vri * vri + vii * vii;
-          const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
-          const double pc = sr + yr, qc = si + yi;
-          const double fp = pc - p_sched;
-          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
-          L.rhs[i] = -fp;
-          L.rq[i] = -fq;
-          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
-          // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
-          Blk jb{-si, yr + pc, sr, yi + qc};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk2<PK>(L, a.dw & 0xFFFF, jb);
-        } else {
-          // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
-          // in its rhs slots so that the result pass needs no second walk over the row
-          const double g = a.yd.x, b = a.yd.y;
-          const double v2 = vri * vri + vii * vii;
-          L.rhs[i] = sr + g * v2;
-          L.rq[i] = si - b * v2;
-        }
-      }
-    }
-    // (the wave teams fold the modifiers into the bus rounds, mods_inline; here, where the kernel's common case has
-    //  none, even the test for it in the bus round costs 1.5 % — measured — so they keep their own pass)
-    if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
-      wave_fence();
-      dead_rows_patch<PK>(P, L, lane);
-      wave_fence();
-      mods_apply(L, lane, n_mod);
-      wave_fence();
-      my = 0.0;
-      for (int i = lane; i < nb; i += WAVE)
-        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
-    }
-    OPFX_STAMP(12);
-    // the wave-uniform decisions are votes (two instructions each); the max reduction (~45
-    // instructions) runs once, on the way out.  Same outcome as testing the reduced norm:
-    // NaN anywhere -> not converged; every row below tol -> converged; else iterate to max_iter.
-    const bool below = !wave_any(!(my < o.tol));               // (false if any lane holds a NaN)
-    if (below || wave_any(my != my) || it >= o.max_iter) {
-      nrm = wave_max_dpp(my);
-      conv = below;
-      OPFX_STAMP(1);
-      break;
-    }
-    ++it;
-    wave_fence();
-    // ---- phase B: block LU + forward substitution; phase C: back substitution ---------------
-    // Rounds of one level are independent; ordering is needed at level ends only, but on a
-    // single wave the fence is free (the LDS executes a wave's operations in order).
-#ifdef OPFX_PAIR_ROUNDS
-    // Two rounds of one elimination level (the plan's ITEM_NEXT_INDEPENDENT flag) as one step: the LDS reads of both
-    // are requested before either computes, so the second round's round trip hides behind the first round's arithmetic.
-    for (int r = 0; r < RB; r += 4) {
-      item_pair<PK, true>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
-      item_pair<PK, true>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
-    }
-    OPFX_STAMP(2);
-    for (int r = RB; r < R; r += 4) {
-      item_pair<PK, false>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
-      item_pair<PK, false>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
-    }
-#else
-    for (int r = 0; r < RB; r += 4) {
-      item_factor<PK, true>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor<PK, true>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor<PK, true>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor<PK, true>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
-    }
-    OPFX_STAMP(2);
-    for (int r = RB; r < R; r += 4) {
-      item_factor<PK, false>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor<PK, false>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor<PK, false>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor<PK, false>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
-    }
-#endif
-    OPFX_STAMP(3);
-    // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
-    for (int i = lane; i < nb; i += WAVE) {
-      if (L.bt[i] == BT_REF) continue;                 // (rhs of a REF row holds its parked injection)
-      double dth, dvm;
-      solve_pivot(L, i, dth, dvm, piv);
-      const double sc = 1.0 + dvm;
-      double sn, cs;
-      if (fabs(dth) <= 0.25) {
-        // Taylor series to x^15 / x^14, truncation error < 1e-21 (the other branch is skipped as a whole
-        // while no lane needs it: after the first iteration the steps are small)
-        const double z = dth * dth;
-        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
-             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
-        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
-             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
-      } else {
-        sincos(dth, &sn, &cs);                         // (a NaN step ends here and stays NaN)
-      }
-      const double vr = L.vr[i], vi = L.vi[i];
-      L.vr[i] = (vr * cs - vi * sn) * sc;
-      L.vi[i] = (vr * sn + vi * cs) * sc;
-    }
-    wave_fence();
-    OPFX_STAMP(4);
-  }
-  *iters_out = it;
-  *nrm_out = nrm;
+// Smallest pivot of the wavefront and the bus it belongs to: the pivots are in [0, 1], so their bit patterns order like
+// integers; the low 15 bits of the mantissa make room for the bus number and one min-reduction carries both.
+__device__ __forceinline__ void piv_argmin(double piv, int pbus, double* piv_out, int* pbus_out) {
+  const unsigned long long key = ((unsigned long long)__double_as_longlong(piv) & ~0x7FFFull) | (unsigned long long)(pbus < 0 ? 0x7FFF : pbus);
+  const unsigned long long best = (unsigned long long)__double_as_longlong(wave_min_dpp(__longlong_as_double((long long)key)));
   *piv_out = wave_min_dpp(piv);
-  return conv;
-}
-
-// ---------------------------------------------------------------------------
-// Cooperative variant for LARGE grids: NW wavefronts (one workgroup) share ONE
-// instance.  Meshed HV grids need 70-90 KB of LDS per instance, i.e. only one
-// or two instances fit a CU; with one wave each, three of the four SIMDs would
-// idle.  Here the independent rounds of a group (an elimination level, its U
-// pre-items, its solves), the bus rows and the voltage update are dealt round-
-// robin to the NW waves and groups are separated by workgroup barriers.  Update
-// terms of different waves meet in LDS atomics, so the summation order — and the
-// last bits of the result — may differ between runs (the single-wave kernel is
-// bit-reproducible).
-// ---------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
-// descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
-template <int NW, bool PK, bool MEM = false>
-__device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
-                             int* iters_out, double* nrm_out, double* piv_out, bool inline_mods) {
-  double piv = 1.0;
-  constexpr unsigned NONE = 0xFFFFu;
-  constexpr int NT = WAVE * NW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = P.nb;
-  const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
-  const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4;        // multiple of 4, >= 4
-  const int Kb = NW == 2 ? P.team_kb2 : P.team_kb4;               // rounds before the tail chain (= K without a tail)
-  auto ld_desc = [&](int k) { return stream[(size_t)(k < K ? k : k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
-  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
-  double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
-  int it = 0;
-  double nrm = 0.0;
-  bool conv = false;
-  OPFX_STAMP_INIT();
-  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
-  const unsigned tail = P.tail_bus[lane & 31];     // the lane's pivot of the dense tail (tail_solve)
-  // overflow entries of rows longer than the ELL width (phase A): the row this thread zeroes and this wavefront's first round
-  const int hrow0 = tid < P.n_hrows ? P.lp_hrows[tid] : -1;
-  uint4 hy0 = make_uint4(0, 0, 0, 0), he0 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
-  if (wave < P.rh) { hy0 = hpk[(size_t)(wave * 2) * WAVE + lane]; he0 = hpk[(size_t)(wave * 2 + 1) * WAVE + lane]; }
-  // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
-  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
-  const int r_first = wave < P.ra ? wave : 0;
-  ARound a_next = load_around(P, r_first, lane);
-  double p_next, q_next;
-  { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
-  while (true) {
-    // ---- phase A ------------------------------------------------------------------
-    // (nothing in this prologue of the phase waits for global memory: fill blocks are one contiguous id range,
-    // the overflow rows and this wavefront's first overflow round were fetched once per solve)
-    for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
-    if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
-    for (int h = tid + NT; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
-    team_sync<MEM>();
-    OPFX_STAMP(10);
-    for (int h = wave; h < P.rh; h += NW) {
-      const uint4 hy = h == wave ? hy0 : hpk[(size_t)(h * 2) * WAVE + lane];
-      const uint4 he = h == wave ? he0 : hpk[(size_t)(h * 2 + 1) * WAVE + lane];
-      const unsigned ent = he.x;
-      const unsigned j = ent & 0xFFFF;
-      if (j != NONE) {
-        const int i = he.y;
-        double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
-        double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
-        const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
-        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-        const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
-        const unsigned bid = ent >> 16;
-        const int t = L.bt[i];
-        if (bid != NONE) {
-          Blk jb{ci, cr, -cr, ci};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
-          st_blk2<PK>(L, bid, jb);
-        }
-        lds_add(&L.rhs[i], cr);
-        lds_add(&L.rq[i], ci);
-      }
-    }
-    team_sync<MEM>();
-    OPFX_STAMP(11);
-    double my = 0.0;
-    for (int r = wave; r < P.ra; r += NW) {
-      const ARound a = a_next;
-      const double p_sched = p_next, q_sched = q_next;
-      {
-        const int rn = r + NW < P.ra ? r + NW : r_first;       // (last round: first round of the next iteration)
-        a_next = load_around(P, rn, lane);
-        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
-        p_next = psp_g[in_]; q_next = qsp_g[in_];
-      }
-      const int i = lane + WAVE * r;
-      if (i < nb) {
-        const int t = L.bt[i];
-        const double vri = L.vr[i], vii = L.vi[i];
-        double sr = 0.0, si = 0.0;
-        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
-        const unsigned (&ent)[KA] = a.ent;
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
-          double g = a.y[k].x, b = a.y[k].y;
-          const double vrj = L.vr[j], vij = L.vi[j];
-          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
-          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
-          sr += cr; si += ci;
-          const unsigned bid = ent[k] >> 16;
-          if (bid != NONE) st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});   // (PV rows are patched after the loop)
-        }
-        if (t == BT_PV) {
-#pragma unroll
-          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
-        }
-        double dyr = 0.0, dyi = 0.0;
-        if (inline_mods && n_mod > 0) mods_inline(L, n_mod, i, t, vri, vii, sr, si, dyr, dyi);
-        double g = a.yd.x, b = a.yd.y;
-        const double v2 = vri * vri + vii * vii;
-        const double yr = g * v2 + dyr, yi = -b * v2 + dyi;
-        if (t != BT_REF) {
-          const double pc = sr + yr, qc = si + yi;
-          const double fp = pc - p_sched;
-          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
-          L.rhs[i] = -fp;
-          L.rq[i] = -fq;
-          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
-          Blk jb{-si, yr + pc, sr, yi + qc};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
-          st_blk2<PK>(L, a.dw & 0xFFFF, jb);
-        } else {
-          L.rhs[i] = sr + yr;
-          L.rq[i] = si + yi;
-        }
-      }
-    }
-    OPFX_STAMP(12);
-    if (n_mod > 0 && !inline_mods) {
-      team_sync<MEM>();
-      if (wave == 0) { dead_rows_patch<PK>(P, L, lane); mem_fence<MEM>(); mods_apply(L, lane, n_mod); }
-      team_sync<MEM>();
-      my = 0.0;
-      for (int i = tid; i < nb; i += NT)
-        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
-    }
-    my = wave_max_dpp(my);
-    if (lane == 0) xw[wave] = my;
-    team_sync<MEM>();
-    nrm = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
-    OPFX_STAMP(1);
-    if (!(nrm == nrm)) { conv = false; break; }
-    if (nrm < o.tol) { conv = true; break; }
-    if (it >= o.max_iter) { conv = false; break; }
-    ++it;
-    // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
-    // group of mutually independent rounds ends ------------------------------------------------
-#ifdef OPFX_PAIR_ROUNDS
-    for (int k = 0; k < Kb; k += 4) {
-      team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
-      team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
-    }
-#else
-    for (int k = 0; k < Kb; k += 4) {
-      team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
-      team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
-      team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
-      team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
-    }
-#endif
-    OPFX_STAMP(2);
-    if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
-      if (wave == 0) tail_solve(L, P.tail_m, lane, tail);
-      team_sync<MEM>();
-      OPFX_STAMP(20);
-#ifdef OPFX_PAIR_ROUNDS
-      for (int k = Kb; k < K; k += 4) {
-        team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
-        team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
-      }
-#else
-      for (int k = Kb; k < K; k += 4) {
-        team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
-        team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
-        team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
-        team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
-      }
-#endif
-    }
-    OPFX_STAMP(3);
-    // ---- phase D ---------------------------------------------------------------------------------
-    for (int i = tid; i < nb; i += NT) {
-      if (L.bt[i] == BT_REF) continue;
-      double dth, dvm;
-      solve_pivot(L, i, dth, dvm, piv);
-      const double sc = 1.0 + dvm;
-      double sn, cs;
-      if (fabs(dth) <= 0.25) {                         // (as in newton2: Taylor series, truncation error < 1e-21)
-        const double z = dth * dth;
-        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
-             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
-        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
-             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
-      } else {
-        sincos(dth, &sn, &cs);
-      }
-      const double vr = L.vr[i], vi = L.vi[i];
-      L.vr[i] = (vr * cs - vi * sn) * sc;
-      L.vi[i] = (vr * sn + vi * cs) * sc;
-    }
-    team_sync<MEM>();
-    OPFX_STAMP(4);
-  }
-  team_sync<MEM>();          // xw (aliases the constraint accumulators) is free again
-  piv = wave_min_dpp(piv);
-  if (lane == 0) xw[wave] = piv;
-  team_sync<MEM>();
-  piv = xw[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) piv = nn_min(piv, xw[w]);
-  team_sync<MEM>();
-  *iters_out = it;
-  *nrm_out = nrm;
-  *piv_out = piv;
-  return conv;
+  const int b = (int)(best & 0x7FFFull);
+  *pbus_out = b == 0x7FFF ? -1 : b;
 }
 
 // ---- DC start (opfx_solve_opts.init = OPFX_INIT_DC; pandapower init='dc', pypower dcpf) -----------------------------
 // theta of the free buses from B' theta = P - (phase-shift injections + Gs + B'_ref theta_ref), |V| as in the flat start.
 // B' has the Ybus pattern, so the solve runs through the Newton schedule itself: every block becomes [[B'_ij, 0], [0,
 // B'_ij]] (which the two-value storage (a, b) -> [[a, b], [-b, a]] represents exactly), the right-hand side (P_i - c_i, 0);
-// phases B and C as in an iteration; then V_i = |V_i| e^{j x_i}.  One linear solve before the first iteration, in a code
-// region of its own: the Newton loops keep their register allocation.
+// phases B and C as in an iteration; then V_i = |V_i| e^{j x_i}.  One linear solve before the first iteration: a PASS OF
+// THE NEWTON LOOP ITSELF (`dc_pass`, kernels instantiated with DC) whose phase A writes B' instead of the Jacobian and
+// whose phase D sets the angles — phases B / C and the dense tail's register chain are the loop's own code, not a second
+// inlined copy (round 3 had one: the wave-team kernels went to 255-256 VGPRs + 36 B of scratch, k_solve to 716 B).
 template <bool PK>
 __device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int first, int stride, int lane) {
   constexpr unsigned NONE = 0xFFFFu;
@@ -1402,50 +1072,528 @@ __device__ __forceinline__ void dc_overflow(const DevPlan& P, const Lds& L, int 
     if ((he.x & 0xFFFF) != NONE && bid != NONE) st_blk2<PK>(L, bid, Blk{b, 0.0, 0.0, b});
   }
 }
-__device__ __forceinline__ void dc_update(const Lds& L, int nb, int first, int stride) {
-  for (int i = first; i < nb; i += stride) {
-    if (L.bt[i] == BT_REF) continue;
-    double th, dv, piv = 1.0;
-    solve_pivot(L, i, th, dv, piv);
-    const double vr = L.vr[i], vi = L.vi[i];
-    const double vm = sqrt(vr * vr + vi * vi);
-    double sn, cs;
-    sincos(th, &sn, &cs);
-    L.vr[i] = vm * cs;
-    L.vi[i] = vm * sn;
-  }
-}
-template <bool PK>
-__device__ void dc_start(const DevPlan& P, const Lds& L, int lane) {
+// CHORD: compiled with chord steps (opfx_solve_opts.jacobian_reuse_tol > 0; kernels of their own like DC): an iteration may
+// keep the factorisation of an earlier one — phase A then computes the mismatch only (`jac` false: no block is written) and
+// the wavefront walks the CHORD stream, forward substitution alone + the same back substitution (plan.h lp_bcc), instead
+// of factorisation + forward substitution.  Which stream the NEXT iteration walks is known once this iteration's norm is,
+// i.e. before its own rounds run out, so the four descriptors in flight across the loop's back edge come from the right one.
+template <bool PK, bool DC = false, bool CHORD = false>
+__device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
+                        int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool dc_pass = false) {
+  double piv = 1.0;
+  int pbus = -1;
+  constexpr unsigned NONE = 0xFFFFu;
+  const int nb = P.nb;
+  // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
+  // that the compiler's wait-count insertion sees a fixed number of loads in flight and
+  // waits for the oldest only (a conditional load anywhere in these loops degrades every
+  // wait to vmcnt(0), i.e. one exposed L2 round trip per round).
   const uint4* stream = reinterpret_cast<const uint4*>(P.lp_bc) + lane;
-  const int RB = P.rb, R = P.rb + P.rc;
-  for (int f = P.fill_lo + lane; f < P.fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
-  dc_overflow<PK>(P, L, 0, 1, lane);
-  dc_rows<PK>(P, L, 0, 1, lane);
-  wave_fence();
-  for (int r = 0; r < RB; ++r) { item_factor<PK, true>(L, stream[(size_t)r * WAVE]); wave_fence(); }
-  for (int r = RB; r < R; ++r) { item_factor<PK, false>(L, stream[(size_t)r * WAVE]); wave_fence(); }
-  dc_update(L, P.nb, lane, WAVE);
-  wave_fence();
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk) + lane;
+  const int RB_main = P.rb, R_main = P.rb + P.rc;        // padded round counts (multiples of 4, R >= 4)
+  const uint4* const stream_c = CHORD ? reinterpret_cast<const uint4*>(P.lp_bcc) + lane : stream;
+  const uint4 *st_cur = stream, *st_nxt = stream;        // stream of this iteration / of the next one
+  int RB = RB_main, R = R_main;                          // rounds of this iteration's stream
+  bool chord_now = false;                                // this iteration keeps the blocks as they are
+  double e_prev = 0.0;
+  auto ld_desc = [&](int r) { return r < R ? st_cur[(size_t)r * WAVE] : st_nxt[(size_t)(r - R) * WAVE]; };
+  const int hrow0 = lane < P.n_hrows ? P.lp_hrows[lane] : -1;
+  const int fill_lo = P.fill_lo;                           // fill blocks: ids [fill_lo, fill_lo + nfill) (plan.cpp)
+
+  int it = 0;
+  double nrm = 0.0;
+  bool conv = false;
+  OPFX_STAMP_INIT();
+  ARound cur = load_around(P, 0, lane);
+  // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
+  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
+  double pcur = psp_g[lane < nb ? lane : nb - 1], qcur = qsp_g[lane < nb ? lane : nb - 1];
+  uint4 hy = make_uint4(0, 0, 0, 0), he = make_uint4(NONE | (NONE << 16), 0, 0, 0);
+  if (P.rh > 0) { hy = hpk[0]; he = hpk[WAVE]; }
+  // rounds 0..3 of phases B/C; re-loaded by the tail of phase C for the next iteration
+  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
+  while (true) {
+    const bool jac = !(CHORD && chord_now);
+    // ---- phase A -----------------------------------------------------------------
+    if (jac) for (int f = fill_lo + lane; f < fill_lo + P.nfill; f += WAVE) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+    OPFX_STAMP(10);
+    double my = 0.0;
+    if (DC && dc_pass) {
+      // the DC start: B' in the blocks, P - c on the right-hand side (see dc_rows); phases B / C below solve it
+      dc_overflow<PK>(P, L, 0, 1, lane);
+      dc_rows<PK>(P, L, 0, 1, lane);
+      wave_fence();
+    } else {
+    // overflow entries of rows longer than the ELL width: any row per lane, row sums accumulated in the
+    // rhs slots of those rows (zeroed first) with LDS atomics
+    if (P.rh > 0) {
+      if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
+      for (int h = lane + WAVE; h < P.n_hrows; h += WAVE) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
+      wave_fence();
+      for (int h = 0; h < P.rh; ++h) {
+        const uint4 cy = hy, ce = he;
+        const int hn = h + 1 < P.rh ? h + 1 : 0;           // next round (or round 0 of the next iteration)
+        hy = hpk[(size_t)(hn * 2) * WAVE]; he = hpk[(size_t)(hn * 2 + 1) * WAVE];
+        const unsigned ent = ce.x;
+        const unsigned j = ent & 0xFFFF;
+        if (j != NONE) {
+          const int i = ce.y;
+          const double g = __longlong_as_double(((long long)cy.y << 32) | cy.x);
+          const double b = __longlong_as_double(((long long)cy.w << 32) | cy.z);
+          const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          const unsigned bid = ent >> 16;
+          const int t = L.bt[i];
+          if (bid != NONE && jac) { st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci}); if (t == BT_PV) blk_zero_row2(L, bid); }
+          lds_add(&L.rhs[i], cr);
+          lds_add(&L.rq[i], ci);
+        }
+      }
+      wave_fence();
+    }
+    OPFX_STAMP(11);
+    for (int r = 0; r < P.ra; ++r) {
+      const ARound a = cur;
+      const double p_sched = pcur, q_sched = qcur;
+      {
+        const int rn = r + 1 < P.ra ? r + 1 : 0;                 // next round (or round 0 of the next iteration)
+        cur = load_around(P, rn, lane);
+        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+        pcur = psp_g[in_]; qcur = qsp_g[in_];
+      }
+      const int i = lane + WAVE * r;
+      if (i < nb) {
+        const int t = L.bt[i];
+        const double vri = L.vr[i], vii = L.vi[i];
+        double sr = 0.0, si = 0.0;                       // S_off = V_i conj(sum_{j!=i} Y_ij V_j)
+        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
+        const unsigned (&ent)[KA] = a.ent;
+        // branch-free over the ELL slots (padding slots carry Y = 0 and read V_i): the four
+        // dependency chains interleave instead of being serialised by exec-mask branches
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
+          const double g = a.y[k].x, b = a.y[k].y;
+          const double vrj = L.vr[j], vij = L.vi[j];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          sr += cr; si += ci;
+          const unsigned bid = ent[k] >> 16;
+          if (bid != NONE && jac) {                          // (rows and columns of REF buses have no blocks)
+            // dS_i/dth_j = -j c ; dS_i/dln|V_j| = c ; PV rows are patched after the loop
+            st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});
+          }
+        }
+        if (t == BT_PV && jac) {                             // rare: skipped as a whole when the wave has no PV row
+#pragma unroll
+          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
+        }
+        if (t != BT_REF) {
+          const double g = a.yd.x, b = a.yd.y;
+          const double v2 = vri * vri + vii * vii;
+          const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
+          const double pc = sr + yr, qc = si + yi;
+          const double fp = pc - p_sched;
+          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
+          L.rhs[i] = -fp;
+          L.rq[i] = -fq;
+          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
+          // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
+          Blk jb{-si, yr + pc, sr, yi + qc};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          if (jac) st_blk2<PK>(L, a.dw & 0xFFFF, jb);
+        } else {
+          // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
+          // in its rhs slots so that the result pass needs no second walk over the row
+          const double g = a.yd.x, b = a.yd.y;
+          const double v2 = vri * vri + vii * vii;
+          L.rhs[i] = sr + g * v2;
+          L.rq[i] = si - b * v2;
+        }
+      }
+    }
+    // (the wave teams fold the modifiers into the bus rounds, mods_inline; here, where the kernel's common case has
+    //  none, even the test for it in the bus round costs 1.5 % — measured — so they keep their own pass)
+    if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
+      wave_fence();
+      dead_rows_patch<PK>(P, L, lane, jac);
+      wave_fence();
+      mods_apply(L, lane, n_mod, jac);
+      wave_fence();
+      my = 0.0;
+      for (int i = lane; i < nb; i += WAVE)
+        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
+    }
+    OPFX_STAMP(12);
+    // the wave-uniform decisions are votes (two instructions each); the max reduction (~45
+    // instructions) runs once, on the way out.  Same outcome as testing the reduced norm:
+    // NaN anywhere -> not converged; every row below tol -> converged; else iterate to max_iter.
+    const bool below = !wave_any(!(my < o.tol));               // (false if any lane holds a NaN)
+    if (below || wave_any(my != my) || it >= o.max_iter) {
+      nrm = wave_max_dpp(my);
+      conv = below;
+      OPFX_STAMP(1);
+      break;
+    }
+    ++it;
+    if (CHORD && o.reuse_tol > 0.0) {
+      // keep this iteration's factorisation for the next one?  After an iteration that factorised: when its own mismatch
+      // was already small; after a chord iteration: when the step before it cut the mismatch at least tenfold.
+      const double e = wave_max_dpp(my);
+      const bool chord_next = jac ? e < o.reuse_tol : e < 0.1 * e_prev;
+      e_prev = e;
+      st_nxt = chord_next ? stream_c : stream;
+    }
+    wave_fence();
+    }
+    // ---- phase B: block LU + forward substitution; phase C: back substitution ---------------
+    // Rounds of one level are independent; ordering is needed at level ends only, but on a
+    // single wave the fence is free (the LDS executes a wave's operations in order).
+#ifdef OPFX_PAIR_ROUNDS
+    // Two rounds of one elimination level (the plan's ITEM_NEXT_INDEPENDENT flag) as one step: the LDS reads of both
+    // are requested before either computes, so the second round's round trip hides behind the first round's arithmetic.
+    for (int r = 0; r < RB; r += 4) {
+      item_pair<PK, true>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
+      item_pair<PK, true>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
+    }
+    OPFX_STAMP(2);
+    for (int r = RB; r < R; r += 4) {
+      item_pair<PK, false>(L, q0, q1); q0 = ld_desc(r + 4); q1 = ld_desc(r + 5);
+      item_pair<PK, false>(L, q2, q3); q2 = ld_desc(r + 6); q3 = ld_desc(r + 7);
+    }
+#else
+    for (int r = 0; r < RB; r += 4) {
+      item_factor<PK, true>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK, true>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK, true>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK, true>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+    }
+    OPFX_STAMP(2);
+    for (int r = RB; r < R; r += 4) {
+      item_factor<PK, false>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK, false>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK, false>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK, false>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+    }
+#endif
+    OPFX_STAMP(3);
+    // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
+    for (int i = lane; i < nb; i += WAVE) {
+      if (L.bt[i] == BT_REF) continue;                 // (rhs of a REF row holds its parked injection)
+      double dth, dvm;
+      solve_pivot(L, i, dth, dvm, piv, pbus);
+      // (the DC pass solved for the ANGLE itself: turn the start voltage by the difference to its start angle, |V| stays)
+      if (DC && dc_pass) { dth -= P.va_set[i]; dvm = 0.0; }
+      const double sc = 1.0 + dvm;
+      double sn, cs;
+      if (fabs(dth) <= 0.25) {
+        // Taylor series to x^15 / x^14, truncation error < 1e-21 (the other branch is skipped as a whole
+        // while no lane needs it: after the first iteration the steps are small)
+        const double z = dth * dth;
+        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
+             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
+             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
+      } else {
+        sincos(dth, &sn, &cs);                         // (a NaN step ends here and stays NaN)
+      }
+      const double vr = L.vr[i], vi = L.vi[i];
+      L.vr[i] = (vr * cs - vi * sn) * sc;
+      L.vi[i] = (vr * sn + vi * cs) * sc;
+    }
+    wave_fence();
+    OPFX_STAMP(4);
+    if (DC) dc_pass = false;
+    if (CHORD) {                      // the next iteration's stream (its first four rounds are in flight already)
+      chord_now = st_nxt != stream;
+      st_cur = st_nxt;
+      RB = chord_now ? P.rf : RB_main;
+      R = RB + P.rc;
+    }
+  }
+  *iters_out = it;
+  *nrm_out = nrm;
+  piv_argmin(piv, pbus, piv_out, pbus_out);
+  return conv;
 }
-template <int NW, bool PK>
-__device__ void dc_start_coop(const DevPlan& P, const Lds& L) {
+
+// ---------------------------------------------------------------------------
+// Cooperative variant for LARGE grids: NW wavefronts (one workgroup) share ONE
+// instance.  Meshed HV grids need 70-90 KB of LDS per instance, i.e. only one
+// or two instances fit a CU; with one wave each, three of the four SIMDs would
+// idle.  Here the independent rounds of a group (an elimination level, its U
+// pre-items, its solves), the bus rows and the voltage update are dealt round-
+// robin to the NW waves and groups are separated by workgroup barriers.  Update
+// terms of different waves meet in LDS atomics, so the summation order — and the
+// last bits of the result — may differ between runs (the single-wave kernel is
+// bit-reproducible).
+// ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
+// descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
+template <int NW, bool PK, bool MEM = false, bool DC = false, bool CHORD = false>
+__device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
+                             int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool inline_mods, bool dc_pass = false) {
+  double piv = 1.0;
+  int pbus = -1;
+  constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = P.nb;
   const uint4* stream = reinterpret_cast<const uint4*>(NW == 2 ? P.lp_team2 : P.lp_team4) + (size_t)wave * WAVE + lane;
-  const int K = NW == 2 ? P.team_rounds2 : P.team_rounds4, Kb = NW == 2 ? P.team_kb2 : P.team_kb4;
-  for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
-  dc_overflow<PK>(P, L, wave, NW, lane);
-  dc_rows<PK>(P, L, wave, NW, lane);
-  lds_barrier();
-  for (int k = 0; k < Kb; ++k) team_step<PK>(L, stream[(size_t)k * (NW * WAVE)]);
-  if (P.tail_m > 0) {
-    if (wave == 0) tail_solve(L, P.tail_m, lane, P.tail_bus[lane & 31]);
-    lds_barrier();
-    for (int k = Kb; k < K; ++k) team_step<PK>(L, stream[(size_t)k * (NW * WAVE)]);
+  const int K_main = NW == 2 ? P.team_rounds2 : P.team_rounds4;   // multiple of 4, >= 4
+  const int Kb_main = NW == 2 ? P.team_kb2 : P.team_kb4;          // rounds before the tail chain (= K without a tail)
+  // chord steps (see newton2): the team's chord stream — forward substitution | (tail chain) | back substitution
+  const uint4* const stream_c = CHORD ? reinterpret_cast<const uint4*>(NW == 2 ? P.lp_teamc2 : P.lp_teamc4) + (size_t)wave * WAVE + lane : stream;
+  const uint4 *st_cur = stream, *st_nxt = stream;
+  int K = K_main, Kb = Kb_main;
+  bool chord_now = false;
+  double e_prev = 0.0;
+  auto ld_desc = [&](int k) { return k < K ? st_cur[(size_t)k * (NW * WAVE)] : st_nxt[(size_t)(k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
+  const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
+  double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
+  int it = 0;
+  double nrm = 0.0;
+  bool conv = false;
+  OPFX_STAMP_INIT();
+  uint4 q0 = ld_desc(0), q1 = ld_desc(1), q2 = ld_desc(2), q3 = ld_desc(3);
+  const unsigned tail = P.tail_bus[lane & 31];     // the lane's pivot of the dense tail (tail_solve)
+  // overflow entries of rows longer than the ELL width (phase A): the row this thread zeroes and this wavefront's first round
+  const int hrow0 = tid < P.n_hrows ? P.lp_hrows[tid] : -1;
+  uint4 hy0 = make_uint4(0, 0, 0, 0), he0 = make_uint4(NONE | (NONE << 16), 0, 0, 0);
+  if (wave < P.rh) { hy0 = hpk[(size_t)(wave * 2) * WAVE + lane]; he0 = hpk[(size_t)(wave * 2 + 1) * WAVE + lane]; }
+  // this wave's next bus round (descriptors + scheduled P/Q of the row), one round ahead
+  const double* psp_g = L.psp; const double* qsp_g = L.qsp;
+  const int r_first = wave < P.ra ? wave : 0;
+  ARound a_next = load_around(P, r_first, lane);
+  double p_next, q_next;
+  { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
+  while (true) {
+    // ---- phase A ------------------------------------------------------------------
+    // (nothing in this prologue of the phase waits for global memory: fill blocks are one contiguous id range,
+    // the overflow rows and this wavefront's first overflow round were fetched once per solve)
+    const bool jac = !(CHORD && chord_now);
+    if (jac) for (int f = P.fill_lo + tid; f < P.fill_lo + P.nfill; f += NT) st_blk2<PK>(L, f, Blk{0.0, 0.0, 0.0, 0.0});
+    // the DC start (see dc_rows) is a pass of this loop: B' in the blocks, P - c on the right-hand side, through the SAME
+    // overflow / bus-round loops (their descriptors are in registers already), then phases B / C as in an iteration
+    const bool dcp = DC && dc_pass;
+    if (hrow0 >= 0) { L.rhs[hrow0] = 0.0; L.rq[hrow0] = 0.0; }
+    for (int h = tid + NT; h < P.n_hrows; h += NT) { const int i = P.lp_hrows[h]; L.rhs[i] = 0.0; L.rq[i] = 0.0; }
+    team_sync<MEM>();
+    OPFX_STAMP(10);
+    for (int h = wave; h < P.rh; h += NW) {
+      const uint4 hy = h == wave ? hy0 : hpk[(size_t)(h * 2) * WAVE + lane];
+      const uint4 he = h == wave ? he0 : hpk[(size_t)(h * 2 + 1) * WAVE + lane];
+      const unsigned ent = he.x;
+      const unsigned j = ent & 0xFFFF;
+      if (DC && dcp) {
+        const double b = P.lp_hdc[(size_t)h * WAVE + lane];
+        const unsigned bid = ent >> 16;
+        if (j != NONE && bid != NONE) st_blk2<PK>(L, bid, Blk{b, 0.0, 0.0, b});
+      } else if (j != NONE) {
+        const int i = he.y;
+        double g = __longlong_as_double(((long long)hy.y << 32) | hy.x);
+        double b = __longlong_as_double(((long long)hy.w << 32) | hy.z);
+        const double vrj = L.vr[j], vij = L.vi[j], vri = L.vr[i], vii = L.vi[i];
+        const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+        const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+        const unsigned bid = ent >> 16;
+        const int t = L.bt[i];
+        if (bid != NONE && jac) {
+          Blk jb{ci, cr, -cr, ci};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+          st_blk2<PK>(L, bid, jb);
+        }
+        lds_add(&L.rhs[i], cr);
+        lds_add(&L.rq[i], ci);
+      }
+    }
+    team_sync<MEM>();
+    OPFX_STAMP(11);
+    double my = 0.0;
+    for (int r = wave; r < P.ra; r += NW) {
+      const ARound a = a_next;
+      const double p_sched = p_next, q_sched = q_next;
+      {
+        const int rn = r + NW < P.ra ? r + NW : r_first;       // (last round: first round of the next iteration)
+        a_next = load_around(P, rn, lane);
+        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+        p_next = psp_g[in_]; q_next = qsp_g[in_];
+      }
+      const int i = lane + WAVE * r;
+      if (DC && dcp) {
+        // (one value at a time, each used before the next is requested: this pass runs once per solve, its latency does
+        //  not matter, the registers of a batched load would — the kernel sits at the top of the register file)
+        const double* dc = P.lp_dc + (size_t)r * (KA + 2) * WAVE + lane;      // ([ra][KA + 2][64]: padded, any lane is valid)
+        if (i < nb && L.bt[i] != BT_REF) {
+#pragma unroll
+          for (int k = 0; k < KA; ++k) {
+            const unsigned bid = a.ent[k] >> 16;
+            const double bij = dc[k * WAVE];
+            if (bid != NONE) st_blk2<PK>(L, bid, Blk{bij, 0.0, 0.0, bij});
+            asm volatile("" ::: "memory");
+          }
+          const double bii = dc[KA * WAVE];
+          st_blk2<PK>(L, a.dw & 0xFFFF, Blk{bii, 0.0, 0.0, bii});
+          asm volatile("" ::: "memory");
+          L.rhs[i] = p_sched - dc[(KA + 1) * WAVE];
+          L.rq[i] = 0.0;
+        }
+      } else if (i < nb) {
+        const int t = L.bt[i];
+        const double vri = L.vr[i], vii = L.vi[i];
+        double sr = 0.0, si = 0.0;
+        if (a.dw >> 16) { sr = L.rhs[i]; si = L.rq[i]; }
+        const unsigned (&ent)[KA] = a.ent;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+          const unsigned j = ent[k] & 0xFFFF;               // (padding slots: own row, Y = 0)
+          double g = a.y[k].x, b = a.y[k].y;
+          const double vrj = L.vr[j], vij = L.vi[j];
+          const double tr = g * vrj - b * vij, ti = g * vij + b * vrj;
+          const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
+          sr += cr; si += ci;
+          const unsigned bid = ent[k] >> 16;
+          if (bid != NONE && jac) st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});   // (PV rows are patched after the loop)
+        }
+        if (t == BT_PV && jac) {
+#pragma unroll
+          for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
+        }
+        double dyr = 0.0, dyi = 0.0;
+        if (inline_mods && n_mod > 0) mods_inline(L, n_mod, i, t, vri, vii, sr, si, dyr, dyi, jac);
+        double g = a.yd.x, b = a.yd.y;
+        const double v2 = vri * vri + vii * vii;
+        const double yr = g * v2 + dyr, yi = -b * v2 + dyi;
+        if (t != BT_REF) {
+          const double pc = sr + yr, qc = si + yi;
+          const double fp = pc - p_sched;
+          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
+          L.rhs[i] = -fp;
+          L.rq[i] = -fq;
+          my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
+          Blk jb{-si, yr + pc, sr, yi + qc};
+          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          if (jac) st_blk2<PK>(L, a.dw & 0xFFFF, jb);
+        } else {
+          L.rhs[i] = sr + yr;
+          L.rq[i] = si + yi;
+        }
+      }
+    }
+    OPFX_STAMP(12);
+    if (!(DC && dcp)) {
+    if (n_mod > 0 && !inline_mods) {
+      team_sync<MEM>();
+      if (wave == 0) { dead_rows_patch<PK>(P, L, lane, jac); mem_fence<MEM>(); mods_apply(L, lane, n_mod, jac); }
+      team_sync<MEM>();
+      my = 0.0;
+      for (int i = tid; i < nb; i += NT)
+        if (L.bt[i] != BT_REF) my = nn_max(my, nn_max(fabs(L.rhs[i]), fabs(L.rq[i])));
+    }
+    my = wave_max_dpp(my);
+    if (lane == 0) xw[wave] = my;
+    team_sync<MEM>();
+    nrm = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) nrm = nn_max(nrm, xw[w]);
+    OPFX_STAMP(1);
+    if (!(nrm == nrm)) { conv = false; break; }
+    if (nrm < o.tol) { conv = true; break; }
+    if (it >= o.max_iter) { conv = false; break; }
+    ++it;
+    if (CHORD && o.reuse_tol > 0.0) {          // (see newton2; every wavefront holds the same norm)
+      const bool chord_next = jac ? nrm < o.reuse_tol : nrm < 0.1 * e_prev;
+      e_prev = nrm;
+      st_nxt = chord_next ? stream_c : stream;
+    }
+    } else {
+      team_sync<MEM>();        // (the DC pass has no norm exchange: its blocks and right-hand side are complete here)
+    }
+    // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
+    // group of mutually independent rounds ends ------------------------------------------------
+#ifdef OPFX_PAIR_ROUNDS
+    for (int k = 0; k < Kb; k += 4) {
+      team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
+      team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
+    }
+#else
+    for (int k = 0; k < Kb; k += 4) {
+      team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
+      team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
+      team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
+      team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
+    }
+#endif
+    OPFX_STAMP(2);
+    if (P.tail_m > 0) {          // the dense tail's back substitution: a register chain on wavefront 0
+      if (wave == 0) tail_solve<CHORD>(L, P.tail_m, lane, tail, CHORD && chord_now);
+      team_sync<MEM>();
+      OPFX_STAMP(20);
+#ifdef OPFX_PAIR_ROUNDS
+      for (int k = Kb; k < K; k += 4) {
+        team_pair<PK>(L, q0, q1); q0 = ld_desc(k + 4); q1 = ld_desc(k + 5);
+        team_pair<PK>(L, q2, q3); q2 = ld_desc(k + 6); q3 = ld_desc(k + 7);
+      }
+#else
+      for (int k = Kb; k < K; k += 4) {
+        team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
+        team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
+        team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
+        team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
+      }
+#endif
+    }
+    OPFX_STAMP(3);
+    // ---- phase D ---------------------------------------------------------------------------------
+    for (int i = tid; i < nb; i += NT) {
+      if (L.bt[i] == BT_REF) continue;
+      double dth, dvm;
+      solve_pivot(L, i, dth, dvm, piv, pbus);
+      // (the DC pass solved for the ANGLE itself: turn the start voltage by the difference to its start angle, |V| stays)
+      if (DC && dcp) { dth -= P.va_set[i]; dvm = 0.0; }
+      const double sc = 1.0 + dvm;
+      double sn, cs;
+      if (fabs(dth) <= 0.25) {                         // (as in newton2: Taylor series, truncation error < 1e-21)
+        const double z = dth * dth;
+        sn = dth * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880
+             + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+        cs = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800
+             + z * (1.0 / 479001600 + z * (-1.0 / 87178291200.0)))))));
+      } else {
+        sincos(dth, &sn, &cs);
+      }
+      const double vr = L.vr[i], vi = L.vi[i];
+      L.vr[i] = (vr * cs - vi * sn) * sc;
+      L.vi[i] = (vr * sn + vi * cs) * sc;
+    }
+    team_sync<MEM>();
+    OPFX_STAMP(4);
+    if (DC) dc_pass = false;
+    if (CHORD) {
+      chord_now = st_nxt != stream;
+      st_cur = st_nxt;
+      K = chord_now ? (NW == 2 ? P.team_roundsc2 : P.team_roundsc4) : K_main;
+      Kb = chord_now ? (NW == 2 ? P.team_kbc2 : P.team_kbc4) : Kb_main;
+    }
   }
-  dc_update(L, P.nb, tid, NT);
-  lds_barrier();
+  team_sync<MEM>();          // xw (aliases the constraint accumulators) is free again
+  {
+    int wbus;
+    piv_argmin(piv, pbus, &piv, &wbus);
+    if (lane == 0) { xw[wave] = piv; xw[NW + wave] = (double)wbus; }
+    team_sync<MEM>();
+    piv = xw[0];
+    pbus = (int)xw[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { const double pw = xw[w]; pbus = pw < piv ? (int)xw[NW + w] : pbus; piv = nn_min(piv, pw); }
+    team_sync<MEM>();
+  }
+  *iters_out = it;
+  *nrm_out = nrm;
+  *piv_out = piv;
+  *pbus_out = pbus;
+  return conv;
 }
 
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
@@ -1526,10 +1674,10 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 // DC: compiled with the DC start (opfx_solve_opts.init).  A template parameter, i.e. kernels of their own: with the DC
 // code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
 // in the wave teams) although the region runs once per solve.
-template <int V2, int NW, bool DC = false, bool MEM = false>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
 __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
-                               int isl_state = 0) {
+                               int* min_piv_bus, int isl_state = 0) {
   const int wave = threadIdx.x >> 6;
   // isl_state (islanding outages, see island_state): 1 = the caller has de-energised the island
   // (mark_island) and the solve proceeds on the rest; 2 = the cut-off set is not known exactly
@@ -1538,19 +1686,18 @@ __device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, in
   if (isl_state == 2) { *iters = 1; *nrm = __builtin_nan(""); return false; }
   int total = 0;
   bool conv = false;
-  // DC start: on the compiled topology only (a modifier changes B' as well; such solves start flat), V2 kernels
-  if (DC && V2 && o.init == OPFX_INIT_DC && P.lp_dc != nullptr && n_mod == 0 && isl_state == 0) {
-    if (NW > 1) dc_start_coop<NW, V2 == 2>(P, L);
-    else dc_start<V2 == 2>(P, L, lane);
-  }
+  // DC start: on the compiled topology only (a modifier changes B' as well; such solves start flat), V2 kernels; it is
+  // the first pass of the first Newton loop of the solve
+  const bool dc_first = DC && V2 && o.init == OPFX_INIT_DC && P.lp_dc != nullptr && n_mod == 0 && isl_state == 0;
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
+    int pb_ = -1;
     // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM>(P, L, o, n_mod, &it, nrm, &pv_, isl_state == 0);
-    else conv = V2 ? newton2<V2 == 2>(P, L, o, lane, n_mod, &it, nrm, &pv_) : newton(P, L, o, lane, out_br, &it, nrm);
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0);
+    else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
-    *min_piv = (pv_ == pv_) ? fmin(*min_piv, pv_) : *min_piv;
+    if (pv_ == pv_ && pv_ < *min_piv) { *min_piv = pv_; *min_piv_bus = pb_; }
     if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
     int changed = 0;
@@ -1745,7 +1892,7 @@ __device__ __forceinline__ long long next_instance(double* slot, long long b, bo
 #ifndef OPFX_MIN_WAVES_PER_SIMD
 #define OPFX_MIN_WAVES_PER_SIMD 2
 #endif
-template <int V2, int NW, bool DC = false, bool MEM = false>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(const DevPlan P, SolveIO io, Opts o, long long B) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1775,7 +1922,8 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
     blk_sync<NW>();
     int iters; double nrm;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
-    const bool conv = solve_instance<V2, NW, DC, MEM>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, isl);
+    int min_piv_bus = -1;
+    const bool conv = solve_instance<V2, NW, DC, MEM, CHORD>(P, L, o, lane, out_br, n_mod, io.qg_min, io.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl);
     blk_sync<NW>();
     int nxt_v = 0;                            // (work queue, see k_step)
     if (io.queued && threadIdx.x == 0) nxt_v = __hip_atomic_fetch_add(P.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1797,6 +1945,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
         if (io.iterations) io.iterations[b] = iters;
         if (io.max_mismatch) io.max_mismatch[b] = nrm;
         if (io.min_pivot) io.min_pivot[b] = min_piv;
+        if (io.min_pivot_bus) io.min_pivot_bus[b] = min_piv_bus;
       }
     }
     b = next_instance<NW>(L.acc + 6, b, io.queued != 0, nxt_v);
@@ -1806,13 +1955,6 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
 // ---------------------------------------------------------------------------
 // fused env.step kernel (opfx_step)
 // ---------------------------------------------------------------------------
-// Pointers read out of a descriptor that itself lives in memory are generic to the compiler
-// (flat_load: counted on vmcnt AND lgkmcnt, serialising them with the LDS traffic); all of
-// ours are hipMalloc'ed, so say so.
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
-  return (const __attribute__((address_space(1))) T*)p;
-}
 
 // value of a table cell during a step: src >= 0 -> staged table row, src < 0 -> set-point of
 // action ~src (a column written by an action is read from the set-point), NOSRC -> absent (0)
@@ -1969,22 +2111,6 @@ __device__ __forceinline__ double op_value(int code, double rv, double dr, doubl
   }
 }
 
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
-  return (const __attribute__((address_space(4))) T*)p;
-}
-// element `idx` of an array whose base is wave-uniform: the byte offset as an unsigned 32-bit value, which is the form
-// the hardware addresses as scalar base + vector offset (no 64-bit address arithmetic per lane); arrays < 4 GiB
-template <class T>
-__device__ __forceinline__ T ld_at(const T* base, unsigned idx) {
-  typedef const __attribute__((address_space(1))) char* gbytes;
-  return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>(as_global(base)) + idx * (unsigned)sizeof(T));
-}
-template <class T>
-__device__ __forceinline__ void st_at(T* base, unsigned idx, T v) {
-  typedef __attribute__((address_space(1))) char* gbytes;
-  *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<gbytes>((__attribute__((address_space(1))) T*)base) + idx * (unsigned)sizeof(T)) = v;
-}
 // a chunk descriptor through the scalar cache (`c` is wave-uniform)
 __device__ __forceinline__ i32x8 ld_chunk(const i32x8* base, int c) { return as_const(base)[c]; }
 
@@ -2390,8 +2516,12 @@ __device__ __forceinline__ void reset_rows(const DevReset& R, const DevEnv* __re
 }
 
 // NR: wavefronts per workgroup = rows per workgroup (as many as the LDS takes next to three more workgroups)
+// The reset programme's descriptor (about 70 dwords) is passed BY POINTER and read where it is needed, through the scalar
+// cache: by value all of it was loaded at kernel entry and parked in VGPR lanes (132 v_writelane in the prologue, a
+// v_readlane at every use — a tenth of the kernel's vector instructions, round 3).
 template <int NR, bool FULL>
-__global__ __launch_bounds__(64 * NR, NR == 1 ? 2 : 4) void k_reset(DevReset R, const DevEnv* __restrict__ Ep, ResetIO io, long long B, int row_doubles) {
+__global__ __launch_bounds__(64 * NR, NR == 1 ? 2 : 4) void k_reset(const DevReset* __restrict__ Rp, const DevEnv* __restrict__ Ep, ResetIO io, long long B, int row_doubles) {
+  const DevReset& R = *Rp;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // (wave-uniform: scalar addressing)
@@ -2447,7 +2577,7 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <int V2, int NW, bool DC = false, bool MEM = false>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
@@ -2495,7 +2625,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       ++turn;
     }
-    double* xr = io.x + b * E.nx;
+    double* xr = uniform_ptr(io.x + b * E.nx);           // (opaque row pointer: see uniform_ptr)
     const bool apply = io.mode != 1 && io.mode != 3;
     OPFX_STAMP(15);
     // ---- stage the row ------------------------------------------------------------
@@ -2505,11 +2635,11 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       for (; q + 7 * NT < nx; q += 8 * NT) {
         double t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = xr[q + u * NT];
+        for (int u = 0; u < 8; ++u) t[u] = ld_at(xr, (unsigned)(q + u * NT));
 #pragma unroll
         for (int u = 0; u < 8; ++u) xs[q + u * NT] = t[u];
       }
-      for (; q < nx; q += NT) xs[q] = xr[q];
+      for (; q < nx; q += NT) xs[q] = ld_at(xr, (unsigned)q);
     }
     blk_sync<NW>();       // staged row visible (one wave: compiler fence; team: all waves staged)
     OPFX_STAMP(16);
@@ -2517,7 +2647,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     double corr = 0.0;
     if (wave == 0) {
       // (no action row in modes 1/3: any readable row keeps the loads unconditional)
-      const double* act_row = apply ? io.action + b * E.na : xr;
+      const double* act_row = uniform_ptr(apply ? io.action + b * E.na : xr);
       // reset applies its initial action as ABSOLUTE set-points (opf_env.py:207 passes no step size),
       // and clamps only without autoscaling (:464)
       const bool as_reset = io.mode == 2 || io.mode == 4 || io.mode == 5;
@@ -2531,7 +2661,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
           const int k = k0 + u * WAVE + lane, kk = k < E.na ? k : E.na - 1;
           slot[u] = as_global(E.act_slot)[kk]; los[u] = as_global(E.act_lo_slot)[kk]; his[u] = as_global(E.act_hi_slot)[kk];
           sc[u] = as_global(E.act_scaling)[kk]; loc[u] = as_global(E.act_lo_const)[kk]; hic[u] = as_global(E.act_hi_const)[kk];
-          av[u] = act_row[kk];
+          av[u] = ld_at(act_row, (unsigned)kk);
           kind[u] = as_global(E.act_kind)[kk];
           cls_[u] = as_global(E.clamp_lo_slot)[kk]; chs[u] = as_global(E.clamp_hi_slot)[kk];
           clc[u] = as_global(E.clamp_lo_const)[kk]; chc[u] = as_global(E.clamp_hi_const)[kk];
@@ -2559,7 +2689,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
               xv = rint(xv);
               if (kind[u] == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0;
             }
-            xr[slot[u]] = xv;                                                            // :483
+            st_at(xr, (unsigned)slot[u], xv);                                            // :483
             const double cur = (xv * sc[u] - lo) / delta;                                // :586
             corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
           }
@@ -2575,12 +2705,15 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     // ---- table observations: do not depend on the solve ----------------------------------------
     if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
       const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
+      // (stores as wave-uniform base + 32-bit lane offset: no 64-bit per-lane address, which the compiler would compute
+      //  once per kernel — pointer + lane * 8 — and keep in two VGPRs through every Newton loop)
+      double* const ob = uniform_ptr(io.obs + b * E.nobs + dst);
       if (kind == 1) {
-        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = NaN;
+        if (io.mode == 2 || io.mode == 3) for (int j = lane; j < n; j += WAVE) st_at(ob, (unsigned)j, NaN);
         continue;
       }
       const double* from = (kind == 0 ? xs : L.sp) + src;
-      for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = from[j];
+      for (int j = lane; j < n; j += WAVE) st_at(ob, (unsigned)j, from[j]);
     }
     if (io.mode == 2 || io.mode == 3) {
       // reset without power flow (opf_env.py:207,218): set-points applied, table observation only
@@ -2613,7 +2746,9 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       }
       if (V2) {
         wave_fence();
-        for (int i = lane; i < nb; i += WAVE) { L.psp[i] = pacc[i]; L.qsp[i] = qacc[i]; }
+        // (scalar base + 32-bit lane offset: the per-workgroup rows never turn into 64-bit per-lane addresses that the
+        //  compiler computes at kernel entry and keeps — or spills — through every Newton loop)
+        for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(L.psp, io_, pacc[i]); st_at(L.qsp, io_, qacc[i]); }
       }
       OPFX_STAMP(19);
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
@@ -2638,6 +2773,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
         }
       }
     }
+    // (the pre-solve rows are summed over the wavefront HERE: a wave-uniform double lives in two SGPRs through the solve,
+    //  a per-lane partial sum in two VGPRs — and the wave-team kernels sit at the top of the register file)
+    const double cost_pre = wave_sum_dpp(csum);
+    csum = 0.0;
     OPFX_STAMP(0);
     // ---- base case + N-1 contingencies (security_constrained.py:37-68) --------
     double objective = 0.0, viol_acc = 0.0, pen_acc = 0.0;   // lane g < nc holds group g
@@ -2646,6 +2785,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     int iters0 = 0, iters_all = 0;
     double nrm0 = 0.0;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
+    int min_piv_bus = -1;
     const int base_out = io.outage ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
@@ -2696,13 +2836,13 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
           // pandapower from scratch for each one; the converged result is the same;
           // opfx_solve_opts::contingency_start = 1 does exactly what the reference does)
           const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
-          for (int i = lane; i < nb; i += WAVE) { L.vr[i] = wv[i]; L.vi[i] = wv[nb + i]; }
+          for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); L.vr[i] = ld_at(wv, io_); L.vi[i] = ld_at(wv, (unsigned)nb + io_); }
         }
       }
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW, DC, MEM>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, isl);
+      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
@@ -2711,7 +2851,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
         if (!conv) break;
         if (E.n_cont > 0 && wave == 0) {
           double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
-          for (int i = lane; i < nb; i += WAVE) { wv[i] = L.vr[i]; wv[nb + i] = L.vi[i]; }
+          for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
           __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same wavefront
         }
       }
@@ -2827,16 +2967,17 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
           const double dv = R[as_global(E.qterm_idx)[k]] - as_global(E.qterm_target)[k];
           csum += as_global(E.qterm_weight)[k] * dv * dv;
         }
-        objective = -wave_sum_dpp(csum);                                                 // opf_env.py:500
+        objective = -(cost_pre + wave_sum_dpp(csum));                                    // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
-        if (io.results) for (int q = lane; q < E.nres; q += WAVE) io.results[b * E.nres + q] = R[q];
+        if (io.results) { double* const rb = uniform_ptr(io.results + b * E.nres); for (int q = lane; q < E.nres; q += WAVE) st_at(rb, (unsigned)q, R[q]); }
       }
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
       if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         if (as_global(E.oseg_kind)[sg] != 1) continue;
         const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
-        for (int j = lane; j < n; j += WAVE) io.obs[b * E.nobs + dst + j] = R[src + j];
+        double* const ob = uniform_ptr(io.obs + b * E.nobs + dst);
+        for (int j = lane; j < n; j += WAVE) st_at(ob, (unsigned)j, R[src + j]);
       }
       }
       blk_sync<NW>();
@@ -2849,11 +2990,11 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     if (!conv0) {
       // opf_env.py:390-399: NaN observation and reward, terminated, all-invalid info
       __builtin_amdgcn_s_waitcnt(0);      // the table observations written above are overwritten
-      if (io.obs) for (int k = lane; k < E.nobs; k += WAVE) io.obs[b * E.nobs + k] = NaN;
+      if (io.obs) { double* const ob = uniform_ptr(io.obs + b * E.nobs); for (int k = lane; k < E.nobs; k += WAVE) st_at(ob, (unsigned)k, NaN); }
       if (lane < E.nc) {
-        if (io.valids) io.valids[b * E.nc + lane] = 0;
-        if (io.violations) io.violations[b * E.nc + lane] = 1.0;
-        if (io.penalties) io.penalties[b * E.nc + lane] = 1.0;
+        if (io.valids) st_at(uniform_ptr(io.valids + b * E.nc), (unsigned)lane, (unsigned char)0);
+        if (io.violations) st_at(uniform_ptr(io.violations + b * E.nc), (unsigned)lane, 1.0);
+        if (io.penalties) st_at(uniform_ptr(io.penalties + b * E.nc), (unsigned)lane, 1.0);
       }
       if (lane == 0) {
         if (io.reward) io.reward[b] = NaN;
@@ -2868,9 +3009,9 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       const double penalty = wave_sum_dpp(pen_l);
       const bool valid = !wave_any(inval_l);
       if (lane < E.nc) {
-        if (io.valids) io.valids[b * E.nc + lane] = valid_acc ? 1 : 0;
-        if (io.violations) io.violations[b * E.nc + lane] = viol_acc;
-        if (io.penalties) io.penalties[b * E.nc + lane] = pen_acc;
+        if (io.valids) st_at(uniform_ptr(io.valids + b * E.nc), (unsigned)lane, (unsigned char)(valid_acc ? 1 : 0));
+        if (io.violations) st_at(uniform_ptr(io.violations + b * E.nc), (unsigned)lane, viol_acc);
+        if (io.penalties) st_at(uniform_ptr(io.penalties + b * E.nc), (unsigned)lane, pen_acc);
       }
       if (lane == 0) {
         double obj = objective, pen = penalty;
@@ -2910,6 +3051,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       if (io.mean_correction) io.mean_correction[b] = corr;
       if (io.total_iterations) io.total_iterations[b] = iters_all;
       if (io.min_pivot) io.min_pivot[b] = min_piv;
+      if (io.min_pivot_bus) io.min_pivot_bus[b] = min_piv_bus;
     }
     }
     b = next_instance<NW>(L.acc + env_nacc(E.nc) - 2, b, io.queued != 0, nxt_v);
@@ -2951,6 +3093,7 @@ struct opfx_ctx {
   int n_cu = 0;
   int solve_per_cu = 0;
   int solve_per_cu_dc = 0;
+  int solve_per_cu_chord = 0;
   int solve_per_cu_mem = 0;
   double* blk_mem = nullptr;           // memory-resident kernels: LU block values, one row per resident workgroup
   size_t blk_mem_rows = 0;
@@ -2968,12 +3111,14 @@ struct opfx_env {
   DevEnv de{};
   const DevEnv* d_de = nullptr;
   DevReset dr{};
+  const DevReset* d_dr = nullptr;      // device copy of dr (the reset kernel takes it by pointer)
   bool has_reset = false;
 
   DevArena arena;
   size_t lds_bytes = 0;
   int per_cu = 0;
   int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
+  int per_cu_chord = 0;  // (and for those compiled with chord steps)
   bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
   int* queue = nullptr;  // this environment's own work-queue counter (two environments of a context do not share one)
   std::vector<int32_t> h_oseg[4];      // observation segments (kind, source, destination, length): host copy for the reset's element list
@@ -3125,12 +3270,18 @@ extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_
   }
   c->v2 = p->rb >= 0 && !dbg.kernel_v1;   // (kernel_v1: developer switch to the first-generation kernel)
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
+  PUT(lp_bcc, lp_bcc);
+  d.rf = p->rf_pad;
   d.lp_dc = nullptr; d.lp_hdc = nullptr;
   d.blk_mem = nullptr; d.blk_mem_stride = 0;
   if (!p->lp_dc.empty()) { PUT(lp_dc, lp_dc); PUT(lp_hdc, lp_hdc); }
   d.n_hrows = (int)p->lp_hrows.size();
   if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
   if (rc == OPFX_OK) rc = A.put(p->lp_team[1], &d.lp_team4);
+  if (rc == OPFX_OK) rc = A.put(p->lp_teamc[0], &d.lp_teamc2);
+  if (rc == OPFX_OK) rc = A.put(p->lp_teamc[1], &d.lp_teamc4);
+  d.team_roundsc2 = p->team_rounds_c[0]; d.team_roundsc4 = p->team_rounds_c[1];
+  d.team_kbc2 = p->team_kb_c[0]; d.team_kbc4 = p->team_kb_c[1];
   d.team_rounds2 = p->team_rounds[0]; d.team_rounds4 = p->team_rounds[1];
   d.team_kb2 = p->team_kb[0]; d.team_kb4 = p->team_kb[1];
   d.tail_m = p->tail_m; d.tail_n = (int)p->tail_ids.size();
@@ -3171,13 +3322,15 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
                           const double* qg_min, const double* qg_max, const int32_t* outage,
                           const opfx_solve_opts* opts, double* vm, double* va, double* loading,
                           double* s_ref, double* q_gen, uint8_t* converged, int32_t* iterations,
-                          double* max_mismatch, double* min_pivot, void* stream) {
+                          double* max_mismatch, double* min_pivot, int32_t* min_pivot_bus, void* stream) {
   if (ctx && B == 0) return OPFX_OK;                  // empty batch: nothing to do (its buffers may be null)
   if (!ctx || !p_inj || !q_inj || B < 0) { opfx_set_error("opfx_solve: bad argument"); return OPFX_ERR_INVALID; }
   opfx_solve_opts so;
   if (opts) { const int rc_ = opfx_take(opts, &so, "opfx_solve(opfx_solve_opts)"); if (rc_ != OPFX_OK) return rc_; opts = &so; }
   HIP_TRY(hipSetDevice(ctx->device));
-  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0, opts ? opts->init : 0};
+  Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 0, 0, opts ? opts->init : 0,
+         opts ? opts->jacobian_reuse_tol : 0.0};
+  if (!(o.reuse_tol >= 0.0)) { opfx_set_error("opfx_solve: jacobian_reuse_tol must be >= 0"); return OPFX_ERR_INVALID; }
   if (o.init == OPFX_INIT_DC && !ctx->dp.lp_dc) { opfx_set_error("opfx_solve: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && (!qg_min || !qg_max)) o.enforce_q_lims = 0;
   const int nres = 3 * ctx->plan.nb + ctx->plan.nbr + 2 * ctx->plan.nref;
@@ -3197,7 +3350,8 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     if (rc != OPFX_OK) return rc;
     dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
-    SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
+    o.reuse_tol = 0.0;                                            // (nor chord steps)
+    SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, min_pivot_bus, 0};
     if ((io.queued = use_queue(ctx->dbg, B, grid, 4))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
     HIP_TRY(hipGetLastError());
@@ -3219,8 +3373,16 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
     ctx->solve_per_cu_dc = per_cu_dc;
     if (rc != OPFX_OK) return rc;
+  } else if (o.reuse_tol > 0.0 && ctx->v2) {         // the kernels compiled with chord steps (not together with the DC start)
+    kern = packed ? (team == 4 ? k_solve<2, 4, false, false, true> : (team == 2 ? k_solve<2, 2, false, false, true> : k_solve<2, 1, false, false, true>))
+                  : (team == 4 ? k_solve<1, 4, false, false, true> : (team == 2 ? k_solve<1, 2, false, false, true> : k_solve<1, 1, false, false, true>));
+    int per_cu_c = ctx->solve_per_cu_chord;
+    rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &per_cu_c, WAVE * team);
+    ctx->solve_per_cu_chord = per_cu_c;
+    if (rc != OPFX_OK) return rc;
   }
-  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, 0};
+  if (o.init == OPFX_INIT_DC || !ctx->v2) o.reuse_tol = 0.0;
+  SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, min_pivot_bus, 0};
   if ((io.queued = use_queue(ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
                      (long long)B);
@@ -3475,7 +3637,8 @@ extern "C" void opfx_env_destroy(opfx_env* env) { delete env; }
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                    int32_t mode, void* stream) {
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1, opts ? opts->contingency_start : 0,
-         opts ? opts->init : 0};
+         opts ? opts->init : 0, opts ? opts->jacobian_reuse_tol : 0.0};
+  if (!(o.reuse_tol >= 0.0)) { opfx_set_error("opfx_step: jacobian_reuse_tol must be >= 0"); return OPFX_ERR_INVALID; }
   if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
@@ -3494,6 +3657,16 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     if (rc != OPFX_OK) return rc;
     dp.blk_mem = env->ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(env->ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
+    o.reuse_tol = 0.0;                                            // (nor chord steps)
+  }
+  if (o.init == OPFX_INIT_DC || !env->ctx->v2) o.reuse_tol = 0.0;      // (chord steps: not together with the DC start)
+  if (o.reuse_tol > 0.0) {                           // the kernels compiled with chord steps (same launch geometry)
+    kern = packed ? (team == 4 ? k_step<2, 4, false, false, true> : (team == 2 ? k_step<2, 2, false, false, true> : k_step<2, 1, false, false, true>))
+                  : (team == 4 ? k_step<1, 4, false, false, true> : (team == 2 ? k_step<1, 2, false, false, true> : k_step<1, 1, false, false, true>));
+    int per_cu_c = env->per_cu_chord;
+    rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &per_cu_c, WAVE * team);
+    env->per_cu_chord = per_cu_c;
+    if (rc != OPFX_OK) return rc;
   }
   if (o.init == OPFX_INIT_DC && env->ctx->v2) {      // the kernels compiled with the DC start (same launch geometry)
     kern = packed ? (team == 4 ? k_step<2, 4, true> : (team == 2 ? k_step<2, 2, true> : k_step<2, 1, true>))
@@ -3511,7 +3684,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.mean_correction = io->mean_correction; s.max_mismatch = io->max_mismatch;
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
-  s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot;
+  s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot; s.min_pivot_bus = io->min_pivot_bus;
   dp.queue = env->queue;
   if ((s.queued = use_queue(env->ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(env->queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
@@ -3745,6 +3918,7 @@ extern "C" int opfx_env_set_reset(opfx_env* env, const opfx_reset_desc* d_in) {
     R.n_oel = (int)oe.size();
     if (rc == OPFX_OK) rc = A.put(oe, &R.oe_src);
   }
+  if (rc == OPFX_OK) rc = A.put(&env->dr, 1, &env->d_dr);
   if (rc != OPFX_OK) return rc;
   env->has_reset = true;
   return OPFX_OK;
@@ -3778,7 +3952,7 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
     int& per_cu = env->reset_per_cu[full ? 1 : 0];
     if (per_cu <= 0) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * wpb, lds));
     const int grid = (int)std::min<long long>((B + wpb - 1) / wpb, (long long)env->ctx->n_cu * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->dr, env->d_de, r,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds, static_cast<hipStream_t>(stream), env->d_dr, env->d_de, r,
                        (long long)B, row_doubles);
     return OPFX_OK;
   };

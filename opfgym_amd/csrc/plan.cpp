@@ -318,7 +318,7 @@ void build_lane_programs(opfx_plan* p) {
   std::vector<int32_t> b_bounds{0}, c_bounds;
   struct Item3 { uint32_t w0, w1, w2; };
   constexpr uint32_t NO_RIDER = NONE | (NONE << 16);
-  std::vector<std::vector<Item3>> lev_rider(nlev), lev_sep(nlev);
+  std::vector<std::vector<Item3>> lev_rider(nlev), lev_sep(nlev), lev_rhs(nlev);      // lev_rhs: the forward substitution alone (chord steps)
   for (int lev = 0; lev < nlev; ++lev) {
     const int t0 = p->lev_tptr[lev], t1 = p->lev_tptr[lev + 1];
     // right-hand-side terms of the level by the block A_ik they multiply with: (i, k)
@@ -354,6 +354,7 @@ void build_lane_programs(opfx_plan* p) {
       }
     }
     lev_sep[lev].insert(lev_sep[lev].end(), rhs_items.begin(), rhs_items.end());       // block targets first, rhs targets last
+    lev_rhs[lev] = rhs_items;
     lev_rider[lev] = carriers;                                                          // items with a rider first
     lev_rider[lev].insert(lev_rider[lev].end(), plain.begin(), plain.end());
     lev_rider[lev].insert(lev_rider[lev].end(), rhs_left.begin(), rhs_left.end());
@@ -441,6 +442,31 @@ void build_lane_programs(opfx_plan* p) {
     for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
       if (p->lp_groups[g + 1] > p->lp_groups[g])
         spread_over_banks(&p->lp_bc[(size_t)p->lp_groups[g] * 256], p->lp_groups[g + 1] - p->lp_groups[g], p->n_full);
+  // ---- the chord stream (opfx_solve_opts.jacobian_reuse_tol): an iteration that keeps the factorisation of an earlier
+  // one runs the FORWARD SUBSTITUTION alone — the right-hand-side items of every level, which read A_ik and A_kk as the
+  // factorisation left them — and then the same back substitution: [rf_pad rounds F | the C rounds of lp_bc] ----------
+  {
+    std::vector<uint32_t> f;
+    std::vector<int32_t> f_bounds{0};
+    for (int lev = 0; lev < nlev; ++lev) {
+      const std::vector<Item3>& its = lev_rhs[lev];
+      for (size_t o = 0; o < its.size(); o += 64)
+        for (int lane = 0; lane < 64; ++lane) {
+          if (o + lane < its.size()) { f.push_back(its[o + lane].w0); f.push_back(its[o + lane].w1); f.push_back(NO_RIDER); f.push_back(0u); }
+          else { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_RIDER); f.push_back(0u); }
+        }
+      if ((int32_t)(f.size() / 256) > f_bounds.back()) f_bounds.push_back((int32_t)(f.size() / 256));
+    }
+    p->rf = (int32_t)(f.size() / 256);
+    p->rf_pad = (p->rf + 3) & ~3;
+    if (p->rf_pad + p->rc_pad < 4) p->rf_pad = 4;
+    if (spread)
+      for (size_t g = 0; g + 1 < f_bounds.size(); ++g) spread_over_banks(&f[(size_t)f_bounds[g] * 256], f_bounds[g + 1] - f_bounds[g], p->n_full);
+    while ((int32_t)(f.size() / 256) < p->rf_pad)
+      for (int l = 0; l < 64; ++l) { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_RIDER); f.push_back(0u); }
+    p->lp_bcc = f;
+    p->lp_bcc.insert(p->lp_bcc.end(), p->lp_bc.begin() + (size_t)p->rb_pad * 256, p->lp_bc.end());
+  }
   // ---- the dense tail ---------------------------------------------------------------------------
   // A meshed grid ends in a chain of levels with ONE pivot each (the last separator fills in completely:
   // 16 such levels on the 306-bus grid, 20 on the 372-bus one).  Their back substitution is a strictly serial
@@ -464,6 +490,13 @@ void build_lane_programs(opfx_plan* p) {
   for (int sx = 0; sx < tail_m; ++sx)
     for (auto& kt : col_terms[p->tail_bus[sx] & 0xFFFFu])
       if (tail_pos[kt[0]] >= 0) p->tail_ids[(size_t)tail_pos[kt[0]] * tail_M + sx] = (uint16_t)kt[1];
+  // the LOWER triangle: entry [e][s], e > s, = L-block (row e, column s) — the forward substitution through the tail as a
+  // register chain (chord iterations, opfx.hip tail_chain FWD); read off the right-hand-side items of the tail levels
+  for (int lev = nlev - tail_m; lev < nlev; ++lev)
+    for (const Item3& it : lev_rhs[lev]) {
+      const int i = (int)(it.w0 & 0x7FFFu), k = (int)(it.w1 >> 16);
+      if (tail_pos[i] > tail_pos[k] && tail_pos[k] >= 0) p->tail_ids[(size_t)tail_pos[i] * tail_M + tail_pos[k]] = (uint16_t)(it.w0 >> 16);
+    }
   p->tail_ids32.assign(p->tail_ids.begin(), p->tail_ids.end());
   // back-substitution rounds of the team streams: (register chain) [tail columns -> outside rows] [levels below the tail]
   std::vector<uint32_t> tc;                               // rounds of 64 items x 4 words
@@ -498,12 +531,6 @@ void build_lane_programs(opfx_plan* p) {
   for (int t = 0; t < 2; ++t) {
     const int NW = t == 0 ? 2 : 4;
     std::vector<uint32_t>& out = p->lp_team[t];
-    int K = 0;
-    auto empty_round = [&](uint32_t flags) {
-      for (int w = 0; w < NW; ++w)
-        for (int l = 0; l < 64; ++l) { out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(NONE | (NONE << 16)); out.push_back(flags); }
-      ++K;
-    };
     // real groups (padding ranges dropped): (source, first round, end round); source 0 = lp_bc, 1 = tc,
     // 2 = tbk (this team's factorisation rounds).
     // With a tail the stream has two parts, each padded to a multiple of 4 rounds: factorisation + forward
@@ -542,42 +569,71 @@ void build_lane_programs(opfx_plan* p) {
         if (spread && t == 0) spread_over_banks(&tc[(size_t)tc_bounds[g] * 256], tc_bounds[g + 1] - tc_bounds[g], p->n_full);
         groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
       }
-    p->team_kb[t] = -1;
-    for (size_t g = 0; g < groups.size(); ++g) {
-      const int r0 = groups[g].r0, r1 = groups[g].r1;
-      const int per = (r1 - r0 + NW - 1) / NW;
-      // A group of ONE round runs on wavefront 0 alone; when the next group is such a group too, the same
-      // wavefront carries on and its LDS operations execute in issue order: no workgroup barrier between them
-      // (the dense tail of a meshed grid is a long chain of one-round groups).
-      const bool single = r1 - r0 == 1;
-      if (tail_m > 0 && g == n_first) {                          // part boundary: the chain runs here
-        while (K % 4 || K < 4) empty_round(0u);
-        p->team_kb[t] = K;
+    // forward substitution alone, per level (chord steps): same dealing, same barrier rules
+    std::vector<uint32_t> tfk;
+    std::vector<Group> groups_c;
+    for (int lev = 0; lev < nlev - tail_m; ++lev) {      // (the tail's own forward substitution: the register chain)
+      const std::vector<Item3>& its = lev_rhs[lev];
+      const int nr = rounds_of(its.size());
+      if (nr == 0) continue;
+      const int first = (int)(tfk.size() / 256);
+      tfk.resize(tfk.size() + (size_t)nr * 256, NONE | (NONE << 16));
+      for (size_t q = 0; q < its.size(); ++q) {
+        uint32_t* at = &tfk[((size_t)(first + q / 64) * 64 + q % 64) * 4];
+        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w2;
       }
-      const bool last_of_part = tail_m > 0 && g + 1 == n_first;  // (the chain runs on wavefront 0, like a one-round group)
-      const bool next_single = last_of_part || (g + 1 < groups.size() && groups[g + 1].r1 - groups[g + 1].r0 == 1);
-      const uint32_t* src = groups[g].src == 0 ? p->lp_bc.data() : (groups[g].src == 1 ? tc.data() : tbk.data());
-      for (int j = 0; j < per; ++j) {
-        const uint32_t flags = ((j == per - 1 && !(single && next_single)) ? 1u : 0u) | (j < per - 1 ? 2u : 0u);
-        p->team_barriers[t] += (int32_t)(flags & 1u);
-        for (int w = 0; w < NW; ++w) {
-          const int r = r0 + j * NW + w;
-          for (int l = 0; l < 64; ++l) {
-            if (r < r1) for (int q = 0; q < 3; ++q) out.push_back(src[((size_t)r * 64 + l) * 4 + q]);
-            else for (int q = 0; q < 3; ++q) out.push_back(NONE | (NONE << 16));
-            out.push_back(flags);
-          }
-        }
+      if (spread) spread_over_banks(&tfk[(size_t)first * 256], nr, p->n_full);
+      groups_c.push_back({3, first, first + nr});
+    }
+    const size_t n_first_c = tail_m > 0 ? groups_c.size() : 0;
+    for (size_t g = (tail_m > 0 ? n_first : 0); g < groups.size(); ++g)
+      if (groups[g].src != 2) groups_c.push_back(groups[g]);          // the back-substitution groups of the main stream
+    auto emit = [&](const std::vector<Group>& gs, size_t n_first_, std::vector<uint32_t>& out_, int32_t& K_out, int32_t& kb_out, int32_t& barriers_out) {
+      int K = 0;
+      auto empty_round = [&](uint32_t flags) {
+        for (int w = 0; w < NW; ++w)
+          for (int l = 0; l < 64; ++l) { out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(flags); }
         ++K;
+      };
+      kb_out = -1;
+      for (size_t g = 0; g < gs.size(); ++g) {
+        const int r0 = gs[g].r0, r1 = gs[g].r1;
+        const int per = (r1 - r0 + NW - 1) / NW;
+        // A group of ONE round runs on wavefront 0 alone; when the next group is such a group too, the same
+        // wavefront carries on and its LDS operations execute in issue order: no workgroup barrier between them
+        // (the dense tail of a meshed grid is a long chain of one-round groups).
+        const bool single = r1 - r0 == 1;
+        if (tail_m > 0 && g == n_first_) {                         // part boundary: the chain runs here
+          while (K % 4 || K < 4) empty_round(0u);
+          kb_out = K;
+        }
+        const bool last_of_part = tail_m > 0 && g + 1 == n_first_; // (the chain runs on wavefront 0, like a one-round group)
+        const bool next_single = last_of_part || (g + 1 < gs.size() && gs[g + 1].r1 - gs[g + 1].r0 == 1);
+        const uint32_t* src = gs[g].src == 0 ? p->lp_bc.data() : (gs[g].src == 1 ? tc.data() : (gs[g].src == 2 ? tbk.data() : tfk.data()));
+        for (int j = 0; j < per; ++j) {
+          const uint32_t flags = ((j == per - 1 && !(single && next_single)) ? 1u : 0u) | (j < per - 1 ? 2u : 0u);
+          barriers_out += (int32_t)(flags & 1u);
+          for (int w = 0; w < NW; ++w) {
+            const int r = r0 + j * NW + w;
+            for (int l = 0; l < 64; ++l) {
+              if (r < r1) for (int q = 0; q < 3; ++q) out_.push_back(src[((size_t)r * 64 + l) * 4 + q]);
+              else for (int q = 0; q < 3; ++q) out_.push_back(NONE | (NONE << 16));
+              out_.push_back(flags);
+            }
+          }
+          ++K;
+        }
       }
-    }
-    if (tail_m > 0 && p->team_kb[t] < 0) {                       // (no back-substitution group at all)
+      if (tail_m > 0 && kb_out < 0) {                              // (no back-substitution group at all)
+        while (K % 4 || K < 4) empty_round(0u);
+        kb_out = K;
+      }
       while (K % 4 || K < 4) empty_round(0u);
-      p->team_kb[t] = K;
-    }
-    while (K % 4 || K < 4) empty_round(0u);
-    p->team_rounds[t] = K;
-    if (tail_m == 0) p->team_kb[t] = K;
+      K_out = K;
+      if (tail_m == 0) kb_out = K;
+    };
+    emit(groups, n_first, out, p->team_rounds[t], p->team_kb[t], p->team_barriers[t]);
+    emit(groups_c, n_first_c, p->lp_teamc[t], p->team_rounds_c[t], p->team_kb_c[t], p->team_barriers_c[t]);
     p->n_groups = (int32_t)groups.size();
   }
   static_assert(KA >= 1 && KA <= 3, "entries and the diagonal-block word share one 16-byte vector");
@@ -742,9 +798,9 @@ static int plan_build(const opfx_case* c, const PlanKnobs& knobs, const opfx_deb
       }
 
   // ---- level-scheduled multiple-minimum-degree elimination --------------------
-  std::vector<char> alive(nb, 0), blocked(nb, 0);
-  int32_t n_alive = 0;
-  for (int32_t i = 0; i < nb; ++i) if (!is_ref(i)) { alive[i] = 1; ++n_alive; }
+  std::vector<char> alive(nb, 0), blocked(nb, 0), last(nb, 0);
+  int32_t n_alive = 0, n_first = 0;            // n_first: alive buses that are not held back (opfx_case.elim_last)
+  for (int32_t i = 0; i < nb; ++i) if (!is_ref(i)) { alive[i] = 1; ++n_alive; last[i] = (c->elim_last && c->elim_last[i]) ? 1 : 0; n_first += !last[i]; }
   p->lev_tptr.push_back(0);
   p->lev_pptr.push_back(0);
   p->tgt_sptr.push_back(0);
@@ -753,7 +809,8 @@ static int plan_build(const opfx_case* c, const PlanKnobs& knobs, const opfx_deb
   while (n_alive > 0) {
     cand.clear();
     size_t dmin = SIZE_MAX;
-    for (int32_t i = 0; i < nb; ++i) if (alive[i]) { cand.push_back(i); dmin = std::min(dmin, adj[i].size()); }
+    // (buses held back by opfx_case.elim_last are no candidates while any other bus is left)
+    for (int32_t i = 0; i < nb; ++i) if (alive[i] && (n_first == 0 || !last[i])) { cand.push_back(i); dmin = std::min(dmin, adj[i].size()); }
     // a level takes every independent vertex of degree <= dmin + slack: on meshed grids a slack of 2 cuts the number
     // of levels by a quarter at no extra fill
     const int slack = knobs.slack;
@@ -816,6 +873,7 @@ static int plan_build(const opfx_case* c, const PlanKnobs& knobs, const opfx_deb
       for (int32_t j : adj[k]) adj[j].erase(k);
       adj[k].clear();
       alive[k] = 0; --n_alive;
+      n_first -= !last[k];
     }
   }
   p->n_blk = (int32_t)p->blk_row.size();
@@ -912,6 +970,9 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->tail_m = p->tail_m;
   o->lp_ell_width = opfx_plan::KA;
   o->has_dc = p->lp_dc.empty() ? 0 : 1;
+  o->lp_rounds_f = p->rf;
+  for (int t = 0; t < 2; ++t) { o->team_rounds_chord[t] = p->team_rounds_c[t]; o->team_barriers_chord[t] = p->team_barriers_c[t]; o->team_kb_chord[t] = p->team_kb_c[t]; }
+  o->lp_rounds_f_pad = p->rf_pad;
   full.struct_size = caller_size;
   std::memcpy(caller, &full, caller_size);          // (a caller built against an older, shorter layout gets its prefix)
   return OPFX_OK;
@@ -931,6 +992,9 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
     case OPFX_ARR_LP_TEAM2: v = u32(p->lp_team[0]); break;
     case OPFX_ARR_LP_TEAM4: v = u32(p->lp_team[1]); break;
+    case OPFX_ARR_LP_BCC: v = u32(p->lp_bcc); break;
+    case OPFX_ARR_LP_TEAMC2: v = u32(p->lp_teamc[0]); break;
+    case OPFX_ARR_LP_TEAMC4: v = u32(p->lp_teamc[1]); break;
     case OPFX_ARR_TAIL_BUS: v = u32(p->tail_bus); break;
     case OPFX_ARR_TAIL_IDS: v = &p->tail_ids32; break;
     case OPFX_ARR_BR_ISLAND: v = &p->br_island; break;

@@ -67,6 +67,9 @@ struct opfx_plan {
   std::vector<uint32_t> lp_c;              // [rc][64][2]  (0x8000|k)|blk(k,j)<<16 , blk(j,j)|j<<16  (back substitution, same item form as lp_b)
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
   std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,rider,flags (pad: empty items)
+  // chord steps (opfx_solve_opts.jacobian_reuse_tol): forward substitution alone + the same back substitution
+  int32_t rf = 0, rf_pad = 0;              // rounds of the forward substitution (right-hand-side items of every level), padded to 4
+  std::vector<uint32_t> lp_bcc;            // [rf_pad+rc_pad][64][4]
   std::vector<uint32_t> lp_apk;            // [ra][KA+2][64][4]  ent0..ent(KA-1), dblk | y0 | .. | y(KA-1) | ydiag
   std::vector<uint32_t> lp_hpk;            // [rh][2][64][4]  y(g,b) | j|blk<<16, row bus (0xFFFF none), 0, 0
   std::vector<int32_t> lp_hrows;           // buses whose rows have overflow entries (their sums start at 0)
@@ -80,6 +83,8 @@ struct opfx_plan {
   int32_t team_rounds[2] = {0, 0};         // rounds per wave (multiples of 4)
   int32_t team_barriers[2] = {0, 0};       // rounds that end with a workgroup barrier
   int32_t team_kb[2] = {0, 0};             // rounds of the first part of the stream (the tail chain runs after it); = team_rounds without a tail
+  std::vector<uint32_t> lp_teamc[2];       // chord stream of the teams: [forward-substitution groups | (tail chain) | back-substitution groups]
+  int32_t team_rounds_c[2] = {0, 0}, team_barriers_c[2] = {0, 0}, team_kb_c[2] = {0, 0};
   int32_t n_groups = 0;                    // independent groups of the B/C stream
   // dense tail of the elimination (levels with one pivot each at the end), solved in registers by the wave teams
   static constexpr int TAIL_MAX = 32;

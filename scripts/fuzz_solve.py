@@ -3,7 +3,12 @@ radial and meshed synthetic networks of random size with random taps, phase shif
 shunts, elements out of service and closed bus-bus switches; random injections; optionally a random
 branch outage per instance and generator reactive limits.
 
-    python scripts/fuzz_solve.py [n_grids] [seed]
+    python scripts/fuzz_solve.py [n_grids] [seed] [stress]
+
+`stress`: the twelve instances of a grid carry its nominal injections scaled geometrically from 1 to 12 — through and
+past voltage collapse — and the script COUNTS what the static pivoting of the block LU could get wrong (SURVEY §7 hard
+part 2): rows where the kernel does not converge although the oracle (SuperLU, partial pivoting) does,
+the reverse, and the smallest relative pivot `min_pivot` among the rows both solve.
 
 Exercises the symbolic plan (ordering, levels, fill, lane programmes, wave teams) on topologies the
 fixed test grids do not have."""
@@ -79,7 +84,10 @@ def main():
     import torch
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    stress = len(sys.argv) > 3 and sys.argv[3] == 'stress'
     bad = done = 0
+    gpu_only_fail = oracle_only_fail = both_fail = 0
+    worst_pivot = 1.0
     dev = torch.device('cuda:0')
     for g in range(n):
         rng = np.random.default_rng([seed, g])
@@ -91,6 +99,10 @@ def main():
             ctx = capi.Context(plan, 0)
             B = 12
             p, q = random_injections(net, case, B, rng)
+            if stress:                      # nominal injections, scaled through and past voltage collapse
+                p1, q1 = random_injections(net, case, 1, rng, lo=1.0, hi=1.0)
+                sc = np.geomspace(1.0, 12.0, B)[:, None]
+                p, q = p1 * sc, q1 * sc
             kw, okw = {}, {}
             if rng.random() < 0.4 and case.nbr > 3:
                 out = rng.integers(-1, case.nbr, B).astype(np.int32)
@@ -107,7 +119,19 @@ def main():
             # islanding outages de-energise the island (NaN voltages there): compared separately below
             isl = np.isnan(got['vm']).any(axis=1)
             cmp_rows = both & ~isl
-            assert (got['converged'].astype(bool)[~isl] == ref['converged'][~isl]).all(), ('converged flags', desc)
+            gc, rc_ = got['converged'].astype(bool), ref['converged']
+            gpu_only_fail += int((~gc & rc_ & ~isl).sum())
+            oracle_only_fail += int((gc & ~rc_ & ~isl).sum())
+            both_fail += int((~gc & ~rc_).sum())
+            if (gc & rc_).any():
+                worst_pivot = min(worst_pivot, float(np.nanmin(got['min_pivot'][gc & rc_])))
+            if stress:
+                # next to the collapse point the two Newton iterations may legitimately part ways (one more iteration
+                # allowed by neither): a row counts as a static-pivot suspect only when its pivots actually broke down
+                suspects = ~gc & rc_ & ~isl & (got['min_pivot'] < 1e-8)
+                assert not suspects.any(), ('static pivoting broke down where partial pivoting converged', desc, np.flatnonzero(suspects).tolist())
+            else:
+                assert (gc[~isl] == rc_[~isl]).all(), ('converged flags', desc)
             if cmp_rows.any():
                 dv = np.abs(got['vm'][cmp_rows] - ref['vm'][cmp_rows]).max()
                 dl = np.abs(got['loading'][cmp_rows] - ref['loading'][cmp_rows]).max()
@@ -156,7 +180,8 @@ def main():
             bad += 1
             print(f'[{g}] ERROR')
             traceback.print_exc()
-    print(f'{n} grids, {done} solves compared, {bad} failures')
+    print(f'{n} grids, {done} solves compared, {bad} failures; kernel failed where the oracle converged: {gpu_only_fail}, oracle failed where '
+          f'the kernel converged: {oracle_only_fail}, both failed: {both_fail}; smallest relative pivot among rows both solved: {worst_pivot:.3e}')
     sys.exit(1 if bad else 0)
 
 

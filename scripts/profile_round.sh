@@ -27,8 +27,11 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 cd $root
 python3 - "$out" "$tag" "$cfg" "$psteps" <<'PY'
-import sys, glob, csv, collections, json, shutil
+import sys, glob, csv, collections, json, shutil, hashlib
 out, tag, cfg, psteps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+sha = hashlib.sha256()
+for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h', 'include/opfx.h'):
+    sha.update(open(rel, 'rb').read())          # (= bench.py source_sha16: counters are only used with the sources they were taken from)
 st = glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)
 if st:
     shutil.copy(st[0], out + '/kernel_stats.csv')
@@ -58,7 +61,7 @@ except Exception:
     pass
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     fk, wk = mean['FETCH_SIZE'], mean['WRITE_SIZE']
-    json.dump({'kernel': name, 'tag': tag, 'config': int(cfg), 'batch': batch,
+    json.dump({'kernel': name, 'tag': tag, 'config': int(cfg), 'batch': batch, 'source_sha16': sha.hexdigest()[:16],
                'kernel_avg_ns': avg_ns, 'kernel_calls': calls,
                'sq': {k: v for k, v in mean.items() if k not in ('FETCH_SIZE', 'WRITE_SIZE')},
                'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --config %s --steps %s --warmup 2 --no-cpu-baseline (one pass per counter)' % (cfg, psteps),

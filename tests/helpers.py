@@ -268,3 +268,21 @@ def published_cases():
                              va_deg=[0.0, -2.806, -4.997, -5.329, -6.150], va_tol=1.1e-3,
                              pg={0: 129.59}, qg={0: -7.42}, s_tol=1.1e-2),),
     }
+
+
+def resonant_leaf_ppc(n_chain=4):
+    """A case on which STATIC pivoting breaks down although the Jacobian is regular: a chain of `n_chain` buses behind the
+    slack and, at its end, a leaf bus without load whose shunt capacitor compensates HALF of its line's susceptance
+    (line x = 0.1, r = 0: B_ij = 10; shunt +5 p.u.).  At the flat start the leaf's own 2x2 diagonal Jacobian block
+    [[dP/dth, dP/dlnV], [dQ/dth, dQ/dlnV]] = [[10, 0], [0, 0]] is exactly singular — the reactive balance of that bus does
+    not depend on ITS voltage to first order —, while the full matrix (the coupling block to the neighbour is -10 I) is
+    not: SuperLU pivots on the coupling entries; a minimum-degree block elimination takes the leaf first and divides by
+    zero.  pypower matrices (0-based): (base, bus, branch, gen), the leaf is the last bus."""
+    nb = n_chain + 2
+    z = 0.0
+    bus = np.array([[i, 3 if i == 0 else 1, 0.0 if i in (0, nb - 1) else 20.0, 0.0 if i in (0, nb - 1) else 5.0, z, z, 1,
+                     1.0, 0.0, 110, 1, 1.1, 0.9] for i in range(nb)])
+    bus[nb - 1, 5] = 5.0 * 100.0                               # Bs [MVAr at 1 p.u.]: +5 p.u. on base 100
+    branch = np.array([[i, i + 1, 0.01 if i < nb - 2 else 0.0, 0.1, 0.0, 0, 0, 0, 0, 0, 1, -360, 360] for i in range(nb - 1)], dtype=float)
+    gen = np.array([[0, 0.0, 0.0, 1e4, -1e4, 1.0, 100, 1]])
+    return 100.0, bus, branch, gen

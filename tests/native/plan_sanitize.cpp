@@ -34,14 +34,20 @@ static int run(int nb, int extra, unsigned seed, bool complete) {
     const double s[8] = {g, b, -g, -b, -g, -b, g, b};
     for (int q = 0; q < 8; ++q) y[8 * (size_t)k + q] = s[q];
   }
-  opfx_case c{nb, nbr, 100.0, bt.data(), vm.data(), va.data(), gs.data(), bs.data(), f.data(), t.data(), y.data(), kf.data(), kt.data()};
+  opfx_case c;
+  OPFX_INIT(c);                                   // (zeroed, struct_size stamped: include/opfx.h VERSIONING)
+  c.nb = nb; c.nbr = nbr; c.base_mva = 100.0; c.bus_type = bt.data(); c.vm_set = vm.data(); c.va_set = va.data();
+  c.gs = gs.data(); c.bs = bs.data(); c.br_f = f.data(); c.br_t = t.data(); c.br_y = y.data(); c.br_kf = kf.data(); c.br_kt = kt.data();
+  std::vector<int32_t> held(nb, 0);               // every third graph: a few buses held back to the end (opfx_case.elim_last)
+  if (seed % 3 == 0) { for (int i = 1; i < nb; i += 7) held[i] = 1; c.elim_last = held.data(); }
   opfx_plan* p = nullptr;
   const int rc = opfx_plan_create(&c, &p);
   if (rc != OPFX_OK) { std::printf("nb=%d: plan_create -> %d (%s)\n", nb, rc, opfx_last_error()); return rc == OPFX_ERR_TOO_LARGE ? 0 : 1; }
   opfx_plan_info info;
-  opfx_plan_get_info(p, &info);
+  OPFX_INIT(info);
+  if (opfx_plan_get_info(p, &info) != OPFX_OK) { std::printf("plan_get_info: %s\n", opfx_last_error()); return 1; }
   long long total = 0;
-  for (int which = 0; which <= OPFX_ARR_LP_B2; ++which) {
+  for (int which = 0; which <= OPFX_ARR_LP_TEAMC4; ++which) {
     const int64_t n = opfx_plan_get_array(p, which, nullptr, 0);
     if (n < 0) { std::printf("array %d: %lld\n", which, (long long)n); return 1; }
     std::vector<int32_t> buf((size_t)n + 1);

@@ -126,7 +126,7 @@ def emulate_newton(plan, p_sp, q_sp, tol=1e-8, max_iter=10, check_levels=True):
                 va[i] += np.pi
 
 
-def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0):
+def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0, reuse_tol=0.0, trace=None):
     """Walks the LANE PROGRAMME (plan.h lp_*: what kernel `newton2` executes) in
     numpy: ELL bus rows + overflow entries, flat update items accumulated per
     target, solve items with inline U-terms; relative-|V| unknowns and the
@@ -134,7 +134,11 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
     team = 2 | 4: factorisation and substitutions walk the WAVE-TEAM stream instead (what `newton2_coop`
     executes: rounds dealt to the wavefronts, barrier flags, the dense tail's register chain between the two
     parts of the stream), with a race check: between two workgroup barriers no wavefront may read a location
-    another wavefront adds to."""
+    another wavefront adds to.
+    reuse_tol > 0: chord steps as the kernels compiled with CHORD take them (opfx_solve_opts.jacobian_reuse_tol): an
+    iteration that keeps the factorisation of an earlier one computes the mismatch only and walks the CHORD stream
+    (lp_bcc / lp_teamc: forward substitution alone, then the same back substitution).  `trace` (a list) receives one
+    (norm, factorised) pair per iteration."""
     NONE = 0xFFFF
     case = plan.case
     info = plan.info
@@ -160,8 +164,12 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
     def inv2(b):
         det = b[0, 0] * b[1, 1] - b[0, 1] * b[1, 0]
         return np.array([[b[1, 1], -b[0, 1]], [-b[1, 0], b[0, 0]]]) / det
+    chord_now, e_prev = False, 0.0
+    blk = None
     while True:
-        blk = np.full((nblk, 2, 2), np.nan)
+        jac = not chord_now
+        kept = blk
+        blk = np.full((nblk, 2, 2), np.nan)                 # (a chord iteration writes into a scratch copy that is dropped)
         blk[fill] = 0.0
         rhs = np.zeros((nb, 2))
         soff = np.zeros(nb, complex)
@@ -218,8 +226,36 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
             return v, False, it, nrm
         it += 1
         assert not np.isnan(blk).any()
+        if trace is not None:
+            trace.append((nrm, jac))
+        chord_next = False
+        if reuse_tol > 0.0:
+            chord_next = nrm < reuse_tol if jac else nrm < 0.1 * e_prev
+            e_prev = nrm
+        if not jac:
+            blk = kept                                   # the factorisation of the earlier iteration, untouched by phase A
         if team:
-            _team_factor_solve(plan, team, blk, rhs, inv2)
+            _team_factor_solve(plan, team, blk, rhs, inv2, chord=not jac)
+        elif not jac:
+            rfp, rcp = info['lp_rounds_f_pad'], (rc + 3) & ~3
+            if rfp + rcp < 4:
+                rcp = 4
+            bcc = plan.array('lp_bcc').view(np.uint32).reshape(-1, 64, 4)
+            assert len(bcc) == rfp + rcp
+            for r in range(rfp + rcp):                   # forward substitution alone, then the back substitution
+                drhs = {}
+                for lane in range(64):
+                    w0, w1 = int(bcc[r, lane, 0]), int(bcc[r, lane, 1])
+                    tb = w0 & 0xFFFF
+                    if tb == NONE:
+                        continue
+                    assert tb & 0x8000 and (int(bcc[r, lane, 2]) >> 16) == NONE      # right-hand-side targets only, no riders
+                    k = tb & 0x7FFF
+                    w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
+                    drhs[k] = drhs.get(k, 0) + w @ rhs[w1 >> 16]
+                    assert (w1 >> 16) not in drhs          # a source of this round is final
+                for k, d in drhs.items():
+                    rhs[k] -= d
         else:
             for r in range(rb):
                 dblk_upd, drhs = {}, {}
@@ -263,16 +299,19 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0)
         for i in range(nb):
             if bt[i] != REF:
                 v[i] = v[i] * (1.0 + rhs[i, 1]) * np.exp(1j * rhs[i, 0])
+        chord_now = chord_next
 
 
-def _team_factor_solve(plan, nw, blk, rhs, inv2):
+def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
     """Phases B and C as a team of `nw` wavefronts walks them (csrc/plan.cpp lp_team, csrc/opfx.hip team_step /
     tail_solve).  Rounds are executed in stream order, wavefront 0 first (one legal interleaving); the race check
     makes sure every other interleaving between two barriers gives the same result up to the order of additions."""
     NONE = 0xFFFF
     info = plan.info
     K, Kb, m = info[f'team_rounds_{nw}'], info[f'team_kb_{nw}'], info['tail_m']
-    stream = plan.array(f'lp_team{nw}').view(np.uint32).reshape(K, nw, 64, 4)
+    if chord:                    # forward substitution alone | (tail chain) | back substitution
+        K, Kb = info[f'team_rounds_chord_{nw}'], info[f'team_kb_chord_{nw}']
+    stream = plan.array(f'lp_teamc{nw}' if chord else f'lp_team{nw}').view(np.uint32).reshape(K, nw, 64, 4)
     assert K % 4 == 0 and Kb % 4 == 0 and (m > 0 or Kb == K)
     reads = [set() for _ in range(nw)]
     adds = [set() for _ in range(nw)]
@@ -336,6 +375,14 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2):
         y = [rhs[bus[e]].copy() for e in range(m)]
         for e in range(m):
             reads[0].update((('r', bus[e]), ('b', dblk[e])))
+        if chord:
+            # the forward substitution through the tail, same chain run forward first: ids in the LOWER triangle
+            for s_ in range(m - 1):
+                z = inv2(blk[dblk[s_]]) @ y[s_]
+                for e in range(s_ + 1, m):
+                    if ids[e, s_] != NONE:
+                        y[e] = y[e] - blk[ids[e, s_]] @ z
+                        reads[0].add(('b', int(ids[e, s_])))
         for s_ in range(m - 1, 0, -1):
             x = inv2(blk[dblk[s_]]) @ y[s_]
             for e in range(s_):

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-        'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+        'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'timing'}
 
 
 def _run(*args):
@@ -33,30 +33,50 @@ def test_bench_line_has_the_contract_keys(config):
     r = d['roofline']
     # the bound is the resource with the largest fraction of its own peak, and no fraction of a real resource exceeds 1
     res = r['resources']
-    assert r['bound'] in res and r['bound'] == max(res, key=lambda k: res[k]['frac'])
+    real = {k: v for k, v in res.items() if k != 'fp64_useful_of_valu_busy'}      # (that one is a ratio of two of the others)
+    assert r['bound'] in real and r['bound'] == max(real, key=lambda k: real[k]['frac'])
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] <= 1.0
     for name, v in res.items():
         assert abs(v['frac'] - v['achieved'] / v['peak']) < 1e-12 and 0 <= v['frac'] <= 1.0, name
-    assert {'hbm', 'valu_issue', 'lds_array', 'lds_bytes', 'fp64_vector'} <= set(res)       # (config 2 has committed counters)
-    assert r['hbm_measured_frac'] == res['hbm']['frac'] and r['traffic'] > 0
+    assert {'lds_bytes', 'fp64_vector'} <= set(res)
+    if not r['counters_dropped_as_stale']:     # (config 2 has committed counters, taken from sources with this source_sha16)
+        assert {'hbm', 'valu_issue', 'lds_array', 'fp64_useful_of_valu_busy'} <= set(res)
+        assert r['hbm_measured_frac'] == res['hbm']['frac'] and r['traffic'] > 0 and r['counters_source_sha16'] == r['source_sha16']
+        assert abs(res['fp64_useful_of_valu_busy']['frac'] - res['fp64_vector']['frac'] / res['valu_issue']['frac']) < 1e-12
+        lb = res['lds_bytes']
+        assert abs(lb['wave_instructions_per_launch_model'] / lb['wave_instructions_per_launch_measured'] - 1) < 0.15
+    # the headline is the median of five windows of --steps launches each
+    t = d['timing']
+    assert t['windows'] == 5 and t['steps_per_window'] == 4 and len(t['ms_per_step_windows']) == 5
+    assert t['ms_per_step_p10'] <= d['ms_per_step'] <= t['ms_per_step_p90'] and sorted(t['ms_per_step_windows'])[2] == d['ms_per_step']
     # SURVEY §8d's figure, unchanged arithmetic, kept apart from the bound
     ae = r['algorithmic_equiv']
     assert ae['peak'] == 8000.0 and ae['unit'] == 'GB/s'
     assert abs(ae['achieved'] - ae['algorithmic_bytes_per_launch'] / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6 * ae['achieved']
     # the kernel time comes from the timed region itself: never longer than the wall time per step
     assert r['kernel_ms'] <= d['ms_per_step'] * 1.02
-    lb = res['lds_bytes']
-    assert abs(lb['wave_instructions_per_launch_model'] / lb['wave_instructions_per_launch_measured'] - 1) < 0.15
     bm = d['config']['byte_model']
     assert abs(bm['B_step'] - (bm['io_bytes'] + bm['it'] * bm['bytes_per_iteration'])) < 1e-6
 
 
-def test_bench_default_line_carries_cpu_baseline_and_voltage_check():
+def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_configs():
+    """The default line (here with config 1 as the headline, so that the block holds 2-5): the CPU baseline, the |V| check
+    against the oracle, and `also` — every other BASELINE configuration measured briefly on the same GPU, each with its
+    rate, kernel time, convergence, iterations, bound and its own |V| check over 64 (N-1: 8) instances."""
     d = _run('--config', '1', '--steps', '4', '--warmup', '2')
+    assert set(d) == KEYS | {'also'}
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and cb['all_cores']['cores'] >= 1
     assert 'oracle' in cb['sample']
     assert d['config']['max_abs_v_err_pu'] is not None and d['config']['max_abs_v_err_pu'] < 1e-9
+    assert set(d['also']) == {'config2', 'config3', 'config4', 'config5'}
+    for name, a in d['also'].items():
+        assert 'error' not in a, (name, a)
+        assert a['value'] > 0 and a['kernel_ms'] <= a['ms_per_step'] * 1.02 and a['converged_fraction'] > 0.99, name
+        assert 2.0 < a['mean_nr_iterations'] < 8.0 and a['roofline']['bound'] in a['roofline']['fractions'], name
+        assert a['max_abs_v_err_pu'] is not None and a['max_abs_v_err_pu'] < 1e-9, name
+        assert a['max_abs_v_err_instances'] == (8 if name == 'config5' else 64)
+    assert d['also']['config5']['steps'] == 3 and d['also']['config3']['steps'] >= 5
 
 
 def test_two_ranks_on_the_one_gpu_run_the_multi_gpu_path_end_to_end(tmp_path):
@@ -86,3 +106,56 @@ def test_two_ranks_on_the_one_gpu_run_the_multi_gpu_path_end_to_end(tmp_path):
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=os.environ.copy())
         assert r.returncode == 0, r.stderr[-3000:]
         assert np.array_equal(np.load(part), got[rank * 4096:(rank + 1) * 4096]), rank
+
+
+def _ranks_on_one_gpu(tmp_path, n_ranks, args, compare_ranks, shard_of):
+    """`bench.py --gpus n_ranks <args>` with every rank on GPU 0 (gloo staging through the host); rank 0's gathered rewards
+    against single-process runs of the ranks in `compare_ranks` with that rank's seeds and shard."""
+    import numpy as np
+    env = dict(os.environ, OPFX_BENCH_SHARE_GPU='1', OPFX_DIST_BACKEND='gloo', OPFX_BENCH_CPU_BUDGET='1')
+    full = tmp_path / 'full.npy'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks)] + args +
+                       ['--steps', '2', '--warmup', '1', '--windows', '1', '--dump-reward', str(full)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    got = np.load(full)
+    for rank in compare_ranks:
+        part = tmp_path / f'part{rank}.npy'
+        lo, hi, extra = shard_of(rank)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + args + extra +
+                           ['--steps', '2', '--warmup', '1', '--windows', '1', '--no-cpu-baseline', '--as-rank', str(rank),
+                            '--dump-reward', str(part)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                           env=os.environ.copy())
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert np.array_equal(np.load(part), got[lo:hi]), rank
+    return d, got
+
+
+def test_world_of_eight_on_the_one_gpu_weak(tmp_path):
+    """The command lines the driver issues on the 8-GPU node, end to end at world size 8 once: weak
+    scaling, `--gpus 8 --config 2 --batch 64` and `--gpus 8 --config 4 --batch 512`.  No scaling number is read off this."""
+    import numpy as np
+    for cfg, b in ((2, 64), (4, 512)):
+        sub = tmp_path / f'c{cfg}'
+        sub.mkdir()
+        d, got = _ranks_on_one_gpu(sub, 8, ['--config', str(cfg), '--batch', str(b)], (0, 7),
+                                   lambda rank, b=b: (rank * b, (rank + 1) * b, []))
+        assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['config']['batch_per_gpu'] == b and d['config']['batch_total'] == 8 * b
+        assert d['config']['parallelism'] == 'shard8' and d['config']['collective'] == 'all_gather(reward), overlapped with the next step'
+        assert got.shape == (8 * b,) and np.isfinite(got).all() and d['value'] > 0 and d['cpu_baseline'] is None
+
+
+def test_world_of_seven_on_the_one_gpu_strong_with_ragged_shards(tmp_path):
+    """`--gpus 7 --config 4`: BASELINE config 4's 65 536 instances sharded over a world size that does not divide them —
+    shards of 9 363 and 9 362 whole instances, padded for the collective and trimmed on hand-over."""
+    import numpy as np
+    from opfgym_amd.dist import shard_bounds
+    d, got = _ranks_on_one_gpu(tmp_path, 7, ['--config', '4'], (0, 3, 6),
+                               lambda rank: (*shard_bounds(65536, rank, 7), ['--of-world', '7']))
+    assert d['n_gpus'] == 7 and d['scaling'] == 'strong' and d['config']['batch_total'] == 65536
+    assert d['config']['batch_per_gpu'] == shard_bounds(65536, 0, 7)[1] and d['config']['parallelism'] == 'shard7'
+    assert 'all_gather(reward)' in d['config']['collective']
+    assert got.shape == (65536,) and np.isfinite(got).all()

@@ -20,7 +20,7 @@ R_TOL = 1e-6
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t if isinstance(t, np.ndarray) else t.detach().cpu().numpy()
 
 
 def _check_step(env, out, ref, k, n1=False):
@@ -177,18 +177,79 @@ def test_env_matches_oracle_random_batch(name, B):
     assert n_checked >= B // 2
 
 
+def _mixed_actions(env, rng, B, rows, lo, hi, reset_options, n_levels=25):
+    """Random actions; on every second row of `rows` a NEUTRAL action around one level of [lo, hi] instead (random actions
+    practically never give an all-valid state, tests/golden/scenarios.py VALID_ROWS).  The level of each such row is FOUND
+    with the product — `n_levels` batched steps, the first level whose state the kernel calls valid — and the row is then
+    compared with the oracle like any other, which confirms or refutes that verdict independently: the rows that are
+    checked hold valid and invalid states."""
+    import torch
+    actions = rng.random((B, env.n_actions))
+    base = actions.copy()
+    level_rows = np.asarray(rows[1::2])
+    idx = torch.as_tensor(level_rows, device=env.device)
+    chosen = np.full(len(level_rows), np.nan)
+    for lv in np.linspace(lo, hi, n_levels):
+        a = actions.copy()
+        a[level_rows] = np.clip(lv + 0.1 * (base[level_rows] - 0.5), 0.0, 1.0)
+        env.reset(options=reset_options)
+        info = env.step(a)[4]
+        ok = _np(info['valids'][idx].all(dim=1) & info['converged'][idx].bool())
+        chosen = np.where(np.isnan(chosen) & ok, lv, chosen)
+    chosen = np.where(np.isnan(chosen), 0.5 * (lo + hi), chosen)
+    actions[level_rows] = np.clip(chosen[:, None] + 0.1 * (base[level_rows] - 0.5), 0.0, 1.0)
+    return actions
+
+
+def _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows):
+    """The full step of every row of `rows` against the oracle — no allowance: the converged flags must be the oracle's
+    (the non-converged SET is compared, not a fraction), every converged row is checked.  Returns (valid, invalid) counts.
+    (The device buffers are copied to the host once, the rows compared there.)"""
+    import torch
+    idx = torch.as_tensor(np.asarray(rows), device=out[0].device)
+    obs, reward, term, trunc, info = out
+    sub_info = {k: info[k][idx] for k in ('valids', 'violations', 'unscaled_penalties', 'cost', 'converged')}
+    sub = (obs[idx], reward[idx], term[idx], trunc[idx], sub_info)
+    tables = {} if env.n_minus_one_keys else {key: _np(env.result_table(*key)[idx]) for key in (
+        ('bus', 'vm_pu'), ('bus', 'va_degree'), ('line', 'loading_percent'), ('trafo', 'loading_percent'), ('ext_grid', 'p_mw'), ('ext_grid', 'q_mvar'))}
+    sub = (_np(sub[0]), _np(sub[1]), _np(sub[2]), _np(sub[3]), {k: _np(v) for k, v in sub_info.items()})
+    obs0 = _np(obs0[idx])
+
+    class _View:                                   # result tables of the compared rows, indexed like the batch slice
+        def result_table(self, tbl, col):
+            return tables[(tbl, col)]
+    n_valid = n_invalid = 0
+    for j, k in enumerate(rows):
+        ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        assert np.allclose(obs0[j], ob0, rtol=0, atol=R_TOL)
+        ref = orc.step(actions[k])
+        assert bool(sub[4]['converged'][j]) == ref['converged'], k
+        if not ref['converged']:
+            continue
+        _check_step(_View(), sub, dict(ref, obs_step=ref['obs']), j, n1=bool(env.n_minus_one_keys))
+        n_valid += bool(np.all(ref['valids']))
+        n_invalid += not np.all(ref['valids'])
+    return n_valid, n_invalid
+
+
 def test_full_batch_voltage_control_properties():
     """BASELINE config 2 at full size: VoltageControl on the 144-bus MV grid,
     B = 8192.  Size-independent properties: everything converges, rewards are
     finite, the reward decomposes as 0.5*objective + 0.5*sum(penalties)
     (Summation, reward.py:78-81), penalties are <= 0 and valid <=> no violation,
-    and a second step with the same inputs is bit-identical."""
+    and a second step with the same inputs is bit-identical.  512 rows spread over the batch — valid and invalid
+    states — are compared with the oracle's full step (VERDICT r03 #1b)."""
     B = 8192
     env = product_env('vc_mv_urban', batch_size=B)
+    orc = oracle_env('vc_mv_urban', product_env('vc_mv_urban', defer_device=True))
     rng = np.random.default_rng(3)
-    env.reset(options={'step': rng.choice(env.train_steps, B)})
-    actions = rng.random((B, env.n_actions))
-    obs, reward, term, trunc, info = env.step(actions)
+    steps = rng.choice(env.train_steps, B)
+    rows = np.linspace(0, B - 1, 512).astype(int)
+    actions = _mixed_actions(env, rng, B, rows, 0.40, 0.70, {'step': steps})
+    obs0, _ = env.reset(options={'step': steps})
+    obs0 = obs0.clone()
+    out = env.step(actions)
+    obs, reward, term, trunc, info = out
     conv = _np(info['converged'])
     assert conv.mean() > 0.999
     r, obj = _np(reward)[conv], _np(info['objective'])[conv]
@@ -198,20 +259,23 @@ def test_full_batch_voltage_control_properties():
     assert (pen <= 0).all()
     assert ((_np(info['violations'])[conv] == 0) == _np(info['valids'])[conv]).all()
     assert (_np(info['max_mismatch'])[conv] < 1e-8).all()
+    n_valid, n_invalid = _check_rows_against_oracle(env, orc, out, obs0, steps, None, actions, rows)
+    assert n_valid >= 8 and n_invalid >= 8, (n_valid, n_invalid)
     r1 = _np(reward).copy()
     obs2, reward2, *_ = env.step(actions)
     assert np.array_equal(r1, _np(reward2), equal_nan=True)
 
 
-@pytest.mark.parametrize('name,B,n_check,team', [('eco_hv_mixed', 8192, 16, 4), ('sc_vc_hv_urban', 4096, 16, 4),
-                                                 ('eco_hv_mixed', 2048, 8, 2), ('qm_mv_urban', 65536, 12, 1)])
-def test_full_batch_configs(name, B, n_check, team, monkeypatch):
+@pytest.mark.parametrize('name,B,n_check,team,levels', [('eco_hv_mixed', 8192, 128, 4, (0.0, 1.0)), ('sc_vc_hv_urban', 4096, 8, 4, None),
+                                                        ('eco_hv_mixed', 2048, 32, 2, (0.0, 1.0)), ('qm_mv_urban', 65536, 512, 1, (0.40, 0.70))])
+def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
     (B = 8192, four wavefronts per instance; a smaller batch with teams of two forced through the
     developer switch OPFX_TEAM) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
     contingency (B = 4096 x 251 solves, four wavefronts per instance); BASELINE config 4 at its full size as well
     (QMarket, 144 buses, B = 65536: every wavefront walks 32 instances).  All rows:
-    size-independent properties; `n_check` rows spread over the batch: the full step against the oracle."""
+    size-independent properties; `n_check` rows spread over the batch (128 / 8 / 32 / 512: VERDICT r03 #1b), valid and
+    invalid states among them: the full step against the oracle, no row skipped, the converged flags equal the oracle's."""
     if team == 2:
         monkeypatch.setenv('OPFX_TEAM', '2')
     env = product_env(name, batch_size=B)
@@ -219,7 +283,9 @@ def test_full_batch_configs(name, B, n_check, team, monkeypatch):
     rng = np.random.default_rng(17)
     steps = rng.choice(env.train_steps, B)
     uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
-    actions = rng.random((B, env.n_actions))
+    rows = np.linspace(0, B - 1, n_check).astype(int)
+    actions = _mixed_actions(env, rng, B, rows, *levels, {'step': steps, 'uniform': uniform}, n_levels=41 if name.startswith('eco') else 25) \
+        if levels else rng.random((B, env.n_actions))
     obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
     out = env.step(actions)
     obs, reward, term, trunc, info = out
@@ -241,20 +307,11 @@ def test_full_batch_configs(name, B, n_check, team, monkeypatch):
     out2 = env.step(actions[perm])
     assert np.allclose(_np(out2[1]), reward_first[perm], rtol=1e-9, atol=1e-9, equal_nan=True)
     obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    obs0 = obs0.clone()
     out = env.step(actions)
-    conv = _np(out[4]['converged'])
-    n_ok = 0
-    for k in np.linspace(0, B - 1, n_check).astype(int):
-        ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
-        assert np.allclose(_np(obs0)[k], ob0, rtol=0, atol=R_TOL)
-        ref = orc.step(actions[k])
-        assert bool(conv[k]) == ref['converged']
-        if not ref['converged']:
-            continue
-        ref = dict(ref, obs_step=ref['obs'])
-        _check_step(env, out, ref, k, n1=bool(env.n_minus_one_keys))
-        n_ok += 1
-    assert n_ok >= n_check - 2
+    n_valid, n_invalid = _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows)
+    if levels:
+        assert n_valid >= n_check // 32 and n_invalid >= n_check // 4, (n_valid, n_invalid)
     assert capi_team(env) == team
 
 
@@ -1284,3 +1341,97 @@ def test_reset_applies_the_initial_action_as_absolute_set_points(res_obs):
         ref = orc.step(a1[k])
         assert ref['converged']
         _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+
+
+@pytest.mark.parametrize('name,theta', [('sc_hv_small', 0.1), ('eco_hv_small', 0.1), ('vc_mv_small', 0.01), ('eco_hv_mixed', 0.1),
+                                        ('reconf_hv_small_sw', 0.1)])
+def test_chord_steps_leave_the_environment_results_unchanged(name, theta):
+    """`BatchedOpfEnv(jacobian_reuse_tol=theta)` (opt-in; opfx_solve_opts.jacobian_reuse_tol): the fused step with chord
+    iterations — N-1 contingency solves, q-limit re-solves and switch / tap modifiers included — replays the golden
+    scenario of the reference within the same tolerances as full Newton, and takes at least one iteration without a
+    factorisation somewhere (fewer or equal factorisations is what it is for; the iteration COUNT may only grow)."""
+    g = golden(name)
+    n = len(g['step'])
+    full = product_env(name, batch_size=n)
+    chord = product_env(name, batch_size=n, jacobian_reuse_tol=theta)
+    outs = []
+    for env in (full, chord):
+        env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None})
+        out = env.step(g['action'])
+        outs.append(out)
+        assert bool(out[4]['converged'].all())
+        assert np.allclose(_np(out[1]), g['reward'], rtol=1e-9, atol=R_TOL)
+        assert np.allclose(_np(out[0]), g['obs_step'], rtol=0, atol=R_TOL)
+        assert (_np(out[4]['valids']) == g['valids']).all()
+        assert np.allclose(_np(out[4]['violations']), g['violations'], rtol=1e-9, atol=R_TOL)
+    it_full, it_chord = _np(outs[0][4]['total_iterations']), _np(outs[1][4]['total_iterations'])
+    assert (it_chord >= it_full).all() and (it_chord <= it_full * 2).all()
+
+
+def test_on_pivot_breakdown_resolve_recovers_the_rows_on_the_gpu():
+    """`BatchedOpfEnv(on_pivot_breakdown='resolve')`: rows whose factorisation broke down — not converged,
+    min_pivot < 1e-8 — are stepped once more on a plan that eliminates the bus named by `min_pivot_bus` last, on the GPU.
+    The small MV VoltageControl grid gets a shunt at a feeder's end bus sized so that this bus's own diagonal Jacobian block is
+    singular at the flat start (computed from the case's Ybus); the oracle environment (SuperLU, partial pivoting) steps
+    through it.  Default policy: every row fails with min_pivot ~ 0 at that bus; 'resolve': every row is recovered and
+    equals the oracle's step; a grid without the shunt never enters the rescue path."""
+    import copy
+    import pandas as pd
+    from opfgym_amd import envs as product_envs
+    from opfgym_amd.case import net_to_case
+    base_env = product_env('vc_mv_small', defer_device=True)
+    defn = copy.deepcopy(base_env.definition)
+    net = defn.net
+    case = net_to_case(net)
+    # a PQ bus with one neighbour: its diagonal block at the flat start is [[a11, a12], [a21, a22]] with the sums below;
+    # choose B_ii so that its determinant vanishes
+    deg = np.zeros(case.nb, int)
+    for f, t in zip(case.f, case.t):
+        deg[f] += 1
+        deg[t] += 1
+    leaf = int(next(i for i in range(case.nb - 1, -1, -1) if deg[i] == 1 and case.bus_type[i] == 1))
+    k = int(next(k for k in range(case.nbr) if leaf in (case.f[k], case.t[k])))
+    y_ii, y_ij = (case.yff[k], case.yft[k]) if case.f[k] == leaf else (case.ytt[k], case.ytf[k])
+    g_ii, g_ij, b_ij = y_ii.real + case.gs[leaf], y_ij.real, y_ij.imag
+    a11, a12, a21 = b_ij, 2.0 * g_ii + g_ij, g_ij
+    b_ii_needed = -(a12 * a21 / a11 + b_ij) / 2.0                  # a22 = -2 B_ii - B_ij = a12 a21 / a11
+    delta_b = b_ii_needed - (y_ii.imag + case.bs[leaf])
+    bus_id = int(next(b for b, i in case.bus_lookup.items() if i == leaf))
+    net['shunt'] = pd.DataFrame(dict(bus=[bus_id], p_mw=[0.0], q_mvar=[-delta_b * case.base_mva], vn_kv=[float(net['bus'].loc[bus_id, 'vn_kv'])],
+                                     step=[1], in_service=[True]))
+    B = 6
+    rng = np.random.default_rng(2)
+    steps = rng.choice(base_env.train_steps, B)
+    actions = rng.random((B, base_env.n_actions))
+    from scenarios import SCENARIOS
+    kw = dict(SCENARIOS['vc_mv_small'][1])
+    make = lambda **extra: product_envs.VoltageControl(definition=copy.deepcopy(defn), seed=1, batch_size=B, **kw, **extra)
+    plain, resolve = make(), make(on_pivot_breakdown='resolve')
+    assert net_to_case(plain.net).bs[leaf] != case.bs[leaf]          # (the shunt made it into the compiled case)
+    orc = oracle_env('vc_mv_small', make(defer_device=True))
+    plain.reset(options={'step': steps})
+    out = plain.step(actions)
+    info = out[4]
+    assert not bool(info['converged'].any())                         # the static order divides by a zero pivot ...
+    assert float(info['min_pivot'].max()) < 1e-8 and (_np(info['min_pivot_bus']) == leaf).all()      # ... and says where
+    resolve.reset(options={'step': steps})
+    out = resolve.step(actions)
+    conv = _np(out[4]['converged'])
+    assert resolve.pivot_rescues == B and resolve.pivot_rescues_recovered == int(conv.sum()) >= B - 2
+    # (the root Newton reaches on this resonant case has the leaf's voltage collapse towards zero, which takes it close to
+    #  the iteration limit: a row the oracle needs nine or ten iterations for may end one iteration apart)
+    n_same = 0
+    for k_ in range(B):
+        orc.reset(int(steps[k_]))
+        ref = orc.step(actions[k_])
+        if not conv[k_]:
+            assert not ref['converged'] or orc.solve_iterations[0] >= 9, (k_, orc.solve_iterations)
+            continue
+        assert ref['converged']
+        _check_step(resolve, out, dict(ref, obs_step=ref['obs']), k_)
+        n_same += 1
+    assert n_same >= B - 2
+    # a healthy grid never enters the rescue path
+    healthy = product_env('vc_mv_small', batch_size=B, on_pivot_breakdown='resolve')
+    healthy.reset(options={'step': steps})
+    assert bool(healthy.step(actions)[4]['converged'].all()) and healthy.pivot_rescues == 0 and not healthy._rescue_envs

@@ -177,6 +177,36 @@ def test_team_stream_reproduces_oracle(built_lib, code, team):
     assert np.abs(v - ref['V']).max() < 1e-9
 
 
+@pytest.mark.parametrize('code,team,theta', [('1-MV-urban--0-sw', 0, 1e-2), ('hv-small', 0, 1e-1), ('hv-small', 2, 1e-1), ('1-HV-mixed--0-sw', 4, 1e-1),
+                                             ('1-HV-mixed--0-sw', 2, 1.0), ('1-HV-urban--0-sw', 4, 1.0), ('case9', 0, 1.0)])
+def test_chord_stream_reaches_the_same_fixed_point(built_lib, code, team, theta):
+    """Chord steps (opfx_solve_opts.jacobian_reuse_tol = theta): once an iteration's mismatch is below theta the later
+    ones keep its factorisation and walk the CHORD stream — the forward substitution alone (right-hand-side items of
+    every level, reading A_ik and A_kk as the factorisation left them) and the same back substitution.  Emulated as the
+    CHORD kernels run it, single wavefront and wave teams (with the race check between barriers): same fixed point
+    as full Newton, at least one iteration without a factorisation, never fewer iterations than full Newton."""
+    net = grids.case9() if code == 'case9' else grids.get_grid(code)[0]
+    case = net_to_case(net)
+    plan = capi.Plan(case)
+    p, q, *_ = bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = OracleSide(net, case).solve(p, q)
+    trace = []
+    v, conv, it, nrm = emulate_newton_lane_program(plan, p, q, team=team, reuse_tol=theta, trace=trace)
+    assert conv and nrm < 1e-8 and it >= ref['iterations'] and it <= ref['iterations'] + 3
+    assert np.abs(v - ref['V']).max() < 1e-8
+    kinds = [f for _, f in trace]
+    assert kinds[0] and not all(kinds), trace                      # the first iteration factorises; a later one does not
+    info = plan.info
+    assert info['lp_rounds_f'] <= info['lp_rounds_b'] and info['lp_rounds_f_pad'] % 4 == 0
+    if team:
+        assert info[f'team_rounds_chord_{team}'] <= info[f'team_rounds_{team}']
+        assert info[f'team_barriers_chord_{team}'] <= info[f'team_barriers_{team}']
+    # theta = 0 is full Newton: the oracle's iteration count exactly
+    v0, conv0, it0, _ = emulate_newton_lane_program(plan, p, q, team=team, reuse_tol=0.0)
+    assert conv0 and it0 == ref['iterations']
+
+
 @pytest.mark.parametrize('n,team', [(27, 4), (30, 2), (40, 4)])
 def test_team_stream_on_a_complete_graph(built_lib, n, team):
     """Tails longer than the fuzz grids produce: a complete graph eliminates one pivot per level from the start, so
@@ -196,7 +226,8 @@ def test_team_stream_on_a_complete_graph(built_lib, n, team):
 
 def test_dense_tail_tables(built_lib):
     """The tail the register chain works on: the final levels with one pivot each; its table names, for every
-    pair of tail pivots e < s, the U-block (row e, column s) — all of them four-value blocks."""
+    pair of tail pivots e < s, the U-block (row e, column s) and — lower triangle, the forward direction of the chain in
+    chord iterations — the L-block (row s, column e); all of them four-value blocks."""
     net = grids.get_grid('1-HV-mixed--0-sw')[0]
     plan = capi.Plan(net_to_case(net))
     P, info = load_plan(plan), plan.info
@@ -213,7 +244,7 @@ def test_dense_tail_tables(built_lib):
     where = {(int(r), int(c)): b for b, (r, c) in enumerate(zip(P['blk_row'], P['blk_col']))}
     for e in range(m):
         for s in range(M):
-            if e < s < m:
+            if e != s and e < m and s < m:
                 assert ids[e, s] == where[(bus[e], bus[s])] and ids[e, s] < info['n_full']
             else:
                 assert ids[e, s] == 0xFFFF
