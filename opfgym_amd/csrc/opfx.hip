@@ -2596,13 +2596,14 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     blk_sync<NW>();
   }
   OPFX_STAMP_INIT();
-  // With many instances per workgroup (opfx_step decides: eight or more) the instances beyond a workgroup's first come
+  // With many instances per workgroup (opfx_step decides, use_queue: twelve or more per single-wave workgroup, eight or more
+  // per wave team) the instances beyond a workgroup's first come
   // from a QUEUE (an atomic counter in the context): instances differ in their Newton iteration count, and with a fixed
   // share per workgroup the launch ends with the unluckiest one (65 536 instances of config 4: 34.5 mean instance times
   // on the slowest of 2 048 wavefronts against a mean load of 32.0; a queue brings that to 32.6).  The next index is
   // fetched after the solve, so that the round trip hides behind the instance's epilogue — not earlier: a claim made an
   // instance ahead is a static assignment again (measured at four instances per wavefront: +12 %).  opfx_step zeroes the
-  // counter in front of such a launch (launches on one context are serialised by the caller).  With few
+  // counter — the environment's own — in front of such a launch.  With few
   // instances per workgroup a queue cannot help (four jobs per worker: the greedy makespan equals the static one) and
   // the shares stay fixed.
 #ifdef OPFX_ENABLE_STAMPS

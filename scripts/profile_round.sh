@@ -14,16 +14,16 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --config $cfg --steps $steps --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --config $cfg --steps $steps --windows 3 --no-cpu-baseline > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --no-cpu-baseline > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --windows 1 --no-cpu-baseline > $out/$c.log 2>&1
 done
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" \
            "SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq$i -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --no-cpu-baseline > $out/sq$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq$i -- python3 $root/bench.py --config $cfg --steps $psteps --warmup 2 --windows 1 --no-cpu-baseline > $out/sq$i.log 2>&1
 done
 cd $root
 python3 - "$out" "$tag" "$cfg" "$psteps" <<'PY'
