@@ -245,9 +245,13 @@ def cpu_baseline(config, budget_s=float(os.environ.get('OPFX_BENCH_CPU_BUDGET', 
     #  the aggregate at 32 processes is reported next to it)
     some = run(32) if n_many > 32 else many
     rate_32 = sum(r['steps'] / r['cpu_s'] for r in some) if some else float('nan')
+    # (a box whose container may use fewer CPUs at once than os.cpu_count() reports runs SLOWER with one process per reported
+    #  core than with 32: the best aggregate observed is named beside the two)
+    best = max(((rate_p, len(many)), (rate_32, len(some)), (rate1, 1)), key=lambda rc: (rc[0] if rc[0] == rc[0] else -1.0))
     return dict(value=rate1, unit='env.step()/s', cores=1, kind='port',
                 all_cores=dict(value=rate_p, cores=len(many), host_cores=cores),
                 at_32_processes=dict(value=rate_32, cores=len(some)),
+                best_aggregate=dict(value=best[0], processes=best[1]),
                 sample=f'{one[0]["steps"] if one else 0} instance-steps of {CONFIGS[config][0]} (scenario {scenario}) with '
                        f'the numpy+SciPy oracle (oracle/env_oracle.py + pf_oracle.py), step() only, '
                        f'{one[0]["cpu_s"] if one else 0:.1f} s of CPU work on one core; then {len(many)} independent '
