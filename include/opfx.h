@@ -234,7 +234,8 @@ typedef struct opfx_solve_opts {
                               * (security_constrained.py:53): identical iteration counts and identical
                               * behaviour next to voltage collapse */
   double jacobian_reuse_tol; /* 0 (default): full Newton, a Jacobian factorisation in every iteration — what pandapower does.
-                              * theta > 0 (Shamanskii / chord steps): once the mismatch norm of an iteration is below theta,
+                              * theta > 0 (Shamanskii / chord steps): once the mismatch norm of an iteration is below theta
+                              * AND the step before it cut the norm at least tenfold (Newton is past its slow start),
                               * the LATER iterations of that solve keep its factorisation — mismatch, forward and back
                               * substitution only, no Jacobian, no block LU — for as long as each such step cuts the norm
                               * at least tenfold (else the next iteration factorises again).  Same fixed point and same

@@ -1238,10 +1238,11 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     ++it;
     if (CHORD && o.reuse_tol > 0.0) {
-      // keep this iteration's factorisation for the next one?  After an iteration that factorised: when its own mismatch
-      // was already small; after a chord iteration: when the step before it cut the mismatch at least tenfold.
+      // keep this iteration's factorisation for the next one?  Only while the step before this iteration cut the mismatch
+      // at least tenfold (Newton is past its slow start / the chord step did its job; never after the first iteration:
+      // e_prev starts at 0) and, for an iteration that factorised, only once its own mismatch is below the threshold.
       const double e = wave_max_dpp(my);
-      const bool chord_next = jac ? e < o.reuse_tol : e < 0.1 * e_prev;
+      const bool chord_next = e < 0.1 * e_prev && (!jac || e < o.reuse_tol);
       e_prev = e;
       st_nxt = chord_next ? stream_c : stream;
     }
@@ -1503,7 +1504,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     if (it >= o.max_iter) { conv = false; break; }
     ++it;
     if (CHORD && o.reuse_tol > 0.0) {          // (see newton2; every wavefront holds the same norm)
-      const bool chord_next = jac ? nrm < o.reuse_tol : nrm < 0.1 * e_prev;
+      const bool chord_next = nrm < 0.1 * e_prev && (!jac || nrm < o.reuse_tol);
       e_prev = nrm;
       st_nxt = chord_next ? stream_c : stream;
     }

@@ -3,7 +3,11 @@ radial and meshed synthetic networks of random size with random taps, phase shif
 shunts, elements out of service and closed bus-bus switches; random injections; optionally a random
 branch outage per instance and generator reactive limits.
 
-    python scripts/fuzz_solve.py [n_grids] [seed] [stress]
+    python scripts/fuzz_solve.py [n_grids] [seed] [stress|chord]
+
+`chord`: every grid is solved with chord steps (opfx_solve_opts.jacobian_reuse_tol drawn from 0.01 ... 10 per grid): the same
+comparison with the oracle's full Newton — converged flags, |V|, loadings — with the iteration count allowed to grow
+(never to shrink).
 
 `stress`: the twelve instances of a grid carry its nominal injections scaled geometrically from 1 to 12 — through and
 past voltage collapse — and the script COUNTS what the static pivoting of the block LU could get wrong (SURVEY §7 hard
@@ -85,6 +89,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     stress = len(sys.argv) > 3 and sys.argv[3] == 'stress'
+    chord = len(sys.argv) > 3 and sys.argv[3] == 'chord'
     bad = done = 0
     gpu_only_fail = oracle_only_fail = both_fail = 0
     worst_pivot = 1.0
@@ -113,6 +118,8 @@ def main():
                 lim = rng.uniform(0.02, 0.4, case.nb) * 100.0 / case.base_mva
                 kw.update(qg_min=torch.tensor(-lim, device=dev), qg_max=torch.tensor(lim, device=dev), enforce_q_lims=True)
                 okw.update(qg_min=-lim, qg_max=lim, enforce_q_lims=True)
+            if chord:
+                kw['jacobian_reuse_tol'] = float(rng.choice([0.01, 0.1, 1.0, 10.0]))
             got = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw).items()}
             ref = oracle_batch(net, case, p, q, **okw)
             both = ref['converged'] & got['converged'].astype(bool)
@@ -135,14 +142,17 @@ def main():
             if cmp_rows.any():
                 dv = np.abs(got['vm'][cmp_rows] - ref['vm'][cmp_rows]).max()
                 dl = np.abs(got['loading'][cmp_rows] - ref['loading'][cmp_rows]).max()
-                assert dv < TOL_V, ('vm', desc, dv)
-                assert dl < 1e-5, ('loading', desc, dl)
-                assert (np.abs(got['iterations'][cmp_rows] - ref['iterations'][cmp_rows]) <= 1).all(), ('iterations', desc)
+                assert dv < (1e-7 if chord else TOL_V), ('vm', desc, dv)      # (chord: the iterate stops just below the mismatch tolerance)
+                assert dl < (1e-4 if chord else 1e-5), ('loading', desc, dl)      # (a chord iterate stops just below the tolerance, Newton overshoots it)
+                if chord:       # (chord iterations converge linearly: more of them, never fewer than Newton minus the usual one)
+                    assert (got['iterations'][cmp_rows] >= ref['iterations'][cmp_rows] - 1).all(), ('iterations', desc)
+                else:
+                    assert (np.abs(got['iterations'][cmp_rows] - ref['iterations'][cmp_rows]) <= 1).all(), ('iterations', desc)
             # islanded rows: the same buses are de-energised (NaN) and the rest of the grid agrees
             for r_ in np.flatnonzero(isl & both):
                 assert (np.isnan(got['vm'][r_]) == np.isnan(ref['vm'][r_])).all(), ('dead buses', desc, int(r_))
                 live = ~np.isnan(ref['vm'][r_])
-                assert np.abs(got['vm'][r_][live] - ref['vm'][r_][live]).max() < TOL_V, ('vm of the energised part', desc, int(r_))
+                assert np.abs(got['vm'][r_][live] - ref['vm'][r_][live]).max() < (1e-7 if chord else TOL_V), ('vm of the energised part', desc, int(r_))
             done += int(cmp_rows.sum()) + int((isl & both).sum())
             # the batch-1 plug-in on the same grid: net.res_* tables against the oracle's runpp restatement
             import copy

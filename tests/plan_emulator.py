@@ -230,7 +230,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0,
             trace.append((nrm, jac))
         chord_next = False
         if reuse_tol > 0.0:
-            chord_next = nrm < reuse_tol if jac else nrm < 0.1 * e_prev
+            chord_next = nrm < 0.1 * e_prev and (not jac or nrm < reuse_tol)
             e_prev = nrm
         if not jac:
             blk = kept                                   # the factorisation of the earlier iteration, untouched by phase A
