@@ -240,7 +240,10 @@ typedef struct opfx_solve_opts {
                               * substitution only, no Jacobian, no block LU — for as long as each such step cuts the norm
                               * at least tenfold (else the next iteration factorises again).  Same fixed point and same
                               * tolerance test; the iterates differ from full Newton's after the switch, so iteration
-                              * counts and the last digits of V may differ from pandapower's.  Sensible: 1e-3 ... 1e-1 */
+                              * counts and the last digits of V may differ from pandapower's.  theta is in p.u. like tol
+                              * (base_mva = 1: MW; flat-start mismatches of the benchmark grids are 10 ... 70, theta = 0.1
+                              * is what profiles/r04_ab_chord.txt recommends).  Ignored (full Newton) together with
+                              * init = OPFX_INIT_DC, on the first-generation fallback kernel and in the memory-resident form */
 } opfx_solve_opts;
 
 int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const double* q_inj,

@@ -30,7 +30,7 @@ python3 - "$out" "$tag" "$cfg" "$psteps" <<'PY'
 import sys, glob, csv, collections, json, shutil, hashlib
 out, tag, cfg, psteps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 sha = hashlib.sha256()
-for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h', 'include/opfx.h'):
+for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h'):      # (kernels + plan compiler)
     sha.update(open(rel, 'rb').read())          # (= bench.py source_sha16: counters are only used with the sources they were taken from)
 st = glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)
 if st:

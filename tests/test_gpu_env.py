@@ -1037,6 +1037,11 @@ def test_reset_resamples_rows_whose_power_flow_fails():
     env.max_reset_retries = 0
     with pytest.raises(RuntimeError, match='power flow failed in reset'):
         env.reset(seed=123)
+    # resample_failed_resets=False: no look at the flags on the host — the failed rows stay failed rows (NaN observation)
+    lazy = product_env('qm_mv_small', batch_size=B, resample_failed_resets=False, **kw)
+    obs, _ = lazy.reset(seed=123)
+    bad = ~lazy.buf['converged']
+    assert 0 < int(bad.sum()) < B // 2 and bool(torch.isnan(obs[bad]).any(dim=1).all()) and bool(torch.isfinite(obs[~bad]).all())
 
 
 def test_reset_of_an_n_minus_one_env_runs_the_base_case_only():
