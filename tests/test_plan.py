@@ -375,3 +375,22 @@ def test_dc_start_arrays_are_the_dc_power_flow_of_the_oracle(code, built_lib):
     side = OracleSide(net, case)
     v0 = po.start_voltage(side.ppc, 'dc')[side.bus_map]
     assert np.abs(np.angle(v0 * np.exp(-1j * theta))).max() < 1e-10
+
+
+def test_the_boundary_is_usable_from_plain_c99(built_lib, tmp_path):
+    """tests/native/abi_c99.c: the header compiled as C99 (-pedantic -Werror) and linked against libopfx.so — OPFX_INIT'ed
+    structs, a two-bus case through plan creation / read-back, refusal of a wrong struct_size, the developer entry point,
+    and opfx_ctx_create returning a status (OPFX_ERR_NO_DEVICE here) instead of crashing.  What a cgo / JNI / cffi binding
+    of the reference's maintainers would do, without Python in between."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('needs gcc')
+    exe = tmp_path / 'abi_c99'
+    lib_dir = os.path.dirname(capi.LIB_PATH)
+    r = subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                        os.path.join(ROOT, 'tests', 'native', 'abi_c99.c'), '-o', str(exe), '-L', lib_dir, '-lopfx',
+                        f'-Wl,-rpath,{lib_dir}', '-Wl,--allow-shlib-undefined'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'abi ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
