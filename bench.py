@@ -78,7 +78,7 @@ def byte_model(env, mean_it_per_solve, solves_per_step):
 def lds_model(env, mean_it_per_solve, solves_per_step, team):
     """LDS bytes one instance-step moves, counted from the compiled plan (8 B per active lane and access; an atomic
     add counts once).  Per NR iteration: phase A (bus rounds: own V + ELL-width neighbours read, blocks / rhs
-    written; overflow entries), phases B + C (twelve reads + four or two atomic adds per live item, riders), phase D
+    written; overflow entries), phases B + C (twelve reads + four or two atomic adds per live item, riders, second columns), phase D
     (diagonal block + rhs + V read, V written), fill blocks zeroed; one more phase A per solve for the final mismatch.
     Per step: the table row staged in LDS and read back by the prologue, the result bank written and read.
     Cross-check: `instructions` (wave-level LDS instructions) against SQ_INSTS_LDS of profiles/*_sq_counters.txt."""
@@ -101,16 +101,18 @@ def lds_model(env, mean_it_per_solve, solves_per_step, team):
         live_b, live_c = (items[:, 0] & 0xFFFF) != 0xFFFF, (itc[:, 0] & 0xFFFF) != 0xFFFF
         rhs_b = live_b & ((items[:, 0] & 0x8000) != 0)
         n_rider = int(((riders >> 16) != 0xFFFF).sum())
+        n_second = int(((plan.array('LP_B3').astype(np.int64) & 0xFFFF) != 0xFFFF).sum())
         n_items, n_rhs = int(live_b.sum() + live_c.sum()), int(rhs_b.sum() + live_c.sum())
         rounds = info['lp_rounds_b'] + info['lp_rounds_c']
     else:
         tm = plan.array('LP_TEAM4' if team == 4 else 'LP_TEAM2').astype(np.int64).reshape(-1, 4) & 0xFFFFFFFF
         live = (tm[:, 0] & 0xFFFF) != 0xFFFF
         n_items, n_rhs, n_rider = int(live.sum()), int((live & ((tm[:, 0] & 0x8000) != 0)).sum()), 0
+        n_second = int((live & ((tm[:, 2] & 0xFFFF) != 0xFFFF)).sum())
         rounds = info[f'team_rounds_{team}'] * team
-    bc_reads = 12 * n_items + 2 * n_rider
-    bc_writes = 4 * (n_items - n_rhs) + 2 * n_rhs + 2 * n_rider
-    bc_instr = rounds * (12 + 4) + (info['lp_rounds_b'] * 4 if team == 1 else 0)
+    bc_reads = 12 * n_items + 2 * n_rider + 4 * n_second           # (a second column: its block read, its target added to)
+    bc_writes = 4 * (n_items - n_rhs) + 2 * n_rhs + 2 * n_rider + 4 * n_second
+    bc_instr = rounds * (12 + 4) + (info['lp_rounds_b'] * (4 + 8) if team == 1 else 0)
     n_free = nb - info['nref']
     d_reads, d_writes = n_free * 8, n_free * 2
     d_instr = info['lp_rounds_a'] * 11
@@ -123,7 +125,7 @@ def lds_model(env, mean_it_per_solve, solves_per_step, team):
     total = it_step * per_it + solves_per_step * per_pass_a + per_step
     instr_it = a_instr + bc_instr + d_instr + (info['n_fill'] * vals_off + 63) // 64
     instr = it_step * instr_it + solves_per_step * a_instr + (2 * env.nx + 2 * env.n_inj + solves_per_step * (2 * nres + 4 * nb + 6 * info['nbr'])) / 64.0
-    return dict(bytes_per_iteration=per_it, bytes_per_step=total, items_per_iteration=n_items, riders=n_rider,
+    return dict(bytes_per_iteration=per_it, bytes_per_step=total, items_per_iteration=n_items, riders=n_rider, second_columns=n_second,
                 rounds_bc=rounds, lds_wave_instructions_per_step=instr)
 
 

@@ -169,12 +169,13 @@ enum {
   OPFX_ARR_LP_B, OPFX_ARR_LP_C,
   OPFX_ARR_BR_ISLAND,  /* [nbr] 1 = taking this branch out cuts some bus off every REF bus */
   OPFX_ARR_ISL_PTR, OPFX_ARR_ISL_BUS,  /* CSR [nbr+1] -> the buses that outage cuts off (they are de-energised) */
-  OPFX_ARR_LP_TEAM2, OPFX_ARR_LP_TEAM4, /* wave-team streams [round][wave][64][4] */
+  OPFX_ARR_LP_TEAM2, OPFX_ARR_LP_TEAM4, /* wave-team streams [round][wave][64][4]: w0, w1, second column, round flags (bits 0-1) | rider bits */
   OPFX_ARR_TAIL_BUS,                    /* [32] bus | diagonal block << 16 of the dense tail's pivots */
   OPFX_ARR_TAIL_IDS,                    /* [tail_m + 1][M] U-block ids inside the tail (0xFFFF none), M = tail_m rounded up to 8 */
   OPFX_ARR_LP_B2,                       /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
   OPFX_ARR_LP_BCC,                      /* chord stream of the single-wave kernels: [rf_pad + rc_pad][64][4] */
-  OPFX_ARR_LP_TEAMC2, OPFX_ARR_LP_TEAMC4 /* chord streams of the wave teams, laid out like OPFX_ARR_LP_TEAM2 / 4 */
+  OPFX_ARR_LP_TEAMC2, OPFX_ARR_LP_TEAMC4, /* chord streams of the wave teams, laid out like OPFX_ARR_LP_TEAM2 / 4 */
+  OPFX_ARR_LP_B3                         /* [rb][64] second column of a factor item (same multiplier): target2 | A_kj2 << 16 (0xFFFF both: none) */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y,

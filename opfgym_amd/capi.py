@@ -27,7 +27,7 @@ ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BL
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
           'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2',
-          'LP_BCC', 'LP_TEAMC2', 'LP_TEAMC4']
+          'LP_BCC', 'LP_TEAMC2', 'LP_TEAMC4', 'LP_B3']
 DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y', 'LP_DC', 'LP_H_DC']
 
 _pd = C.POINTER(C.c_double)
@@ -162,6 +162,7 @@ class DebugOpts(Sized):
     """include/opfx_debug.h: developer switches, handed explicitly to the *_debug constructors (0 = library default)."""
     _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in (
         'plan_search', 'plan_dcap_slack', 'plan_seed', 'plan_no_bank', 'plan_no_pack', 'plan_no_riders', 'plan_no_tail',
+        'plan_no_pairs',
         'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
         'reset_team')]
 
@@ -187,6 +188,7 @@ def debug_from_env(environ=None) -> DebugOpts:
     d.plan_seed = int(e.get('OPFX_PLAN_SEED') or 0)
     d.plan_no_bank, d.plan_no_pack = flag('OPFX_PLAN_NO_BANK'), flag('OPFX_PLAN_NO_PACK')
     d.plan_no_riders, d.plan_no_tail = flag('OPFX_NO_RIDERS'), flag('OPFX_NO_TAIL')
+    d.plan_no_pairs = int(e.get('OPFX_PLAN_NO_PAIRS') or 0)
     d.team = int(e.get('OPFX_TEAM') or 0)
     d.queue, d.packed = tri('OPFX_QUEUE'), tri('OPFX_PACKED')
     d.force_mem, d.kernel_v1 = flag('OPFX_FORCE_MEM'), flag('OPFX_KERNEL_V1')

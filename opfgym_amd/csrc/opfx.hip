@@ -595,9 +595,15 @@ __device__ __forceinline__ void ld_blk_raw(const Lds& L, unsigned id, double& a1
 // The twelve values an item reads.  Loading (item_load) and using them (item_apply) are separate steps so
 // that the reads of the NEXT round can be in flight while this round computes, whenever the plan marks the two
 // rounds as independent (ITEM_NEXT_INDEPENDENT: same elimination level / same back-substitution group).
-struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22, y1, y2; };
+// (round 4: an item may carry a SECOND column of the same multiplier — word 2: target2 | A_kj2 << 16 — whose block is `e`;
+// word 3 holds the round's flags in bits 0-1 and the rider's buses i / k in bits 2-16 / 17-31, 0x7FFF: none)
+struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, c22, e11, e12, e21, e22, y1, y2; };
+__device__ __forceinline__ unsigned rider_i(const uint4 d) { return (d.w >> 2) & 0x7FFFu; }
+__device__ __forceinline__ unsigned rider_k(const uint4 d) { return d.w >> 17; }
 constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;   // flags in word 3 of a round's items (plan.cpp)
-template <bool PK, bool RIDERS>
+// LATE2: the second column's block is read in item_apply, after the first column's updates have been issued, into the
+// registers the first column has left (the wave-team kernels, which have no eight registers to spare: scratch otherwise).
+template <bool PK, bool RIDERS, bool LATE2 = false>
 __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -614,12 +620,16 @@ __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   const double* c3p = rhs_t ? (L.rq + kj) : (L.blk + bx21(L, kjc));
   r.c11 = *c1p; r.c21 = *c3p;
   r.c12 = L.blk[bx12(L, kjb)]; r.c22 = L.blk[bx22(L, kjc)];
+  // the second column: read only where a lane of the wavefront has one (most rounds of a wave team have none, plan.cpp level_for)
+  const bool two = live && (d.z & 0xFFFF) != NONE;
+  r.e11 = 0.0; r.e12 = 0.0; r.e21 = 0.0; r.e22 = 0.0;
+  if (!LATE2 && two) ld_blk_raw<PK>(L, d.z >> 16, r.e11, r.e12, r.e21, r.e22);
   // rider (plan.cpp): the item's multiplier also takes y_k to y_i — the forward substitution of the pair (i, k)
   r.y1 = 0.0; r.y2 = 0.0;
-  if (RIDERS && (d.z >> 16) != NONE) { const unsigned k = d.z >> 16; r.y1 = L.rhs[k]; r.y2 = L.rq[k]; }
+  if (RIDERS && rider_i(d) != 0x7FFFu) { const unsigned k = rider_k(d); r.y1 = L.rhs[k]; r.y2 = L.rq[k]; }
   return r;
 }
-template <bool PK, bool RIDERS>
+template <bool PK, bool RIDERS, bool LATE2 = false>
 __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const ItemRegs& r) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -649,8 +659,20 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
     lds_add(L.blk + bx12(L, tb), m11 * c12 + m12 * c22);
     lds_add(L.blk + bx22(L, tb), m21 * c12 + m22 * c22);
   }
-  if (RIDERS && (d.z >> 16) != NONE) {
-    const unsigned i = d.z & 0xFFFF;
+  const unsigned tb2 = d.z & 0xFFFF;
+  if (tb2 != NONE) {                      // the second column of the same multiplier: A_ij2 += m A_kj2 (a block target always)
+    const unsigned ej = d.z >> 16;
+    const bool fe = !PK || ej < (unsigned)L.nfull;
+    double e11 = r.e11, e12 = r.e12, x21 = r.e21, x22 = r.e22;
+    if (LATE2) ld_blk_raw<PK>(L, ej, e11, e12, x21, x22);
+    const double e21 = fe ? x21 : -e12, e22 = fe ? x22 : e11;
+    lds_add(L.blk + bx11(L, tb2), m11 * e11 + m12 * e21);
+    lds_add(L.blk + bx21(L, tb2), m21 * e11 + m22 * e21);
+    lds_add(L.blk + bx12(L, tb2), m11 * e12 + m12 * e22);
+    lds_add(L.blk + bx22(L, tb2), m21 * e12 + m22 * e22);
+  }
+  if (RIDERS && rider_i(d) != 0x7FFFu) {
+    const unsigned i = rider_i(d);
     lds_add(L.rhs + i, m11 * r.y1 + m12 * r.y2);
     lds_add(L.rq + i, m21 * r.y1 + m22 * r.y2);
   }
@@ -659,11 +681,11 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
 // there a rider saves whole rounds (144-bus grid: 11 -> 8 rounds of factorisation, 0.286 -> 0.273 ms), whereas the
 // wave teams walk one round per wavefront through most levels either way and the two tests per item cost more
 // than the saved rounds give back (config 3: 1.967 -> 1.976 ms with riders, 2.06 ms with the tests but no riders).
-template <bool PK, bool RIDERS>
+template <bool PK, bool RIDERS, bool LATE2 = false>
 __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
-  const ItemRegs r = item_load<PK, RIDERS>(L, d);
-  item_apply<PK, RIDERS>(L, d, r);
+  const ItemRegs r = item_load<PK, RIDERS, LATE2>(L, d);
+  item_apply<PK, RIDERS, LATE2>(L, d, r);
 }
 // Two consecutive rounds of one wavefront.  When the plan marks the second as independent of the first (same group)
 // all LDS reads of both are requested first.
@@ -803,7 +825,7 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
 template <bool PK, bool MEM = false>
 __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
-  item_factor<PK, false>(L, d);
+  item_factor<PK, false, true>(L, d);
   if (fl & ITEM_BARRIER) team_sync<MEM>(); else mem_fence<MEM>();  // (no barrier: the same wavefront carries on)
 }
 
@@ -1676,7 +1698,7 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 // code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
 // in the wave teams) although the region runs once per solve.
 template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
-__device__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
+__device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
                                int* min_piv_bus, int isl_state = 0) {
   const int wave = threadIdx.x >> 6;

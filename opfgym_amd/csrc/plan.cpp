@@ -117,25 +117,36 @@ void renumber_blocks(opfx_plan* p) {
 // atomics, a rider's y_k / y_i; a group of 32 lanes takes as many cycles as its busiest bank holds addresses).
 // `base`: n_rounds x 64 items x 4 words, in place; word 3 (flags) stays with its round.  opfx_debug_opts.plan_no_bank keeps the
 // plan's own order.
+// Word 3 of an item: bits 0-1 flags of its ROUND, bits 2-16 / 17-31 the rider's buses i / k (0x7FFF: none).
+constexpr uint32_t RIDER_NONE15 = 0x7FFFu, NO_RIDER_BITS = (RIDER_NONE15 << 2) | (RIDER_NONE15 << 17);
+inline uint32_t rider_bits(uint32_t rider_ik) {        // from the host form i | k << 16 (0xFFFF both: none)
+  const uint32_t i = rider_ik & 0xFFFFu, k = rider_ik >> 16;
+  return (i == 0xFFFFu || k == 0xFFFFu) ? NO_RIDER_BITS : ((i << 2) | (k << 17));
+}
+
 void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
   constexpr uint32_t NONE = 0xFFFFu;
-  struct It { uint32_t w[3]; int id[6]; int wt[6]; };
+  constexpr int NC = 8;
+  struct It { uint32_t w[3]; uint32_t rider; int id[NC]; int wt[NC]; };
   std::vector<It> live;
   for (int l = 0; l < 64 * n_rounds; ++l) {
     const uint32_t* w = base + 4 * l;
     if ((w[0] & 0xFFFF) == NONE) continue;
     It it{};
     for (int q = 0; q < 3; ++q) it.w[q] = w[q];
+    it.rider = w[3] & ~3u;
     const uint32_t tb = w[0] & 0xFFFF, ik = w[0] >> 16, kk = w[1] & 0xFFFF, kj = w[1] >> 16;
     const bool rhs_t = (tb & 0x8000u) != 0;
     // access classes: 0 blocks read through ik, 1 through kk, 2 through kj (block) / 3 (right-hand side), 4 target
-    // atomics on blocks / 5 on the right-hand side (weights: LDS instructions of that access; atomics count double)
-    for (int c = 0; c < 6; ++c) { it.id[c] = -1; it.wt[c] = 0; }
+    // atomics on blocks / 5 on the right-hand side, 6 / 7 the second column's block and target (weights: LDS
+    // instructions of that access; atomics count double)
+    for (int c = 0; c < NC; ++c) { it.id[c] = -1; it.wt[c] = 0; }
     it.id[0] = (int)ik; it.wt[0] = (int)ik < n_full ? 4 : 2;
     it.id[1] = (int)kk; it.wt[1] = 4;
     if (rhs_t) { it.id[3] = (int)kj; it.wt[3] = 2; it.id[5] = (int)(tb & 0x7FFF); it.wt[5] = 4; }
     else { it.id[2] = (int)kj; it.wt[2] = (int)kj < n_full ? 4 : 2; it.id[4] = (int)tb; it.wt[4] = 8; }
-    if ((w[2] >> 16) != NONE) { it.id[3] = (int)(w[2] >> 16); it.wt[3] += 2; if (it.id[5] < 0) { it.id[5] = (int)(w[2] & 0xFFFF); it.wt[5] = 4; } }
+    if ((w[2] & 0xFFFF) != NONE) { const int kj2 = (int)(w[2] >> 16); it.id[6] = kj2; it.wt[6] = kj2 < n_full ? 4 : 2; it.id[7] = (int)(w[2] & 0xFFFF); it.wt[7] = 8; }
+    if (it.rider != NO_RIDER_BITS) { it.id[3] = (int)(it.rider >> 17); it.wt[3] += 2; if (it.id[5] < 0) { it.id[5] = (int)((it.rider >> 2) & 0x7FFFu); it.wt[5] = 4; } }
     live.push_back(it);
   }
   const int n = (int)live.size(), nbin = 2 * n_rounds;
@@ -144,28 +155,29 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
   // the plan's order stays empty: padding)
   const int used_rounds = (n + 63) / 64, used_bins = 2 * used_rounds;
   struct Banks { std::array<std::vector<int>, 32> ids; int worst = 0; };
-  std::vector<std::array<Banks, 6>> tab(used_bins);
+  std::vector<std::array<Banks, NC>> tab(used_bins);
+  auto is_read = [](int c) { return c < 4 || c == 6; };
   std::vector<int> cnt(used_bins, 0), bin_of(n, 0);
   auto price = [&](int h, const It& it) {
     int c_ = 0;
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (it.id[c] < 0) continue;
       const auto& v = tab[h][c].ids[it.id[c] & 31];
       // (reads of one address are a broadcast; atomic adds on one address are serialised like any other conflict)
-      if (c < 4 && std::find(v.begin(), v.end(), it.id[c]) != v.end()) continue;
+      if (is_read(c) && std::find(v.begin(), v.end(), it.id[c]) != v.end()) continue;
       if ((int)v.size() + 1 > std::max(tab[h][c].worst, 1)) c_ += it.wt[c];
     }
     return c_;
   };
   auto put = [&](int h, const It& it) {
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < NC; ++c) {
       if (it.id[c] < 0) continue;
       auto& v = tab[h][c].ids[it.id[c] & 31];
-      if (c >= 4 || std::find(v.begin(), v.end(), it.id[c]) == v.end()) { v.push_back(it.id[c]); tab[h][c].worst = std::max(tab[h][c].worst, (int)v.size()); }
+      if (!is_read(c) || std::find(v.begin(), v.end(), it.id[c]) == v.end()) { v.push_back(it.id[c]); tab[h][c].worst = std::max(tab[h][c].worst, (int)v.size()); }
     }
   };
   auto rebuild = [&](int h, int skip) {          // the tables of half-round h without item `skip`
-    for (int c = 0; c < 6; ++c) { for (auto& v : tab[h][c].ids) v.clear(); tab[h][c].worst = 0; }
+    for (int c = 0; c < NC; ++c) { for (auto& v : tab[h][c].ids) v.clear(); tab[h][c].worst = 0; }
     for (int q = 0; q < n; ++q) if (bin_of[q] == h && q != skip) put(h, live[q]);
   };
   auto choose = [&](const It& it) {
@@ -185,7 +197,7 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
     for (int q = 0; q < n; ++q) {
       const int h0 = bin_of[q];
       bool hot = false;
-      for (int c = 0; c < 6 && !hot; ++c)
+      for (int c = 0; c < NC && !hot; ++c)
         if (live[q].id[c] >= 0 && tab[h0][c].worst > 1 && (int)tab[h0][c].ids[live[q].id[c] & 31].size() == tab[h0][c].worst) hot = true;
       if (!hot) continue;
       rebuild(h0, q); --cnt[h0]; bin_of[q] = -1;
@@ -198,12 +210,13 @@ void spread_over_banks(uint32_t* base, int n_rounds, int n_full) {
     if (!moved) break;
   }
   (void)nbin;
-  for (int l = 0; l < 64 * n_rounds; ++l) { uint32_t* w = base + 4 * l; w[0] = NONE | (NONE << 16); w[1] = NONE | (NONE << 16); w[2] = NONE | (NONE << 16); }
+  for (int l = 0; l < 64 * n_rounds; ++l) { uint32_t* w = base + 4 * l; w[0] = NONE | (NONE << 16); w[1] = NONE | (NONE << 16); w[2] = NONE | (NONE << 16); w[3] = (w[3] & 3u) | NO_RIDER_BITS; }
   std::vector<int> at(used_bins);
   for (int h = 0; h < used_bins; ++h) at[h] = (h / 2) * 64 + (h & 1) * 32;
   for (int q = 0; q < n; ++q) {
     uint32_t* w = base + 4 * (at[bin_of[q]]++);
     for (int k = 0; k < 3; ++k) w[k] = live[q].w[k];
+    w[3] = (w[3] & 3u) | live[q].rider;
   }
 }
 
@@ -313,63 +326,96 @@ void build_lane_programs(opfx_plan* p) {
   // carrier (none on a symmetric pattern) would follow as items of their own.
   // A rider lengthens its item (two more LDS reads, two more atomics), so it only pays where it saves a round:
   // each stream — one wavefront, teams of two and of four — decides per level by the rounds a wavefront walks
-  // (`use_riders`); a level whose items fit one round per wavefront either way keeps separate items.
+  // (`level_for`); a level whose items fit one round per wavefront either way keeps separate items.
   const int nlev = p->n_levels();
   std::vector<int32_t> b_bounds{0}, c_bounds;
-  struct Item3 { uint32_t w0, w1, w2; };
-  constexpr uint32_t NO_RIDER = NONE | (NONE << 16);
-  std::vector<std::vector<Item3>> lev_rider(nlev), lev_sep(nlev), lev_rhs(nlev);      // lev_rhs: the forward substitution alone (chord steps)
-  for (int lev = 0; lev < nlev; ++lev) {
+  // An item: w0 = target | A_ik << 16, w1 = A_kk | A_kj << 16, w2 = rider i | k << 16 (host form), w3 = a SECOND column
+  // target2 | A_kj2 << 16 of the same multiplier (round 4): the terms A_ij -= A_ik A_kk^-1 A_kj of one pair (i, k) share
+  // -A_ik A_kk^-1, two thirds of an item's arithmetic and eight of its twelve LDS reads, so two of them travel in one item
+  // (375 -> 219 block items on the 144-bus grid, 8 -> 5 factorisation rounds; 7 115 -> 3 834 on the 372-bus grid).
+  struct Item3 { uint32_t w0, w1, w2, w3; };
+  constexpr uint32_t NO_RIDER = NONE | (NONE << 16), NO_SECOND = NONE | (NONE << 16);
+  // The items of one level in the four forms a stream may take them: with / without second columns, with / without riders.
+  std::vector<std::vector<Item3>> lev_rhs(nlev);      // the forward substitution alone (chord steps)
+  auto level_items = [&](int lev, bool pairs, bool riders) {
     const int t0 = p->lev_tptr[lev], t1 = p->lev_tptr[lev + 1];
     // right-hand-side terms of the level by the block A_ik they multiply with: (i, k)
     std::unordered_map<int32_t, std::pair<int32_t, int32_t>> rhs_of;
-    for (int t = t0; t < t1; ++t)
-      if (p->tgt_blk[t] < 0)
-        for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) rhs_of[p->src_ik[s]] = {-1 - p->tgt_blk[t], p->src_kj[s]};
-    std::vector<Item3> carriers, plain, rhs_items, rhs_left;
+    if (riders)
+      for (int t = t0; t < t1; ++t)
+        if (p->tgt_blk[t] < 0)
+          for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) rhs_of[p->src_ik[s]] = {-1 - p->tgt_blk[t], p->src_kj[s]};
+    // block terms by their multiplier block A_ik, in the order the targets come (the diagonal target first: it carries
+    // the rider)
+    struct Term { int32_t tb, kk, kj; bool diagonal; };
+    std::vector<int32_t> ik_order;
+    std::unordered_map<int32_t, std::vector<Term>> by_ik;
     for (int t = t0; t < t1; ++t) {
       const int tb = p->tgt_blk[t];
       if (tb < 0) continue;
       const bool diagonal = p->blk_row[tb] == p->blk_col[tb];
       for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) {
-        const Item3 it{(uint32_t)tb | ((uint32_t)p->src_ik[s] << 16), (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16), NO_RIDER};
-        lev_sep[lev].push_back(it);
-        auto f = diagonal ? rhs_of.find(p->src_ik[s]) : rhs_of.end();
-        if (f != rhs_of.end() && f->second.first == p->blk_row[tb]) {
-          carriers.push_back({it.w0, it.w1, (uint32_t)f->second.first | ((uint32_t)f->second.second << 16)});
+        auto& v = by_ik[p->src_ik[s]];
+        if (v.empty()) ik_order.push_back(p->src_ik[s]);
+        if (diagonal) v.insert(v.begin(), Term{tb, p->src_kk[s], p->src_kj[s], true});
+        else v.push_back(Term{tb, p->src_kk[s], p->src_kj[s], false});
+      }
+    }
+    std::vector<Item3> carriers, plain, rhs_left;
+    for (int32_t ik : ik_order) {
+      const auto& v = by_ik[ik];
+      for (size_t q = 0; q < v.size(); q += pairs ? 2 : 1) {
+        const bool two = pairs && q + 1 < v.size();
+        const Item3 it{(uint32_t)v[q].tb | ((uint32_t)ik << 16), (uint32_t)v[q].kk | ((uint32_t)v[q].kj << 16), NO_RIDER,
+                       two ? ((uint32_t)v[q + 1].tb | ((uint32_t)v[q + 1].kj << 16)) : NO_SECOND};
+        auto f = (q == 0 && v[0].diagonal) ? rhs_of.find(ik) : rhs_of.end();
+        if (f != rhs_of.end() && f->second.first == p->blk_row[v[0].tb]) {
+          carriers.push_back({it.w0, it.w1, (uint32_t)f->second.first | ((uint32_t)f->second.second << 16), it.w3});
           rhs_of.erase(f);
         } else {
           plain.push_back(it);
         }
       }
     }
-    for (int t = t0; t < t1; ++t) {
+    for (const Item3& it : lev_rhs[lev])
+      if (!riders || rhs_of.count(it.w0 >> 16)) rhs_left.push_back(it);          // (riders: the terms without a carrier)
+    std::vector<Item3> out = carriers;                                             // items with a rider first, rhs targets last
+    out.insert(out.end(), plain.begin(), plain.end());
+    out.insert(out.end(), rhs_left.begin(), rhs_left.end());
+    return out;
+  };
+  for (int lev = 0; lev < nlev; ++lev)
+    for (int t = p->lev_tptr[lev]; t < p->lev_tptr[lev + 1]; ++t) {
       const int tb = p->tgt_blk[t];
       if (tb >= 0) continue;
-      for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s) {
-        const Item3 it{(0x8000u | (uint32_t)(-1 - tb)) | ((uint32_t)p->src_ik[s] << 16),
-                       (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16), NO_RIDER};
-        rhs_items.push_back(it);
-        if (rhs_of.count(p->src_ik[s])) rhs_left.push_back(it);          // (a term without a carrier)
-      }
+      for (int s = p->tgt_sptr[t]; s < p->tgt_sptr[t + 1]; ++s)
+        lev_rhs[lev].push_back({(0x8000u | (uint32_t)(-1 - tb)) | ((uint32_t)p->src_ik[s] << 16),
+                                (uint32_t)p->src_kk[s] | ((uint32_t)p->src_kj[s] << 16), NO_RIDER, NO_SECOND});
     }
-    lev_sep[lev].insert(lev_sep[lev].end(), rhs_items.begin(), rhs_items.end());       // block targets first, rhs targets last
-    lev_rhs[lev] = rhs_items;
-    lev_rider[lev] = carriers;                                                          // items with a rider first
-    lev_rider[lev].insert(lev_rider[lev].end(), plain.begin(), plain.end());
-    lev_rider[lev].insert(lev_rider[lev].end(), rhs_left.begin(), rhs_left.end());
-  }
   auto rounds_of = [](size_t n) { return (int)((n + 63) / 64); };
-  auto use_riders = [&](int lev, int nw) {
-    const int with = (rounds_of(lev_rider[lev].size()) + nw - 1) / nw, without = (rounds_of(lev_sep[lev].size()) + nw - 1) / nw;
-    return with < without && !p->dbg.plan_no_riders;
+  // A stream of `nw` wavefronts takes a level in the plainest form that needs the fewest rounds PER WAVEFRONT: second columns
+  // and riders make a round heavier (four more reads and atomics; the rider's two tests), which only pays where whole rounds
+  // go — a wave team walks most levels in one round per wavefront either way (config 3, second columns everywhere: 1.78 ->
+  // 1.85 ms although the team's rounds fell from 48 to 40).  plan_no_pairs 1: never second columns, 2: wherever there is one.
+  auto level_for = [&](int lev, int nw, bool may_ride) {
+    std::vector<Item3> best;
+    int best_r = INT32_MAX;
+    for (int form = 0; form < 4; ++form) {
+      const bool pr = form & 2, rd = form & 1;
+      if ((pr && p->dbg.plan_no_pairs == 1) || (rd && (!may_ride || p->dbg.plan_no_riders))) continue;
+      if (!pr && p->dbg.plan_no_pairs == 2) continue;
+      std::vector<Item3> its = level_items(lev, pr, rd);
+      const int r = (rounds_of(its.size()) + nw - 1) / nw;
+      if (r < best_r) { best_r = r; best = std::move(its); }
+    }
+    return best;
   };
   for (int lev = 0; lev < nlev; ++lev) {
-    const std::vector<Item3>& its = use_riders(lev, 1) ? lev_rider[lev] : lev_sep[lev];
+    const std::vector<Item3> its = level_for(lev, 1, true);
     for (size_t o = 0; o < its.size(); o += 64)
       for (int lane = 0; lane < 64; ++lane) {
-        if (o + lane < its.size()) { p->lp_b.push_back(its[o + lane].w0); p->lp_b.push_back(its[o + lane].w1); p->lp_b2.push_back(its[o + lane].w2); }
-        else { p->lp_b.push_back(NONE | (NONE << 16)); p->lp_b.push_back(0); p->lp_b2.push_back(NO_RIDER); }
+        if (o + lane < its.size()) { p->lp_b.push_back(its[o + lane].w0); p->lp_b.push_back(its[o + lane].w1); p->lp_b2.push_back(its[o + lane].w2); p->lp_b3.push_back(its[o + lane].w3); }
+        else { p->lp_b.push_back(NONE | (NONE << 16)); p->lp_b.push_back(0); p->lp_b2.push_back(NO_RIDER); p->lp_b3.push_back(NO_SECOND); }
       }
     b_bounds.push_back((int32_t)(p->lp_b.size() / 128));
   }
@@ -419,13 +465,15 @@ void build_lane_programs(opfx_plan* p) {
   auto put_d = [](std::vector<uint32_t>& v, size_t at, double x) { std::memcpy(&v[at], &x, 8); };
   p->lp_bc.assign((size_t)(p->rb_pad + p->rc_pad) * 64 * 4, 0u);
   for (size_t q = 0; q < p->lp_bc.size(); q += 4) {
-    p->lp_bc[q] = NONE | (NONE << 16); p->lp_bc[q + 1] = NONE | (NONE << 16); p->lp_bc[q + 2] = NONE | (NONE << 16);
+    p->lp_bc[q] = NONE | (NONE << 16); p->lp_bc[q + 1] = NONE | (NONE << 16); p->lp_bc[q + 2] = NONE | (NONE << 16); p->lp_bc[q + 3] = NO_RIDER_BITS;
   }
+  // device words: w2 = the second column, w3 = round flags | rider bits
   for (int r = 0; r < p->rb; ++r)
     for (int l = 0; l < 64; ++l) {
       p->lp_bc[((size_t)r * 64 + l) * 4 + 0] = p->lp_b[((size_t)r * 64 + l) * 2];
       p->lp_bc[((size_t)r * 64 + l) * 4 + 1] = p->lp_b[((size_t)r * 64 + l) * 2 + 1];
-      p->lp_bc[((size_t)r * 64 + l) * 4 + 2] = p->lp_b2[(size_t)r * 64 + l];
+      p->lp_bc[((size_t)r * 64 + l) * 4 + 2] = p->lp_b3[(size_t)r * 64 + l];
+      p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = rider_bits(p->lp_b2[(size_t)r * 64 + l]);
     }
   for (int r = 0; r < p->rc; ++r)
     for (int l = 0; l < 64; ++l)
@@ -436,7 +484,7 @@ void build_lane_programs(opfx_plan* p) {
   // then issues its LDS reads before this round computes)
   for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
     for (int r = p->lp_groups[g]; r + 1 < p->lp_groups[g + 1]; ++r)
-      for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] = 2u;
+      for (int l = 0; l < 64; ++l) p->lp_bc[((size_t)r * 64 + l) * 4 + 3] |= 2u;
   const bool spread = !p->dbg.plan_no_bank;
   if (spread)
     for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g)
@@ -452,8 +500,8 @@ void build_lane_programs(opfx_plan* p) {
       const std::vector<Item3>& its = lev_rhs[lev];
       for (size_t o = 0; o < its.size(); o += 64)
         for (int lane = 0; lane < 64; ++lane) {
-          if (o + lane < its.size()) { f.push_back(its[o + lane].w0); f.push_back(its[o + lane].w1); f.push_back(NO_RIDER); f.push_back(0u); }
-          else { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_RIDER); f.push_back(0u); }
+          if (o + lane < its.size()) { f.push_back(its[o + lane].w0); f.push_back(its[o + lane].w1); f.push_back(NO_SECOND); f.push_back(NO_RIDER_BITS); }
+          else { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_SECOND); f.push_back(NO_RIDER_BITS); }
         }
       if ((int32_t)(f.size() / 256) > f_bounds.back()) f_bounds.push_back((int32_t)(f.size() / 256));
     }
@@ -463,7 +511,7 @@ void build_lane_programs(opfx_plan* p) {
     if (spread)
       for (size_t g = 0; g + 1 < f_bounds.size(); ++g) spread_over_banks(&f[(size_t)f_bounds[g] * 256], f_bounds[g + 1] - f_bounds[g], p->n_full);
     while ((int32_t)(f.size() / 256) < p->rf_pad)
-      for (int l = 0; l < 64; ++l) { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_RIDER); f.push_back(0u); }
+      for (int l = 0; l < 64; ++l) { f.push_back(NONE | (NONE << 16)); f.push_back(NONE | (NONE << 16)); f.push_back(NO_SECOND); f.push_back(NO_RIDER_BITS); }
     p->lp_bcc = f;
     p->lp_bcc.insert(p->lp_bcc.end(), p->lp_bc.begin() + (size_t)p->rb_pad * 256, p->lp_bc.end());
   }
@@ -499,17 +547,10 @@ void build_lane_programs(opfx_plan* p) {
     }
   p->tail_ids32.assign(p->tail_ids.begin(), p->tail_ids.end());
   // back-substitution rounds of the team streams: (register chain) [tail columns -> outside rows] [levels below the tail]
-  std::vector<uint32_t> tc;                               // rounds of 64 items x 4 words
-  std::vector<int32_t> tc_bounds{0};
+  std::vector<std::vector<std::array<uint32_t, 2>>> tc_groups;      // item lists, one per group (materialised per team size below)
   auto tc_flush = [&]() {
-    for (size_t o = 0; o < items.size(); o += 64)
-      for (int lane = 0; lane < 64; ++lane) {
-        if (o + lane < items.size()) { tc.push_back(items[o + lane][0]); tc.push_back(items[o + lane][1]); }
-        else { tc.push_back(NONE | (NONE << 16)); tc.push_back(NONE | (NONE << 16)); }
-        tc.push_back(NONE | (NONE << 16)); tc.push_back(0u);
-      }
+    if (!items.empty()) tc_groups.push_back(items);
     items.clear();
-    if ((int32_t)(tc.size() / 256) > tc_bounds.back()) tc_bounds.push_back((int32_t)(tc.size() / 256));
   };
   if (tail_m > 0) {
     for (int sx = 0; sx < tail_m; ++sx) {
@@ -541,21 +582,33 @@ void build_lane_programs(opfx_plan* p) {
     std::vector<Group> groups;
     // factorisation + forward substitution: per level the item form that needs fewer rounds per wavefront of THIS
     // team; items with a rider are dealt round-robin over the level's rounds so that no wavefront gets all of them
+    // (Dealing a group's items over a whole number of rounds PER WAVEFRONT — 105 items as 27 + 26 + 26 + 26 on four
+    // wavefronts instead of 64 + 41 on two — was measured and is slower, config 3 1.85 -> 1.89 ms: a round's fixed cost
+    // outweighs its lanes' LDS passes.)
     std::vector<uint32_t> tbk;
     for (int lev = 0; lev < nlev; ++lev) {
-      const bool rid = false;          // (the team kernels' items take no riders, opfx.hip item_factor; `use_riders(lev, NW)` is how it was measured)
-      const std::vector<Item3>& its = rid ? lev_rider[lev] : lev_sep[lev];
+      const std::vector<Item3> its = level_for(lev, NW, false);          // (the team kernels' items take no riders, opfx.hip item_factor)
       const int nr = rounds_of(its.size());
       if (nr == 0) continue;
       const int first = (int)(tbk.size() / 256);
       tbk.resize(tbk.size() + (size_t)nr * 256, NONE | (NONE << 16));
       for (size_t q = 0; q < its.size(); ++q) {
-        const size_t r = rid ? q % nr : q / 64, l = rid ? q / nr : q % 64;
-        uint32_t* at = &tbk[((size_t)(first + r) * 64 + l) * 4];
-        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w2;
+        uint32_t* at = &tbk[((size_t)(first + q / 64) * 64 + q % 64) * 4];
+        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w3;          // (word 2 of a device item: the second column)
       }
       if (spread) spread_over_banks(&tbk[(size_t)first * 256], nr, p->n_full);
       groups.push_back({2, first, first + nr});
+    }
+    std::vector<uint32_t> tc;                               // this team's back-substitution rounds below the tail
+    for (const auto& its : tc_groups) {
+      const int nr = rounds_of(its.size());
+      const int first = (int)(tc.size() / 256);
+      tc.resize(tc.size() + (size_t)nr * 256, NONE | (NONE << 16));
+      for (size_t q = 0; q < its.size(); ++q) {
+        uint32_t* at = &tc[((size_t)(first + q / 64) * 64 + q % 64) * 4];
+        at[0] = its[q][0]; at[1] = its[q][1];
+      }
+      if (spread) spread_over_banks(&tc[(size_t)first * 256], nr, p->n_full);
     }
     if (tail_m == 0)
       for (size_t g = 0; g + 1 < p->lp_groups.size(); ++g) {     // back substitution: the rounds of lp_bc
@@ -564,11 +617,10 @@ void build_lane_programs(opfx_plan* p) {
         groups.push_back({0, r0, r1});
       }
     const size_t n_first = tail_m > 0 ? groups.size() : 0;
-    if (tail_m > 0)
-      for (size_t g = 0; g + 1 < tc_bounds.size(); ++g) {
-        if (spread && t == 0) spread_over_banks(&tc[(size_t)tc_bounds[g] * 256], tc_bounds[g + 1] - tc_bounds[g], p->n_full);
-        groups.push_back({1, tc_bounds[g], tc_bounds[g + 1]});
-      }
+    if (tail_m > 0) {
+      int first = 0;
+      for (const auto& its : tc_groups) { const int nr = rounds_of(its.size()); groups.push_back({1, first, first + nr}); first += nr; }
+    }
     // forward substitution alone, per level (chord steps): same dealing, same barrier rules
     std::vector<uint32_t> tfk;
     std::vector<Group> groups_c;
@@ -580,7 +632,7 @@ void build_lane_programs(opfx_plan* p) {
       tfk.resize(tfk.size() + (size_t)nr * 256, NONE | (NONE << 16));
       for (size_t q = 0; q < its.size(); ++q) {
         uint32_t* at = &tfk[((size_t)(first + q / 64) * 64 + q % 64) * 4];
-        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w2;
+        at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w3;
       }
       if (spread) spread_over_banks(&tfk[(size_t)first * 256], nr, p->n_full);
       groups_c.push_back({3, first, first + nr});
@@ -592,7 +644,7 @@ void build_lane_programs(opfx_plan* p) {
       int K = 0;
       auto empty_round = [&](uint32_t flags) {
         for (int w = 0; w < NW; ++w)
-          for (int l = 0; l < 64; ++l) { out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(flags); }
+          for (int l = 0; l < 64; ++l) { out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(NONE | (NONE << 16)); out_.push_back(flags | NO_RIDER_BITS); }
         ++K;
       };
       kb_out = -1;
@@ -618,7 +670,7 @@ void build_lane_programs(opfx_plan* p) {
             for (int l = 0; l < 64; ++l) {
               if (r < r1) for (int q = 0; q < 3; ++q) out_.push_back(src[((size_t)r * 64 + l) * 4 + q]);
               else for (int q = 0; q < 3; ++q) out_.push_back(NONE | (NONE << 16));
-              out_.push_back(flags);
+              out_.push_back(flags | NO_RIDER_BITS);
             }
           }
           ++K;
@@ -989,6 +1041,7 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_LP_H_ROW: v = u32(p->lp_h_row); break;
     case OPFX_ARR_LP_B: v = u32(p->lp_b); break;
     case OPFX_ARR_LP_B2: v = u32(p->lp_b2); break;
+    case OPFX_ARR_LP_B3: v = u32(p->lp_b3); break;
     case OPFX_ARR_LP_C: v = u32(p->lp_c); break;
     case OPFX_ARR_LP_TEAM2: v = u32(p->lp_team[0]); break;
     case OPFX_ARR_LP_TEAM4: v = u32(p->lp_team[1]); break;

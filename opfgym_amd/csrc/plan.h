@@ -64,9 +64,10 @@ struct opfx_plan {
   std::vector<double> lp_h_y;              // [rh][64][2]
   std::vector<uint32_t> lp_b;              // [rb][64][2]  tb|ik<<16 , kk|kj<<16
   std::vector<uint32_t> lp_b2;             // [rb][64]     i|k<<16: the item also applies its multiplier to y_k -> y_i (0xFFFF|0xFFFF<<16: no)
+  std::vector<uint32_t> lp_b3;             // [rb][64]     a SECOND column of the same multiplier: target2 | A_kj2 << 16 (0xFFFF both: none)
   std::vector<uint32_t> lp_c;              // [rc][64][2]  (0x8000|k)|blk(k,j)<<16 , blk(j,j)|j<<16  (back substitution, same item form as lp_b)
   // device-facing packed forms (16-byte vectors, one coalesced KB per wave-load):
-  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0,w1,rider,flags (pad: empty items)
+  std::vector<uint32_t> lp_bc;             // [rb_pad+rc_pad][64][4]  w0, w1, second column, round flags | rider bits (pad: empty items)
   // chord steps (opfx_solve_opts.jacobian_reuse_tol): forward substitution alone + the same back substitution
   int32_t rf = 0, rf_pad = 0;              // rounds of the forward substitution (right-hand-side items of every level), padded to 4
   std::vector<uint32_t> lp_bcc;            // [rf_pad+rc_pad][64][4]

@@ -155,6 +155,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0,
     h_y = plan.darray('lp_h_y').reshape(rh, 64, 2) if rh else np.zeros((0, 64, 2))
     lp_b = plan.array('lp_b').view(np.uint32).reshape(rb, 64, 2)
     lp_b2 = plan.array('lp_b2').view(np.uint32).reshape(rb, 64)      # riders: i | k << 16 (forward substitution of the pair)
+    lp_b3 = plan.array('lp_b3').view(np.uint32).reshape(rb, 64)      # a second column of the same multiplier: target2 | A_kj2 << 16
     lp_c = plan.array('lp_c').view(np.uint32).reshape(rc, 64, 2)
     fill = plan.array('fill_blk')
     v = case.vm_set * np.exp(1j * case.va_set)
@@ -249,7 +250,7 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0,
                     tb = w0 & 0xFFFF
                     if tb == NONE:
                         continue
-                    assert tb & 0x8000 and (int(bcc[r, lane, 2]) >> 16) == NONE      # right-hand-side targets only, no riders
+                    assert tb & 0x8000 and (int(bcc[r, lane, 2]) & 0xFFFF) == NONE and (int(bcc[r, lane, 3]) >> 2) == 0x3FFFFFFF   # right-hand-side targets only: no second column, no rider
                     k = tb & 0x7FFF
                     w = blk[w0 >> 16] @ inv2(blk[w1 & 0xFFFF])
                     drhs[k] = drhs.get(k, 0) + w @ rhs[w1 >> 16]
@@ -270,6 +271,10 @@ def emulate_newton_lane_program(plan, p_sp, q_sp, tol=1e-8, max_iter=10, team=0,
                         drhs[i] = drhs.get(i, 0) + w @ rhs[w1 >> 16]
                     else:
                         dblk_upd[tb] = dblk_upd.get(tb, 0) + w @ blk[w1 >> 16]
+                    second = int(lp_b3[r, lane])
+                    if (second & 0xFFFF) != NONE:
+                        assert not tb & 0x8000 and not (second & 0x8000)      # block targets only
+                        dblk_upd[second & 0xFFFF] = dblk_upd.get(second & 0xFFFF, 0) + w @ blk[second >> 16]
                     rider = int(lp_b2[r, lane])
                     if (rider >> 16) != NONE:
                         assert not tb & 0x8000
@@ -328,8 +333,9 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
 
     def run(k0, k1):
         for k in range(k0, k1):
-            flags = set(int(f) for f in stream[k, :, :, 3].ravel())
+            flags = set(int(f) & 3 for f in stream[k, :, :, 3].ravel())
             assert len(flags) == 1                           # one flag word per round, the same for every wavefront
+            assert all((int(f) >> 2) == 0x3FFFFFFF for f in stream[k, :, :, 3].ravel())     # (team items carry no riders)
             for w in range(nw):
                 upd_b, upd_r = {}, {}
                 for lane in range(64):
@@ -349,12 +355,13 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
                         upd_b[tb] = upd_b.get(tb, 0) + mlt @ blk[kj]
                         reads[w].add(('b', kj))
                         adds[w].add(('b', tb))
-                    rider = int(stream[k, w, lane, 2])
-                    if (rider >> 16) != NONE:
-                        i2, k2 = rider & 0xFFFF, rider >> 16
-                        upd_r[i2] = upd_r.get(i2, 0) + mlt @ rhs[k2]
-                        reads[w].add(('r', k2))
-                        adds[w].add(('r', i2))
+                    second = int(stream[k, w, lane, 2])          # a second column of the same multiplier
+                    if (second & 0xFFFF) != NONE:
+                        assert not tb & 0x8000
+                        tb2, kj2 = second & 0xFFFF, second >> 16
+                        upd_b[tb2] = upd_b.get(tb2, 0) + mlt @ blk[kj2]
+                        reads[w].add(('b', kj2))
+                        adds[w].add(('b', tb2))
                     # an item never reads what an item of the same round adds to (one group = independent items)
                 for tb, d in upd_b.items():
                     blk[tb] -= d

@@ -177,6 +177,40 @@ def test_team_stream_reproduces_oracle(built_lib, code, team):
     assert np.abs(v - ref['V']).max() < 1e-9
 
 
+@pytest.mark.parametrize('code,team', [('1-MV-urban--0-sw', 0), ('hv-small', 2), ('1-HV-mixed--0-sw', 4)])
+def test_second_columns_carry_every_update_term_once(built_lib, code, team):
+    """Round 4: a factor item may carry a SECOND column of the same multiplier -A_ik A_kk^-1 (device word 2).  Each stream
+    takes a level with second columns only where that saves a round per wavefront; plan_no_pairs = 1 / 2 switches them
+    off / on everywhere.  All three plans hold every update term of the schedule exactly once and give the oracle's
+    iterates."""
+    net = grids.get_grid(code)[0]
+    case = net_to_case(net)
+    p, q, *_ = bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = OracleSide(net, case).solve(p, q)
+    counts = {}
+    for mode in (0, 1, 2):
+        d = capi.DebugOpts()
+        d.plan_no_pairs = mode
+        plan = capi.Plan(case, debug=d)
+        if team:
+            it4 = plan.array(f'LP_TEAM{team}').astype(np.int64).reshape(-1, 4) & 0xFFFFFFFF
+            first, second = it4[:, 0], it4[:, 2]            # (back-substitution items have right-hand-side targets)
+        else:
+            first = plan.array('LP_B').astype(np.int64).reshape(-1, 2)[:, 0] & 0xFFFFFFFF
+            second = plan.array('LP_B3').astype(np.int64) & 0xFFFFFFFF
+        live = (first & 0xFFFF) != 0xFFFF
+        blk = live & ((first & 0x8000) == 0)
+        two = live & ((second & 0xFFFF) != 0xFFFF)
+        assert not (two & ~blk).any()                          # only a block target has a second column
+        counts[mode] = (int(blk.sum() + two.sum()), int(two.sum()))
+        v, conv, it, _ = emulate_newton_lane_program(plan, p, q, team=team)
+        assert conv and it == ref['iterations'] and np.abs(v - ref['V']).max() < 1e-9
+    n_block_terms = int((np.repeat(load_plan(capi.Plan(case))['tgt_blk'], np.diff(load_plan(capi.Plan(case))['tgt_sptr'])) >= 0).sum())
+    assert counts[0][0] == counts[1][0] == counts[2][0] == n_block_terms
+    assert counts[1][1] == 0 and counts[0][1] <= counts[2][1] and counts[2][1] > 0      # (a small grid on a team: none by default)
+
+
 @pytest.mark.parametrize('code,team,theta', [('1-MV-urban--0-sw', 0, 1e-2), ('hv-small', 0, 1e-1), ('hv-small', 2, 1e-1), ('1-HV-mixed--0-sw', 4, 1e-1),
                                              ('1-HV-mixed--0-sw', 2, 1.0), ('1-HV-urban--0-sw', 4, 1.0), ('case9', 0, 1.0)])
 def test_chord_stream_reaches_the_same_fixed_point(built_lib, code, team, theta):
