@@ -601,9 +601,12 @@ struct ItemRegs { double i11, i12, i21, i22, k11, k12, k21, k22, c11, c12, c21, 
 __device__ __forceinline__ unsigned rider_i(const uint4 d) { return (d.w >> 2) & 0x7FFFu; }
 __device__ __forceinline__ unsigned rider_k(const uint4 d) { return d.w >> 17; }
 constexpr unsigned ITEM_BARRIER = 1u, ITEM_NEXT_INDEPENDENT = 2u;   // flags in word 3 of a round's items (plan.cpp)
-// LATE2: the second column's block is read in item_apply, after the first column's updates have been issued, into the
-// registers the first column has left (the wave-team kernels, which have no eight registers to spare: scratch otherwise).
-template <bool PK, bool RIDERS, bool LATE2 = false>
+// SEC: how the stream's second columns are handled — SEC_NONE: it has none (back substitution: no test, no registers);
+// SEC_EARLY: the block is read with the item's other blocks; SEC_LATE: it is read in item_apply, after the first column's
+// updates have been issued, into the registers the first column has left (the wave-team kernels, which have no eight
+// registers to spare: scratch otherwise).
+constexpr int SEC_NONE = 0, SEC_EARLY = 1, SEC_LATE = 2;
+template <bool PK, bool RIDERS, int SEC = SEC_EARLY>
 __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -621,15 +624,15 @@ __device__ __forceinline__ ItemRegs item_load(const Lds& L, const uint4 d) {
   r.c11 = *c1p; r.c21 = *c3p;
   r.c12 = L.blk[bx12(L, kjb)]; r.c22 = L.blk[bx22(L, kjc)];
   // the second column: read only where a lane of the wavefront has one (most rounds of a wave team have none, plan.cpp level_for)
-  const bool two = live && (d.z & 0xFFFF) != NONE;
+  const bool two = SEC != SEC_NONE && live && (d.z & 0xFFFF) != NONE;
   r.e11 = 0.0; r.e12 = 0.0; r.e21 = 0.0; r.e22 = 0.0;
-  if (!LATE2 && two) ld_blk_raw<PK>(L, d.z >> 16, r.e11, r.e12, r.e21, r.e22);
+  if (SEC == SEC_EARLY && two) ld_blk_raw<PK>(L, d.z >> 16, r.e11, r.e12, r.e21, r.e22);
   // rider (plan.cpp): the item's multiplier also takes y_k to y_i — the forward substitution of the pair (i, k)
   r.y1 = 0.0; r.y2 = 0.0;
   if (RIDERS && rider_i(d) != 0x7FFFu) { const unsigned k = rider_k(d); r.y1 = L.rhs[k]; r.y2 = L.rq[k]; }
   return r;
 }
-template <bool PK, bool RIDERS, bool LATE2 = false>
+template <bool PK, bool RIDERS, int SEC = SEC_EARLY>
 __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const ItemRegs& r) {
   constexpr unsigned NONE = 0xFFFFu;
   const unsigned tb = d.x & 0xFFFF;
@@ -660,11 +663,11 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
     lds_add(L.blk + bx22(L, tb), m21 * c12 + m22 * c22);
   }
   const unsigned tb2 = d.z & 0xFFFF;
-  if (tb2 != NONE) {                      // the second column of the same multiplier: A_ij2 += m A_kj2 (a block target always)
+  if (SEC != SEC_NONE && tb2 != NONE) {                      // the second column of the same multiplier: A_ij2 += m A_kj2 (a block target always)
     const unsigned ej = d.z >> 16;
     const bool fe = !PK || ej < (unsigned)L.nfull;
     double e11 = r.e11, e12 = r.e12, x21 = r.e21, x22 = r.e22;
-    if (LATE2) ld_blk_raw<PK>(L, ej, e11, e12, x21, x22);
+    if (SEC == SEC_LATE) ld_blk_raw<PK>(L, ej, e11, e12, x21, x22);
     const double e21 = fe ? x21 : -e12, e22 = fe ? x22 : e11;
     lds_add(L.blk + bx11(L, tb2), m11 * e11 + m12 * e21);
     lds_add(L.blk + bx21(L, tb2), m21 * e11 + m22 * e21);
@@ -681,11 +684,11 @@ __device__ __forceinline__ void item_apply(const Lds& L, const uint4 d, const It
 // there a rider saves whole rounds (144-bus grid: 11 -> 8 rounds of factorisation, 0.286 -> 0.273 ms), whereas the
 // wave teams walk one round per wavefront through most levels either way and the two tests per item cost more
 // than the saved rounds give back (config 3: 1.967 -> 1.976 ms with riders, 2.06 ms with the tests but no riders).
-template <bool PK, bool RIDERS, bool LATE2 = false>
+template <bool PK, bool RIDERS, int SEC = SEC_EARLY>
 __device__ __forceinline__ void item_factor(const Lds& L, const uint4 d) {
   if ((d.x & 0xFFFF) == 0xFFFFu) return;           // empty item: nothing read (idle waves of a team stay off the LDS)
-  const ItemRegs r = item_load<PK, RIDERS, LATE2>(L, d);
-  item_apply<PK, RIDERS, LATE2>(L, d, r);
+  const ItemRegs r = item_load<PK, RIDERS, SEC>(L, d);
+  item_apply<PK, RIDERS, SEC>(L, d, r);
 }
 // Two consecutive rounds of one wavefront.  When the plan marks the second as independent of the first (same group)
 // all LDS reads of both are requested first.
@@ -825,7 +828,7 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
 template <bool PK, bool MEM = false>
 __device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
   const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
-  item_factor<PK, false, true>(L, d);
+  item_factor<PK, false, SEC_LATE>(L, d);
   if (fl & ITEM_BARRIER) team_sync<MEM>(); else mem_fence<MEM>();  // (no barrier: the same wavefront carries on)
 }
 
@@ -1294,10 +1297,10 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     OPFX_STAMP(2);
     for (int r = RB; r < R; r += 4) {
-      item_factor<PK, false>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
-      item_factor<PK, false>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
-      item_factor<PK, false>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
-      item_factor<PK, false>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
+      item_factor<PK, false, SEC_NONE>(L, q0); wave_fence(); q0 = ld_desc(r + 4);
+      item_factor<PK, false, SEC_NONE>(L, q1); wave_fence(); q1 = ld_desc(r + 5);
+      item_factor<PK, false, SEC_NONE>(L, q2); wave_fence(); q2 = ld_desc(r + 6);
+      item_factor<PK, false, SEC_NONE>(L, q3); wave_fence(); q3 = ld_desc(r + 7);
     }
 #endif
     OPFX_STAMP(3);
