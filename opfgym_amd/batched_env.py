@@ -1303,7 +1303,8 @@ class BatchedOpfEnv:
             rio.obs = self.buf['obs'].data_ptr()
         with t.cuda.device(self.device):
             capi.check(capi.lib().opfx_reset(self._env_handle, B, C.byref(rio), capi._stream()), 'opfx_reset')
-        self.step_count.zero_()
+        if self.steps_per_episode != 1:                                    # (single-step episodes never read the counter:
+            self.step_count.zero_()                                        #  no launch for it in the reset + step cycle)
         if self.pf_for_obs:                                                # :209-216
             self._launch_step(act, mode=4, with_initial_obj=False)
             if self._host_finisher is not None:
