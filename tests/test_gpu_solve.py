@@ -64,6 +64,31 @@ def test_the_answer_does_not_depend_on_the_elimination_order(code, B, monkeypatc
         assert (a['iterations'] == b['iterations']).all()
 
 
+@pytest.mark.parametrize('code,B,team', [('1-MV-urban--0-sw', 128, 0), ('1-HV-mixed--0-sw', 48, 4), ('1-HV-mixed--0-sw', 32, 2),
+                                         ('1-HV-urban--0-sw', 24, 4), ('hv-small', 64, 2)])
+def test_second_columns_everywhere_nowhere_and_where_they_pay_give_the_same_answer(code, B, team, monkeypatch):
+    """A factor item may carry a second column of the same multiplier (plan.cpp level_for): by default only in levels where
+    that saves a round per wavefront.  OPFX_PLAN_NO_PAIRS=2 puts one wherever two terms share a multiplier — every round of
+    every kernel form (early reads in the single-wave kernel, late reads in the wave teams) then runs that code — and =1
+    none at all.  Same power flow, same iteration counts, the oracle's answer."""
+    if team:
+        monkeypatch.setenv('OPFX_TEAM', str(team))
+    runs = []
+    for mode in ('0', '1', '2'):
+        monkeypatch.setenv('OPFX_PLAN_NO_PAIRS', mode)
+        net, case, p, q, out = _run(code, B, seed=23)
+        runs.append(out)
+    ref = oracle_batch(net, case, p, q)
+    assert ref['converged'].all()
+    for out in runs:
+        assert out['converged'].astype(bool).all()
+        assert np.abs(out['vm'] - ref['vm']).max() < TOL_V
+        assert np.abs(np.angle(np.exp(1j * (out['va'] - ref['va'])))).max() < TOL_V
+        assert np.abs(out['loading'] - ref['loading']).max() < 1e-6
+        assert (out['iterations'] == runs[0]['iterations']).all()
+        assert np.abs(out['vm'] - runs[0]['vm']).max() < 1e-12
+
+
 def test_full_batch_properties():
     """B = 8192 (BASELINE config 2 size): every instance converges and the
     solution satisfies the power-flow equations — checked for all rows through
