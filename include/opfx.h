@@ -349,9 +349,12 @@ typedef struct opfx_env_desc {
    * case branch whose four stamps follow an integer state column of the store:
    * stamps = bmod_y[bmod_ptr[m] + clip(round(x[bmod_slot[m]]) - bmod_lo[m], 0, bmod_n[m]-1)];
    * an all-zero table row takes the branch out of service.  The plan is compiled with every
-   * such branch present; at most one state column per branch. */
+   * such branch present; at most one state column per branch.
+   * A row with bmod_branch[m] = -1 - bus is a BUS SHUNT in steps (an ('shunt','step') actuator,
+   * opf_env.py:476-481): its table rows hold (0, 0, 0, 0, 0, 0, dG, dB), the DIFFERENCE of the bus's shunt
+   * admittance at that step to the compiled case, p.u. */
   int32_t n_bmod;
-  const int32_t* bmod_branch;     /* [n_bmod] case branch index              */
+  const int32_t* bmod_branch;     /* [n_bmod] case branch index, or -1 - bus */
   const int32_t* bmod_slot;       /* [n_bmod] column of the store            */
   const int32_t* bmod_lo;         /* [n_bmod] state value of table row 0     */
   const int32_t* bmod_n;          /* [n_bmod] table rows                     */

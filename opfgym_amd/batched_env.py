@@ -398,9 +398,9 @@ class BatchedOpfEnv:
                 dev_constraints.append(con)
         self.device_constraints = dev_constraints
         self.host_mode = self.host_objective is not None or bool(self._host_constraints)
-        if self.host_mode and n_minus_one_keys:
-            raise NotImplementedError('Python objective / constraint callables cannot be combined with N-1 '
-                                      'contingencies: the per-contingency result tables never leave the kernel')
+        # (host callables together with N-1 contingencies: the kernel still walks the contingencies for its own constraints;
+        #  for the callables every contingency is solved once more by a contingency-free twin of the environment with the
+        #  branch out, `contingency_results`, and evaluated on the host — host_fallback.py)
         self.n_minus_one_keys = n_minus_one_keys or ()
         for _, column, _ in self.n_minus_one_keys:
             assert column in ('in_service', 'closed')                      # security_constrained.py:34-35
@@ -640,8 +640,9 @@ class BatchedOpfEnv:
     # ------------------------------------------------------------------ compile
     def _branch_state_column(self, unit, col, idxs, rows, bmod):
         """Actuator columns that change Ybus values per instance: transformer tap
-        positions (one stamp table row per integer position, computed by the case builder itself)
-        and line/trafo switches or in_service flags (stamps or nothing)."""
+        positions (one stamp table row per integer position, computed by the case builder itself),
+        line/trafo switches or in_service flags (stamps or nothing) and shunts in steps (the bus's
+        shunt admittance per integer step)."""
         net, c, st = self.net, self.case, self.store
         br_of = {(int(kd), int(e)): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem))}
 
@@ -697,6 +698,40 @@ class BatchedOpfEnv:
                     k = branch(KIND_LINE if unit == 'line' else KIND_TRAFO, r, f'{unit}.in_service')
                     opened = [0.0] * 8
                 bmod.append(dict(branch=k, slot=slot0 + int(r), lo=0, table=[opened, _branch_stamps(c, k)]))
+        elif col == 'step' and unit == 'shunt':
+            # a shunt in steps (opf_env.py:476-481 rounds the set-point): the bus's shunt admittance for every integer step,
+            # computed by the case builder itself, as the DIFFERENCE to the compiled case (bmod_branch = -1 - bus)
+            df = net['shunt']
+            lo_col = 'min_min_step' if 'min_min_step' in df.columns else 'min_step'
+            hi_col = 'max_max_step' if 'max_max_step' in df.columns else ('max_step' if 'max_step' in df.columns else None)
+            lo = int(np.floor(df[lo_col].loc[list(idxs)].min())) if lo_col in df.columns else 0
+            if hi_col is None:
+                raise ValueError("('shunt', 'step') actuator: the shunt table needs max_step (or max_max_step)")
+            hi = int(np.ceil(df[hi_col].loc[list(idxs)].max()))
+            buses = {}
+            for r in rows:
+                b = int(df['bus'].iloc[int(r)])
+                if b not in c.bus_lookup:
+                    raise ValueError('shunt.step: the shunt is not part of the energised grid')
+                if not bool(df['in_service'].iloc[int(r)] if 'in_service' in df.columns else True):
+                    raise ValueError('shunt.step: the shunt is out of service')
+                if c.bus_lookup[b] in buses.values():
+                    raise NotImplementedError('shunt.step: two controllable shunts at one bus')
+                buses[int(r)] = c.bus_lookup[b]
+            saved = df['step'].copy()
+            tables = {int(r): [] for r in rows}
+            try:
+                for pos in range(lo, hi + 1):
+                    for r in rows:
+                        net['shunt']['step'] = saved                         # (one shunt at a time: buses may be fused)
+                        net['shunt'].loc[df.index[int(r)], 'step'] = pos
+                        cp = _case_all_branches_in(net, self.act_keys)
+                        i = buses[int(r)]
+                        tables[int(r)].append([0.0] * 6 + [float(cp.gs[i] - c.gs[i]), float(cp.bs[i] - c.bs[i])])
+            finally:
+                net['shunt']['step'] = saved
+            for r in rows:
+                bmod.append(dict(branch=-1 - buses[int(r)], slot=slot0 + int(r), lo=lo, table=tables[int(r)]))
         else:
             raise NotImplementedError(f'actuator {unit}.{col} is not supported')
 
@@ -911,14 +946,16 @@ class BatchedOpfEnv:
             c_pp.append(con.penalty_power); c_cp.append(con.violation_count_penalty)
             c_wc.append(int(bool(con.only_worst_case_violations)))
         # ---- N-1 list (security_constrained.py:44-50) -------------------------------------
-        cont = []
+        cont, cont_pos = [], []
         for unit, column, idxs in self.n_minus_one_keys:
             kind = {'line': KIND_LINE, 'trafo': KIND_TRAFO}[unit]
             pos_to_br = {int(e): k for k, (kd, e) in enumerate(zip(c.br_kind, c.br_elem)) if kd == kind}
             for pos in st.rows(unit, idxs):
+                cont_pos.append(pos_to_br.get(int(pos), -1))
                 if int(pos) in pos_to_br:          # already out of service -> skipped (:46-48)
                     cont.append(pos_to_br[int(pos)])
         self.contingencies = cont
+        self._contingency_positions = cont_pos     # (per element of the N-1 keys: its case branch, -1 = not energised)
         # ---- fill the descriptor -------------------------------------------------------------
         self.nx = st.n
         d.nx = st.n
@@ -1006,6 +1043,9 @@ class BatchedOpfEnv:
             d.bmod_ptr = _keep(keep, ptr[:-1], 'i')
             d.bmod_y = _keep(keep, np.concatenate([np.asarray(b['table'], float).ravel() for b in bmod]), 'd')
         self.branch_state_columns = bmod
+        if getattr(self, '_env_handle_base_only', None) is not None:
+            capi.lib().opfx_env_destroy(self._env_handle_base_only)
+            self._env_handle_base_only = None
         if self._env_handle is not None:
             capi.lib().opfx_env_destroy(self._env_handle)
             self._env_handle = None
@@ -1013,6 +1053,17 @@ class BatchedOpfEnv:
         capi.check(capi.lib().opfx_env_create(self.ctx.handle, C.byref(d), C.byref(h)), 'opfx_env_create')
         self._env_handle = h
         self._env_desc, self._env_desc_keep = d, keep        # (the rescue environments of on_pivot_breakdown reuse them)
+        if getattr(self, '_env_handle_base_only', None) is not None:
+            capi.lib().opfx_env_destroy(self._env_handle_base_only)
+        self._env_handle_base_only = None
+        if self.host_mode and cont:
+            n_cont, d.n_cont = d.n_cont, 0                   # the same environment without its contingency list
+            h0 = C.c_void_p()
+            try:
+                capi.check(capi.lib().opfx_env_create(self.ctx.handle, C.byref(d), C.byref(h0)), 'opfx_env_create (base case only)')
+            finally:
+                d.n_cont = n_cont
+            self._env_handle_base_only = h0
         self._rescue_envs = {}
         self.n_obs_raw = len(oidx)
         self.n_constraints = len(self.constraints)
@@ -1123,6 +1174,25 @@ class BatchedOpfEnv:
                                             mode, capi._stream()), 'opfx_step')
         if resolve:
             self._rescue_pivot_breakdown(action, mode, with_initial_obj, x_before)
+
+    def contingency_results(self, branch):
+        """Result bank [B, n_results] and convergence flags [B] of the CURRENT set-points with case branch `branch` out of
+        service — one power flow per instance, no action applied, nothing of the step's outputs touched (the host
+        fallback's view of one N-1 contingency, security_constrained.py:50-56)."""
+        t = self.torch
+        if self._env_handle_base_only is None:
+            raise RuntimeError('contingency_results: only for environments with host callables and N-1 keys')
+        io = capi.StepIO()
+        io.x = self.x.data_ptr()
+        io.step_in_episode = self.step_count.data_ptr() if self.steps_per_episode != 1 else None
+        out = t.full((self.B,), int(branch), dtype=t.int32, device=self.device)
+        res = t.empty(self.B, self.n_results, dtype=t.float64, device=self.device)
+        conv = t.zeros(self.B, dtype=t.uint8, device=self.device)
+        io.outage, io.results, io.converged = out.data_ptr(), res.data_ptr(), conv.data_ptr()
+        with t.cuda.device(self.device):
+            capi.check(capi.lib().opfx_step(self._env_handle_base_only, self.B, C.byref(io), C.byref(self.solve_opts),
+                                            1, capi._stream()), 'opfx_step (one contingency)')
+        return res, conv
 
     PIVOT_BREAKDOWN = 1e-8
 
@@ -1548,6 +1618,9 @@ class BatchedOpfEnv:
         for _, _, h in getattr(self, '_rescue_envs', {}).values():
             capi.lib().opfx_env_destroy(h)
         self._rescue_envs = {}
+        if getattr(self, '_env_handle_base_only', None) is not None:
+            capi.lib().opfx_env_destroy(self._env_handle_base_only)
+            self._env_handle_base_only = None
         if self._env_handle is not None:
             capi.lib().opfx_env_destroy(self._env_handle)
             self._env_handle = None

@@ -936,6 +936,20 @@ __device__ __forceinline__ void mod_set(const DevPlan& P, const Lds& L, int lane
   wave_fence();
 }
 
+// Modifier m for a BUS SHUNT in steps (an ('shunt', 'step') actuator, opf_env.py:476-481): a branch modifier whose two ends
+// are the same bus, without off-diagonal stamps and without a branch; lanes 6 / 7 hold the change (dG, dB) of the bus's shunt
+// admittance against the compiled case — the "to" end's self admittance, which is the end mods_inline picks when both are
+// the bus.  Ends with a wave fence.
+__device__ __forceinline__ void mod_set_shunt(const DevPlan& P, const Lds& L, int lane, int m, int bus, double dy_lane) {
+  if (lane < 8) mod_dy(L, m)[lane] = lane >= 6 ? dy_lane : 0.0;
+  int* id = mod_ids(L, m);
+  if (lane == 8) { id[0] = bus; id[1] = bus; }
+  if (lane == 9) { const int d = P.diag_blk[bus]; id[4] = d; id[5] = d; }
+  if (lane == 10) { id[2] = -1; id[3] = -1; }
+  if (lane == 12) { id[6] = -1; id[7] = 0; }
+  wave_fence();
+}
+
 // De-energised buses (mark_island): their rows become identity rows — off-diagonal blocks 0,
 // diagonal block I, right-hand side 0.  Runs after phase A in the modifier path only (an island
 // always comes with the modifier of the branch that cut it off), re-reading the row descriptors.
@@ -2822,6 +2836,15 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       const int br = as_global(E.bmod_branch)[m];
       const int st = (int)rint(src_val(xs, L.sp, as_global(E.bmod_src)[m])) - as_global(E.bmod_lo)[m];
       const int row = as_global(E.bmod_ptr)[m] + min(max(st, 0), as_global(E.bmod_n)[m] - 1);
+      if (br < 0) {
+        // a bus shunt in steps (bus -1 - br): the row holds (…, dG, dB), the DIFFERENCE to the compiled shunt of the bus
+        double dsh = 0.0;
+        if (lane >= 6 && lane < 8) dsh = as_global(E.bmod_y)[row * 8 + lane];
+        if (!__any(dsh != 0.0)) continue;
+        if (wave == 0) mod_set_shunt(P, L, lane, n_mod_base, -1 - br, dsh);
+        ++n_mod_base;
+        continue;
+      }
       double y = 0.0, dy = 0.0;
       if (lane < 8) { y = as_global(E.bmod_y)[row * 8 + lane]; dy = y - P.br_y[br * 8 + lane]; }
       if (br == base_out || !__any(dy != 0.0)) continue;      // outaged anyway / state = compiled state
@@ -3626,10 +3649,10 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
     size_t rows = 0;
     std::vector<int32_t> src(d->n_bmod);
     for (int m = 0; m < d->n_bmod; ++m) {
-      if (d->bmod_branch[m] < 0 || d->bmod_branch[m] >= p.nbr || d->bmod_slot[m] < 0 || d->bmod_slot[m] >= d->nx || d->bmod_n[m] < 1) {
+      if (d->bmod_branch[m] < -p.nb || d->bmod_branch[m] >= p.nbr || d->bmod_slot[m] < 0 || d->bmod_slot[m] >= d->nx || d->bmod_n[m] < 1) {
         rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: bad branch state column"); break;
       }
-      for (int j = 0; j < m; ++j) if (d->bmod_branch[j] == d->bmod_branch[m]) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: two state columns for one branch"); }
+      for (int j = 0; j < m; ++j) if (d->bmod_branch[j] == d->bmod_branch[m]) { rc = OPFX_ERR_INVALID; opfx_set_error("opfx_env_create: two state columns for one branch / bus shunt"); }
       rows = std::max(rows, (size_t)d->bmod_ptr[m] + d->bmod_n[m]);
       src[m] = src_of(d->bmod_slot[m]);
     }

@@ -11,8 +11,10 @@ and recomputes reward / cost / info with the reward function's host formulas (re
 
 Cost: O(B) Python calls and DataFrame writes per step (milliseconds per instance) — a compatibility path,
 not a fast one; objects that describe themselves (`opfgym_amd.objectives`, `constraints.ApparentPower`)
-stay on the device.  Not available together with N-1 contingencies (their per-contingency result tables
-never leave the kernel).
+stay on the device.  With N-1 contingencies (security_constrained.py:37-68) the kernel still accumulates its own
+constraints over the contingencies inside the fused launch; for the host constraints every contingency is solved once
+more on the GPU with the branch out (`BatchedOpfEnv.contingency_results`: one launch per contingency, the result bank
+comes back) and evaluated here per instance — K extra launches and B x K more Python calls per step.
 """
 from __future__ import annotations
 
@@ -110,6 +112,38 @@ class HostFinisher:
             net['res_gen'] = pd.DataFrame({'p_mw': gen['p_mw'].to_numpy(float) * sc, 'q_mvar': q, 'vm_pu': vm}, index=gen.index)
         return net
 
+    def _contingencies(self, x, conv, valids, viol, pen):
+        """security_constrained.py:44-66 for the HOST constraints (the kernel has done it for its own): every listed element
+        out of service in turn, the case re-solved on the GPU, `valids &=`, `violations +=`, `penalties +=`; a contingency
+        whose power flow fails invalidates the row and adds `not_converged_penalty` (with the reference's sign)."""
+        env = self.env
+        host_cols = [(j, idx) for j, (where, idx) in enumerate(self.order) if where == 'host']
+        cells = [(unit, column, net_idx) for unit, column, idxs in env.n_minus_one_keys for net_idx in idxs]
+        cells = [cell for cell, pos in zip(cells, env._contingency_positions) if pos >= 0]      # (energised elements only)
+        assert len(cells) == len(env.contingencies)
+        ncp = float(env.not_converged_penalty)
+        for (unit, column, net_idx), branch in zip(cells, env.contingencies):
+            res_c, conv_c = env.contingency_results(branch)
+            res_c, conv_c = res_c.cpu().numpy(), conv_c.cpu().numpy().astype(bool)
+            for k in range(env.B):
+                if not conv[k]:
+                    continue
+                if not conv_c[k]:
+                    for j, _ in host_cols:
+                        valids[k, j] = False; viol[k, j] += ncp; pen[k, j] += ncp
+                    continue
+                net = self.net_view(x[k], res_c[k])
+                old = net[unit].at[net_idx, column]
+                net[unit].at[net_idx, column] = False            # (what the reference's net looks like during this evaluation)
+                try:
+                    for j, idx in host_cols:
+                        v, vi, pe = self.host_constraints[idx].metrics(net)
+                        valids[k, j] = valids[k, j] and v
+                        viol[k, j] += vi
+                        pen[k, j] += pe
+                finally:
+                    net[unit].at[net_idx, column] = old
+
     def finish(self, mode, initial_obj=None):
         """Overwrites objective / reward / cost and assembles valids / violations / penalties [B, nc] in the
         user's constraint order.  Returns the dict of final info tensors."""
@@ -144,9 +178,14 @@ class HostFinisher:
                     objective[k] -= init[k]
             for j, (where, idx) in enumerate(self.order):
                 if where == 'dev':
-                    valids[k, j], viol[k, j], pen[k, j] = dv[k, idx], dvi[k, idx], dpe[k, idx]
+                    valids[k, j], viol[k, j], pen[k, j] = dv[k, idx], dvi[k, idx], dpe[k, idx]   # (contingencies included)
                 else:
                     valids[k, j], viol[k, j], pen[k, j] = self.host_constraints[idx].metrics(net)
+        if self.host_constraints and env.contingencies and mode in (0, 1, 5):
+            self._contingencies(x, conv, valids, viol, pen)
+        for k in range(B):
+            if not conv[k]:
+                continue
             valid = bool(valids[k, :nc].all()) if nc else True
             penalty = float(pen[k, :nc].sum()) if nc else 0.0
             r = rf(objective[k], penalty, valid)                  # reward.py:61-98

@@ -567,6 +567,49 @@ def test_host_fallback_for_python_callables():
     assert (variants['device']['violations'][:, -1] > 0).any(), 'the custom constraint must bind for the test to mean something'
 
 
+def test_host_callables_together_with_n_minus_one_contingencies():
+    """A Python constraint callable in an environment with N-1 keys (security_constrained.py:37-68 calls
+    `calculate_violations` once per contingency): the kernel accumulates its own constraints over the contingencies, the
+    host constraint sees every contingency's result tables through `contingency_results` (one more launch per
+    contingency).  The same constraint in its device form — already pinned against the oracle's N-1 loop — gives the same
+    valids / violations / penalties / rewards; a contingency that does not converge invalidates the row in both."""
+    import pandas as pd
+    from opfgym_amd import constraints as pc, envs
+    B = 10
+    keys = (('line', 'in_service', np.array([1, 5, 9])), ('trafo', 'in_service', np.array([0])))
+    lim = lambda net_: {'max': pd.Series(35.0, index=net_.line.index)}
+    makers = {'device': lambda: pc.Constraint('line', 'loading_percent', get_boundaries=lim),
+              'callable': lambda: pc.Constraint('line', 'loading_percent', get_boundaries=lim,
+                                                get_values=lambda net: net.res_line.loading_percent)}
+    rng = np.random.default_rng(31)
+    got = {}
+    base_net = envs.EcoDispatch(simbench_network_name='hv-small', batch_size=1, defer_device=True, seed=23).net
+    clist = lambda mk: pc.create_default_constraints(base_net, {}) + [mk()]
+    for name, mk in makers.items():
+        e = envs.EcoDispatch(simbench_network_name='hv-small', batch_size=B, device='cuda:0', seed=23,
+                                custom_constraints=clist(mk), n_minus_one_keys=keys)
+        assert e.host_mode == (name == 'callable') and len(e.contingencies) == 4
+        if name == 'device':
+            steps, act = rng.choice(e.train_steps, B), rng.random((B, e.n_actions))
+        e.reset(options={'step': steps})
+        obs, reward, term, trunc, info = e.step(act)
+        got[name] = {k: _np(v).copy().astype(float) for k, v in dict(reward=reward, cost=info['cost'], valids=info['valids'],
+                     violations=info['violations'], penalties=info['unscaled_penalties']).items()}
+        if name == 'callable':
+            # one contingency alone: its result bank differs from the base case's and carries the outage
+            res_c, conv_c = e.contingency_results(e.contingencies[0])
+            assert _np(conv_c).all() and np.abs(_np(res_c) - _np(e.buf['results'])).max() > 1e-3
+    for k in got['device']:
+        assert np.allclose(got['device'][k], got['callable'][k], rtol=0, atol=1e-9, equal_nan=True), k
+    assert (got['device']['violations'][:, -1] > 0).any(), 'the custom constraint must bind for the test to mean something'
+    # without the contingencies the numbers are others: the N-1 terms are in there
+    e0 = envs.EcoDispatch(simbench_network_name='hv-small', batch_size=B, device='cuda:0', seed=23,
+                             custom_constraints=clist(makers['callable']))
+    e0.reset(options={'step': steps})
+    _, _, _, _, info0 = e0.step(act)
+    assert not np.allclose(_np(info0['violations']).astype(float)[:, -1], got['callable']['violations'][:, -1])
+
+
 def test_custom_reward_classes_run_through_their_own_methods():
     """`adjust_objective` / `adjust_penalty` are the reference's extension points (reward.py:106-112,
     abstract there).  A user subclass that overrides them — or a foreign object with the reference's interface — must
@@ -835,6 +878,77 @@ def test_n_minus_one_on_switched_and_tapped_branches():
             _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=True)
             n_ok += 1
     assert n_ok >= B // 2
+
+
+@pytest.mark.parametrize('team', [0, 2])
+def test_shunt_steps_as_actuators(team, monkeypatch):
+    """(team 2: the wave-team kernels fold the modifiers into the bus rounds of phase A, `mods_inline`; the single-wave
+    kernel applies them in a pass of their own, `mods_apply`.)
+    ('shunt', 'step', idxs) action keys (the reference rounds the set-point, opf_env.py:476-481): a per-instance
+    diagonal admittance, carried as a branch modifier whose two ends are the same bus (opfx_env_desc.bmod_branch =
+    -1 - bus).  Three shunts in steps next to switch actuators, one of them with a conductance; every step count from
+    0 to max_step occurs in the batch; rewards, observations and results against the environment oracle, which writes
+    the rounded steps into the net and rebuilds the case."""
+    import pandas as pd
+    from opfgym_amd import envs
+    from opfgym_amd.batched_env import BatchedOpfEnv
+    from oracle import env_oracle
+    from env_cases import reward_dict
+
+    class ShuntSteps(BatchedOpfEnv):
+        def __init__(self, **kw):
+            base = envs.NetworkReconfiguration(simbench_network_name='hv-small-sw', batch_size=1, defer_device=True)
+            net, profiles = base.definition.net, base.definition.profiles
+            buses = net.bus.index[[3, 7, 11]]
+            net['shunt'] = pd.DataFrame(dict(bus=buses, p_mw=[0.0, 0.5, 0.0], q_mvar=[-8.0, -5.0, 6.0],
+                                             vn_kv=net.bus.vn_kv.loc[buses].to_numpy(), step=[1, 0, 2],
+                                             max_step=[4, 3, 2], min_step=[0, 0, 0], in_service=True))
+            net.shunt['max_max_step'] = net.shunt.max_step
+            net.shunt['min_min_step'] = net.shunt.min_step
+            obs_keys = [('load', 'p_mw', net.load.index), ('res_bus', 'vm_pu', net.bus.index)]
+            act_keys = [('switch', 'closed', net.switch.index[net.switch.controllable.to_numpy(bool)]),
+                        ('shunt', 'step', net.shunt.index)]
+            BatchedOpfEnv.__init__(self, net, act_keys, obs_keys, profiles=profiles, **kw)
+    B = 24
+    if team:
+        monkeypatch.setenv('OPFX_TEAM', str(team))
+    env = ShuntSteps(batch_size=B, device='cuda:0', seed=3)
+    h = ShuntSteps(batch_size=1, defer_device=True, seed=3)
+    d = h.host_definition()
+    orc = env_oracle.EnvOracle(
+        d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
+        reward_dict(d['reward_function']), lambda net, dr: None,
+        autoscale_actions=h.autoscale_actions, diff_action_step_size=h.diff_action_step_size,
+        clipped_action_penalty=h.clipped_action_penalty, diff_objective=h.diff_objective,
+        add_mean_obs=h.add_mean_obs, pf_for_obs=h.pf_for_obs, steps_per_episode=h.steps_per_episode,
+        data=h.train_data, state_keys=h.state_keys, sampling_params=h.sampling_params,
+        bus_wise_obs=h.bus_wise_obs, multi_stage=False, split=(h.test_steps, h.validation_steps, h.train_steps))
+    assert [(b['branch'] < 0, len(b['table'])) for b in env.branch_state_columns][-3:] == [(True, 5)] * 3
+    rng = np.random.default_rng(5)
+    steps = rng.choice(env.train_steps, B)
+    actions = rng.random((B, env.n_actions))
+    actions[:5, -3:] = np.linspace(0.0, 1.0, 5)[:, None]           # every step count of every shunt
+    actions[:8, :-3] = 1.0                                          # (all switches closed there)
+    env.reset(options={'step': steps})
+    out = env.step(actions)
+    seen, n_ok = set(), 0
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        seen.add(tuple(int(v) for v in orc.net.shunt.step))
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+            n_ok += 1
+    assert n_ok >= B // 2 and len(seen) >= 8
+    assert {s[0] for s in seen} == {0, 1, 2, 3, 4}
+    # the shunts matter: the same rows with every shunt at step 0 see other voltages
+    a0 = actions.copy()
+    a0[:, -3:] = 0.0
+    obs_with = _np(out[0]).copy()                                   # (the outputs are views of persistent buffers)
+    env.reset(options={'step': steps})
+    out0 = env.step(a0)
+    assert np.abs(_np(out0[0])[1:8] - obs_with[1:8]).max() > 1e-4
 
 
 def test_vector_env_same_step_autoreset():

@@ -271,3 +271,45 @@ def test_reward_extension_points_are_honoured_on_the_host():
     rw.check_host_reward(Foreign())
     with pytest.raises(TypeError, match='calculate_cost'):
         rw.check_host_reward(object())
+
+
+def test_shunt_step_actuator_tables_are_the_case_builders_own_differences():
+    """('shunt', 'step') actuators (opf_env.py:476-481): the descriptor holds, per integer step, the DIFFERENCE of the bus's
+    shunt admittance to the compiled case as the last two entries of a modifier row named -1 - bus — computed by building
+    the case with that step, not by a formula of its own."""
+    import pandas as pd
+    from opfgym_amd import envs
+    from opfgym_amd.batched_env import BatchedOpfEnv
+    from opfgym_amd.case import net_to_case
+
+    class ShuntSteps(BatchedOpfEnv):
+        def __init__(self, **kw):
+            base = envs.NetworkReconfiguration(simbench_network_name='hv-small-sw', batch_size=1, defer_device=True)
+            net, profiles = base.definition.net, base.definition.profiles
+            buses = net.bus.index[[3, 7]]
+            net['shunt'] = pd.DataFrame(dict(bus=buses, p_mw=[0.0, 0.5], q_mvar=[-8.0, 6.0], vn_kv=net.bus.vn_kv.loc[buses].to_numpy() * [1.0, 1.1],
+                                             step=[1, 2], max_step=[4, 3], min_step=[0, 0], in_service=True))
+            BatchedOpfEnv.__init__(self, net, [('shunt', 'step', net.shunt.index)], [('load', 'p_mw', net.load.index)],
+                                   profiles=profiles, **kw)
+    h = ShuntSteps(batch_size=1, defer_device=True, seed=3)
+    assert h.n_actions == 2
+    bm = []
+    h._branch_state_column('shunt', 'step', h.net.shunt.index, h.store.rows('shunt', h.net.shunt.index), bm)
+    assert [b['lo'] for b in bm] == [0, 0] and [len(b['table']) for b in bm] == [5, 5]      # steps 0 .. max over the key
+    for r, b in enumerate(bm):
+        bus = -1 - b['branch']
+        assert bus == h.case.bus_lookup[int(h.net.shunt.bus.iloc[r])]
+        t = np.asarray(b['table'])
+        assert (t[:, :6] == 0).all() and (t[int(h.net.shunt.step.iloc[r])] == 0).all()       # compiled step: no change
+        for step in range(5):
+            net = h.net
+            saved = net.shunt['step'].copy()
+            net.shunt.loc[net.shunt.index[r], 'step'] = step
+            c = net_to_case(net)
+            net.shunt['step'] = saved
+            assert np.isclose(t[step, 6], c.gs[bus] - h.case.gs[bus], atol=1e-15) and np.isclose(t[step, 7], c.bs[bus] - h.case.bs[bus], atol=1e-15)
+    assert abs(bm[1]['table'][0][6]) > 0 and abs(bm[0]['table'][0][7]) > 0                   # (a conductance, a susceptance)
+    # a net without max_step cannot say how many steps there are
+    h.net.shunt.drop(columns=['max_step'], inplace=True)
+    with pytest.raises(ValueError, match='max_step'):
+        h._branch_state_column('shunt', 'step', h.net.shunt.index, h.store.rows('shunt', h.net.shunt.index), [])
