@@ -225,6 +225,24 @@ class NetworkReconfiguration(_Defined, BatchedOpfEnv):
                         args, kwargs)
 
 
+class SwitchedShunts(NetworkReconfiguration):
+    """No class of the reference: NetworkReconfiguration's definition on a grid that also carries three shunts in steps
+    (`simbench_build.add_switched_shunts`), which join the switches and tap changers as discrete actuators through an
+    `('shunt', 'step', idxs)` action key — the reference's generic `_apply_actions` rounds such set-points like tap
+    positions (opf_env.py:476-481).  A step count changes the bus's shunt admittance per instance
+    (opfx_env_desc.bmod_branch = -1 - bus)."""
+    PREPARE = 'add_switched_shunts'
+
+    def __init__(self, simbench_network_name='1-HV-urban--0-sw', controllable_switch_idxs=(1, 3), *args, **kwargs):
+        class_kwargs = dict(simbench_network_name=simbench_network_name,
+                            controllable_switch_idxs=np.array([int(v) for v in controllable_switch_idxs]))
+        sel, grid_seed, _ = split_kwargs(type(self), class_kwargs, kwargs)
+        defn = kwargs.get('definition') or definition.resolve(self.REFERENCE, sel, grid_seed=grid_seed, prepare=self.PREPARE)
+        if not any(u == 'shunt' for u, _, _ in defn.act_keys):
+            defn.act_keys = list(defn.act_keys) + [('shunt', 'step', np.asarray(defn.net.shunt.index))]
+        self._construct(BatchedOpfEnv, class_kwargs, args, dict(kwargs, definition=defn))
+
+
 class MixedContinuousDiscrete(_Defined, BatchedOpfEnv):
     """Stands for `opfgym.examples.mixed_continuous_discrete.MixedContinuousDiscrete`: reactive power of all sgens
     (continuous) and the transformer taps (discrete), slack voltage sampled per instance.  Its objective — a

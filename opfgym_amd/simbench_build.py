@@ -118,3 +118,18 @@ def get_simbench_time_observation(current_step, total_n_steps=24 * 4 * 366):
         out.append(np.sin(ang))
         out.append(np.cos(ang))
     return np.stack(out, axis=-1)
+
+
+def add_switched_shunts(net, profiles):
+    """Stand-in helper (no counterpart in the reference's grids): three shunts in steps — a capacitor bank, a bank with
+    losses and a reactor — at the 4th, 8th and 12th bus, with the limit columns an `('shunt', 'step')` action key needs
+    (`min_step` / `max_step` and their `min_min_` / `max_max_` twins, opf_env.py:439-446).  In place."""
+    import pandas as pd
+    buses = net.bus.index[[3, 7, 11]]
+    sh = pd.DataFrame(dict(bus=np.asarray(buses, dtype=np.int64), p_mw=[0.0, 0.5, 0.0], q_mvar=[-8.0, -5.0, 6.0],
+                           vn_kv=net.bus.vn_kv.loc[buses].to_numpy(float), step=[1, 0, 2], max_step=[4, 3, 2],
+                           min_step=[0, 0, 0], in_service=True))
+    sh['max_max_step'] = sh['max_step']
+    sh['min_min_step'] = sh['min_step']
+    net['shunt'] = sh
+    return net, profiles

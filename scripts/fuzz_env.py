@@ -2,7 +2,7 @@
 random combinations of the in-scope OpfEnv options on the small scenario grids, one reset
 and up to three steps each, every instance compared with the oracle on the same draws.
 
-    python scripts/fuzz_env.py [n_configs] [seed] [only_config]
+    python scripts/fuzz_env.py [n_configs] [seed] [only_config]        (OPFX_FUZZ_BASES=a,b: draw from these scenarios only)
 
 Prints one line per configuration and a summary; exits non-zero on the first mismatch."""
 import os
@@ -18,7 +18,7 @@ from env_cases import oracle_env, product_env  # noqa: E402
 R_TOL, V_TOL = 1e-6, 1e-7      # (both Newton solvers stop at ||F||inf < 1e-8 p.u.; north-star bar 1e-6 p.u.)
 REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
 BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
-         'sc_hv_small', 'reconf_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
+         'sc_hv_small', 'reconf_hv_small_sw', 'shunt_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
          'custom_constraint_lv', 'multistage_lv']
 
 
@@ -276,7 +276,9 @@ def run_mixed(env, orc, kw, rng, B):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # replay one configuration
+    only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].lstrip('-').isdigit() else None      # replay one configuration
+    if os.environ.get('OPFX_FUZZ_BASES'):                       # e.g. OPFX_FUZZ_BASES=shunt_hv_small_sw,reconf_hv_small_sw
+        BASES[:] = os.environ['OPFX_FUZZ_BASES'].split(',')
     total = bad = 0
     for c in range(n):
         if only is not None and c != only:

@@ -91,10 +91,33 @@ class RefScVoltageControl(opfgym.envs.VoltageControl, ref_sc.SecurityConstrained
             vc_mod.build_simbench_net = original
 
 
+class RefSwitchedShunts(ref_nr.NetworkReconfiguration):
+    """The reference's own NetworkReconfiguration on a grid with three shunts in steps, whose `('shunt', 'step')` key joins
+    its action keys: the grid helper is the product's (`simbench_build.add_switched_shunts`, a stand-in grid matter), the
+    key is appended to what the reference class hands to `OpfEnv.__init__` — no reference code is restated."""
+
+    def __init__(self, *args, **kwargs):
+        from opfgym_amd.simbench_build import add_switched_shunts
+        original, base_init = ref_nr.build_simbench_net, ref_opf_env.OpfEnv.__init__
+
+        def prepared(*a, **k):
+            net, profiles = original(*a, **k)
+            add_switched_shunts(net, profiles)
+            return net, profiles
+
+        def init_with_shunts(self_, net, act_keys, obs_keys, *a, **k):
+            return base_init(self_, net, list(act_keys) + [('shunt', 'step', net.shunt.index)], obs_keys, *a, **k)
+        ref_nr.build_simbench_net, ref_opf_env.OpfEnv.__init__ = prepared, init_with_shunts
+        try:
+            super().__init__(*args, **kwargs)
+        finally:
+            ref_nr.build_simbench_net, ref_opf_env.OpfEnv.__init__ = original, base_init
+
+
 REF = {'VoltageControl': opfgym.envs.VoltageControl, 'SecurityConstrainedVoltageControl': RefScVoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
        'SecurityConstrained': ref_sc_example.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
-       'NetworkReconfiguration': ref_nr.NetworkReconfiguration,
+       'NetworkReconfiguration': ref_nr.NetworkReconfiguration, 'SwitchedShunts': RefSwitchedShunts,
        'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete,
        'ConstraintSatisfaction': ref_cs.ConstraintSatisfaction, 'PartiallyObservable': ref_po.PartiallyObservable,
        'NonSimbenchNet': ref_ns.NonSimbenchNet, 'AddCustomConstraint': RefAddCustomConstraint}
@@ -253,7 +276,7 @@ def run(name):
         except KeyError:      # no res_switch / res_trafo.tap_pos in pandapower: only the table route works
             push('current_actions', env.get_current_actions(from_results_table=False))
         for tbl, col in (('sgen', 'q_mvar'), ('sgen', 'p_mw'), ('storage', 'q_mvar'), ('gen', 'p_mw'),
-                         ('switch', 'closed'), ('trafo', 'tap_pos')):
+                         ('switch', 'closed'), ('trafo', 'tap_pos'), ('shunt', 'step')):
             if tbl in env.net and len(env.net[tbl]) and col in env.net[tbl].columns:
                 push(f'post__{tbl}__{col}', np.array(env.net[tbl][col].to_numpy(dtype=float), copy=True))
     out = {k: np.stack(v) for k, v in rec.items()}

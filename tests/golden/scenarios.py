@@ -77,6 +77,9 @@ SCENARIOS.update({
     # (examples/network_reconfiguration.py; opf_env.py:476-481)
     'reconf_hv_small_sw': ('NetworkReconfiguration', dict(simbench_network_name='hv-small-sw',
                                                           controllable_switch_idxs=(1, 3)), 8, 21),
+    # the same plus three shunts in steps as actuators (('shunt', 'step'): rounded like tap positions, opf_env.py:476-481)
+    'shunt_hv_small_sw': ('SwitchedShunts', dict(simbench_network_name='hv-small-sw',
+                                                 controllable_switch_idxs=(1, 3)), 10, 43),
     # continuous + discrete actuators, objective_function seam, per-instance slack voltage
     # (examples/mixed_continuous_discrete.py)
     'mixed_lv': ('MixedContinuousDiscrete', dict(simbench_network_name='1-LV-rural1--0-sw'), 8, 22),
