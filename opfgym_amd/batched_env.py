@@ -246,14 +246,24 @@ _DISCRETE_KIND = {'closed': capi.ACT_BOOLEAN, 'in_service': capi.ACT_BOOLEAN,
                   'tap_pos': capi.ACT_INTEGER, 'step': capi.ACT_INTEGER}          # opf_env.py:476-481
 
 
-def _case_all_branches_in(net, act_keys):
+def _case_all_branches_in(net, act_keys, bus_bus_open=False):
     """The plan is compiled with every branch an actuator can switch present (closed / in
-    service); their per-instance state then only changes Ybus VALUES (opfx_env_desc.bmod_*)."""
+    service); their per-instance state then only changes Ybus VALUES (opfx_env_desc.bmod_*).
+    A bus-bus switch changes the bus SET instead: its state belongs to the plan (`_topology_variant`).  `bus_bus_open`: compile
+    with every bus-bus switch ACTUATOR open — the environment that owns the batch does, so that its result bank has a row
+    for every bus any topology can tell apart; a topology variant keeps the states of its net."""
     saved = []
     for unit, col, idxs in act_keys:
         if col in ('closed', 'in_service') and unit in ('switch', 'line', 'trafo') and len(idxs):
-            saved.append((unit, col, list(idxs), net[unit].loc[list(idxs), col].copy()))
-            net[unit].loc[list(idxs), col] = True
+            idxs = list(idxs)
+            if unit == 'switch':
+                bb = [i for i in idxs if net['switch'].at[i, 'et'] == 'b']
+                idxs = [i for i in idxs if net['switch'].at[i, 'et'] in ('l', 't')]
+                if bb and bus_bus_open:
+                    saved.append((unit, col, bb, net[unit].loc[bb, col].copy()))
+                    net[unit].loc[bb, col] = False
+            saved.append((unit, col, idxs, net[unit].loc[idxs, col].copy()))
+            net[unit].loc[idxs, col] = True
     try:
         return net_to_case(net)
     finally:
@@ -295,6 +305,12 @@ class BatchedOpfEnv:
                  contingency_start='base_case', init='flat', jacobian_reuse_tol=0.0, resample_failed_resets=True,
                  on_pivot_breakdown='ignore', **kwargs):
         from .objectives import QuadraticDeviation
+        # (the arguments as given: a bus-bus switch actuator needs twins of this environment on other topologies)
+        self._pre_init_attrs = {k: v for k, v in self.__dict__.items() if not k.startswith('_pre_init')}   # (what a subclass set before)
+        self._topology_fixed = bool(kwargs.pop('_topology_fixed', False))
+        self._ctor = {k: v for k, v in locals().items() if k not in ('self', 'net', 'kwargs', 'QuadraticDeviation', '__class__')}
+        self._ctor_kwargs = dict(kwargs)
+        self._bb_switches, self._topology_variants = [], {}
         # on_pivot_breakdown: the block LU pivots statically (fixed elimination order, the 2x2 diagonal block of a bus as its
         # pivot), pandapower's SuperLU partially.  'ignore' (default): a row whose factorisation broke down is a failed row
         # like any other (`converged` 0; `min_pivot` ~ 0 and `min_pivot_bus` say why).  'resolve': such rows — not
@@ -420,7 +436,7 @@ class BatchedOpfEnv:
         self.np_random = np.random.default_rng(seed)
 
         # ---- compile the grid --------------------------------------------------
-        self.case = _case_all_branches_in(net, self.act_keys)
+        self.case = _case_all_branches_in(net, self.act_keys, not self._topology_fixed)
         self.plan = capi.Plan(self.case)
         if self.init == 'auto':
             # (a case whose DC model is not finite — a zero-reactance branch — carries no B': 'auto' then stays flat)
@@ -638,7 +654,7 @@ class BatchedOpfEnv:
         self._sampling_ops(self.ops)
 
     # ------------------------------------------------------------------ compile
-    def _branch_state_column(self, unit, col, idxs, rows, bmod):
+    def _branch_state_column(self, unit, col, idxs, rows, bmod, a0=0):
         """Actuator columns that change Ybus values per instance: transformer tap
         positions (one stamp table row per integer position, computed by the case builder itself),
         line/trafo switches or in_service flags (stamps or nothing) and shunts in steps (the bus's
@@ -662,7 +678,7 @@ class BatchedOpfEnv:
             try:
                 for pos in range(lo, hi + 1):
                     df.loc[list(idxs), 'tap_pos'] = pos
-                    cp = _case_all_branches_in(net, self.act_keys)
+                    cp = _case_all_branches_in(net, self.act_keys, not self._topology_fixed)
                     assert cp.nbr == c.nbr
                     for r in rows:
                         tables[int(r)].append(_branch_stamps(cp, branch(KIND_TRAFO, r, 'trafo.tap_pos')))
@@ -672,12 +688,18 @@ class BatchedOpfEnv:
                 bmod.append(dict(branch=branch(KIND_TRAFO, r, 'trafo.tap_pos'), slot=slot0 + int(r), lo=lo,
                                  table=tables[int(r)]))
         elif col in ('closed', 'in_service') and unit in ('switch', 'line', 'trafo'):
-            for r in rows:
+            for j, r in enumerate(rows):
                 if unit == 'switch':
                     et, elem = net['switch']['et'].iloc[int(r)], int(net['switch']['element'].iloc[int(r)])
+                    if et == 'b':
+                        # a bus-bus switch FUSES two buses when closed: another bus set, another plan.  Its column is a plain
+                        # integer column of the store here; the instances of a step are routed, by the states of these
+                        # switches, to twins of this environment compiled on that topology (`_launch_step_by_topology`)
+                        self._bb_switches.append(dict(row=int(r), act=a0 + j, slot=slot0 + int(r),
+                                                      index=net['switch'].index[int(r)]))
+                        continue
                     if et not in ('l', 't'):
-                        raise NotImplementedError('bus-bus switches as actuators change the bus set of the '
-                                                  'compiled plan: not supported')
+                        raise NotImplementedError(f"switch.closed: element type '{et}' is not supported")
                     tbl = 'line' if et == 'l' else 'trafo'
                     kind, pos = (KIND_LINE if et == 'l' else KIND_TRAFO), st.rows(tbl, [elem])[0]
                     k = branch(kind, pos, 'switch.closed')
@@ -689,7 +711,7 @@ class BatchedOpfEnv:
                               for u, cl, ix in self.act_keys]
                     try:
                         net['switch'].at[sw_idx, 'closed'] = False
-                        cp = _case_all_branches_in(net, others)
+                        cp = _case_all_branches_in(net, others, not self._topology_fixed)
                     finally:
                         net['switch'].at[sw_idx, 'closed'] = saved
                     hit = [j for j, (kd, e) in enumerate(zip(cp.br_kind, cp.br_elem)) if (int(kd), int(e)) == (kind, int(pos))]
@@ -725,7 +747,7 @@ class BatchedOpfEnv:
                     for r in rows:
                         net['shunt']['step'] = saved                         # (one shunt at a time: buses may be fused)
                         net['shunt'].loc[df.index[int(r)], 'step'] = pos
-                        cp = _case_all_branches_in(net, self.act_keys)
+                        cp = _case_all_branches_in(net, self.act_keys, not self._topology_fixed)
                         i = buses[int(r)]
                         tables[int(r)].append([0.0] * 6 + [float(cp.gs[i] - c.gs[i]), float(cp.bs[i] - c.bs[i])])
             finally:
@@ -825,6 +847,7 @@ class BatchedOpfEnv:
         # ---- actions (opf_env.py:421-491) ------------------------------------------
         a_slot, a_sc, lo_s, hi_s, lo_c, hi_c = [], [], [], [], [], []
         a_kind, bmod = [], []
+        self._bb_switches = []
         cl_s, ch_s, cl_c, ch_c = [], [], [], []
         clamp = (not self.autoscale_actions) or bool(self.diff_action_step_size)
         for unit, col, idxs in self.act_keys:
@@ -834,7 +857,7 @@ class BatchedOpfEnv:
             rows = st.rows(unit, idxs)
             a_kind += [_DISCRETE_KIND.get(col, capi.ACT_CONTINUOUS)] * len(rows)
             if col in _DISCRETE_KIND:
-                self._branch_state_column(unit, col, idxs, rows, bmod)
+                self._branch_state_column(unit, col, idxs, rows, bmod, a0=len(a_slot))
             a_slot += (st.slot(unit, col) + rows).tolist()
             a_sc += (df['scaling'].to_numpy(float)[rows] if 'scaling' in df.columns
                      else np.ones(len(rows))).tolist()
@@ -848,6 +871,24 @@ class BatchedOpfEnv:
                 else:
                     ss += [-2] * len(rows); cc += [0.0] * len(rows)
         na = len(a_slot)
+        if self._bb_switches:
+            # what `_apply_actions` needs for the bus-bus switch columns alone (their state decides the topology BEFORE the
+            # launch): range and clamp limits, constants of the switch table (opf_env.py:439-470)
+            cols = [sw['act'] for sw in self._bb_switches]
+            if any(lo_s[c] >= 0 or hi_s[c] >= 0 or cl_s[c] >= 0 or ch_s[c] >= 0 for c in cols):
+                raise NotImplementedError('bus-bus switch actuators with sampled (per-instance) limits')
+            nan = float('nan')
+            self._bb_act = dict(cols=cols, slots=[sw['slot'] for sw in self._bb_switches],
+                                lo=[lo_c[c] for c in cols], hi=[hi_c[c] for c in cols], sc=[a_sc[c] for c in cols],
+                                cl=[cl_c[c] if cl_s[c] == -1 else nan for c in cols],
+                                ch=[ch_c[c] if ch_s[c] == -1 else nan for c in cols])
+            if len(cols) > 6:
+                raise NotImplementedError(f'{len(cols)} bus-bus switch actuators: up to 6 (64 topologies) are supported')
+            if not self._topology_fixed:
+                if self.on_pivot_breakdown == 'resolve':
+                    raise NotImplementedError("on_pivot_breakdown='resolve' together with bus-bus switch actuators")
+                if self.host_mode and self.n_minus_one_keys:
+                    raise NotImplementedError('host callables under N-1 keys together with bus-bus switch actuators')
         # ---- bus injections (makeSbus) -----------------------------------------------
         plist = [[] for _ in range(nb)]
         qlist = [[] for _ in range(nb)]
@@ -1043,6 +1084,9 @@ class BatchedOpfEnv:
             d.bmod_ptr = _keep(keep, ptr[:-1], 'i')
             d.bmod_y = _keep(keep, np.concatenate([np.asarray(b['table'], float).ravel() for b in bmod]), 'd')
         self.branch_state_columns = bmod
+        for var in getattr(self, '_topology_variants', {}).values():
+            var.close()
+        self._topology_variants = {}
         if getattr(self, '_env_handle_base_only', None) is not None:
             capi.lib().opfx_env_destroy(self._env_handle_base_only)
             self._env_handle_base_only = None
@@ -1165,6 +1209,8 @@ class BatchedOpfEnv:
         self.power_flow_available = mode in (0, 1, 4, 5)
         self._objective_is_diff = bool(with_initial_obj)
         self._last_host = None
+        if self._bb_switches and not self._topology_fixed and mode in (0, 1, 4, 5):
+            return self._launch_step_by_topology(action, mode, with_initial_obj)
         io = self._io(action, with_initial_obj)
         resolve = self.on_pivot_breakdown == 'resolve' and mode in (0, 1, 4, 5)
         # (incremental actions are applied to the row in place: the rescue starts from the row as it was)
@@ -1174,6 +1220,128 @@ class BatchedOpfEnv:
                                             mode, capi._stream()), 'opfx_step')
         if resolve:
             self._rescue_pivot_breakdown(action, mode, with_initial_obj, x_before)
+
+    # ---- bus-bus switches as actuators: one plan per topology -----------------------------------------------------------
+    def _bb_states_after(self, action, mode):
+        """[B, n] states (0 / 1) of the bus-bus switch actuators AFTER this launch has applied `action` — opf_env.py:429-481
+        for those columns alone, because the topology must be known before the launch: clip, absolute or incremental
+        set-point, clamp, scaling, rounding.  mode 1 applies no action: the states in the store."""
+        t, d = self.torch, self._bb_act
+        as_d = lambda v: t.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
+        prev = self.x[:, t.as_tensor(d['slots'], device=self.device)]
+        if mode == 1 or action is None:
+            return t.round(prev).to(t.int64)
+        a = action[:, t.as_tensor(d['cols'], device=self.device)].clamp(0.0, 1.0)          # :429
+        lo, hi, sc = as_d(d['lo']), as_d(d['hi']), as_d(d['sc'])
+        incremental = bool(self.diff_action_step_size) and mode == 0
+        if incremental:
+            sp = (a * 2 - 1) * self.diff_action_step_size * (hi - lo) + prev * sc        # :452-458
+        else:
+            sp = a * (hi - lo) + lo                                                      # :461
+        if (not self.autoscale_actions) or incremental:                                  # :464-470
+            cl, ch = as_d(d['cl']), as_d(d['ch'])
+            sp = t.where(t.isnan(ch), sp, t.minimum(sp, ch))
+            sp = t.where(t.isnan(cl), sp, t.maximum(sp, cl))
+        return t.round(sp / sc).clamp(0, 1).to(t.int64)                                  # :472-478
+
+    def _topology_variant(self, states):
+        """The twin of this environment on the topology `states` (one 0 / 1 per bus-bus switch actuator): the same net with
+        those switches set, compiled to its own case, plan and descriptor; in it the switch columns are plain columns.
+        Built on first use and kept."""
+        key = tuple(int(v) for v in states)
+        if key not in self._topology_variants:
+            net = copy.deepcopy(self.net)
+            for sw, v in zip(self._bb_switches, key):
+                net['switch'].at[sw['index'], 'closed'] = bool(v)
+            kw = dict(self._ctor)
+            kw.update(self._ctor_kwargs)
+            kw.update(batch_size=1, device=self.device_spec, defer_device=False, seed=None, _topology_fixed=True,
+                      reward_function=self.reward_function if self.reward_function is not None else kw['reward_function'],
+                      state_keys=self.state_keys, on_pivot_breakdown='ignore', copy_outputs=False)
+            action_keys, observation_keys = kw.pop('action_keys'), kw.pop('observation_keys')
+            var = type(self).__new__(type(self))                  # (the same class: its `_sampling_ops` decides the row layout)
+            var.__dict__.update(self._pre_init_attrs)
+            BatchedOpfEnv.__init__(var, net, action_keys, observation_keys, **kw)
+            if var.store.n != self.store.n or var.n_obs_raw != self.n_obs_raw or var.n_constraints != self.n_constraints:
+                raise RuntimeError('a topology variant laid its rows out differently from its parent')
+            var._results_from = self._results_map(var)
+            self._topology_variants[key] = var
+        return self._topology_variants[key]
+
+    def _results_map(self, var):
+        """(positions in this environment's result bank, positions in the variant's) of the same physical quantities:
+        bus voltages and angles through the net's bus numbers (a fused bus serves both of its net buses), branch
+        loadings through the net elements, slack powers through the ext_grids; derived rows by position."""
+        c, v = self.case, var.case
+        nb, nbv = c.nb, v.nb
+        mine, theirs = [], []
+        inv = {}
+        for net_bus, i in c.bus_lookup.items():
+            inv.setdefault(i, net_bus)
+        for i in range(nb):
+            j = v.bus_lookup.get(inv[i], -1) if i in inv else -1
+            if j >= 0:
+                for off_m, off_v in ((0, 0), (nb, nbv)):
+                    mine.append(off_m + i); theirs.append(off_v + j)
+        vbr = {(int(k), int(e)): n for n, (k, e) in enumerate(zip(v.br_kind, v.br_elem))}
+        for n, (k, e) in enumerate(zip(c.br_kind, c.br_elem)):
+            if (int(k), int(e)) in vbr:
+                mine.append(2 * nb + n); theirs.append(2 * nbv + vbr[(int(k), int(e))])
+        ref_m, ref_v = np.flatnonzero(c.bus_type == REF), np.flatnonzero(v.bus_type == REF)
+        for r, i in enumerate(ref_m):
+            j = v.bus_lookup.get(inv.get(int(i), -1), -1)
+            hit = np.flatnonzero(ref_v == j)
+            if len(hit):
+                for q in range(2):
+                    mine.append(2 * nb + c.nbr + q * len(ref_m) + r); theirs.append(2 * nbv + v.nbr + q * len(ref_v) + int(hit[0]))
+        base_m, base_v = 2 * nb + c.nbr + 2 * len(ref_m), 2 * nbv + v.nbr + 2 * len(ref_v)
+        for i in range(nb):                                               # (reactive power of the generators per bus)
+            j = v.bus_lookup.get(inv[i], -1) if i in inv else -1
+            if j >= 0:
+                mine.append(base_m + i); theirs.append(base_v + j)
+        for k in range(min(len(self._xres), len(var._xres))):             # (derived rows: allocated in the same order)
+            mine.append(base_m + nb + k); theirs.append(base_v + nbv + k)
+        t = self.torch
+        return (t.as_tensor(mine, dtype=t.int64, device=self.device), t.as_tensor(theirs, dtype=t.int64, device=self.device))
+
+    def _launch_step_by_topology(self, action, mode, with_initial_obj):
+        """One step for a batch whose instances sit on different topologies (bus-bus switch actuators): the rows are
+        grouped by the switch states the action leaves them in, every group is stepped by the twin compiled for that
+        topology (its rows gathered into a compact batch, as the pivot rescue does) and scattered back.  One host
+        synchronisation per step (which topologies occur) and one launch per topology that occurs."""
+        t, b = self.torch, self.buf
+        states = self._bb_states_after(action, mode)
+        weights = t.as_tensor([1 << k for k in range(states.shape[1])], dtype=t.int64, device=self.device)
+        codes = (states * weights).sum(dim=1)
+        for code in t.unique(codes).cpu().tolist():
+            idx = (codes == code).nonzero().flatten()
+            var = self._topology_variant([(code >> k) & 1 for k in range(states.shape[1])])
+            n = int(idx.numel())
+            x2 = self.x[idx].contiguous()
+            tmp = {name: buf[idx].contiguous() for name, buf in b.items() if name != 'results'}
+            tmp['results'] = t.full((n, var.n_results), float('nan'), dtype=t.float64, device=self.device)
+            io = capi.StepIO()
+            io.x = x2.data_ptr()
+            act2 = action[idx].contiguous() if action is not None else None
+            io.action = act2.data_ptr() if act2 is not None else None
+            init2 = self.initial_obj[idx].contiguous() if with_initial_obj else None
+            io.initial_obj = init2.data_ptr() if init2 is not None else None
+            cnt2 = self.step_count[idx].contiguous() if self.steps_per_episode != 1 else None
+            io.step_in_episode = cnt2.data_ptr() if cnt2 is not None else None
+            io.outage = None
+            for name, buf in tmp.items():
+                setattr(io, name, buf.data_ptr())
+            with t.cuda.device(self.device):
+                capi.check(capi.lib().opfx_step(var._env_handle, n, C.byref(io), C.byref(self.solve_opts), mode,
+                                                capi._stream()), 'opfx_step (topology variant)')
+            self.x[idx] = x2
+            for name, buf in tmp.items():
+                if name != 'results':
+                    b[name][idx] = buf
+            mine, theirs = var._results_from
+            rows = t.full((n, self.n_results), float('nan'), dtype=t.float64, device=self.device)
+            rows[:, mine] = tmp['results'][:, theirs]
+            b['results'][idx] = rows
 
     def contingency_results(self, branch):
         """Result bank [B, n_results] and convergence flags [B] of the CURRENT set-points with case branch `branch` out of
@@ -1618,6 +1786,9 @@ class BatchedOpfEnv:
         for _, _, h in getattr(self, '_rescue_envs', {}).values():
             capi.lib().opfx_env_destroy(h)
         self._rescue_envs = {}
+        for var in getattr(self, '_topology_variants', {}).values():
+            var.close()
+        self._topology_variants = {}
         if getattr(self, '_env_handle_base_only', None) is not None:
             capi.lib().opfx_env_destroy(self._env_handle_base_only)
             self._env_handle_base_only = None

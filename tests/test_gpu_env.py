@@ -951,6 +951,96 @@ def test_shunt_steps_as_actuators(team, monkeypatch):
     assert np.abs(_np(out0[0])[1:8] - obs_with[1:8]).max() > 1e-4
 
 
+def _split_busbars(net, buses):
+    """Substation buses become two busbars with a coupler — a bus-bus switch — between them; every second line end
+    moves to the new bar.  Closed coupler: the grid as it was; open: the two bars hang together through the rest of the
+    meshed grid only."""
+    from opfgym_amd import net as ppn
+    couplers = []
+    for b in buses:
+        ends = [(i, 'from_bus') for i in net.line.index[net.line.from_bus == b]] + \
+               [(i, 'to_bus') for i in net.line.index[net.line.to_bus == b]]
+        assert len(ends) >= 4
+        new = ppn.create_bus(net, vn_kv=float(net.bus.vn_kv.at[b]))
+        for c in net.bus.columns:
+            if c != 'name':
+                net.bus.at[new, c] = net.bus.at[b, c]
+        for i, side in ends[1::2]:
+            net.line.at[i, side] = new
+        couplers.append(ppn.create_switch(net, int(b), int(new), 'b', closed=True))
+    return couplers
+
+
+@pytest.mark.parametrize('diff_step', [None, 0.6])
+def test_bus_bus_switches_as_actuators(diff_step):
+    """A closed bus-bus switch FUSES two buses: another unknown set, which one plan cannot express per instance.  The
+    environment keeps one twin per topology that occurs (`_topology_variant`: same net, those switches set, own case /
+    plan / descriptor) and routes the rows of a step by the switch states the action leaves them in
+    (`_launch_step_by_topology`).  Two busbar couplers next to line switches and tap changers; all four topologies occur
+    in the batch; every row against the environment oracle, which writes the states into the net and rebuilds the case.
+    (diff_step: incremental actions — the states then depend on the row's previous state.)"""
+    from opfgym_amd import envs
+    from opfgym_amd.batched_env import BatchedOpfEnv
+    from oracle import env_oracle
+    from env_cases import reward_dict
+
+    class Couplers(BatchedOpfEnv):
+        def __init__(self, **kw):
+            base = envs.NetworkReconfiguration(simbench_network_name='hv-small-sw', batch_size=1, defer_device=True)
+            net, profiles = base.definition.net, base.definition.profiles
+            couplers = _split_busbars(net, [7, 11])
+            for col, v in (('controllable', True), ('min_closed', 0), ('max_closed', 1), ('min_min_closed', 0), ('max_max_closed', 1)):
+                net.switch.loc[couplers, col] = v
+            obs_keys = [('load', 'p_mw', net.load.index), ('res_bus', 'vm_pu', net.bus.index)]
+            act_keys = [('switch', 'closed', net.switch.index[net.switch.controllable.to_numpy(bool)]),
+                        ('trafo', 'tap_pos', net.trafo.index)]
+            BatchedOpfEnv.__init__(self, net, act_keys, obs_keys, profiles=profiles, **kw)
+    B = 24
+    kw = dict(diff_action_step_size=diff_step, steps_per_episode=2) if diff_step else {}
+    env = Couplers(batch_size=B, device='cuda:0', seed=3, **kw)
+    h = Couplers(batch_size=1, defer_device=True, seed=3, **kw)
+    assert len(env._bb_switches) == 2 and env.n_actions == len(h.net.trafo) + 4
+    d = h.host_definition()
+    orc = env_oracle.EnvOracle(
+        d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
+        reward_dict(d['reward_function']), lambda net, dr: None,
+        autoscale_actions=h.autoscale_actions, diff_action_step_size=h.diff_action_step_size,
+        clipped_action_penalty=h.clipped_action_penalty, diff_objective=h.diff_objective,
+        add_mean_obs=h.add_mean_obs, pf_for_obs=h.pf_for_obs, steps_per_episode=h.steps_per_episode,
+        data=h.train_data, state_keys=h.state_keys, sampling_params=h.sampling_params,
+        bus_wise_obs=h.bus_wise_obs, multi_stage=False, split=(h.test_steps, h.validation_steps, h.train_steps))
+    rng = np.random.default_rng(5)
+    steps = rng.choice(env.train_steps, B)
+    actions = rng.random((B, env.n_actions))
+    bb = [sw['act'] for sw in env._bb_switches]
+    for k in range(8):                                              # every combination of the two couplers, twice
+        actions[k, bb] = [0.9 * (k & 1) + 0.05, 0.9 * ((k >> 1) & 1) + 0.05]
+    obs0, _ = env.reset(options={'step': steps})                    # (the centre action: every switch open, np.round(0.5) = 0)
+    obs0 = _np(obs0).copy()
+    out = env.step(actions)
+    seen, n_ok = set(), 0
+    for k in range(B):
+        ref0 = orc.reset(int(steps[k]))
+        assert np.allclose(obs0[k], ref0, rtol=0, atol=R_TOL, equal_nan=True)
+        ref = orc.step(actions[k])
+        seen.add(tuple(bool(v) for v in orc.net.switch.closed.loc[[sw['index'] for sw in env._bb_switches]]))
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+            n_ok += 1
+    assert n_ok >= B // 2 and len(seen) == 4 and len(env._topology_variants) >= 4
+    if diff_step:                                                   # the second step of the episode starts from the switch states of the first
+        a2 = rng.random((B, env.n_actions))
+        out2 = env.step(a2)
+        for k in range(0, B, 3):
+            orc.reset(int(steps[k]))
+            orc.step(actions[k])
+            ref = orc.step(a2[k])
+            if ref['converged'] and bool(_np(out2[4]['converged'])[k]):
+                _check_step(env, out2, dict(ref, obs_step=ref['obs']), k)
+    env.close()
+
+
 def test_vector_env_same_step_autoreset():
     """OpfVectorEnv: gymnasium.vector-shaped face of a batched env; single-step episodes end on
     every step, 'same_step' autoreset hands back the first observation of the next episode and
