@@ -557,9 +557,10 @@ def main():
     ms = capi.C.c_float()
     reps = max(5, min(args.steps, 50))
     with torch.cuda.device(device):
-        capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io),
-                                              capi.C.byref(env.solve_opts), reps,
-                                              capi._stream(), capi.C.byref(ms)), 'opfx_time_steps')
+        for _ in range(2):                     # (the first pass brings the clocks back up after the host-side work above)
+            capi.check(capi.lib().opfx_time_steps(env._env_handle, B, capi.C.byref(io),
+                                                  capi.C.byref(env.solve_opts), reps,
+                                                  capi._stream(), capi.C.byref(ms)), 'opfx_time_steps')
     kernel_ms_helper = ms.value / reps
 
     # the cycle of a single-step benchmark environment: reset (device-side sampling) + step
