@@ -243,6 +243,14 @@ class SwitchedShunts(NetworkReconfiguration):
         self._construct(BatchedOpfEnv, class_kwargs, args, dict(kwargs, definition=defn))
 
 
+class BusbarCouplers(NetworkReconfiguration):
+    """No class of the reference: its NetworkReconfiguration on a grid whose substation buses 7 and 11 are split into two
+    busbars with a coupler each (`simbench_build.split_busbars`) — BUS-BUS switches, which `controllable_switch_idxs` may
+    name like any other switch (examples/network_reconfiguration.py:34-35).  A closed coupler fuses two buses: the batch is
+    routed over one compiled twin of the environment per topology that occurs (`BatchedOpfEnv._topology_variant`)."""
+    PREPARE = 'split_busbars'
+
+
 class MixedContinuousDiscrete(_Defined, BatchedOpfEnv):
     """Stands for `opfgym.examples.mixed_continuous_discrete.MixedContinuousDiscrete`: reactive power of all sgens
     (continuous) and the transformer taps (discrete), slack voltage sampled per instance.  Its objective — a

@@ -133,3 +133,23 @@ def add_switched_shunts(net, profiles):
     sh['min_min_step'] = sh['min_step']
     net['shunt'] = sh
     return net, profiles
+
+
+def split_busbars(net, profiles, buses=(7, 11)):
+    """Stand-in helper (the synthetic grids have single busbars): the given substation buses become two busbars with a
+    COUPLER — a closed bus-bus switch — between them; every second line end moves to the new bar.  Coupler closed: the grid
+    as it was; open: the two bars hang together through the rest of the meshed grid only.  The couplers are the last rows of
+    the switch table.  In place."""
+    from . import net as ppn
+    for b in buses:
+        ends = [(i, 'from_bus') for i in net.line.index[net.line.from_bus == b]] + \
+               [(i, 'to_bus') for i in net.line.index[net.line.to_bus == b]]
+        assert len(ends) >= 4, f'bus {b}: a busbar split needs at least four line ends'
+        new = ppn.create_bus(net, vn_kv=float(net.bus.vn_kv.at[b]))
+        for c in net.bus.columns:
+            if c != 'name':
+                net.bus.at[new, c] = net.bus.at[b, c]
+        for i, side in ends[1::2]:
+            net.line.at[i, side] = new
+        ppn.create_switch(net, int(b), int(new), 'b', closed=True)
+    return net, profiles

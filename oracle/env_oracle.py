@@ -177,7 +177,7 @@ TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
          'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding,
          'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None,
-         'SwitchedShunts': lambda net, d: None,
+         'SwitchedShunts': lambda net, d: None, 'BusbarCouplers': lambda net, d: None,
          'MixedContinuousDiscrete': tail_mixed_continuous_discrete,
          'ConstraintSatisfaction': lambda net, d: None, 'PartiallyObservable': lambda net, d: None,
          'NonSimbenchNet': lambda net, d: None, 'AddCustomConstraint': tail_custom_constraint}

@@ -91,6 +91,25 @@ class RefScVoltageControl(opfgym.envs.VoltageControl, ref_sc.SecurityConstrained
             vc_mod.build_simbench_net = original
 
 
+class RefBusbarCouplers(ref_nr.NetworkReconfiguration):
+    """The reference's own NetworkReconfiguration, unchanged, on a grid with two busbar couplers (the product's stand-in
+    grid helper `simbench_build.split_busbars`); which switches are controllable is its own constructor argument."""
+
+    def __init__(self, *args, **kwargs):
+        from opfgym_amd.simbench_build import split_busbars
+        original = ref_nr.build_simbench_net
+
+        def prepared(*a, **k):
+            net, profiles = original(*a, **k)
+            split_busbars(net, profiles)
+            return net, profiles
+        ref_nr.build_simbench_net = prepared
+        try:
+            super().__init__(*args, **kwargs)
+        finally:
+            ref_nr.build_simbench_net = original
+
+
 class RefSwitchedShunts(ref_nr.NetworkReconfiguration):
     """The reference's own NetworkReconfiguration on a grid with three shunts in steps, whose `('shunt', 'step')` key joins
     its action keys: the grid helper is the product's (`simbench_build.add_switched_shunts`, a stand-in grid matter), the
@@ -118,6 +137,7 @@ REF = {'VoltageControl': opfgym.envs.VoltageControl, 'SecurityConstrainedVoltage
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
        'SecurityConstrained': ref_sc_example.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
        'NetworkReconfiguration': ref_nr.NetworkReconfiguration, 'SwitchedShunts': RefSwitchedShunts,
+       'BusbarCouplers': RefBusbarCouplers,
        'MixedContinuousDiscrete': ref_mcd.MixedContinuousDiscrete,
        'ConstraintSatisfaction': ref_cs.ConstraintSatisfaction, 'PartiallyObservable': ref_po.PartiallyObservable,
        'NonSimbenchNet': ref_ns.NonSimbenchNet, 'AddCustomConstraint': RefAddCustomConstraint}

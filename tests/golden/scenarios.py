@@ -78,6 +78,9 @@ SCENARIOS.update({
     'reconf_hv_small_sw': ('NetworkReconfiguration', dict(simbench_network_name='hv-small-sw',
                                                           controllable_switch_idxs=(1, 3)), 8, 21),
     # the same plus three shunts in steps as actuators (('shunt', 'step'): rounded like tap positions, opf_env.py:476-481)
+    # two busbar couplers (bus-bus switches 44, 45 of the prepared grid) among the controllable switches: four topologies
+    'busbar_hv_small_sw': ('BusbarCouplers', dict(simbench_network_name='hv-small-sw',
+                                                  controllable_switch_idxs=(1, 3, 44, 45)), 12, 44),
     'shunt_hv_small_sw': ('SwitchedShunts', dict(simbench_network_name='hv-small-sw',
                                                  controllable_switch_idxs=(1, 3)), 10, 43),
     # continuous + discrete actuators, objective_function seam, per-instance slack voltage
