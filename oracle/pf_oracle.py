@@ -22,17 +22,35 @@ flows; reactive dispatch split among generators sharing a bus in proportion to
 their ranges) and pandapower's result definitions (`i_ka`, `loading_percent`
 of lines and transformers with `trafo_loading='current'`).
 
-PARITY UNPINNED against pandapower: the reference's own tests hold no
-numerical power-flow result at all, and pandapower cannot be run
-here.  This oracle is pinned instead by (tests/test_oracle_pf.py):
+PARITY against pandapower: pinned by PUBLISHED pandapower numbers, not by a pandapower run.  The
+reference's own tests hold no numerical power-flow result at all and pandapower cannot
+be run here, so `fixtures/` (exports written by scripts/export_pandapower_case.py wherever pandapower
+exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pandapower_published.py):
+  * constants pandapower itself publishes [3P, from memory, kept only where every digit reproduced —
+    tests/pandapower_published.py]: the documentation's minimal example (res_bus / res_ext_grid to the six
+    printed decimals) and six networks of pandapower's own test/loadflow/test_results.py ("result
+    values from powerfactory", asserted there and here at 1e-6 p.u. / 1e-3 % / 1e-6 kA):
+      element formula                                            exercised by
+      line pi-model, parallel, df, loading_percent / i_ka        tests_line, tests_load_sgen
+      line open at one end (auxiliary bus), line out of service  tests_line
+      load / sgen injections, unit in_service mask               tests_load_sgen
+      2w transformer from vk/vkr/pfe/i0 (T-model), lv cable      docs_minimal_example
+      2w transformer tap (hv), parallel, open at one side,       tests_trafo (hv bus voltage and loading only)
+        loading_percent with trafo_loading='current'
+      3w transformer star equivalent, hv tap, loading            tests_trafo3w
+      PV bus, generator reactive dispatch                        tests_gen
+      enforce_q_lims (PV -> PQ at the limit)                     tests_enforce_qlims
+      slack P/Q (res_ext_grid)                                   docs_minimal_example
+    NOT exercised by any pandapower-originated number: the `_is_elements` zero rule of result rows,
+    bus-bus switch fusing, shunts, storages, several ext_grids, tap on the lv side, tap_phase_shifter,
+    the vector-group phase shift (calculate_voltage_angles on grids above 70 kV), DC start values,
+    lines with g_us_per_km, transformer df.
   * the closed-form two-bus solution,
   * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
     (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to
-    0.001 degree, slack generation and losses to 0.01 MW), Grainger & Stevenson 4-bus, Wood &
-    Wollenberg 6-bus,
-  * algebraic self-checks (mismatch < tol, power balance = losses),
-  * `fixtures/*.npz` written by scripts/export_pandapower_case.py wherever pandapower exists
-    (none can be produced in this container: the test skips while the directory is empty).
+    0.001 degree, slack generation and losses to 0.01 MW), IEEE 30-bus, Grainger & Stevenson 4-bus,
+    Wood & Wollenberg 6-bus, Stagg & El-Abiad 5-bus,
+  * algebraic self-checks (mismatch < tol, power balance = losses).
 """
 from __future__ import annotations
 
