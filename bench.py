@@ -287,16 +287,18 @@ def percentile(v, q):
     return float(np.percentile(np.asarray(v, float), q))
 
 
-def timed_windows(one_step, steps, windows, world, device, flush=None):
+def timed_windows(one_step, steps, windows, world, device, flush=None, collective=None):
     """`windows` timed regions of exactly `steps` steps each, every one bracketed by a barrier + synchronize on both sides,
     the elapsed time of a window = max over ranks; HIP events on the launch stream around the same regions.  Returns
     (wall seconds per window, device milliseconds per window, the last step's info, what `flush` returned last)."""
     import torch
     import torch.distributed as dist
     wall, dev_ms, info, tail = [], [], None, None
+    if collective is None:                     # (a forced world of one runs the barrier and the max-reduce for real)
+        collective = world > 1
     for _ in range(windows):
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -307,10 +309,10 @@ def timed_windows(one_step, steps, windows, world, device, flush=None):
         if flush is not None:                  # (the last step's gather belongs to the timed region)
             tail = flush()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if collective:
             tt = torch.tensor([el], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -334,7 +336,13 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     # ---- what the committed rocprofv3 passes of this configuration measured (profiles/pmc_latest.json) ----
     pm = measured_counters(config, B)
     stale = bool(pm) and pm.get('source_sha16') != source_sha16()
-    if stale:                                  # counters of another state of the sources: not mixed into this line
+    # the instantiation that ran: the DC start and the chord steps are kernels of their own (other register counts,
+    # other occupancy) — the committed counters are those of the plain one and are not mixed into their lines
+    # (opfx.hip do_step: the DC start wins over chord steps; the configurations of this bench all run LDS-resident)
+    dc = env.init == 'dc'
+    chord = env.jacobian_reuse_tol > 0.0 and not dc
+    other_kernel = bool(pm) and (dc or chord)
+    if stale or other_kernel:                  # counters of another state of the sources / of another kernel
         pm = {}
     sq = pm.get('sq', {})
     traffic, traffic_raw = pm.get('hbm_bytes_per_launch_fetch_x2'), pm.get('hbm_bytes_per_launch_raw')
@@ -370,7 +378,7 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     # the binding resource: the largest fraction of its own peak (none of them can exceed 1)
     cand = {k: v['frac'] for k, v in fr.items() if k != 'fp64_useful_of_valu_busy'}
     bound = max(cand, key=cand.get)
-    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}>'
+    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + '>'
     # what the launch really has to read and write: the instance rows of the caller's buffers
     buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
                  'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
@@ -391,7 +399,7 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
                               'compulsory_io_bytes_per_launch': bm['io_bytes'] * B},
         'buffer_io_bytes_per_launch': buffer_io,
         'counters_from': pm.get('tag'), 'counters_source_sha16': pm.get('source_sha16'), 'source_sha16': source_sha16(),
-        'counters_dropped_as_stale': stale,
+        'counters_dropped_as_stale': stale, 'counters_dropped_as_other_kernel': other_kernel,
         'hbm_target_note': 'north_star asks for >= 40 % of the HBM roofline: structurally n/a for this design — the Newton '
                            'state is LDS-resident, HBM carries inputs + outputs only (hbm_measured_frac); the binding '
                            'resource and its fraction are what `bound` / `frac` report',
@@ -404,14 +412,15 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     return roof, bm, lm, ki, n_cu, n_simd
 
 
-def also_config(config, device, steps, warmup):
-    """One of the other BASELINE configurations, measured briefly on this GPU after the headline: the
-    driver's one line then carries all five."""
+def also_config(config, device, steps, warmup, **env_kw):
+    """One of the BASELINE configurations, measured briefly on this GPU after the headline: the
+    driver's one line then carries all five.  `env_kw`: environment settings on top of the configuration's (the
+    `reference_settings` block passes reference_faithful=True)."""
     import torch
     from opfgym_amd import envs
     cls_name, kw, B, scaling, _ = CONFIGS[config]
     t_build = time.perf_counter()
-    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=0, **kw)
+    env = getattr(envs, cls_name)(batch_size=B, device=device, seed=0, **kw, **env_kw)
     rng = np.random.default_rng(1234)
     opts = {'step': rng.choice(env.train_steps, B)}
     if env.n_uniform:
@@ -432,6 +441,7 @@ def also_config(config, device, steps, warmup):
                        f'{solves_per_step} NR solve(s) per step',
            'value': B * steps / wall[0], 'unit': 'env.step()/s', 'steps': steps, 'warmup': warmup,
            'ms_per_step': wall[0] / steps * 1e3, 'kernel_ms': kernel_ms, 'kernel': roof['kernel'],
+           'newton_start': env.init, 'contingency_start': 'flat' if env.solve_opts.contingency_start else 'base_case',
            'nr_solves_per_s': B * solves_per_step * steps / wall[0],
            'converged_fraction': float(info['converged'].double().mean().item()),
            'mean_nr_iterations': float(info['iterations'].double().mean().item()),
@@ -488,7 +498,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     cls_name, kw, batch_cfg, scaling, _ = CONFIGS[args.config]
-    gather_mode = args.gather or ('reward' if world > 1 else 'none')
+    # the collectives run when there is more than one rank — or when a single rank is told to execute them anyway
+    # (OPFX_FORCE_COLLECTIVE=1 under torchrun: the RCCL path on a one-GPU box, tests/test_gpu_bench.py)
+    collective = dist.is_initialized() and (world > 1 or odist.force_collective())
+    gather_mode = args.gather or ('reward' if collective else 'none')
     seed_rank = rank if args.as_rank is None else args.as_rank
     # --batch N: N instances per GPU (weak scaling), whatever the configuration; without it the configuration's own batch —
     # per GPU for the weak ones, as a TOTAL sharded over the ranks for the strong ones (whole instances per rank; a world
@@ -522,7 +535,7 @@ def main():
 
     def one_step():
         obs, reward, term, trunc, info = env.step(actions)
-        if world > 1 and gather:
+        if collective and gather:
             g_reward.submit(reward)
             if 'obs' in gather:
                 g_obs.submit(obs)
@@ -539,7 +552,13 @@ def main():
     # `windows` windows of EXACTLY --steps steps, each bracketed by a barrier + synchronize on both sides and reduced to
     # the max over ranks; the reported time is the MEDIAN window (a 5 ms region is otherwise one sample), p10 / p90 beside it
     wall, dev_ms, info, last_reward = timed_windows(one_step, args.steps, max(1, args.windows), world, device,
-                                                    flush if (world > 1 and gather) else None)
+                                                    flush if (collective and gather) else None, collective)
+    gather_check = None
+    if collective and gather and last_reward is not None:
+        # the all-gathered batch of the last step holds this rank's rewards at this rank's rows
+        lo_ = sum(sizes[:rank]) if sizes is not None else rank * B
+        gather_check = {'rows': int(last_reward.shape[0]), 'expected_rows': int(total_B),
+                        'local_shard_identical': bool(torch.equal(last_reward[lo_:lo_ + B].to(env.buf['reward'].device), env.buf['reward']))}
     order = np.argsort(wall)
     mid = int(order[len(order) // 2])
     elapsed = wall[mid]
@@ -585,6 +604,10 @@ def main():
             'value': total_B * args.steps / elapsed,
             'unit': 'env.step()/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            # what torch.distributed itself saw (None / 1: no process group — a single process without collectives)
+            'dist_backend': dist.get_backend() if dist.is_initialized() else None,
+            'world_seen': dist.get_world_size() if dist.is_initialized() else 1,
+            'gather_check': gather_check,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong' if strong_total is not None else 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
@@ -598,7 +621,7 @@ def main():
                        'parallelism': f'shard{world}', 'newton_variant': 'full Newton (a Jacobian factorisation per iteration)' if not args.reuse_tol else
                                          f'Shamanskii / chord steps below a mismatch of {args.reuse_tol:g} (jacobian_reuse_tol; opt-in, NOT the reference\'s algorithm)',
                        'newton_start': env.init,
-                       'collective': {'none': 'none', 'reward': 'all_gather(reward), overlapped with the next step', 'obs': 'all_gather(reward+obs), overlapped with the next step'}[gather_mode] if world > 1 else 'none',
+                       'collective': {'none': 'none', 'reward': 'all_gather(reward), overlapped with the next step', 'obs': 'all_gather(reward+obs), overlapped with the next step'}[gather_mode] if collective else 'none',
                        'converged_fraction': conv, 'mean_nr_iterations': mean_it_base,
                        'mean_nr_iterations_all_solves': mean_it_total, 'solves_per_step': solves_per_step,
                        'nr_solves_per_s': total_B * solves_per_step * args.steps / elapsed,
@@ -631,10 +654,24 @@ def main():
                     out['also'][f'config{c}'] = also_config(c, device, 3 if c == 5 else (20 if c == 1 else 5), 1 if c == 5 else 2)
                 except Exception as exc:           # (a failure here must not cost the headline line)
                     out['also'][f'config{c}'] = {'error': f'{type(exc).__name__}: {exc}'}
+        if full and not args.no_also and args.batch is None and args.as_rank is None:
+            # the SAME workloads at the reference's own solver settings: pandapower's init='auto' — a DC
+            # power flow first on every grid fed above 70 kV, which is all of these — and, for the N-1
+            # configuration, every contingency solved from scratch (security_constrained.py:53).  Same fixed point and
+            # tolerance as the headline; the iteration path, and with it `iterations` and the time, are the reference's.
+            out['reference_settings'] = {
+                'what': "BatchedOpfEnv(reference_faithful=True): init='auto', contingency_start='flat' (carry_over_state=True "
+                        'concerns reset only); the headline and `also` run init=flat / contingency_start=base_case'}
+            for c in (2, 3, 5):
+                try:
+                    out['reference_settings'][f'config{c}'] = also_config(c, device, 3 if c == 5 else 5, 1 if c == 5 else 2,
+                                                                          reference_faithful=True)
+                except Exception as exc:
+                    out['reference_settings'][f'config{c}'] = {'error': f'{type(exc).__name__}: {exc}'}
         # timed after the GPU work, in child processes (one, then one per host core)
         out['cpu_baseline'] = cpu_baseline(args.config) if full else None
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

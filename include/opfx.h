@@ -64,7 +64,9 @@ extern "C" {
 #endif
 
 #define OPFX_VERSION_MAJOR 0
-#define OPFX_VERSION_MINOR 2      /* 0.2: struct_size in every struct, developer switches out of the environment */
+#define OPFX_VERSION_MINOR 3      /* 0.2: struct_size in every struct, developer switches out of the environment;
+                                   * 0.3: members appended to opfx_case / opfx_step_io / opfx_solve_opts / opfx_plan_info and
+                                   *      min_pivot_bus added to opfx_solve after the first 0.2 layout -> a new series */
 #define OPFX_VERSION_PATCH 0
 
 /* zero a struct of this header and stamp its size: opfx_solve_opts o; OPFX_INIT(o); o.tol = 1e-8; ... */

@@ -17,6 +17,7 @@ holding TABLE values exactly as the reference net does (i.e. before `scaling`).
 from __future__ import annotations
 
 import copy
+import logging
 import ctypes as C
 
 import numpy as np
@@ -282,6 +283,30 @@ def _keep(lst, arr, kind):
     return a.ctypes.data_as(capi._pd if kind == 'd' else capi._pi)
 
 
+_noticed = set()
+
+
+def _notice_deviations(env):
+    """`from_reference` promises the reference's problem; say (once per process and setting) where the SOLVER SETTINGS
+    are the fast defaults instead of the reference's, and how to get those."""
+    dev = dict(env.reference_deviations)
+    if dev.get('init') == 'flat' and env.init == 'flat' and not (env.case.meta.get('calc_angles') and env.plan.info['has_dc']):
+        dev.pop('init')                  # pandapower's 'auto' is 'flat' on this grid too
+    if not env.n_minus_one_keys:
+        dev.pop('contingency_start', None)
+    key = tuple(sorted((k, str(v)) for k, v in dev.items()))
+    if not dev or key in _noticed:
+        return
+    _noticed.add(key)
+    why = {'init': "init='flat' (pandapower starts grids fed above 70 kV from a DC power flow: init='auto')",
+           'contingency_start': "contingency_start='base_case' (the reference solves every contingency from scratch: 'flat')",
+           'carry_over_state': "carry_over_state=False (the reference's single net carries unsampled columns over episodes, D12: True)"}
+    logging.getLogger('opfgym_amd').warning(
+        'BatchedOpfEnv.from_reference: same problem and fixed point as the reference, but not its iteration path: %s. '
+        'iterations[B], and converged[B] of rows next to voltage collapse, can differ; pass reference_faithful=True '
+        '(or the single options) to reproduce it.', '; '.join(why[k] for k in dev))
+
+
 class PowerFlowNotAvailable(Exception):
     """opf_env.py:22"""
 
@@ -301,14 +326,29 @@ class BatchedOpfEnv:
                  objective_function=None, power_flow_solver=None, optimal_power_flow_solver=None,
                  seed=None, batch_size=1, device='cuda:0', n_minus_one_keys=None,
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
-                 defer_device=False, validate_actions=False, carry_over_state=False, copy_outputs=False,
-                 contingency_start='base_case', init='flat', jacobian_reuse_tol=0.0, resample_failed_resets=True,
-                 on_pivot_breakdown='ignore', **kwargs):
+                 defer_device=False, validate_actions=False, carry_over_state=None, copy_outputs=False,
+                 contingency_start=None, init=None, jacobian_reuse_tol=0.0, resample_failed_resets=True,
+                 on_pivot_breakdown='ignore', reference_faithful=False, **kwargs):
         from .objectives import QuadraticDeviation
+        # reference_faithful: ONE switch for the three defaults that trade the reference's iteration path for speed.
+        # Each of `init`, `contingency_start`, `carry_over_state` left at None takes the fast default ('flat',
+        # 'base_case', False) or, with reference_faithful=True, what the reference does: init='auto' (pandapower's
+        # default, 'dc' on grids fed above 70 kV — SURVEY P1), contingency_start='flat' (every contingency is a fresh
+        # runpp, security_constrained.py:53) and carry_over_state=True (one net lives through all episodes, D12).
+        # Converged results agree either way (same fixed point, same tolerance); `iterations`, and `converged` of rows
+        # next to voltage collapse, follow the start.  An explicit value always wins.
+        self.reference_faithful = bool(reference_faithful)
+        faithful = dict(init='auto', contingency_start='flat', carry_over_state=True)
+        fast = dict(init='flat', contingency_start='base_case', carry_over_state=False)
+        given = dict(init=init, contingency_start=contingency_start, carry_over_state=carry_over_state)
+        resolved = {k: (v if v is not None else (faithful if reference_faithful else fast)[k]) for k, v in given.items()}
+        init, contingency_start, carry_over_state = (resolved[k] for k in ('init', 'contingency_start', 'carry_over_state'))
+        #: the settings under which this environment does NOT walk the reference's own iteration path
+        self.reference_deviations = {k: v for k, v in resolved.items() if v != faithful[k]}
         # (the arguments as given: a bus-bus switch actuator needs twins of this environment on other topologies)
         self._pre_init_attrs = {k: v for k, v in self.__dict__.items() if not k.startswith('_pre_init')}   # (what a subclass set before)
         self._topology_fixed = bool(kwargs.pop('_topology_fixed', False))
-        self._ctor = {k: v for k, v in locals().items() if k not in ('self', 'net', 'kwargs', 'QuadraticDeviation', '__class__')}
+        self._ctor = {k: v for k, v in locals().items() if k not in ('self', 'net', 'kwargs', 'QuadraticDeviation', '__class__', 'faithful', 'fast', 'given', 'resolved')}
         self._ctor_kwargs = dict(kwargs)
         self._bb_switches, self._topology_variants = [], {}
         # on_pivot_breakdown: the block LU pivots statically (fixed elimination order, the 2x2 diagonal block of a bus as its
@@ -441,6 +481,11 @@ class BatchedOpfEnv:
         if self.init == 'auto':
             # (a case whose DC model is not finite — a zero-reactance branch — carries no B': 'auto' then stays flat)
             self.init = 'dc' if self.case.meta.get('calc_angles') and self.plan.info['has_dc'] else 'flat'
+        if self.init == 'dc' and not self.plan.info['has_dc']:
+            if not self._topology_fixed:
+                raise ValueError("init='dc': this grid has no finite DC model (a zero-reactance branch has no 1/x); use "
+                                 "init='auto' or 'flat'")
+            self.init = 'flat'              # (a topology twin of a 'dc' parent without a DC model of its own)
         self.solve_opts.init = capi.INIT[self.init]
         self.store = ColumnStore(net)
         for tbl in ('load', 'sgen', 'storage'):
@@ -537,6 +582,7 @@ class BatchedOpfEnv:
         env.test_steps, env.validation_steps, env.train_steps = (np.asarray(v) for v in (
             ref_env.test_steps, ref_env.validation_steps, ref_env.train_steps))
         env.definition = defn
+        _notice_deviations(env)
         if not defer:
             env.attach_device()
         return env
@@ -1108,7 +1154,7 @@ class BatchedOpfEnv:
             finally:
                 d.n_cont = n_cont
             self._env_handle_base_only = h0
-        self._rescue_envs = {}
+        self._drop_rescue_envs()
         self.n_obs_raw = len(oidx)
         self.n_constraints = len(self.constraints)
         self.n_device_constraints = len(self.device_constraints)
@@ -1332,7 +1378,8 @@ class BatchedOpfEnv:
             for name, buf in tmp.items():
                 setattr(io, name, buf.data_ptr())
             with t.cuda.device(self.device):
-                capi.check(capi.lib().opfx_step(var._env_handle, n, C.byref(io), C.byref(self.solve_opts), mode,
+                # (the twin's own start: its topology decides whether it has a DC model; everything else is the parent's)
+                capi.check(capi.lib().opfx_step(var._env_handle, n, C.byref(io), C.byref(var.solve_opts), mode,
                                                 capi._stream()), 'opfx_step (topology variant)')
             self.x[idx] = x2
             for name, buf in tmp.items():
@@ -1369,17 +1416,19 @@ class BatchedOpfEnv:
         buses named by `min_pivot_bus` last (see `on_pivot_breakdown`): gathered into a compact batch, stepped by a second
         environment object on that plan (same descriptor), scattered back.  GPU only — there is no CPU fallback."""
         t, b = self.torch, self.buf
-        bad = (~b['converged']) & (b['min_pivot'] < self.PIVOT_BREAKDOWN) & (b['min_pivot_bus'] >= 0)
+        bad = (b['converged'] == 0) & (b['min_pivot'] < self.PIVOT_BREAKDOWN) & (b['min_pivot_bus'] >= 0)
         if not bool(bad.any()):                                            # (the one host synchronisation of this option)
             return
         idx = bad.nonzero().flatten()
         buses = tuple(sorted(set(b['min_pivot_bus'][idx].cpu().tolist())))
         if buses not in self._rescue_envs:
+            self._drop_rescue_envs(keep=self.MAX_RESCUE_PLANS - 1)         # (each holds a plan, a context and a device copy)
             plan = capi.Plan(self.case, elim_last=buses)
             ctx = capi.Context(plan, self.device.index or 0)
             h = C.c_void_p()
             capi.check(capi.lib().opfx_env_create(ctx.handle, C.byref(self._env_desc), C.byref(h)), 'opfx_env_create (rescue plan)')
             self._rescue_envs[buses] = (plan, ctx, h)
+        self._rescue_envs[buses] = self._rescue_envs.pop(buses)            # most recently used last
         _, _, handle = self._rescue_envs[buses]
         n = int(idx.numel())
         x2 = (x_before if x_before is not None else self.x)[idx].contiguous()
@@ -1782,10 +1831,18 @@ class BatchedOpfEnv:
         return dict(waves_per_instance=team.value, lds_bytes_per_instance=lds.value, instances_per_cu=per_cu.value,
                     packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value)
 
-    def close(self):
-        for _, _, h in getattr(self, '_rescue_envs', {}).values():
+    MAX_RESCUE_PLANS = 8
+
+    def _drop_rescue_envs(self, keep=0):
+        """Destroy rescue environments (oldest first) until `keep` are left: the env handle before its context goes."""
+        cache = getattr(self, '_rescue_envs', None) or {}
+        while len(cache) > keep:
+            _, _, h = cache.pop(next(iter(cache)))
             capi.lib().opfx_env_destroy(h)
-        self._rescue_envs = {}
+        self._rescue_envs = cache
+
+    def close(self):
+        self._drop_rescue_envs()
         for var in getattr(self, '_topology_variants', {}).values():
             var.close()
         self._topology_variants = {}

@@ -40,7 +40,7 @@ class OpfxError(RuntimeError):
 
 
 # the version of include/opfx.h these ctypes structs were written for; lib() refuses a library of another major.minor
-ABI_VERSION = (0, 2)
+ABI_VERSION = (0, 3)
 
 
 class Sized(C.Structure):

@@ -3770,17 +3770,19 @@ extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
   }
   HIP_TRY(hipSetDevice(env->ctx->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, st));
+  // (the two events are released on every path out, HIP failures included)
+  struct Events {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.e0));
+  HIP_TRY(hipEventCreate(&ev.e1));
+  HIP_TRY(hipEventRecord(ev.e0, st));
   int rc = OPFX_OK;
   for (int r = 0; r < reps && rc == OPFX_OK; ++r) rc = do_step(env, B, io, opts, 0, stream);
-  HIP_TRY(hipEventRecord(e1, st));
-  HIP_TRY(hipEventSynchronize(e1));
-  HIP_TRY(hipEventElapsedTime(elapsed_ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  HIP_TRY(hipEventRecord(ev.e1, st));
+  HIP_TRY(hipEventSynchronize(ev.e1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, ev.e0, ev.e1));
   return rc;
 }
 

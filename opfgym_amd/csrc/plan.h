@@ -105,6 +105,10 @@ void opfx_set_error(const std::string& msg);
 // Versioned structs (include/opfx.h, VERSIONING): copy the caller's struct into a zeroed one of THIS library's layout.
 // Accepted sizes: [min_size, sizeof(T)] — members are only ever appended, a shorter struct of the same series leaves the
 // new ones zero (their defaults); anything else is a caller built against another header and is refused.
+// `min_size` is the struct's size in the FIRST layout of the current major.minor series.  The default, sizeof(T), is right
+// for as long as nothing has been appended since the last MINOR bump (true for 0.3); whoever appends a member without
+// bumping passes the previous sizeof here — and whoever changes a function signature or reorders members bumps MINOR
+// (include/opfx.h) together with ABI_VERSION in opfgym_amd/capi.py.
 #include <cstring>
 template <class T>
 inline int opfx_take(const T* in, T* out, const char* what, size_t min_size = sizeof(T)) {

@@ -13,12 +13,25 @@ from __future__ import annotations
 import os
 
 
+def force_collective() -> bool:
+    """OPFX_FORCE_COLLECTIVE=1 (read by this Python layer, not by the library): a world of ONE rank initialises its
+    process group and runs every collective of this module for real instead of short-circuiting — the way to execute
+    the RCCL code path (communicator set-up, `all_gather_into_tensor` on device tensors, the asynchronous gather, the
+    barrier and the max-reduce of the bench) on a box with a single GPU."""
+    return os.environ.get('OPFX_FORCE_COLLECTIVE', '') == '1'
+
+
+def _local_only(world: int) -> bool:
+    import torch.distributed as dist
+    return not dist.is_initialized() or (world == 1 and not force_collective())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world == 1 or dist.is_initialized():
+    if (world == 1 and not force_collective()) or dist.is_initialized():
         return int(os.environ.get('RANK', '0')), world, int(os.environ.get('LOCAL_RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
@@ -49,7 +62,7 @@ def all_gather_rows(local, world: int, sizes=None):
     largest shard and trim."""
     import torch
     import torch.distributed as dist
-    if world == 1 or not dist.is_initialized():
+    if _local_only(world):
         return local
     if local.is_cuda and dist.get_backend() == 'gloo':
         # debugging aid (several ranks sharing one GPU): stage through the host
@@ -110,7 +123,7 @@ class OverlappedGather:
     def submit(self, local):
         import torch
         import torch.distributed as dist
-        if self.world == 1 or not dist.is_initialized():
+        if _local_only(self.world):
             return local
         if local.is_cuda and dist.get_backend() == 'gloo':        # (debugging aid: ranks sharing one GPU)
             prev, self._last = getattr(self, '_last', None), all_gather_rows(local, self.world, self.sizes)
@@ -133,8 +146,7 @@ class OverlappedGather:
 
     def flush(self):
         """The full-batch tensor of the last submitted step."""
-        import torch.distributed as dist
-        if self.world == 1 or not dist.is_initialized():
+        if _local_only(self.world):
             return None
         if getattr(self, '_last', None) is not None:
             return self._last

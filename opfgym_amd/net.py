@@ -98,10 +98,13 @@ def _append(net, table: str, row: dict, index=None) -> int:
     df = net[table]
     if index is None:
         index = 0 if len(df) == 0 else int(df.index.max()) + 1
-    for col in row:
-        if col not in df.columns:
-            df[col] = pd.Series(dtype=object if isinstance(row[col], (str, list)) else float)
-    df.loc[index] = pd.Series(row, dtype=object)
+    # rows are collected as objects (`finalize` gives the columns their dtypes); the frame is rebuilt rather than
+    # enlarged through `.loc`: pandas' enlargement concatenates and guesses a dtype for all-missing entries (deprecated)
+    cols = list(df.columns) + [c for c in row if c not in df.columns]
+    keep = [pos for pos, i in enumerate(df.index) if i != index]          # (an existing index is overwritten)
+    data = {c: ([df[c].iloc[pos] for pos in keep] if c in df.columns else [np.nan] * len(keep)) + [row.get(c, np.nan)]
+            for c in cols}
+    net[table] = pd.DataFrame(data, index=[df.index[pos] for pos in keep] + [index], dtype=object, columns=cols)
     return index
 
 

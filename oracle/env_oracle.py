@@ -52,7 +52,7 @@ def set_simbench_state(net, profiles, step, noise=None, col_range=None, interp=N
         off += n
         lo, hi = col_range[(unit, col)] if col_range else (df.min()[idx].to_numpy(float),
                                                           df.max()[idx].to_numpy(float))
-        net[unit].loc[idx, col] = np.clip(data, lo, hi)
+        _assign(net, unit, col, idx, np.clip(data, lo, hi))
 
 
 def profile_ranges(profiles):
@@ -60,6 +60,16 @@ def profile_ranges(profiles):
     every reset, opf_env.py:364-369 — defect D10, numerically identical)."""
     return {k: (df.min().to_numpy(float), df.max().to_numpy(float))
             for k, df in profiles.items() if df.shape[1]}
+
+
+def _assign(net, unit, col, idxs, values):
+    """`net[unit].loc[idxs, col] = values` as the reference writes it (opf_env.py:284,315,368,483).  Where floats go
+    into an integer column pandas upcasts the column today and will refuse tomorrow: the cast is made explicit."""
+    df = net[unit]
+    values = np.asarray(values)
+    if values.dtype.kind == 'f' and df[col].dtype.kind in 'iub':
+        df[col] = df[col].astype(float)
+    df.loc[idxs, col] = values
 
 
 # ---------------------------------------------------------------------------
@@ -75,7 +85,7 @@ def sample_from_range(net, unit, col, idxs, draws):
     r = lo + (hi - lo) * u
     if 'scaling' in df:
         r = r / df['scaling'].loc[idxs].to_numpy(float)
-    net[unit].loc[idxs, col] = r
+    _assign(net, unit, col, idxs, r)
 
 
 def sample_normal(net, state_keys, zdraws, relative_std=None):
@@ -91,7 +101,7 @@ def sample_normal(net, state_keys, zdraws, relative_std=None):
         std = relative_std * diff if relative_std else df[f'std_dev_{col}'].to_numpy(float)
         z = np.array([next(zdraws) for _ in range(len(idxs))])
         vals = df[f'mean_{col}'].to_numpy(float) + (std * diff) * z
-        net[unit].loc[idxs, col] = np.clip(vals, lo, hi)
+        _assign(net, unit, col, idxs, np.clip(vals, lo, hi))
 
 
 def sample_truncated_normal(net, state_keys, udraws, relative_std=None):
@@ -110,7 +120,7 @@ def sample_truncated_normal(net, state_keys, udraws, relative_std=None):
         diff = hi - lo
         std = relative_std * diff if relative_std else df[f'std_dev_{col}'].to_numpy(float)
         u = np.array([next(udraws) for _ in range(len(idxs))])
-        net[unit].loc[idxs, col] = stats.truncnorm.ppf(u, lo, hi, df[f'mean_{col}'].to_numpy(float), std * diff)
+        _assign(net, unit, col, idxs, stats.truncnorm.ppf(u, lo, hi, df[f'mean_{col}'].to_numpy(float), std * diff))
 
 
 def tail_voltage_control(net, draws, market_based):
@@ -219,7 +229,7 @@ def apply_actions(net, act_keys, action, autoscale=True, diff_step=None):
             sp = np.round(sp).astype(bool)
         elif col in ('tap_pos', 'step'):                                    # :479-481
             sp = np.round(sp)
-        net[unit].loc[idxs, col] = sp                                       # :483
+        _assign(net, unit, col, idxs, sp)                                   # :483
         k += n
     cur = current_actions(net, act_keys, autoscale, from_results=False)
     with np.errstate(invalid='ignore'):

@@ -38,6 +38,20 @@ REF = {'VoltageControl': opfgym.envs.VoltageControl, 'QMarket': opfgym.envs.QMar
        'MaxRenewable': opfgym.envs.MaxRenewable, 'LoadShedding': opfgym.envs.LoadShedding,
        'SecurityConstrained': ex_sc.SecurityConstrained, 'MultiStageOpf': ex_ms.MultiStageOpf,
        'PartiallyObservable': ex_po.PartiallyObservable, 'MixedContinuousDiscrete': ex_mcd.MixedContinuousDiscrete}
+import logging  # noqa: E402
+
+
+class _Notices(logging.Handler):
+    def __init__(self):
+        super().__init__()
+        self.lines = []
+
+    def emit(self, record):
+        self.lines.append(record.getMessage())
+
+
+notices = _Notices()
+logging.getLogger('opfgym_amd').addHandler(notices)
 bad = 0
 for name, rec in recorded.items():
     cls, kw, _, seed = SCENARIOS[name]
@@ -63,4 +77,19 @@ for name, rec in recorded.items():
         print('   ', {k: v for k, v in checks.items() if not v}, live.store.n, rec.store.n)
     print(f'{name:22s} {"same definition" if ok else "DIFFERENT"}  ({cls}, {live.n_actions} actions, {len(live.ops.ops)} reset ops)')
     bad += not ok
+# 3) the solver settings `from_reference` does NOT take from the reference by default are said out loud, once per setting,
+#    and `reference_faithful=True` leaves nothing to say
+cls, kw, _, seed = SCENARIOS['sc_hv_small']
+ref_env = REF[cls](seed=seed, **kw)
+text = ' '.join(notices.lines)
+said = all(w in text for w in ("init='flat'", "contingency_start='base_case'", 'carry_over_state=False', 'reference_faithful=True'))
+n_before = len(notices.lines)
+fast = BatchedOpfEnv.from_reference(ref_env, defer_device=True, seed=seed)                   # (same settings again: no second notice)
+faithful = BatchedOpfEnv.from_reference(ref_env, defer_device=True, seed=seed, reference_faithful=True)
+quiet = len(notices.lines) == n_before
+ok = said and quiet and set(fast.reference_deviations) == {'init', 'contingency_start', 'carry_over_state'} \
+    and faithful.reference_deviations == {} and faithful.init == 'dc' and faithful.solve_opts.contingency_start == 1 \
+    and faithful.carry_over_state and fast.init == 'flat' and fast.solve_opts.contingency_start == 0
+print(f'{"solver-settings notice":22s} {"same definition" if ok else "DIFFERENT"}  ({len(notices.lines)} notices; said={said}, quiet={quiet})')
+bad += not ok
 sys.exit(1 if bad else 0)

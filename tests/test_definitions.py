@@ -94,3 +94,23 @@ def test_bench_checker_leg_reproduces_the_oracle(tmp_path):
         env_oracle.apply_actions(orc.net, orc.act_keys, np.asarray(d['actions'][k]), orc.autoscale, orc.diff_step)
         assert orc.solve()
         assert np.allclose(vm[k], orc.net['res_bus']['vm_pu'].to_numpy(float), rtol=0, atol=0)
+
+
+def test_reference_faithful_is_one_switch_and_explicit_options_win():
+    """`reference_faithful=True` = init='auto' (pandapower's default: 'dc' on grids fed above 70 kV),
+    contingency_start='flat' (security_constrained.py:53: every contingency a fresh runpp), carry_over_state=True (D12);
+    the default is the fast path, which `reference_deviations` names; an explicitly given option always wins."""
+    from opfgym_amd import envs
+    kw = dict(simbench_network_name='hv-small', batch_size=1, defer_device=True, seed=0)
+    fast = envs.EcoDispatch(**kw)
+    assert fast.reference_deviations == {'init': 'flat', 'contingency_start': 'base_case', 'carry_over_state': False}
+    assert fast.init == 'flat' and fast.solve_opts.contingency_start == 0 and not fast.carry_over_state and not fast.reference_faithful
+    ref = envs.EcoDispatch(reference_faithful=True, **kw)
+    assert ref.reference_deviations == {} and ref.reference_faithful
+    assert ref.init == 'dc' and ref.solve_opts.init == 1 and ref.solve_opts.contingency_start == 1 and ref.carry_over_state
+    mixed = envs.EcoDispatch(reference_faithful=True, init='flat', **kw)
+    assert mixed.reference_deviations == {'init': 'flat'} and mixed.init == 'flat' and mixed.solve_opts.contingency_start == 1
+    # below 70 kV pandapower's 'auto' IS the flat start
+    lv = envs.MaxRenewable(simbench_network_name='1-LV-rural1--0-sw', min_sgen_power=0.005, min_storage_power=0.005,
+                           batch_size=1, defer_device=True, seed=0, reference_faithful=True)
+    assert lv.init == 'flat' and lv.reference_deviations == {}

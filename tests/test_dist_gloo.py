@@ -214,3 +214,41 @@ def test_overlapped_gather_with_ragged_shards():
     for k in range(4):
         want = (np.arange(7.0) + 100 * k).reshape(-1, 1).repeat(2, axis=1)
         assert got[k + 1].shape == (7, 2) and np.array_equal(got[k + 1], want)
+
+
+def _forced_world_of_one(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    from opfgym_amd import dist as od
+    plain = od.OverlappedGather(1)
+    x = torch.arange(6, dtype=torch.float64).reshape(3, 2)
+    short = (od.init_from_env('gloo'), dist.is_initialized(), plain.submit(x) is x, plain.flush(), od.all_gather_rows(x, 1) is x)
+    os.environ['OPFX_FORCE_COLLECTIVE'] = '1'
+    r, w, _ = od.init_from_env('gloo')
+    g = od.OverlappedGather(1)
+    first = g.submit(x)
+    second = g.submit(x + 10)
+    last = g.flush()
+    rows = od.all_gather_rows(x, 1)
+    q.put((short[0][:2], short[1], short[2], short[3], short[4], (r, w), dist.is_initialized(), dist.get_world_size(), first,
+           second.numpy(), last.numpy(), rows is x, rows.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_forced_world_of_one_runs_the_collectives_instead_of_short_circuiting():
+    """OPFX_FORCE_COLLECTIVE=1 (how the RCCL branch is executed on a one-GPU box, tests/test_gpu_bench.py): a single rank
+    initialises its process group and `OverlappedGather` / `all_gather_rows` go through the collective (staging buffers,
+    previous-step hand-over) — without it the same calls hand the local tensor straight back."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world_of_one, args=(29671, q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    rw0, init0, same0, flush0, rows_same0, rw, init1, world, first, second, last, rows_same, rows = got
+    assert rw0 == (0, 1) and not init0 and same0 and flush0 is None and rows_same0          # short circuit
+    assert rw == (0, 1) and init1 and world == 1
+    x = np.arange(6.0).reshape(3, 2)
+    assert first is None and np.array_equal(second, x) and np.array_equal(last, x + 10)     # the previous step, then the last
+    assert not rows_same and np.array_equal(rows, x)

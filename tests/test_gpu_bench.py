@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-        'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'timing'}
+        'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'timing', 'dist_backend', 'world_seen', 'gather_check'}
 
 
 def _run(*args):
@@ -26,6 +26,7 @@ def _run(*args):
 def test_bench_line_has_the_contract_keys(config):
     d = _run('--config', str(config), '--steps', '4', '--warmup', '2', '--no-cpu-baseline')
     assert set(d) == KEYS
+    assert d['dist_backend'] is None and d['world_seen'] == 1 and d['gather_check'] is None      # (a plain single process)
     assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['higher_is_better'] is True
     assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None and d['cpu_baseline'] is None
     assert d['value'] > 0 and abs(d['value'] - d['config']['batch_total'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
@@ -64,7 +65,7 @@ def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_con
     against the oracle, and `also` — every other BASELINE configuration measured briefly on the same GPU, each with its
     rate, kernel time, convergence, iterations, bound and its own |V| check over 64 (N-1: 8) instances."""
     d = _run('--config', '1', '--steps', '4', '--warmup', '2')
-    assert set(d) == KEYS | {'also'}
+    assert set(d) == KEYS | {'also', 'reference_settings'}
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and cb['all_cores']['cores'] >= 1
     assert 'oracle' in cb['sample']
@@ -77,6 +78,46 @@ def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_con
         assert a['max_abs_v_err_pu'] is not None and a['max_abs_v_err_pu'] < 1e-9, name
         assert a['max_abs_v_err_instances'] == (8 if name == 'config5' else 64)
     assert d['also']['config5']['steps'] == 3 and d['also']['config3']['steps'] >= 5
+    assert all(a['newton_start'] == 'flat' and a['contingency_start'] == 'base_case' for a in d['also'].values())
+    # the same workloads at the reference's own solver settings: pandapower's init='auto' is 'dc' on all of them (every
+    # stand-in hangs on 110 kV or above), contingencies from scratch; same fixed point -> same |V| check
+    rs = d['reference_settings']
+    assert set(rs) == {'what', 'config2', 'config3', 'config5'}
+    for name in ('config2', 'config3', 'config5'):
+        a = rs[name]
+        assert 'error' not in a, (name, a)
+        assert a['newton_start'] == 'dc' and a['contingency_start'] == 'flat' and ',DC>' in a['kernel'], (name, a['kernel'])
+        assert a['value'] > 0 and a['converged_fraction'] > 0.99 and a['max_abs_v_err_pu'] is not None and a['max_abs_v_err_pu'] < 1e-9, name
+        assert a['roofline']['counters_from'] is None          # (the committed counters are the plain kernel's)
+    # contingencies from scratch cost iterations: more of them than from the base case's solution
+    assert rs['config5']['mean_nr_iterations_all_solves'] > d['also']['config5']['mean_nr_iterations_all_solves']
+
+
+def test_the_rccl_path_runs_on_hardware_with_a_world_of_one(tmp_path):
+    """RCCL itself, executed: one rank under torchrun with OPFX_FORCE_COLLECTIVE=1 does not short-circuit —
+    `init_process_group('nccl', device_id=...)`, the barriers and the max-reduce of the timed windows, the asynchronous
+    `all_gather_into_tensor` of rewards and observations on device tensors (OverlappedGather) and `destroy_process_group`
+    all run on the nccl (= RCCL) backend.  The gathered rewards must be the local ones."""
+    import numpy as np
+    env = dict(os.environ, OPFX_FORCE_COLLECTIVE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('OPFX_DIST_BACKEND', None)
+    full, part = tmp_path / 'full.npy', tmp_path / 'part.npy'
+    args = ['--gpus', '1', '--config', '2', '--batch', '512', '--steps', '3', '--warmup', '1', '--windows', '2', '--no-cpu-baseline']
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+                        '--master-port', '29533', os.path.join(ROOT, 'bench.py')] + args + ['--gather', 'obs', '--dump-reward', str(full)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['dist_backend'] == 'nccl' and d['world_seen'] == 1 and d['n_gpus'] == 1
+    assert d['config']['collective'] == 'all_gather(reward+obs), overlapped with the next step'
+    assert d['gather_check'] == {'rows': 512, 'expected_rows': 512, 'local_shard_identical': True}
+    got = np.load(full)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args + ['--dump-reward', str(part)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=os.environ.copy())
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert got.shape == (512,) and np.isfinite(got).all() and np.array_equal(np.load(part), got)
 
 
 def test_two_ranks_on_the_one_gpu_run_the_multi_gpu_path_end_to_end(tmp_path):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(built_lib, name), name
     ver = [capi.C.c_int() for _ in range(3)]
     built_lib.opfx_version(*[capi.C.byref(v) for v in ver])
-    assert (ver[0].value, ver[1].value) == capi.ABI_VERSION == (0, 2)
+    assert (ver[0].value, ver[1].value) == capi.ABI_VERSION == (0, 3)
     # the header and the library agree on the version; the developer entry points live in a header of their own
     assert re.search(r'#define OPFX_VERSION_MAJOR (\d+)', header).group(1) == str(ver[0].value)
     assert re.search(r'#define OPFX_VERSION_MINOR (\d+)', header).group(1) == str(ver[1].value)
