@@ -660,8 +660,9 @@ def main():
             # configuration, every contingency solved from scratch (security_constrained.py:53).  Same fixed point and
             # tolerance as the headline; the iteration path, and with it `iterations` and the time, are the reference's.
             out['reference_settings'] = {
-                'what': "BatchedOpfEnv(reference_faithful=True): init='auto', contingency_start='flat' (carry_over_state=True "
-                        'concerns reset only); the headline and `also` run init=flat / contingency_start=base_case'}
+                'what': "BatchedOpfEnv(reference_faithful=True): init='auto', contingency_start='flat', enforce_q_lims on pypower's own "
+                        'path (generators with min_q = max_q start as PV buses: config 3), carry_over_state=True (concerns reset '
+                        'only); the headline and `also` run init=flat / contingency_start=base_case / such generators pinned from the start'}
             for c in (2, 3, 5):
                 try:
                     out['reference_settings'][f'config{c}'] = also_config(c, device, 3 if c == 5 else 5, 1 if c == 5 else 2,

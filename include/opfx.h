@@ -223,7 +223,11 @@ typedef struct opfx_solve_opts {
   int32_t reserved0;         /* (alignment) 0                                */
   double tol;                /* inf-norm tolerance on the mismatch, p.u. (pandapower tolerance_mva=1e-8) */
   int32_t max_iter;          /* pandapower max_iteration 'auto' -> 10        */
-  int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits */
+  int32_t enforce_q_lims;    /* opf_env.py:697: PV->PQ switching on Q limits.  0: off.  1: on; a generator whose reactive
+                              * range is a single point (eco_dispatch.py:86-88: min_q = max_q = 0) STARTS pinned at it — where
+                              * the first pass always puts it — which saves one Newton solve.  2: on, pypower's own path: every
+                              * generator starts as a PV bus, violated limits are pinned after the first converged solve
+                              * (same result; `iterations` then count both solves, as pandapower's do) */
   int32_t init;              /* start of the base-case Newton iteration: OPFX_INIT_FLAT (0, default): |V| = 1 (set-points at
                               * PV / REF buses), angles = the slack angle carried through the transformer phase shifts;
                               * OPFX_INIT_DC (1): angles from a DC power flow B' theta = P first (pandapower init='dc',

@@ -294,13 +294,17 @@ def _notice_deviations(env):
         dev.pop('init')                  # pandapower's 'auto' is 'flat' on this grid too
     if not env.n_minus_one_keys:
         dev.pop('contingency_start', None)
+    if not (env.solve_opts.enforce_q_lims and len(env.net.gen)):
+        dev.pop('pin_point_q_ranges', None)
     key = tuple(sorted((k, str(v)) for k, v in dev.items()))
     if not dev or key in _noticed:
         return
     _noticed.add(key)
     why = {'init': "init='flat' (pandapower starts grids fed above 70 kV from a DC power flow: init='auto')",
            'contingency_start': "contingency_start='base_case' (the reference solves every contingency from scratch: 'flat')",
-           'carry_over_state': "carry_over_state=False (the reference's single net carries unsampled columns over episodes, D12: True)"}
+           'carry_over_state': "carry_over_state=False (the reference's single net carries unsampled columns over episodes, D12: True)",
+           'pin_point_q_ranges': "pin_point_q_ranges=True (pypower starts a generator with min_q = max_q as a PV bus and pins it after "
+                                 "the first solve: False)"}
     logging.getLogger('opfgym_amd').warning(
         'BatchedOpfEnv.from_reference: same problem and fixed point as the reference, but not its iteration path: %s. '
         'iterations[B], and converged[B] of rows next to voltage collapse, can differ; pass reference_faithful=True '
@@ -328,21 +332,24 @@ class BatchedOpfEnv:
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
                  defer_device=False, validate_actions=False, carry_over_state=None, copy_outputs=False,
                  contingency_start=None, init=None, jacobian_reuse_tol=0.0, resample_failed_resets=True,
-                 on_pivot_breakdown='ignore', reference_faithful=False, **kwargs):
+                 on_pivot_breakdown='ignore', reference_faithful=False, pin_point_q_ranges=None, **kwargs):
         from .objectives import QuadraticDeviation
-        # reference_faithful: ONE switch for the three defaults that trade the reference's iteration path for speed.
-        # Each of `init`, `contingency_start`, `carry_over_state` left at None takes the fast default ('flat',
-        # 'base_case', False) or, with reference_faithful=True, what the reference does: init='auto' (pandapower's
-        # default, 'dc' on grids fed above 70 kV — SURVEY P1), contingency_start='flat' (every contingency is a fresh
-        # runpp, security_constrained.py:53) and carry_over_state=True (one net lives through all episodes, D12).
+        # reference_faithful: ONE switch for the four defaults that trade the reference's iteration path for speed.
+        # Each of `init`, `contingency_start`, `carry_over_state`, `pin_point_q_ranges` left at None takes the fast default
+        # ('flat', 'base_case', False, True) or, with reference_faithful=True, what the reference does: init='auto'
+        # (pandapower's default, 'dc' on grids fed above 70 kV — SURVEY P1), contingency_start='flat' (every contingency is a
+        # fresh runpp, security_constrained.py:53), carry_over_state=True (one net lives through all episodes, D12) and
+        # pin_point_q_ranges=False (enforce_q_lims as pypower walks it: a generator with min_q = max_q, eco_dispatch.py:86-88,
+        # starts as a PV bus and is pinned after the first converged solve instead of starting pinned — one more solve).
         # Converged results agree either way (same fixed point, same tolerance); `iterations`, and `converged` of rows
         # next to voltage collapse, follow the start.  An explicit value always wins.
         self.reference_faithful = bool(reference_faithful)
-        faithful = dict(init='auto', contingency_start='flat', carry_over_state=True)
-        fast = dict(init='flat', contingency_start='base_case', carry_over_state=False)
-        given = dict(init=init, contingency_start=contingency_start, carry_over_state=carry_over_state)
+        faithful = dict(init='auto', contingency_start='flat', carry_over_state=True, pin_point_q_ranges=False)
+        fast = dict(init='flat', contingency_start='base_case', carry_over_state=False, pin_point_q_ranges=True)
+        given = dict(init=init, contingency_start=contingency_start, carry_over_state=carry_over_state,
+                     pin_point_q_ranges=pin_point_q_ranges)
         resolved = {k: (v if v is not None else (faithful if reference_faithful else fast)[k]) for k, v in given.items()}
-        init, contingency_start, carry_over_state = (resolved[k] for k in ('init', 'contingency_start', 'carry_over_state'))
+        init, contingency_start, carry_over_state, pin_point_q_ranges = (resolved[k] for k in given)
         #: the settings under which this environment does NOT walk the reference's own iteration path
         self.reference_deviations = {k: v for k, v in resolved.items() if v != faithful[k]}
         # (the arguments as given: a bus-bus switch actuator needs twins of this environment on other topologies)
@@ -471,7 +478,8 @@ class BatchedOpfEnv:
         # fixed point and tolerance, cheaper iterations; iteration counts may then differ from pandapower's
         assert jacobian_reuse_tol >= 0.0
         self.jacobian_reuse_tol = float(jacobian_reuse_tol)
-        self.solve_opts = capi.SolveOpts(tolerance, max_iteration, int(bool(enforce_q_lims)), 0,
+        self.pin_point_q_ranges = bool(pin_point_q_ranges)
+        self.solve_opts = capi.SolveOpts(tolerance, max_iteration, (1 if self.pin_point_q_ranges else 2) if enforce_q_lims else 0, 0,
                                          int(contingency_start == 'flat'), self.jacobian_reuse_tol)
         self.np_random = np.random.default_rng(seed)
 

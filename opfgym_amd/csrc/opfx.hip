@@ -47,6 +47,18 @@
 namespace {
 
 constexpr int WAVE = 64;
+// SPEC: what the environment fixes for the WHOLE batch, as a template parameter of the step kernels, so that the tests for
+// it disappear at compile time instead of being skipped at run time (round 5; the single-wave kernel is instruction-issue
+// bound, only fewer instructions make it faster: BASELINE config 2 0.242 -> 0.230 ms with both bits):
+//   SPEC_NO_PV   no PV bus in the plan (voltage_control.py:102 asserts a grid without generators): the bus-type tests for PV
+//                rows, the q-limit loop and its bus types go;
+//   SPEC_NO_MOD  no per-instance branch modifier of any kind — no switch / tap / shunt-step column, no outage array, no N-1
+//                contingency, no per-instance |V| set-point: the modifier plumbing, islands and de-energised buses go.
+// opfx_step picks the instantiation per launch (do_step); -DOPFX_FORCE_SPEC=n (probe builds) forces n's bits into every one.
+constexpr int SPEC_NO_PV = 1, SPEC_NO_MOD = 2;
+#ifndef OPFX_FORCE_SPEC
+#define OPFX_FORCE_SPEC 0
+#endif
 constexpr int MODE_SOLVE = 0;
 constexpr int MODE_ENV = 1;
 
@@ -1116,11 +1128,12 @@ __device__ __forceinline__ void dc_overflow(const DevPlan& P, const Lds& L, int 
 // the wavefront walks the CHORD stream, forward substitution alone + the same back substitution (plan.h lp_bcc), instead
 // of factorisation + forward substitution.  Which stream the NEXT iteration walks is known once this iteration's norm is,
 // i.e. before its own rounds run out, so the four descriptors in flight across the loop's back edge come from the right one.
-template <bool PK, bool DC = false, bool CHORD = false>
+template <bool PK, bool DC = false, bool CHORD = false, int SPEC = 0>
 __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
                         int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool dc_pass = false) {
   double piv = 1.0;
   int pbus = -1;
+  constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
@@ -1184,7 +1197,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double cr = vri * tr + vii * ti, ci = vii * tr - vri * ti;
           const unsigned bid = ent >> 16;
           const int t = L.bt[i];
-          if (bid != NONE && jac) { st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci}); if (t == BT_PV) blk_zero_row2(L, bid); }
+          if (bid != NONE && jac) { st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci}); if (!NOPV && t == BT_PV) blk_zero_row2(L, bid); }
           lds_add(&L.rhs[i], cr);
           lds_add(&L.rq[i], ci);
         }
@@ -1224,7 +1237,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
             st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});
           }
         }
-        if (t == BT_PV && jac) {                             // rare: skipped as a whole when the wave has no PV row
+        if (!NOPV && t == BT_PV && jac) {                      // rare: skipped as a whole when the wave has no PV row
 #pragma unroll
           for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
@@ -1234,13 +1247,13 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           const double yr = g * v2, yi = -b * v2;          // V_i conj(Y_ii V_i) = conj(Y_ii)|V_i|^2
           const double pc = sr + yr, qc = si + yi;
           const double fp = pc - p_sched;
-          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
+          const double fq = (!NOPV && t == BT_PV) ? 0.0 : qc - q_sched;
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
           my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
           // dS_i/dth_i = j S_off ; dS_i/dln|V_i| = V_i conj(Y_ii V_i) + S_i
           Blk jb{-si, yr + pc, sr, yi + qc};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          if (!NOPV && t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
           if (jac) st_blk2<PK>(L, a.dw & 0xFFFF, jb);
         } else {
           // REF row: no equation; park the calculated injection S_i = S_off + conj(Y_ii)|V_i|^2
@@ -1254,7 +1267,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     }
     // (the wave teams fold the modifiers into the bus rounds, mods_inline; here, where the kernel's common case has
     //  none, even the test for it in the bus round costs 1.5 % — measured — so they keep their own pass)
-    if (n_mod > 0) {                       // rare: outage / contingency / switch / tap (see mods_apply)
+    if (!NOMOD && n_mod > 0) {             // rare: outage / contingency / switch / tap (see mods_apply)
       wave_fence();
       dead_rows_patch<PK>(P, L, lane, jac);
       wave_fence();
@@ -1371,11 +1384,12 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // ---------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
-template <int NW, bool PK, bool MEM = false, bool DC = false, bool CHORD = false>
+template <int NW, bool PK, bool MEM = false, bool DC = false, bool CHORD = false, int SPEC = 0>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
                              int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool inline_mods, bool dc_pass = false) {
   double piv = 1.0;
   int pbus = -1;
+  constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1441,7 +1455,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
         const int t = L.bt[i];
         if (bid != NONE && jac) {
           Blk jb{ci, cr, -cr, ci};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
+          if (!NOPV && t == BT_PV) { jb.a21 = 0.0; jb.a22 = 0.0; }
           st_blk2<PK>(L, bid, jb);
         }
         lds_add(&L.rhs[i], cr);
@@ -1496,24 +1510,24 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           const unsigned bid = ent[k] >> 16;
           if (bid != NONE && jac) st_blk2<PK>(L, bid, Blk{ci, cr, -cr, ci});   // (PV rows are patched after the loop)
         }
-        if (t == BT_PV && jac) {
+        if (!NOPV && t == BT_PV && jac) {
 #pragma unroll
           for (int k = 0; k < KA; ++k) if ((ent[k] >> 16) != NONE) blk_zero_row2(L, ent[k] >> 16);
         }
         double dyr = 0.0, dyi = 0.0;
-        if (inline_mods && n_mod > 0) mods_inline(L, n_mod, i, t, vri, vii, sr, si, dyr, dyi, jac);
+        if (!NOMOD && inline_mods && n_mod > 0) mods_inline(L, n_mod, i, t, vri, vii, sr, si, dyr, dyi, jac);
         double g = a.yd.x, b = a.yd.y;
         const double v2 = vri * vri + vii * vii;
         const double yr = g * v2 + dyr, yi = -b * v2 + dyi;
         if (t != BT_REF) {
           const double pc = sr + yr, qc = si + yi;
           const double fp = pc - p_sched;
-          const double fq = (t == BT_PV) ? 0.0 : qc - q_sched;
+          const double fq = (!NOPV && t == BT_PV) ? 0.0 : qc - q_sched;
           L.rhs[i] = -fp;
           L.rq[i] = -fq;
           my = nn_max(my, nn_max(fabs(fp), fabs(fq)));
           Blk jb{-si, yr + pc, sr, yi + qc};
-          if (t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
+          if (!NOPV && t == BT_PV) { jb.a21 = 0.0; jb.a22 = 1.0; }
           if (jac) st_blk2<PK>(L, a.dw & 0xFFFF, jb);
         } else {
           L.rhs[i] = sr + yr;
@@ -1523,7 +1537,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
     OPFX_STAMP(12);
     if (!(DC && dcp)) {
-    if (n_mod > 0 && !inline_mods) {
+    if (!NOMOD && n_mod > 0 && !inline_mods) {
       team_sync<MEM>();
       if (wave == 0) { dead_rows_patch<PK>(P, L, lane, jac); mem_fence<MEM>(); mods_apply(L, lane, n_mod, jac); }
       team_sync<MEM>();
@@ -1639,11 +1653,12 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
 // (Re)start an instance: flat/shift-aware start voltages and the grid's bus types.
 // A bus that an earlier solve of this instance pinned at a reactive limit gets
 // its generator share removed from q_sp again (L.bt must hold valid codes).
-template <int V2>
+template <int V2, int SPEC = 0>
 __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
-                             const double* qg_max, bool enforce_q_lims) {
+                             const double* qg_max, bool pin_point_ranges) {
+  constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0;           // (no PV bus: nothing is ever pinned at a reactive limit)
   for (int i = lane; i < P.nb; i += WAVE) {
-    const int t = L.bt[i];
+    const int t = NOPV ? BT_PQ : L.bt[i];
     if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];
     if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
     if (!V2) { L.vm[i] = P.vm_set[i]; L.va[i] = P.va_set[i]; }
@@ -1651,8 +1666,9 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
     int bt0 = P.bus_type[i];
     // A generator whose reactive range is a single point (eco_dispatch.py:86-88 sets
     // min_q = max_q = 0) always ends at that limit after the first enforce_q_lims pass
-    // (unless its free Q happens to equal it exactly): start it there, one solve saved.
-    if (bt0 == BT_PV && enforce_q_lims && qg_min != nullptr && qg_min[i] == qg_max[i]) {
+    // (unless its free Q happens to equal it exactly): start it there, one solve saved
+    // (opfx_solve_opts.enforce_q_lims = 1; = 2 walks pypower's path: every generator starts as PV).
+    if (!NOPV && bt0 == BT_PV && pin_point_ranges && qg_min != nullptr && qg_min[i] == qg_max[i]) {
       bt0 = BT_PQ_HI;
       L.qsp[i] += qg_max[i];
     }
@@ -1714,7 +1730,7 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 // DC: compiled with the DC start (opfx_solve_opts.init).  A template parameter, i.e. kernels of their own: with the DC
 // code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
 // in the wave teams) although the region runs once per solve.
-template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC = 0>
 __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
                                int* min_piv_bus, int isl_state = 0) {
@@ -1734,11 +1750,11 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
     int pb_ = -1;
     // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0);
-    else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0) : newton(P, L, o, lane, out_br, &it, nrm);
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM, SPEC>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0);
+    else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0, SPEC>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (pv_ == pv_ && pv_ < *min_piv) { *min_piv = pv_; *min_piv_bus = pb_; }
-    if (!conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
+    if ((SPEC & SPEC_NO_PV) || !conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
     // generator reactive output at PV buses: Qg = Qcalc - q_inj(non-generator)
     int changed = 0;
     sec_sync<NW>();
@@ -1785,10 +1801,11 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 // `lane` / `stride`: the calling thread's index and the number of threads that share the work (a wavefront,
 // or the whole wave team)
-template <int V2>
+template <int V2, int SPEC = 0>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle, int stride = WAVE) {
+  constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
   double* r_va = R + nb;
@@ -1805,13 +1822,13 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     const int t = L.bt[i];
     double qgen = 0.0;
-    if (t == BT_DEAD) {                      // de-energised: no voltage (NaN as in pandapower's res_bus)
+    if (!NOMOD && t == BT_DEAD) {        // de-energised: no voltage (NaN as in pandapower's res_bus)
       r_vm[i] = __builtin_nan(""); r_va[i] = __builtin_nan("");
     } else if (V2 && t == BT_REF) {
       const int ro = P.ref_ord[i];
       r_pe[ro] = (L.rhs[i] - L.psp[i]) * base;          // (V2: rhs/rq are separate arrays)
       r_qe[ro] = (L.rq[i] - L.qsp[i]) * base;
-    } else if (t == BT_REF || t == BT_PV) {
+    } else if ((!V2 && t == BT_REF) || (!NOPV && t == BT_PV)) {
       double ir = 0.0, ii = 0.0;
       for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
         const int j = P.y_col[e];
@@ -1825,7 +1842,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
         ir += g * L.vr[j] - b * L.vi[j];
         ii += g * L.vi[j] + b * L.vr[j];
       }
-      if (V2) mods_row_current(L, n_mod, i, ir, ii);
+      if (V2 && !NOMOD) mods_row_current(L, n_mod, i, ir, ii);
       const double pc = L.vr[i] * ir + L.vi[i] * ii, qc = L.vi[i] * ir - L.vr[i] * ii;
       if (t == BT_REF) {
         const int ro = P.ref_ord[i];
@@ -1834,9 +1851,9 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
       } else {
         qgen = (qc - L.qsp[i]) * base;
       }
-    } else if (t == BT_PQ_HI) {
+    } else if (!NOPV && t == BT_PQ_HI) {
       qgen = qg_max[i] * base;
-    } else if (t == BT_PQ_LO) {
+    } else if (!NOPV && t == BT_PQ_LO) {
       qgen = qg_min[i] * base;
     }
     r_qg[i] = qgen;
@@ -1847,7 +1864,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
 #pragma unroll
     for (int q = 0; q < 8; ++q) y[q] = P.br_y[8 * k + q];
     bool removed = !V2 && k == out_br;
-    if (V2) for (int m = 0; m < n_mod; ++m) {
+    if (V2 && !NOMOD) for (int m = 0; m < n_mod; ++m) {
       const int* id = mod_ids(L, m);
       if (id[6] != k) continue;
       const double* dy = mod_dy(L, m);
@@ -1858,7 +1875,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     // |V| of a de-energised bus is NaN and so is every current computed with it (pandapower divides the
     // branch's apparent power by it), in service or not
     const int f = P.br_f[k], t = P.br_t[k];
-    if (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD) { r_ld[k] = __builtin_nan(""); continue; }
+    if (!NOMOD && (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD)) { r_ld[k] = __builtin_nan(""); continue; }
     if (!removed) {
       const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
       const double ifr = y[0] * vfr - y[1] * vfi + y[2] * vtr - y[3] * vti;
@@ -1952,7 +1969,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
         L.qsp[i] = io.q_inj[b * P.nb + i];
         L.bt[i] = BT_PQ;
       }
-      init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims != 0);
+      init_voltage<V2>(P, L, lane, io.qg_min, io.qg_max, o.enforce_q_lims == 1);
     }
     const int out_br = io.outage ? io.outage[b] : -1;
     const int n_mod = (V2 && out_br >= 0) ? 1 : 0;
@@ -2617,12 +2634,14 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC_ = 0>
 __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
   // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
   const DevEnv& E = *Ep;
+  constexpr int SPEC = V2 ? (SPEC_ | OPFX_FORCE_SPEC) : 0;      // (the first-generation kernel is not specialised)
+  constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2827,11 +2846,11 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     double nrm0 = 0.0;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
     int min_piv_bus = -1;
-    const int base_out = io.outage ? io.outage[b] : -1;
+    const int base_out = (!NOMOD && io.outage) ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
     int n_rem_base = 0, isl_br_base = -1;       // removed branches so far / one of them that islands
-    if (V2) for (int m = 0; m < E.n_bmod; ++m) {
+    if (V2 && !NOMOD) for (int m = 0; m < E.n_bmod; ++m) {
       // stamps of this branch for the instance's state (tap position, switch / in_service flag)
       const int br = as_global(E.bmod_branch)[m];
       const int st = (int)rint(src_val(xs, L.sp, as_global(E.bmod_src)[m])) - as_global(E.bmod_lo)[m];
@@ -2858,7 +2877,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
     if (base_out >= 0) { ++n_rem_base; if (P.br_island[base_out]) isl_br_base = base_out; }
     // (a reset runs the base case only: the reference's reset calls run_power_flow, opf_env.py:209-216;
     // the N-1 loop belongs to calculate_violations, security_constrained.py:37)
-    const int n_cont_run = (io.mode == 2 || io.mode == 4) ? 0 : E.n_cont;
+    const int n_cont_run = (NOMOD || io.mode == 2 || io.mode == 4) ? 0 : E.n_cont;
     for (int c = 0; c <= n_cont_run; ++c) {
       const int out_br = c == 0 ? base_out : as_global(E.cont_branch)[c - 1];
       if (c > 0 && out_br == base_out) continue;            // already out of service (:46-48)
@@ -2870,10 +2889,10 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       const bool multi = V2 != 0 && n_rem >= 2;
       const int isl = multi ? 1 : island_state(V2 != 0, n_rem, isl_br >= 0);
       if (wave == 0) {
-        init_voltage<V2>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims != 0);
+        init_voltage<V2, SPEC>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims == 1);
         if (multi) mark_islands_multi(P, L, lane, n_mod, E.qg_min, E.qg_max);
         else if (isl == 1) mark_island(P, L, lane, isl_br, E.qg_min, E.qg_max);
-        if (E.vset_src) for (int i = lane; i < nb; i += WAVE) {
+        if (!NOMOD && E.vset_src) for (int i = lane; i < nb; i += WAVE) {
           // per-instance |V| set-point of a REF / PV bus (a sampled ext_grid.vm_pu)
           const int src = as_global(E.vset_src)[i];
           if (src == NOSRC) continue;
@@ -2892,14 +2911,14 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl);
+      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD, SPEC>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) {
         conv0 = conv; iters0 = iters; nrm0 = nrm;
         if (!conv) break;
-        if (E.n_cont > 0 && wave == 0) {
+        if (!NOMOD && E.n_cont > 0 && wave == 0) {
           double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
           for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
           __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same wavefront
@@ -2916,7 +2935,7 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
-      compute_results<V2>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT);
+      compute_results<V2, SPEC>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT);
       blk_sync<NW>();
       if (wave == 0) {
       for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
@@ -2994,12 +3013,12 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
           double pw_, qv_;
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
           else {                                               // generator: zero power on a de-energised bus (results_gen.py)
-            pw_ = L.bt[pi] == BT_DEAD ? 0.0 : src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r];
+            pw_ = (!NOMOD && L.bt[pi] == BT_DEAD) ? 0.0 : src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r];
             qv_ = r_qg[pi];
           }
           csum += cost_row(E, xr, meta, as_global(E.cost_cbase)[r], pw_, qv_);
         }
-        if (isl != 0 && E.cost_bus) {
+        if (!NOMOD && isl != 0 && E.cost_bus) {
           // rare: this instance has a de-energised island.  Units on it report zero power (results_bus.py), so
           // the rows the prologue evaluated from their set-points are replaced by rows at zero power — on the
           // lane that added them, from the instance's row in global memory (the staged copy is gone)
@@ -3118,15 +3137,45 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(con
 // ---------------------------------------------------------------------------
 // host objects
 // ---------------------------------------------------------------------------
+// Device copies of the plan / environment arrays.  Small arrays are carved out of CHUNKS (one hipMalloc per 256 KB, 256-byte
+// aligned pieces) instead of one hipMalloc each: a context holds ~55 arrays and an allocation costs at least a page table
+// entry's worth of memory and tens of microseconds — 2.5 MB and 55 calls per context before, which is what the 256 cached
+// plans of the batch-1 plug-in and the 64 topology twins of a bus-bus-switch environment multiplied
+// (tests/test_gpu_footprint.py).  `ptrs`: buffers allocated on their own (scratch rows that grow, the probe's stamps).
 struct DevArena {
   std::vector<void*> ptrs;
-  ~DevArena() { for (void* p : ptrs) (void)hipFree(p); }
+  std::vector<void*> chunks;
+  char* cur = nullptr;
+  size_t left = 0;
+  static constexpr size_t CHUNK = 256 * 1024, ALIGN = 256;
+  ~DevArena() { for (void* p : ptrs) (void)hipFree(p); for (void* p : chunks) (void)hipFree(p); }
+  int take(size_t bytes, void** out) {
+    bytes = (std::max<size_t>(bytes, 1) + ALIGN - 1) / ALIGN * ALIGN;
+    if (bytes > left) {
+      if (bytes >= CHUNK / 2) {              // a large array: its own allocation (the current chunk keeps its remainder)
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        chunks.push_back(d);
+        *out = d;
+        return OPFX_OK;
+      }
+      void* d = nullptr;
+      HIP_TRY(hipMalloc(&d, CHUNK));
+      chunks.push_back(d);
+      cur = static_cast<char*>(d);
+      left = CHUNK;
+    }
+    *out = cur;
+    cur += bytes;
+    left -= bytes;
+    return OPFX_OK;
+  }
   template <typename T>
   int put(const T* host, size_t n, const T** dev) {
     *dev = nullptr;
     void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)));
-    ptrs.push_back(d);
+    const int rc = take(n * sizeof(T), &d);
+    if (rc != OPFX_OK) return rc;
     if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
     *dev = static_cast<const T*>(d);
     return OPFX_OK;
@@ -3147,6 +3196,10 @@ struct opfx_ctx {
   int solve_per_cu_mem = 0;
   double* blk_mem = nullptr;           // memory-resident kernels: LU block values, one row per resident workgroup
   size_t blk_mem_rows = 0;
+  // per-workgroup scratch rows in global memory (L2), one per workgroup of the launch grid (ensure_scratch): scheduled P/Q
+  // of the workgroup's instance, and — N-1 environments only — the base-case voltages its contingency solves start from
+  double *pq = nullptr, *warm = nullptr;
+  size_t pq_rows = 0, warm_rows = 0;
   opfx_plan plan;     // host copy
   DevPlan dp{};
   const DevPlan* d_dp = nullptr;   // device copy of dp (kernels take it by pointer)
@@ -3166,7 +3219,9 @@ struct opfx_env {
 
   DevArena arena;
   size_t lds_bytes = 0;
-  int per_cu = 0;
+  int per_cu = 0;        // resident workgroups per CU of the kernel that ran last (report: opfx_env_get_info)
+  int per_cu_spec[4] = {0, 0, 0, 0};   // ... cached per specialisation of the plain step kernel (SPEC)
+  int spec = 0;          // SPEC bits the environment itself allows (opfx_env_create)
   int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
   int per_cu_chord = 0;  // (and for those compiled with chord steps)
   bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
@@ -3263,6 +3318,25 @@ static bool wants_mem(const opfx_debug_opts& dbg, size_t lds_resident, bool v2) 
   return v2 && (lds_resident > 160 * 1024 || dbg.force_mem != 0);    // (force_mem: developer / test switch)
 }
 static size_t blk_mem_stride(const opfx_plan& p) { return 4 * ((((size_t)p.n_blk + 1) & ~(size_t)1)); }
+// Rows for `grid` workgroups (a batch-1 context needs ONE; a full launch n_cu x resident workgroups per CU <= 16).  Grown by
+// doubling; a smaller buffer stays with the arena until the context goes (a launch in flight may still use it).
+static int grow_rows(opfx_ctx* ctx, double** buf, size_t* have, size_t rows, size_t row_doubles, const char* what) {
+  if (rows <= *have) return OPFX_OK;
+  const size_t cap = (size_t)ctx->n_cu * 16;
+  const size_t want = std::min(std::max(rows, 2 * *have), std::max(cap, rows));
+  void* d = nullptr;
+  if (hipMalloc(&d, want * row_doubles * sizeof(double)) != hipSuccess) { opfx_set_error(std::string("hipMalloc(") + what + ") failed"); return OPFX_ERR_HIP; }
+  ctx->arena.ptrs.push_back(d);
+  *buf = static_cast<double*>(d);
+  *have = want;
+  return OPFX_OK;
+}
+static int ensure_scratch(opfx_ctx* ctx, int grid, bool warm) {
+  const size_t nbe = ((size_t)ctx->plan.nb + 1) & ~(size_t)1;
+  int rc = grow_rows(ctx, &ctx->pq, &ctx->pq_rows, (size_t)grid, 2 * nbe, "P/Q scratch");
+  if (rc == OPFX_OK && (warm || ctx->dbg.stamps)) rc = grow_rows(ctx, &ctx->warm, &ctx->warm_rows, (size_t)grid, 2 * (size_t)ctx->plan.nb, "warm-start scratch");
+  return rc;
+}
 static int ensure_blk_mem(opfx_ctx* ctx, int rows) {
   if ((size_t)rows <= ctx->blk_mem_rows) return OPFX_OK;
   void* d = nullptr;
@@ -3337,20 +3411,11 @@ extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_
   d.tail_m = p->tail_m; d.tail_n = (int)p->tail_ids.size();
   if (rc == OPFX_OK) rc = A.put(p->tail_bus, &d.tail_bus);
   if (rc == OPFX_OK) rc = A.put(p->tail_ids, &d.tail_ids);
+  d.warm = nullptr; d.pq = nullptr;          // (per-workgroup scratch rows: sized by the launch grid, ensure_scratch)
   {
-    void* ws = nullptr;
-    const size_t n_ws = (size_t)c->n_cu * 16 * 2 * (size_t)p->nb;
-    if (hipMalloc(&ws, n_ws * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(warm-start scratch) failed"); return OPFX_ERR_HIP; }
-    A.ptrs.push_back(ws);
-    d.warm = static_cast<double*>(ws);
-    void* pq = nullptr;
-    const size_t nbe = ((size_t)p->nb + 1) & ~(size_t)1;
-    if (hipMalloc(&pq, (size_t)c->n_cu * 16 * 2 * nbe * sizeof(double)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(P/Q scratch) failed"); return OPFX_ERR_HIP; }
-    A.ptrs.push_back(pq);
-    d.pq = static_cast<double*>(pq);
     void* qu = nullptr;
-    if (hipMalloc(&qu, 2 * sizeof(int)) != hipSuccess || hipMemset(qu, 0, 2 * sizeof(int)) != hipSuccess) { delete c; opfx_set_error("hipMalloc(work queue) failed"); return OPFX_ERR_HIP; }
-    A.ptrs.push_back(qu);
+    if (rc == OPFX_OK) rc = A.take(2 * sizeof(int), &qu);
+    if (rc == OPFX_OK && hipMemset(qu, 0, 2 * sizeof(int)) != hipSuccess) { delete c; opfx_set_error("hipMemset(work queue) failed"); return OPFX_ERR_HIP; }
     d.queue = static_cast<int*>(qu);
   }
   {
@@ -3401,6 +3466,9 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     dp.blk_mem = ctx->blk_mem; dp.blk_mem_stride = (long long)blk_mem_stride(ctx->plan);
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
     o.reuse_tol = 0.0;                                            // (nor chord steps)
+    rc = ensure_scratch(ctx, grid, false);
+    if (rc != OPFX_OK) return rc;
+    dp.pq = ctx->pq; dp.warm = ctx->warm;
     SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, min_pivot_bus, 0};
     if ((io.queued = use_queue(ctx->dbg, B, grid, 4))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * 4), lds, static_cast<hipStream_t>(stream), dp, io, o, (long long)B);
@@ -3432,6 +3500,9 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     if (rc != OPFX_OK) return rc;
   }
   if (o.init == OPFX_INIT_DC || !ctx->v2) o.reuse_tol = 0.0;
+  rc = ensure_scratch(ctx, grid, false);
+  if (rc != OPFX_OK) return rc;
+  dp.pq = ctx->pq; dp.warm = ctx->warm;
   SolveIO io{p_inj, q_inj, qg_min, qg_max, outage, vm, va, loading, s_ref, q_gen, max_mismatch, converged, iterations, min_pivot, min_pivot_bus, 0};
   if ((io.queued = use_queue(ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(ctx->dp.queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), lds, static_cast<hipStream_t>(stream), dp, io, o,
@@ -3672,6 +3743,9 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
   if (rc == OPFX_OK) rc = A.put(&e->de, 1, &e->d_de);
   if (rc == OPFX_OK) { const int zero[2] = {0, 0}; const int* q = nullptr; rc = A.put(zero, 2, &q); e->queue = const_cast<int*>(q); }
   if (rc != OPFX_OK) { delete e; return rc; }
+  // what this environment fixes for the whole batch (SPEC): no PV bus in the plan; no branch-state column, no contingency and no
+  // per-instance |V| set-point in the descriptor (an outage array arrives with the call: do_step)
+  e->spec = (p.npv == 0 ? SPEC_NO_PV : 0) | ((d->n_bmod == 0 && d->n_cont == 0 && !E.vset_src) ? SPEC_NO_MOD : 0);
   e->lds_bytes = choose_block_storage(p, ctx->dbg, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, env_nacc(d->nc), E.max_mod, nf); }, &e->n_full);
   if (wants_mem(ctx->dbg, e->lds_bytes, ctx->v2)) {
     e->mem = true;
@@ -3683,6 +3757,13 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
 }
 
 extern "C" void opfx_env_destroy(opfx_env* env) { delete env; }
+
+using StepKernel = void (*)(const DevPlan, const DevEnv*, StepIO, Opts, long long);
+template <int SPEC>
+static StepKernel step_kernel(bool packed, int team) {
+  return packed ? (team == 4 ? k_step<2, 4, false, false, false, SPEC> : (team == 2 ? k_step<2, 2, false, false, false, SPEC> : k_step<2, 1, false, false, false, SPEC>))
+                : (team == 4 ? k_step<1, 4, false, false, false, SPEC> : (team == 2 ? k_step<1, 2, false, false, false, SPEC> : k_step<1, 1, false, false, false, SPEC>));
+}
 
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                    int32_t mode, void* stream) {
@@ -3696,11 +3777,15 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   DevPlan dp = env->ctx->dp;
   dp.nfull = env->n_full;
   const bool packed = env->n_full < env->ctx->plan.n_blk;
-  auto kern = !env->ctx->v2 ? k_step<0, 1>
-            : packed ? (team == 4 ? k_step<2, 4> : (team == 2 ? k_step<2, 2> : k_step<2, 1>))
-                     : (team == 4 ? k_step<1, 4> : (team == 2 ? k_step<1, 2> : k_step<1, 1>));
+  // the specialisation of this launch (SPEC): what the environment fixes for the whole batch, less what the call brings along
+  int spec = env->ctx->v2 && !env->mem ? env->spec : 0;
+  if (io->outage) spec &= ~SPEC_NO_MOD;
+  StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
+                  : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
+                  : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
   if (env->mem) kern = k_step<1, 4, false, true>;
-  int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu, WAVE * team);
+  int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_spec[spec], WAVE * team);
+  env->per_cu = env->per_cu_spec[spec];
   if (rc != OPFX_OK) return rc;
   if (env->mem) {
     rc = ensure_blk_mem(env->ctx, env->per_cu * env->ctx->n_cu);
@@ -3735,6 +3820,9 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   s.terminated = io->terminated; s.truncated = io->truncated; s.valids = io->valids;
   s.converged = io->converged; s.iterations = io->iterations; s.mode = mode;
   s.total_iterations = io->total_iterations; s.min_pivot = io->min_pivot; s.min_pivot_bus = io->min_pivot_bus;
+  rc = ensure_scratch(env->ctx, grid, env->de.n_cont > 0);
+  if (rc != OPFX_OK) return rc;
+  dp.pq = env->ctx->pq; dp.warm = env->ctx->warm;
   dp.queue = env->queue;
   if ((s.queued = use_queue(env->ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(env->queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),
@@ -4019,13 +4107,13 @@ extern "C" int opfx_reset(opfx_env* env, int64_t B, const opfx_reset_io* io, voi
 // (100 MHz) at its last instance, instances and Newton iterations it processed since the last read, wall clock at its
 // start, HW_ID and XCC_ID registers (six doubles per workgroup); clears them
 extern "C" int opfx_debug_read_finish(opfx_ctx* ctx, double* out3, int n_wg) {
-  if (!ctx || !ctx->dp.warm) return OPFX_ERR_INVALID;
+  if (!ctx || !ctx->warm || (size_t)n_wg > ctx->warm_rows) return OPFX_ERR_INVALID;
   HIP_TRY(hipDeviceSynchronize());
   const size_t stride = 2 * (size_t)ctx->plan.nb;
   std::vector<double> row(3);
   for (int g = 0; g < n_wg; ++g) {
-    HIP_TRY(hipMemcpy(out3 + 6 * g, ctx->dp.warm + g * stride, 6 * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(ctx->dp.warm + g * stride, 0, 6 * sizeof(double)));
+    HIP_TRY(hipMemcpy(out3 + 6 * g, ctx->warm + g * stride, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->warm + g * stride, 0, 6 * sizeof(double)));
   }
   return OPFX_OK;
 }

@@ -415,6 +415,9 @@ class EnvOracle:
         self.sampling_params = sampling_params or {}
         self.bus_wise_obs, self.multi_stage, self.split = bus_wise_obs, multi_stage, split
         self.initial_obj = 0.0
+        # start of every power flow: 'flat' (what the product runs by default) or 'dc' — what pandapower's default
+        # init='auto' resolves to on grids fed above 70 kV; same solution, other iteration counts
+        self.init = 'flat'
 
     def costs(self):
         return np.asarray(self.objective_fn(self.net), float) if self.objective_fn else cost_vector(self.net)
@@ -423,7 +426,7 @@ class EnvOracle:
         """One `run_power_flow` (opf_env.py:646-662).  `solve_iterations` collects the Newton iterations of every
         successful call since the last reset()/step() began (base case first, then the contingencies)."""
         try:
-            sol = pf_oracle.runpp(self.net, enforce_q_lims=self.enforce_q_lims)
+            sol = pf_oracle.runpp(self.net, enforce_q_lims=self.enforce_q_lims, init=self.init)
             self.solve_iterations.append(int(sol['iterations']))
             return True
         except pf_oracle.LoadflowNotConverged:

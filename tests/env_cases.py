@@ -6,7 +6,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
-from scenarios import EPISODE_STEPS, SCENARIOS  # noqa: E402
+from scenarios import EPISODE_STEPS, PRODUCT_KWARGS, SCENARIOS  # noqa: E402
 
 SINGLE_STEP = [n for n in SCENARIOS if n not in EPISODE_STEPS]
 
@@ -21,6 +21,7 @@ def golden(name):
 def product_env(name, batch_size=1, defer_device=False, **extra):
     cls, kwargs, _, seed = SCENARIOS[name]
     kw = dict(kwargs)
+    kw.update(PRODUCT_KWARGS.get(name, {}))
     kw.update(extra)
     return getattr(product_envs, cls)(seed=seed, batch_size=batch_size, defer_device=defer_device, **kw)
 
@@ -86,3 +87,26 @@ def mixed_modes(name, g, prefix=''):
     p = (kwargs.get('sampling_params') or {}).get('data_probabilities', (0.5, 0.75, 1.0))
     r = g[prefix + 'interp'][:, 0]
     return (r >= p[0]).astype(np.int32) + (r >= p[1]).astype(np.int32)
+
+
+def _oracle_rows_worker(args):
+    """(worker process) reset + step of the oracle environment for a share of the rows: [(row, obs at reset, step output)]."""
+    name, items = args
+    orc = oracle_env(name)
+    out = []
+    for k, step, uni, act in items:
+        ob0 = orc.reset(int(step), uni if uni is not None else ())
+        out.append((k, ob0, orc.step(act)))
+    return out
+
+
+def oracle_rows_parallel(name, steps, uniform, actions, rows, n_proc=8):
+    """The oracle's reset + step of `rows` in `n_proc` worker processes (spawned: the caller may hold a GPU context) — the
+    N-1 configuration costs ~3 s of oracle per row.  Returns {row: (obs at reset, step output)}."""
+    import multiprocessing as mp
+    rows = [int(k) for k in rows]
+    shares = [rows[w::n_proc] for w in range(n_proc)]
+    jobs = [(name, [(k, steps[k], None if uniform is None else uniform[k], actions[k]) for k in share]) for share in shares if share]
+    with mp.get_context('spawn').Pool(len(jobs)) as pool:
+        parts = pool.map(_oracle_rows_worker, jobs)
+    return {k: (ob0, ref) for part in parts for k, ob0, ref in part}

@@ -87,7 +87,7 @@ n_before = len(notices.lines)
 fast = BatchedOpfEnv.from_reference(ref_env, defer_device=True, seed=seed)                   # (same settings again: no second notice)
 faithful = BatchedOpfEnv.from_reference(ref_env, defer_device=True, seed=seed, reference_faithful=True)
 quiet = len(notices.lines) == n_before
-ok = said and quiet and set(fast.reference_deviations) == {'init', 'contingency_start', 'carry_over_state'} \
+ok = said and quiet and set(fast.reference_deviations) == {'init', 'contingency_start', 'carry_over_state', 'pin_point_q_ranges'} \
     and faithful.reference_deviations == {} and faithful.init == 'dc' and faithful.solve_opts.contingency_start == 1 \
     and faithful.carry_over_state and fast.init == 'flat' and fast.solve_opts.contingency_start == 0
 print(f'{"solver-settings notice":22s} {"same definition" if ok else "DIFFERENT"}  ({len(notices.lines)} notices; said={said}, quiet={quiet})')

@@ -27,7 +27,8 @@ import numpy as np  # noqa: E402
 import opfgym.envs  # noqa: E402,F401  (reference)
 import opfgym.examples.security_constrained as ref_sc_example  # noqa: E402
 import opfgym.security_constrained as ref_sc  # noqa: E402
-from scenarios import E12_SCENARIOS, EPISODE_START_STEPS, EPISODE_STEPS, SCENARIOS, TRACKED, VALID_ROWS  # noqa: E402
+from scenarios import (CANDIDATE_STEPS, E12_SCENARIOS, EPISODE_START_STEPS, EPISODE_STEPS, FAILED_CONTINGENCY_ROWS,  # noqa: E402
+                       SCENARIOS, TRACKED, VALID_ROWS)
 import opfgym.examples.multi_stage as ref_ms  # noqa: E402
 import opfgym.examples.network_reconfiguration as ref_nr  # noqa: E402
 import opfgym.examples.mixed_continuous_discrete as ref_mcd  # noqa: E402
@@ -218,9 +219,23 @@ def run(name):
     # fixtures with a quota of all-valid rows (scenarios.VALID_ROWS): candidates are recorded until both kinds are full
     want_valid, levels = VALID_ROWS.get(name, (None, ()))
     have = {True: 0, False: 0}
+    # quota of rows with a FAILED contingency (scenarios.FAILED_CONTINGENCY_ROWS): the power flows that raise inside the
+    # reference's step are counted at the stub's `runpp`
+    import pandapower as pp_stub
+    want_failed, have_failed, n_raised = FAILED_CONTINGENCY_ROWS.get(name, 0), 0, [0]
+    stub_runpp = pp_stub.runpp
+
+    def counting_runpp(*a, **kw_):
+        try:
+            return stub_runpp(*a, **kw_)
+        except pp_stub.powerflow.LoadflowNotConverged:
+            n_raised[0] += 1
+            raise
+    pp_stub.runpp = counting_runpp
+    first_steps = list(CANDIDATE_STEPS.get(name, ()))
     while done < n:
         k += 1
-        step = int(rng.choice(pool))
+        step = int(first_steps.pop(0)) if first_steps else int(rng.choice(pool))
         found = None
         if want_valid is not None and have[True] < want_valid and (k % 2 == 1 or have[False] >= n - want_valid):
             # look for an all-valid state along one scalar action level (see scenarios.VALID_ROWS); every trial is the
@@ -249,7 +264,13 @@ def run(name):
             action = np.clip(action * 1.6 - 0.3, -0.2, 1.2)        # exercise the [0,1] clipping
         snap = snapshot(env.net)
         init_obj = np.sum(env.initial_obj) if env.pf_for_obs else None
+        n_raised[0] = 0
         obs, reward, terminated, truncated, info = env.step(action)
+        failed_contingencies = n_raised[0] if 'cost' in info else 0
+        if want_failed and 'cost' in info:
+            if failed_contingencies == 0 and n - done <= want_failed - have_failed:
+                continue                                           # the rows still to record must be ones with a failure
+            have_failed += failed_contingencies > 0
         if 'cost' not in info:
             # power flow failed (opf_env.py:390-399): keep the inputs as a failure case
             push('fail_step', step)
@@ -284,6 +305,8 @@ def run(name):
         push('violations', info['violations'])
         push('penalties', info['unscaled_penalties'])
         push('cost', info['cost'])
+        if want_failed:
+            push('failed_contingencies', failed_contingencies)
         push('objective_vector', env.calculate_objective(diff_objective=False))
         push('vm_pu', env.net.res_bus.vm_pu.to_numpy())
         push('va_degree', env.net.res_bus.va_degree.to_numpy())
@@ -299,12 +322,16 @@ def run(name):
                          ('switch', 'closed'), ('trafo', 'tap_pos'), ('shunt', 'step')):
             if tbl in env.net and len(env.net[tbl]) and col in env.net[tbl].columns:
                 push(f'post__{tbl}__{col}', np.array(env.net[tbl][col].to_numpy(dtype=float), copy=True))
+    pp_stub.runpp = stub_runpp
     out = {k: np.stack(v) for k, v in rec.items()}
     out['n_obs'] = np.array(env.observation_space.shape[0])
     out['obs_low'], out['obs_high'] = env.observation_space.low, env.observation_space.high
     out['n_act'] = np.array(env.action_space.shape[0])
     out['n_bus'] = np.array(len(env.net.bus))
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    if want_failed:
+        print(f'{name}: failed contingencies per sample {out["failed_contingencies"].tolist()}, base-case failures '
+              f'{len(out["fail_step"]) if "fail_step" in out else 0}')
     print(f'{name}: {n} samples, obs {out["obs_step"].shape}, reward {out["reward"].round(4)}, '
           f'valid {out["valids"].all(axis=1)}')
 

@@ -102,7 +102,12 @@ SCENARIOS.update({
     # a grid with a three-winding transformer: Trafo3wOverloadConstraint among the defaults (constraints.py:164-172,210)
     'vc_mv_3w': ('VoltageControl', dict(simbench_network_name='mv-3w'), 5, 33),
     'sc_vc_hv_urban': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
-                                                                 n_minus_one_lines='all'), 2, 32),
+                                                                 n_minus_one_lines='all'), 6, 32),
+    # the same N-1 problem next to voltage collapse (loads scaled 4.6 instead of 1.5: the base case still solves, a part of
+    # the 250 contingency cases does not): rows with FAILED contingencies — the +penalty sign of defect D6, `valids` all
+    # False, security_constrained.py:59-63 — recorded from the reference itself (FAILED_CONTINGENCY_ROWS below)
+    'sc_vc_hv_urban_stress': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
+                                                                        n_minus_one_lines='all', load_scaling=4.6), 3, 36),
     # the same N-1 problem with a reactive exchange band an HV grid can meet (the reference's default of +-0.5 Mvar is an
     # MV figure: on the 372-bus grid no action keeps all 251 cases inside it): valid AND invalid states of config 5's kind
     'sc_vc_hv_urban_wide': ('SecurityConstrainedVoltageControl', dict(simbench_network_name='1-HV-urban--0-sw',
@@ -126,6 +131,16 @@ VALID_ROWS = {
     'vc_parameterized': (4, _levels(0.30, 0.70, 0.01)),
     'sc_vc_hv_urban_wide': (2, [0.5, 0.49, 0.51]),
 }
+
+# Fixtures that must hold rows in which a contingency's power flow FAILS while the base case converges: name -> how many of
+# the n samples; the generator counts the LoadflowNotConverged raised inside the reference's N-1 loop.
+FAILED_CONTINGENCY_ROWS = {'sc_vc_hv_urban_stress': 2}
+# explicit time steps to try first (else drawn from the training steps): heavy-load steps of the stand-in profiles
+CANDIDATE_STEPS = {'sc_vc_hv_urban_stress': [30976, 14521, 21626]}
+# solver settings of the PRODUCT environment that replays a fixture (not arguments of the reference's classes).  The fixtures
+# are recorded with every power flow started flat (the stub's runpp); next to collapse WHICH contingencies converge depends
+# on the start, so the replay must start the contingencies the same way
+PRODUCT_KWARGS = {'sc_vc_hv_urban_stress': dict(contingency_start='flat')}
 
 # E12 (`estimate_reward_distribution`, reward.py:181-216): fixture name -> (scenario whose environment is sampled, samples)
 E12_SCENARIOS = {'e12_vc_mv_small': ('vc_mv_small', 64), 'e12_sc_hv_small': ('sc_hv_small', 24),

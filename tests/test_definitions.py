@@ -103,11 +103,13 @@ def test_reference_faithful_is_one_switch_and_explicit_options_win():
     from opfgym_amd import envs
     kw = dict(simbench_network_name='hv-small', batch_size=1, defer_device=True, seed=0)
     fast = envs.EcoDispatch(**kw)
-    assert fast.reference_deviations == {'init': 'flat', 'contingency_start': 'base_case', 'carry_over_state': False}
+    assert fast.reference_deviations == {'init': 'flat', 'contingency_start': 'base_case', 'carry_over_state': False, 'pin_point_q_ranges': True}
+    assert fast.solve_opts.enforce_q_lims == 1
     assert fast.init == 'flat' and fast.solve_opts.contingency_start == 0 and not fast.carry_over_state and not fast.reference_faithful
     ref = envs.EcoDispatch(reference_faithful=True, **kw)
     assert ref.reference_deviations == {} and ref.reference_faithful
     assert ref.init == 'dc' and ref.solve_opts.init == 1 and ref.solve_opts.contingency_start == 1 and ref.carry_over_state
+    assert ref.solve_opts.enforce_q_lims == 2 and not ref.pin_point_q_ranges          # (pypower's own q-limit path)
     mixed = envs.EcoDispatch(reference_faithful=True, init='flat', **kw)
     assert mixed.reference_deviations == {'init': 'flat'} and mixed.init == 'flat' and mixed.solve_opts.contingency_start == 1
     # below 70 kV pandapower's 'auto' IS the flat start

@@ -201,7 +201,7 @@ def _mixed_actions(env, rng, B, rows, lo, hi, reset_options, n_levels=25):
     return actions
 
 
-def _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows):
+def _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows, precomputed=None):
     """The full step of every row of `rows` against the oracle — no allowance: the converged flags must be the oracle's
     (the non-converged SET is compared, not a fraction), every converged row is checked.  Returns (valid, invalid) counts.
     (The device buffers are copied to the host once, the rows compared there.)"""
@@ -220,9 +220,12 @@ def _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, row
             return tables[(tbl, col)]
     n_valid = n_invalid = 0
     for j, k in enumerate(rows):
-        ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        if precomputed is not None:                  # (the oracle's rows came from worker processes: env_cases.oracle_rows_parallel)
+            ob0, ref = precomputed[int(k)]
+        else:
+            ob0 = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+            ref = orc.step(actions[k])
         assert np.allclose(obs0[j], ob0, rtol=0, atol=R_TOL)
-        ref = orc.step(actions[k])
         assert bool(sub[4]['converged'][j]) == ref['converged'], k
         if not ref['converged']:
             continue
@@ -266,7 +269,7 @@ def test_full_batch_voltage_control_properties():
     assert np.array_equal(r1, _np(reward2), equal_nan=True)
 
 
-@pytest.mark.parametrize('name,B,n_check,team,levels', [('eco_hv_mixed', 8192, 128, 4, (0.0, 1.0)), ('sc_vc_hv_urban', 4096, 8, 4, None),
+@pytest.mark.parametrize('name,B,n_check,team,levels', [('eco_hv_mixed', 8192, 128, 4, (0.0, 1.0)), ('sc_vc_hv_urban', 4096, 32, 4, None),
                                                         ('eco_hv_mixed', 2048, 32, 2, (0.0, 1.0)), ('qm_mv_urban', 65536, 512, 1, (0.40, 0.70))])
 def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
@@ -274,7 +277,8 @@ def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     developer switch OPFX_TEAM) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
     contingency (B = 4096 x 251 solves, four wavefronts per instance); BASELINE config 4 at its full size as well
     (QMarket, 144 buses, B = 65536: every wavefront walks 32 instances).  All rows:
-    size-independent properties; `n_check` rows spread over the batch (128 / 8 / 32 / 512: VERDICT r03 #1b), valid and
+    size-independent properties; `n_check` rows spread over the batch (128 / 32 / 32 / 512; the N-1 rows — 251 oracle power flows
+    each — in eight worker processes: VERDICT r04 #8), valid and
     invalid states among them: the full step against the oracle, no row skipped, the converged flags equal the oracle's."""
     if team == 2:
         monkeypatch.setenv('OPFX_TEAM', '2')
@@ -309,10 +313,49 @@ def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
     obs0 = obs0.clone()
     out = env.step(actions)
-    n_valid, n_invalid = _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows)
+    pre = None
+    if env.n_minus_one_keys:
+        from env_cases import oracle_rows_parallel
+        pre = oracle_rows_parallel(name, steps, uniform, actions, rows, n_proc=8)
+    n_valid, n_invalid = _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows, precomputed=pre)
     if levels:
         assert n_valid >= n_check // 32 and n_invalid >= n_check // 4, (n_valid, n_invalid)
     assert capi_team(env) == team
+
+
+@pytest.mark.parametrize('name,B,n_check', [('vc_mv_urban', 8192, 64), ('eco_hv_mixed', 8192, 32)])
+def test_full_batch_under_the_reference_solver_settings(name, B, n_check):
+    """BASELINE configs 2 and 3 at full size with `reference_faithful=True`: pandapower's own start (`init='auto'` = a DC
+    power flow first: both stand-in grids hang on 110 kV or above).  Every row converges; on `n_check` rows
+    spread over the batch the Newton iteration count equals the oracle's DC-started Newton ROW BY ROW (the reference's
+    iteration path, not only its fixed point), and the full step — rewards, violations, observations, result tables —
+    equals the oracle's."""
+    env = product_env(name, batch_size=B, reference_faithful=True)
+    assert env.init == 'dc' and env.reference_deviations == {} and env.kernel_info()['waves_per_instance'] == (1 if name == 'vc_mv_urban' else 4)
+    orc = oracle_env(name, product_env(name, defer_device=True))
+    orc.init = 'dc'
+    rng = np.random.default_rng(29)
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    actions = rng.random((B, env.n_actions))
+    rows = np.linspace(0, B - 1, n_check).astype(int)
+    obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    obs0 = obs0.clone()
+    out = env.step(actions)
+    info = out[4]
+    assert _np(info['converged']).mean() > 0.999 and (_np(info['max_mismatch'])[_np(info['converged']).astype(bool)] < 1e-8).all()
+    its = _np(info['iterations'])
+    _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, rows)
+    for k in rows:                                   # (once more for the counts: the helper does not keep them)
+        orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        ref = orc.step(actions[k])
+        assert ref['converged'] and int(its[k]) == orc.solve_iterations[0], (k, int(its[k]), orc.solve_iterations)
+    # and the flat start reaches the same fixed point with other counts
+    flat = product_env(name, batch_size=B)
+    flat.reset(options={'step': steps, 'uniform': uniform})
+    out_f = flat.step(actions)
+    assert np.allclose(_np(out_f[1]), _np(out[1]), rtol=0, atol=1e-7, equal_nan=True)
+    assert (its != _np(out_f[4]['iterations'])).any()
 
 
 def test_contingency_start_flat_reproduces_the_reference_iteration_for_iteration():
