@@ -378,7 +378,10 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     # the binding resource: the largest fraction of its own peak (none of them can exceed 1)
     cand = {k: v['frac'] for k, v in fr.items() if k != 'fp64_useful_of_valu_busy'}
     bound = max(cand, key=cand.get)
-    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + '>'
+    # (template arguments as rocprofv3 prints them: block storage, wavefronts per instance, then DC / CHORD or — the plain
+    #  kernels — SPEC=n, the specialisation on what the environment fixes for the whole batch, opfx_env_get_spec)
+    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + \
+        (f',SPEC={ki["spec"]}' if not (dc or chord) else '') + '>'
     # what the launch really has to read and write: the instance rows of the caller's buffers
     buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
                  'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}

@@ -1833,11 +1833,13 @@ class BatchedOpfEnv:
     def kernel_info(self) -> dict:
         """Launch configuration of the fused step kernel (report / diagnostics): wavefronts per instance, LDS bytes per
         instance, instances resident per CU (0 before the first step) and whether the two-value block storage is used."""
-        team, lds, per_cu, nblk, nfour = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        team, lds, per_cu, nblk, nfour, spec = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         capi.check(capi.lib().opfx_env_get_info(self._env_handle, C.byref(team), C.byref(lds), C.byref(per_cu)), 'opfx_env_get_info')
         capi.check(capi.lib().opfx_env_get_storage(self._env_handle, C.byref(nblk), C.byref(nfour)), 'opfx_env_get_storage')
+        capi.check(capi.lib().opfx_env_get_spec(self._env_handle, C.byref(spec)), 'opfx_env_get_spec')
         return dict(waves_per_instance=team.value, lds_bytes_per_instance=lds.value, instances_per_cu=per_cu.value,
-                    packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value)
+                    packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value,
+                    spec=spec.value)          # (SPEC bits of the plain step kernel: 1 no PV bus, 2 no modifiers)
 
     MAX_RESCUE_PLANS = 8
 

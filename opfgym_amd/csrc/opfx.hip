@@ -59,6 +59,9 @@ constexpr int SPEC_NO_PV = 1, SPEC_NO_MOD = 2;
 #ifndef OPFX_FORCE_SPEC
 #define OPFX_FORCE_SPEC 0
 #endif
+#ifndef OPFX_SPEC_MASK                      // (probe builds: -DOPFX_SPEC_MASK=0|1|2 keeps only these bits of what a launch would pick)
+#define OPFX_SPEC_MASK 3
+#endif
 constexpr int MODE_SOLVE = 0;
 constexpr int MODE_ENV = 1;
 
@@ -3780,6 +3783,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   // the specialisation of this launch (SPEC): what the environment fixes for the whole batch, less what the call brings along
   int spec = env->ctx->v2 && !env->mem ? env->spec : 0;
   if (io->outage) spec &= ~SPEC_NO_MOD;
+  spec &= OPFX_SPEC_MASK;
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
                   : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
@@ -3880,6 +3884,12 @@ extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instanc
   if (waves_per_instance) *waves_per_instance = env->mem ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2);
   if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
   if (instances_per_cu) *instances_per_cu = env->per_cu;
+  return OPFX_OK;
+}
+
+extern "C" int opfx_env_get_spec(const opfx_env* env, int32_t* spec) {
+  if (!env) { opfx_set_error("opfx_env_get_spec: null environment"); return OPFX_ERR_INVALID; }
+  if (spec) *spec = (env->ctx->v2 && !env->mem) ? (env->spec & OPFX_SPEC_MASK) : 0;
   return OPFX_OK;
 }
 

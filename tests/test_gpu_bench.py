@@ -79,6 +79,8 @@ def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_con
         assert a['max_abs_v_err_instances'] == (8 if name == 'config5' else 64)
     assert d['also']['config5']['steps'] == 3 and d['also']['config3']['steps'] >= 5
     assert all(a['newton_start'] == 'flat' and a['contingency_start'] == 'base_case' for a in d['also'].values())
+    # the plain kernels are specialised on what each environment fixes for the whole batch (no PV bus = 1, no modifiers = 2)
+    assert [d['also'][f'config{c}']['kernel'] for c in (2, 3, 4, 5)] == ['k_step<2,1,SPEC=3>', 'k_step<1,4,SPEC=2>', 'k_step<2,1,SPEC=3>', 'k_step<2,4,SPEC=1>']
     # the same workloads at the reference's own solver settings: pandapower's init='auto' is 'dc' on all of them (every
     # stand-in hangs on 110 kV or above), contingencies from scratch; same fixed point -> same |V| check
     rs = d['reference_settings']
