@@ -445,6 +445,8 @@ def also_config(config, device, steps, warmup, **env_kw):
            'value': B * steps / wall[0], 'unit': 'env.step()/s', 'steps': steps, 'warmup': warmup,
            'ms_per_step': wall[0] / steps * 1e3, 'kernel_ms': kernel_ms, 'kernel': roof['kernel'],
            'newton_start': env.init, 'contingency_start': 'flat' if env.solve_opts.contingency_start else 'base_case',
+           'kernel_launch': {k: ki[k] for k in ('waves_per_instance', 'lds_bytes_per_instance', 'instances_per_cu')},
+           'shared_slots': env.plan.info['n_shared'],
            'nr_solves_per_s': B * solves_per_step * steps / wall[0],
            'converged_fraction': float(info['converged'].double().mean().item()),
            'mean_nr_iterations': float(info['iterations'].double().mean().item()),
@@ -633,6 +635,7 @@ def main():
                        'min_relative_pivot': min_pivot,
                        'tolerance_pu': env.solve_opts.tol, 'byte_model': bm, 'lds_model': lm,
                        'kernel_launch': {k: ki[k] for k in ('waves_per_instance', 'lds_bytes_per_instance', 'instances_per_cu')},
+                       'shared_slots': env.plan.info['n_shared'],      # fill blocks living in the LDS slot of a dead block (plan.cpp share_slots)
                        'device': {'compute_units': n_cu, 'simds': n_simd}},
             'roofline': roof,
         }

@@ -149,6 +149,9 @@ typedef struct opfx_plan_info {
   int32_t team_kb_chord[2];  /* rounds of the chord stream before the tail chain (as team_kb) */
   int32_t lp_rounds_f_pad;   /* lp_rounds_f padded to the multiple of four the stream OPFX_ARR_LP_BCC is laid out with; its
                               * back-substitution part follows with lp_rounds_c padded likewise */
+  int32_t n_shared;          /* fill blocks that live in the id (= LDS slot) of a block that is dead by then (plan.cpp share_slots;
+                              * 0: every block has an id of its own).  Such a plan runs on the wave-team kernels with full Newton
+                              * only: the single-wave and chord streams carry no zero-at-birth operations */
 } opfx_plan_info;
 
 /* Symbolic analysis on the host (no GPU needed): bus partition, Ybus block
@@ -177,7 +180,10 @@ enum {
   OPFX_ARR_LP_B2,                       /* [rb][64] right-hand-side rider of a factor item: i | k << 16 (0xFFFF both: none) */
   OPFX_ARR_LP_BCC,                      /* chord stream of the single-wave kernels: [rf_pad + rc_pad][64][4] */
   OPFX_ARR_LP_TEAMC2, OPFX_ARR_LP_TEAMC4, /* chord streams of the wave teams, laid out like OPFX_ARR_LP_TEAM2 / 4 */
-  OPFX_ARR_LP_B3                         /* [rb][64] second column of a factor item (same multiplier): target2 | A_kj2 << 16 (0xFFFF both: none) */
+  OPFX_ARR_LP_B3,                        /* [rb][64] second column of a factor item (same multiplier): target2 | A_kj2 << 16 (0xFFFF both: none) */
+  OPFX_ARR_ZERO_LEV, OPFX_ARR_ZERO_BLK   /* shared slots (opfx_plan_info.n_shared): block id ZERO_BLK[q] is set to zero during elimination level
+                                          * ZERO_LEV[q] — between the last read of the block that held the id and the first update of the fill
+                                          * block that holds it next */
 };
 /* double arrays of the lane programme: Ybus values per descriptor */
 enum { OPFX_DARR_LP_A_Y = 0, OPFX_DARR_LP_A_YDIAG, OPFX_DARR_LP_H_Y,

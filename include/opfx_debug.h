@@ -47,6 +47,11 @@ typedef struct opfx_debug_opts {
   int32_t verbose;           /* 1: launch geometry on stderr                                                    */
   int32_t stamps;            /* 1: allocate the cycle-stamp buffer (builds with -DOPFX_ENABLE_STAMPS fill it)   */
   int32_t reset_team;        /* 1 / 2 / 4: rows per workgroup of the reset kernel, when smaller than the default */
+  /* ---- plan, appended in round 5 ------------------------------------------------------------------------------ */
+  int32_t plan_share_slots;  /* 1: lower LU blocks that are dead give their LDS slot to fill blocks born later (plan.cpp share_slots;
+                              * opfx_plan_info.n_shared): less LDS per instance, for the wave-team kernels with full Newton only.
+                              * 0 (default): every block keeps a slot of its own.  opfgym_amd.BatchedOpfEnv builds such a plan
+                              * where it lets a CU hold a third instance of the grid */
 } opfx_debug_opts;
 
 int opfx_plan_create_debug(const opfx_case* c, const opfx_debug_opts* dbg, opfx_plan** out);

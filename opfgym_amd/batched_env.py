@@ -604,7 +604,43 @@ class BatchedOpfEnv:
         self.ctx = capi.Context(self.plan, self.device.index or 0)
         self._resolve_reward(allow_estimate=True)
         self._create_env()
+        self._try_shared_slots()
         self._alloc(self.batch_size)
+
+    def _try_shared_slots(self):
+        """A grid whose instance takes more than a third of a CU's LDS runs as two wave teams of four per CU, and LDS — not
+        registers or bandwidth — is what keeps a third instance out.  The plan compiler can let fill blocks that are born late
+        live in the LDS slots of lower blocks that are dead by then (`opfx_debug_opts.plan_share_slots`, plan.cpp share_slots:
+        wave-team kernels with full Newton only).  Where that brings the environment under a third of the LDS — three teams of
+        two per CU — the environment switches to such a plan; otherwise (or with chord steps, which re-read the lower blocks)
+        it keeps the one it has.  OPFX_PLAN_SHARE=0 in the process environment switches the attempt off."""
+        import os
+        if self.jacobian_reuse_tol > 0.0 or self.plan.info['n_shared'] or os.environ.get('OPFX_PLAN_SHARE') == '0' \
+                or os.environ.get('OPFX_TEAM') or os.environ.get('OPFX_FORCE_MEM') or os.environ.get('OPFX_KERNEL_V1'):
+            return
+
+        def per_cu(info):
+            return (160 * 1024) // (-(-info['lds_bytes_per_instance'] // 1024) * 1024)
+        before = self.kernel_info()
+        # (two teams of four per CU on the LDS-resident kernels: not the single-wave grids, not the grids past the LDS, whose
+        #  block values are in global memory anyway)
+        if before['waves_per_instance'] != 4 or per_cu(before) != 2 or self.plan.info['lds_doubles'] * 8 > 150 * 1024:
+            return
+        dbg = capi.DebugOpts.from_buffer_copy(self.plan.debug)
+        dbg.plan_share_slots = 1
+        shared = capi.Plan(self.case, debug=dbg, elim_last=self.plan.elim_last)
+        if not shared.info['n_shared']:
+            return
+        plain = (self.plan, self.ctx)
+        try:
+            self.plan, self.ctx = shared, capi.Context(shared, self.device.index or 0)
+            self._create_env()
+            gained = per_cu(self.kernel_info()) > per_cu(before)
+        except capi.OpfxError:
+            gained = False
+        if not gained:                                         # (nothing gained: back to the plan without shared slots)
+            self.plan, self.ctx = plain
+            self._create_env()
 
     def _resolve_reward(self, allow_estimate):
         reward_function, params = self._reward_spec                        # opf_env.py:166-175

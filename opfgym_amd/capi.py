@@ -27,7 +27,7 @@ ARRAYS = ['Y_PTR', 'Y_COL', 'Y_BLK', 'DIAG_BLK', 'FILL_BLK', 'LEV_TPTR', 'TGT_BL
           'TGT_SPTR', 'SRC_IK', 'SRC_KK', 'SRC_KJ', 'LEV_PPTR', 'PIV_BUS', 'PIV_UPTR',
           'U_BLK', 'U_COL', 'BLK_ROW', 'BLK_COL', 'LP_A_ENT', 'LP_A_DBLK', 'LP_H_ENT', 'LP_H_ROW',
           'LP_B', 'LP_C', 'BR_ISLAND', 'ISL_PTR', 'ISL_BUS', 'LP_TEAM2', 'LP_TEAM4', 'TAIL_BUS', 'TAIL_IDS', 'LP_B2',
-          'LP_BCC', 'LP_TEAMC2', 'LP_TEAMC4', 'LP_B3']
+          'LP_BCC', 'LP_TEAMC2', 'LP_TEAMC4', 'LP_B3', 'ZERO_LEV', 'ZERO_BLK']
 DARRAYS = ['LP_A_Y', 'LP_A_YDIAG', 'LP_H_Y', 'LP_DC', 'LP_H_DC']
 
 _pd = C.POINTER(C.c_double)
@@ -65,7 +65,7 @@ class PlanInfo(Sized):
         'team_rounds_2', 'team_rounds_4', 'team_barriers_2', 'team_barriers_4', 'n_groups',
         'team_kb_2', 'team_kb_4', 'tail_m', 'lp_ell_width', 'has_dc', 'lp_rounds_f', 'team_rounds_chord_2',
         'team_rounds_chord_4', 'team_barriers_chord_2', 'team_barriers_chord_4', 'team_kb_chord_2', 'team_kb_chord_4',
-        'lp_rounds_f_pad')]
+        'lp_rounds_f_pad', 'n_shared')]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_size'}
@@ -164,7 +164,7 @@ class DebugOpts(Sized):
         'plan_search', 'plan_dcap_slack', 'plan_seed', 'plan_no_bank', 'plan_no_pack', 'plan_no_riders', 'plan_no_tail',
         'plan_no_pairs',
         'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
-        'reset_team')]
+        'reset_team', 'plan_share_slots')]
 
     def any(self):
         return any(getattr(self, n) for n, _ in self._fields_ if n != 'struct_size')
@@ -195,6 +195,7 @@ def debug_from_env(environ=None) -> DebugOpts:
     d.waves_per_cu = int(e.get('OPFX_WAVES_PER_CU') or 0)
     d.verbose, d.stamps = flag('OPFX_VERBOSE'), flag('OPFX_STAMPS')
     d.reset_team = int(e.get('OPFX_RESET_TEAM') or 0)
+    d.plan_share_slots = int(e.get('OPFX_PLAN_SHARE') or 0)
     return d
 
 

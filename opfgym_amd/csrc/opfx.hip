@@ -75,6 +75,7 @@ constexpr int GETREG_HW_ID = (31 << 11) | 4, GETREG_XCC_ID = (31 << 11) | 20;
 struct DevPlan {
   int nb, nbr, nref, nblk, nlev, nfill, npv;
   int nfull;                 // blocks [0, nfull) are stored with four values (per launch: choose_block_storage)
+  int n_shared;              // > 0: some block ids are LDS slots shared over time (plan.cpp share_slots): team items carry zero stores
   int fill_lo;               // fill blocks: ids [fill_lo, fill_lo + nfill)
   double base_mva;
   const int *bus_type, *y_ptr, *y_col, *y_blk, *diag_blk, *fill_blk;
@@ -840,10 +841,20 @@ __device__ __forceinline__ void tail_solve(const Lds& L, int m, int lane, unsign
 // the plan marks independent rounds, ITEM_NEXT_INDEPENDENT — was tried and is slower: the compiler's wait-count
 // insertion treats loads that are pending across the loop's back edge conservatively and drains the LDS queue,
 // lgkmcnt(0), at the first use, so the early reads only lengthen that wait: config 3 2.27 -> 2.66 ms.)
+// zops (wave-uniform: the plan shares slots, plan.cpp share_slots): bits 2-16 of an item's word 3 name a four-value block id
+// to be set to zero during this round — the slot of a block that is dead, for the fill block that is born into it at a later
+// level (team items carry no rider there; 0x7FFF: none).
 template <bool PK, bool MEM = false>
-__device__ __forceinline__ void team_step(const Lds& L, const uint4 d) {
+__device__ __forceinline__ void team_step(const Lds& L, const uint4 d, bool zops) {
   const unsigned fl = __builtin_amdgcn_readfirstlane(d.w);        // same for every item of a round
   item_factor<PK, false, SEC_LATE>(L, d);
+  if (!MEM && zops) {        // (the memory-resident form needs no shared slots: its block values are not in LDS; refused at launch)
+    const unsigned z = (d.w >> 2) & 0x7FFFu;
+    // (stored through an explicit LDS pointer: with the generic one this ROCm's AMDGPU backend dies in two instantiations
+    //  with "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" — the LDS-to-flat cast of a uniform pointer)
+    auto* const lb = (__attribute__((address_space(3))) double*)L.blk;
+    if (z != 0x7FFFu) { lb[bx11(L, z)] = 0.0; lb[bx12(L, z)] = 0.0; lb[bx21(L, z)] = 0.0; lb[bx22(L, z)] = 0.0; }
+  }
   if (fl & ITEM_BARRIER) team_sync<MEM>(); else mem_fence<MEM>();  // (no barrier: the same wavefront carries on)
 }
 
@@ -858,8 +869,8 @@ __device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const ui
     item_apply<PK, false>(L, db, rb);
     if (fb & ITEM_BARRIER) lds_barrier(); else wave_fence();
   } else {
-    team_step<PK>(L, da);
-    team_step<PK>(L, db);
+    team_step<PK>(L, da, false);
+    team_step<PK>(L, db, false);
   }
 }
 #endif
@@ -1409,6 +1420,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   auto ld_desc = [&](int k) { return k < K ? st_cur[(size_t)k * (NW * WAVE)] : st_nxt[(size_t)(k - K) * (NW * WAVE)]; };   // unconditional (see newton2)
   const uint4* hpk = reinterpret_cast<const uint4*>(P.lp_hpk);
   double* xw = L.acc;                     // [NW] cross-wave scratch (reuses the constraint accumulators)
+  const bool zops = P.n_shared > 0;
   int it = 0;
   double nrm = 0.0;
   bool conv = false;
@@ -1576,10 +1588,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
 #else
     for (int k = 0; k < Kb; k += 4) {
-      team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
-      team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
-      team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
-      team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
+      team_step<PK, MEM>(L, q0, zops); q0 = ld_desc(k + 4);
+      team_step<PK, MEM>(L, q1, zops); q1 = ld_desc(k + 5);
+      team_step<PK, MEM>(L, q2, zops); q2 = ld_desc(k + 6);
+      team_step<PK, MEM>(L, q3, zops); q3 = ld_desc(k + 7);
     }
 #endif
     OPFX_STAMP(2);
@@ -1594,10 +1606,10 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       }
 #else
       for (int k = Kb; k < K; k += 4) {
-        team_step<PK, MEM>(L, q0); q0 = ld_desc(k + 4);
-        team_step<PK, MEM>(L, q1); q1 = ld_desc(k + 5);
-        team_step<PK, MEM>(L, q2); q2 = ld_desc(k + 6);
-        team_step<PK, MEM>(L, q3); q3 = ld_desc(k + 7);
+        team_step<PK, MEM>(L, q0, zops); q0 = ld_desc(k + 4);
+        team_step<PK, MEM>(L, q1, zops); q1 = ld_desc(k + 5);
+        team_step<PK, MEM>(L, q2, zops); q2 = ld_desc(k + 6);
+        team_step<PK, MEM>(L, q3, zops); q3 = ld_desc(k + 7);
       }
 #endif
     }
@@ -2637,8 +2649,12 @@ __device__ __forceinline__ double cost_row(const DevEnv& E, const double* xc, in
 // rows that do not depend on the solve; (2) Newton; (3) results, constraints, remaining
 // costs, reward, result observations.  Descriptor loads are batched (fixed unroll, clamped
 // indices) so that each phase pays one L2 round trip, not one per 64 items.
-template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC_ = 0>
-__global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
+// MINW: wavefronts per SIMD the kernel is compiled for (launch bounds: 2 -> up to 256 VGPRs, 3 -> 168).  Three is for ONE case,
+// measured in round 5: a grid whose instance takes just under a third of the LDS (the 306-bus grid on a plan with shared slots)
+// runs 13.7 % faster as three teams of FOUR per CU — twelve wavefronts, 168 VGPRs and 216 B of scratch per lane — than as two
+// teams of four at 216 VGPRs without scratch, and 10 % faster than as three teams of two (profiles/r05_ab_three_teams.txt).
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC_ = 0, int MINW = OPFX_MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const DevEnv* __restrict__ Ep, StepIO io, Opts o,
                                                   long long B) {
   // The environment descriptor (about 50 pointers) stays in memory and is read where it is
   // needed: held in SGPRs it would be spilled to VGPR lanes across the whole Newton loop.
@@ -3273,13 +3289,14 @@ int use_queue(const opfx_debug_opts& dbg, long long B, int grid, int team) {
   return dbg.queue ? dbg.queue > 0 : B >= (team > 1 ? 8LL : 12LL) * grid;
 }
 
-int pick_team(const opfx_debug_opts& dbg, size_t lds, bool v2) {
+// shared: the plan shares LDS slots over time (plan.cpp share_slots): wave teams only (their items carry the zero stores)
+int pick_team(const opfx_debug_opts& dbg, size_t lds, bool v2, bool shared = false) {
   if (!v2) return 1;
-  if (dbg.team == 1 || dbg.team == 2 || dbg.team == 4) return dbg.team;
+  if (dbg.team == 2 || dbg.team == 4 || (dbg.team == 1 && !shared)) return dbg.team;
   const size_t granule = 1024;
   const int inst = (int)((160 * 1024) / ((lds + granule - 1) / granule * granule));
   if (inst <= 2) return 4;
-  if (inst <= 4) return 2;
+  if (inst <= 4 || shared) return 2;
   return 1;
 }
 
@@ -3377,6 +3394,7 @@ extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_
   DevPlan& d = c->dp;
   d.nb = p->nb; d.nbr = p->nbr; d.nref = p->nref; d.nblk = p->n_blk; d.nlev = p->n_levels();
   d.nfill = (int)p->fill_blk.size(); d.npv = p->npv; d.base_mva = p->base_mva;
+  d.n_shared = p->n_shared;
   DevArena& A = c->arena;
   int rc = OPFX_OK;
 #define PUT(field, vec) if (rc == OPFX_OK) rc = A.put(p->vec, &d.field)
@@ -3396,6 +3414,7 @@ extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_
     if (hipMalloc(&st, 32 * sizeof(unsigned long long)) == hipSuccess) { (void)hipMemset(st, 0, 32 * sizeof(unsigned long long)); A.ptrs.push_back(st); d.stamps = static_cast<unsigned long long*>(st); }
   }
   c->v2 = p->rb >= 0 && !dbg.kernel_v1;   // (kernel_v1: developer switch to the first-generation kernel)
+  if (p->n_shared > 0 && !c->v2) { delete c; opfx_set_error("opfx_ctx_create: a plan with shared slots runs on the wave-team kernels only"); return OPFX_ERR_INVALID; }
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   PUT(lp_bcc, lp_bcc);
   d.rf = p->rf_pad;
@@ -3456,6 +3475,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   size_t lds = choose_block_storage(ctx->plan, ctx->dbg, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
   DevPlan dp = ctx->dp;
   if (wants_mem(ctx->dbg, lds, ctx->v2)) {
+    if (ctx->plan.n_shared > 0) { opfx_set_error("opfx_solve: a plan with shared slots does not run on the memory-resident kernels"); return OPFX_ERR_INVALID; }
     // the LU blocks do not fit the LDS beside the state vectors: wave team of four, four-value blocks in global memory
     n_full = ctx->plan.n_blk;
     lds = solver_lds_bytes(ctx->plan, 0, nres, true, 8, 1, n_full, true);
@@ -3480,13 +3500,14 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   }
   dp.nfull = n_full;
   int grid = 0;
-  const int team = pick_team(ctx->dbg, lds, ctx->v2);
+  const int team = pick_team(ctx->dbg, lds, ctx->v2, ctx->plan.n_shared > 0);
   const bool packed = n_full < ctx->plan.n_blk;
   auto kern = !ctx->v2 ? k_solve<0, 1>
             : packed ? (team == 4 ? k_solve<2, 4> : (team == 2 ? k_solve<2, 2> : k_solve<2, 1>))
                      : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
   int rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
+  if (ctx->plan.n_shared > 0) o.reuse_tol = 0.0;      // (chord iterations re-read lower blocks whose slots have new tenants by then)
   if (o.init == OPFX_INIT_DC && ctx->v2) {           // the kernels compiled with the DC start (same launch geometry)
     kern = packed ? (team == 4 ? k_solve<2, 4, true> : (team == 2 ? k_solve<2, 2, true> : k_solve<2, 1, true>))
                   : (team == 4 ? k_solve<1, 4, true> : (team == 2 ? k_solve<1, 2, true> : k_solve<1, 1, true>));
@@ -3502,7 +3523,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     ctx->solve_per_cu_chord = per_cu_c;
     if (rc != OPFX_OK) return rc;
   }
-  if (o.init == OPFX_INIT_DC || !ctx->v2) o.reuse_tol = 0.0;
+  if (o.init == OPFX_INIT_DC || !ctx->v2 || ctx->plan.n_shared > 0) o.reuse_tol = 0.0;
   rc = ensure_scratch(ctx, grid, false);
   if (rc != OPFX_OK) return rc;
   dp.pq = ctx->pq; dp.warm = ctx->warm;
@@ -3751,6 +3772,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
   e->spec = (p.npv == 0 ? SPEC_NO_PV : 0) | ((d->n_bmod == 0 && d->n_cont == 0 && !E.vset_src) ? SPEC_NO_MOD : 0);
   e->lds_bytes = choose_block_storage(p, ctx->dbg, [&](int nf) { return solver_lds_bytes(p, d->na, E.nblk_d, ctx->v2, env_nacc(d->nc), E.max_mod, nf); }, &e->n_full);
   if (wants_mem(ctx->dbg, e->lds_bytes, ctx->v2)) {
+    if (p.n_shared > 0) { delete e; opfx_set_error("opfx_env_create: a plan with shared slots does not run on the memory-resident kernels (build it without plan_share_slots)"); return OPFX_ERR_INVALID; }
     e->mem = true;
     e->n_full = p.n_blk;
     e->lds_bytes = solver_lds_bytes(p, d->na, E.nblk_d, true, env_nacc(d->nc), E.max_mod, e->n_full, true);
@@ -3768,6 +3790,18 @@ static StepKernel step_kernel(bool packed, int team) {
                 : (team == 4 ? k_step<1, 4, false, false, false, SPEC> : (team == 2 ? k_step<1, 2, false, false, false, SPEC> : k_step<1, 1, false, false, false, SPEC>));
 }
 
+template <int SPEC>
+static StepKernel step_kernel_w3() { return k_step<2, 4, false, false, false, SPEC, 3>; }
+
+// Three instances of the grid fit a CU and its blocks are stored two-value: the plain step kernel runs them as three teams of
+// FOUR wavefronts compiled for three wavefronts per SIMD (k_step<2,4,...,MINW=3>) instead of three teams of two.
+static bool env_three_teams_of_four(const opfx_env* env) {
+  if (!env->ctx->v2 || env->mem || env->ctx->dbg.team != 0 || env->ctx->dbg.waves_per_cu != 0) return false;
+  if (!(env->n_full < env->ctx->plan.n_blk)) return false;
+  const size_t granule = 1024;
+  return (160 * 1024) / ((env->lds_bytes + granule - 1) / granule * granule) == 3;
+}
+
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
                    int32_t mode, void* stream) {
   Opts o{opts ? opts->tol : 1e-8, opts ? opts->max_iter : 10, opts ? opts->enforce_q_lims : 1, opts ? opts->contingency_start : 0,
@@ -3776,7 +3810,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  const int team = env->mem ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2);
+  // (the DC-start and chord kernels exist for two wavefronts per SIMD only: such launches keep the teams of two)
+  const bool plain_newton = o.init != OPFX_INIT_DC && !(o.reuse_tol > 0.0 && env->ctx->plan.n_shared == 0);
+  const bool w3 = plain_newton && env_three_teams_of_four(env);
+  const int team = env->mem ? 4 : (w3 ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0));
   DevPlan dp = env->ctx->dp;
   dp.nfull = env->n_full;
   const bool packed = env->n_full < env->ctx->plan.n_blk;
@@ -3787,6 +3824,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
                   : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
+  if (w3) kern = spec == 3 ? step_kernel_w3<3>() : spec == 2 ? step_kernel_w3<2>() : spec == 1 ? step_kernel_w3<1>() : step_kernel_w3<0>();
   if (env->mem) kern = k_step<1, 4, false, true>;
   int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_spec[spec], WAVE * team);
   env->per_cu = env->per_cu_spec[spec];
@@ -3798,7 +3836,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     if (o.init == OPFX_INIT_DC) o.init = OPFX_INIT_FLAT;          // (no DC start in the memory-resident form)
     o.reuse_tol = 0.0;                                            // (nor chord steps)
   }
-  if (o.init == OPFX_INIT_DC || !env->ctx->v2) o.reuse_tol = 0.0;      // (chord steps: not together with the DC start)
+  if (o.init == OPFX_INIT_DC || !env->ctx->v2 || env->ctx->plan.n_shared > 0) o.reuse_tol = 0.0;      // (chord steps: not together with the DC start, nor on shared slots)
   if (o.reuse_tol > 0.0) {                           // the kernels compiled with chord steps (same launch geometry)
     kern = packed ? (team == 4 ? k_step<2, 4, false, false, true> : (team == 2 ? k_step<2, 2, false, false, true> : k_step<2, 1, false, false, true>))
                   : (team == 4 ? k_step<1, 4, false, false, true> : (team == 2 ? k_step<1, 2, false, false, true> : k_step<1, 1, false, false, true>));
@@ -3881,7 +3919,7 @@ extern "C" int opfx_time_steps(opfx_env* env, int64_t B, const opfx_step_io* io,
 extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instance, int64_t* lds_bytes_per_instance,
                                  int32_t* instances_per_cu) {
   if (!env) { opfx_set_error("opfx_env_get_info: null environment"); return OPFX_ERR_INVALID; }
-  if (waves_per_instance) *waves_per_instance = env->mem ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2);
+  if (waves_per_instance) *waves_per_instance = (env->mem || env_three_teams_of_four(env)) ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0);
   if (lds_bytes_per_instance) *lds_bytes_per_instance = (int64_t)env->lds_bytes;
   if (instances_per_cu) *instances_per_cu = env->per_cu;
   return OPFX_OK;

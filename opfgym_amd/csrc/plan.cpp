@@ -108,6 +108,109 @@ void renumber_blocks(opfx_plan* p) {
   std::sort(p->fill_blk.begin(), p->fill_blk.end());
 }
 
+// Shared slots (round 5).  What pins the wave teams of a meshed grid at two instances per CU is LDS, and a LOWER block (i, j)
+// — column j eliminated before row i — is read for the last time at level(j), as the multiplier A_ik of that level, while fill
+// blocks are born throughout the elimination (a fill block is first touched at the level that creates it).  So a fill block
+// born at level b may live in the id (= LDS slot) of a four-value lower block that died at a level d <= b - 2; what it needs
+// is a ZERO in the slot at its birth (its first updates are atomic adds): the plan records (level z, id) pairs with
+// d < z < b, and a team item of level z carries the store (build_lane_programs: the rider bits of a team item are free).
+// Greedy over the fill blocks in birth order (optimal for intervals up to the one-level gap); a level takes as many zero
+// stores as it has items.  Ids afterwards, as before:  [four-value ids whose first tenant is an original block |
+// ids whose first tenant is a fill block (zeroed as one range in phase A) | two-value ids].
+// Such a plan is for the wave-team kernels with full Newton: the single-wave stream has no room for the stores (its items
+// carry riders) and chord iterations re-read the lower blocks.
+// Whether it pays — whether a CU then holds a third instance — depends on the environment's own LDS needs as well: the caller
+// decides (opfgym_amd.BatchedOpfEnv builds both plans where the grid is in the two-instances-per-CU regime and keeps the better).
+void share_slots(opfx_plan* p) {
+  const int32_t n = p->n_blk, nlev = p->n_levels(), nfull = p->n_full;
+  if (n == 0 || nlev < 3) return;
+  std::vector<int32_t> lev_of(p->nb, -1);
+  for (int lev = 0; lev < nlev; ++lev)
+    for (int q = p->lev_pptr[lev]; q < p->lev_pptr[lev + 1]; ++q) lev_of[p->piv_bus[q]] = lev;
+  std::vector<char> is_fill(n, 0);
+  for (int32_t f : p->fill_blk) is_fill[f] = 1;
+  std::vector<int32_t> birth(n, -1);                       // fill blocks: the first level that targets them
+  std::vector<int32_t> cap(nlev, 0);                       // items of a level (with second columns: the smaller count)
+  for (int lev = 0; lev < nlev; ++lev) {
+    std::unordered_map<int32_t, int32_t> per_ik;
+    for (int t = p->lev_tptr[lev]; t < p->lev_tptr[lev + 1]; ++t) {
+      const int32_t tb = p->tgt_blk[t];
+      const int32_t ns = p->tgt_sptr[t + 1] - p->tgt_sptr[t];
+      if (tb < 0) { cap[lev] += ns; continue; }
+      if (is_fill[tb] && birth[tb] < 0) birth[tb] = lev;
+      for (int s_ = p->tgt_sptr[t]; s_ < p->tgt_sptr[t + 1]; ++s_) ++per_ik[p->src_ik[s_]];
+    }
+    for (auto& kv : per_ik) cap[lev] += (kv.second + 1) / 2;
+  }
+  auto death = [&](int32_t b) {                            // level of the last read of a lower block, else -1 (lives on)
+    const int32_t i = p->blk_row[b], j = p->blk_col[b];
+    return (i != j && lev_of[i] >= 0 && lev_of[j] >= 0 && lev_of[j] < lev_of[i]) ? lev_of[j] : -1;
+  };
+  // releases: (first level at which the slot may be zeroed, slot)
+  std::vector<std::vector<int32_t>> release_at(nlev + 2);
+  for (int32_t b = 0; b < nfull; ++b) if (!is_fill[b]) { const int d = death(b); if (d >= 0) release_at[d + 1].push_back(b); }
+  std::vector<int32_t> fills;
+  for (int32_t b = 0; b < n; ++b) if (is_fill[b] && birth[b] >= 0) fills.push_back(b);
+  std::stable_sort(fills.begin(), fills.end(), [&](int32_t a, int32_t b) { return birth[a] < birth[b]; });
+  std::vector<int32_t> host(n, -1);                        // fill block -> the id it moves into
+  std::vector<std::pair<int32_t, int32_t>> zero_ops;       // (level, slot in OLD ids)
+  std::vector<std::pair<int32_t, int32_t>> free_slots;     // (zero-able from level, slot)
+  std::vector<int32_t> cap_left = cap;
+  size_t fi = 0;
+  for (int lev = 0; lev < nlev; ++lev) {
+    for (int32_t sl : release_at[lev]) free_slots.push_back({lev, sl});
+    for (; fi < fills.size() && birth[fills[fi]] == lev; ++fi) {
+      const int32_t f = fills[fi];
+      int32_t slot = f;
+      // a free slot whose window [from, lev - 1] holds a level with a store to spare (the latest such level)
+      for (size_t q = 0; q < free_slots.size(); ++q) {
+        int z = -1;
+        for (int l = lev - 1; l >= free_slots[q].first; --l) if (cap_left[l] > 0) { z = l; break; }
+        if (z < 0) continue;
+        slot = free_slots[q].second;
+        host[f] = slot;
+        --cap_left[z];
+        zero_ops.push_back({z, slot});
+        free_slots.erase(free_slots.begin() + (long)q);
+        break;
+      }
+      const int d = death(f);
+      if (d >= 0) release_at[std::min(d + 1, nlev + 1)].push_back(slot);
+    }
+  }
+  const int32_t n_hosted = (int32_t)zero_ops.size();
+  if (n_hosted == 0) return;
+  // ---- new ids --------------------------------------------------------------------------------------------------
+  std::vector<int32_t> perm(n, -1);
+  int32_t next = 0;
+  for (int32_t b = 0; b < nfull; ++b) if (!is_fill[b]) perm[b] = next++;                   // originals, four-value
+  const int32_t fill_lo = next;
+  for (int32_t b = 0; b < nfull; ++b) if (is_fill[b] && host[b] < 0) perm[b] = next++;     // fill blocks in a slot of their own
+  const int32_t n_full_new = next;
+  for (int32_t b = nfull; b < n; ++b) perm[b] = next++;                                    // two-value
+  const int32_t n_new = next;
+  for (int32_t f : fills) if (host[f] >= 0) {               // (hosts are resolved in birth order: a host's own id is final)
+    int32_t h = host[f];
+    while (host[h] >= 0) h = host[h];
+    perm[f] = perm[h];
+  }
+  auto map = [&](std::vector<int32_t>& v) { for (auto& x : v) if (x >= 0) x = perm[x]; };
+  map(p->y_blk); map(p->diag_blk); map(p->tgt_blk); map(p->src_ik); map(p->src_kk); map(p->u_blk);
+  const int32_t ntgt = (int32_t)p->tgt_blk.size();
+  for (int32_t t = 0; t < ntgt; ++t)
+    if (p->tgt_blk[t] >= 0)
+      for (int32_t s_ = p->tgt_sptr[t]; s_ < p->tgt_sptr[t + 1]; ++s_) p->src_kj[s_] = perm[p->src_kj[s_]];
+  std::vector<int32_t> row(n_new, -1), col(n_new, -1);
+  for (int32_t b = 0; b < n; ++b) if (host[b] < 0) { row[perm[b]] = p->blk_row[b]; col[perm[b]] = p->blk_col[b]; }   // (the FIRST tenant)
+  p->blk_row.swap(row); p->blk_col.swap(col);
+  p->fill_blk.clear();
+  for (int32_t id = fill_lo; id < n_full_new; ++id) p->fill_blk.push_back(id);
+  for (auto& zo : zero_ops) { p->zero_lev.push_back(zo.first); p->zero_id.push_back(perm[zo.second]); }
+  p->n_blk = n_new;
+  p->n_full = n_full_new;
+  p->n_shared = n_hosted;
+}
+
 // LDS bank conflicts of the B/C items.  A wave's 64-bit LDS access is served in two groups of 32 lanes over 32
 // eight-byte banks, and every operand array of the kernels is indexed by an id, so within one access the bank of a lane
 // is (array base + id) mod 32: two lanes of a group collide when their ids differ but agree mod 32 (equal ids are a
@@ -597,6 +700,19 @@ void build_lane_programs(opfx_plan* p) {
         at[0] = its[q].w0; at[1] = its[q].w1; at[2] = its[q].w3;          // (word 2 of a device item: the second column)
       }
       if (spread) spread_over_banks(&tbk[(size_t)first * 256], nr, p->n_full);
+      // shared slots: the ids to be zeroed during this level ride on its items, one each (bits 2-16 of word 3, which a
+      // team item does not use for a rider; plan.cpp share_slots made sure the level has enough items)
+      for (size_t q = first * 64; q < (size_t)(first + nr) * 64; ++q) tbk[q * 4 + 3] = NO_RIDER_BITS;
+      {
+        size_t at = (size_t)first * 64;
+        for (size_t z = 0; z < p->zero_lev.size(); ++z) {
+          if (p->zero_lev[z] != lev) continue;
+          while (at < (size_t)(first + nr) * 64 && (tbk[at * 4] & 0xFFFF) == NONE) ++at;
+          if (at >= (size_t)(first + nr) * 64) { p->ra = p->rb = p->rc = -1; return; }     // (cannot happen: capacity was counted)
+          tbk[at * 4 + 3] = ((uint32_t)p->zero_id[z] << 2) | (RIDER_NONE15 << 17);
+          ++at;
+        }
+      }
       groups.push_back({2, first, first + nr});
     }
     std::vector<uint32_t> tc;                               // this team's back-substitution rounds below the tail
@@ -670,7 +786,8 @@ void build_lane_programs(opfx_plan* p) {
             for (int l = 0; l < 64; ++l) {
               if (r < r1) for (int q = 0; q < 3; ++q) out_.push_back(src[((size_t)r * 64 + l) * 4 + q]);
               else for (int q = 0; q < 3; ++q) out_.push_back(NONE | (NONE << 16));
-              out_.push_back(flags | NO_RIDER_BITS);
+              // (word 3: the round's flags | for a factorisation item of a plan with shared slots the id it zeroes)
+              out_.push_back(flags | ((r < r1 && gs[g].src == 2) ? (src[((size_t)r * 64 + l) * 4 + 3] & ~3u) : NO_RIDER_BITS));
             }
           }
           ++K;
@@ -930,6 +1047,7 @@ static int plan_build(const opfx_case* c, const PlanKnobs& knobs, const opfx_deb
   }
   p->n_blk = (int32_t)p->blk_row.size();
   renumber_blocks(p);
+  if (dbg.plan_share_slots > 0 && nb <= 0x7FFF) share_slots(p);
   build_lane_programs(p);
   *out = p;
   return OPFX_OK;
@@ -942,6 +1060,10 @@ static double plan_cost(const opfx_plan* p) {
   const size_t nbe = (size_t)(p->nb + 1) & ~(size_t)1;
   const size_t lds_doubles = 4 * nbe + 2 * (((size_t)p->n_blk + 1) & ~(size_t)1) + 2 * (((size_t)p->n_full + 1) & ~(size_t)1);
   const double items = 1e-4 * (double)p->src_ik.size();          // (equal rounds: the plan with fewer update terms)
+  // a plan with shared slots is asked for to bring a THIRD instance into the CU, as teams of two: rounds of that stream, and a
+  // plan that stays above a third of the LDS (less ~2.7 KB of an environment's own arrays) is no candidate
+  if (p->dbg.plan_share_slots > 0 && p->n_shared > 0)
+    return p->team_rounds[0] + 0.25 * p->team_barriers[0] + items + (lds_doubles * 8 > 50 * 1024 + 512 ? 1000.0 : 0.0);
   if (lds_doubles * 8 > 52 * 1024) return p->team_rounds[1] + 0.25 * p->team_barriers[1] + items;   // <= 2 instances per CU
   if (lds_doubles * 8 > 31 * 1024) return p->team_rounds[0] + 0.25 * p->team_barriers[0] + items;   // <= 4
   return p->rb + p->rc + items;
@@ -1025,6 +1147,7 @@ extern "C" int opfx_plan_get_info(const opfx_plan* p, opfx_plan_info* o) {
   o->lp_rounds_f = p->rf;
   for (int t = 0; t < 2; ++t) { o->team_rounds_chord[t] = p->team_rounds_c[t]; o->team_barriers_chord[t] = p->team_barriers_c[t]; o->team_kb_chord[t] = p->team_kb_c[t]; }
   o->lp_rounds_f_pad = p->rf_pad;
+  o->n_shared = p->n_shared;
   full.struct_size = caller_size;
   std::memcpy(caller, &full, caller_size);          // (a caller built against an older, shorter layout gets its prefix)
   return OPFX_OK;
@@ -1071,6 +1194,8 @@ extern "C" int64_t opfx_plan_get_array(const opfx_plan* p, int which, int32_t* o
     case OPFX_ARR_U_COL: v = &p->u_col; break;
     case OPFX_ARR_BLK_ROW: v = &p->blk_row; break;
     case OPFX_ARR_BLK_COL: v = &p->blk_col; break;
+    case OPFX_ARR_ZERO_LEV: v = &p->zero_lev; break;
+    case OPFX_ARR_ZERO_BLK: v = &p->zero_id; break;
     default: opfx_set_error("opfx_plan_get_array: unknown array id"); return OPFX_ERR_INVALID;
   }
   const int64_t n_copy = std::min<int64_t>(cap, (int64_t)v->size());

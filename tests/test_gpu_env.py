@@ -269,20 +269,31 @@ def test_full_batch_voltage_control_properties():
     assert np.array_equal(r1, _np(reward2), equal_nan=True)
 
 
-@pytest.mark.parametrize('name,B,n_check,team,levels', [('eco_hv_mixed', 8192, 128, 4, (0.0, 1.0)), ('sc_vc_hv_urban', 4096, 32, 4, None),
-                                                        ('eco_hv_mixed', 2048, 32, 2, (0.0, 1.0)), ('qm_mv_urban', 65536, 512, 1, (0.40, 0.70))])
+@pytest.mark.parametrize('name,B,n_check,team,levels', [('eco_hv_mixed', 8192, 128, 'shared', (0.0, 1.0)), ('sc_vc_hv_urban', 4096, 32, 4, None),
+                                                        ('eco_hv_mixed', 2048, 32, 2, (0.0, 1.0)), ('eco_hv_mixed', 2048, 32, 4, (0.0, 1.0)),
+                                                        ('qm_mv_urban', 65536, 512, 1, (0.40, 0.70))])
 def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
-    (B = 8192, four wavefronts per instance; a smaller batch with teams of two forced through the
-    developer switch OPFX_TEAM) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
+    (B = 8192 on the plan with shared LDS slots the environment picks — three teams of four wavefronts per CU; smaller batches
+    with teams of two forced through the developer switch OPFX_TEAM and with teams of four on the plan without shared slots) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
     contingency (B = 4096 x 251 solves, four wavefronts per instance); BASELINE config 4 at its full size as well
     (QMarket, 144 buses, B = 65536: every wavefront walks 32 instances).  All rows:
     size-independent properties; `n_check` rows spread over the batch (128 / 32 / 32 / 512; the N-1 rows — 251 oracle power flows
     each — in eight worker processes: VERDICT r04 #8), valid and
     invalid states among them: the full step against the oracle, no row skipped, the converged flags equal the oracle's."""
+    shared = team == 'shared'
     if team == 2:
         monkeypatch.setenv('OPFX_TEAM', '2')
+    if team == 4 and name == 'eco_hv_mixed':
+        monkeypatch.setenv('OPFX_PLAN_SHARE', '0')            # (the plan without shared slots: two teams of four per CU)
     env = product_env(name, batch_size=B)
+    if shared:
+        # round 5: the 306-bus grid runs on a plan with SHARED SLOTS (plan.cpp share_slots) — three teams per CU, of FOUR
+        # wavefronts each on the kernel compiled for three wavefronts per SIMD
+        assert env.plan.info['n_shared'] > 150 and env.kernel_info()['lds_bytes_per_instance'] <= 160 * 1024 // 3
+        team = 4
+    else:
+        assert env.plan.info['n_shared'] == 0
     orc = oracle_env(name, product_env(name, defer_device=True))
     rng = np.random.default_rng(17)
     steps = rng.choice(env.train_steps, B)
@@ -331,7 +342,7 @@ def test_full_batch_under_the_reference_solver_settings(name, B, n_check):
     iteration path, not only its fixed point), and the full step — rewards, violations, observations, result tables —
     equals the oracle's."""
     env = product_env(name, batch_size=B, reference_faithful=True)
-    assert env.init == 'dc' and env.reference_deviations == {} and env.kernel_info()['waves_per_instance'] == (1 if name == 'vc_mv_urban' else 4)
+    assert env.init == 'dc' and env.reference_deviations == {} and env.kernel_info()['waves_per_instance'] == (1 if name == 'vc_mv_urban' else 4)      # (306-bus grid: shared slots; the DC launches run as teams of two)
     orc = oracle_env(name, product_env(name, defer_device=True))
     orc.init = 'dc'
     rng = np.random.default_rng(29)

@@ -177,6 +177,42 @@ def test_team_stream_reproduces_oracle(built_lib, code, team):
     assert np.abs(v - ref['V']).max() < 1e-9
 
 
+@pytest.mark.parametrize('code,team', [('hv-small', 2), ('hv-small', 4), ('1-HV-mixed--0-sw', 2), ('1-HV-mixed--0-sw', 4),
+                                       ('1-HV-urban--0-sw', 4)])
+def test_shared_slots_give_the_same_power_flow_with_less_lds(built_lib, code, team):
+    """opfx_debug_opts.plan_share_slots (round 5, plan.cpp share_slots): fill blocks born late live in the ids (= LDS slots) of
+    lower blocks that are dead by then; a zero store riding on a team item of an earlier level prepares the slot.  The
+    emulation walks the team stream with those stores and its race check covers them (no wavefront may use, between two
+    barriers, a slot another one zeroes); the raw schedule is walked as well.  Same iterates, fewer blocks."""
+    from plan_emulator import emulate_newton
+    net = grids.get_grid(code)[0]
+    case = net_to_case(net)
+    plain = capi.Plan(case, debug=capi.debug_from_env({}))
+    shared = capi.Plan(case, debug=capi.debug_from_env({'OPFX_PLAN_SHARE': '1'}))
+    ns = shared.info['n_shared']
+    assert plain.info['n_shared'] == 0 and ns > 0
+    if case.nb < 200:            # (from 200 buses on the plan is SEARCHED, and with less LDS another elimination order may win)
+        assert shared.info['n_blk'] == plain.info['n_blk'] - ns and shared.info['n_full'] == plain.info['n_full'] - ns
+        assert abs(plain.info['lds_doubles'] - shared.info['lds_doubles'] - 4 * ns) <= 4      # (counts are rounded up to even)
+        assert len(shared.array('fill_blk')) == plain.info['n_fill'] - ns
+    assert shared.info['lds_doubles'] < plain.info['lds_doubles']
+    zl, zb = shared.array('zero_lev'), shared.array('zero_blk')
+    assert len(zl) == len(zb) == ns and (zb < shared.info['n_full']).all() and (zl >= 0).all() and (zl < shared.info['n_levels']).all()
+    fill = shared.array('fill_blk')                               # (ids whose FIRST tenant is a fill block: one range, zeroed in phase A)
+    assert (np.diff(fill) == 1).all() and fill[-1] == shared.info['n_full'] - 1
+    p, q, *_ = bus_injections(net, case)
+    p, q = p / case.base_mva, q / case.base_mva
+    ref = OracleSide(net, case).solve(p, q)
+    v, conv, it, nrm = emulate_newton_lane_program(shared, p, q, team=team)
+    assert conv and it == ref['iterations']
+    assert np.abs(v - ref['V']).max() < 1e-9
+    v0, conv0, it0, _ = emulate_newton_lane_program(plain, p, q, team=team)
+    assert it0 == it and np.abs(v - v0).max() < 1e-10
+    if code != '1-HV-urban--0-sw':                                # (the raw schedule of the largest grid takes a minute in numpy)
+        vr, convr, itr, _ = emulate_newton(shared, p, q)
+        assert convr and itr == it and np.abs(vr - ref['V']).max() < 1e-9
+
+
 @pytest.mark.parametrize('code,team', [('1-MV-urban--0-sw', 0), ('hv-small', 2), ('1-HV-mixed--0-sw', 4)])
 def test_second_columns_carry_every_update_term_once(built_lib, code, team):
     """Round 4: a factor item may carry a SECOND column of the same multiplier -A_ik A_kk^-1 (device word 2).  Each stream
