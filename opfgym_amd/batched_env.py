@@ -332,7 +332,8 @@ class BatchedOpfEnv:
                  not_converged_penalty=1, tolerance=1e-8, max_iteration=10, enforce_q_lims=True,
                  defer_device=False, validate_actions=False, carry_over_state=None, copy_outputs=False,
                  contingency_start=None, init=None, jacobian_reuse_tol=0.0, resample_failed_resets=True,
-                 on_pivot_breakdown='ignore', reference_faithful=False, pin_point_q_ranges=None, **kwargs):
+                 on_pivot_breakdown='ignore', reference_faithful=False, pin_point_q_ranges=None, share_lds_slots='auto',
+                 **kwargs):
         from .objectives import QuadraticDeviation
         # reference_faithful: ONE switch for the four defaults that trade the reference's iteration path for speed.
         # Each of `init`, `contingency_start`, `carry_over_state`, `pin_point_q_ranges` left at None takes the fast default
@@ -344,6 +345,10 @@ class BatchedOpfEnv:
         # Converged results agree either way (same fixed point, same tolerance); `iterations`, and `converged` of rows
         # next to voltage collapse, follow the start.  An explicit value always wins.
         self.reference_faithful = bool(reference_faithful)
+        # share_lds_slots: 'auto' (default) lets attach_device() switch to a plan with shared LDS slots where that brings a third
+        # instance into the CU (_try_shared_slots); False never does
+        assert share_lds_slots in ('auto', False), share_lds_slots
+        self.share_lds_slots = share_lds_slots
         faithful = dict(init='auto', contingency_start='flat', carry_over_state=True, pin_point_q_ranges=False)
         fast = dict(init='flat', contingency_start='base_case', carry_over_state=False, pin_point_q_ranges=True)
         given = dict(init=init, contingency_start=contingency_start, carry_over_state=carry_over_state,
@@ -613,9 +618,9 @@ class BatchedOpfEnv:
         live in the LDS slots of lower blocks that are dead by then (`opfx_debug_opts.plan_share_slots`, plan.cpp share_slots:
         wave-team kernels with full Newton only).  Where that brings the environment under a third of the LDS — three teams of
         two per CU — the environment switches to such a plan; otherwise (or with chord steps, which re-read the lower blocks)
-        it keeps the one it has.  OPFX_PLAN_SHARE=0 in the process environment switches the attempt off."""
+        it keeps the one it has.  `share_lds_slots=False` (or OPFX_PLAN_SHARE=0 in the process environment) switches the attempt off."""
         import os
-        if self.jacobian_reuse_tol > 0.0 or self.plan.info['n_shared'] or os.environ.get('OPFX_PLAN_SHARE') == '0' \
+        if self.share_lds_slots is False or self.jacobian_reuse_tol > 0.0 or self.plan.info['n_shared'] or os.environ.get('OPFX_PLAN_SHARE') == '0' \
                 or os.environ.get('OPFX_TEAM') or os.environ.get('OPFX_FORCE_MEM') or os.environ.get('OPFX_KERNEL_V1'):
             return
 
