@@ -3792,6 +3792,11 @@ static StepKernel step_kernel(bool packed, int team) {
 
 template <int SPEC>
 static StepKernel step_kernel_w3() { return k_step<2, 4, false, false, false, SPEC, 3>; }
+// the single-wave kernel compiled for three wavefronts per SIMD (167 VGPRs + 20 B of scratch): small grids, see env_small_grid
+template <int SPEC>
+static StepKernel step_kernel_w3_single(bool packed) {
+  return packed ? k_step<2, 1, false, false, false, SPEC, 3> : k_step<1, 1, false, false, false, SPEC, 3>;
+}
 
 // Three instances of the grid fit a CU and its blocks are stored two-value: the plain step kernel runs them as three teams of
 // FOUR wavefronts compiled for three wavefronts per SIMD (k_step<2,4,...,MINW=3>) instead of three teams of two.
@@ -3800,6 +3805,17 @@ static bool env_three_teams_of_four(const opfx_env* env) {
   if (!(env->n_full < env->ctx->plan.n_blk)) return false;
   const size_t granule = 1024;
   return (160 * 1024) / ((env->lds_bytes + granule - 1) / granule * granule) == 3;
+}
+
+// A SMALL grid on the single-wave kernel: LDS would hold ten or more instances per CU, but at 171-190 VGPRs only two
+// wavefronts fit a SIMD, i.e. eight per CU.  The kernel compiled for three wavefronts per SIMD holds twelve: 33-bus grid
+// 0.250 -> 0.196 ms per 16 384 instances (65.5 -> 83.7 M step/s), 15-bus grid 0.193 -> 0.153 ms (round 5,
+// scripts/probe_small_grid_occupancy.py).  Below ten instances the spills cost more than the extra wavefronts give (144-bus
+// grid, eight by LDS either way: 0.224 -> 0.235 ms).
+static bool env_small_grid(const opfx_env* env) {
+  if (!env->ctx->v2 || env->mem || env->ctx->dbg.waves_per_cu != 0 || (env->ctx->dbg.team != 0 && env->ctx->dbg.team != 1)) return false;
+  const size_t granule = 1024;
+  return (160 * 1024) / ((env->lds_bytes + granule - 1) / granule * granule) >= 10;
 }
 
 static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_solve_opts* opts,
@@ -3825,6 +3841,9 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
                   : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
   if (w3) kern = spec == 3 ? step_kernel_w3<3>() : spec == 2 ? step_kernel_w3<2>() : spec == 1 ? step_kernel_w3<1>() : step_kernel_w3<0>();
+  if (plain_newton && team == 1 && env_small_grid(env))
+    kern = spec == 3 ? step_kernel_w3_single<3>(packed) : spec == 2 ? step_kernel_w3_single<2>(packed)
+         : spec == 1 ? step_kernel_w3_single<1>(packed) : step_kernel_w3_single<0>(packed);
   if (env->mem) kern = k_step<1, 4, false, true>;
   int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_spec[spec], WAVE * team);
   env->per_cu = env->per_cu_spec[spec];

@@ -369,6 +369,22 @@ def test_full_batch_under_the_reference_solver_settings(name, B, n_check):
     assert (its != _np(out_f[4]['iterations'])).any()
 
 
+def test_small_grids_run_three_wavefronts_per_simd():
+    """A small grid leaves LDS for ten or more instances per CU, but the single-wave kernel's 171 VGPRs only for two wavefronts
+    per SIMD = eight per CU; such environments run on the instantiation compiled for three (k_step<.,1,...,MINW=3>: twelve
+    resident, round 5: 33-bus grid 65.5 -> 83.7 M step/s).  The 144-bus grid (eight instances by LDS) stays on the 2-per-SIMD
+    kernel.  Results: the goldens of the small grids run through this kernel (test_env_matches_reference_golden)."""
+    small = product_env('vc_mv_small', batch_size=4096)
+    big = product_env('vc_mv_urban', batch_size=4096)
+    rng = np.random.default_rng(1)
+    for env in (small, big):
+        env.reset(seed=3)
+        out = env.step(rng.random((4096, env.n_actions)))
+        assert _np(out[4]['converged']).mean() > 0.99
+    assert small.kernel_info()['instances_per_cu'] == 12 and small.kernel_info()['waves_per_instance'] == 1
+    assert big.kernel_info()['instances_per_cu'] == 8
+
+
 def test_contingency_start_flat_reproduces_the_reference_iteration_for_iteration():
     """N-1 loop, `contingency_start`: the reference calls pandapower anew for every contingency
     (security_constrained.py:53), i.e. from the flat start; the kernel's default starts each contingency solve
