@@ -13,6 +13,7 @@ from env_cases import EPISODE_STEPS, SINGLE_STEP, draws, golden, noise_factors, 
 from scenarios import E12_SCENARIOS
 
 TAB_TOL = 1e-12
+CPU_SAMPLES = {'sc_vc_hv_urban': 3}
 
 
 @pytest.mark.parametrize('name', SINGLE_STEP)
@@ -22,7 +23,9 @@ def test_oracle_matches_reference_golden(name):
     assert len(env.net.bus) == int(g['n_bus'])
     assert env.n_actions == int(g['n_act'])
     orc = oracle_env(name, env)
-    n = len(g['step'])
+    # (the N-1 fixtures at BASELINE size cost 251 oracle power flows per sample: the CPU suite replays the first three of
+    #  `sc_vc_hv_urban`'s six — the GPU suite replays all of them, test_gpu_env.py::test_env_matches_reference_golden)
+    n = min(len(g['step']), CPU_SAMPLES.get(name, 10 ** 9))
     for k in range(n):
         noise = noise_factors(name, g['noise'][k])
         d = draws(g, k)
