@@ -384,7 +384,8 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     #  compiled for three wavefronts per SIMD, which the DC-start kernels do not have — those launches run as teams of two)
     name_team = 2 if (dc and team == 4 and env.plan.info['n_shared'] and ki['packed']) else team
     kernel_name = f'k_step<{2 if ki["packed"] else 1},{name_team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + \
-        (f',SPEC={ki["spec"]}' if not (dc or chord) else '') + '>'
+        (f',SPEC={ki["spec"]}' if not (dc or chord) else '') + \
+        (',MINW=3' if not (dc or chord) and ki['waves_per_instance'] * ki['instances_per_cu'] > 8 else '') + '>'    # (the instantiation compiled for three wavefronts per SIMD)
     # what the launch really has to read and write: the instance rows of the caller's buffers
     buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
                  'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}

@@ -80,7 +80,7 @@ def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_con
     assert d['also']['config5']['steps'] == 3 and d['also']['config3']['steps'] >= 5
     assert all(a['newton_start'] == 'flat' and a['contingency_start'] == 'base_case' for a in d['also'].values())
     # the plain kernels are specialised on what each environment fixes for the whole batch (no PV bus = 1, no modifiers = 2)
-    assert [d['also'][f'config{c}']['kernel'] for c in (2, 3, 4, 5)] == ['k_step<2,1,SPEC=3>', 'k_step<2,4,SPEC=2>', 'k_step<2,1,SPEC=3>', 'k_step<2,4,SPEC=1>']
+    assert [d['also'][f'config{c}']['kernel'] for c in (2, 3, 4, 5)] == ['k_step<2,1,SPEC=3>', 'k_step<2,4,SPEC=2,MINW=3>', 'k_step<2,1,SPEC=3>', 'k_step<2,4,SPEC=1>']
     # (config 3: three teams of four per CU on the plan with shared LDS slots, BatchedOpfEnv._try_shared_slots)
     assert d['also']['config3']['kernel_launch']['instances_per_cu'] == 3 and d['also']['config5']['kernel_launch']['instances_per_cu'] == 2
     assert d['also']['config3']['shared_slots'] > 150 and d['also']['config5']['shared_slots'] == 0
