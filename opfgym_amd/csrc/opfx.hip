@@ -874,6 +874,18 @@ __device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const ui
   }
 }
 #endif
+// POLAR SHADOW (round 5).  The solver keeps V in rectangular form only, so the result bank used to take |V| = sqrt(vr^2 + vi^2)
+// and the angle = atan2(vi, vr) of every bus after the solve: 38 + 121 vector instructions per bus round, 3.2 % of all the
+// instructions of a 144-bus step, in a kernel whose time is its instruction count.  But phase D already holds both in
+// polar form — V <- V (1 + d|V|/|V|) e^{j dth} — and the bus -> lane map of phase D (bus lane + 64 r) is that of the result
+// pass: the lane keeps theta and |V| of its buses in REGISTERS (2 x POLAR_R doubles; the single-wave kernels have 80 VGPRs to
+// spare at two wavefronts per SIMD), theta += dth and |V| *= 1 + d|V|/|V| per iteration, and the result pass reads them.
+// Same values to rounding (the product / sum of the steps against sqrt / atan2 of the rotated vector: ~1e-16 per
+// iteration).  Used where every solve of the launch starts from init_voltage and nothing rescales V behind the solver's
+// back: single-wave step kernels specialised SPEC_NO_MOD (no modifiers, contingencies, per-instance |V| set-points), grids
+// of at most 64 POLAR_R buses; everything else takes sqrt / atan2 as before.
+constexpr int POLAR_R = 4;
+struct Polar { double th[POLAR_R], vm[POLAR_R]; };
 // Phase D of the lane-programme kernels: after the back-substitution items y_i of bus i holds its
 // right-hand side with every U-term removed; x_i = A_ii^-1 y_i, then V_i <- V_i (1 + d|V|/|V|) e^{j dth}.
 // `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
@@ -1142,9 +1154,9 @@ __device__ __forceinline__ void dc_overflow(const DevPlan& P, const Lds& L, int 
 // the wavefront walks the CHORD stream, forward substitution alone + the same back substitution (plan.h lp_bcc), instead
 // of factorisation + forward substitution.  Which stream the NEXT iteration walks is known once this iteration's norm is,
 // i.e. before its own rounds run out, so the four descriptors in flight across the loop's back edge come from the right one.
-template <bool PK, bool DC = false, bool CHORD = false, int SPEC = 0>
+template <bool PK, bool DC = false, bool CHORD = false, int SPEC = 0, bool POLAR = false>
 __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane, int n_mod,
-                        int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool dc_pass = false) {
+                        int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool dc_pass = false, Polar* pol = nullptr) {
   double piv = 1.0;
   int pbus = -1;
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
@@ -1346,13 +1358,15 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 #endif
     OPFX_STAMP(3);
     // ---- phase D: x_i = A_ii^-1 y_i, V <- V (1 + d|V|/|V|) e^{j dth}  (rectangular update, no |V|/angle arrays) ----
-    for (int i = lane; i < nb; i += WAVE) {
-      if (L.bt[i] == BT_REF) continue;                 // (rhs of a REF row holds its parked injection)
+    auto phase_d = [&](int i, int r) {
+      if (L.bt[i] == BT_REF) return;                   // (rhs of a REF row holds its parked injection)
       double dth, dvm;
       solve_pivot(L, i, dth, dvm, piv, pbus);
       // (the DC pass solved for the ANGLE itself: turn the start voltage by the difference to its start angle, |V| stays)
       if (DC && dc_pass) { dth -= P.va_set[i]; dvm = 0.0; }
       const double sc = 1.0 + dvm;
+      // (the polar shadow of this lane's buses, see Polar; a step past |V| = 0 — 1 + d|V|/|V| < 0 — turns V by pi)
+      if (POLAR) { pol->th[r] += sc < 0.0 ? dth + M_PI : dth; pol->vm[r] *= fabs(sc); }
       double sn, cs;
       if (fabs(dth) <= 0.25) {
         // Taylor series to x^15 / x^14, truncation error < 1e-21 (the other branch is skipped as a whole
@@ -1368,6 +1382,12 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       const double vr = L.vr[i], vi = L.vi[i];
       L.vr[i] = (vr * cs - vi * sn) * sc;
       L.vi[i] = (vr * sn + vi * cs) * sc;
+    };
+    if (POLAR) {
+#pragma unroll
+      for (int r = 0; r < POLAR_R; ++r) { const int i = lane + WAVE * r; if (i < nb) phase_d(i, r); }
+    } else {
+      for (int i = lane; i < nb; i += WAVE) phase_d(i, 0);
     }
     wave_fence();
     OPFX_STAMP(4);
@@ -1745,10 +1765,10 @@ __device__ void mark_islands_multi(const DevPlan& P, const Lds& L, int lane, int
 // DC: compiled with the DC start (opfx_solve_opts.init).  A template parameter, i.e. kernels of their own: with the DC
 // code inlined next to them the Newton loops of the plain kernels lose registers (216 -> 224 VGPRs single-wave, spills
 // in the wave teams) although the region runs once per solve.
-template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC = 0>
+template <int V2, int NW, bool DC = false, bool MEM = false, bool CHORD = false, int SPEC = 0, bool POLAR = false>
 __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, const Opts& o, int lane, int out_br, int n_mod,
                                const double* qg_min, const double* qg_max, int* iters, double* nrm, double* min_piv,
-                               int* min_piv_bus, int isl_state = 0) {
+                               int* min_piv_bus, int isl_state = 0, Polar* pol = nullptr) {
   const int wave = threadIdx.x >> 6;
   // isl_state (islanding outages, see island_state): 1 = the caller has de-energised the island
   // (mark_island) and the solve proceeds on the rest; 2 = the cut-off set is not known exactly
@@ -1766,7 +1786,7 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
     int pb_ = -1;
     // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
     if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM, SPEC>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0);
-    else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0, SPEC>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0) : newton(P, L, o, lane, out_br, &it, nrm);
+    else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0, SPEC, POLAR && NW == 1 && V2 != 0>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0, pol) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (pv_ == pv_ && pv_ < *min_piv) { *min_piv = pv_; *min_piv_bus = pb_; }
     if ((SPEC & SPEC_NO_PV) || !conv || !o.enforce_q_lims || P.npv == 0 || qg_min == nullptr) break;
@@ -1816,10 +1836,10 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 // `lane` / `stride`: the calling thread's index and the number of threads that share the work (a wavefront,
 // or the whole wave team)
-template <int V2, int SPEC = 0>
+template <int V2, int SPEC = 0, bool POLAR = false>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
-                                bool want_angle, int stride = WAVE) {
+                                bool want_angle, int stride = WAVE, const Polar* pol = nullptr) {
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
@@ -1829,11 +1849,28 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
   double* r_qe = r_pe + nref;
   double* r_qg = r_qe + nref;
   const double base = physical ? P.base_mva : 1.0;
+  if (POLAR) {
+    // |V| and the angle from the polar shadow (see Polar; stride == WAVE here: the bus -> lane map of phase D); the angle
+    // brought back into (-pi, pi] as atan2 reports it
+#pragma unroll
+    for (int r = 0; r < POLAR_R; ++r) {
+      const int i = lane + WAVE * r;
+      if (i >= nb) continue;
+      r_vm[i] = pol->vm[r];
+      if (want_angle) {
+        const double th = pol->th[r];
+        const double ang = fabs(th) <= M_PI ? th : th - (2.0 * M_PI) * rint(th * (0.5 / M_PI));
+        r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+      }
+    }
+  }
   for (int i = lane; i < nb; i += stride) {
-    r_vm[i] = sqrt(L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]);
-    if (want_angle) {
-      const double ang = atan2(L.vi[i], L.vr[i]);
-      r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+    if (!POLAR) {
+      r_vm[i] = sqrt(L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]);
+      if (want_angle) {
+        const double ang = atan2(L.vi[i], L.vr[i]);
+        r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
+      }
     }
     const int t = L.bt[i];
     double qgen = 0.0;
@@ -2033,6 +2070,19 @@ __global__ __launch_bounds__(WAVE * NW, OPFX_MIN_WAVES_PER_SIMD) void k_solve(co
 constexpr int NOSRC = 0x7FFFFFFF;
 __device__ __forceinline__ double src_val(const double* xs, const double* sp, int src) {
   return src == NOSRC ? 0.0 : (src >= 0 ? xs[src] : sp[~src]);
+}
+
+// the same with the table row in GLOBAL memory (after the solve the staged copy is gone) and the set-points in LDS: explicit
+// address spaces, so that no generic pointer is selected between the two (a flat load, and in some instantiations this
+// ROCm's backend dies on the LDS-to-flat cast of the uniform pointer: "Illegal instruction detected: V_CMP_NE_U32_e32 0,
+// $src_shared_base" — the stamps build did, round 5)
+__device__ __forceinline__ double src_val_g(const double* xr, const double* sp, int src) {
+  double v = 0.0;
+  if (src != NOSRC) {
+    if (src >= 0) v = ld_at(xr, (unsigned)src);
+    else v = ((const __attribute__((address_space(3))) double*)sp)[~src];
+  }
+  return v;
 }
 
 __device__ __forceinline__ double sgn(double v) { return (v > 0.0) - (v < 0.0); }
@@ -2661,6 +2711,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
   const DevEnv& E = *Ep;
   constexpr int SPEC = V2 ? (SPEC_ | OPFX_FORCE_SPEC) : 0;      // (the first-generation kernel is not specialised)
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
+  // (the polar shadow, see Polar: single-wave kernels at two wavefronts per SIMD without modifiers; the launch keeps grids of
+  //  more than 64 POLAR_R buses off these instantiations, do_step)
+  constexpr bool POLAR = V2 != 0 && NW == 1 && !MEM && !DC && !CHORD && MINW == 2 && NOMOD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2865,6 +2918,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     double nrm0 = 0.0;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
     int min_piv_bus = -1;
+    Polar pol;
     const int base_out = (!NOMOD && io.outage) ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
@@ -2909,13 +2963,20 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       const int isl = multi ? 1 : island_state(V2 != 0, n_rem, isl_br >= 0);
       if (wave == 0) {
         init_voltage<V2, SPEC>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims == 1);
+        if (POLAR) {                       // the polar shadow starts where init_voltage starts V (plan: vr0 + j vi0 = vm_set e^{j va_set})
+#pragma unroll
+          for (int r = 0; r < POLAR_R; ++r) {
+            const unsigned i = (unsigned)min(lane + WAVE * r, nb - 1);
+            pol.th[r] = ld_at(P.va_set, i); pol.vm[r] = ld_at(P.vm_set, i);
+          }
+        }
         if (multi) mark_islands_multi(P, L, lane, n_mod, E.qg_min, E.qg_max);
         else if (isl == 1) mark_island(P, L, lane, isl_br, E.qg_min, E.qg_max);
         if (!NOMOD && E.vset_src) for (int i = lane; i < nb; i += WAVE) {
           // per-instance |V| set-point of a REF / PV bus (a sampled ext_grid.vm_pu)
           const int src = as_global(E.vset_src)[i];
           if (src == NOSRC) continue;
-          const double f = src_val(xr, L.sp, src) / P.vm_set[i];
+          const double f = src_val_g(xr, L.sp, src) / P.vm_set[i];
           L.vr[i] *= f; L.vi[i] *= f;
           if (!V2) L.vm[i] *= f;
         }
@@ -2930,7 +2991,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD, SPEC>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl);
+      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD, SPEC, POLAR>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl, &pol);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
@@ -2954,7 +3015,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
-      compute_results<V2, SPEC>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT);
+      compute_results<V2, SPEC, POLAR>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
       blk_sync<NW>();
       if (wave == 0) {
       for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
@@ -2964,9 +3025,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         if (kind == OPFX_XRES_MAX3) {                      // (rows of this kind come after the rows they read)
           v = nan_max(nan_max(R[as_global(E.xres_p)[k]], R[as_global(E.xres_q)[k]]), R[as_global(E.xres_r)[k]]);
         } else {
-          const double pv_ = src_val(xr, L.sp, as_global(E.xres_p)[k]) * sc;
+          const double pv_ = src_val_g(xr, L.sp, as_global(E.xres_p)[k]) * sc;
           v = pv_;
-          if (kind == OPFX_XRES_S) { const double qv = src_val(xr, L.sp, as_global(E.xres_q)[k]) * sc; v = sqrt(pv_ * pv_ + qv * qv); }
+          if (kind == OPFX_XRES_S) { const double qv = src_val_g(xr, L.sp, as_global(E.xres_q)[k]) * sc; v = sqrt(pv_ * pv_ + qv * qv); }
         }
         R[E.nres_base + k] = v;
       }
@@ -3032,7 +3093,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
           double pw_, qv_;
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
           else {                                               // generator: zero power on a de-energised bus (results_gen.py)
-            pw_ = (!NOMOD && L.bt[pi] == BT_DEAD) ? 0.0 : src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r];
+            pw_ = (!NOMOD && L.bt[pi] == BT_DEAD) ? 0.0 : src_val_g(xr, L.sp, as_global(E.cost_qsrc)[r]) * as_global(E.cost_scale)[r];
             qv_ = r_qg[pi];
           }
           csum += cost_row(E, xr, meta, as_global(E.cost_cbase)[r], pw_, qv_);
@@ -3046,8 +3107,8 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
             if (bus < 0 || L.bt[bus] != BT_DEAD) continue;
             const int meta = as_global(E.cost_meta)[r], cbase = as_global(E.cost_cbase)[r];
             const double scl_ = as_global(E.cost_scale)[r];
-            csum -= cost_row(E, xr, meta, cbase, src_val(xr, L.sp, as_global(E.cost_psrc)[r]) * scl_,
-                             src_val(xr, L.sp, as_global(E.cost_qsrc)[r]) * scl_);
+            csum -= cost_row(E, xr, meta, cbase, src_val_g(xr, L.sp, as_global(E.cost_psrc)[r]) * scl_,
+                             src_val_g(xr, L.sp, as_global(E.cost_qsrc)[r]) * scl_);
             csum += cost_row(E, xr, meta, cbase, 0.0, 0.0);
           }
         }
@@ -3124,10 +3185,13 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         if (io.reward) io.reward[b] = rew;
         if (io.cost) io.cost[b] = valid ? 0.0 : fabs(penalty * E.penalty_factor) + cost_extra;  // :93-98,301-305
         if (io.objective) io.objective[b] = objective;
-        const int sie = io.step_in_episode ? io.step_in_episode[b] : 1;
+        // (the counter is read only where it decides something: the load would be waited for together with every result and
+        //  observation store issued above — one vmcnt counts both)
+        const int spe = E.steps_per_episode;
+        const int sie = (spe != 1 && io.step_in_episode) ? io.step_in_episode[b] : 1;
         unsigned char term = 0, trunc = 0;
-        if (E.steps_per_episode == 1) term = 1;                                      // opf_env.py:406-414
-        else if (sie >= E.steps_per_episode) trunc = 1;
+        if (spe == 1) term = 1;                                                      // opf_env.py:406-414
+        else if (sie >= spe) trunc = 1;
         if (io.terminated) io.terminated[b] = term;
         if (io.truncated) io.truncated[b] = trunc;
       }
@@ -3836,6 +3900,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   // the specialisation of this launch (SPEC): what the environment fixes for the whole batch, less what the call brings along
   int spec = env->ctx->v2 && !env->mem ? env->spec : 0;
   if (io->outage) spec &= ~SPEC_NO_MOD;
+  if (team == 1 && env->ctx->plan.nb > WAVE * POLAR_R) spec &= ~SPEC_NO_MOD;      // (the no-modifier single-wave kernels keep a polar shadow of POLAR_R bus rounds)
   spec &= OPFX_SPEC_MASK;
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
@@ -3946,7 +4011,11 @@ extern "C" int opfx_env_get_info(const opfx_env* env, int32_t* waves_per_instanc
 
 extern "C" int opfx_env_get_spec(const opfx_env* env, int32_t* spec) {
   if (!env) { opfx_set_error("opfx_env_get_spec: null environment"); return OPFX_ERR_INVALID; }
-  if (spec) *spec = (env->ctx->v2 && !env->mem) ? (env->spec & OPFX_SPEC_MASK) : 0;
+  if (spec) {
+    *spec = (env->ctx->v2 && !env->mem) ? (env->spec & OPFX_SPEC_MASK) : 0;
+    if (env->ctx->plan.nb > WAVE * POLAR_R && !env_three_teams_of_four(env)
+        && pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0) == 1) *spec &= ~SPEC_NO_MOD;      // (as do_step)
+  }
   return OPFX_OK;
 }
 
