@@ -3017,8 +3017,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
       compute_results<V2, SPEC, POLAR>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
       blk_sync<NW>();
-      if (wave == 0) {
-      for (int k = lane; k < E.n_xres; k += WAVE) {       // derived rows: unit power echoes, apparent power
+      // (derived rows and the constraint pass are shared by the whole team as well — with 250 contingencies per step they run
+      //  251 times per instance and were 5 % of an N-1 step on wavefront 0 alone, the other three parked at the barrier)
+      for (int k = tid; k < E.n_xres; k += NT) {          // derived rows: unit power echoes, apparent power
         const double sc = as_global(E.xres_scale)[k];
         const int kind = as_global(E.xres_kind)[k];
         double v;
@@ -3031,24 +3032,23 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         }
         R[E.nres_base + k] = v;
       }
-      sec_sync<NW>();
+      for (int q = tid; q < 5 * E.nc; q += NT) L.acc[q] = 0.0;
+      blk_sync<NW>();
       OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
       // violating lanes accumulate per-constraint sum / worst case / count in LDS
       {
-        for (int q = lane; q < 5 * E.nc; q += WAVE) L.acc[q] = 0.0;
-        wave_fence();
-        for (int e0 = 0; e0 < E.ncel; e0 += 2 * WAVE) {
+        for (int e0 = 0; e0 < E.ncel; e0 += 2 * NT) {
           int2 cd[2];
           double lo[2], hi[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int e = e0 + u * WAVE + lane, ee = e < E.ncel ? e : E.ncel - 1;
+            const int e = e0 + u * NT + tid, ee = e < E.ncel ? e : E.ncel - 1;
             { const auto* q = as_global(reinterpret_cast<const int*>(E.con_pk)) + 2 * (size_t)ee; cd[u] = make_int2(q[0], q[1]); } lo[u] = as_global(E.con_min)[ee]; hi[u] = as_global(E.con_max)[ee];
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int e = e0 + u * WAVE + lane;
+            const int e = e0 + u * NT + tid;
             if (e >= E.ncel) continue;
             const double v = R[cd[u].x];
             double* a = L.acc + 5 * cd[u].y;
@@ -3056,17 +3056,20 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
               const double d = fabs(v - lo[u]);
               lds_add(a + 0, d); lds_add(a + 4, 1.0);
               __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 2), (unsigned long long)__double_as_longlong(d),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                     __ATOMIC_RELAXED, NW == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (v > hi[u]) {
               const double d = fabs(v - hi[u]);
               lds_add(a + 1, d); lds_add(a + 4, 1.0);
               __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(a + 3), (unsigned long long)__double_as_longlong(d),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                     __ATOMIC_RELAXED, NW == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
-        wave_fence();
+      }
+      blk_sync<NW>();
+      if (wave == 0) {
+      {
         if (lane < E.nc) {
           const int g = lane;
           const double* a = L.acc + 5 * g;
