@@ -380,12 +380,11 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
     bound = max(cand, key=cand.get)
     # (template arguments as rocprofv3 prints them: block storage, wavefronts per instance, then DC / CHORD or — the plain
     #  kernels — SPEC=n, the specialisation on what the environment fixes for the whole batch, opfx_env_get_spec)
-    # (opfx_env_get_info reports the PLAIN kernel's team: on a plan with shared slots that is three teams of four on the kernel
-    #  compiled for three wavefronts per SIMD, which the DC-start kernels do not have — those launches run as teams of two)
-    name_team = 2 if (dc and team == 4 and env.plan.info['n_shared'] and ki['packed']) else team
-    kernel_name = f'k_step<{2 if ki["packed"] else 1},{name_team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + \
-        (f',SPEC={ki["spec"]}' if not (dc or chord) else '') + \
-        (',MINW=3' if not (dc or chord) and ki['waves_per_instance'] * ki['instances_per_cu'] > 8 else '') + '>'    # (the instantiation compiled for three wavefronts per SIMD)
+    # (the full-Newton kernels, plain and with the DC start, are specialised and exist for three wavefronts per SIMD; the
+    #  chord kernels are neither)
+    kernel_name = f'k_step<{2 if ki["packed"] else 1},{team}' + (',DC' if dc else '') + (',CHORD' if chord else '') + \
+        (f',SPEC={ki["spec"]}' if not chord else '') + \
+        (',MINW=3' if not chord and ki['waves_per_instance'] * ki['instances_per_cu'] > 8 and not (dc and team == 1) else '') + '>'    # (the instantiation compiled for three wavefronts per SIMD)
     # what the launch really has to read and write: the instance rows of the caller's buffers
     buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
                  'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}

@@ -577,9 +577,10 @@ int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t* n_four_va
  * of k_step in a profile): bit 0 = the plan has no PV bus, bit 1 = the environment has no per-instance branch modifier of
  * any kind (no switch / tap / shunt-step column, no N-1 contingency, no per-instance |V| set-point).  What the environment
  * fixes for the whole batch is compiled out of the kernel instead of being tested per instance; a call that brings an
- * `outage` array runs without bit 1.  (The plain full-Newton kernels only: the DC-start, chord-step and memory-resident
- * kernels and the first-generation fallback are not specialised — the DC + no-modifier combination runs into an
- * "Illegal instruction detected" error of this ROCm's AMDGPU backend, see EXPERIMENTS.md.) */
+ * `outage` array runs without bit 1; a single-wave launch on a grid of more than 256 buses runs without bit 1 as well (the
+ * no-modifier single-wave kernels keep |V| and the angle of four bus rounds in registers).  (The full-Newton kernels,
+ * plain and with the DC start; the chord-step and memory-resident kernels and the first-generation fallback are not
+ * specialised.) */
 int opfx_env_get_spec(const opfx_env* env, int32_t* spec);
 
 #ifdef __cplusplus

@@ -3308,7 +3308,7 @@ struct opfx_env {
   int per_cu = 0;        // resident workgroups per CU of the kernel that ran last (report: opfx_env_get_info)
   int per_cu_spec[4] = {0, 0, 0, 0};   // ... cached per specialisation of the plain step kernel (SPEC)
   int spec = 0;          // SPEC bits the environment itself allows (opfx_env_create)
-  int per_cu_dc = 0;     // (the same for the kernels compiled with the DC start)
+  int per_cu_dc[4] = {0, 0, 0, 0};     // (the same for the kernels compiled with the DC start)
   int per_cu_chord = 0;  // (and for those compiled with chord steps)
   bool mem = false;      // memory-resident step kernel (the LU blocks of this grid do not fit the LDS)
   int* queue = nullptr;  // this environment's own work-queue counter (two environments of a context do not share one)
@@ -3865,6 +3865,16 @@ static StepKernel step_kernel_w3_single(bool packed) {
   return packed ? k_step<2, 1, false, false, false, SPEC, 3> : k_step<1, 1, false, false, false, SPEC, 3>;
 }
 
+// the same for the kernels compiled with the DC start (round 5: specialised like the plain ones — the backend error that kept
+// them generic came from a generic pointer selected between the global row and the LDS set-points, see src_val_g)
+template <int SPEC>
+static StepKernel step_kernel_dc(bool packed, int team) {
+  return packed ? (team == 4 ? k_step<2, 4, true, false, false, SPEC> : (team == 2 ? k_step<2, 2, true, false, false, SPEC> : k_step<2, 1, true, false, false, SPEC>))
+                : (team == 4 ? k_step<1, 4, true, false, false, SPEC> : (team == 2 ? k_step<1, 2, true, false, false, SPEC> : k_step<1, 1, true, false, false, SPEC>));
+}
+template <int SPEC>
+static StepKernel step_kernel_dc_w3() { return k_step<2, 4, true, false, false, SPEC, 3>; }
+
 // Three instances of the grid fit a CU and its blocks are stored two-value: the plain step kernel runs them as three teams of
 // FOUR wavefronts compiled for three wavefronts per SIMD (k_step<2,4,...,MINW=3>) instead of three teams of two.
 static bool env_three_teams_of_four(const opfx_env* env) {
@@ -3893,9 +3903,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (o.init == OPFX_INIT_DC && !env->ctx->dp.lp_dc) { opfx_set_error("opfx_step: init = OPFX_INIT_DC needs a case with br_bdc / br_pfinj"); return OPFX_ERR_INVALID; }
   if (o.enforce_q_lims && !env->de.qg_min) o.enforce_q_lims = 0;
   int grid = 0;
-  // (the DC-start and chord kernels exist for two wavefronts per SIMD only: such launches keep the teams of two)
-  const bool plain_newton = o.init != OPFX_INIT_DC && !(o.reuse_tol > 0.0 && env->ctx->plan.n_shared == 0);
-  const bool w3 = plain_newton && env_three_teams_of_four(env);
+  // (the chord kernels exist for two wavefronts per SIMD only: such launches keep the teams of two)
+  const bool chord_launch = o.init != OPFX_INIT_DC && o.reuse_tol > 0.0 && env->ctx->plan.n_shared == 0;
+  const bool plain_newton = o.init != OPFX_INIT_DC && !chord_launch;
+  const bool w3 = !chord_launch && env_three_teams_of_four(env);
   const int team = env->mem ? 4 : (w3 ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0));
   DevPlan dp = env->ctx->dp;
   dp.nfull = env->n_full;
@@ -3908,7 +3919,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
                   : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
-  if (w3) kern = spec == 3 ? step_kernel_w3<3>() : spec == 2 ? step_kernel_w3<2>() : spec == 1 ? step_kernel_w3<1>() : step_kernel_w3<0>();
+  if (w3 && plain_newton) kern = spec == 3 ? step_kernel_w3<3>() : spec == 2 ? step_kernel_w3<2>() : spec == 1 ? step_kernel_w3<1>() : step_kernel_w3<0>();
   if (plain_newton && team == 1 && env_small_grid(env))
     kern = spec == 3 ? step_kernel_w3_single<3>(packed) : spec == 2 ? step_kernel_w3_single<2>(packed)
          : spec == 1 ? step_kernel_w3_single<1>(packed) : step_kernel_w3_single<0>(packed);
@@ -3933,11 +3944,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     if (rc != OPFX_OK) return rc;
   }
   if (o.init == OPFX_INIT_DC && env->ctx->v2) {      // the kernels compiled with the DC start (same launch geometry)
-    kern = packed ? (team == 4 ? k_step<2, 4, true> : (team == 2 ? k_step<2, 2, true> : k_step<2, 1, true>))
-                  : (team == 4 ? k_step<1, 4, true> : (team == 2 ? k_step<1, 2, true> : k_step<1, 1, true>));
-    int per_cu_dc = env->per_cu_dc;
-    rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &per_cu_dc, WAVE * team);
-    env->per_cu_dc = per_cu_dc;
+    kern = spec == 3 ? step_kernel_dc<3>(packed, team) : spec == 2 ? step_kernel_dc<2>(packed, team)
+         : spec == 1 ? step_kernel_dc<1>(packed, team) : step_kernel_dc<0>(packed, team);
+    if (w3) kern = spec == 3 ? step_kernel_dc_w3<3>() : spec == 2 ? step_kernel_dc_w3<2>() : spec == 1 ? step_kernel_dc_w3<1>() : step_kernel_dc_w3<0>();
+    rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_dc[spec], WAVE * team);
     if (rc != OPFX_OK) return rc;
   }
   StepIO s{};

@@ -8,6 +8,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 CFG = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 import bench
 cls, kw, _, _, _ = bench.CONFIGS[CFG]
+if os.environ.get('OPFX_REF'):                      # the reference's own solver settings (DC start, contingencies from scratch)
+    kw = dict(kw, reference_faithful=True)
 env = getattr(envs, cls)(batch_size=B, device='cuda:0', seed=0, **kw)
 rng = np.random.default_rng(1234)
 env.reset(options={'step': rng.choice(env.train_steps, B)})
