@@ -62,6 +62,15 @@ constexpr int SPEC_NO_PV = 1, SPEC_NO_MOD = 2;
 #ifndef OPFX_SPEC_MASK                      // (probe builds: -DOPFX_SPEC_MASK=0|1|2 keeps only these bits of what a launch would pick)
 #define OPFX_SPEC_MASK 3
 #endif
+// Developer probe (-DOPFX_DUP=<bit mask>, scripts/ab_dup.sh): phase k of k_step's prologue / epilogue runs TWICE — every one
+// of them is idempotent as far as the solve and the timing go — so that (time with the bit) - (time without) is what the
+// phase costs in the real mix of wavefronts, without the distortion of in-kernel cycle stamps (each stamp is a memory round
+// trip of its own and serialises what the hardware overlaps).  0 in the product: the loops fold away.
+#ifndef OPFX_DUP
+#define OPFX_DUP 0
+#endif
+#define OPFX_REP(k) for (int rep__ = 0; rep__ < 1 + ((OPFX_DUP >> (k)) & 1); ++rep__, dup_fence())
+__device__ __forceinline__ void dup_fence() { asm volatile("" ::: "memory"); }
 constexpr int MODE_SOLVE = 0;
 constexpr int MODE_ENV = 1;
 
@@ -2761,7 +2770,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     const bool apply = io.mode != 1 && io.mode != 3;
     OPFX_STAMP(15);
     // ---- stage the row ------------------------------------------------------------
-    {
+    OPFX_REP(0) {
       const int nx = E.nx;
       int q = tid;
       for (; q + 7 * NT < nx; q += 8 * NT) {
@@ -2777,7 +2786,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     OPFX_STAMP(16);
     // ---- apply actions (opf_env.py:421-491) -----------------------------------
     double corr = 0.0;
-    if (wave == 0) {
+    OPFX_REP(1) if (wave == 0) {
       // (no action row in modes 1/3: any readable row keeps the loads unconditional)
       const double* act_row = uniform_ptr(apply ? io.action + b * E.na : xr);
       // reset applies its initial action as ABSOLUTE set-points (opf_env.py:207 passes no step size),
@@ -2835,7 +2844,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     // (limits are read before any set-point of this step is written back: xs keeps the
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
-    if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+    OPFX_REP(2) if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
       const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
       // (stores as wave-uniform base + 32-bit lane offset: no 64-bit per-lane address, which the compiler would compute
       //  once per kernel — pointer + lane * 8 — and keep in two VGPRs through every Newton loop)
@@ -2861,6 +2870,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // workgroup's P/Q row
       double* const pacc = V2 ? L.vr : L.psp;
       double* const qacc = V2 ? L.vi : L.qsp;
+      OPFX_REP(3) {
       for (int i = lane; i < nb; i += WAVE) { pacc[i] = 0.0; qacc[i] = 0.0; L.bt[i] = BT_PQ; }
       wave_fence();
       for (int e0 = 0; e0 < E.n_inj; e0 += 4 * WAVE) {
@@ -2882,13 +2892,14 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         //  compiler computes at kernel entry and keeps — or spills — through every Newton loop)
         for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(L.psp, io_, pacc[i]); st_at(L.qsp, io_, qacc[i]); }
       }
+      }
       OPFX_STAMP(19);
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
       // (Every phase of this prologue starts with descriptor loads and so with a memory round trip of its own,
       // 17 k of the 135 k cycles of a 144-bus step in the cycle stamps.  Issuing each phase's first batch of loads
       // one phase ahead shortened the prologue by 12 % and the kernel by nothing, 0.3027 vs 0.3003 ms: the second
       // wavefront of the SIMD already fills those waits; what bounds the kernel is the instructions it issues.)
-      for (int r0 = 0; r0 < E.ncost_pre; r0 += 2 * WAVE) {
+      OPFX_REP(4) for (int r0 = 0; r0 < E.ncost_pre; r0 += 2 * WAVE) {
         int meta[2], ps[2], qs[2], cb[2];
         double scl[2];
 #pragma unroll
@@ -2962,7 +2973,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       const bool multi = V2 != 0 && n_rem >= 2;
       const int isl = multi ? 1 : island_state(V2 != 0, n_rem, isl_br >= 0);
       if (wave == 0) {
-        init_voltage<V2, SPEC>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims == 1);
+        OPFX_REP(5) init_voltage<V2, SPEC>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims == 1);
         if (POLAR) {                       // the polar shadow starts where init_voltage starts V (plan: vr0 + j vi0 = vm_set e^{j va_set})
 #pragma unroll
           for (int r = 0; r < POLAR_R; ++r) {
@@ -3015,11 +3026,11 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
-      compute_results<V2, SPEC, POLAR>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
+      OPFX_REP(6) compute_results<V2, SPEC, POLAR>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
       blk_sync<NW>();
       // (derived rows and the constraint pass are shared by the whole team as well — with 250 contingencies per step they run
       //  251 times per instance and were 5 % of an N-1 step on wavefront 0 alone, the other three parked at the barrier)
-      for (int k = tid; k < E.n_xres; k += NT) {          // derived rows: unit power echoes, apparent power
+      OPFX_REP(7) for (int k = tid; k < E.n_xres; k += NT) {          // derived rows: unit power echoes, apparent power
         const double sc = as_global(E.xres_scale)[k];
         const int kind = as_global(E.xres_kind)[k];
         double v;
@@ -3037,7 +3048,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       OPFX_STAMP(6);
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
       // violating lanes accumulate per-constraint sum / worst case / count in LDS
-      {
+      OPFX_REP(8) {
         for (int e0 = 0; e0 < E.ncel; e0 += 2 * NT) {
           int2 cd[2];
           double lo[2], hi[2];
@@ -3091,7 +3102,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         const double* r_pe = R + 2 * nb + P.nbr;
         const double* r_qe = r_pe + P.nref;
         const double* r_qg = r_qe + P.nref;
-        for (int r = E.ncost_pre + lane; r < E.ncost; r += WAVE) {
+        OPFX_REP(9) for (int r = E.ncost_pre + lane; r < E.ncost; r += WAVE) {
           const int meta = as_global(E.cost_meta)[r], pi = as_global(E.cost_psrc)[r];
           double pw_, qv_;
           if ((meta & 15) == OPFX_COST_EXT_GRID) { pw_ = r_pe[pi]; qv_ = r_qe[pi]; }
@@ -3121,11 +3132,11 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         }
         objective = -(cost_pre + wave_sum_dpp(csum));                                    // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
-        if (io.results) { double* const rb = uniform_ptr(io.results + b * E.nres); for (int q = lane; q < E.nres; q += WAVE) st_at(rb, (unsigned)q, R[q]); }
+        OPFX_REP(10) if (io.results) { double* const rb = uniform_ptr(io.results + b * E.nres); for (int q = lane; q < E.nres; q += WAVE) st_at(rb, (unsigned)q, R[q]); }
       }
       OPFX_STAMP(8);
       // result observations reflect the LAST solved case (defect D7 of the reference)
-      if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+      OPFX_REP(11) if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
         if (as_global(E.oseg_kind)[sg] != 1) continue;
         const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
         double* const ob = uniform_ptr(io.obs + b * E.nobs + dst);
@@ -3541,6 +3552,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
   int n_full = ctx->plan.n_blk;
   size_t lds = choose_block_storage(ctx->plan, ctx->dbg, [&](int nf) { return solver_lds_bytes(ctx->plan, 0, nres, ctx->v2, 8, 1, nf); }, &n_full);
   DevPlan dp = ctx->dp;
+#ifndef OPFX_DEV_MIN
   if (wants_mem(ctx->dbg, lds, ctx->v2)) {
     if (ctx->plan.n_shared > 0) { opfx_set_error("opfx_solve: a plan with shared slots does not run on the memory-resident kernels"); return OPFX_ERR_INVALID; }
     // the LU blocks do not fit the LDS beside the state vectors: wave team of four, four-value blocks in global memory
@@ -3565,16 +3577,25 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     HIP_TRY(hipGetLastError());
     return OPFX_OK;
   }
+#endif
   dp.nfull = n_full;
   int grid = 0;
   const int team = pick_team(ctx->dbg, lds, ctx->v2, ctx->plan.n_shared > 0);
   const bool packed = n_full < ctx->plan.n_blk;
+  // (-DOPFX_DEV_MIN: a developer build with the headline instantiations only — k_solve<2,1>, k_step<2,1,SPEC=3> — that
+  //  compiles in seconds; it serves launches that would pick exactly those and nothing else)
+#ifdef OPFX_DEV_MIN
+  if (!ctx->v2 || !packed || team != 1 || o.init == OPFX_INIT_DC || o.reuse_tol > 0.0) { opfx_set_error("OPFX_DEV_MIN build: k_solve<2,1> only"); return OPFX_ERR_INVALID; }
+  auto kern = k_solve<2, 1>;
+#else
   auto kern = !ctx->v2 ? k_solve<0, 1>
             : packed ? (team == 4 ? k_solve<2, 4> : (team == 2 ? k_solve<2, 2> : k_solve<2, 1>))
                      : (team == 4 ? k_solve<1, 4> : (team == 2 ? k_solve<1, 2> : k_solve<1, 1>));
+#endif
   int rc = launch_geometry(ctx->dbg, kern, lds, ctx->n_cu, B, &grid, &ctx->solve_per_cu, WAVE * team);
   if (rc != OPFX_OK) return rc;
   if (ctx->plan.n_shared > 0) o.reuse_tol = 0.0;      // (chord iterations re-read lower blocks whose slots have new tenants by then)
+#ifndef OPFX_DEV_MIN
   if (o.init == OPFX_INIT_DC && ctx->v2) {           // the kernels compiled with the DC start (same launch geometry)
     kern = packed ? (team == 4 ? k_solve<2, 4, true> : (team == 2 ? k_solve<2, 2, true> : k_solve<2, 1, true>))
                   : (team == 4 ? k_solve<1, 4, true> : (team == 2 ? k_solve<1, 2, true> : k_solve<1, 1, true>));
@@ -3590,6 +3611,7 @@ extern "C" int opfx_solve(opfx_ctx* ctx, int64_t B, const double* p_inj, const d
     ctx->solve_per_cu_chord = per_cu_c;
     if (rc != OPFX_OK) return rc;
   }
+#endif
   if (o.init == OPFX_INIT_DC || !ctx->v2 || ctx->plan.n_shared > 0) o.reuse_tol = 0.0;
   rc = ensure_scratch(ctx, grid, false);
   if (rc != OPFX_OK) return rc;
@@ -3916,6 +3938,10 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (io->outage) spec &= ~SPEC_NO_MOD;
   if (team == 1 && env->ctx->plan.nb > WAVE * POLAR_R) spec &= ~SPEC_NO_MOD;      // (the no-modifier single-wave kernels keep a polar shadow of POLAR_R bus rounds)
   spec &= OPFX_SPEC_MASK;
+#ifdef OPFX_DEV_MIN
+  if (!env->ctx->v2 || env->mem || !packed || team != 1 || spec != 3 || !plain_newton || env_small_grid(env)) { opfx_set_error("OPFX_DEV_MIN build: k_step<2,1,SPEC=3> only"); return OPFX_ERR_INVALID; }
+  StepKernel kern = k_step<2, 1, false, false, false, 3>;
+#else
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)
                   : spec == 1 ? step_kernel<1>(packed, team) : step_kernel<0>(packed, team);
@@ -3924,6 +3950,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     kern = spec == 3 ? step_kernel_w3_single<3>(packed) : spec == 2 ? step_kernel_w3_single<2>(packed)
          : spec == 1 ? step_kernel_w3_single<1>(packed) : step_kernel_w3_single<0>(packed);
   if (env->mem) kern = k_step<1, 4, false, true>;
+#endif
   int rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_spec[spec], WAVE * team);
   env->per_cu = env->per_cu_spec[spec];
   if (rc != OPFX_OK) return rc;
@@ -3935,6 +3962,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     o.reuse_tol = 0.0;                                            // (nor chord steps)
   }
   if (o.init == OPFX_INIT_DC || !env->ctx->v2 || env->ctx->plan.n_shared > 0) o.reuse_tol = 0.0;      // (chord steps: not together with the DC start, nor on shared slots)
+#ifndef OPFX_DEV_MIN
   if (o.reuse_tol > 0.0) {                           // the kernels compiled with chord steps (same launch geometry)
     kern = packed ? (team == 4 ? k_step<2, 4, false, false, true> : (team == 2 ? k_step<2, 2, false, false, true> : k_step<2, 1, false, false, true>))
                   : (team == 4 ? k_step<1, 4, false, false, true> : (team == 2 ? k_step<1, 2, false, false, true> : k_step<1, 1, false, false, true>));
@@ -3950,6 +3978,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_dc[spec], WAVE * team);
     if (rc != OPFX_OK) return rc;
   }
+#endif
   StepIO s{};
   s.x = io->x; s.action = io->action; s.initial_obj = io->initial_obj;
   s.step_in_episode = io->step_in_episode; s.outage = io->outage;
