@@ -1919,11 +1919,26 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     r_qg[i] = qgen;
   }
+  // (the stamps and factors of the NEXT round of branches are requested before this round is worked: the rounds were a chain
+  //  of memory round trips — 5 % of a 144-bus step, found with -DOPFX_DUP — and are one round trip plus arithmetic now)
+  struct BrRow { double y[8]; int f, t; double kf, kt; };
+  auto ld_row = [&](int k) {
+    const unsigned kc = (unsigned)(k < nbr ? k : nbr - 1);
+    BrRow r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r.y[q] = ld_at(P.br_y, 8 * kc + q);
+    r.f = ld_at(P.br_f, kc); r.t = ld_at(P.br_t, kc); r.kf = ld_at(P.br_kf, kc); r.kt = ld_at(P.br_kt, kc);
+    return r;
+  };
+  BrRow nxt_row{};
+  if (nbr > 0) nxt_row = ld_row(lane);
   for (int k = lane; k < nbr; k += stride) {
     double ld = 0.0;
+    const BrRow row = nxt_row;
+    nxt_row = ld_row(k + stride);
     double y[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) y[q] = P.br_y[8 * k + q];
+    for (int q = 0; q < 8; ++q) y[q] = row.y[q];
     bool removed = !V2 && k == out_br;
     if (V2 && !NOMOD) for (int m = 0; m < n_mod; ++m) {
       const int* id = mod_ids(L, m);
@@ -1935,7 +1950,7 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     }
     // |V| of a de-energised bus is NaN and so is every current computed with it (pandapower divides the
     // branch's apparent power by it), in service or not
-    const int f = P.br_f[k], t = P.br_t[k];
+    const int f = row.f, t = row.t;
     if (!NOMOD && (L.bt[f] == BT_DEAD || L.bt[t] == BT_DEAD)) { r_ld[k] = __builtin_nan(""); continue; }
     if (!removed) {
       const double vfr = L.vr[f], vfi = L.vi[f], vtr = L.vr[t], vti = L.vi[t];
@@ -1943,7 +1958,8 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
       const double ifi = y[0] * vfi + y[1] * vfr + y[2] * vti + y[3] * vtr;
       const double itr = y[4] * vfr - y[5] * vfi + y[6] * vtr - y[7] * vti;
       const double iti = y[4] * vfi + y[5] * vfr + y[6] * vti + y[7] * vtr;
-      ld = fmax(sqrt(ifr * ifr + ifi * ifi) * P.br_kf[k], sqrt(itr * itr + iti * iti) * P.br_kt[k]);
+      // (one square root for the two ends: kf, kt >= 0, so max(|If| kf, |It| kt) = sqrt(max(|If|^2 kf^2, |It|^2 kt^2)))
+      ld = sqrt(fmax((ifr * ifr + ifi * ifi) * (row.kf * row.kf), (itr * itr + iti * iti) * (row.kt * row.kt)));
     }
     r_ld[k] = ld;
   }
@@ -2873,14 +2889,32 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       OPFX_REP(3) {
       for (int i = lane; i < nb; i += WAVE) { pacc[i] = 0.0; qacc[i] = 0.0; L.bt[i] = BT_PQ; }
       wave_fence();
-      for (int e0 = 0; e0 < E.n_inj; e0 += 4 * WAVE) {
-        uint4 d[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = e0 + u * WAVE + lane; const auto* q = as_global(reinterpret_cast<const unsigned*>(E.inj_pk)) + 4 * (size_t)(e < E.n_inj ? e : E.n_inj - 1); d[u] = make_uint4(q[0], q[1], q[2], q[3]); }
+      // (the entries of the next batch are requested before this batch is added up: one memory round trip for the list
+      //  instead of one per batch of 256 entries)
+      const int n_inj = E.n_inj;
+      const uint4* const inj_pk = E.inj_pk;
+      struct InjBatch { uint4 d[4]; };
+      auto ld_inj = [&](int e0) {
+        InjBatch r;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u * WAVE + lane;
-          if (e >= E.n_inj) continue;
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 w = ld_at(reinterpret_cast<const u32x4*>(inj_pk), (unsigned)(e < n_inj ? e : n_inj - 1));
+          r.d[u] = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        return r;
+      };
+      InjBatch nxt_inj{};
+      if (n_inj > 0) nxt_inj = ld_inj(0);
+      for (int e0 = 0; e0 < n_inj; e0 += 4 * WAVE) {
+        const InjBatch cur_inj = nxt_inj;
+        nxt_inj = ld_inj(e0 + 4 * WAVE);
+        const uint4 (&d)[4] = cur_inj.d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * WAVE + lane;
+          if (e >= n_inj) continue;
           const int bq = d[u].x;
           const double v = u2d(d[u].z, d[u].w) * src_val(xs, L.sp, (int)d[u].y);
           lds_add(((bq >> 16) ? qacc : pacc) + (bq & 0xFFFF), v);
@@ -3049,18 +3083,33 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // ---- constraints (constraints.py:70-128): one pass over all bounded values; the rare
       // violating lanes accumulate per-constraint sum / worst case / count in LDS
       OPFX_REP(8) {
-        for (int e0 = 0; e0 < E.ncel; e0 += 2 * NT) {
-          int2 cd[2];
-          double lo[2], hi[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int e = e0 + u * NT + tid, ee = e < E.ncel ? e : E.ncel - 1;
-            { const auto* q = as_global(reinterpret_cast<const int*>(E.con_pk)) + 2 * (size_t)ee; cd[u] = make_int2(q[0], q[1]); } lo[u] = as_global(E.con_min)[ee]; hi[u] = as_global(E.con_max)[ee];
-          }
+        // (the descriptors of the next batch are requested before this batch is worked: one memory round trip for the pass
+        //  instead of one per batch)
+        struct ConBatch { int2 cd[2]; double lo[2], hi[2]; };
+        const int ncel = E.ncel;
+        const int2* const con_pk = E.con_pk; const double* const con_min = E.con_min; const double* const con_max = E.con_max;
+        auto ld_con = [&](int e0) {
+          ConBatch c;
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int e = e0 + u * NT + tid;
-            if (e >= E.ncel) continue;
+            const unsigned ee = (unsigned)(e < ncel ? e : ncel - 1);
+            const long long pk = ld_at(reinterpret_cast<const long long*>(con_pk), ee);
+            c.cd[u] = make_int2((int)(unsigned)pk, (int)(pk >> 32)); c.lo[u] = ld_at(con_min, ee); c.hi[u] = ld_at(con_max, ee);
+          }
+          return c;
+        };
+        ConBatch nxt_con{};
+        if (ncel > 0) nxt_con = ld_con(0);
+        for (int e0 = 0; e0 < ncel; e0 += 2 * NT) {
+          const ConBatch cb_ = nxt_con;
+          nxt_con = ld_con(e0 + 2 * NT);
+          const int2 (&cd)[2] = cb_.cd;
+          const double (&lo)[2] = cb_.lo, (&hi)[2] = cb_.hi;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * NT + tid;
+            if (e >= ncel) continue;
             const double v = R[cd[u].x];
             double* a = L.acc + 5 * cd[u].y;
             if (v < lo[u]) {
@@ -3977,6 +4026,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
     if (w3) kern = spec == 3 ? step_kernel_dc_w3<3>() : spec == 2 ? step_kernel_dc_w3<2>() : spec == 1 ? step_kernel_dc_w3<1>() : step_kernel_dc_w3<0>();
     rc = launch_geometry(env->ctx->dbg, kern, env->lds_bytes, env->ctx->n_cu, B, &grid, &env->per_cu_dc[spec], WAVE * team);
     if (rc != OPFX_OK) return rc;
+    env->per_cu = env->per_cu_dc[spec];          // (what opfx_env_get_info reports: the launch that ran last)
   }
 #endif
   StepIO s{};

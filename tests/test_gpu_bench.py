@@ -91,9 +91,11 @@ def test_bench_default_line_carries_cpu_baseline_voltage_check_and_the_other_con
     for name in ('config2', 'config3', 'config5'):
         a = rs[name]
         assert 'error' not in a, (name, a)
-        assert a['newton_start'] == 'dc' and a['contingency_start'] == 'flat' and ',DC>' in a['kernel'], (name, a['kernel'])
+        assert a['newton_start'] == 'dc' and a['contingency_start'] == 'flat' and ',DC,' in a['kernel'], (name, a['kernel'])
         assert a['value'] > 0 and a['converged_fraction'] > 0.99 and a['max_abs_v_err_pu'] is not None and a['max_abs_v_err_pu'] < 1e-9, name
         assert a['roofline']['counters_from'] is None          # (the committed counters are the plain kernel's)
+    # (the DC-start kernels are specialised and compiled for three wavefronts per SIMD like the plain ones)
+    assert [rs[f'config{c}']['kernel'] for c in (2, 3, 5)] == ['k_step<2,1,DC,SPEC=3>', 'k_step<2,4,DC,SPEC=2,MINW=3>', 'k_step<2,4,DC,SPEC=1>']
     # contingencies from scratch cost iterations: more of them than from the base case's solution
     assert rs['config5']['mean_nr_iterations_all_solves'] > d['also']['config5']['mean_nr_iterations_all_solves']
 
