@@ -3988,8 +3988,15 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   if (team == 1 && env->ctx->plan.nb > WAVE * POLAR_R) spec &= ~SPEC_NO_MOD;      // (the no-modifier single-wave kernels keep a polar shadow of POLAR_R bus rounds)
   spec &= OPFX_SPEC_MASK;
 #ifdef OPFX_DEV_MIN
-  if (!env->ctx->v2 || env->mem || !packed || team != 1 || spec != 3 || !plain_newton || env_small_grid(env)) { opfx_set_error("OPFX_DEV_MIN build: k_step<2,1,SPEC=3> only"); return OPFX_ERR_INVALID; }
-  StepKernel kern = k_step<2, 1, false, false, false, 3>;
+  // (-DOPFX_DEV_TEAM=4 -DOPFX_DEV_SPEC=1: the developer build for another plain two-value instantiation, e.g. config 5's)
+#ifndef OPFX_DEV_TEAM
+#define OPFX_DEV_TEAM 1
+#endif
+#ifndef OPFX_DEV_SPEC
+#define OPFX_DEV_SPEC 3
+#endif
+  if (!env->ctx->v2 || env->mem || !packed || team != OPFX_DEV_TEAM || spec != OPFX_DEV_SPEC || !plain_newton || w3 || (team == 1 && env_small_grid(env))) { opfx_set_error("OPFX_DEV_MIN build: one plain two-value k_step instantiation only"); return OPFX_ERR_INVALID; }
+  StepKernel kern = k_step<2, OPFX_DEV_TEAM, false, false, false, OPFX_DEV_SPEC>;
 #else
   StepKernel kern = !env->ctx->v2 ? static_cast<StepKernel>(k_step<0, 1>)
                   : spec == 3 ? step_kernel<3>(packed, team) : spec == 2 ? step_kernel<2>(packed, team)

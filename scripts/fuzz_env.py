@@ -139,7 +139,11 @@ def np_(t):
 
 
 def run_one(base, kw, rng, B=8):
-    env = product_env(base, batch_size=B, **kw)
+    # OPFX_FUZZ_INIT=auto|dc: the product with pandapower's start (a DC power flow first where the grid is fed above 70 kV):
+    # the DC-start kernels and their specialisations against the same oracle — same fixed point, same converged set away from
+    # voltage collapse (nothing is drawn for it, so a campaign replays with and without)
+    pk = dict(kw, init=os.environ['OPFX_FUZZ_INIT']) if os.environ.get('OPFX_FUZZ_INIT') else kw
+    env = product_env(base, batch_size=B, **pk)
     orc = oracle_env(base, product_env(base, defer_device=True, **kw))
     is_test = 'test_data' in kw and rng.random() < 0.5
     distr = env.test_data if is_test else env.train_data
