@@ -120,6 +120,7 @@ struct DevEnv {
   int nblk_d;                // doubles reserved for [LU blocks | result bank | staged table row beyond rhs]
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
   int n_cont, n_inj, n_oseg, need_angle, ncel;
+  int n_oseg_res;            // observation segments read from the result bank (0: the epilogue writes no observation)
   int max_mod;               // modifier records reserved per instance (env modifiers + outage + contingency)
   int n_bmod;                // branch state columns (taps, switches): see opfx_env_desc.bmod_*
   const int *act_kind, *bmod_branch, *bmod_src, *bmod_lo, *bmod_n, *bmod_ptr;
@@ -2860,7 +2861,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     // (limits are read before any set-point of this step is written back: xs keeps the
     //  pre-step values, exactly as the reference reads min/max columns that actions never touch)
     // ---- table observations: do not depend on the solve ----------------------------------------
-    OPFX_REP(2) if (wave == 0 && io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
+    // (the copy phases of a team's prologue and epilogue — table observations, injections, results, result observations — are
+    //  shared by its wavefronts: segment by segment, or thread by thread; with one wavefront this is the code it always was)
+    OPFX_REP(2) if (io.obs) for (int sg = wave; sg < E.n_oseg; sg += NW) {
       const int kind = as_global(E.oseg_kind)[sg], src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
       // (stores as wave-uniform base + 32-bit lane offset: no 64-bit per-lane address, which the compiler would compute
       //  once per kernel — pointer + lane * 8 — and keep in two VGPRs through every Newton loop)
@@ -2880,15 +2883,15 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     }
     OPFX_STAMP(18);
     double csum = 0.0;                       // this lane's share of the cost rows
-    if (wave == 0) {
+    {
       // ---- bus injections (makeSbus): flat list, LDS accumulate ----------------------------------
       // accumulated in the voltage arrays (free until init_voltage), then written to this
       // workgroup's P/Q row
       double* const pacc = V2 ? L.vr : L.psp;
       double* const qacc = V2 ? L.vi : L.qsp;
       OPFX_REP(3) {
-      for (int i = lane; i < nb; i += WAVE) { pacc[i] = 0.0; qacc[i] = 0.0; L.bt[i] = BT_PQ; }
-      wave_fence();
+      for (int i = tid; i < nb; i += NT) { pacc[i] = 0.0; qacc[i] = 0.0; L.bt[i] = BT_PQ; }
+      blk_sync<NW>();
       // (the entries of the next batch are requested before this batch is added up: one memory round trip for the list
       //  instead of one per batch of 256 entries)
       const int n_inj = E.n_inj;
@@ -2898,7 +2901,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         InjBatch r;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * WAVE + lane;
+          const int e = e0 + u * NT + tid;
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const u32x4 w = ld_at(reinterpret_cast<const u32x4*>(inj_pk), (unsigned)(e < n_inj ? e : n_inj - 1));
           r.d[u] = make_uint4(w.x, w.y, w.z, w.w);
@@ -2907,13 +2910,13 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       };
       InjBatch nxt_inj{};
       if (n_inj > 0) nxt_inj = ld_inj(0);
-      for (int e0 = 0; e0 < n_inj; e0 += 4 * WAVE) {
+      for (int e0 = 0; e0 < n_inj; e0 += 4 * NT) {
         const InjBatch cur_inj = nxt_inj;
-        nxt_inj = ld_inj(e0 + 4 * WAVE);
+        nxt_inj = ld_inj(e0 + 4 * NT);
         const uint4 (&d)[4] = cur_inj.d;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * WAVE + lane;
+          const int e = e0 + u * NT + tid;
           if (e >= n_inj) continue;
           const int bq = d[u].x;
           const double v = u2d(d[u].z, d[u].w) * src_val(xs, L.sp, (int)d[u].y);
@@ -2921,12 +2924,15 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         }
       }
       if (V2) {
-        wave_fence();
+        blk_sync<NW>();
         // (scalar base + 32-bit lane offset: the per-workgroup rows never turn into 64-bit per-lane addresses that the
         //  compiler computes at kernel entry and keeps — or spills — through every Newton loop)
-        for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(L.psp, io_, pacc[i]); st_at(L.qsp, io_, qacc[i]); }
+        for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); st_at(L.psp, io_, pacc[i]); st_at(L.qsp, io_, qacc[i]); }
+        if (NW > 1) blk_sync<NW>();          // (the sums are out of the voltage arrays before wavefront 0 starts them: init_voltage)
       }
       }
+    }
+    if (wave == 0) {
       OPFX_STAMP(19);
       // ---- cost rows whose power is a table value / set-point (objective.py:34-54) --------------
       // (Every phase of this prologue starts with descriptor loads and so with a memory round trip of its own,
@@ -3127,6 +3133,15 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
           }
         }
       }
+      // (the result bank is complete and stays as it is until the next solve: written out by the whole team)
+      if (c == 0) OPFX_REP(10) if (io.results) { double* const rb = uniform_ptr(io.results + b * E.nres); for (int q = tid; q < E.nres; q += NT) st_at(rb, (unsigned)q, R[q]); }
+      // result observations reflect the LAST solved case (defect D7 of the reference)
+      OPFX_REP(11) if (io.obs && E.n_oseg_res > 0) for (int sg = wave; sg < E.n_oseg; sg += NW) {
+        if (as_global(E.oseg_kind)[sg] != 1) continue;
+        const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
+        double* const ob = uniform_ptr(io.obs + b * E.nobs + dst);
+        for (int j = lane; j < n; j += WAVE) st_at(ob, (unsigned)j, R[src + j]);
+      }
       blk_sync<NW>();
       if (wave == 0) {
       {
@@ -3181,16 +3196,8 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         }
         objective = -(cost_pre + wave_sum_dpp(csum));                                    // opf_env.py:500
         if (E.diff_objective && io.initial_obj) objective -= io.initial_obj[b];      // :497-498
-        OPFX_REP(10) if (io.results) { double* const rb = uniform_ptr(io.results + b * E.nres); for (int q = lane; q < E.nres; q += WAVE) st_at(rb, (unsigned)q, R[q]); }
       }
       OPFX_STAMP(8);
-      // result observations reflect the LAST solved case (defect D7 of the reference)
-      OPFX_REP(11) if (io.obs) for (int sg = 0; sg < E.n_oseg; ++sg) {
-        if (as_global(E.oseg_kind)[sg] != 1) continue;
-        const int src = as_global(E.oseg_src)[sg], dst = as_global(E.oseg_dst)[sg], n = as_global(E.oseg_n)[sg];
-        double* const ob = uniform_ptr(io.obs + b * E.nobs + dst);
-        for (int j = lane; j < n; j += WAVE) st_at(ob, (unsigned)j, R[src + j]);
-      }
       }
       blk_sync<NW>();
     }
@@ -3829,6 +3836,7 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
       else { sk.push_back(kind); ss.push_back(src); sd.push_back(k); sn.push_back(1); }
     }
     E.n_oseg = (int)sk.size();
+    E.n_oseg_res = (int)std::count(sk.begin(), sk.end(), 1);
     e->h_oseg[0] = sk; e->h_oseg[1] = ss; e->h_oseg[2] = sd; e->h_oseg[3] = sn;
     if (rc == OPFX_OK) rc = A.put(sk, &E.oseg_kind);
     if (rc == OPFX_OK) rc = A.put(ss, &E.oseg_src);
