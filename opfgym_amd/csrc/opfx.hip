@@ -1700,9 +1700,9 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
 // its generator share removed from q_sp again (L.bt must hold valid codes).
 template <int V2, int SPEC = 0>
 __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const double* qg_min,
-                             const double* qg_max, bool pin_point_ranges) {
+                             const double* qg_max, bool pin_point_ranges, int stride = WAVE) {
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0;           // (no PV bus: nothing is ever pinned at a reactive limit)
-  for (int i = lane; i < P.nb; i += WAVE) {
+  for (int i = lane; i < P.nb; i += stride) {
     const int t = NOPV ? BT_PQ : L.bt[i];
     if (t == BT_PQ_HI) L.qsp[i] -= qg_max[i];
     if (t == BT_PQ_LO) L.qsp[i] -= qg_min[i];
@@ -3012,8 +3012,12 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // one branch out: its cut-off set is precomputed; several: connectivity is labelled per instance
       const bool multi = V2 != 0 && n_rem >= 2;
       const int isl = multi ? 1 : island_state(V2 != 0, n_rem, isl_br >= 0);
+      // (the start voltages — and the base-case voltages a contingency starts from — are written by the whole team: with 250
+      //  contingencies per step this runs 251 times per instance; the rare rest keeps to wavefront 0, between two barriers)
+      OPFX_REP(5) init_voltage<V2, SPEC>(P, L, tid, E.qg_min, E.qg_max, o.enforce_q_lims == 1, NT);
+      const bool rare_start = multi || isl == 1 || (!NOMOD && E.vset_src != nullptr);
+      if (NW > 1 && rare_start) blk_sync<NW>();
       if (wave == 0) {
-        OPFX_REP(5) init_voltage<V2, SPEC>(P, L, lane, E.qg_min, E.qg_max, o.enforce_q_lims == 1);
         if (POLAR) {                       // the polar shadow starts where init_voltage starts V (plan: vr0 + j vi0 = vm_set e^{j va_set})
 #pragma unroll
           for (int r = 0; r < POLAR_R; ++r) {
@@ -3031,13 +3035,14 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
           L.vr[i] *= f; L.vi[i] *= f;
           if (!V2) L.vm[i] *= f;
         }
-        if (c > 0 && o.contingency_start == 0) {
-          // contingency cases start from the base-case solution (the reference restarts
-          // pandapower from scratch for each one; the converged result is the same;
-          // opfx_solve_opts::contingency_start = 1 does exactly what the reference does)
-          const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
-          for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); L.vr[i] = ld_at(wv, io_); L.vi[i] = ld_at(wv, (unsigned)nb + io_); }
-        }
+      }
+      if (NW > 1 && rare_start) blk_sync<NW>();
+      if (c > 0 && o.contingency_start == 0) {
+        // contingency cases start from the base-case solution (the reference restarts
+        // pandapower from scratch for each one; the converged result is the same;
+        // opfx_solve_opts::contingency_start = 1 does exactly what the reference does)
+        const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
+        for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); L.vr[i] = ld_at(wv, io_); L.vi[i] = ld_at(wv, (unsigned)nb + io_); }
       }
       blk_sync<NW>();
       int iters; double nrm;
@@ -3049,10 +3054,10 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       if (c == 0) {
         conv0 = conv; iters0 = iters; nrm0 = nrm;
         if (!conv) break;
-        if (!NOMOD && E.n_cont > 0 && wave == 0) {
+        if (!NOMOD && E.n_cont > 0) {
           double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
-          for (int i = lane; i < nb; i += WAVE) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
-          __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same wavefront
+          for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
+          __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same threads (the same bus -> thread map)
         }
       }
       if (!conv) {
