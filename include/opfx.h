@@ -239,8 +239,11 @@ typedef struct opfx_solve_opts {
                               * OPFX_INIT_DC (1): angles from a DC power flow B' theta = P first (pandapower init='dc',
                               * its 'auto' choice whenever voltage angles are calculated, i.e. for grids fed above 70 kV):
                               * one linear solve through the same block-LU schedule.  Same fixed point, other iteration
-                              * counts.  Applies to solves on the compiled topology (no outage / switch / tap modifier:
-                              * those start flat). */
+                              * counts.  A solve with branches OUT OF SERVICE — the `outage` array, an N-1 contingency
+                              * (with contingency_start = 1), an open line / transformer switch — starts from the DC power
+                              * flow of the grid without them, as pandapower's does; a solve with any other per-instance
+                              * modifier (tap position, branch open at one end, shunt step), with several branches out
+                              * at once or with a de-energised island starts flat. */
   int32_t contingency_start; /* opfx_step, N-1 loop: 0 = every contingency solve starts from the base-case
                               * solution (default; same fixed point, one iteration fewer), 1 = from the flat
                               * start, as the reference does by calling pandapower anew

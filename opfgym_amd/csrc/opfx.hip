@@ -108,6 +108,7 @@ struct DevPlan {
   const unsigned *lp_teamc2, *lp_teamc4; // chord streams of the teams
   int team_roundsc2, team_roundsc4, team_kbc2, team_kbc4;
   const double *lp_dc, *lp_hdc;          // DC start (plan.h): B' on the Ybus pattern + constant right-hand side; nullptr: none
+  const double *br_bdc, *br_pfinj;       // [nbr] DC susceptance / phase-shift injection of every branch (DC start of a solve with branches out)
   double* blk_mem;           // memory-resident kernels: [resident workgroups][blk_mem_stride] LU block values
   long long blk_mem_stride;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
@@ -1159,6 +1160,38 @@ __device__ __forceinline__ void dc_overflow(const DevPlan& P, const Lds& L, int 
     if ((he.x & 0xFFFF) != NONE && bid != NONE) st_blk2<PK>(L, bid, Blk{b, 0.0, 0.0, b});
   }
 }
+// The DC start of a solve with branches OUT OF SERVICE (an outage, an N-1 contingency, an open line switch: modifiers of kind
+// MOD_REMOVED) — pandapower runs its DC power flow on the net as it is, i.e. without them: B' and the constant part of the
+// right-hand side (plan.cpp) less the share of every removed branch k = (f, t): B'_ff -= b, B'_tt -= b, B'_ft += b, B'_tf += b;
+// c_f -= Pfinj, c_t += Pfinj; a REF end contributes B'_ir theta_r to c_i.  Two lanes per modifier, one per end, after the
+// pass has written the compiled values (blocks [[B', 0], [0, B']]: the first and, where stored, the fourth component).
+// Solves with other modifiers (a tap position, an open-ended branch, a shunt step change B' in ways the per-branch arrays
+// do not describe) start flat: dc_start_possible.
+__device__ __forceinline__ void dc_mods(const DevPlan& P, const Lds& L, int lane, int n_mod) {
+  if (lane >= 2 * n_mod) return;
+  const int m = lane >> 1, e = lane & 1;
+  const int* id = mod_ids(L, m);
+  const int i = id[e], j = id[1 - e], ob = id[2 + e], db = id[4 + e], br = id[6];
+  if (L.bt[i] == BT_REF) return;
+  const double b = P.br_bdc[br], pf = P.br_pfinj[br];
+  if (ob >= 0) {
+    lds_add(L.blk + blk_c(L, ob, 0), b);
+    if (ob < L.nfull) lds_add(L.blk + blk_c(L, ob, 3), b);
+  }
+  lds_add(L.blk + blk_c(L, db, 0), -b);
+  lds_add(L.blk + blk_c(L, db, 3), -b);
+  double dr = e == 0 ? pf : -pf;                          // rhs = P - c
+  if (L.bt[j] == BT_REF) dr -= b * P.va_set[j];           // (c_i held B'_ij theta_j = -b theta_j)
+  lds_add(&L.rhs[i], dr);
+}
+// every modifier of the solve takes a branch out of service (wave-uniform)
+__device__ __forceinline__ bool dc_start_possible(const DevPlan& P, const Lds& L, int n_mod) {
+  if (n_mod == 0) return true;
+  if (P.br_bdc == nullptr) return false;
+  bool ok = true;
+  for (int m = 0; m < n_mod; ++m) ok = ok && mod_ids(L, m)[7] == MOD_REMOVED && mod_ids(L, m)[6] >= 0;
+  return ok;
+}
 // CHORD: compiled with chord steps (opfx_solve_opts.jacobian_reuse_tol > 0; kernels of their own like DC): an iteration may
 // keep the factorisation of an earlier one — phase A then computes the mismatch only (`jac` false: no block is written) and
 // the wavefront walks the CHORD stream, forward substitution alone + the same back substitution (plan.h lp_bcc), instead
@@ -1211,6 +1244,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       dc_overflow<PK>(P, L, 0, 1, lane);
       dc_rows<PK>(P, L, 0, 1, lane);
       wave_fence();
+      if (!NOMOD && n_mod > 0) { dc_mods(P, L, lane, n_mod); wave_fence(); }
     } else {
     // overflow entries of rows longer than the ELL width: any row per lane, row sums accumulated in the
     // rhs slots of those rows (zeroed first) with LDS atomics
@@ -1608,6 +1642,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     }
     } else {
       team_sync<MEM>();        // (the DC pass has no norm exchange: its blocks and right-hand side are complete here)
+      if (!NOMOD && n_mod > 0) { if (wave == 0) dc_mods(P, L, lane, n_mod); team_sync<MEM>(); }
     }
     // ---- phases B and C: this wave's rounds in its own stream (4 in flight), a barrier where a
     // group of mutually independent rounds ends ------------------------------------------------
@@ -1789,7 +1824,9 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
   bool conv = false;
   // DC start: on the compiled topology only (a modifier changes B' as well; such solves start flat), V2 kernels; it is
   // the first pass of the first Newton loop of the solve
-  const bool dc_first = DC && V2 && o.init == OPFX_INIT_DC && P.lp_dc != nullptr && n_mod == 0 && isl_state == 0;
+  // (a solve whose modifiers all take a branch out of service — outage, contingency, open line switch — starts from the DC
+  //  power flow of the net without them, as pandapower does, dc_mods; other modifiers or a de-energised island: flat)
+  const bool dc_first = DC && V2 && o.init == OPFX_INIT_DC && P.lp_dc != nullptr && isl_state == 0 && dc_start_possible(P, L, n_mod);
   for (int outer = 0; outer <= P.npv; ++outer) {
     int it;
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
@@ -3557,9 +3594,9 @@ extern "C" int opfx_ctx_create_debug(const opfx_plan* p, int device, const opfx_
   PUT(lp_bc, lp_bc); PUT(lp_apk, lp_apk); PUT(lp_hpk, lp_hpk); PUT(lp_hrows, lp_hrows);
   PUT(lp_bcc, lp_bcc);
   d.rf = p->rf_pad;
-  d.lp_dc = nullptr; d.lp_hdc = nullptr;
+  d.lp_dc = nullptr; d.lp_hdc = nullptr; d.br_bdc = nullptr; d.br_pfinj = nullptr;
   d.blk_mem = nullptr; d.blk_mem_stride = 0;
-  if (!p->lp_dc.empty()) { PUT(lp_dc, lp_dc); PUT(lp_hdc, lp_hdc); }
+  if (!p->lp_dc.empty()) { PUT(lp_dc, lp_dc); PUT(lp_hdc, lp_hdc); PUT(br_bdc, br_bdc); PUT(br_pfinj, br_pfinj); }
   d.n_hrows = (int)p->lp_hrows.size();
   if (rc == OPFX_OK) rc = A.put(p->lp_team[0], &d.lp_team2);
   if (rc == OPFX_OK) rc = A.put(p->lp_team[1], &d.lp_team4);

@@ -342,7 +342,7 @@ def test_full_batch_under_the_reference_solver_settings(name, B, n_check):
     iteration path, not only its fixed point), and the full step — rewards, violations, observations, result tables —
     equals the oracle's."""
     env = product_env(name, batch_size=B, reference_faithful=True)
-    assert env.init == 'dc' and env.reference_deviations == {} and env.kernel_info()['waves_per_instance'] == (1 if name == 'vc_mv_urban' else 4)      # (306-bus grid: shared slots; the DC launches run as teams of two)
+    assert env.init == 'dc' and env.reference_deviations == {} and env.kernel_info()['waves_per_instance'] == (1 if name == 'vc_mv_urban' else 4)      # (306-bus grid: shared slots, three teams of four — the DC-start kernels too)
     orc = oracle_env(name, product_env(name, defer_device=True))
     orc.init = 'dc'
     rng = np.random.default_rng(29)
@@ -367,6 +367,41 @@ def test_full_batch_under_the_reference_solver_settings(name, B, n_check):
     out_f = flat.step(actions)
     assert np.allclose(_np(out_f[1]), _np(out[1]), rtol=0, atol=1e-7, equal_nan=True)
     assert (its != _np(out_f[4]['iterations'])).any()
+
+
+def test_reference_faithful_n_minus_one_follows_the_reference_iteration_for_iteration():
+    """`reference_faithful=True` on an N-1 environment of an HV grid: pandapower starts EVERY power flow of the step — the base
+    case and each contingency, a fresh `runpp` per case (security_constrained.py:53) — from a DC power flow of the net as it
+    is in that case, i.e. without the outaged line.  The kernel's DC start of a solve with branches out of service
+    (`dc_mods`) does the same: the Newton iterations of the base case and their sum over all contingencies equal the
+    DC-started oracle's counts exactly, and the step's results are the oracle's."""
+    B = 24
+    env = product_env('sc_hv_small', batch_size=B, reference_faithful=True)
+    assert env.init == 'dc' and env.solve_opts.contingency_start == 1 and env.reference_deviations == {}
+    orc = oracle_env('sc_hv_small', product_env('sc_hv_small', defer_device=True))
+    orc.init = 'dc'
+    rng = np.random.default_rng(15)
+    actions = rng.random((B, env.n_actions))
+    steps = np.random.default_rng(16).choice(env.train_steps, B)
+    env.reset(options={'step': steps})
+    obs, reward, term, trunc, info = env.step(actions)
+    base, total, conv = _np(info['iterations']), _np(info['total_iterations']), _np(info['converged'])
+    flat_total = None
+    assert conv.all()
+    for k in range(0, B, 3):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert ref['converged'] and len(orc.solve_iterations) > 1
+        assert orc.solve_iterations[0] == base[k]
+        assert sum(orc.solve_iterations) == total[k], (k, orc.solve_iterations, total[k])
+        assert abs(ref['reward'] - _np(reward)[k]) < 1e-7
+        assert np.allclose(_np(info['violations'])[k][:len(ref['violations'])], ref['violations'], rtol=1e-6, atol=1e-6)
+    # the same step with every solve started flat reaches the same results (on this lightly loaded grid in as many iterations;
+    # that the start matters is tests/test_gpu_solve.py::test_dc_start_with_a_branch_out_of_service_follows_the_oracle)
+    flat = product_env('sc_hv_small', batch_size=B, contingency_start='flat')
+    flat.reset(options={'step': steps})
+    out_f = flat.step(actions)
+    assert np.allclose(_np(out_f[1]), _np(reward), rtol=0, atol=1e-7)
 
 
 def test_small_grids_run_three_wavefronts_per_simd():

@@ -538,6 +538,42 @@ def test_dc_start_reproduces_the_oracle_iteration_for_iteration(code, B):
     assert np.abs(out['vm'] - flat['vm']).max() < 1e-8 and np.abs(out['loading'] - flat['loading']).max() < 1e-5
 
 
+@pytest.mark.parametrize('code,B', [('hv-small', 48), ('1-HV-urban--0-sw', 24), ('1-HV-mixed--0-sw', 24)])
+def test_dc_start_with_a_branch_out_of_service_follows_the_oracle(code, B):
+    """The DC start of a solve with a branch out of service (an `outage` array: the N-1 contingencies and open line switches of
+    the environments take the same path): pandapower's DC power flow runs on the net WITHOUT that branch, and so does the
+    kernel's (`dc_mods`: B' and the constant right-hand side less the branch's share) — the iteration count of the oracle
+    started from the DC solution of the net without the branch, instance for instance, and its voltages."""
+    import torch
+    from helpers import OracleSide, non_bridge_branches
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = grids.get_grid(code)
+    case = net_to_case(net)
+    cand = non_bridge_branches(case)
+    assert len(cand)
+    ctx = capi.Context(capi.Plan(case), 0)
+    p, q = random_injections(net, case, B, seed=37, lo=0.3, hi=1.2)
+    outage = np.random.default_rng(9).choice(cand, B).astype(np.int32)
+    dev = torch.device('cuda:0')
+    out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), init='dc',
+                                                     outage=torch.tensor(outage, device=dev)).items()}
+    flat = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev),
+                                                      outage=torch.tensor(outage, device=dev)).items()}
+    side = OracleSide(net, case)
+    ref_it, ref_flat = np.zeros(B, int), np.zeros(B, int)
+    for b in range(B):
+        r = side.solve(p[b], q[b], outage=int(outage[b]), init='dc')
+        assert r['converged'] and out['converged'][b], b
+        ref_it[b] = r['iterations']
+        ref_flat[b] = side.solve(p[b], q[b], outage=int(outage[b]))['iterations']
+        assert np.abs(out['vm'][b] - r['vm']).max() < TOL_V
+        assert np.abs(np.angle(np.exp(1j * (out['va'][b] - r['va'])))).max() < TOL_V
+    assert np.array_equal(out['iterations'], ref_it), (out['iterations'], ref_it)
+    assert np.array_equal(flat['iterations'], ref_flat)
+    assert (ref_it != ref_flat).any()          # (the start matters: without dc_mods these solves started flat)
+
+
 def test_dc_start_needs_the_dc_model_of_the_branches():
     import torch
     from opfgym_amd import capi, grids
