@@ -247,15 +247,15 @@ def solve(ppc: PPC, enforce_q_lims=False, tol=1e-8, max_it=10, status=None, v_in
     pd_, qd_ = ppc.pd.copy(), ppc.qd.copy()
     if v_init is not None:
         v = v_init.copy()
-    elif status is None:
-        v = start_voltage(ppc, init)
     else:
-        saved = ppc.status
-        ppc.status = st
+        # (the start is computed on the grid as it is solved: branch status of this call, unsupplied buses taken out — a DC
+        #  start on a grid with a cut-off island would otherwise be singular; pandapower drops such buses before its DC run)
+        saved = ppc.status, ppc.bus_type
+        ppc.status, ppc.bus_type = st, bus_type
         try:
             v = start_voltage(ppc, init)
         finally:
-            ppc.status = saved
+            ppc.status, ppc.bus_type = saved
     v = np.where(supplied, v, 1.0 + 0j)
     total_it = 0
     g_q = np.zeros(len(ppc.g_bus))

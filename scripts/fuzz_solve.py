@@ -93,6 +93,7 @@ def main():
     bad = done = 0
     gpu_only_fail = oracle_only_fail = both_fail = 0
     worst_pivot = 1.0
+    dc_rows_same = dc_rows_all = 0
     dev = torch.device('cuda:0')
     for g in range(n):
         rng = np.random.default_rng([seed, g])
@@ -120,6 +121,12 @@ def main():
                 okw.update(qg_min=-lim, qg_max=lim, enforce_q_lims=True)
             if chord:
                 kw['jacobian_reuse_tol'] = float(rng.choice([0.01, 0.1, 1.0, 10.0]))
+            # OPFX_FUZZ_INIT=dc: both sides started from the DC power flow (pandapower init='dc'; of the grid WITHOUT the branch
+            # that is out of service, dc_mods) — nothing is drawn for it, a campaign replays with and without
+            dc_start = os.environ.get('OPFX_FUZZ_INIT') == 'dc' and plan.info['has_dc'] and not chord
+            if dc_start:
+                kw['init'] = 'dc'
+                okw['init'] = 'dc'
             got = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw).items()}
             ref = oracle_batch(net, case, p, q, **okw)
             both = ref['converged'] & got['converged'].astype(bool)
@@ -148,6 +155,9 @@ def main():
                     assert (got['iterations'][cmp_rows] >= ref['iterations'][cmp_rows] - 1).all(), ('iterations', desc)
                 else:
                     assert (np.abs(got['iterations'][cmp_rows] - ref['iterations'][cmp_rows]) <= 1).all(), ('iterations', desc)
+                if dc_start:
+                    dc_rows_same += int((got['iterations'][cmp_rows] == ref['iterations'][cmp_rows]).sum())
+                    dc_rows_all += int(cmp_rows.sum())
             # islanded rows: the same buses are de-energised (NaN) and the rest of the grid agrees
             for r_ in np.flatnonzero(isl & both):
                 assert (np.isnan(got['vm'][r_]) == np.isnan(ref['vm'][r_])).all(), ('dead buses', desc, int(r_))
@@ -191,7 +201,8 @@ def main():
             print(f'[{g}] ERROR')
             traceback.print_exc()
     print(f'{n} grids, {done} solves compared, {bad} failures; kernel failed where the oracle converged: {gpu_only_fail}, oracle failed where '
-          f'the kernel converged: {oracle_only_fail}, both failed: {both_fail}; smallest relative pivot among rows both solved: {worst_pivot:.3e}')
+          f'the kernel converged: {oracle_only_fail}, both failed: {both_fail}; smallest relative pivot among rows both solved: {worst_pivot:.3e}'
+          + (f'; DC start: {dc_rows_same} of {dc_rows_all} rows with the oracle\'s iteration count exactly' if dc_rows_all else ''))
     sys.exit(1 if bad else 0)
 
 
