@@ -67,7 +67,7 @@ extern "C" {
 #define OPFX_VERSION_MINOR 3      /* 0.2: struct_size in every struct, developer switches out of the environment;
                                    * 0.3: members appended to opfx_case / opfx_step_io / opfx_solve_opts / opfx_plan_info and
                                    *      min_pivot_bus added to opfx_solve after the first 0.2 layout -> a new series */
-#define OPFX_VERSION_PATCH 0
+#define OPFX_VERSION_PATCH 1      /* 0.3.1: xres_offset / cost_pres / cost_qres appended to opfx_env_desc, OPFX_XRES_AFFINE */
 
 /* zero a struct of this header and stamp its size: opfx_solve_opts o; OPFX_INIT(o); o.tol = 1e-8; ... */
 #define OPFX_INIT(x) do { memset(&(x), 0, sizeof(x)); (x).struct_size = (uint32_t)sizeof(x); } while (0)
@@ -243,7 +243,8 @@ typedef struct opfx_solve_opts {
                               * (with contingency_start = 1), an open line / transformer switch — starts from the DC power
                               * flow of the grid without them, as pandapower's does; a solve with any other per-instance
                               * modifier (tap position, branch open at one end, shunt step), with several branches out
-                              * at once or with a de-energised island starts flat. */
+                              * at once or with a de-energised island starts flat.  A contingency that starts from the
+                              * base case's solution (contingency_start = 0) starts THERE: no DC pass on a warm start. */
   int32_t contingency_start; /* opfx_step, N-1 loop: 0 = every contingency solve starts from the base-case
                               * solution (default; same fixed point, one iteration fewer), 1 = from the flat
                               * start, as the reference does by calling pandapower anew
@@ -288,7 +289,7 @@ enum { OPFX_REWARD_SUMMATION = 0, OPFX_REWARD_REPLACEMENT = 1,
 /* kinds of actuator columns (opfx_env_desc.act_kind) */
 enum { OPFX_ACT_CONTINUOUS = 0, OPFX_ACT_INTEGER = 1 /* np.round */, OPFX_ACT_BOOLEAN = 2 /* np.round(..).astype(bool) */ };
 
-enum { OPFX_XRES_P = 0, OPFX_XRES_S = 1, OPFX_XRES_MAX3 = 2 };
+enum { OPFX_XRES_P = 0, OPFX_XRES_S = 1, OPFX_XRES_MAX3 = 2, OPFX_XRES_AFFINE = 3 };
 
 typedef struct opfx_env_desc {
   uint32_t struct_size;      /* = sizeof(opfx_env_desc)                      */
@@ -393,7 +394,15 @@ typedef struct opfx_env_desc {
    *   OPFX_XRES_P: x[xres_p[k]] * xres_scale[k]        (res_<unit>.p_mw / q_mvar = set-point * scaling)
    *   OPFX_XRES_S: sqrt(P^2 + Q^2) of x[xres_p[k]], x[xres_q[k]] (apparent power)
    *   OPFX_XRES_MAX3: NaN-propagating max of the RESULT-BANK entries xres_p[k], xres_q[k], xres_r[k]:
-   *       res_trafo3w.loading_percent = the worst of the three windings of its star equivalent */
+   *       res_trafo3w.loading_percent = the worst of the three windings of its star equivalent
+   *   OPFX_XRES_AFFINE: xres_offset[k] + xres_scale[k] * RESULT-BANK entry xres_p[k] (an entry of the solver's part,
+   *       index < nres_base); 0 when xres_q[k] >= 0 names a bus that is de-energised in this instance.  The share of ONE
+   *       generator (or ext_grid) in the reactive power generated at its bus, which the solver reports per BUS (q_gen /
+   *       q_ext): pypower's `pfsoln` splits the bus total among the generators of a bus in proportion to their reactive
+   *       ranges, Q_g = Qmin_g + (Q_bus - sum Qmin) / (sum Qmax - sum Qmin + eps) * (Qmax_g - Qmin_g) — affine in Q_bus
+   *       with constants the caller computes once (opfgym_amd/case.py generator_dispatch); likewise the active power of an
+   *       ext_grid that is not the first generator of its REF bus (0 * p_ext).  Read by res_gen.q_mvar / res_ext_grid
+   *       observations, constraints and cost rows (objective.py:48-54). */
   int32_t n_xres;
   const int32_t* xres_kind;       /* [n_xres] OPFX_XRES_*                    */
   const int32_t* xres_p;          /* [n_xres] column of the store            */
@@ -404,6 +413,14 @@ typedef struct opfx_env_desc {
    * power for units on a de-energised bus (results_bus.py: set-point x `_is_elements`), so the cost rows of units on
    * an island that a switch state or an outage has cut off vanish from the objective (objective.py:34-54). */
   const int32_t* cost_bus;        /* [npoly+npwl] */
+  /* ---- appended in 0.3.1 (a caller compiled against 0.3.0 leaves them out: NULL) ---- */
+  const double* xres_offset;      /* [n_xres] constant term of OPFX_XRES_AFFINE rows (else unused); NULL = zeros */
+  /* Result-bank entries (derived rows allowed) that replace what an OPFX_COST_EXT_GRID / OPFX_COST_GEN row reads from the
+   * solver's per-BUS values: cost_pres[r] for the active power of an ext_grid row, cost_qres[r] for the reactive power of
+   * an ext_grid or generator row; -1 = the bus value (p_ext / q_ext of the REF bus, q_gen of the generator's bus).  For
+   * units that share their bus with other generators (see OPFX_XRES_AFFINE).  NULL = none. */
+  const int32_t* cost_pres;       /* [npoly+npwl] */
+  const int32_t* cost_qres;       /* [npoly+npwl] */
 } opfx_env_desc;
 
 int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d, opfx_env** out);

@@ -888,19 +888,48 @@ class BatchedOpfEnv:
                     continue
                 key = ('trafo3w', col, int(pos))
                 if key not in self._xres:
-                    self._xres[key] = (len(self._xres), capi.XRES_MAX3, 2 * nb + br[0], 2 * nb + br[1], 1.0, 2 * nb + br[2])
+                    self._xres[key] = (len(self._xres), capi.XRES_MAX3, 2 * nb + br[0], 2 * nb + br[1], 1.0, 2 * nb + br[2], 0.0)
                 out.append(base3 + self._xres[key][0])
         elif unit == 'ext_grid':
             off = 2 * nb + nbr + (0 if col == 'p_mw' else nref)
             ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+            share = self._generator_shares()['ext_grid']
             for pos in self.store.rows(unit, idxs):
                 bus = int(self.net.ext_grid['bus'].iloc[pos])
-                out.append(off + ordinal[c.bus_lookup[bus]] if bus in c.bus_lookup else -1)
+                if bus not in c.bus_lookup:
+                    out.append(-1)
+                    continue
+                src = off + ordinal[c.bus_lookup[bus]]
+                a, b = (0.0, float(share['p_b'][pos])) if col == 'p_mw' else (float(share['q_a'][pos]), float(share['q_b'][pos]))
+                # an ext_grid alone on its bus reads the bus value; one that shares it with other generators its own share
+                # (a derived row; allocated for every ext_grid of a net whose topology may fuse generator buses, so that
+                # the twins of a bus-bus-switch environment number their derived rows alike)
+                if (a, b) == (0.0, 1.0) and not self._shares_may_change():
+                    out.append(src)
+                else:
+                    out.append(self._affine_row(('ext_grid', col, int(pos)), src, a, b, -1))
+        elif unit == 'gen' and col == 'q_mvar':
+            # res_gen.q_mvar: the generator's share of the reactive power generated at its bus (pypower pfsoln,
+            # case.generator_dispatch) — a derived row, affine in the bus total, where the bus is shared; zero for a generator out of service
+            share = self._generator_shares()['gen']
+            ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+            for pos in self.store.rows(unit, idxs):
+                i = int(share['bus'][pos])
+                if i < 0:
+                    out.append(zero)
+                    continue
+                src = 2 * nb + nbr + nref + ordinal[i] if c.bus_type[i] == REF else 2 * nb + nbr + 2 * nref + i
+                a, b = float(share['q_a'][pos]), float(share['q_b'][pos])
+                # (alone on its bus: the bus's own entry — unless another switch state may give it company, see ext_grid)
+                if (a, b) == (0.0, 1.0) and not self._shares_may_change():
+                    out.append(src)
+                else:
+                    out.append(self._affine_row(('gen', col, int(pos)), src, a, b, i))
         elif unit in ('sgen', 'load', 'storage', 'gen') and col in ('p_mw', 'q_mvar', 's_mva'):
             # res_<unit> echoes of the set-points (= table value x scaling) and their apparent power:
             # derived rows behind the solver's result bank (opfx_env_desc.xres_*), allocated on demand
             if unit == 'gen' and col != 'p_mw':
-                raise NotImplementedError('res_gen.q_mvar per generator is not in the device result bank')
+                raise NotImplementedError(f'res_gen.{col} is not in the device result bank')
             df = self.net[unit]
             base = 3 * nb + nbr + 2 * nref
             p0 = self.store.slot(unit, 'p_mw')
@@ -912,11 +941,32 @@ class BatchedOpfEnv:
                     kind = capi.XRES_S if col == 's_mva' else capi.XRES_P
                     psl = (q0 if col == 'q_mvar' else p0) + int(pos)
                     qsl = q0 + int(pos) if col == 's_mva' else -1
-                    self._xres[key] = (len(self._xres), kind, psl, qsl, sc, 0)
+                    self._xres[key] = (len(self._xres), kind, psl, qsl, sc, 0, 0.0)
                 out.append(base + self._xres[key][0])
         else:
             raise NotImplementedError(f'result column res_{unit}.{col} is not in the device result bank')
         return np.array(out, dtype=np.int64)
+
+    def _generator_shares(self):
+        """`case.generator_dispatch` of this environment's net and case (cached per compiled case)."""
+        cached = getattr(self, '_gen_shares', None)
+        if cached is None or cached[0] is not self.case:
+            from .case import generator_dispatch
+            cached = self._gen_shares = (self.case, generator_dispatch(self.net, self.case))
+        return cached[1]
+
+    def _shares_may_change(self):
+        """A net with bus-bus switches and more than one generator row: another switch state may put generators on one bus."""
+        sw = self.net['switch'] if 'switch' in self.net else None
+        has_bb = sw is not None and len(sw) and any(str(v) == 'b' for v in sw['et'])
+        return bool(has_bb) and len(self.net['gen']) + len(self.net['ext_grid']) > 1
+
+    def _affine_row(self, key, src, a, b, bus):
+        """Result index of the derived row `a + b * result[src]` (OPFX_XRES_AFFINE; 0 while `bus` is de-energised)."""
+        if key not in self._xres:
+            self._xres[key] = (len(self._xres), capi.XRES_AFFINE, int(src), int(bus), float(b), 0, float(a))
+        nref = int((self.case.bus_type == REF).sum())
+        return 3 * self.case.nb + self.case.nbr + 2 * nref + self._xres[key][0]
 
     def _create_env(self):
         net, c, st = self.net, self.case, self.store
@@ -942,6 +992,7 @@ class BatchedOpfEnv:
         # ---- actions (opf_env.py:421-491) ------------------------------------------
         a_slot, a_sc, lo_s, hi_s, lo_c, hi_c = [], [], [], [], [], []
         a_kind, bmod = [], []
+        a_part = []            # 1.0: the unit takes part in the power flow (its res_ row echoes the set-point), 0.0: it does not
         self._bb_switches = []
         cl_s, ch_s, cl_c, ch_c = [], [], [], []
         clamp = (not self.autoscale_actions) or bool(self.diff_action_step_size)
@@ -956,6 +1007,13 @@ class BatchedOpfEnv:
             a_slot += (st.slot(unit, col) + rows).tolist()
             a_sc += (df['scaling'].to_numpy(float)[rows] if 'scaling' in df.columns
                      else np.ones(len(rows))).tolist()
+            live = np.ones(len(rows))
+            if unit in ('load', 'sgen', 'storage', 'gen') and col in ('p_mw', 'q_mvar'):
+                # (pandapower reports zero power for a unit out of service or on a bus outside the power flow,
+                #  results_bus.py / results_gen.py: what `get_current_actions(from_results_table=True)` reads, opf_env.py:574)
+                on = df['in_service'].to_numpy(bool)[rows] if 'in_service' in df.columns else np.ones(len(rows), bool)
+                live = np.array([float(o and int(b) in c.bus_lookup) for o, b in zip(on, df['bus'].to_numpy()[rows])])
+            a_part += live.tolist()
             pre_lo, pre_hi = ('min_', 'max_') if self.autoscale_actions else ('min_min_', 'max_max_')
             s, v = self._range_source(unit, pre_lo + col, rows); lo_s += s.tolist(); lo_c += v.tolist()
             s, v = self._range_source(unit, pre_hi + col, rows); hi_s += s.tolist(); hi_c += v.tolist()
@@ -1027,13 +1085,32 @@ class BatchedOpfEnv:
         ref_buses = np.flatnonzero(c.bus_type == REF)
         ref_ord = {int(b): k for k, b in enumerate(ref_buses)}
 
+        cost_pres, cost_qres = [], []         # per cost row: derived rows replacing the per-bus values it reads (-1: none)
+
+        def own_share(unit, col, pos, default):
+            """Result index of `res_<unit>.<col>` of one ext_grid / generator where it is not the per-bus value `default`
+            the cost row reads anyway (a unit that shares its bus, or takes no part in the power flow), else -1."""
+            ridx = int(self._result_index(unit, col, [net[unit].index[pos]])[0])
+            return -1 if ridx == default else ridx
+
         def cost_source(et, element):
             pos = int(st.rows(et, [element])[0])
+            off_ref = 2 * nb + c.nbr
             if et == 'ext_grid':
-                return capi.COST_EXT_GRID, ref_ord[c.bus_lookup[int(net.ext_grid['bus'].iloc[pos])]], -1, 1.0, -1
+                k = ref_ord[c.bus_lookup[int(net.ext_grid['bus'].iloc[pos])]]
+                cost_pres.append(own_share('ext_grid', 'p_mw', pos, off_ref + k))
+                cost_qres.append(own_share('ext_grid', 'q_mvar', pos, off_ref + len(ref_buses) + k))
+                return capi.COST_EXT_GRID, k, -1, 1.0, -1
             sc = float(net[et]['scaling'].iloc[pos]) if 'scaling' in net[et].columns else 1.0
             if et == 'gen':
-                return capi.COST_GEN, c.bus_lookup[int(net.gen['bus'].iloc[pos])], st.slot('gen', 'p_mw') + pos, sc, -1
+                # (a generator out of service, or on a bus outside the compiled case, reports zero power: results_gen.py)
+                bus = c.bus_lookup.get(int(net.gen['bus'].iloc[pos]), -1)
+                if bus < 0 or ('in_service' in net.gen.columns and not bool(net.gen['in_service'].iloc[pos])):
+                    sc, bus = 0.0, (bus if bus >= 0 else int(ref_buses[0]))
+                cost_pres.append(-1)
+                cost_qres.append(own_share('gen', 'q_mvar', pos, off_ref + 2 * len(ref_buses) + bus))
+                return capi.COST_GEN, bus, st.slot('gen', 'p_mw') + pos, sc, -1
+            cost_pres.append(-1); cost_qres.append(-1)
             # (a unit on a bus that is not part of the compiled case — permanently de-energised — or out of
             #  service reports zero power, results_bus.py: its row keeps the constant term only)
             bus = c.bus_lookup.get(int(net[et]['bus'].iloc[pos]), -1)
@@ -1112,6 +1189,8 @@ class BatchedOpfEnv:
         d.cost_kind, d.cost_pidx, d.cost_qidx = _keep(keep, ck, 'i'), _keep(keep, cp, 'i'), _keep(keep, cq, 'i')
         d.cost_scale, d.pwl_is_q, d.cost_coef = _keep(keep, cs, 'd'), _keep(keep, is_q, 'i'), _keep(keep, coef, 'd')
         d.cost_bus = _keep(keep, cbus, 'i')
+        if any(v >= 0 for v in cost_pres + cost_qres):
+            d.cost_pres, d.cost_qres = _keep(keep, cost_pres, 'i'), _keep(keep, cost_qres, 'i')
         d.nprice = len(price_slot)
         d.price_slot, d.price_coef = _keep(keep, price_slot, 'i'), _keep(keep, price_coef, 'i')
         d.nc = len(self.device_constraints)
@@ -1167,6 +1246,7 @@ class BatchedOpfEnv:
             d.xres_kind, d.xres_p = _keep(keep, [v[1] for v in xr_], 'i'), _keep(keep, [v[2] for v in xr_], 'i')
             d.xres_q, d.xres_scale = _keep(keep, [v[3] for v in xr_], 'i'), _keep(keep, [v[4] for v in xr_], 'd')
             d.xres_r = _keep(keep, [v[5] for v in xr_], 'i')
+            d.xres_offset = _keep(keep, [v[6] for v in xr_], 'd')
         if q_idx:
             d.qterm_idx, d.qterm_target, d.qterm_weight = _keep(keep, q_idx, 'i'), _keep(keep, q_tgt, 'd'), _keep(keep, q_w, 'd')
         d.n_bmod = len(bmod)
@@ -1216,7 +1296,7 @@ class BatchedOpfEnv:
         as_i = lambda v: t.as_tensor(np.asarray(v, dtype=np.int64), device=self.device)
         as_d = lambda v: t.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
         self._act_desc = dict(slot=as_i(a_slot), scaling=as_d(a_sc), lo_slot=as_i(lo_s), hi_slot=as_i(hi_s),
-                              lo_const=as_d(lo_c), hi_const=as_d(hi_c))
+                              lo_const=as_d(lo_c), hi_const=as_d(hi_c), part=as_d(a_part))
         self._set_reset()
 
     def _set_reset(self):
@@ -1792,12 +1872,15 @@ class BatchedOpfEnv:
     # ------------------------------------------------------------------ helpers
     def get_current_actions(self, from_results_table=True):
         """opf_env.py:566-588 for the batch: (set-point·scaling − min)/(max − min) per action,
-        [B, n_actions].  `res_<unit>.<col>` equals set-point·scaling (SURVEY §8b results
-        contract), so both variants read the same columns of x."""
+        [B, n_actions].  `res_<unit>.<col>` equals set-point·scaling for a unit that takes part in the power flow and
+        zero for one that does not (out of service, bus outside the compiled case), so both variants read the same
+        columns of x; the table variant (`from_results_table=False`) has no such mask (opf_env.py:577-578)."""
         t = self.torch
         d = self._act_desc
         x = self.x
         sp = x[:, d['slot']] * d['scaling']
+        if from_results_table:
+            sp = sp * d['part']
         lo = t.where(d['lo_slot'] >= 0, x[:, d['lo_slot'].clamp(min=0)], d['lo_const'])
         hi = t.where(d['hi_slot'] >= 0, x[:, d['hi_slot'].clamp(min=0)], d['hi_const'])
         return (sp - lo) / (hi - lo)

@@ -118,11 +118,12 @@ class EnvDesc(Sized):
         ('vset_slot', _pi),
         ('n_qterm', C.c_int32), ('qterm_idx', _pi), ('qterm_target', _pd), ('qterm_weight', _pd),
         ('n_xres', C.c_int32), ('xres_kind', _pi), ('xres_p', _pi), ('xres_q', _pi), ('xres_scale', _pd),
-                ('xres_r', _pi), ('cost_bus', _pi)]
+                ('xres_r', _pi), ('cost_bus', _pi),
+                ('xres_offset', _pd), ('cost_pres', _pi), ('cost_qres', _pi)]        # (appended in 0.3.1)
 
 
 ACT_CONTINUOUS, ACT_INTEGER, ACT_BOOLEAN = 0, 1, 2
-XRES_P, XRES_S, XRES_MAX3 = 0, 1, 2
+XRES_P, XRES_S, XRES_MAX3, XRES_AFFINE = 0, 1, 2, 3
 
 
 class StepIO(Sized):

@@ -627,3 +627,59 @@ def bus_injections(net, case: Case):
                 has[i] = True
         qmin[has], qmax[has] = acc_lo[has], acc_hi[has]
     return p, q, qmin, qmax
+
+
+# pandapower's reactive limit of a generator row that names none (`_init_ppc_gen`: +-1e9 Mvar; ext_grids always) and the
+# guard pypower's pfsoln adds to the summed range [3P]
+Q_LIMIT_DEFAULT = 1e9
+_PFSOLN_EPS = float(np.finfo(float).eps)
+
+
+def generator_dispatch(net, case: Case) -> dict:
+    """How the power generated at a bus is reported per GENERATOR (pypower `pfsoln` [3P]).
+
+    The power flow knows generation per bus.  pypower's `pfsoln` — and with it `net.res_gen` / `net.res_ext_grid`, which
+    the reference reads at objective.py:48-54 (cost rows with `et='gen'`) and opf_env.py:566-588 — writes it per
+    generator row of the ppc (in-service ext_grids first, then in-service gens, pandapower `_build_gen_ppc`):
+
+      * reactive power: the bus total Q_bus in equal shares where the summed range of the bus's generators is zero,
+        otherwise in proportion to the ranges, Q_g = Qmin_g + (Q_bus - sum Qmin) / (sum Qmax - sum Qmin + eps) * (Qmax_g - Qmin_g);
+        both are AFFINE in Q_bus: Q_g = q_a + q_b * Q_bus;
+      * active power at a REF bus: the FIRST generator row of the bus balances it (what the solver reports as p_ext,
+        the generators' own set-points already taken off), every other ext_grid there reports its ppc set-point, zero.
+
+    Returns {'gen': {...}, 'ext_grid': {...}} with arrays over the rows of the two tables: `bus` (case bus, -1 for a row
+    that takes no part in the power flow), `q_a` [Mvar], `q_b`, and for ext_grids `p_b` (1.0 / 0.0).  Q_bus is the
+    solver's `q_gen[bus]` at PV buses (the limit total where `enforce_q_lims` has pinned the bus) and `q_ext` at REF buses.
+    """
+    eg, gen = net['ext_grid'], net['gen']
+    members = {}                                   # case bus -> [(table, pos, qmin, qmax)] in ppc row order
+    eg_on = _col(eg, 'in_service', True).astype(bool) if len(eg) else np.zeros(0, bool)
+    for pos, b in enumerate(eg['bus'].to_numpy() if len(eg) else ()):
+        if eg_on[pos] and int(b) in case.bus_lookup:
+            members.setdefault(case.bus_lookup[int(b)], []).append(('ext_grid', pos, -Q_LIMIT_DEFAULT, Q_LIMIT_DEFAULT))
+    if len(gen):
+        g_on = _col(gen, 'in_service', True).astype(bool)
+        lo_c = _col(gen, 'min_q_mvar', -Q_LIMIT_DEFAULT)
+        hi_c = _col(gen, 'max_q_mvar', Q_LIMIT_DEFAULT)
+        for pos, b in enumerate(gen['bus'].to_numpy()):
+            if g_on[pos] and int(b) in case.bus_lookup:
+                members.setdefault(case.bus_lookup[int(b)], []).append(('gen', pos, float(lo_c[pos]), float(hi_c[pos])))
+    out = {tbl: dict(bus=np.full(len(net[tbl]), -1, dtype=np.int64), q_a=np.zeros(len(net[tbl])), q_b=np.zeros(len(net[tbl])))
+           for tbl in ('gen', 'ext_grid')}
+    out['ext_grid']['p_b'] = np.zeros(len(eg))
+    for bus, rows in members.items():
+        lo_sum, hi_sum = sum(r[2] for r in rows), sum(r[3] for r in rows)
+        for k, (tbl, pos, lo, hi) in enumerate(rows):
+            o = out[tbl]
+            o['bus'][pos] = bus
+            if len(rows) == 1:
+                o['q_a'][pos], o['q_b'][pos] = 0.0, 1.0
+            elif lo_sum == hi_sum:
+                o['q_a'][pos], o['q_b'][pos] = 0.0, 1.0 / len(rows)
+            else:
+                share = (hi - lo) / (hi_sum - lo_sum + _PFSOLN_EPS)
+                o['q_a'][pos], o['q_b'][pos] = lo - lo_sum * share, share
+            if tbl == 'ext_grid':
+                o['p_b'][pos] = 1.0 if k == 0 else 0.0
+    return out

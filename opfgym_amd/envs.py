@@ -119,6 +119,27 @@ class EcoDispatch(_Defined, BatchedOpfEnv):
                         df['max_cp1_eur_per_mw'].to_numpy(float))
 
 
+class EcoDispatchSharedBus(EcoDispatch):
+    """No class of the reference: its EcoDispatch on a grid where generators SHARE buses
+    (`simbench_build.share_generator_buses`: two and three on one bus, one out of service, one beside the ext_grid), with
+    reactive ranges and `cq1` / `cq2` prices on the generators' cost rows (`simbench_build.shared_bus_reactive_setup`,
+    applied to the finished definition — EcoDispatch itself zeroes every reactive range, eco_dispatch.py:84-88).  The
+    objective then reads `res_gen.q_mvar` per generator (objective.py:48-54), which pypower's `pfsoln` fills by splitting
+    the bus's reactive generation over its generators' ranges: the device does that in derived result rows
+    (OPFX_XRES_AFFINE, `case.generator_dispatch`).  Golden fixture `eco_hv_small_shared`."""
+    PREPARE = 'share_generator_buses'
+
+    def __init__(self, simbench_network_name='hv-small', gen_scaling=1.0, load_scaling=1.5, max_price_eur_gwh=0.5,
+                 min_power=0, *args, **kwargs):
+        from .simbench_build import shared_bus_reactive_setup
+        class_kwargs = dict(simbench_network_name=simbench_network_name, gen_scaling=gen_scaling, load_scaling=load_scaling,
+                            max_price_eur_gwh=max_price_eur_gwh, min_power=min_power)
+        sel, grid_seed, _ = split_kwargs(type(self), class_kwargs, kwargs)
+        defn = kwargs.get('definition') or definition.resolve(self.REFERENCE, sel, grid_seed=grid_seed, prepare=self.PREPARE)
+        shared_bus_reactive_setup(defn.net)
+        self._construct(BatchedOpfEnv, class_kwargs, args, dict(kwargs, definition=defn))
+
+
 class MaxRenewable(_Defined, BatchedOpfEnv):
     """Stands for `opfgym.envs.MaxRenewable` (max_renewable.py): maximise renewable feed-in."""
     REFERENCE = 'opfgym.envs.MaxRenewable'

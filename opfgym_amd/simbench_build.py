@@ -153,3 +153,61 @@ def split_busbars(net, profiles, buses=(7, 11)):
             net.line.at[i, side] = new
         ppn.create_switch(net, int(b), int(new), 'b', closed=True)
     return net, profiles
+
+
+def share_generator_buses(net, profiles):
+    """Stand-in helper (the synthetic grids carry one generator per bus): more generators on buses that already have one —
+    a second on the bus of generator 0, a second and a third on the bus of generator 1, one OUT OF SERVICE on the bus of
+    generator 2, and one on the bus of the first ext_grid (a REF bus).  pypower's `pfsoln` splits the reactive power
+    generated at such a bus among its generators by their reactive ranges (`case.generator_dispatch`); `res_gen.q_mvar`
+    and the cost rows of these generators (objective.py:48-54) depend on that split.  Time series of the new rows: an
+    existing generator's, scaled.  In place."""
+    from . import net as ppn
+    gen = net.gen
+    g_bus = [int(b) for b in gen.bus.iloc[:3]]
+    new = [(g_bus[0], 8.0, 0, True), (g_bus[1], 12.0, 1, True), (g_bus[1], 6.0, 2, True), (g_bus[2], 9.0, 0, False),
+           (int(net.ext_grid.bus.iloc[0]), 5.0, 1, True)]
+    key = ('gen', 'p_mw')
+    df = profiles[key] if profiles is not None and key in profiles else None
+    scaling = float(gen.scaling.iloc[0]) if 'scaling' in gen.columns else 1.0
+    added = []
+    for bus, p_mw, like, on in new:
+        vm = float(gen.vm_pu[gen.bus == bus].iloc[0]) if (gen.bus == bus).any() else float(net.ext_grid.vm_pu.iloc[0])
+        idx = ppn.create_gen(net, bus, p_mw, vm_pu=vm, in_service=on, scaling=scaling)
+        added.append(idx)
+        if df is not None:
+            src = df.columns[like]
+            df[idx] = df[src].to_numpy() / max(float(df[src].max()), 1e-9) * p_mw
+    ppn.finalize(net)
+    if df is not None and 'max_max_p_mw' in net.gen.columns:
+        # applied to a grid `build_simbench_net` has already worked on: the columns it derives from the time series
+        # (build_simbench_net.py:68-81) for the new rows, the same way
+        for idx in added:
+            net.gen.at[idx, 'max_max_p_mw'] = float(df[idx].max()) * scaling
+            net.gen.at[idx, 'min_min_p_mw'] = float(df[idx].min()) * scaling
+            net.gen.at[idx, 'mean_p_mw'] = float(df[idx].mean())
+            net.gen.at[idx, 'std_dev_p_mw'] = float(df[idx].std())
+    if df is not None and hasattr(profiles, 'rel'):
+        profiles.rel.pop(key, None)               # (the factored form no longer covers the table)
+    return net, profiles
+
+
+def shared_bus_reactive_setup(net):
+    """Reactive ranges and reactive cost terms for the generators of `share_generator_buses` (applied AFTER the problem
+    definition, which for EcoDispatch zeroes every reactive range, eco_dispatch.py:84-88): different ranges on a shared
+    bus, a zero range beside non-zero ones, a bus whose summed range binds under `enforce_q_lims`, and `cq1` / `cq2`
+    prices on the generators' polynomial cost rows so that the objective reads `res_gen.q_mvar` per generator.  In place."""
+    lo = [-10.0, -20.0, -15.0, -1.0, -4.0, -6.0, 0.0, -5.0, -5.0]
+    hi = [4.0, 25.0, 20.0, 0.15, 1.5, 6.0, 0.0, 5.0, 8.0]
+    n = len(net.gen)
+    assert n == len(lo), 'shared_bus_reactive_setup expects the generators of hv-small + share_generator_buses'
+    net.gen['min_q_mvar'] = lo
+    net.gen['max_q_mvar'] = hi
+    pc = net.poly_cost
+    if not len(pc):
+        return net
+    rows = pc.index[pc.et == 'gen']
+    pos = net.gen.index.get_indexer([int(e) for e in pc.loc[rows, 'element']])
+    pc.loc[rows, 'cq1_eur_per_mvar'] = 0.02 * (1.0 + pos)
+    pc.loc[rows, 'cq2_eur_per_mvar2'] = 0.001 * (1.0 + (pos % 3))
+    return net

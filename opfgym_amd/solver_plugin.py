@@ -16,7 +16,7 @@ import numpy as np
 import pandas as pd
 
 from . import capi
-from .case import KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, bus_injections, net_to_case
+from .case import KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, bus_injections, generator_dispatch, net_to_case
 
 
 class LoadflowNotConverged(Exception):
@@ -116,12 +116,18 @@ class BatchedPowerFlowSolver:
             net['res_trafo3w'] = pd.DataFrame({'loading_percent': ld3}, index=net['trafo3w'].index)
         ref_buses = np.flatnonzero(case.bus_type == REF)
         ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+        # generation per GENERATOR from the solver's per-bus values, as pypower's pfsoln reports it (case.generator_dispatch):
+        # reactive power shared among the generators of a bus by range, the first ext_grid of a REF bus balancing it
+        share = generator_dispatch(net, case)
+
+        def bus_q_mvar(i):
+            return r['s_ref'][ordinal[i], 1] * base if case.bus_type[i] == REF else r['q_gen'][i] * base
         eg = net['ext_grid']
         pe, qe = np.full(len(eg), np.nan), np.full(len(eg), np.nan)
-        for pos, b in enumerate(eg['bus'].to_numpy()):
-            if int(b) in case.bus_lookup:
-                k = ordinal[case.bus_lookup[int(b)]]
-                pe[pos], qe[pos] = r['s_ref'][k, 0] * base, r['s_ref'][k, 1] * base
+        for pos, i in enumerate(share['ext_grid']['bus']):
+            if i >= 0:
+                pe[pos] = share['ext_grid']['p_b'][pos] * r['s_ref'][ordinal[int(i)], 0] * base
+                qe[pos] = share['ext_grid']['q_a'][pos] + share['ext_grid']['q_b'][pos] * bus_q_mvar(int(i))
         net['res_ext_grid'] = pd.DataFrame({'p_mw': pe, 'q_mvar': qe}, index=eg.index)
         # units outside the power flow (out of service, or on a de-energised bus): zero rows, as pandapower's
         # `_is_elements` mask produces them (results_bus.py write_pq_results_to_element, results_gen.py)
@@ -147,7 +153,8 @@ class BatchedPowerFlowSolver:
             for pos, b in enumerate(gen['bus'].to_numpy()):
                 if live[pos]:
                     i = case.bus_lookup[int(b)]
-                    pg[pos], qg[pos], vg[pos] = pset[pos], r['q_gen'][i] * base, r['vm'][i]
+                    pg[pos], vg[pos] = pset[pos], r['vm'][i]
+                    qg[pos] = share['gen']['q_a'][pos] + share['gen']['q_b'][pos] * bus_q_mvar(i)
         net['res_gen'] = pd.DataFrame({'p_mw': pg, 'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
 
 

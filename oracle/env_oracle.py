@@ -184,7 +184,7 @@ def tail_load_shedding(net, draws, efficiency=0.95):
 
 TAILS = {'VoltageControl': lambda net, d: tail_voltage_control(net, d, False),
          'QMarket': lambda net, d: tail_voltage_control(net, d, True),
-         'EcoDispatch': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
+         'EcoDispatch': tail_eco_dispatch, 'EcoDispatchSharedBus': tail_eco_dispatch, 'MaxRenewable': tail_max_renewable,
          'SecurityConstrained': lambda net, d: None, 'LoadShedding': tail_load_shedding,
          'MultiStageOpf': lambda net, d: None, 'NetworkReconfiguration': lambda net, d: None,
          'SwitchedShunts': lambda net, d: None, 'BusbarCouplers': lambda net, d: None,

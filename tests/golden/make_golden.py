@@ -134,7 +134,31 @@ class RefSwitchedShunts(ref_nr.NetworkReconfiguration):
             ref_nr.build_simbench_net, ref_opf_env.OpfEnv.__init__ = original, base_init
 
 
-REF = {'VoltageControl': opfgym.envs.VoltageControl, 'SecurityConstrainedVoltageControl': RefScVoltageControl, 'QMarket': opfgym.envs.QMarket,
+class RefEcoDispatchSharedBus(opfgym.envs.EcoDispatch):
+    """The reference's own EcoDispatch on a grid whose generators share buses: the grid helper and the reactive ranges /
+    prices are the product's stand-in helpers (`simbench_build.share_generator_buses`, `shared_bus_reactive_setup` — grid
+    data, applied before / after the reference's `_define_opf`); objective, constraints and `res_gen` handling are the
+    reference's, the per-generator reactive power comes from the oracle's pfsoln."""
+
+    def _define_opf(self, simbench_network_name, *args, **kwargs):
+        import opfgym.envs.eco_dispatch as ed_mod
+        from opfgym_amd.simbench_build import share_generator_buses, shared_bus_reactive_setup
+        original = ed_mod.build_simbench_net
+
+        def prepared(*a, **k):
+            net, profiles = original(*a, **k)
+            share_generator_buses(net, profiles)
+            return net, profiles
+        ed_mod.build_simbench_net = prepared
+        try:
+            net, profiles = super()._define_opf(simbench_network_name, *args, **kwargs)
+        finally:
+            ed_mod.build_simbench_net = original
+        shared_bus_reactive_setup(net)
+        return net, profiles
+
+
+REF = {'VoltageControl': opfgym.envs.VoltageControl, 'EcoDispatchSharedBus': RefEcoDispatchSharedBus, 'SecurityConstrainedVoltageControl': RefScVoltageControl, 'QMarket': opfgym.envs.QMarket,
        'EcoDispatch': opfgym.envs.EcoDispatch, 'MaxRenewable': opfgym.envs.MaxRenewable,
        'SecurityConstrained': ref_sc_example.SecurityConstrained, 'LoadShedding': opfgym.envs.LoadShedding, 'MultiStageOpf': ref_ms.MultiStageOpf,
        'NetworkReconfiguration': ref_nr.NetworkReconfiguration, 'SwitchedShunts': RefSwitchedShunts,
@@ -314,6 +338,8 @@ def run(name):
         push('trafo_loading', env.net.res_trafo.loading_percent.to_numpy())
         push('p_ext', env.net.res_ext_grid.p_mw.to_numpy())
         push('q_ext', env.net.res_ext_grid.q_mvar.to_numpy())
+        if len(env.net.gen):
+            push('q_gen', env.net.res_gen.q_mvar.to_numpy())
         try:
             push('current_actions', env.get_current_actions())
         except KeyError:      # no res_switch / res_trafo.tap_pos in pandapower: only the table route works

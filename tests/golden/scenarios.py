@@ -114,6 +114,13 @@ SCENARIOS.update({
                                                                       n_minus_one_lines='all', max_q_exchange=150.0), 4, 34),
 })
 
+SCENARIOS.update({
+    # generators SHARING buses (two and three on one bus, one out of service, one beside the ext_grid) with different
+    # reactive ranges and reactive prices on their cost rows: `res_gen.q_mvar` per generator as pypower's pfsoln splits
+    # the bus total (objective.py:48-54), limits binding under enforce_q_lims
+    'eco_hv_small_shared': ('EcoDispatchSharedBus', dict(simbench_network_name='hv-small'), 8, 51),
+})
+
 # Fixtures that must hold all-valid AND invalid states (the reward classes' `valid` branch, reward.py:246-252,254-305,
 # needs reference-generated rows of both kinds): name -> (all-valid rows among the n samples, action levels searched).
 # Random actions practically never give a valid state (the ext-grid band is narrow), so the generator looks for one

@@ -40,6 +40,8 @@ def _check_step(env, out, ref, k, n1=False):
         assert np.allclose(_np(env.result_table('trafo', 'loading_percent'))[k], ref['trafo_loading'], rtol=0, atol=R_TOL, equal_nan=True)
         assert np.allclose(_np(env.result_table('ext_grid', 'p_mw'))[k], ref['p_ext'], rtol=0, atol=R_TOL)
         assert np.allclose(_np(env.result_table('ext_grid', 'q_mvar'))[k], ref['q_ext'], rtol=0, atol=R_TOL)
+        if 'q_gen' in ref:                    # res_gen.q_mvar per generator: pypower pfsoln's split of the bus total (P6)
+            assert np.allclose(_np(env.result_table('gen', 'q_mvar'))[k], ref['q_gen'], rtol=0, atol=R_TOL)
 
 
 @pytest.mark.parametrize('name', SINGLE_STEP)
@@ -402,6 +404,33 @@ def test_reference_faithful_n_minus_one_follows_the_reference_iteration_for_iter
     flat.reset(options={'step': steps})
     out_f = flat.step(actions)
     assert np.allclose(_np(out_f[1]), _np(reward), rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('name,B', [('sc_hv_small', 24), ('sc_vc_hv_urban', 6)])
+def test_dc_start_leaves_the_warm_start_of_the_contingencies_alone(name, B):
+    """with `init='dc'` and the DEFAULT `contingency_start='base_case'` a contingency starts from the
+    base case's solution; the DC pass belongs to solves that start from the compiled voltages only (the base case here) —
+    run on a warm start it would turn the loaded voltages by theta_dc - va_set.  The contingencies must take exactly the
+    iterations they take after a flat-started base case (the same warm start), never more than from scratch — on the
+    372-bus grid with its 250 contingencies far fewer — and give the same results."""
+    rng = np.random.default_rng(25)
+    actions = rng.random((B, product_env(name, defer_device=True).n_actions))
+    out = {}
+    for mode, kw in (('dc_warm', dict(init='dc')), ('flat_warm', {}), ('dc_scratch', dict(init='dc', contingency_start='flat'))):
+        env = product_env(name, batch_size=B, **kw)
+        env.reset(options={'step': np.random.default_rng(26).choice(env.train_steps, B)})
+        obs, reward, term, trunc, info = env.step(actions)
+        assert _np(info['converged']).all()
+        out[mode] = (_np(reward), _np(info['total_iterations']) - _np(info['iterations']), _np(info['violations']))
+        env.close()
+    cont_dc, cont_flat, cont_scratch = out['dc_warm'][1], out['flat_warm'][1], out['dc_scratch'][1]
+    assert (cont_dc == cont_flat).all(), (cont_dc, cont_flat)           # the same warm start -> the same contingency iterations
+    assert (cont_dc <= cont_scratch).all()
+    if name == 'sc_vc_hv_urban':
+        assert (cont_dc < 0.85 * cont_scratch).all(), (cont_dc, cont_scratch)
+    for mode in ('flat_warm', 'dc_scratch'):
+        assert np.allclose(out['dc_warm'][0], out[mode][0], rtol=0, atol=1e-7)
+        assert np.allclose(out['dc_warm'][2], out[mode][2], rtol=1e-6, atol=1e-6)
 
 
 def test_small_grids_run_three_wavefronts_per_simd():
@@ -1749,3 +1778,31 @@ def test_on_pivot_breakdown_resolve_recovers_the_rows_on_the_gpu():
     healthy = product_env('vc_mv_small', batch_size=B, on_pivot_breakdown='resolve')
     healthy.reset(options={'step': steps})
     assert bool(healthy.step(actions)[4]['converged'].all()) and healthy.pivot_rescues == 0 and not healthy._rescue_envs
+
+
+def test_generators_sharing_a_bus_report_their_own_reactive_power():
+    """P6: `res_gen.q_mvar` of generators that share a bus — pypower's pfsoln splits the bus's reactive
+    generation over their ranges.  The fixture `eco_hv_small_shared` is recorded from the reference's EcoDispatch on a grid
+    with two and three generators on one bus, one out of service and one beside the ext_grid, with reactive prices on the
+    generators' cost rows: its objective holds one q-cost entry per generator (objective.py:48-54); the golden test above
+    compares cost and result table.  Here the per-generator values also feed a CONSTRAINT (constraints.py:100-128), whose
+    violation is recomputed by hand from the fixture's numbers."""
+    from opfgym_amd import constraints as cons
+    g = golden('eco_hv_small_shared')
+    n = len(g['step'])
+    d = product_env('eco_hv_small_shared', defer_device=True).definition
+    qcon = cons.Constraint('gen', 'q_mvar', get_boundaries=lambda net_: {'min': net_.gen.min_q_mvar.to_numpy(float) * 0.5,
+                                                                          'max': net_.gen.max_q_mvar.to_numpy(float) * 0.5})
+    env = product_env('eco_hv_small_shared', batch_size=n, definition=d,
+                      custom_constraints=cons.create_default_constraints(d.net, {}) + [qcon])
+    env.reset(options={'step': g['step'], 'uniform': g['uniform']})
+    out = env.step(g['action'])
+    assert _np(out[4]['converged']).all()
+    assert np.allclose(_np(env.result_table('gen', 'q_mvar')), g['q_gen'], rtol=0, atol=R_TOL)
+    assert np.allclose(_np(out[4]['cost']), g['cost'], rtol=1e-9, atol=R_TOL)
+    lo, hi = d.net.gen.min_q_mvar.to_numpy(float) * 0.5, d.net.gen.max_q_mvar.to_numpy(float) * 0.5
+    viol = (np.clip(g['q_gen'] - hi, 0, None) + np.clip(lo - g['q_gen'], 0, None)).sum(axis=1)
+    assert (viol > 0).any()
+    scale = qcon.autoscale_factor(d.net)
+    assert np.allclose(_np(out[4]['violations'])[:, -1], viol * (scale if scale else 1.0), rtol=1e-9, atol=R_TOL)
+    assert (_np(out[4]['valids'])[:, -1] == (viol == 0)).all()
