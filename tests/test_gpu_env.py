@@ -429,7 +429,7 @@ def test_dc_start_leaves_the_warm_start_of_the_contingencies_alone(name, B):
     if name == 'sc_vc_hv_urban':
         assert (cont_dc < 0.85 * cont_scratch).all(), (cont_dc, cont_scratch)
     for mode in ('flat_warm', 'dc_scratch'):
-        assert np.allclose(out['dc_warm'][0], out[mode][0], rtol=0, atol=1e-7)
+        assert np.allclose(out['dc_warm'][0], out[mode][0], rtol=1e-9, atol=1e-7)       # (rewards of the N-1 grid are ~1e5)
         assert np.allclose(out['dc_warm'][2], out[mode][2], rtol=1e-6, atol=1e-6)
 
 
