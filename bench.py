@@ -465,6 +465,8 @@ def also_config(config, device, steps, warmup, **env_kw):
 
 
 def main():
+    from opfgym_amd import capi as _capi
+    _capi.set_default_debug(_capi.debug_from_env())      # A/B harnesses steer this script through OPFX_* variables; the driver sets none
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument('--gpus', type=int, default=1)
@@ -500,7 +502,9 @@ def main():
     import torch
     import torch.distributed as dist
     from opfgym_amd import capi, dist as odist, envs
-    rank, world, local_rank = odist.init_from_env()
+    # (switches of this harness, mapped onto arguments: the package itself reads the torchrun variables only)
+    rank, world, local_rank = odist.init_from_env(backend=os.environ.get('OPFX_DIST_BACKEND') or None,
+                                                  force_collective=os.environ.get('OPFX_FORCE_COLLECTIVE', '') == '1')
     if os.environ.get('OPFX_BENCH_SHARE_GPU'):       # debugging aid: all ranks on GPU 0 (use with gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -333,7 +333,7 @@ class BatchedOpfEnv:
                  defer_device=False, validate_actions=False, carry_over_state=None, copy_outputs=False,
                  contingency_start=None, init=None, jacobian_reuse_tol=0.0, resample_failed_resets=True,
                  on_pivot_breakdown='ignore', reference_faithful=False, pin_point_q_ranges=None, share_lds_slots='auto',
-                 **kwargs):
+                 debug=None, **kwargs):
         from .objectives import QuadraticDeviation
         # reference_faithful: ONE switch for the four defaults that trade the reference's iteration path for speed.
         # Each of `init`, `contingency_start`, `carry_over_state`, `pin_point_q_ranges` left at None takes the fast default
@@ -349,6 +349,9 @@ class BatchedOpfEnv:
         # instance into the CU (_try_shared_slots); False never does
         assert share_lds_slots in ('auto', False), share_lds_slots
         self.share_lds_slots = share_lds_slots
+        # debug: developer switches of the library (include/opfx_debug.h) for this environment's plan and context — None, a
+        # dict of member names (`dict(team=2)`) or a capi.DebugOpts; the process environment is never consulted
+        self.debug = capi.debug_opts(debug)
         faithful = dict(init='auto', contingency_start='flat', carry_over_state=True, pin_point_q_ranges=False)
         fast = dict(init='flat', contingency_start='base_case', carry_over_state=False, pin_point_q_ranges=True)
         given = dict(init=init, contingency_start=contingency_start, carry_over_state=carry_over_state,
@@ -490,7 +493,7 @@ class BatchedOpfEnv:
 
         # ---- compile the grid --------------------------------------------------
         self.case = _case_all_branches_in(net, self.act_keys, not self._topology_fixed)
-        self.plan = capi.Plan(self.case)
+        self.plan = capi.Plan(self.case, debug=self.debug)
         if self.init == 'auto':
             # (a case whose DC model is not finite — a zero-reactance branch — carries no B': 'auto' then stays flat)
             self.init = 'dc' if self.case.meta.get('calc_angles') and self.plan.info['has_dc'] else 'flat'
@@ -606,7 +609,7 @@ class BatchedOpfEnv:
         import torch
         self.torch = torch
         self.device = torch.device(self.device_spec)
-        self.ctx = capi.Context(self.plan, self.device.index or 0)
+        self.ctx = capi.Context(self.plan, self.device.index or 0, debug=self.debug)
         self._resolve_reward(allow_estimate=True)
         self._create_env()
         self._try_shared_slots()
@@ -618,10 +621,13 @@ class BatchedOpfEnv:
         live in the LDS slots of lower blocks that are dead by then (`opfx_debug_opts.plan_share_slots`, plan.cpp share_slots:
         wave-team kernels with full Newton only).  Where that brings the environment under a third of the LDS — three teams of
         two per CU — the environment switches to such a plan; otherwise (or with chord steps, which re-read the lower blocks)
-        it keeps the one it has.  `share_lds_slots=False` (or OPFX_PLAN_SHARE=0 in the process environment) switches the attempt off."""
-        import os
-        if self.share_lds_slots is False or self.jacobian_reuse_tol > 0.0 or self.plan.info['n_shared'] or os.environ.get('OPFX_PLAN_SHARE') == '0' \
-                or os.environ.get('OPFX_TEAM') or os.environ.get('OPFX_FORCE_MEM') or os.environ.get('OPFX_KERNEL_V1'):
+        it keeps the one it has.  `share_lds_slots=False` switches the attempt off, and so does a `debug=` that fixes the kernel
+        form (team, force_mem, kernel_v1) or the plan's slot sharing itself (plan_share_slots).  What was decided:
+        `kernel_info()['shared_slots']`."""
+        dbg = self.debug
+        self.shared_slots = bool(self.plan.info['n_shared'])
+        if self.share_lds_slots is False or self.jacobian_reuse_tol > 0.0 or self.plan.info['n_shared'] \
+                or dbg.plan_share_slots or dbg.team or dbg.force_mem or dbg.kernel_v1:
             return
 
         def per_cu(info):
@@ -631,14 +637,16 @@ class BatchedOpfEnv:
         #  block values are in global memory anyway)
         if before['waves_per_instance'] != 4 or per_cu(before) != 2 or self.plan.info['lds_doubles'] * 8 > 150 * 1024:
             return
-        dbg = capi.DebugOpts.from_buffer_copy(self.plan.debug)
+        dbg = capi.debug_opts(self.debug)
         dbg.plan_share_slots = 1
         shared = capi.Plan(self.case, debug=dbg, elim_last=self.plan.elim_last)
         if not shared.info['n_shared']:
             return
+        # (whether a CU then holds a third instance depends on the block storage the library picks for the new plan —
+        #  two-value blocks where they buy an instance — so it is asked, not estimated: one more context and environment)
         plain = (self.plan, self.ctx)
         try:
-            self.plan, self.ctx = shared, capi.Context(shared, self.device.index or 0)
+            self.plan, self.ctx = shared, capi.Context(shared, self.device.index or 0, debug=dbg)
             self._create_env()
             gained = per_cu(self.kernel_info()) > per_cu(before)
         except capi.OpfxError:
@@ -646,6 +654,12 @@ class BatchedOpfEnv:
         if not gained:                                         # (nothing gained: back to the plan without shared slots)
             self.plan, self.ctx = plain
             self._create_env()
+        else:
+            import logging
+            logging.getLogger('opfgym_amd').info(
+                'environment switched to a plan with shared LDS slots (%d fill blocks hosted, %d -> %d instances per CU); '
+                'chord steps (jacobian_reuse_tol) are not available on it', shared.info['n_shared'], per_cu(before), per_cu(self.kernel_info()))
+        self.shared_slots = bool(self.plan.info['n_shared'])
 
     def _resolve_reward(self, allow_estimate):
         reward_function, params = self._reward_spec                        # opf_env.py:166-175
@@ -1552,8 +1566,8 @@ class BatchedOpfEnv:
         buses = tuple(sorted(set(b['min_pivot_bus'][idx].cpu().tolist())))
         if buses not in self._rescue_envs:
             self._drop_rescue_envs(keep=self.MAX_RESCUE_PLANS - 1)         # (each holds a plan, a context and a device copy)
-            plan = capi.Plan(self.case, elim_last=buses)
-            ctx = capi.Context(plan, self.device.index or 0)
+            plan = capi.Plan(self.case, elim_last=buses, debug=self.debug)
+            ctx = capi.Context(plan, self.device.index or 0, debug=self.debug)
             h = C.c_void_p()
             capi.check(capi.lib().opfx_env_create(ctx.handle, C.byref(self._env_desc), C.byref(h)), 'opfx_env_create (rescue plan)')
             self._rescue_envs[buses] = (plan, ctx, h)
@@ -1963,7 +1977,7 @@ class BatchedOpfEnv:
         capi.check(capi.lib().opfx_env_get_spec(self._env_handle, C.byref(spec)), 'opfx_env_get_spec')
         return dict(waves_per_instance=team.value, lds_bytes_per_instance=lds.value, instances_per_cu=per_cu.value,
                     packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value,
-                    spec=spec.value)          # (SPEC bits of the plain step kernel: 1 no PV bus, 2 no modifiers)
+                    spec=spec.value, shared_slots=bool(self.plan.info['n_shared']), debug=self.debug.as_dict())          # (SPEC bits of the plain step kernel: 1 no PV bus, 2 no modifiers)
 
     MAX_RESCUE_PLANS = 8
 

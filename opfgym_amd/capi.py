@@ -170,11 +170,44 @@ class DebugOpts(Sized):
     def any(self):
         return any(getattr(self, n) for n, _ in self._fields_ if n != 'struct_size')
 
+    def as_dict(self) -> dict:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_size' and getattr(self, n)}
+
+
+_default_debug = None
+
+
+def set_default_debug(debug=None) -> None:
+    """What `debug=None` means from now on in this process (None: all zero again).  For harness scripts that build many
+    objects and are steered from a shell loop: `capi.set_default_debug(capi.debug_from_env())` as their first statement.
+    The package itself never calls it; tests pass `debug=` explicitly."""
+    global _default_debug
+    _default_debug = None if debug is None else debug_opts(debug)
+
+
+def debug_opts(debug=None) -> DebugOpts:
+    """`debug=` arguments of this package as the struct: None (all zero: the library's own choices — unless a harness script
+    has called `set_default_debug`), a dict of field names
+    (`dict(team=2, queue=-1)`) or a DebugOpts (copied).  The package never reads the process environment for these;
+    scripts and A/B harnesses that are steered by OPFX_* variables call `debug_from_env()` themselves and pass the result."""
+    if debug is None:
+        return DebugOpts.from_buffer_copy(_default_debug) if _default_debug is not None else DebugOpts()
+    if isinstance(debug, DebugOpts):
+        return DebugOpts.from_buffer_copy(debug)
+    d = DebugOpts()
+    for k, v in dict(debug).items():
+        if k not in {n for n, _ in DebugOpts._fields_} or k == 'struct_size':
+            raise KeyError(f'opfx_debug_opts has no member {k!r}')
+        setattr(d, k, int(v))
+    return d
+
 
 def debug_from_env(environ=None) -> DebugOpts:
-    """Developer switches of THIS binding's test / A-B harness: OPFX_* variables of the Python process, read when a
-    Plan / Context is constructed without an explicit `debug=` and turned into the explicit struct the library takes
-    (the C library itself reads no environment variable).  Tri-state switches: '1' on, '0' off, unset = automatic."""
+    """Developer switches as OPFX_* variables of the calling process, turned into the explicit struct the library takes:
+    the ONE place of this package that reads them, and nothing in the package calls it — scripts/ (profiling, A/B and fuzz
+    harnesses, which are steered from shell loops) do, and hand the result on as `debug=`.  Neither the C library nor
+    `Plan` / `Context` / `BatchedOpfEnv` read the environment themselves.  Tri-state switches: '1' on, '0' off, unset =
+    automatic."""
     e = os.environ if environ is None else environ
     d = DebugOpts()
 
@@ -288,7 +321,7 @@ class Plan:
         the static pivoting at those buses (opfx_case.elim_last, `min_pivot_bus`)."""
         self.case = case
         self.elim_last = None if elim_last is None else sorted(int(b) for b in elim_last)
-        self.debug = debug if debug is not None else debug_from_env()
+        self.debug = debug_opts(debug)
         keep = []
         cs = CaseStruct()
         cs.nb, cs.nbr, cs.base_mva = case.nb, case.nbr, float(case.base_mva)
@@ -369,7 +402,7 @@ class Context:
     def __init__(self, plan: Plan, device: int = 0, debug: DebugOpts = None):
         self.plan = plan
         self.device = device
-        self.debug = debug if debug is not None else debug_from_env()
+        self.debug = debug_opts(debug)
         h = C.c_void_p()
         if self.debug.any():
             check(lib().opfx_ctx_create_debug(plan.handle, int(device), C.byref(self.debug), C.byref(h)), 'opfx_ctx_create_debug')

@@ -34,6 +34,9 @@ TABLES = ('bus', 'line', 'trafo', 'trafo3w', 'load', 'sgen', 'storage', 'gen', '
 _INT_COLS = ('bus', 'from_bus', 'to_bus', 'hv_bus', 'mv_bus', 'lv_bus', 'element')
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEF_DIR = os.path.join(HERE, 'definitions')
+# True: classes with a native recipe are read from their recorded definition as well (a test / comparison switch, set by the
+# caller — this module does not consult the process environment)
+PREFER_RECORDED = False
 
 
 @dataclass
@@ -248,9 +251,9 @@ def resolve(ref_path: str, class_kwargs: dict, grid_seed=0, prepare=None) -> Def
         from . import simbench_build
         return build_from_reference(cls, class_kwargs, getattr(simbench_build, prepare) if prepare else None)
     from . import native_definition, simbench_build
-    if native_definition.has_recipe(ref_path) and not os.environ.get('OPFX_RECORDED_DEFINITIONS'):
+    if native_definition.has_recipe(ref_path) and not PREFER_RECORDED:
         # the native, parameterised builder (rule tables of opfgym_amd/native_definition.py): any constructor
-        # arguments, on the synthetic stand-in grids.  (OPFX_RECORDED_DEFINITIONS=1: the recorded files instead.)
+        # arguments, on the synthetic stand-in grids.  (definition.PREFER_RECORDED = True: the recorded files instead.)
         return native_definition.build(ref_path, class_kwargs, grid_seed,
                                        getattr(simbench_build, prepare) if prepare else None)
     key = request_key(ref_path, class_kwargs, grid_seed, prepare)

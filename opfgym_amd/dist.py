@@ -13,12 +13,16 @@ from __future__ import annotations
 import os
 
 
+_FORCE_COLLECTIVE = False
+
+
 def force_collective() -> bool:
-    """OPFX_FORCE_COLLECTIVE=1 (read by this Python layer, not by the library): a world of ONE rank initialises its
-    process group and runs every collective of this module for real instead of short-circuiting — the way to execute
-    the RCCL code path (communicator set-up, `all_gather_into_tensor` on device tensors, the asynchronous gather, the
-    barrier and the max-reduce of the bench) on a box with a single GPU."""
-    return os.environ.get('OPFX_FORCE_COLLECTIVE', '') == '1'
+    """True after `init_from_env(..., force_collective=True)`: a world of ONE rank has initialised its process group and
+    runs every collective of this module for real instead of short-circuiting — the way to execute the RCCL code path
+    (communicator set-up, `all_gather_into_tensor` on device tensors, the asynchronous gather, the barrier and the
+    max-reduce of the bench) on a box with a single GPU.  An argument of the caller (bench.py maps its own
+    OPFX_FORCE_COLLECTIVE switch onto it); this module reads the torchrun variables and nothing else."""
+    return _FORCE_COLLECTIVE
 
 
 def _local_only(world: int) -> bool:
@@ -26,16 +30,19 @@ def _local_only(world: int) -> bool:
     return not dist.is_initialized() or (world == 1 and not force_collective())
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
+def init_from_env(backend=None, force_collective=False):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  `backend`: None = 'nccl' (RCCL) with a GPU,
+    else 'gloo'.  `force_collective`: initialise the group even for a world of one (see `force_collective()`)."""
     import torch
     import torch.distributed as dist
+    global _FORCE_COLLECTIVE
+    _FORCE_COLLECTIVE = bool(force_collective)
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if (world == 1 and not force_collective()) or dist.is_initialized():
+    if (world == 1 and not _FORCE_COLLECTIVE) or dist.is_initialized():
         return int(os.environ.get('RANK', '0')), world, int(os.environ.get('LOCAL_RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
-        backend = os.environ.get('OPFX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
     if backend == 'nccl':

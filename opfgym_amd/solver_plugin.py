@@ -34,8 +34,9 @@ def _not_converged_exception():
 
 
 class BatchedPowerFlowSolver:
-    def __init__(self, device='cuda:0', tolerance=1e-8, max_iteration=10):
+    def __init__(self, device='cuda:0', tolerance=1e-8, max_iteration=10, debug=None):
         self.device = device
+        self.debug = capi.debug_opts(debug)          # developer switches (include/opfx_debug.h); never from the environment
         self.tol, self.max_it = tolerance, max_iteration
         self._cache = {}
         self.max_cached_plans = 256
@@ -51,7 +52,7 @@ class BatchedPowerFlowSolver:
         if ctx is None:
             import torch
             dev = torch.device(self.device)
-            ctx = capi.Context(capi.Plan(case), dev.index or 0)
+            ctx = capi.Context(capi.Plan(case, debug=self.debug), dev.index or 0, debug=self.debug)
             while len(self._cache) >= self.max_cached_plans:
                 self._cache.pop(next(iter(self._cache)))
         self._cache[key] = ctx

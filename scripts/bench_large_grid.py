@@ -18,6 +18,7 @@ import torch  # noqa: E402
 from helpers import random_injections  # noqa: E402
 from opfgym_amd import capi, grids  # noqa: E402
 from opfgym_amd.case import net_to_case  # noqa: E402
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048

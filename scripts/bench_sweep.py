@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 import numpy as np, torch
 from opfgym_amd import envs
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 from env_cases import oracle_env, product_env
 
 GRID = '1-MV-urban--0-sw'

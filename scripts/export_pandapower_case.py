@@ -24,6 +24,8 @@ import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from opfgym_amd.definition import arrays_to_net as load_tables, tables_to_arrays as dump_tables  # noqa: E402,F401
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 
 RESULTS = (('res_bus', ('vm_pu', 'va_degree')), ('res_line', ('loading_percent',)),
            ('res_trafo', ('loading_percent',)), ('res_trafo3w', ('loading_percent',)),

@@ -27,6 +27,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 from helpers import oracle_batch  # noqa: E402
 from opfgym_amd import capi, grids  # noqa: E402
 from opfgym_amd.case import net_to_case  # noqa: E402
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 
 TOL_V = 1e-8
 

@@ -10,6 +10,7 @@ import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__
 import numpy as np
 from opfgym_amd import capi, grids
 from opfgym_amd.case import net_to_case
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 from plan_emulator import load_plan
 for code in ('1-HV-mixed--0-sw','1-HV-urban--0-sw','1-MV-urban--0-sw'):
     case = net_to_case(grids.get_grid(code)[0]); plan = capi.Plan(case); P = load_plan(plan); info = plan.info

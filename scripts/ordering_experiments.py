@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from opfgym_amd import capi, grids  # noqa: E402
 from opfgym_amd.case import net_to_case  # noqa: E402
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 
 
 def graph(code):

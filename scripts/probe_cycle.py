@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import numpy as np, torch
 from opfgym_amd import envs
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 B = 8192
 env = envs.VoltageControl(simbench_network_name='1-MV-urban--0-sw', batch_size=B, device='cuda:0', seed=0)
 act = torch.rand(B, env.n_actions, dtype=torch.float64, device='cuda:0')

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import numpy as np, torch
 from opfgym_amd import capi, envs
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 import bench
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 cls, kw, B, _, _ = bench.CONFIGS[cfg]

@@ -2,6 +2,8 @@ import sys, os; sys.path[:0]=['/root/repo']
 import numpy as np, torch, heapq
 import bench
 from opfgym_amd import envs
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 for cfg in (2, 3, 4):
     cls, kw, B, _, _ = bench.CONFIGS[cfg]
     env = getattr(envs, cls)(batch_size=B, device='cuda:0', seed=0, **kw)

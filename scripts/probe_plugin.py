@@ -2,6 +2,8 @@
 import os, sys, time, cProfile, pstats
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from opfgym_amd import grids, power_flow_solver
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 code = sys.argv[1] if len(sys.argv) > 1 else '1-MV-urban--0-sw'
 net, _ = grids.get_grid(code)
 for _ in range(3):

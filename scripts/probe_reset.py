@@ -4,6 +4,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 from opfgym_amd import envs
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 cls = getattr(envs, sys.argv[2]) if len(sys.argv) > 2 else envs.VoltageControl
 env = cls(simbench_network_name='1-MV-urban--0-sw', batch_size=B, device='cuda:0', seed=0)

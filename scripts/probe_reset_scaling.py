@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 import torch
 from opfgym_amd import envs
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 for B in (64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
     env = envs.VoltageControl(simbench_network_name='1-MV-urban--0-sw', batch_size=B, device='cuda:0', seed=0)
     for _ in range(3):

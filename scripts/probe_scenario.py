@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 from env_cases import product_env
 from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 name = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 20

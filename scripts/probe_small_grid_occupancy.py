@@ -14,6 +14,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from opfgym_amd import envs  # noqa: E402
+from opfgym_amd import capi
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 for code in ('mv-small', '1-LV-rural1--0-sw'):

@@ -4,6 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')]
 from opfgym_amd import capi, envs
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 CFG = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 import bench

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from opfgym_amd import capi, grids
 from opfgym_amd.case import net_to_case
+capi.set_default_debug(capi.debug_from_env())      # this harness is steered through OPFX_* variables (see capi.debug_from_env)
 from helpers import random_injections
 code = sys.argv[1] if len(sys.argv) > 1 else '1-MV-urban--0-sw'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192

@@ -286,3 +286,18 @@ def resonant_leaf_ppc(n_chain=4):
     branch = np.array([[i, i + 1, 0.01 if i < nb - 2 else 0.0, 0.1, 0.0, 0, 0, 0, 0, 0, 1, -360, 360] for i in range(nb - 1)], dtype=float)
     gen = np.array([[0, 0.0, 0.0, 1e4, -1e4, 1.0, 100, 1]])
     return 100.0, bus, branch, gen
+
+
+# Developer switches of the library (include/opfx_debug.h) for the GPU tests.  The package never reads the process
+# environment for them; this harness does, in ONE place: a test run may be steered as a whole from outside
+# (OPFX_KERNEL_V1=1 python -m pytest ... re-runs the solver tests on the first-generation kernel,
+# tests/test_gpu_solve.py::test_first_generation_kernel_still_correct), individual tests add their own members.
+DEBUG_OVERRIDES = {}
+
+
+def harness_debug(**members):
+    from opfgym_amd import capi
+    d = capi.debug_from_env()
+    for k, v in {**DEBUG_OVERRIDES, **members}.items():
+        setattr(d, k, int(v))
+    return d

@@ -222,8 +222,7 @@ def _forced_world_of_one(port, q):
     plain = od.OverlappedGather(1)
     x = torch.arange(6, dtype=torch.float64).reshape(3, 2)
     short = (od.init_from_env('gloo'), dist.is_initialized(), plain.submit(x) is x, plain.flush(), od.all_gather_rows(x, 1) is x)
-    os.environ['OPFX_FORCE_COLLECTIVE'] = '1'
-    r, w, _ = od.init_from_env('gloo')
+    r, w, _ = od.init_from_env('gloo', force_collective=True)
     g = od.OverlappedGather(1)
     first = g.submit(x)
     second = g.submit(x + 10)
@@ -236,7 +235,7 @@ def _forced_world_of_one(port, q):
 
 
 def test_a_forced_world_of_one_runs_the_collectives_instead_of_short_circuiting():
-    """OPFX_FORCE_COLLECTIVE=1 (how the RCCL branch is executed on a one-GPU box, tests/test_gpu_bench.py): a single rank
+    """`init_from_env(force_collective=True)` (bench.py's OPFX_FORCE_COLLECTIVE=1: how the RCCL branch is executed on a one-GPU box, tests/test_gpu_bench.py): a single rank
     initialises its process group and `OverlappedGather` / `all_gather_rows` go through the collective (staging buffers,
     previous-step hand-over) — without it the same calls hand the local tensor straight back."""
     ctx = mp.get_context('spawn')

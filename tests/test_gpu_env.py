@@ -98,13 +98,12 @@ def test_env_matches_reference_golden(name):
 def test_work_queue_and_fixed_shares_give_the_same_rows(name, B, monkeypatch):
     """Batches of eight or more instances per workgroup are handed out through a work queue (opfx.hip: use_queue), smaller
     ones in fixed shares.  Which workgroup solves an instance must not matter: the same reset and actions under both
-    policies (OPFX_QUEUE forces one) give the same rows — bit for bit on the single-wavefront kernel, whose arithmetic
+    policies (`debug=dict(queue=...)` forces one) give the same rows — bit for bit on the single-wavefront kernel, whose arithmetic
     does not depend on the workgroup."""
     import torch
     outs = []
-    for q in ('0', '1'):
-        monkeypatch.setenv('OPFX_QUEUE', q)
-        env = product_env(name, batch_size=B)
+    for q in (-1, 1):                                       # (tri-state member: -1 fixed shares, 1 work queue)
+        env = product_env(name, batch_size=B, debug=dict(queue=q))
         rng = np.random.default_rng(3)
         env.reset(seed=11)
         a = rng.random((B, env.n_actions))
@@ -121,14 +120,13 @@ def test_work_queue_and_fixed_shares_give_the_same_rows(name, B, monkeypatch):
 @pytest.mark.parametrize('name', ['vc_mv_small', 'vc_mixed_simbench', 'vc_mixed_uniform', 'vc_noisy', 'vc_normal_noise', 'vc_interpolate', 'qm_mv_small', 'eco_hv_small', 'loadshed_mv_small'])
 def test_reset_kernel_teams_of_one_and_two_wavefronts(name, team, monkeypatch):
     """The reset kernel runs as teams of 4, 2 or 1 wavefronts (= rows per workgroup) depending on the size of the table
-    row; the grids of the goldens all take teams of four.  The smaller teams are forced here (OPFX_RESET_TEAM) and must
+    row; the grids of the goldens all take teams of four.  The smaller teams are forced here (`debug=dict(reset_team=...)`) and must
     reproduce the reference's sampled tables and reset observation, on batches that are no multiple of the team."""
     if name not in SINGLE_STEP:
         pytest.skip(f'no golden {name}')
-    monkeypatch.setenv('OPFX_RESET_TEAM', str(team))
     g = golden(name)
     n = len(g['step'])
-    env = product_env(name, batch_size=n)
+    env = product_env(name, batch_size=n, debug=dict(reset_team=team))
     noise = None
     if noise_factors(name, g['noise'][0]) is not None:
         noise = np.stack([noise_factors(name, g['noise'][k]) for k in range(n)])
@@ -277,18 +275,19 @@ def test_full_batch_voltage_control_properties():
 def test_full_batch_configs(name, B, n_check, team, levels, monkeypatch):
     """BASELINE configs 3 and 5 at full size on their own grids: EcoDispatch on the 306-bus meshed HV grid
     (B = 8192 on the plan with shared LDS slots the environment picks — three teams of four wavefronts per CU; smaller batches
-    with teams of two forced through the developer switch OPFX_TEAM and with teams of four on the plan without shared slots) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
+    with teams of two forced through the developer switch `debug=dict(team=2)` and with teams of four on the plan without shared slots) and N-1 VoltageControl on the 372-bus grid with every non-islanding line as
     contingency (B = 4096 x 251 solves, four wavefronts per instance); BASELINE config 4 at its full size as well
     (QMarket, 144 buses, B = 65536: every wavefront walks 32 instances).  All rows:
     size-independent properties; `n_check` rows spread over the batch (128 / 32 / 32 / 512; the N-1 rows — 251 oracle power flows
     each — in eight worker processes: VERDICT r04 #8), valid and
     invalid states among them: the full step against the oracle, no row skipped, the converged flags equal the oracle's."""
     shared = team == 'shared'
+    extra = {}
     if team == 2:
-        monkeypatch.setenv('OPFX_TEAM', '2')
+        extra['debug'] = dict(team=2)
     if team == 4 and name == 'eco_hv_mixed':
-        monkeypatch.setenv('OPFX_PLAN_SHARE', '0')            # (the plan without shared slots: two teams of four per CU)
-    env = product_env(name, batch_size=B)
+        extra['share_lds_slots'] = False                      # (the plan without shared slots: two teams of four per CU)
+    env = product_env(name, batch_size=B, **extra)
     if shared:
         # round 5: the 306-bus grid runs on a plan with SHARED SLOTS (plan.cpp share_slots) — three teams per CU, of FOUR
         # wavefronts each on the kernel compiled for three wavefronts per SIMD
@@ -816,12 +815,11 @@ def test_env_option_init_dc_and_auto():
 
 @pytest.mark.parametrize('name', ['eco_hv_small', 'sc_hv_small', 'vc_mv_small', 'reconf_hv_small_sw'])
 def test_env_on_the_memory_resident_kernel_matches_the_golden(name, monkeypatch):
-    """The fused step on the memory-resident form of the team kernel (OPFX_FORCE_MEM: block values in global memory)
+    """The fused step on the memory-resident form of the team kernel (`debug=dict(force_mem=1)`: block values in global memory)
     replays golden scenarios of the reference — q-limits, N-1 contingencies, switch / tap modifiers included."""
-    monkeypatch.setenv('OPFX_FORCE_MEM', '1')
     g = golden(name)
     n = len(g['step'])
-    env = product_env(name, batch_size=n)
+    env = product_env(name, batch_size=n, debug=dict(force_mem=1))
     assert env.kernel_info()['waves_per_instance'] == 4
     env.reset(options={'step': g['step'], 'uniform': g['uniform'] if g['uniform'].shape[1] else None})
     out = env.step(g['action'])
@@ -1044,9 +1042,7 @@ def test_shunt_steps_as_actuators(team, monkeypatch):
                         ('shunt', 'step', net.shunt.index)]
             BatchedOpfEnv.__init__(self, net, act_keys, obs_keys, profiles=profiles, **kw)
     B = 24
-    if team:
-        monkeypatch.setenv('OPFX_TEAM', str(team))
-    env = ShuntSteps(batch_size=B, device='cuda:0', seed=3)
+    env = ShuntSteps(batch_size=B, device='cuda:0', seed=3, debug=dict(team=team) if team else None)
     h = ShuntSteps(batch_size=1, defer_device=True, seed=3)
     d = h.host_definition()
     orc = env_oracle.EnvOracle(

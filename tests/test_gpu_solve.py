@@ -4,7 +4,7 @@ SciPy oracle.  Tolerance: 1e-9 p.u. on |V| and angle (the north-star bar is
 import numpy as np
 import pytest
 
-from helpers import oracle_batch, random_injections
+from helpers import DEBUG_OVERRIDES, harness_debug, oracle_batch, random_injections
 
 pytestmark = pytest.mark.gpu
 
@@ -17,8 +17,8 @@ def _run(code, B, seed, **kw):
     from opfgym_amd.case import net_to_case
     net, _ = grids.get_grid(code) if code != 'case9' else (grids.case9(), None)
     case = net_to_case(net)
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     p, q = random_injections(net, case, B, seed)
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), **kw)
@@ -49,11 +49,11 @@ def test_the_answer_does_not_depend_on_the_elimination_order(code, B, monkeypatc
     order means other block numbers, levels and rounding — and the same power flow: the first order (OPFX_PLAN_SEARCH=0),
     the searched one and a pinned third one agree to rounding, with the same iteration counts."""
     runs = []
-    for env in ({'OPFX_PLAN_SEARCH': '0'}, {}, {'OPFX_PLAN_SEED': '7', 'OPFX_PLAN_DCAP_SLACK': '3'}):
-        for k in ('OPFX_PLAN_SEARCH', 'OPFX_PLAN_SEED', 'OPFX_PLAN_DCAP_SLACK'):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for members in (dict(plan_search=-1), {}, dict(plan_seed=7, plan_dcap_slack=3)):       # (plan_search -1: the first order only)
+        for k in ('plan_search', 'plan_seed', 'plan_dcap_slack'):
+            DEBUG_OVERRIDES.pop(k, None)
+        for k, v in members.items():
+            monkeypatch.setitem(DEBUG_OVERRIDES, k, v)
         runs.append(_run(code, B, seed=5)[4])
     a = runs[0]
     assert a['converged'].astype(bool).all()
@@ -72,10 +72,10 @@ def test_second_columns_everywhere_nowhere_and_where_they_pay_give_the_same_answ
     every kernel form (early reads in the single-wave kernel, late reads in the wave teams) then runs that code — and =1
     none at all.  Same power flow, same iteration counts, the oracle's answer."""
     if team:
-        monkeypatch.setenv('OPFX_TEAM', str(team))
+        monkeypatch.setitem(DEBUG_OVERRIDES, 'team', int(team))
     runs = []
     for mode in ('0', '1', '2'):
-        monkeypatch.setenv('OPFX_PLAN_NO_PAIRS', mode)
+        monkeypatch.setitem(DEBUG_OVERRIDES, 'plan_no_pairs', int(mode))
         net, case, p, q, out = _run(code, B, seed=23)
         runs.append(out)
     ref = oracle_batch(net, case, p, q)
@@ -103,8 +103,8 @@ def test_full_batch_properties():
     p2 = np.concatenate([p[:4]] * 8)
     import torch
     from opfgym_amd import capi
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     o2 = capi.solve(ctx, torch.tensor(p2, device=dev), torch.tensor(np.concatenate([q[:4]] * 8), device=dev))
     vm2 = o2['vm'].cpu().numpy()
@@ -121,7 +121,7 @@ def test_ragged_batches_give_the_same_rows(B):
     from opfgym_amd.case import net_to_case
     net, _ = grids.get_grid('1-MV-urban--0-sw')
     case = net_to_case(net)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     p, q = random_injections(net, case, B, 3)
     dev = torch.device('cuda:0')
     full = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
@@ -180,7 +180,7 @@ def test_ieee14_published_solution_on_the_gpu():
     from opfgym_amd.ppci_io import case_from_ppc
     base, bus, branch, gen, pub = ieee14_ppc()
     case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev))
     assert bool(out['converged'][0]) and int(out['iterations'][0]) <= 5
@@ -204,7 +204,7 @@ def test_ieee30_published_solution_on_the_gpu():
     from opfgym_amd.ppci_io import case_from_ppc
     base, bus, branch, gen, pub = ieee30_ppc()
     case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev))
     assert bool(out['converged'][0]) and int(out['iterations'][0]) <= 5
@@ -231,10 +231,10 @@ def test_complete_graph_on_the_gpu(n, team, monkeypatch):
     from helpers import dense_ppc, oracle_ppc_solve
     from opfgym_amd import capi
     from opfgym_amd.ppci_io import case_from_ppc
-    monkeypatch.setenv('OPFX_TEAM', str(team))
+    monkeypatch.setitem(DEBUG_OVERRIDES, 'team', int(team))
     base, bus, branch, gen = dense_ppc(n)
     case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     B = 9
     scale = np.linspace(0.6, 1.4, B)[:, None]
@@ -259,7 +259,7 @@ def test_published_textbook_solutions_on_the_gpu(name):
     from opfgym_amd.ppci_io import case_from_ppc
     base, bus, branch, gen, pub = published_cases()[name]
     case, p, q, _, _ = case_from_ppc(base, bus, branch, gen)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     out = {k: v[0].cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev)).items()}
     assert bool(out['converged']) and int(out['iterations']) <= 5
@@ -293,7 +293,7 @@ def _check_export_on_the_gpu(path):
     from opfgym_amd.ppci_io import load_exported_case
     dev = torch.device('cuda:0')
     case, p, q, qmin, qmax, ref = load_exported_case(path)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     out = capi.solve(ctx, torch.tensor(p[None], device=dev), torch.tensor(q[None], device=dev),
                      qg_min=torch.tensor(qmin, device=dev), qg_max=torch.tensor(qmax, device=dev), enforce_q_lims=True)
     assert bool(out['converged'][0]), path
@@ -372,7 +372,7 @@ def test_min_pivot_diagnoses_a_near_singular_jacobian():
     from opfgym_amd import capi, grids
     from opfgym_amd.case import net_to_case
     case = net_to_case(grids.two_bus())
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     load = np.linspace(0.5, 40.0, 160)                        # MW at cos(phi) ~ 0.96, far beyond the nose
     p = np.zeros((len(load), 2)); q = np.zeros((len(load), 2))
@@ -389,7 +389,7 @@ def test_min_pivot_diagnoses_a_near_singular_jacobian():
     # a well-conditioned grid stays far from zero
     net, _ = grids.get_grid('1-MV-urban--0-sw')
     c2 = net_to_case(net)
-    ctx2 = capi.Context(capi.Plan(c2), 0)
+    ctx2 = capi.Context(capi.Plan(c2, debug=harness_debug()), 0, debug=harness_debug())
     p2, q2 = random_injections(net, c2, 64, 1)
     o2 = capi.solve(ctx2, torch.tensor(p2, device=dev), torch.tensor(q2, device=dev))
     assert bool(o2['converged'].all()) and float(o2['min_pivot'].min()) > 0.3
@@ -402,8 +402,8 @@ def test_outage_axis():
     from opfgym_amd.case import net_to_case
     net, _ = grids.get_grid('1-HV-mixed--0-sw')
     case = net_to_case(net)
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     B = 24
     p, q = random_injections(net, case, B, 3, lo=0.2, hi=0.8)
     # only branches whose removal keeps the grid connected (no bridges)
@@ -435,8 +435,8 @@ def test_islanding_outage_de_energises_the_island(code):
     from opfgym_amd.case import net_to_case
     net, _ = grids.get_grid(code)
     case = net_to_case(net)
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     island = plan.array('br_island')
     from helpers import non_bridge_branches
     assert set(np.flatnonzero(island == 0).tolist()) == set(non_bridge_branches(case).tolist())
@@ -470,8 +470,8 @@ def test_enforce_q_lims():
     from opfgym_amd.case import net_to_case
     net = grids.case9()
     case = net_to_case(net)
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     B = 32
     p, q = random_injections(net, case, B, 9, lo=0.6, hi=1.3)
     qmin = np.full(case.nb, -np.inf)
@@ -519,7 +519,7 @@ def test_dc_start_reproduces_the_oracle_iteration_for_iteration(code, B):
     from opfgym_amd.case import net_to_case
     net, _ = grids.get_grid(code)
     case = net_to_case(net)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     p, q = random_injections(net, case, B, seed=31, lo=0.3, hi=1.3)
     dev = torch.device('cuda:0')
     out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev), init='dc').items()}
@@ -552,7 +552,7 @@ def test_dc_start_with_a_branch_out_of_service_follows_the_oracle(code, B):
     case = net_to_case(net)
     cand = non_bridge_branches(case)
     assert len(cand)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     p, q = random_injections(net, case, B, seed=37, lo=0.3, hi=1.2)
     outage = np.random.default_rng(9).choice(cand, B).astype(np.int32)
     dev = torch.device('cuda:0')
@@ -581,7 +581,7 @@ def test_dc_start_needs_the_dc_model_of_the_branches():
     net, _ = grids.get_grid('hv-small')
     case = net_to_case(net)
     case.bdc = None
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     z = torch.zeros(2, case.nb, dtype=torch.float64, device='cuda:0')
     with pytest.raises(capi.OpfxError, match='OPFX_INIT_DC'):
         capi.solve(ctx, z, z, init='dc')
@@ -592,7 +592,7 @@ def test_memory_resident_kernel_matches_the_oracle_on_grids_that_also_fit_the_ld
     """The memory-resident form of the wave-team kernel (LU block values in a per-workgroup row of global memory,
     state vectors in LDS; chosen when a grid's blocks do not fit the LDS) forced on grids the LDS-resident kernels
     also run (OPFX_FORCE_MEM): same voltages, loadings, slack power and iteration counts, outages included."""
-    monkeypatch.setenv('OPFX_FORCE_MEM', '1')
+    monkeypatch.setitem(DEBUG_OVERRIDES, 'force_mem', 1)
     net, case, p, q, out = _run(code, B, seed=41)
     ref = oracle_batch(net, case, p, q)
     assert ref['converged'].all() and out['converged'].astype(bool).all()
@@ -609,7 +609,7 @@ def test_memory_resident_kernel_matches_the_oracle_on_grids_that_also_fit_the_ld
     if not len(cand):                      # (a radial grid: every branch is a bridge)
         return
     outage = np.random.default_rng(5).choice(cand, B).astype(np.int32)
-    ctx = capi.Context(capi.Plan(case), 0)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
     dev = torch.device('cuda:0')
     o2 = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev),
                                                      outage=torch.tensor(outage, device=dev)).items()}
@@ -628,9 +628,9 @@ def test_a_grid_past_the_lds_runs_on_the_memory_resident_kernel():
     from opfgym_amd.case import net_to_case
     net, _ = grids.synthetic_hv(5, nb=1000, n_ext=2, n_gen=10)
     case = net_to_case(net)
-    plan = capi.Plan(case)
+    plan = capi.Plan(case, debug=harness_debug())
     assert plan.info['lds_doubles'] * 8 > 160 * 1024 and plan.info['n_blk'] < 32768
-    ctx = capi.Context(plan, 0)
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     B = 6
     p, q = random_injections(net, case, B, seed=3, lo=0.5, hi=1.0)
     dev = torch.device('cuda:0')
@@ -657,15 +657,15 @@ def test_chord_steps_reach_the_fixed_point_of_full_newton(code, B, team, theta, 
     iteration count is the one the CPU emulation of the chord stream takes (tests/plan_emulator.py), never below full
     Newton's; enforce_q_lims and outages go through the same kernels."""
     if team:
-        monkeypatch.setenv('OPFX_TEAM', str(team))
+        monkeypatch.setitem(DEBUG_OVERRIDES, 'team', int(team))
     import torch
     from opfgym_amd import capi, grids
     from opfgym_amd.case import net_to_case
     from plan_emulator import emulate_newton_lane_program
     net, _ = grids.get_grid(code) if code != 'case9' else (grids.case9(), None)
     case = net_to_case(net)
-    plan = capi.Plan(case)
-    ctx = capi.Context(plan, 0)
+    plan = capi.Plan(case, debug=harness_debug())
+    ctx = capi.Context(plan, 0, debug=harness_debug())
     p, q = random_injections(net, case, B, seed=23)
     dev = torch.device('cuda:0')
     tp, tq = torch.tensor(p, device=dev), torch.tensor(q, device=dev)
@@ -720,12 +720,12 @@ def test_pivot_breakdown_is_located_and_a_rescue_plan_recovers_it():
     dev = torch.device('cuda:0')
     B = 5
     tp, tq = torch.tensor(np.tile(p, (B, 1)), device=dev), torch.tensor(np.tile(q, (B, 1)), device=dev)
-    plain = capi.solve(capi.Context(capi.Plan(case), 0), tp, tq)
+    plain = capi.solve(capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug()), tp, tq)
     assert not bool(plain['converged'].any())
     assert float(plain['min_pivot'].max()) < 1e-8 and (plain['min_pivot_bus'].cpu().numpy() == leaf).all()
-    rescue_plan = capi.Plan(case, elim_last=[leaf])
+    rescue_plan = capi.Plan(case, elim_last=[leaf], debug=harness_debug())
     assert rescue_plan.array('PIV_BUS')[-1] == leaf
-    out = capi.solve(capi.Context(rescue_plan, 0), tp, tq)
+    out = capi.solve(capi.Context(rescue_plan, 0, debug=harness_debug()), tp, tq)
     assert bool(out['converged'].all()) and (out['iterations'].cpu().numpy() == ref['iterations']).all()
     assert np.abs(out['vm'].cpu().numpy() - np.abs(ref['V'])).max() < 1e-9
     assert float(out['min_pivot'].min()) > 1e-6
@@ -733,5 +733,5 @@ def test_pivot_breakdown_is_located_and_a_rescue_plan_recovers_it():
     # changes the order, not the answer
     net, case2, p2, q2, got = _run('1-MV-urban--0-sw', 16, seed=3)
     assert (got['min_pivot'] > 1e-3).all() and ((got['min_pivot_bus'] >= 0) & (got['min_pivot_bus'] < case2.nb)).all()
-    held = capi.solve(capi.Context(capi.Plan(case2, elim_last=[5, 17, 60]), 0), torch.tensor(p2, device=dev), torch.tensor(q2, device=dev))
+    held = capi.solve(capi.Context(capi.Plan(case2, elim_last=[5, 17, 60], debug=harness_debug()), 0, debug=harness_debug()), torch.tensor(p2, device=dev), torch.tensor(q2, device=dev))
     assert bool(held['converged'].all()) and np.abs(held['vm'].cpu().numpy() - got['vm']).max() < 1e-10

@@ -100,14 +100,19 @@ def test_structs_carry_their_size_and_a_wrong_size_is_refused(built_lib):
 
 def test_developer_switches_travel_in_an_explicit_struct(built_lib, monkeypatch):
     """include/opfx_debug.h: what used to be OPFX_* environment variables of the LIBRARY is a struct handed to the *_debug
-    constructors; the binding fills it from its own process environment (debug_from_env) or takes it explicitly."""
+    constructors; the binding takes it explicitly (`debug=`: a struct or a dict of member names) and never reads the
+    process environment for it — `debug_from_env()` is a helper for scripts."""
     case = net_to_case(grids.get_grid('1-HV-mixed--0-sw')[0])
     default = capi.Plan(case).info
     d = capi.DebugOpts()
     d.plan_search = -1
     first = capi.Plan(case, debug=d).info
+    # the process environment steers NOTHING by itself: a Plan built without `debug=` is the default plan whatever OPFX_*
+    # says; `debug_from_env()` is the explicit helper of scripts and harnesses that turns such variables into the struct
     monkeypatch.setenv('OPFX_PLAN_SEARCH', '0')
-    assert capi.debug_from_env().plan_search == -1 and capi.Plan(case).info == first
+    assert capi.Plan(case).info == default
+    assert capi.debug_from_env().plan_search == -1 and capi.Plan(case, debug=capi.debug_from_env()).info == first
+    assert capi.Plan(case, debug=dict(plan_search=-1)).info == first
     monkeypatch.delenv('OPFX_PLAN_SEARCH')
     d = capi.DebugOpts()
     d.plan_no_tail = 1
@@ -187,8 +192,8 @@ def test_shared_slots_give_the_same_power_flow_with_less_lds(built_lib, code, te
     from plan_emulator import emulate_newton
     net = grids.get_grid(code)[0]
     case = net_to_case(net)
-    plain = capi.Plan(case, debug=capi.debug_from_env({}))
-    shared = capi.Plan(case, debug=capi.debug_from_env({'OPFX_PLAN_SHARE': '1'}))
+    plain = capi.Plan(case)
+    shared = capi.Plan(case, debug=dict(plan_share_slots=1))
     ns = shared.info['n_shared']
     assert plain.info['n_shared'] == 0 and ns > 0
     if case.nb < 200:            # (from 200 buses on the plan is SEARCHED, and with less LDS another elimination order may win)
@@ -332,17 +337,12 @@ def test_plan_search_keeps_the_cheapest_elimination_order(built_lib, monkeypatch
     searched = capi.Plan(case).info
     again = capi.Plan(case).info
     assert searched == again
-    monkeypatch.setenv('OPFX_PLAN_SEARCH', '0')
-    first = capi.Plan(case).info
+    first = capi.Plan(case, debug=dict(plan_search=-1)).info
     assert cost(searched) <= cost(first)
-    monkeypatch.setenv('OPFX_PLAN_SEARCH', '3')
-    few = capi.Plan(case).info
+    few = capi.Plan(case, debug=dict(plan_search=3)).info
     assert cost(searched) <= cost(few) <= cost(first)
     small = net_to_case(grids.get_grid('1-MV-urban--0-sw')[0])
-    monkeypatch.delenv('OPFX_PLAN_SEARCH')
-    a = capi.Plan(small).info
-    monkeypatch.setenv('OPFX_PLAN_SEARCH', '0')
-    assert capi.Plan(small).info == a
+    assert capi.Plan(small, debug=dict(plan_search=-1)).info == capi.Plan(small).info
 
 
 def test_plan_structure_invariants(built_lib):
