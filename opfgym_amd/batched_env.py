@@ -902,6 +902,7 @@ class BatchedOpfEnv:
                     continue
                 key = ('trafo3w', col, int(pos))
                 if key not in self._xres:
+                    self._new_derived_row(key)
                     self._xres[key] = (len(self._xres), capi.XRES_MAX3, 2 * nb + br[0], 2 * nb + br[1], 1.0, 2 * nb + br[2], 0.0)
                 out.append(base3 + self._xres[key][0])
         elif unit == 'ext_grid':
@@ -951,6 +952,7 @@ class BatchedOpfEnv:
             for pos in self.store.rows(unit, idxs):
                 key = (unit, col, int(pos))
                 if key not in self._xres:
+                    self._new_derived_row(key)
                     sc = float(df['scaling'].iloc[pos]) if 'scaling' in df.columns else 1.0
                     kind = capi.XRES_S if col == 's_mva' else capi.XRES_P
                     psl = (q0 if col == 'q_mvar' else p0) + int(pos)
@@ -975,16 +977,24 @@ class BatchedOpfEnv:
         has_bb = sw is not None and len(sw) and any(str(v) == 'b' for v in sw['et'])
         return bool(has_bb) and len(self.net['gen']) + len(self.net['ext_grid']) > 1
 
+    def _new_derived_row(self, key):
+        """Derived rows exist in the result bank only if the compiled environment asked for them (an observation, a
+        constraint, an objective term or a cost row reads them): a request after compilation has no column to point at."""
+        if getattr(self, '_xres_frozen', False):
+            raise KeyError(f'res_{key[0]}.{key[1]} (row {key[2]}) is not in this environment\'s result bank: derived rows are '
+                           f'compiled in when an observation, constraint, objective term or cost row reads them')
+
     def _affine_row(self, key, src, a, b, bus):
         """Result index of the derived row `a + b * result[src]` (OPFX_XRES_AFFINE; 0 while `bus` is de-energised)."""
         if key not in self._xres:
+            self._new_derived_row(key)
             self._xres[key] = (len(self._xres), capi.XRES_AFFINE, int(src), int(bus), float(b), 0, float(a))
         nref = int((self.case.bus_type == REF).sum())
         return 3 * self.case.nb + self.case.nbr + 2 * nref + self._xres[key][0]
 
     def _create_env(self):
         net, c, st = self.net, self.case, self.store
-        self._xres = {}
+        self._xres, self._xres_frozen = {}, False
         nb, base = c.nb, c.base_mva
         keep = []
         d = capi.EnvDesc()
@@ -1306,6 +1316,7 @@ class BatchedOpfEnv:
             from .host_fallback import HostFinisher
             self._host_finisher = HostFinisher(self, self.host_objective, self._host_constraints, self._constraint_order)
         self.n_results = 3 * nb + c.nbr + 2 * len(ref_buses) + len(self._xres)
+        self._xres_frozen = True
         t = self.torch
         as_i = lambda v: t.as_tensor(np.asarray(v, dtype=np.int64), device=self.device)
         as_d = lambda v: t.as_tensor(np.asarray(v, dtype=np.float64), device=self.device)
@@ -1918,6 +1929,8 @@ class BatchedOpfEnv:
         """`net.res_<unit>.<col>` of the last step for all instances, [B, n_rows]
         in the row order of `net.<unit>` (NaN for de-energised elements)."""
         t = self.torch
+        if unit == 'ext_grid' or (unit == 'gen' and col == 'q_mvar'):
+            return self._generator_result_table(unit, col)
         idx = self._result_index(unit, col, self.net[unit].index)
         gather = t.as_tensor(np.where(idx < 0, 0, idx), device=self.device)
         out = self.buf['results'][:, gather]
@@ -1925,6 +1938,37 @@ class BatchedOpfEnv:
             out = out.clone()
             out[:, t.as_tensor(idx < 0, device=self.device)] = float('nan')
         return out
+
+    def _generator_result_table(self, unit, col):
+        """`res_ext_grid.p_mw / q_mvar` and `res_gen.q_mvar` from the solver's per-BUS entries of the result bank and the
+        shares of `case.generator_dispatch` (the same affine map the kernel applies in its derived rows, which exist only
+        where the compiled environment reads them): NaN for an ext_grid outside the power flow, zero for such a generator
+        or one whose bus is de-energised in the instance."""
+        t = self.torch
+        c = self.case
+        nb, nbr = c.nb, c.nbr
+        ref_buses = np.flatnonzero(c.bus_type == REF)
+        nref = len(ref_buses)
+        ordinal = {int(b): k for k, b in enumerate(ref_buses)}
+        share = self._generator_shares()[unit]
+        n = len(self.net[unit])
+        src, a, b, vm_of = np.zeros(n, np.int64), np.zeros(n), np.zeros(n), np.zeros(n, np.int64)
+        for pos in range(n):
+            i = int(share['bus'][pos])
+            if i < 0:
+                a[pos] = np.nan if unit == 'ext_grid' else 0.0
+                continue
+            vm_of[pos] = i
+            if unit == 'ext_grid' and col == 'p_mw':
+                src[pos], a[pos], b[pos] = 2 * nb + nbr + ordinal[i], 0.0, share['p_b'][pos]
+            else:
+                src[pos] = 2 * nb + nbr + nref + ordinal[i] if c.bus_type[i] == REF else 2 * nb + nbr + 2 * nref + i
+                a[pos], b[pos] = share['q_a'][pos], share['q_b'][pos]
+        res = self.buf['results']
+        dev = lambda v: t.as_tensor(v, device=self.device)
+        out = dev(a) + dev(b) * res[:, dev(src)]
+        dead = t.isnan(res[:, dev(vm_of)]) & dev(share['bus'] >= 0)          # (|V| of a de-energised bus is NaN)
+        return t.where(dead, t.zeros_like(out), out) if unit == 'gen' else out
 
     def table_column(self, unit, col):
         """Current per-instance values of a table column held in x, [B, n_rows]."""
