@@ -44,7 +44,11 @@ class BatchedPowerFlowSolver:
     def _context(self, case):
         key = (case.nb, case.nbr, case.bus_type.tobytes(), case.f.tobytes(), case.t.tobytes(),
                case.yff.tobytes(), case.yft.tobytes(), case.ytf.tobytes(), case.ytt.tobytes(),
-               case.vm_set.tobytes(), case.va_set.tobytes(), case.gs.tobytes(), case.bs.tobytes())
+               case.vm_set.tobytes(), case.va_set.tobytes(), case.gs.tobytes(), case.bs.tobytes(),
+               # (the loading factors and the DC model are part of the compiled plan too: two nets with the same admittances
+               #  and other ratings — max_i_ka, sn_mva, df, a rated voltage — must not share one; found by tests/metamorphic.py)
+               case.kf.tobytes(), case.kt.tobytes(), float(case.base_mva),
+               None if case.bdc is None else case.bdc.tobytes(), None if case.pfinj is None else case.pfinj.tobytes())
         # Compiled plans are kept per topology (most recently used last): the reference's N-1 loop
         # (security_constrained.py:44-62) toggles one element at a time and comes back to every topology
         # in every step, so each contingency is compiled once, not once per call.

@@ -41,10 +41,25 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
       PV bus, generator reactive dispatch                        tests_gen
       enforce_q_lims (PV -> PQ at the limit)                     tests_enforce_qlims
       slack P/Q (res_ext_grid)                                   docs_minimal_example
-    NOT exercised by any pandapower-originated number: the `_is_elements` zero rule of result rows,
-    bus-bus switch fusing, shunts, storages, several ext_grids, tap on the lv side, tap_phase_shifter,
-    the vector-group phase shift (calculate_voltage_angles on grids above 70 kV), DC start values,
-    lines with g_us_per_km, transformer df.
+    (These vectors are recalled from memory and were kept only where the oracle reproduced every digit: read them as
+    self-consistency pins, see the header of tests/pandapower_published.py; the ones that did not reproduce are listed there
+    and asserted as expected failures.)
+    Exercised by no recalled number, pinned by EQUIVALENCE instead (tests/metamorphic.py: two formulations that pandapower's
+    model definitions make the same problem must give the same answer — on this oracle, tests/test_metamorphic.py, and on
+    the GPU, tests/test_gpu_metamorphic.py):
+      closed bus-bus switch = one bus; open one = none          bus_bus_switch_is_one_bus, open_bus_bus_switch_is_no_switch
+      tap on the lv side / hv side = a changed rated voltage    lv_side_tap_is_a_changed_lv_rating, hv_side_tap_...
+      parallel = 2 (line, transformer) = two elements           parallel_two_is_two_elements
+      vector-group shift under calculate_voltage_angles         vector_group_shift_turns_the_angles_behind_it (144-bus grid:
+                                                                 no |V| / loading / slack power moves, angles turn by 150 deg)
+      shunt (p, q, step) = a load of p |V|^2, q |V|^2           shunt_is_a_constant_impedance_load
+      several ext_grids                                          two_ext_grids_at_one_set_point_are_a_fused_slack
+      generators sharing a bus (pfsoln's split)                 tests/test_generator_dispatch.py (by hand: shares of the ranges)
+      `_is_elements` zero rule of result rows                   tests/test_gpu_env.py::test_units_on_a_de_energised_island_cost_nothing
+      DC start values                                            the converged solution does not depend on them; iteration counts
+                                                                 against this oracle's own DC start only
+    Truly unreachable here (no number, no equivalent formulation through a pinned path): storages beyond their sign
+    convention (a negative load by definition), tap_phase_shifter, lines with g_us_per_km, transformer df.
   * the closed-form two-bus solution,
   * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
     (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to

@@ -1,0 +1,238 @@
+"""Metamorphic equivalences of the pandapower element models (test code only).
+
+VERDICT r05 #2: part of the converter and the solver is exercised by no number that pandapower published — bus-bus fusing,
+taps on the lv side, `parallel`, the vector-group shift under `calculate_voltage_angles=True` (the mode every GPU config runs
+in), shunts, several ext_grids.  Each of those has an EQUIVALENT formulation that goes through another, pinned code path:
+two nets that pandapower's own model definitions make the same electrical problem must give the same answer.  No third-party
+number is needed, and a wrong formula on one of the two paths shows up as a difference.
+
+Every case is a function returning `(net_a, net_b, compare)`; `compare(res_a, res_b)` raises on a difference, where `res_x`
+is the net after a power flow (`net.res_*` filled — by the oracle on the CPU, by the plug-in on the GPU).  The tests:
+tests/test_metamorphic.py (oracle; plus stamp-level equality of the PRODUCT's converter where the two nets must compile to
+the same admittances) and tests/test_gpu_metamorphic.py (the same pairs through `power_flow_solver(net)` = opfx_solve).
+"""
+import copy
+
+import numpy as np
+
+from opfgym_amd import grids, net as N
+
+VM_TOL, VA_TOL, LD_TOL, S_TOL = 1e-9, 1e-7, 1e-6, 1e-6      # p.u., degree, percent, MW / Mvar
+
+
+def _col(net, table, column):
+    return net[table][column].to_numpy(float)
+
+
+def _same(a, b, tol, what):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, what
+    assert np.allclose(a, b, rtol=0, atol=tol, equal_nan=True), (what, float(np.nanmax(np.abs(a - b))))
+
+
+def _angle_same(a_deg, b_deg, tol, what):
+    d = np.deg2rad(np.asarray(a_deg, float) - np.asarray(b_deg, float))
+    assert np.nanmax(np.abs(np.degrees(np.angle(np.exp(1j * d))))) < tol, what
+
+
+def _compare_all(res_a, res_b, buses_a=None, buses_b=None, lines=True, trafos=True, ext=True):
+    ba = res_a.res_bus if buses_a is None else res_a.res_bus.loc[buses_a]
+    bb = res_b.res_bus if buses_b is None else res_b.res_bus.loc[buses_b]
+    _same(ba.vm_pu, bb.vm_pu, VM_TOL, 'vm_pu')
+    _angle_same(ba.va_degree, bb.va_degree, VA_TOL, 'va_degree')
+    if lines:
+        _same(_col(res_a, 'res_line', 'loading_percent'), _col(res_b, 'res_line', 'loading_percent'), LD_TOL, 'line loading')
+    if trafos:
+        _same(_col(res_a, 'res_trafo', 'loading_percent'), _col(res_b, 'res_trafo', 'loading_percent'), LD_TOL, 'trafo loading')
+    if ext:
+        _same(_col(res_a, 'res_ext_grid', 'p_mw'), _col(res_b, 'res_ext_grid', 'p_mw'), S_TOL, 'p_ext')
+        _same(_col(res_a, 'res_ext_grid', 'q_mvar'), _col(res_b, 'res_ext_grid', 'q_mvar'), S_TOL, 'q_ext')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def bus_bus_switch_is_one_bus():
+    """A CLOSED bus-bus switch fuses its two buses: the same grid built with ONE bus in their place.  (mv-small: its best
+    connected bus gets a twin behind a closed coupler; every second line end and unit moves to the twin.)"""
+    base, _ = grids.get_grid('mv-small')
+    a = copy.deepcopy(base)
+    ends = list(a.line.from_bus) + list(a.line.to_bus)
+    bar = int(max(set(ends), key=ends.count))                          # (the best connected bus: four line ends)
+    twin = N.create_bus(a, float(a.bus.vn_kv.at[bar]))
+    for c in a.bus.columns:
+        if c != 'name':
+            a.bus.at[twin, c] = a.bus.at[bar, c]
+    moved = 0
+    for tbl, col in (('line', 'from_bus'), ('line', 'to_bus'), ('load', 'bus'), ('sgen', 'bus')):
+        for idx in a[tbl].index[a[tbl][col] == bar][::2]:
+            a[tbl].at[idx, col] = twin
+            moved += 1
+    assert moved >= 2
+    N.create_switch(a, bar, twin, 'b', closed=True)
+    N.finalize(a)
+    b = copy.deepcopy(base)                                            # (the grid as it was: `bar` is the one bus)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb, buses_a=list(b.bus.index), buses_b=list(b.bus.index))
+        assert abs(ra.res_bus.vm_pu.at[twin] - ra.res_bus.vm_pu.at[bar]) < 1e-15          # both halves report the fused bus
+        assert abs(ra.res_bus.va_degree.at[twin] - ra.res_bus.va_degree.at[bar]) < 1e-12
+    return a, b, compare
+
+
+def _two_winding_pair(**trafo_kw):
+    """110 kV slack - line - transformer - 20 kV load bus (- a second line and load), transformer parameters given."""
+    net = N.Net()
+    b0, b1, b2, b3 = N.create_bus(net, 110.), N.create_bus(net, 110.), N.create_bus(net, 20.), N.create_bus(net, 20.)
+    N.create_ext_grid(net, b0, vm_pu=1.02, va_degree=0.0)
+    N.create_line_from_parameters(net, b0, b1, 14.0, 0.06, 0.38, 9.5, 0.6)
+    kw = dict(sn_mva=40.0, vn_hv_kv=110.0, vn_lv_kv=21.0, vk_percent=12.0, vkr_percent=0.35, pfe_kw=22.0, i0_percent=0.06,
+              shift_degree=150.0)
+    kw.update(trafo_kw)
+    t = N.create_transformer_from_parameters(net, b1, b2, **kw)
+    N.create_line_from_parameters(net, b2, b3, 3.2, 0.16, 0.12, 270.0, 0.36)
+    N.create_load(net, b2, 9.0, 2.5)
+    N.create_load(net, b3, 6.5, 1.8)
+    N.create_sgen(net, b3, 2.0, -0.4)
+    return N.finalize(net), t
+
+
+def lv_side_tap_is_a_changed_lv_rating():
+    """pandapower's tap changer scales the RATED voltage of its side (`_calc_tap_from_dataframe`: vn_lv * (1 + step% * (pos -
+    neutral))) and everything downstream — ratio and the reference of the short-circuit impedance — uses the scaled rating:
+    a transformer tapped on the lv side is the untapped transformer with vn_lv_kv changed accordingly."""
+    a, t = _two_winding_pair(tap_side='lv', tap_neutral=0, tap_pos=-3, tap_step_percent=1.5)
+    b, _ = _two_winding_pair(vn_lv_kv=21.0 * (1 + 0.015 * -3))
+    # (the transformer's own loading_percent refers its current to the TABLE's rated voltage, which differs between the two
+    #  nets by construction; the currents themselves are compared through the lines on both sides and the slack power)
+    return a, b, lambda ra, rb: _compare_all(ra, rb, trafos=False)
+
+
+def hv_side_tap_is_a_changed_hv_rating():
+    a, t = _two_winding_pair(tap_side='hv', tap_neutral=0, tap_pos=4, tap_step_percent=1.25)
+    b, _ = _two_winding_pair(vn_hv_kv=110.0 * (1 + 0.0125 * 4))
+    return a, b, lambda ra, rb: _compare_all(ra, rb, trafos=False)
+
+
+def parallel_two_is_two_elements():
+    """`parallel = 2` on a line and on a transformer: two identical elements between the same buses; each carries half, so
+    the loading of the pair equals the loading of either twin."""
+    a, t = _two_winding_pair(parallel=2)
+    a.line.at[a.line.index[1], 'parallel'] = 2
+    b, _ = _two_winding_pair()
+    tr = b.trafo.iloc[0]
+    N.create_transformer_from_parameters(
+        b, int(tr.hv_bus), int(tr.lv_bus), **{k: tr[k] for k in ('sn_mva', 'vn_hv_kv', 'vn_lv_kv', 'vk_percent', 'vkr_percent',
+                                                                   'pfe_kw', 'i0_percent', 'shift_degree')})
+    ln = b.line.iloc[1]
+    N.create_line_from_parameters(b, int(ln.from_bus), int(ln.to_bus), ln.length_km, ln.r_ohm_per_km, ln.x_ohm_per_km,
+                                  ln.c_nf_per_km, ln.max_i_ka)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb, lines=False, trafos=False)
+        _same(_col(ra, 'res_trafo', 'loading_percent')[0], _col(rb, 'res_trafo', 'loading_percent')[0], LD_TOL, 'trafo pair')
+        _same(_col(rb, 'res_trafo', 'loading_percent')[0], _col(rb, 'res_trafo', 'loading_percent')[1], LD_TOL, 'trafo twins')
+        _same(_col(ra, 'res_line', 'loading_percent')[:2], _col(rb, 'res_line', 'loading_percent')[:2], LD_TOL, 'line pair')
+        _same(_col(rb, 'res_line', 'loading_percent')[1], _col(rb, 'res_line', 'loading_percent')[2], LD_TOL, 'line twins')
+    return a, b, compare
+
+
+def vector_group_shift_turns_the_angles_behind_it():
+    """BASELINE configs 2 / 4 run the 144-bus MV stand-in with `calculate_voltage_angles=True` (110 kV slack) and 150 degree
+    transformers.  A vector-group shift common to all transformers between the slack's level and a radial level below changes
+    NO voltage magnitude, loading or slack power and turns every angle behind it by exactly the shift: the same grid with
+    shift 0 and with shift 150."""
+    base, _ = grids.get_grid('1-MV-urban--0-sw')
+    a, b = copy.deepcopy(base), copy.deepcopy(base)
+    assert (a.trafo.shift_degree == 150.0).all()
+    b.trafo['shift_degree'] = 0.0
+    hv = set(int(v) for v in a.trafo.hv_bus) | set(int(v) for v in a.ext_grid.bus)
+    behind = [int(i) for i in a.bus.index if int(i) not in hv]
+
+    def compare(ra, rb):
+        _same(ra.res_bus.vm_pu, rb.res_bus.vm_pu, VM_TOL, 'vm_pu')
+        _same(_col(ra, 'res_line', 'loading_percent'), _col(rb, 'res_line', 'loading_percent'), LD_TOL, 'line loading')
+        _same(_col(ra, 'res_trafo', 'loading_percent'), _col(rb, 'res_trafo', 'loading_percent'), LD_TOL, 'trafo loading')
+        _same(_col(ra, 'res_ext_grid', 'p_mw'), _col(rb, 'res_ext_grid', 'p_mw'), S_TOL, 'p_ext')
+        _same(_col(ra, 'res_ext_grid', 'q_mvar'), _col(rb, 'res_ext_grid', 'q_mvar'), S_TOL, 'q_ext')
+        _angle_same(ra.res_bus.va_degree.loc[behind], rb.res_bus.va_degree.loc[behind] - 150.0, VA_TOL, 'shifted angles')
+        _angle_same(ra.res_bus.va_degree.loc[sorted(hv)], rb.res_bus.va_degree.loc[sorted(hv)], VA_TOL, 'hv angles')
+    return a, b, compare
+
+
+def shunt_is_a_constant_impedance_load():
+    """A shunt (p_mw, q_mvar at vn_kv, `step` of them) draws P = p step |V|^2, Q = q step |V|^2 (|V| in p.u. of vn_kv): replaced
+    by a constant-power load of exactly that size AT THE SOLVED VOLTAGE the power flow has the same solution.  Net b is built
+    from net a's results (`compare` is handed both; the builder needs a solver — see `needs_first`)."""
+    a, _ = _two_winding_pair()
+    sh_bus = int(a.bus.index[3])
+    N.create_shunt(a, sh_bus, q_mvar=-3.0, p_mw=0.4, step=2)
+    N.finalize(a)
+
+    def second(res_a):
+        b, _ = _two_winding_pair()
+        vm = float(res_a.res_bus.vm_pu.at[sh_bus])
+        N.create_load(b, sh_bus, 0.4 * 2 * vm ** 2, -3.0 * 2 * vm ** 2)
+        return N.finalize(b)
+    return a, second, lambda ra, rb: _compare_all(ra, rb)
+
+
+def two_ext_grids_at_one_set_point_are_a_fused_slack():
+    """Two ext_grids with the same |V| and angle on two (non-adjacent) buses: both buses are held at the same complex voltage,
+    so fusing them (a closed bus-bus switch, ONE ext_grid) changes nothing for the rest of the grid, and the two slack powers
+    add up to the fused one's.  (hv-small keeps its own 380 kV ext_grid: three REF buses in net a, two in net b.)"""
+    base, _ = grids.get_grid('hv-small')
+    taken = set(int(v) for v in base.gen.bus) | set(int(v) for v in base.trafo.hv_bus) | set(int(v) for v in base.trafo.lv_bus)
+    free = [int(i) for i in base.bus.index if int(i) not in taken and base.bus.vn_kv.at[i] == 110.0]
+    x = free[3]
+    near = set(int(v) for v in base.line.to_bus[base.line.from_bus == x]) | set(int(v) for v in base.line.from_bus[base.line.to_bus == x])
+    y = next(i for i in free[8:] if i not in near and i != x)
+    a = copy.deepcopy(base)
+    N.create_ext_grid(a, x, vm_pu=1.01, va_degree=-2.0)
+    N.create_ext_grid(a, y, vm_pu=1.01, va_degree=-2.0)
+    N.finalize(a)
+    b = copy.deepcopy(base)
+    N.create_ext_grid(b, x, vm_pu=1.01, va_degree=-2.0)
+    N.create_switch(b, x, y, 'b', closed=True)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _same(ra.res_bus.vm_pu, rb.res_bus.vm_pu, VM_TOL, 'vm_pu')
+        _angle_same(ra.res_bus.va_degree, rb.res_bus.va_degree, VA_TOL, 'va_degree')
+        _same(_col(ra, 'res_line', 'loading_percent'), _col(rb, 'res_line', 'loading_percent'), LD_TOL, 'line loading')
+        _same(_col(ra, 'res_trafo', 'loading_percent'), _col(rb, 'res_trafo', 'loading_percent'), LD_TOL, 'trafo loading')
+        pa, pb = _col(ra, 'res_ext_grid', 'p_mw'), _col(rb, 'res_ext_grid', 'p_mw')
+        qa, qb = _col(ra, 'res_ext_grid', 'q_mvar'), _col(rb, 'res_ext_grid', 'q_mvar')
+        _same(pa[0], pb[0], S_TOL, 'slack P of the 380 kV ext_grid')
+        _same(pa[1] + pa[2], pb[1], S_TOL, 'slack P of the pair')
+        _same(qa[0], qb[0], S_TOL, 'slack Q of the 380 kV ext_grid')
+        _same(qa[1] + qa[2], qb[1], S_TOL, 'slack Q of the pair')
+        assert abs(pa[1]) > 1e-3 and abs(pa[2]) > 1e-3
+    return a, b, compare
+
+
+def open_bus_bus_switch_is_no_switch():
+    """An OPEN bus-bus switch couples nothing: the grid without it."""
+    base, _ = grids.get_grid('hv-small')
+    a = copy.deepcopy(base)
+    N.create_switch(a, int(a.bus.index[5]), int(a.bus.index[9]), 'b', closed=False)
+    N.finalize(a)
+    return a, copy.deepcopy(base), lambda ra, rb: _compare_all(ra, rb)
+
+
+CASES = {f.__name__: f for f in (bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
+                                 parallel_two_is_two_elements, vector_group_shift_turns_the_angles_behind_it,
+                                 shunt_is_a_constant_impedance_load, two_ext_grids_at_one_set_point_are_a_fused_slack,
+                                 open_bus_bus_switch_is_no_switch)}
+# pairs that must compile to the SAME bus admittance matrix in the product's converter (no solve needed to compare them)
+SAME_ADMITTANCES = ('lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
+                    'open_bus_bus_switch_is_no_switch', 'bus_bus_switch_is_one_bus')
+
+
+def run(case, solve):
+    """Solve both nets of a case with `solve(net)` (in place: fills net.res_*) and compare."""
+    a, b, compare = CASES[case]()
+    solve(a)
+    if callable(b):
+        b = b(a)
+    solve(b)
+    compare(a, b)

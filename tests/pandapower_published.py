@@ -22,6 +22,14 @@ Sources
 
 Which element formulas each vector exercises is listed per case (`covers`) and summarised in the header of
 oracle/pf_oracle.py.
+
+HOW MUCH THIS PINS: the selection rule above makes the oracle the filter of its own pins — a vector that did
+not reproduce was dropped, not debugged against the source (which is not in this image).  Read these vectors as
+RECALLED-AND-SELF-CONSISTENT: strong evidence against a gross modelling error on the paths they cover (nine-digit agreement
+of several numbers per network does not happen by accident), not an independent reproduction of a pandapower run.  The
+vectors that did not reproduce stay visible as expected failures (`NOT_REPRODUCED`, tests/test_pandapower_published.py::
+test_recalled_constants_the_oracle_does_not_reproduce) and, where a hand calculation decides which side is wrong, say so.
+What no recalled number covers is pinned by equivalence instead: tests/metamorphic.py.
 """
 import numpy as np
 
@@ -173,12 +181,33 @@ CASES = {
 # whatever happened to agree):
 NOT_REPRODUCED = {
     'tests_trafo lv bus': 'recalled vm_pu 0.9677532 at the 0.4 kV bus; oracle 0.980003 (hv bus and loading of the same '
-                          'case reproduce to 5e-8 / 3e-4, so the constant is the doubtful part)',
+                          'case reproduce to 5e-8 / 3e-4, so the constant is the doubtful part; hand calculation below)',
     'tests_trafo_tap': 'recalled 1.010114175 / 0.924072090; the network was not recalled well enough (oracle on the '
                        'guessed one: 1.010154 / 0.970778)',
     'tests_bus_bus_switch': 'recalled 0.982265380; the network carries ward / xward elements that are not modelled here',
     'tests_ext_grid, tests_shunt': 'no constant recalled to its digits',
 }
+
+# The tapped-transformer case by hand (VERDICT r05 #2c).  20 kV buses, 0.4 kV lv bus, system base 1 MVA.  Two transformers in
+# parallel (the third is open at its lv side): sn 0.4 MVA, 22 / 0.42 kV, vk 5 %, vkr 2 %, hv tap at position 3 of neutral 5,
+# 1.25 % per step -> tap factor 1 + (3 - 5) * 0.0125 = 0.975.
+#   ratio to the bus bases: (22 * 0.975 / 0.42) / (20 / 0.4) = 51.0714 / 50 = 1.021429
+#   no-load lv voltage: |V_hv| / ratio = 1.010159 / 1.021429 = 0.98897        (|V_hv| = the published 1.010159155, reproduced)
+#   short-circuit impedance of ONE transformer on the lv bus base: 0.05 * (0.42 / 0.4)^2 * (1 / 0.4) = 0.13781 p.u.,
+#     r = 0.02 * 1.1025 * 2.5 = 0.055125, x = sqrt(0.13781^2 - 0.055125^2) = 0.12631;  two in parallel: r = 0.02756, x = 0.06316
+#   load 0.2 MW + j 0.05 Mvar = 0.2 + j 0.05 p.u.:  dV ~ (r P + x Q) / |V| = (0.005512 + 0.003158) / 0.985 = 0.00880
+#   |V_lv| ~ 0.98897 - 0.00880 = 0.9802        -> the oracle's 0.980003; the recalled 0.9677532 would need 2.4 times the
+#   voltage drop a 5 % transformer pair gives at half load: a mis-recalled constant, not an open question about the model.
+TRAFO_LV_BY_HAND = 0.9802
+
+
+def recalled_but_not_reproduced():
+    """[(label, net builder, (table, column, index getter), recalled constant)] of NOT_REPRODUCED entries whose network IS
+    recalled: asserted as EXPECTED FAILURES so that the gap stays in every test report."""
+    def trafo_lv():
+        net, checks, kw = tests_trafo()
+        return net, ('res_bus', 'vm_pu', int(net.trafo.lv_bus.iloc[0])), 0.9677532, kw
+    return [('tests_trafo lv bus', trafo_lv)]
 
 
 def evaluate(net, checks):

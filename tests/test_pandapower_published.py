@@ -29,6 +29,24 @@ def test_product_case_equals_oracle_case_on_published_networks(name):
     _compare(net)
 
 
+@pytest.mark.parametrize('label,build', pub.recalled_but_not_reproduced(), ids=[l for l, _ in pub.recalled_but_not_reproduced()])
+@pytest.mark.xfail(strict=True, reason='a recalled constant the oracle does not reproduce (pandapower_published.NOT_REPRODUCED): '
+                                       'kept visible; the hand calculation in that file sides with the oracle')
+def test_recalled_constants_the_oracle_does_not_reproduce(label, build):
+    from oracle import pf_oracle as po
+    net, (tbl, col, idx), recalled, kw = build()
+    po.runpp(net, **kw)
+    assert abs(float(net[tbl].loc[idx, col]) - recalled) <= pub.V_TOL
+
+
+def test_the_hand_calculation_of_the_tapped_transformer_sides_with_the_oracle():
+    from oracle import pf_oracle as po
+    net, (tbl, col, idx), recalled, kw = pub.recalled_but_not_reproduced()[0][1]()
+    po.runpp(net, **kw)
+    got = float(net[tbl].loc[idx, col])
+    assert abs(got - pub.TRAFO_LV_BY_HAND) < 5e-4 < abs(recalled - pub.TRAFO_LV_BY_HAND)
+
+
 def test_every_case_names_source_and_coverage():
     for name, (fn, source, covers) in pub.CASES.items():
         assert source in ('DOCS', 'TESTS') and covers
