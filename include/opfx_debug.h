@@ -52,6 +52,10 @@ typedef struct opfx_debug_opts {
                               * opfx_plan_info.n_shared): less LDS per instance, for the wave-team kernels with full Newton only.
                               * 0 (default): every block keeps a slot of its own.  opfgym_amd.BatchedOpfEnv builds such a plan
                               * where it lets a CU hold a third instance of the grid */
+  /* ---- context, appended in round 6 ---------------------------------------------------------------------------- */
+  int32_t no_rank1_dc;       /* 1: every N-1 contingency that starts from a DC power flow runs its own DC pass through the block-LU
+                              * schedule (round 5's path) instead of the rank-1 update of the base case's DC angles (A/B runs, and the
+                              * tests of the fallback that a base case with modifiers takes anyway) */
 } opfx_debug_opts;
 
 int opfx_plan_create_debug(const opfx_case* c, const opfx_debug_opts* dbg, opfx_plan** out);

@@ -165,7 +165,7 @@ class DebugOpts(Sized):
         'plan_search', 'plan_dcap_slack', 'plan_seed', 'plan_no_bank', 'plan_no_pack', 'plan_no_riders', 'plan_no_tail',
         'plan_no_pairs',
         'team', 'queue', 'packed', 'force_mem', 'kernel_v1', 'waves_per_cu', 'verbose', 'stamps',
-        'reset_team', 'plan_share_slots')]
+        'reset_team', 'plan_share_slots', 'no_rank1_dc')]
 
     def any(self):
         return any(getattr(self, n) for n, _ in self._fields_ if n != 'struct_size')
@@ -230,6 +230,7 @@ def debug_from_env(environ=None) -> DebugOpts:
     d.verbose, d.stamps = flag('OPFX_VERBOSE'), flag('OPFX_STAMPS')
     d.reset_team = int(e.get('OPFX_RESET_TEAM') or 0)
     d.plan_share_slots = int(e.get('OPFX_PLAN_SHARE') or 0)
+    d.no_rank1_dc = flag('OPFX_NO_RANK1_DC')
     return d
 
 

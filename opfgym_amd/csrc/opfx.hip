@@ -584,6 +584,64 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
     for (size_t i = 0; i < ncel; ++i) if (d->con_src[i] >= nb && d->con_src[i] < 2 * nb) E.need_angle = 1;
   }
   PUTN(cont_branch, d->cont_branch, d->n_cont);
+  E.cont_dc_w = nullptr; E.cont_dc_k = nullptr;
+  if (rc == OPFX_OK && d->n_cont > 0 && !p.br_bdc.empty() && nb <= 1536) {
+    // DC start of the contingencies by a rank-1 update (k_step): B' of the compiled grid (pypower makeBdc, the free buses),
+    // factorised ONCE here on the host — it is the same matrix for every instance and step —, then w = B'^-1 u per
+    // contingency (f, t), u = e_f - e_t on the free buses, and 1 / (1 - b u'w); 0 there marks a contingency that keeps
+    // its own DC pass (no DC model of the branch, or a bridge: 1 - b u'w = 0 is the islanding case)
+    std::vector<int> pos(nb, -1);
+    int nf = 0;
+    for (int i = 0; i < nb; ++i) if (p.bus_type[i] != OPFX_REF) pos[i] = nf++;
+    std::vector<double> B((size_t)nf * nf, 0.0);
+    for (int k = 0; k < p.nbr; ++k) {
+      const double b = p.br_bdc[k];
+      if (b == 0.0) continue;
+      const int f = pos[p.br_f[k]], t = pos[p.br_t[k]];
+      if (f >= 0) B[(size_t)f * nf + f] += b;
+      if (t >= 0) B[(size_t)t * nf + t] += b;
+      if (f >= 0 && t >= 0) { B[(size_t)f * nf + t] -= b; B[(size_t)t * nf + f] -= b; }
+    }
+    // dense LU with partial pivoting (nf <= 1536: at most a few 1e9 flops, once per environment)
+    std::vector<int> perm(nf);
+    bool regular = true;
+    for (int i = 0; i < nf; ++i) perm[i] = i;
+    for (int c = 0; c < nf && regular; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < nf; ++r) if (std::fabs(B[(size_t)r * nf + c]) > std::fabs(B[(size_t)piv * nf + c])) piv = r;
+      if (std::fabs(B[(size_t)piv * nf + c]) < 1e-12) { regular = false; break; }
+      if (piv != c) { for (int j = 0; j < nf; ++j) std::swap(B[(size_t)c * nf + j], B[(size_t)piv * nf + j]); std::swap(perm[c], perm[piv]); }
+      const double inv = 1.0 / B[(size_t)c * nf + c];
+      for (int r = c + 1; r < nf; ++r) {
+        const double m = B[(size_t)r * nf + c] * inv;
+        if (m == 0.0) continue;
+        B[(size_t)r * nf + c] = m;
+        double* rr = &B[(size_t)r * nf];
+        const double* rc_ = &B[(size_t)c * nf];
+        for (int j = c + 1; j < nf; ++j) rr[j] -= m * rc_[j];
+      }
+    }
+    if (regular) {
+      std::vector<double> W((size_t)d->n_cont * nb, 0.0), K((size_t)d->n_cont * 4, 0.0), y(nf);
+      for (int c = 0; c < d->n_cont; ++c) {
+        const int br = d->cont_branch[c];
+        if (br < 0 || br >= p.nbr) continue;
+        const double b = p.br_bdc[br];
+        const int f = pos[p.br_f[br]], t = pos[p.br_t[br]];
+        if (b == 0.0 || (f < 0 && t < 0)) continue;
+        for (int i = 0; i < nf; ++i) { const int src = perm[i]; y[i] = (src == f ? 1.0 : 0.0) - (src == t ? 1.0 : 0.0); }
+        for (int i = 0; i < nf; ++i) { double v = y[i]; const double* r = &B[(size_t)i * nf]; for (int j = 0; j < i; ++j) v -= r[j] * y[j]; y[i] = v; }
+        for (int i = nf - 1; i >= 0; --i) { double v = y[i]; const double* r = &B[(size_t)i * nf]; for (int j = i + 1; j < nf; ++j) v -= r[j] * y[j]; y[i] = v / r[i]; }
+        const double s_ = (f >= 0 ? y[f] : 0.0) - (t >= 0 ? y[t] : 0.0);
+        const double den = 1.0 - b * s_;
+        if (std::fabs(den) < 1e-9) continue;
+        for (int i = 0; i < nb; ++i) if (pos[i] >= 0) W[(size_t)c * nb + i] = y[pos[i]];
+        K[(size_t)c * 4] = b; K[(size_t)c * 4 + 1] = p.br_pfinj[br]; K[(size_t)c * 4 + 2] = 1.0 / den;
+      }
+      if (rc == OPFX_OK) rc = A.put(W, &E.cont_dc_w);
+      if (rc == OPFX_OK) rc = A.put(K, &E.cont_dc_k);
+    }
+  }
   {
     std::vector<int32_t> kind(d->na, OPFX_ACT_CONTINUOUS);
     if (d->act_kind) kind.assign(d->act_kind, d->act_kind + d->na);
@@ -772,6 +830,9 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   rc = ensure_scratch(env->ctx, grid, env->de.n_cont > 0);
   if (rc != OPFX_OK) return rc;
   dp.pq = env->ctx->pq; dp.warm = env->ctx->warm;
+  // (contingencies that start from a DC power flow of their own take it from the base case's by a rank-1 update where the
+  //  environment holds the tables: the scratch row then keeps the base case's DC angles, see k_step)
+  dp.theta0 = (env->de.cont_dc_w && o.init == OPFX_INIT_DC && o.contingency_start == 1 && env->ctx->dbg.no_rank1_dc == 0) ? env->ctx->warm : nullptr;
   dp.queue = env->queue;
   if ((s.queued = use_queue(env->ctx->dbg, B, grid, team))) HIP_TRY(hipMemsetAsync(env->queue, 0, sizeof(int), static_cast<hipStream_t>(stream)));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * team), env->lds_bytes, static_cast<hipStream_t>(stream),

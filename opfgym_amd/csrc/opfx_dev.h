@@ -114,6 +114,8 @@ struct DevPlan {
   double* blk_mem;           // memory-resident kernels: [resident workgroups][blk_mem_stride] LU block values
   long long blk_mem_stride;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
+  double* theta0;            // the same rows used for the base case's DC angles instead (launches whose contingencies start from
+                             // a DC power flow of their own, derived from the base case's by a rank-1 update: cont_dc_*), or nullptr
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
   int* queue;                // work queue of the step kernel: instances handed out beyond the first one per workgroup
 };
@@ -154,6 +156,9 @@ struct DevEnv {
   const int* con_worst;
   const double *con_min, *con_max, *con_autoscale, *con_pfac, *con_ppow, *con_cpen;
   const int *cont_branch;
+  // DC start of the N-1 contingencies by a rank-1 update of the base case's DC power flow (opfx_env_create): per contingency
+  // w = B'^-1 (e_f - e_t) [nb] and {b, Pfinj, 1 / (1 - b (w_f - w_t)), -}; nullptr: every contingency runs its own DC pass
+  const double *cont_dc_w, *cont_dc_k;
 };
 
 struct SolveIO {
@@ -1410,7 +1415,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       double dth, dvm;
       solve_pivot(L, i, dth, dvm, piv, pbus);
       // (the DC pass solved for the ANGLE itself: turn the start voltage by the difference to its start angle, |V| stays)
-      if (DC && dc_pass) { dth -= P.va_set[i]; dvm = 0.0; }
+      if (DC && dc_pass) { if (P.theta0) st_at(P.theta0 + (size_t)blockIdx.x * 2 * P.nb, (unsigned)i, dth); dth -= P.va_set[i]; dvm = 0.0; }
       const double sc = 1.0 + dvm;
       // (the polar shadow of this lane's buses, see Polar; a step past |V| = 0 — 1 + d|V|/|V| < 0 — turns V by pi)
       if (POLAR) { pol->th[r] += sc < 0.0 ? dth + M_PI : dth; pol->vm[r] *= fabs(sc); }
@@ -1688,7 +1693,7 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
       double dth, dvm;
       solve_pivot(L, i, dth, dvm, piv, pbus);
       // (the DC pass solved for the ANGLE itself: turn the start voltage by the difference to its start angle, |V| stays)
-      if (DC && dcp) { dth -= P.va_set[i]; dvm = 0.0; }
+      if (DC && dcp) { if (P.theta0) st_at(P.theta0 + (size_t)blockIdx.x * 2 * nb, (unsigned)i, dth); dth -= P.va_set[i]; dvm = 0.0; }
       const double sc = 1.0 + dvm;
       double sn, cs;
       if (fabs(dth) <= 0.25) {                         // (as in newton2: Taylor series, truncation error < 1e-21)
@@ -3086,17 +3091,50 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
         for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); L.vr[i] = ld_at(wv, io_); L.vi[i] = ld_at(wv, (unsigned)nb + io_); }
       }
+      // A contingency that starts from a DC power flow of its own (init = DC, contingency_start = 1: what the reference does,
+      // security_constrained.py:53) — B' is the SAME matrix for every instance and every step, and the outage of branch
+      // (f, t) is a rank-1 change of it: with w = B'^-1 (e_f - e_t), computed once per grid and contingency on the host,
+      // Sherman-Morrison gives theta_c = theta_0 + w (Pfinj + b (theta_0f - theta_0t)) / (1 - b (w_f - w_t)) from the BASE
+      // case's DC angles theta_0 (kept in the workgroup's scratch row by the base case's DC pass): one pass over the buses
+      // instead of a factorisation and two substitutions through the block-LU schedule per contingency.  Only on the compiled
+      // topology (no modifier in the base case, nothing islanded); otherwise the solve runs its own DC pass as before.
+      bool dc_rank1 = false;
+      if (DC && !MEM && V2 && !NOMOD && c > 0 && o.init == OPFX_INIT_DC && o.contingency_start == 1 && P.theta0 != nullptr
+          && E.cont_dc_w != nullptr && n_mod_base == 0 && isl == 0 && conv0) {
+        const double* const rec = E.cont_dc_k + 4 * (size_t)(c - 1);
+        const double inv_d = rec[2];
+        if (inv_d != 0.0) {
+          dc_rank1 = true;
+          const double* const th0 = P.theta0 + (size_t)blockIdx.x * 2 * nb;
+          const int f = P.br_f[out_br], t = P.br_t[out_br];
+          const double thf = L.bt[f] == BT_REF ? P.va_set[f] : ld_at(th0, (unsigned)f);
+          const double tht = L.bt[t] == BT_REF ? P.va_set[t] : ld_at(th0, (unsigned)t);
+          const double alpha = (rec[1] + rec[0] * (thf - tht)) * inv_d;
+          const double* const w = E.cont_dc_w + (size_t)(c - 1) * nb;
+          for (int i = tid; i < nb; i += NT) {
+            if (L.bt[i] == BT_REF) continue;
+            const unsigned io_ = opaque((unsigned)i);
+            const double dth = ld_at(th0, io_) + alpha * ld_at(w, io_) - P.va_set[i];     // (turn the start voltage, as the DC pass's phase D)
+            double sn, cs;
+            sincos(dth, &sn, &cs);
+            const double vr = L.vr[i], vi = L.vi[i];
+            L.vr[i] = vr * cs - vi * sn;
+            L.vi[i] = vr * sn + vi * cs;
+          }
+        }
+      }
       blk_sync<NW>();
       int iters; double nrm;
       OPFX_STAMP_RESET();
-      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD, SPEC, POLAR>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl, &pol, c > 0 && o.contingency_start == 0);
+      const bool conv = solve_instance<V2, NW, DC, MEM, CHORD, SPEC, POLAR>(P, L, o, lane, out_br, n_mod, E.qg_min, E.qg_max, &iters, &nrm, &min_piv, &min_piv_bus, isl, &pol, (c > 0 && o.contingency_start == 0) || dc_rank1);
       iters_all += iters;
       blk_sync<NW>();
       OPFX_STAMP(5);
       if (c == 0) {
         conv0 = conv; iters0 = iters; nrm0 = nrm;
         if (!conv) break;
-        if (!NOMOD && E.n_cont > 0) {
+        if (P.theta0) __builtin_amdgcn_s_waitcnt(0);      // (the DC angles the base case's DC pass stored: read by other lanes below)
+        if (!NOMOD && E.n_cont > 0 && o.contingency_start == 0) {      // (the row holds the base case's DC angles otherwise)
           double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
           for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
           __builtin_amdgcn_s_waitcnt(0);      // written and read back by the same threads (the same bus -> thread map)

@@ -406,6 +406,33 @@ def test_reference_faithful_n_minus_one_follows_the_reference_iteration_for_iter
 
 
 @pytest.mark.parametrize('name,B', [('sc_hv_small', 24), ('sc_vc_hv_urban', 6)])
+def test_rank_one_dc_start_of_the_contingencies_equals_their_own_dc_pass(name, B):
+    """`reference_faithful=True`: every contingency starts from the DC power flow of the grid without its branch
+    (security_constrained.py:53 -> a fresh runpp -> pandapower's init='dc').  B' is one matrix per grid, the outage a rank-1
+    change of it: the kernel takes theta_c from the base case's DC angles by Sherman-Morrison with host-computed
+    w = B'^-1 (e_f - e_t) (opfx_env_create) instead of running a DC pass through the block-LU schedule per contingency
+    (`debug=dict(no_rank1_dc=1)`: round 5's path).  Same start to rounding: the same Newton iterations in every solve of
+    every row, the same results — on the single-wave kernel (40 buses) and on the teams of four (372 buses, 250
+    contingencies).  The oracle's counts: test_reference_faithful_n_minus_one_follows_the_reference_iteration_for_iteration."""
+    rng = np.random.default_rng(35)
+    actions = rng.random((B, product_env(name, defer_device=True).n_actions))
+    out = {}
+    for mode, dbg in (('rank1', None), ('own_pass', dict(no_rank1_dc=1))):
+        env = product_env(name, batch_size=B, reference_faithful=True, debug=dbg)
+        assert env.init == 'dc' and env.solve_opts.contingency_start == 1
+        env.reset(options={'step': np.random.default_rng(36).choice(env.train_steps, B)})
+        obs, reward, term, trunc, info = env.step(actions)
+        assert _np(info['converged']).all()
+        out[mode] = (_np(info['total_iterations']).copy(), _np(info['iterations']).copy(), _np(reward).copy(),
+                     _np(info['violations']).copy(), _np(obs).copy())
+        env.close()
+    a, b = out['rank1'], out['own_pass']
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all(), (a[0], b[0])
+    assert np.allclose(a[2], b[2], rtol=1e-9, atol=1e-7) and np.allclose(a[3], b[3], rtol=1e-6, atol=1e-6)
+    assert np.allclose(a[4], b[4], rtol=0, atol=1e-7, equal_nan=True)
+
+
+@pytest.mark.parametrize('name,B', [('sc_hv_small', 24), ('sc_vc_hv_urban', 6)])
 def test_dc_start_leaves_the_warm_start_of_the_contingencies_alone(name, B):
     """with `init='dc'` and the DEFAULT `contingency_start='base_case'` a contingency starts from the
     base case's solution; the DC pass belongs to solves that start from the compiled voltages only (the base case here) —
