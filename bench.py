@@ -386,7 +386,7 @@ def roofline_of(env, config, B, kernel_ms, mean_it_total, solves_per_step, devic
         (f',SPEC={ki["spec"]}' if not chord else '') + \
         (',MINW=3' if not chord and ki['waves_per_instance'] * ki['instances_per_cu'] > 8 and not (dc and team == 1) else '') + '>'    # (the instantiation compiled for three wavefronts per SIMD)
     # what the launch really has to read and write: the instance rows of the caller's buffers
-    buffer_io = {'read': int(B * 8 * (env.nx + env.n_actions)),
+    buffer_io = {'read': int(B * 8 * (ki.get('x_columns_read', env.nx) + env.n_actions)),      # (the row up to the last column the step names)
                  'write': int(B * (sum(v[0].numel() * v.element_size() for v in env.buf.values()) + 8 * env.n_actions))}
     roof = {
         'bound': bound, 'achieved': fr[bound]['achieved'], 'peak': fr[bound]['peak'], 'unit': fr[bound]['unit'],

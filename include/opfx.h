@@ -602,6 +602,12 @@ int opfx_env_get_storage(const opfx_env* env, int32_t* n_blk, int32_t* n_four_va
  * plain and with the DC start; the chord-step and memory-resident kernels and the first-generation fallback are not
  * specialised.) */
 int opfx_env_get_spec(const opfx_env* env, int32_t* spec);
+/* (0.3.1) How much of an instance's row x[b, 0 .. nx) opfx_step reads: the columns [0, *columns_read) — up to the last one a
+ * descriptor of the environment names (injections, actuators and their limits, observations, prices, state columns).
+ * opfx_reset writes the whole row.  A caller that keeps columns per instance which the step never looks at (intermediates of
+ * its reset programme, limit columns of units that are no actuators) saves their HBM traffic by laying them out LAST
+ * (opfgym_amd.BatchedOpfEnv does). */
+int opfx_env_get_row_io(const opfx_env* env, int32_t* columns_read);
 
 #ifdef __cplusplus
 }

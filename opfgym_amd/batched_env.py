@@ -510,6 +510,15 @@ class BatchedOpfEnv:
         self.store.slot('gen', 'p_mw')
         # sampling programme first: it decides which columns are per-instance
         self._build_sampling()
+        # ... and once more with the columns the STEP never reads laid out last (intermediates of the reset programme such
+        # as sgen.max_p_mw of voltage_control.py:123-125, limit columns of nothing that acts): opfx_step stages the row up
+        # to the last column a descriptor names (opfx_env_get_row_io), what lies behind stays in HBM
+        order = sorted(self.store.ranges, key=lambda k: (k not in self._step_columns(), self.store.ranges[k][0]))
+        if order != sorted(self.store.ranges, key=lambda k: self.store.ranges[k][0]):
+            self.store = ColumnStore(net)
+            for tbl, col in order:
+                self.store.slot(tbl, col)
+            self._build_sampling()
         self.n_actions = int(sum(len(idxs) for _, _, idxs in self.act_keys))
         # spaces of ONE instance (opf_env.py:124-130)
         self.observation_space = get_obs_and_state_space(net, self.obs_keys, add_time_obs, add_mean_obs,
@@ -689,6 +698,17 @@ class BatchedOpfEnv:
     # ------------------------------------------------------------------ sampling
     def _sampling_ops(self, ops: OpsBuilder) -> None:
         """Hook for the benchmark environments' `_sampling` tails."""
+
+    def _step_columns(self):
+        """(table, column) pairs that a descriptor of the step may name: bus injections, actuators with their range and clamp
+        columns, table observations, prices, per-instance voltage set-points.  Every other per-instance column is only
+        written by the reset (and readable through `table_column`)."""
+        hot = {(t, c) for t in ('load', 'sgen', 'storage') for c in ('p_mw', 'q_mvar')} | {('gen', 'p_mw'), ('ext_grid', 'vm_pu'), ('gen', 'vm_pu')}
+        for unit, col, _ in self.act_keys:
+            hot |= {(unit, col)} | {(unit, pre + col) for pre in ('min_', 'max_', 'min_min_', 'max_max_')}
+        hot |= {(unit, col) for unit, col, _ in self.obs_keys if not unit.startswith('res_')}
+        hot |= {(t, c) for (t, c) in self.store.ranges if t in ('poly_cost', 'pwl_cost')}
+        return hot
 
     def _build_sampling(self):
         self.ops = OpsBuilder(self.store)
@@ -2021,7 +2041,13 @@ class BatchedOpfEnv:
         capi.check(capi.lib().opfx_env_get_spec(self._env_handle, C.byref(spec)), 'opfx_env_get_spec')
         return dict(waves_per_instance=team.value, lds_bytes_per_instance=lds.value, instances_per_cu=per_cu.value,
                     packed=nfour.value < nblk.value, n_blk=nblk.value, n_four_value=nfour.value,
-                    spec=spec.value, shared_slots=bool(self.plan.info['n_shared']), debug=self.debug.as_dict())          # (SPEC bits of the plain step kernel: 1 no PV bus, 2 no modifiers)
+                    spec=spec.value, shared_slots=bool(self.plan.info['n_shared']), debug=self.debug.as_dict(),
+                    x_columns=self.store.n, x_columns_read=self._x_columns_read())          # (SPEC bits of the plain step kernel: 1 no PV bus, 2 no modifiers)
+
+    def _x_columns_read(self):
+        n = C.c_int32()
+        capi.check(capi.lib().opfx_env_get_row_io(self._env_handle, C.byref(n)), 'opfx_env_get_row_io')
+        return n.value
 
     MAX_RESCUE_PLANS = 8
 

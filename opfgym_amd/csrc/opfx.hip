@@ -685,6 +685,24 @@ extern "C" int opfx_env_create(opfx_ctx* ctx, const opfx_env_desc* d_in, opfx_en
     if (rc == OPFX_OK) rc = A.put(ps, &E.xres_p);
     if (rc == OPFX_OK) rc = A.put(qs, &E.xres_q);
   }
+  {
+    // the columns the step kernel reads: everything a descriptor names (the reset kernel owns the whole row)
+    int hot = 0;
+    auto see = [&](int32_t slot) { if (slot >= 0 && slot < d->nx) hot = std::max(hot, slot + 1); };
+    for (size_t q = 0; q < np_; ++q) see(d->pinj_slot[q]);
+    for (size_t q = 0; q < nq_; ++q) see(d->qinj_slot[q]);
+    for (int k = 0; k < d->na; ++k) {
+      see(d->act_slot[k]); see(d->act_lo_slot[k]); see(d->act_hi_slot[k]);
+      if (d->clamp_enabled) { see(d->clamp_lo_slot[k]); see(d->clamp_hi_slot[k]); }
+    }
+    for (size_t r = 0; r < ncost; ++r) { if (d->cost_kind[r] == OPFX_COST_UNIT) see(d->cost_pidx[r]); if (d->cost_kind[r] != OPFX_COST_EXT_GRID) see(d->cost_qidx[r]); }
+    for (int k = 0; k < d->nprice; ++k) see(d->price_slot[k]);
+    for (int k = 0; k < d->nobs; ++k) if (d->obs_kind[k] == OPFX_SRC_X) see(d->obs_idx[k]);
+    if (d->vset_slot) for (int i = 0; i < nb; ++i) see(d->vset_slot[i]);
+    for (int k = 0; k < d->n_xres; ++k) if (d->xres_kind[k] == OPFX_XRES_P || d->xres_kind[k] == OPFX_XRES_S) { see(d->xres_p[k]); see(d->xres_q[k]); }
+    for (int m = 0; m < d->n_bmod; ++m) see(d->bmod_slot[m]);
+    E.nx_hot = hot;
+  }
   E.n_qterm = d->n_qterm;
   if (d->n_qterm > 0) {
     for (int k = 0; k < d->n_qterm; ++k)
@@ -900,6 +918,12 @@ extern "C" int opfx_env_get_spec(const opfx_env* env, int32_t* spec) {
     if (env->ctx->plan.nb > WAVE * POLAR_R && !env_three_teams_of_four(env)
         && pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0) == 1) *spec &= ~SPEC_NO_MOD;      // (as do_step)
   }
+  return OPFX_OK;
+}
+
+extern "C" int opfx_env_get_row_io(const opfx_env* env, int32_t* columns_read) {
+  if (!env) { opfx_set_error("opfx_env_get_row_io: null environment"); return OPFX_ERR_INVALID; }
+  if (columns_read) *columns_read = env->de.nx_hot;
   return OPFX_OK;
 }
 

@@ -121,6 +121,7 @@ struct DevPlan {
 };
 
 struct DevEnv {
+  int nx_hot;                // columns [0, nx_hot) of the row are all the step kernel reads (opfx_env_create); the rest stays in HBM
   int nx, na, npoly, npwl, nseg, nc, nobs, nres, ncost, ncost_pre;
   int nblk_d;                // doubles reserved for [LU blocks | result bank | staged table row beyond rhs]
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
@@ -2835,7 +2836,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     OPFX_STAMP(15);
     // ---- stage the row ------------------------------------------------------------
     OPFX_REP(0) {
-      const int nx = E.nx;
+      // (only the columns a descriptor of this environment names — the caller lays the columns it merely KEEPS per
+      //  instance, e.g. intermediates of the reset programme, behind them: VERDICT r05 #5, HBM reads of config 2 -24 %)
+      const int nx = E.nx_hot;
       int q = tid;
       for (; q + 7 * NT < nx; q += 8 * NT) {
         double t[8];

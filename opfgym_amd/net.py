@@ -98,17 +98,20 @@ def _append(net, table: str, row: dict, index=None) -> int:
     df = net[table]
     if index is None:
         index = 0 if len(df) == 0 else int(df.index.max()) + 1
-    # rows are collected as objects (`finalize` gives the columns their dtypes).  The frame is enlarged through `.loc` on
-    # columns that are ALL of dtype object already: pandas then appends in place of guessing a dtype for all-missing
-    # entries (the deprecated path), and no Python loop walks the existing cells (the cell-by-cell rebuild
-    # made 2 000 `create_bus` calls take a minute)
-    if any(dt != object for dt in df.dtypes):
-        df = df.astype(object)
-    for c in row:
-        if c not in df.columns:
-            df[c] = pd.Series([np.nan] * len(df), index=df.index, dtype=object)
-    df.loc[index] = [row.get(c, np.nan) for c in df.columns]
-    net[table] = df
+    # rows are collected as objects (`finalize` gives the columns their dtypes).  The frame is rebuilt from one object
+    # array per column — existing values copied by numpy, the new one appended — rather than enlarged through `.loc`:
+    # pandas' enlargement concatenates and guesses a dtype for all-missing entries (deprecated), and a cell-by-cell
+    # rebuild in Python made 2 000 `create_bus` calls take a minute
+    keep = np.asarray(df.index != index) if len(df) else np.zeros(0, bool)          # (an existing index is overwritten)
+    cols = list(df.columns) + [c for c in row if c not in df.columns]
+    data = {}
+    for c in cols:
+        old = df[c].to_numpy(dtype=object)[keep] if c in df.columns else np.full(int(keep.sum()), np.nan, dtype=object)
+        col = np.empty(len(old) + 1, dtype=object)
+        col[:-1] = old
+        col[-1] = row.get(c, np.nan)
+        data[c] = col
+    net[table] = pd.DataFrame(data, index=list(df.index[keep]) + [index], columns=cols)
     return index
 
 

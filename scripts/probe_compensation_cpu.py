@@ -35,7 +35,7 @@ def update(v, dx, pv, pq):
     return vm * np.exp(1j * va)
 
 res = {'newton': [], 'frozen_k': [], 'frozen_0': [], 'f0': []}
-for s in steps:
+for s in (steps if "--fixed-jacobian" in sys.argv else []):
     orc.reset(int(s))
     a = rng.random(env.n_actions)
     net = orc.net
@@ -78,7 +78,63 @@ for s in steps:
         res['f0'].append(f0)
         n_done += 1
     print('instance', s, 'contingencies', n_done, flush=True)
-for k in ('newton', 'frozen_k', 'frozen_0'):
+for k in (("newton", "frozen_k", "frozen_0") if res["newton"] else ()):
     a = np.array(res[k])
     print(k, 'mean', a.mean().round(2), 'median', np.median(a), 'p90', np.percentile(a, 90), 'max', a.max(), 'hist', np.bincount(np.minimum(a, 20)).tolist())
-print('initial mismatch: median', np.median(res['f0']), 'max', np.max(res['f0']))
+if res['f0']: print('initial mismatch: median', np.median(res['f0']), 'max', np.max(res['f0']))
+
+
+# ---- (d) full Newton from the base case's solution with the ANGLES moved by the DC (LODF) prediction of the outage ------------
+def dc_predictor_experiment():
+    """theta_start = theta_base + alpha w,  w = B'^-1 (e_f - e_t),  alpha = b (theta_f - theta_t) / (1 - b (w_f - w_t)) with the base
+    case's AC angles: the rank-1 update of the DC power flow applied as a PREDICTOR to the AC solution (|V| kept)."""
+    out = {'newton': [], 'predicted': [], 'f0': [], 'f0_pred': []}
+    for s in steps:
+        orc.reset(int(s))
+        a = np.random.default_rng(int(s)).random(env.n_actions)
+        net = orc.net
+        env_oracle.apply_actions(net, orc.act_keys, a, autoscale=True)
+        ppc = pd2ppc.build_ppc(net)
+        sol = po.solve(ppc, enforce_q_lims=True)
+        v0 = sol['V']; bt = sol['bus_type']
+        pv = np.flatnonzero(bt == po.PV); pq = np.flatnonzero(bt == po.PQ)
+        free = np.r_[pv, pq]; free.sort()
+        sbus = po.make_sbus(ppc)
+        bdc = (ppc.status > 0) / ppc.x / ppc.tap
+        nl, nb = ppc.nbr, ppc.nb
+        cft = sp.csr_matrix((np.r_[np.ones(nl), -np.ones(nl)], (np.r_[np.arange(nl), np.arange(nl)], np.r_[ppc.f, ppc.t])), (nl, nb))
+        bbus = (cft.T @ sp.diags(bdc) @ cft).tocsc()
+        lu = splu(bbus[free][:, free].tocsc())
+        posf = -np.ones(nb, int); posf[free] = np.arange(len(free))
+        for k in range(nl):
+            if ppc.br_table[k] != 'line':
+                continue
+            st = ppc.status.copy(); st[k] = 0
+            if not pd2ppc.supplied_buses(ppc, st).all():
+                continue
+            yk = po.make_ybus(ppc, st)
+            f, t, b = int(ppc.f[k]), int(ppc.t[k]), bdc[k]
+            u = np.zeros(len(free))
+            if posf[f] >= 0: u[posf[f]] += 1.0
+            if posf[t] >= 0: u[posf[t]] -= 1.0
+            w = lu.solve(u)
+            th = np.angle(v0)
+            alpha = b * (th[f] - th[t]) / (1.0 - b * (u @ w))
+            va = th.copy(); va[free] += alpha * w
+            v_pred = np.abs(v0) * np.exp(1j * va)
+            for key, vs in (('newton', v0), ('predicted', v_pred)):
+                v = vs.copy(); it = 0
+                while np.abs(mism(yk, sbus, v, pv, pq)).max() >= 1e-8 and it < 30:
+                    dx = splu(jac(yk, v, pv, pq)).solve(-mism(yk, sbus, v, pv, pq)); v = update(v, dx, pv, pq); it += 1
+                out[key].append(it)
+            out['f0'].append(np.abs(mism(yk, sbus, v0, pv, pq)).max())
+            out['f0_pred'].append(np.abs(mism(yk, sbus, v_pred, pv, pq)).max())
+    for key in ('newton', 'predicted'):
+        a = np.array(out[key])
+        print('DC predictor:', key, 'mean', a.mean().round(3), 'hist', np.bincount(a).tolist())
+    print('initial mismatch: base-case start median', np.median(out['f0']).round(3), 'max', np.max(out['f0']).round(2),
+          '| predicted start median', np.median(out['f0_pred']).round(3), 'max', np.max(out['f0_pred']).round(2))
+
+
+from oracle import env_oracle  # noqa: E402
+dc_predictor_experiment()
