@@ -278,7 +278,7 @@ def source_sha16():
     taken from another state of the sources are not mixed into a line."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h'):      # (kernels + plan compiler)
+    for rel in ('opfgym_amd/csrc/opfx_dev.h', 'opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h'):      # (kernels, host side, plan compiler)
         h.update(open(os.path.join(ROOT, rel), 'rb').read())
     return h.hexdigest()[:16]
 

@@ -608,6 +608,11 @@ int opfx_env_get_spec(const opfx_env* env, int32_t* spec);
  * its reset programme, limit columns of units that are no actuators) saves their HBM traffic by laying them out LAST
  * (opfgym_amd.BatchedOpfEnv does). */
 int opfx_env_get_row_io(const opfx_env* env, int32_t* columns_read);
+/* (0.3.1) Allocate the context's per-workgroup scratch rows for launches of up to B instances NOW.  Without it the first
+ * opfx_step / opfx_reset (and any later one with a larger launch grid) allocates them itself: a synchronising hipMalloc on
+ * the hot path, which must not happen inside a stream capture and belongs outside a timed region.  (The block-value rows of
+ * the memory-resident kernels, grids past the LDS, are still allocated by their first launch.) */
+int opfx_env_prepare(opfx_env* env, int64_t B);
 
 #ifdef __cplusplus
 }

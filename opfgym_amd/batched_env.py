@@ -455,6 +455,8 @@ class BatchedOpfEnv(DescriptorCompiler, TopologyMixin):
         nc = max(1, self.n_device_constraints)      # (host constraints get their columns in host_fallback.finish)
         self.B = B
         self._state_valid = False
+        # (the library's scratch rows for launches of this batch: allocated here, not by the first step — ADVICE r05)
+        capi.check(capi.lib().opfx_env_prepare(self._env_handle, int(B)), 'opfx_env_prepare')
         self.x = t.zeros(B, self.nx, **f64)
         self.buf = dict(
             obs=t.zeros(B, max(1, self.n_obs_raw), **f64), reward=t.zeros(B, **f64),

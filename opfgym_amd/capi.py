@@ -240,7 +240,7 @@ EXPORTS = ['opfx_plan_create', 'opfx_plan_destroy', 'opfx_plan_get_info', 'opfx_
            'opfx_plan_get_ybus', 'opfx_plan_get_darray', 'opfx_ctx_create', 'opfx_ctx_destroy', 'opfx_last_error',
            'opfx_version', 'opfx_solve', 'opfx_env_create', 'opfx_env_destroy', 'opfx_step',
            'opfx_env_set_reset', 'opfx_reset', 'opfx_time_steps', 'opfx_env_get_info', 'opfx_env_get_storage',
-           'opfx_env_get_spec', 'opfx_env_get_row_io']
+           'opfx_env_get_spec', 'opfx_env_get_row_io', 'opfx_env_prepare']
 # include/opfx_debug.h (developer entry points, not part of the boundary)
 DEBUG_EXPORTS = ['opfx_plan_create_debug', 'opfx_ctx_create_debug', 'opfx_debug_read_stamps', 'opfx_debug_read_finish']
 
@@ -295,6 +295,7 @@ def lib():
     L.opfx_env_get_storage.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.opfx_env_get_spec.argtypes = [vp, C.POINTER(C.c_int32)]
     L.opfx_env_get_row_io.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.opfx_env_prepare.argtypes = [vp, C.c_int64]
     _lib = L
     return L
 

@@ -921,6 +921,17 @@ extern "C" int opfx_env_get_spec(const opfx_env* env, int32_t* spec) {
   return OPFX_OK;
 }
 
+// The per-workgroup scratch rows of a context grow on demand (ensure_scratch): the first launch — and any launch with a larger
+// grid — would otherwise call hipMalloc on the hot path, which synchronises and cannot happen inside a stream capture
+// (ADVICE r05).  Sized for the largest grid a launch of B instances can take: min(B, CUs x 16 resident workgroups).
+extern "C" int opfx_env_prepare(opfx_env* env, int64_t B) {
+  if (!env || B < 0) { opfx_set_error("opfx_env_prepare: bad argument"); return OPFX_ERR_INVALID; }
+  if (B == 0) return OPFX_OK;
+  HIP_TRY(hipSetDevice(env->ctx->device));
+  const int grid = (int)std::min<long long>((long long)B, (long long)env->ctx->n_cu * 16);
+  return ensure_scratch(env->ctx, grid, env->de.n_cont > 0);
+}
+
 extern "C" int opfx_env_get_row_io(const opfx_env* env, int32_t* columns_read) {
   if (!env) { opfx_set_error("opfx_env_get_row_io: null environment"); return OPFX_ERR_INVALID; }
   if (columns_read) *columns_read = env->de.nx_hot;

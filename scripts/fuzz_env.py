@@ -19,7 +19,7 @@ capi.set_default_debug(capi.debug_from_env())      # this harness is steered thr
 
 R_TOL, V_TOL = 1e-6, 1e-7      # (both Newton solvers stop at ||F||inf < 1e-8 p.u.; north-star bar 1e-6 p.u.)
 REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
-BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
+BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'eco_hv_small_shared', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
          'sc_hv_small', 'reconf_hv_small_sw', 'shunt_hv_small_sw', 'busbar_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
          'custom_constraint_lv', 'multistage_lv']
 

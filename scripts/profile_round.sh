@@ -30,7 +30,7 @@ python3 - "$out" "$tag" "$cfg" "$psteps" <<'PY'
 import sys, glob, csv, collections, json, shutil, hashlib
 out, tag, cfg, psteps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 sha = hashlib.sha256()
-for rel in ('opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h'):      # (kernels + plan compiler)
+for rel in ('opfgym_amd/csrc/opfx_dev.h', 'opfgym_amd/csrc/opfx.hip', 'opfgym_amd/csrc/plan.cpp', 'opfgym_amd/csrc/plan.h'):      # (kernels, host side, plan compiler)
     sha.update(open(rel, 'rb').read())          # (= bench.py source_sha16: counters are only used with the sources they were taken from)
 st = glob.glob(out + '/trace/**/*kernel_stats.csv', recursive=True)
 if st:
@@ -53,6 +53,16 @@ if st:
     for r in csv.DictReader(open(st[0])):
         if 'k_step' in r.get('Name', ''):
             avg_ns, calls = float(r['AverageNs']), int(r['Calls'])
+# min / median of the k_step launches of the stats pass (the kept profile's average has been above the
+# driver's clock two rounds running; the spread says whether that is noise)
+dur = []
+for f in glob.glob(out + '/trace/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'k_step' in r.get('Kernel_Name', ''):
+            dur.append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+dur.sort()
+min_ns = dur[0] if dur else None
+med_ns = dur[len(dur) // 2] if dur else None
 batch = None
 try:
     line = [ln for ln in open(out + '/trace.log') if ln.startswith('{')][-1]
@@ -62,7 +72,7 @@ except Exception:
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     fk, wk = mean['FETCH_SIZE'], mean['WRITE_SIZE']
     json.dump({'kernel': name, 'tag': tag, 'config': int(cfg), 'batch': batch, 'source_sha16': sha.hexdigest()[:16],
-               'kernel_avg_ns': avg_ns, 'kernel_calls': calls,
+               'kernel_avg_ns': avg_ns, 'kernel_min_ns': min_ns, 'kernel_median_ns': med_ns, 'kernel_calls': calls,
                'sq': {k: v for k, v in mean.items() if k not in ('FETCH_SIZE', 'WRITE_SIZE')},
                'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --config %s --steps %s --warmup 2 --no-cpu-baseline (one pass per counter)' % (cfg, psteps),
                'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk,
