@@ -6,6 +6,7 @@
 
 // Weak fallbacks of the kernel accessors (opfx_kernels.h): a build that leaves a kernel translation unit out links, and the
 // launches that would need its kernels are refused (kernel_missing).
+#ifndef OPFX_SINGLE_TU        // (a probe build that #includes every kernel unit into this one has the strong definitions at hand)
 #define OPFX_WEAK_KERNELS3(name) __attribute__((weak)) const void* name(int, int, int) { return nullptr; }
 OPFX_WEAK_KERNELS3(opfx_k_step_plain0) OPFX_WEAK_KERNELS3(opfx_k_step_plain1) OPFX_WEAK_KERNELS3(opfx_k_step_plain2)
 OPFX_WEAK_KERNELS3(opfx_k_step_plain3) OPFX_WEAK_KERNELS3(opfx_k_step_dc0) OPFX_WEAK_KERNELS3(opfx_k_step_dc1)
@@ -13,6 +14,7 @@ OPFX_WEAK_KERNELS3(opfx_k_step_dc2) OPFX_WEAK_KERNELS3(opfx_k_step_dc3) OPFX_WEA
 OPFX_WEAK_KERNELS3(opfx_k_solve)
 __attribute__((weak)) const void* opfx_k_reset(int, int) { return nullptr; }
 #undef OPFX_WEAK_KERNELS3
+#endif
 
 namespace {
 

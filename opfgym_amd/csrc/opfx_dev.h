@@ -114,14 +114,15 @@ struct DevPlan {
   double* blk_mem;           // memory-resident kernels: [resident workgroups][blk_mem_stride] LU block values
   long long blk_mem_stride;
   double* warm;              // [resident workgroups][2*nb] base-case voltages, start of the N-1 solves
-  double* theta0;            // the same rows used for the base case's DC angles instead (launches whose contingencies start from
-                             // a DC power flow of their own, derived from the base case's by a rank-1 update: cont_dc_*), or nullptr
   double* pq;                // [resident workgroups][2*nbe] scheduled P/Q of the workgroup's instance (see carve)
   int* queue;                // work queue of the step kernel: instances handed out beyond the first one per workgroup
+  // (members added in round 6 go to the END: the struct is a kernel argument, and the offsets of the members above decide how the
+  //  scalar loads of the hot kernels group — an int put in front of DevEnv cost 0.8 % of a config-2 step, profiles/r06_ab_prev_tree.txt)
+  double* theta0;            // the `warm` rows used for the base case's DC angles instead (launches whose contingencies start from a
+                             // DC power flow of their own, derived from the base case's by a rank-1 update: cont_dc_*), or nullptr
 };
 
 struct DevEnv {
-  int nx_hot;                // columns [0, nx_hot) of the row are all the step kernel reads (opfx_env_create); the rest stays in HBM
   int nx, na, npoly, npwl, nseg, nc, nobs, nres, ncost, ncost_pre;
   int nblk_d;                // doubles reserved for [LU blocks | result bank | staged table row beyond rhs]
   int reward_kind, diff_objective, steps_per_episode, clamp_enabled;
@@ -129,14 +130,15 @@ struct DevEnv {
   int n_oseg_res;            // observation segments read from the result bank (0: the epilogue writes no observation)
   int max_mod;               // modifier records reserved per instance (env modifiers + outage + contingency)
   int n_bmod;                // branch state columns (taps, switches): see opfx_env_desc.bmod_*
+  int nx_hot;                // columns [0, nx_hot) of the row are all the step kernel reads (opfx_env_create); the rest stays in HBM
+                             // (the 24th int: the slot that used to be padding in front of the pointers — no other member moves)
   const int *act_kind, *bmod_branch, *bmod_src, *bmod_lo, *bmod_n, *bmod_ptr;
   const double* bmod_y;
   const int* vset_src;       // [nb] source of a per-instance |V| set-point (NOSRC: compiled value), or nullptr
   int n_qterm;               // quadratic objective terms on the result bank
   int n_xres, nres_base;     // derived result rows [nres_base, nres_base + n_xres)
   const int *xres_kind, *xres_p, *xres_q, *xres_r;
-  const double *xres_scale, *xres_off;
-  const int2* cost_res;      // [ncost] {P, Q} result-bank entries that replace the per-bus values a solve-fed cost row reads (-1: none), or nullptr
+  const double* xres_scale;
   const int* qterm_idx;
   const double *qterm_target, *qterm_weight;
   double penalty_weight, clip_lo, clip_hi, objective_factor, objective_bias;
@@ -160,6 +162,8 @@ struct DevEnv {
   // DC start of the N-1 contingencies by a rank-1 update of the base case's DC power flow (opfx_env_create): per contingency
   // w = B'^-1 (e_f - e_t) [nb] and {b, Pfinj, 1 / (1 - b (w_f - w_t)), -}; nullptr: every contingency runs its own DC pass
   const double *cont_dc_w, *cont_dc_k;
+  const double* xres_off;    // [n_xres] constant term of OPFX_XRES_AFFINE rows
+  const int2* cost_res;      // [ncost] {P, Q} result-bank entries that replace the per-bus values a solve-fed cost row reads (-1: none), or nullptr
 };
 
 struct SolveIO {
@@ -2847,7 +2851,17 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
 #pragma unroll
         for (int u = 0; u < 8; ++u) xs[q + u * NT] = t[u];
       }
-      for (; q < nx; q += NT) xs[q] = ld_at(xr, (unsigned)q);
+      // (the rest in batches of clamped loads as well — eight per lane for a single wavefront, two for a team —: one load per
+      //  pass of this loop is one memory round trip per pass; with the row cut at nx_hot the rest grew from 58 to 302 columns
+      //  on config 2 and five serial round trips cost 0.8 % of the step)
+      constexpr int TB = NW == 1 ? 8 : 2;
+      for (; q < nx; q += TB * NT) {
+        double t[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) t[u] = ld_at(xr, (unsigned)min(q + u * NT, nx - 1));
+#pragma unroll
+        for (int u = 0; u < TB; ++u) if (q + u * NT < nx) xs[q + u * NT] = t[u];
+      }
     }
     blk_sync<NW>();       // staged row visible (one wave: compiler fence; team: all waves staged)
     OPFX_STAMP(16);
@@ -3136,7 +3150,11 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       if (c == 0) {
         conv0 = conv; iters0 = iters; nrm0 = nrm;
         if (!conv) break;
-        if (P.theta0) __builtin_amdgcn_s_waitcnt(0);      // (the DC angles the base case's DC pass stored: read by other lanes below)
+        // (the DC angles the base case's DC pass stored are read by other lanes below: a team has met at a workgroup barrier since,
+        //  a single wavefront waits for its own stores.  Compile-time for the kernels without the DC start: the test alone — a
+        //  kernel-argument load and a branch per instance — cost config 3 0.8 %, profiles/r06_ab_bisect_c3.txt)
+        if (DC && NW == 1 && P.theta0) __builtin_amdgcn_s_waitcnt(0);
+      // (the DC angles the base case's DC pass stored: read by other lanes below)
         if (!NOMOD && E.n_cont > 0 && o.contingency_start == 0) {      // (the row holds the base case's DC angles otherwise)
           double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
           for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); st_at(wv, io_, L.vr[i]); st_at(wv, (unsigned)nb + io_, L.vi[i]); }
