@@ -54,12 +54,15 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
                                                                  no |V| / loading / slack power moves, angles turn by 150 deg)
       shunt (p, q, step) = a load of p |V|^2, q |V|^2           shunt_is_a_constant_impedance_load
       several ext_grids                                          two_ext_grids_at_one_set_point_are_a_fused_slack
+      ideal phase shifter (tap_phase_shifter, tap_step_degree)   ideal_phase_shifter_is_a_changed_vector_group (in a loop with a plain
+                                                                 transformer: the circulating flow; hv and lv side)
+      storages (sign convention, scaling)                        storage_is_a_load
       generators sharing a bus (pfsoln's split)                 tests/test_generator_dispatch.py (by hand: shares of the ranges)
       `_is_elements` zero rule of result rows                   tests/test_gpu_env.py::test_units_on_a_de_energised_island_cost_nothing
       DC start values                                            the converged solution does not depend on them; iteration counts
                                                                  against this oracle's own DC start only
-    Truly unreachable here (no number, no equivalent formulation through a pinned path): storages beyond their sign
-    convention (a negative load by definition), tap_phase_shifter, lines with g_us_per_km, transformer df.
+    Truly unreachable here (no number, no equivalent formulation through a pinned path): lines with g_us_per_km, transformer df,
+    a phase shifter given as tap_step_percent.
   * the closed-form two-bus solution,
   * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
     (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to

@@ -2,7 +2,8 @@
 random combinations of the in-scope OpfEnv options on the small scenario grids, one reset
 and up to three steps each, every instance compared with the oracle on the same draws.
 
-    python scripts/fuzz_env.py [n_configs] [seed] [only_config]        (OPFX_FUZZ_BASES=a,b: draw from these scenarios only)
+    python scripts/fuzz_env.py [n_configs] [seed] [only_config]        (OPFX_FUZZ_BASES=a,b: draw from these scenarios only;
+                                                                        OPFX_FUZZ_INIT=auto|dc, OPFX_FUZZ_FAITHFUL=1: see run_one)
 
 Prints one line per configuration and a summary; exits non-zero on the first mismatch."""
 import os
@@ -145,6 +146,10 @@ def run_one(base, kw, rng, B=8):
     # the DC-start kernels and their specialisations against the same oracle — same fixed point, same converged set away from
     # voltage collapse (nothing is drawn for it, so a campaign replays with and without)
     pk = dict(kw, init=os.environ['OPFX_FUZZ_INIT']) if os.environ.get('OPFX_FUZZ_INIT') else kw
+    # OPFX_FUZZ_FAITHFUL=1: the product under the reference's own solver settings (reference_faithful=True: DC start, every N-1
+    # contingency from scratch — from round 6 on from a rank-1 update of the base case's DC angles —, pypower's q-limit path)
+    if os.environ.get('OPFX_FUZZ_FAITHFUL'):
+        pk = dict(pk, reference_faithful=True)
     env = product_env(base, batch_size=B, **pk)
     orc = oracle_env(base, product_env(base, defer_device=True, **kw))
     is_test = 'test_data' in kw and rng.random() < 0.5

@@ -219,12 +219,51 @@ def open_bus_bus_switch_is_no_switch():
     return a, copy.deepcopy(base), lambda ra, rb: _compare_all(ra, rb)
 
 
-CASES = {f.__name__: f for f in (bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
+def ideal_phase_shifter_is_a_changed_vector_group():
+    """An ideal phase shifter (`tap_phase_shifter`, `tap_step_degree` per step) only turns the angle: the same transformer with its
+    vector-group shift changed by direction * (pos - neutral) * tap_step_degree (+ on the hv side, - on the lv side) and no tap.
+    The two transformers in a LOOP with a plain line (an angle that is merely carried along a radial path would cancel out of
+    every |V|): the circulating flow the shifter drives must be the same."""
+    def grid(**kw):
+        net, t = _two_winding_pair(shift_degree=0.0, **kw)
+        # a second, plain transformer in parallel closes the loop the phase shifter acts on
+        tr = dict(sn_mva=40.0, vn_hv_kv=110.0, vn_lv_kv=21.0, vk_percent=12.0, vkr_percent=0.35, pfe_kw=22.0, i0_percent=0.06, shift_degree=0.0)
+        N.create_transformer_from_parameters(net, int(net.trafo.hv_bus.iloc[0]), int(net.trafo.lv_bus.iloc[0]), **tr)
+        return N.finalize(net)
+    out = []
+    for side, sign in (('hv', 1.0), ('lv', -1.0)):
+        a = grid(tap_side=side, tap_neutral=0, tap_pos=3, tap_step_degree=1.5, tap_phase_shifter=True)
+        b = grid()
+        b.trafo.at[b.trafo.index[0], 'shift_degree'] = sign * 3 * 1.5
+        out.append((a, b))
+    (a, b), (a2, b2) = out
+
+    def compare(ra, rb):
+        _compare_all(ra, rb)
+        ld = _col(ra, 'res_trafo', 'loading_percent')
+        assert abs(ld[0] - ld[1]) > 1.0                      # (the shifter does drive a circulating flow: the twins are loaded unequally)
+    compare.second_pair = (a2, b2)
+    return a, b, compare
+
+
+def storage_is_a_load():
+    """A storage unit enters the power flow as a load of its p_mw, q_mvar (x scaling): positive = charging = consumption."""
+    a, _ = _two_winding_pair()
+    bus = int(a.bus.index[3])
+    N.create_storage(a, bus, 1.7, 0.4, scaling=1.2)
+    N.finalize(a)
+    b, _ = _two_winding_pair()
+    N.create_load(b, bus, 1.7 * 1.2, 0.4 * 1.2)
+    N.finalize(b)
+    return a, b, lambda ra, rb: _compare_all(ra, rb)
+
+
+CASES = {f.__name__: f for f in (ideal_phase_shifter_is_a_changed_vector_group, storage_is_a_load, bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
                                  parallel_two_is_two_elements, vector_group_shift_turns_the_angles_behind_it,
                                  shunt_is_a_constant_impedance_load, two_ext_grids_at_one_set_point_are_a_fused_slack,
                                  open_bus_bus_switch_is_no_switch)}
 # pairs that must compile to the SAME bus admittance matrix in the product's converter (no solve needed to compare them)
-SAME_ADMITTANCES = ('lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
+SAME_ADMITTANCES = ('ideal_phase_shifter_is_a_changed_vector_group', 'storage_is_a_load', 'lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
                     'open_bus_bus_switch_is_no_switch', 'bus_bus_switch_is_one_bus')
 
 
@@ -236,3 +275,8 @@ def run(case, solve):
         b = b(a)
     solve(b)
     compare(a, b)
+    if hasattr(compare, 'second_pair'):          # (a case may carry a second pair checked the same way)
+        a2, b2 = compare.second_pair
+        solve(a2)
+        solve(b2)
+        compare(a2, b2)
