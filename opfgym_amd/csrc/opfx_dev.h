@@ -2911,7 +2911,9 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
               xv = rint(xv);
               if (kind[u] == OPFX_ACT_BOOLEAN) xv = xv != 0.0 ? 1.0 : 0.0;
             }
+#ifndef OPFX_PROBE_NO_SETPOINT_WRITEBACK        // (probe build: what the scattered 8-byte set-point stores cost in HBM writes, EXPERIMENTS #33)
             st_at(xr, (unsigned)slot[u], xv);                                            // :483
+#endif
             const double cur = (xv * sc[u] - lo) / delta;                                // :586
             corr += (delta != 0.0) ? fabs(cur - a) : 0.0;                                // D11 guard
           }
