@@ -804,6 +804,7 @@ static int do_step(opfx_env* env, int64_t B, const opfx_step_io* io, const opfx_
   int spec = env->ctx->v2 && !env->mem ? env->spec : 0;
   if (io->outage) spec &= ~SPEC_NO_MOD;
   if (team == 1 && env->ctx->plan.nb > WAVE * POLAR_R) spec &= ~SPEC_NO_MOD;      // (the no-modifier single-wave kernels keep a polar shadow of POLAR_R bus rounds)
+  if (team > 1 && env->ctx->plan.nb > WAVE * team * TEAM_PQ_R) spec &= ~SPEC_NO_PV;  // (the no-PV team kernels keep P / Q of TEAM_PQ_R bus rounds per wavefront in registers)
   spec &= OPFX_SPEC_MASK;
   const int v2s = packed ? 2 : 1;
   // (three wavefronts per SIMD: three teams of four on two-value blocks, w3; a SMALL grid on the single wave, env_small_grid)
@@ -919,6 +920,10 @@ extern "C" int opfx_env_get_spec(const opfx_env* env, int32_t* spec) {
     *spec = (env->ctx->v2 && !env->mem) ? (env->spec & OPFX_SPEC_MASK) : 0;
     if (env->ctx->plan.nb > WAVE * POLAR_R && !env_three_teams_of_four(env)
         && pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0) == 1) *spec &= ~SPEC_NO_MOD;      // (as do_step)
+    {
+      const int team = (env->mem || env_three_teams_of_four(env)) ? 4 : pick_team(env->ctx->dbg, env->lds_bytes, env->ctx->v2, env->ctx->plan.n_shared > 0);
+      if (team > 1 && env->ctx->plan.nb > WAVE * team * TEAM_PQ_R) *spec &= ~SPEC_NO_PV;
+    }
   }
   return OPFX_OK;
 }

@@ -909,7 +909,19 @@ __device__ __forceinline__ void team_pair(const Lds& L, const uint4 da, const ui
 // back: single-wave step kernels specialised SPEC_NO_MOD (no modifiers, contingencies, per-instance |V| set-points), grids
 // of at most 64 POLAR_R buses; everything else takes sqrt / atan2 as before.
 constexpr int POLAR_R = 4;
-struct Polar { double th[POLAR_R], vm[POLAR_R]; };
+// PQREG (round 6): in the same kernels, when the plan has no PV bus either (SPEC_NO_PV: nothing ever moves a bus's scheduled Q), the
+// scheduled P / Q of the lane's buses stay in REGISTERS as well instead of in the workgroup's row of global memory: they are read-only
+// after the prologue, and the 2 304 B row per 144-bus instance was written through to HBM for every instance (20 MB of the 92 MB a
+// config-2 launch writes, EXPERIMENTS #33).  A register array wants a compile-time index: the bus rounds of phase A are unrolled
+// over the POLAR_R rounds such a grid can have (round r of a lane is bus lane + 64 r, the map of the polar shadow).
+#ifndef OPFX_PQREG
+#define OPFX_PQREG 1
+#endif
+#ifndef OPFX_TPQ              // (the same for the wave teams, see TEAM_PQ_R; 0: probe builds)
+#define OPFX_TPQ 1
+#endif
+struct Polar { double th[POLAR_R], vm[POLAR_R], p[POLAR_R], q[POLAR_R]; };
+constexpr int TEAM_PQ_R = 2;       // bus rounds per wavefront of a team whose P / Q stay in registers: grids of up to 64 NW TEAM_PQ_R buses (do_step)
 // Phase D of the lane-programme kernels: after the back-substitution items y_i of bus i holds its
 // right-hand side with every U-term removed; x_i = A_ii^-1 y_i, then V_i <- V_i (1 + d|V|/|V|) e^{j dth}.
 // `piv` keeps the smallest relative pivot seen by this lane: |det| / (|a11 a22| + |a12 a21|) of the 2x2
@@ -1216,6 +1228,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   double piv = 1.0;
   int pbus = -1;
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
+  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV && !DC;      // scheduled P / Q in pol->p / pol->q (see Polar)
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
@@ -1241,7 +1254,8 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   ARound cur = load_around(P, 0, lane);
   // scheduled P/Q of this lane's row of the next round, fetched with the descriptors (global row, see carve)
   const double* psp_g = L.psp; const double* qsp_g = L.qsp;
-  double pcur = psp_g[lane < nb ? lane : nb - 1], qcur = qsp_g[lane < nb ? lane : nb - 1];
+  double pcur = 0.0, qcur = 0.0;
+  if (!PQREG) { pcur = psp_g[lane < nb ? lane : nb - 1]; qcur = qsp_g[lane < nb ? lane : nb - 1]; }
   uint4 hy = make_uint4(0, 0, 0, 0), he = make_uint4(NONE | (NONE << 16), 0, 0, 0);
   if (P.rh > 0) { hy = hpk[0]; he = hpk[WAVE]; }
   // rounds 0..3 of phases B/C; re-loaded by the tail of phase C for the next iteration
@@ -1288,14 +1302,16 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
       wave_fence();
     }
     OPFX_STAMP(11);
-    for (int r = 0; r < P.ra; ++r) {
+    // one bus round: rows lane + 64 r (the descriptors of the NEXT round are requested first)
+    auto bus_round = [&](const int r, const double p_sched, const double q_sched) __attribute__((always_inline)) {
       const ARound a = cur;
-      const double p_sched = pcur, q_sched = qcur;
       {
         const int rn = r + 1 < P.ra ? r + 1 : 0;                 // next round (or round 0 of the next iteration)
         cur = load_around(P, rn, lane);
-        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
-        pcur = psp_g[in_]; qcur = qsp_g[in_];
+        if (!PQREG) {
+          const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+          pcur = psp_g[in_]; qcur = qsp_g[in_];
+        }
       }
       const int i = lane + WAVE * r;
       if (i < nb) {
@@ -1347,6 +1363,12 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
           L.rq[i] = si - b * v2;
         }
       }
+    };
+    if (PQREG) {
+#pragma unroll
+      for (int r = 0; r < POLAR_R; ++r) if (r < P.ra) bus_round(r, pol->p[r], pol->q[r]);
+    } else {
+      for (int r = 0; r < P.ra; ++r) { const double p_sched = pcur, q_sched = qcur; bus_round(r, p_sched, q_sched); }
     }
     // (the wave teams fold the modifiers into the bus rounds, mods_inline; here, where the kernel's common case has
     //  none, even the test for it in the bus round costs 1.5 % — measured — so they keep their own pass)
@@ -1477,10 +1499,14 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
 // descriptor loads in flight (s_waitcnt vmcnt(0)) at every group end.
 template <int NW, bool PK, bool MEM = false, bool DC = false, bool CHORD = false, int SPEC = 0>
 __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int n_mod,
-                             int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool inline_mods, bool dc_pass = false) {
+                             int* iters_out, double* nrm_out, double* piv_out, int* pbus_out, bool inline_mods, bool dc_pass = false,
+                             const Polar* pol = nullptr) {
   double piv = 1.0;
   int pbus = -1;
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
+  // TPQ: the scheduled P / Q of the thread's buses in registers (pol->p / q [TEAM_PQ_R]) — team kernels of plans without a PV bus,
+  // where nothing changes them after the prologue (see Polar / PQREG; bus tid + NT k is round wave + NW k of this wavefront)
+  constexpr bool TPQ = OPFX_PQREG && OPFX_TPQ && NOPV && !MEM && NW > 1;
   constexpr unsigned NONE = 0xFFFFu;
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1512,8 +1538,8 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
   const double* psp_g = L.psp; const double* qsp_g = L.qsp;
   const int r_first = wave < P.ra ? wave : 0;
   ARound a_next = load_around(P, r_first, lane);
-  double p_next, q_next;
-  { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
+  double p_next = 0.0, q_next = 0.0;
+  if (!TPQ) { const int in_ = lane + WAVE * r_first < nb ? lane + WAVE * r_first : nb - 1; p_next = psp_g[in_]; q_next = qsp_g[in_]; }
   while (true) {
     // ---- phase A ------------------------------------------------------------------
     // (nothing in this prologue of the phase waits for global memory: fill blocks are one contiguous id range,
@@ -1557,14 +1583,15 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
     team_sync<MEM>();
     OPFX_STAMP(11);
     double my = 0.0;
-    for (int r = wave; r < P.ra; r += NW) {
+    auto bus_round = [&](const int r, const double p_sched, const double q_sched) __attribute__((always_inline)) {
       const ARound a = a_next;
-      const double p_sched = p_next, q_sched = q_next;
       {
         const int rn = r + NW < P.ra ? r + NW : r_first;       // (last round: first round of the next iteration)
         a_next = load_around(P, rn, lane);
-        const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
-        p_next = psp_g[in_]; q_next = qsp_g[in_];
+        if (!TPQ) {
+          const int in_ = lane + WAVE * rn < nb ? lane + WAVE * rn : nb - 1;
+          p_next = psp_g[in_]; q_next = qsp_g[in_];
+        }
       }
       const int i = lane + WAVE * r;
       if (DC && dcp) {
@@ -1626,6 +1653,12 @@ __device__ bool newton2_coop(const DevPlan& P, const Lds& L, const Opts& o, int 
           L.rq[i] = si + yi;
         }
       }
+    };
+    if (TPQ) {
+#pragma unroll
+      for (int k = 0; k < TEAM_PQ_R; ++k) { const int r = wave + NW * k; if (r < P.ra) bus_round(r, pol->p[k], pol->q[k]); }
+    } else {
+      for (int r = wave; r < P.ra; r += NW) { const double p_sched = p_next, q_sched = q_next; bus_round(r, p_sched, q_sched); }
     }
     OPFX_STAMP(12);
     if (!(DC && dcp)) {
@@ -1847,7 +1880,7 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
     double pv_ = __builtin_nan("");          // (the first-generation kernel does not monitor its pivots)
     int pb_ = -1;
     // (modifiers are folded into the bus rounds of phase A unless an island has been de-energised)
-    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM, SPEC>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0);
+    if (NW > 1) conv = newton2_coop<NW, V2 == 2, MEM, DC && !MEM, CHORD && !MEM, SPEC>(P, L, o, n_mod, &it, nrm, &pv_, &pb_, isl_state == 0, dc_first && outer == 0, pol);
     else conv = V2 ? newton2<V2 == 2, DC && V2 != 0, CHORD && V2 != 0, SPEC, POLAR && NW == 1 && V2 != 0>(P, L, o, lane, n_mod, &it, nrm, &pv_, &pb_, dc_first && outer == 0, pol) : newton(P, L, o, lane, out_br, &it, nrm);
     total += it;
     if (pv_ == pv_ && pv_ < *min_piv) { *min_piv = pv_; *min_piv_bus = pb_; }
@@ -1898,11 +1931,14 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 // `lane` / `stride`: the calling thread's index and the number of threads that share the work (a wavefront,
 // or the whole wave team)
-template <int V2, int SPEC = 0, bool POLAR = false>
+template <int V2, int SPEC = 0, bool POLAR = false, bool TEAMPQ = false>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle, int stride = WAVE, const Polar* pol = nullptr) {
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
+  // scheduled P / Q in pol->p / pol->q (see Polar): single-wave PQREG kernels (bus lane + 64 r) and the teams' TPQ kernels
+  // (bus tid + NT k; `stride` = NT there)
+  constexpr bool PQREG = OPFX_PQREG && NOPV && V2 != 0 && (POLAR || TEAMPQ);
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
   double* r_va = R + nb;
@@ -1924,6 +1960,22 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
         const double ang = fabs(th) <= M_PI ? th : th - (2.0 * M_PI) * rint(th * (0.5 / M_PI));
         r_va[i] = physical ? ang * (180.0 / M_PI) : ang;
       }
+      if (PQREG && L.bt[i] == BT_REF) {           // slack power: the parked injection less what was scheduled at the bus
+        const int ro = P.ref_ord[i];
+        (R + 2 * nb + nbr)[ro] = (L.rhs[i] - pol->p[r]) * base;
+        (R + 2 * nb + nbr + nref)[ro] = (L.rq[i] - pol->q[r]) * base;
+      }
+    }
+  }
+  if (TEAMPQ && PQREG) {
+#pragma unroll
+    for (int k = 0; k < TEAM_PQ_R; ++k) {
+      const int i = lane + stride * k;
+      if (i < nb && L.bt[i] == BT_REF) {
+        const int ro = P.ref_ord[i];
+        (R + 2 * nb + nbr)[ro] = (L.rhs[i] - pol->p[k]) * base;
+        (R + 2 * nb + nbr + nref)[ro] = (L.rq[i] - pol->q[k]) * base;
+      }
     }
   }
   for (int i = lane; i < nb; i += stride) {
@@ -1939,9 +1991,11 @@ __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int ou
     if (!NOMOD && t == BT_DEAD) {        // de-energised: no voltage (NaN as in pandapower's res_bus)
       r_vm[i] = __builtin_nan(""); r_va[i] = __builtin_nan("");
     } else if (V2 && t == BT_REF) {
-      const int ro = P.ref_ord[i];
-      r_pe[ro] = (L.rhs[i] - L.psp[i]) * base;          // (V2: rhs/rq are separate arrays)
-      r_qe[ro] = (L.rq[i] - L.qsp[i]) * base;
+      if (!PQREG) {
+        const int ro = P.ref_ord[i];
+        r_pe[ro] = (L.rhs[i] - L.psp[i]) * base;          // (V2: rhs/rq are separate arrays)
+        r_qe[ro] = (L.rq[i] - L.qsp[i]) * base;
+      }
     } else if ((!V2 && t == BT_REF) || (!NOPV && t == BT_PV)) {
       double ir = 0.0, ii = 0.0;
       for (int e = P.y_ptr[i]; e < P.y_ptr[i + 1]; ++e) {
@@ -2792,6 +2846,8 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
   // (the polar shadow, see Polar: single-wave kernels at two wavefronts per SIMD without modifiers; the launch keeps grids of
   //  more than 64 POLAR_R buses off these instantiations, do_step)
   constexpr bool POLAR = V2 != 0 && NW == 1 && !MEM && !DC && !CHORD && MINW == 2 && NOMOD;
+  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV;      // scheduled P / Q in registers (see Polar)
+  constexpr bool TPQ = OPFX_PQREG && OPFX_TPQ && V2 != 0 && NW > 1 && NOPV && !MEM;      // ... of a team's threads (newton2_coop)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2948,6 +3004,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       continue;
     }
     OPFX_STAMP(18);
+    Polar pol;                               // polar shadow / scheduled P, Q of the lane's buses (POLAR, PQREG kernels)
     double csum = 0.0;                       // this lane's share of the cost rows
     {
       // ---- bus injections (makeSbus): flat list, LDS accumulate ----------------------------------
@@ -2989,7 +3046,17 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
           lds_add(((bq >> 16) ? qacc : pacc) + (bq & 0xFFFF), v);
         }
       }
-      if (V2) {
+      if (PQREG) {
+        blk_sync<NW>();
+        // (no PV bus, no modifier: the sums never change after this point and stay with the lane that owns the bus)
+#pragma unroll
+        for (int r = 0; r < POLAR_R; ++r) { const int i = min(lane + WAVE * r, nb - 1); pol.p[r] = pacc[i]; pol.q[r] = qacc[i]; }
+      } else if (TPQ) {
+        blk_sync<NW>();
+#pragma unroll
+        for (int k = 0; k < TEAM_PQ_R; ++k) { const int i = min(tid + NT * k, nb - 1); pol.p[k] = pacc[i]; pol.q[k] = qacc[i]; }
+        blk_sync<NW>();                      // (the sums are out of the voltage arrays before init_voltage writes them)
+      } else if (V2) {
         blk_sync<NW>();
         // (scalar base + 32-bit lane offset: the per-workgroup rows never turn into 64-bit per-lane addresses that the
         //  compiler computes at kernel entry and keeps — or spills — through every Newton loop)
@@ -3035,7 +3102,6 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
     double nrm0 = 0.0;
     double min_piv = V2 ? 1.0 : __builtin_nan("");
     int min_piv_bus = -1;
-    Polar pol;
     const int base_out = (!NOMOD && io.outage) ? io.outage[b] : -1;
     // modifiers of this instance: [env modifiers (taps, switches) | outage | contingency]
     int n_mod_base = 0;
@@ -3174,7 +3240,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
-      OPFX_REP(6) compute_results<V2, SPEC, POLAR>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
+      OPFX_REP(6) compute_results<V2, SPEC, POLAR, TPQ>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
       blk_sync<NW>();
       // (derived rows and the constraint pass are shared by the whole team as well — with 250 contingencies per step they run
       //  251 times per instance and were 5 % of an N-1 step on wavefront 0 alone, the other three parked at the barrier)

@@ -886,6 +886,41 @@ def test_environment_on_a_grid_past_the_lds(monkeypatch):
     assert n_ok >= 2
 
 
+@pytest.mark.parametrize('nb,n_minus_one', [(420, False), (560, False), (560, True)])
+def test_team_kernels_without_a_pv_bus_keep_scheduled_power_in_registers_up_to_their_size(nb, n_minus_one, monkeypatch):
+    """Round 6: the team kernels of a plan WITHOUT a PV bus keep the scheduled P / Q of each thread's buses in registers
+    (`TEAM_PQ_R` = 2 bus rounds per wavefront: up to 512 buses on a team of four); a larger grid that still fits the LDS runs the
+    instantiation without the no-PV bit, i.e. with the per-workgroup rows in global memory (do_step).  Both must give the oracle's
+    step — VoltageControl (generators turned into fixed sgens: no PV bus) on meshed HV stand-ins of 420 and 560 buses, the larger one
+    also under N-1 keys (modifiers, islands: SPEC without the no-modifier bit)."""
+    import env_cases
+    from opfgym_amd import grids
+    code = f'hv-{nb}'
+    monkeypatch.setitem(grids.GRIDS, code, lambda seed=0: grids.synthetic_hv(seed + 11, nb=nb, n_ext=2, n_gen=6, name=f'syn-hv-{nb}'))
+    kw = dict(simbench_network_name=code)
+    if n_minus_one:
+        kw['n_minus_one_lines'] = (2, 5, 9, 14)
+    monkeypatch.setitem(env_cases.SCENARIOS, 'sc_big', ('SecurityConstrainedVoltageControl', kw, 4, 3))
+    B = 4
+    env = product_env('sc_big', batch_size=B)
+    ki = env.kernel_info()
+    assert ki['waves_per_instance'] in (2, 4) and env.plan.info['lds_doubles'] * 8 <= 160 * 1024
+    assert bool(ki['spec'] & 1) == (nb <= 64 * ki['waves_per_instance'] * 2), ki            # (SPEC_NO_PV survives only where the registers reach)
+    orc = oracle_env('sc_big', product_env('sc_big', defer_device=True))
+    rng = np.random.default_rng(8)
+    steps = rng.choice(env.train_steps, B)
+    uniform = rng.random((B, env.n_uniform)) if env.n_uniform else None
+    actions = rng.random((B, env.n_actions))
+    obs0, _ = env.reset(options={'step': steps, 'uniform': uniform})
+    out = env.step(actions)
+    for k in range(B):
+        ob = orc.reset(int(steps[k]), uniform[k] if uniform is not None else ())
+        assert np.allclose(_np(obs0)[k], ob, rtol=0, atol=R_TOL)
+        ref = orc.step(actions[k])
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged'] and ref['converged']
+        _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=n_minus_one)
+
+
 def test_is_state_valid_without_any_constraint():
     """no constraints at all -> an empty all() is True (opf_env.py:613-618), not a column the kernel never writes."""
     from opfgym_amd import envs
