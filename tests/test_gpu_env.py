@@ -897,9 +897,7 @@ def test_team_kernels_without_a_pv_bus_keep_scheduled_power_in_registers_up_to_t
     from opfgym_amd import grids
     code = f'hv-{nb}'
     monkeypatch.setitem(grids.GRIDS, code, lambda seed=0: grids.synthetic_hv(seed + 11, nb=nb, n_ext=2, n_gen=6, name=f'syn-hv-{nb}'))
-    kw = dict(simbench_network_name=code)
-    if n_minus_one:
-        kw['n_minus_one_lines'] = (2, 5, 9, 14)
+    kw = dict(simbench_network_name=code, n_minus_one_lines=(2, 5, 9, 14) if n_minus_one else ())      # (no line: the plain VoltageControl step)
     monkeypatch.setitem(env_cases.SCENARIOS, 'sc_big', ('SecurityConstrainedVoltageControl', kw, 4, 3))
     B = 4
     env = product_env('sc_big', batch_size=B)
