@@ -25,7 +25,7 @@ import numpy as np
 from . import capi
 from . import constraints as constraints_mod
 from . import reward as reward_mod
-from .case import REF
+from .case import REF, static_consumption
 from .simbench_build import define_test_train_split, get_simbench_time_observation
 from .descriptors import DescriptorCompiler, _case_all_branches_in
 from .spaces import Box, get_obs_and_state_space  # noqa: F401
@@ -257,6 +257,9 @@ class BatchedOpfEnv(DescriptorCompiler, TopologyMixin):
             self.store.slot(tbl, 'p_mw')
             self.store.slot(tbl, 'q_mvar')
         self.store.slot('gen', 'p_mw')
+        static = {(tbl, col): v for tbl, pq in static_consumption(net).items() for col, v in zip(('_p_mw', '_q_mvar'), pq)}
+        for (tbl, col), v in static.items():                    # (wards, motors: computed columns, descriptors.py)
+            self.store.computed(tbl, col, v)
         # sampling programme first: it decides which columns are per-instance
         self._build_sampling()
         # ... and once more with the columns the STEP never reads laid out last (intermediates of the reset programme such
@@ -266,7 +269,10 @@ class BatchedOpfEnv(DescriptorCompiler, TopologyMixin):
         if order != sorted(self.store.ranges, key=lambda k: self.store.ranges[k][0]):
             self.store = ColumnStore(net)
             for tbl, col in order:
-                self.store.slot(tbl, col)
+                if (tbl, col) in static:
+                    self.store.computed(tbl, col, static[(tbl, col)])
+                else:
+                    self.store.slot(tbl, col)
             self._build_sampling()
         self.n_actions = int(sum(len(idxs) for _, _, idxs in self.act_keys))
         # spaces of ONE instance (opf_env.py:124-130)

@@ -9,7 +9,9 @@ scale factors that turn per-unit branch currents into `loading_percent`.
  for the element types that occur in the SimBench
 benchmark grids: buses, lines, two-winding transformers, loads, sgens,
 storages, gens, ext_grids, shunts, bus-bus/line/trafo switches, three-winding
-transformers (star equivalent with an auxiliary bus).  pandapower is
+transformers (star equivalent with an auxiliary bus) — and, beyond those
+grids (round 6), wards, series impedances, motors and closed bus-bus switches
+with an impedance.  pandapower is
 not importable here, so the element formulas are restated from its published
 documentation ("Electric model" pages of line / trafo); parity of this
 conversion against pandapower itself is NOT verified in this repository (see
@@ -22,7 +24,9 @@ from dataclasses import dataclass, field
 import numpy as np
 
 PQ, PV, REF = 1, 2, 3
-KIND_LINE, KIND_TRAFO, KIND_TRAFO3W = 0, 1, 2
+KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, KIND_IMPEDANCE, KIND_SWITCH = 0, 1, 2, 3, 4
+# pandapower `runpp(switch_rx_ratio=2)`: a closed bus-bus switch with z_ohm > 0 is a branch of |z| = z_ohm with r / x = 2
+SWITCH_RX_RATIO = 2.0
 
 
 @dataclass
@@ -44,8 +48,8 @@ class Case:
     ytt: np.ndarray
     kf: np.ndarray                # f64 [nbr] loading% = max(|If|*kf, |It|*kt)
     kt: np.ndarray
-    br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo
-    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w
+    br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo / 2 trafo3w winding / 3 impedance / 4 bus-bus switch with z_ohm
+    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w / net.impedance / net.switch
     br_side: np.ndarray = None    # int32 [nbr]  trafo3w: 0 hv, 1 mv, 2 lv winding of its star equivalent (else 0)
     # DC model of the branches (pypower makeBdc; for opfx_solve_opts.init = OPFX_INIT_DC)
     bdc: np.ndarray = None        # f64 [nbr]  1 / (x * ratio), 0 for a branch that couples nothing (open-ended)
@@ -140,8 +144,17 @@ def _flags(df, name, default=False):
 
 # pandapower element tables that take part in `runpp` and that this converter has no model for: a net that
 # fills one of them would be solved WITHOUT those elements — a silently different grid — so it is refused
-UNMODELLED_TABLES = ('ward', 'xward', 'impedance', 'dcline', 'motor', 'asymmetric_load', 'asymmetric_sgen',
+UNMODELLED_TABLES = ('xward', 'dcline', 'asymmetric_load', 'asymmetric_sgen',
                      'svc', 'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc')
+
+
+def _table(net, name):
+    """net[name] if the net has such a table with rows, else None (a pandapowerNet of another version may lack it)."""
+    try:
+        df = net[name]
+    except (KeyError, AttributeError):
+        return None
+    return df if hasattr(df, 'columns') and len(df) else None
 
 
 def _count_nonzero(df, col):
@@ -160,9 +173,9 @@ def pd_to_float(values):
 
 def check_supported(net) -> None:
     """Raise ValueError (naming the table / column) for net content that `pp.runpp` would model and this
-    converter does not (opf_env.py:703 hands the WHOLE net to pandapower): rows in `ward`, `xward`,
-    `impedance`, `dcline`, `motor`, the asymmetric / FACTS tables; voltage-dependent (ZIP) loads; switches
-    with an impedance; switches at three-winding transformers; generators acting as slack;
+    converter does not (opf_env.py:703 hands the WHOLE net to pandapower): rows in `xward`, `dcline`, the
+    asymmetric / FACTS tables; voltage-dependent (ZIP) loads; line / transformer switches with an
+    impedance; switches at three-winding transformers; generators acting as slack;
     characteristic-dependent transformer impedances."""
     def table(name):
         try:
@@ -181,8 +194,9 @@ def check_supported(net) -> None:
                 raise ValueError(f'net.load.{col} is non-zero: voltage-dependent (ZIP) loads are not modelled')
     sw = table('switch')
     if sw is not None:
-        if _count_nonzero(sw, 'z_ohm'):
-            raise ValueError('net.switch.z_ohm is non-zero: switches with an impedance are not modelled')
+        if 'z_ohm' in sw.columns and np.nan_to_num(pd_to_float(sw['z_ohm'].to_numpy()))[[str(v) != 'b' for v in sw['et']]].any():
+            raise ValueError('net.switch.z_ohm is non-zero at a line / transformer switch: only bus-bus switches with an '
+                             'impedance are modelled')
         if 'et' in sw.columns and any(str(v) == 't3' for v in sw['et']):
             raise ValueError("net.switch: et='t3' (switches at three-winding transformers) is not modelled")
     gen = table('gen')
@@ -259,10 +273,14 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     uf = _UnionFind(bus_ids)
     line_open, trafo_open = {}, {}          # element -> buses at which one of its switches is open
     sw = net['switch'] if 'switch' in net else None
+    z_switches = []                         # closed bus-bus switches with an impedance: (row, bus, other bus, z_ohm)
     if sw is not None and len(sw):
-        for b, e, et, closed in zip(sw['bus'], sw['element'], sw['et'], sw['closed']):
+        z_sw = np.nan_to_num(pd_to_float(sw['z_ohm'].to_numpy())) if 'z_ohm' in sw.columns else np.zeros(len(sw))
+        for pos, (b, e, et, closed) in enumerate(zip(sw['bus'], sw['element'], sw['et'], sw['closed'])):
             if et == 'b':
-                if closed:
+                if closed and z_sw[pos] > 0:
+                    z_switches.append((pos, int(b), int(e), float(z_sw[pos])))
+                elif closed:
                     uf.union(int(b), int(e))
             elif et == 'l':
                 if not closed:
@@ -382,6 +400,29 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             kt = base * (vn_lv / vb_lv) / sn * 100.0 / (par[pos] * dfac[pos])
             rows.append((hb, lb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO, pos, kf, kt, oside, 0))
 
+    # --- series impedances (pandapower `_calc_impedance_parameter`): per unit of their own sn_mva, referred to the net's;
+    # the to-side values may differ: Yff = -Yft = 1 / z_ft, Ytt = -Ytf = 1 / z_tf (pandapower's makeYbus, BR_R_ASYM / BR_X_ASYM)
+    asym = {}                                          # (kind, row) -> (r, x) seen from the to side
+    imp = _table(net, 'impedance')
+    if imp is not None:
+        on = _col(imp, 'in_service', True).astype(bool)
+        k_sn = base / imp['sn_mva'].to_numpy(float)
+        num = lambda c_: imp[c_].to_numpy(float)
+        for pos, idx in enumerate(imp.index):
+            fb, tb = int(imp.at[idx, 'from_bus']), int(imp.at[idx, 'to_bus'])
+            if not on[pos] or not (bus_on(fb) and bus_on(tb)):
+                continue
+            rows.append((fb, tb, num('rft_pu')[pos] * k_sn[pos], num('xft_pu')[pos] * k_sn[pos], 0.0 + 0.0j, 1.0, 0.0,
+                         KIND_IMPEDANCE, pos, 0.0, 0.0, 0, 0))
+            asym[(KIND_IMPEDANCE, pos)] = (num('rtf_pu')[pos] * k_sn[pos], num('xtf_pu')[pos] * k_sn[pos])
+    # --- closed bus-bus switches with an impedance (pandapower `_calc_switch_parameter`): |z| = z_ohm, r / x = switch_rx_ratio
+    for pos, b, e, z in z_switches:
+        if not (bus_on(b) and bus_on(e)):
+            continue
+        zb = float(vn[b]) ** 2 / base
+        rows.append((b, e, z * SWITCH_RX_RATIO / np.hypot(1.0, SWITCH_RX_RATIO) / zb, z / np.hypot(1.0, SWITCH_RX_RATIO) / zb,
+                     0.0 + 0.0j, 1.0, 0.0, KIND_SWITCH, pos, 0.0, 0.0, 0, 0))
+
     # --- three-winding transformers: star equivalent (pandapower `_trafo_df_from_trafo3w`) -------------
     # an auxiliary bus on the hv voltage level per transformer and three two-winding transformers
     # hv-bus -> star, star -> mv-bus, star -> lv-bus; the pairwise short-circuit voltages (hv-mv, mv-lv,
@@ -498,6 +539,10 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
     yff, yft, ytf, ytt = branch_stamps(
         [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
         [r[5] for r in rows], [r[6] for r in rows])
+    for k, r in enumerate(rows):
+        if (r[7], r[8]) in asym:
+            y_t = 1.0 / complex(*asym[(r[7], r[8])])
+            ytt[k], ytf[k] = y_t, -y_t
     yff, yft, ytf, ytt = open_ended_stamps(yff, yft, ytf, ytt, np.array([r[11] for r in rows], dtype=np.int32))
 
     bus_type = np.full(nb, PQ, dtype=np.int32)
@@ -533,6 +578,14 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
                 v_ratio = (vn[int(b)] / float(sh_df['vn_kv'].iloc[pos])) ** 2
                 gs[i] += float(sh_df['p_mw'].iloc[pos]) * step[pos] * v_ratio / base
                 bs[i] -= float(sh_df['q_mvar'].iloc[pos]) * step[pos] * v_ratio / base
+
+    ward = _table(net, 'ward')
+    if ward is not None:                   # constant-impedance part of a ward: MW / Mvar at 1 p.u. (no voltage-level ratio)
+        w_on = _col(ward, 'in_service', True).astype(bool)
+        for pos, b in enumerate(ward['bus']):
+            if w_on[pos] and int(b) in bus_lookup:
+                gs[bus_lookup[int(b)]] += float(ward['pz_mw'].iloc[pos]) / base
+                bs[bus_lookup[int(b)]] -= float(ward['qz_mvar'].iloc[pos]) / base
 
     # start angles: propagate the REF angle through transformer phase shifts
     # (equivalent in effect to pandapower's init='dc' for shifted MV grids:
@@ -609,6 +662,11 @@ def bus_injections(net, case: Case):
                 i = case.bus_lookup[int(b)]
                 p[i] += sign * pv[pos] * sc[pos]
                 q[i] += sign * qv[pos] * sc[pos]
+    for tbl, (pv, qv) in static_consumption(net).items():
+        for pos, b in enumerate(net[tbl]['bus'].to_numpy()):
+            if int(b) in case.bus_lookup:
+                p[case.bus_lookup[int(b)]] -= pv[pos]
+                q[case.bus_lookup[int(b)]] -= qv[pos]
     qmin = np.full(nb, -np.inf)
     qmax = np.full(nb, np.inf)
     gen = net['gen']
@@ -627,6 +685,28 @@ def bus_injections(net, case: Case):
                 has[i] = True
         qmin[has], qmax[has] = acc_lo[has], acc_hi[has]
     return p, q, qmin, qmax
+
+
+def static_consumption(net) -> dict:
+    """Constant-power consumption of the element types that neither the reference's sampling nor its actuators touch, per
+    row of their table in MW / Mvar (zero for a row out of service): {'ward': (p, q), 'motor': (p, q)}.
+
+      * ward (pandapower `_calc_pq_elements_and_add_on_ppc`): ps_mw, qs_mvar (the constant-impedance part is a shunt: net_to_case);
+      * motor (pandapower `_get_motor_pq`): P = pn_mech_mw / (efficiency_percent / 100) * loading_percent / 100 * scaling,
+        S = P / cos_phi, Q = sqrt(S^2 - P^2)."""
+    out = {}
+    ward = _table(net, 'ward')
+    if ward is not None:
+        on = _col(ward, 'in_service', True).astype(float)
+        out['ward'] = (ward['ps_mw'].to_numpy(float) * on, ward['qs_mvar'].to_numpy(float) * on)
+    motor = _table(net, 'motor')
+    if motor is not None:
+        on = _col(motor, 'in_service', True).astype(float)
+        p_m = (motor['pn_mech_mw'].to_numpy(float) / _col(motor, 'efficiency_percent', 100.0) * 100.0
+               * _col(motor, 'loading_percent', 100.0) / 100.0 * _col(motor, 'scaling', 1.0) * on)
+        s_m = p_m / motor['cos_phi'].to_numpy(float)
+        out['motor'] = (p_m, np.sqrt(np.maximum(s_m ** 2 - p_m ** 2, 0.0)))
+    return out
 
 
 # pandapower's reactive limit of a generator row that names none (`_init_ppc_gen`: +-1e9 Mvar; ext_grids always) and the

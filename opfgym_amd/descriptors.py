@@ -12,7 +12,7 @@ import numpy as np
 
 from . import capi
 from . import reward as reward_mod
-from .case import KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, REF, net_to_case
+from .case import KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, REF, net_to_case, static_consumption
 from .grids import factored_profile
 from .store import OpsBuilder, _normal_and_clip, _truncated_normal
 
@@ -67,6 +67,7 @@ class DescriptorCompiler:
         columns, table observations, prices, per-instance voltage set-points.  Every other per-instance column is only
         written by the reset (and readable through `table_column`)."""
         hot = {(t, c) for t in ('load', 'sgen', 'storage') for c in ('p_mw', 'q_mvar')} | {('gen', 'p_mw'), ('ext_grid', 'vm_pu'), ('gen', 'vm_pu')}
+        hot |= {(t, c) for t in ('ward', 'motor') for c in ('_p_mw', '_q_mvar')}
         for unit, col, _ in self.act_keys:
             hot |= {(unit, col)} | {(unit, pre + col) for pre in ('min_', 'max_', 'min_min_', 'max_max_')}
         hot |= {(unit, col) for unit, col, _ in self.obs_keys if not unit.startswith('res_')}
@@ -467,6 +468,14 @@ class DescriptorCompiler:
                     plist[i].append((p0 + pos, sign * sc[pos] / base))
                     if has_q:
                         qlist[i].append((q0 + pos, sign * sc[pos] / base))
+
+        # (wards' constant-power part and motors: consumption that nothing samples or actuates — one computed column each)
+        for tbl, (pv, qv) in static_consumption(net).items():
+            p0, q0 = st.computed(tbl, '_p_mw', pv), st.computed(tbl, '_q_mvar', qv)
+            for pos, b in enumerate(net[tbl]['bus'].to_numpy()):
+                if int(b) in c.bus_lookup:
+                    plist[c.bus_lookup[int(b)]].append((p0 + pos, -1.0 / base))
+                    qlist[c.bus_lookup[int(b)]].append((q0 + pos, -1.0 / base))
 
         def csr(lists):
             ptr = np.zeros(nb + 1, dtype=np.int32)

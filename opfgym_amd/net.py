@@ -40,6 +40,10 @@ _TABLES = {
     'ext_grid': ['name', 'bus', 'vm_pu', 'va_degree', 'in_service'],
     'shunt': ['bus', 'p_mw', 'q_mvar', 'vn_kv', 'step', 'in_service'],
     'switch': ['bus', 'element', 'et', 'closed'],
+    # pandapower element types beyond those of the SimBench grids (static in the batched environment: no actuator / sampling)
+    'ward': ['name', 'bus', 'ps_mw', 'qs_mvar', 'pz_mw', 'qz_mvar', 'in_service'],
+    'impedance': ['name', 'from_bus', 'to_bus', 'rft_pu', 'xft_pu', 'rtf_pu', 'xtf_pu', 'sn_mva', 'in_service'],
+    'motor': ['name', 'bus', 'pn_mech_mw', 'cos_phi', 'efficiency_percent', 'loading_percent', 'scaling', 'in_service'],
     'poly_cost': ['element', 'et', 'cp0_eur', 'cp1_eur_per_mw',
                   'cp2_eur_per_mw2', 'cq0_eur', 'cq1_eur_per_mvar',
                   'cq2_eur_per_mvar2'],
@@ -244,9 +248,35 @@ def create_shunt(net, bus, q_mvar, p_mw=0.0, vn_kv=None, step=1,
                                       in_service=bool(in_service)), index)
 
 
-def create_switch(net, bus, element, et, closed=True, index=None) -> int:
-    return _append(net, 'switch', dict(bus=int(bus), element=int(element),
-                                       et=et, closed=bool(closed)), index)
+def create_switch(net, bus, element, et, closed=True, index=None, z_ohm=0.0) -> int:
+    row = dict(bus=int(bus), element=int(element), et=et, closed=bool(closed))
+    if z_ohm or 'z_ohm' in net['switch'].columns:          # (the column exists only in nets that use it)
+        row['z_ohm'] = float(z_ohm)
+    return _append(net, 'switch', row, index)
+
+
+def create_ward(net, bus, ps_mw, qs_mvar, pz_mw, qz_mvar, in_service=True, name=None, index=None) -> int:
+    """pandapower.create_ward: a constant-power part (ps, qs) and a constant-impedance part (pz, qz at 1 p.u.), consumption
+    positive."""
+    return _append(net, 'ward', dict(name=name, bus=int(bus), ps_mw=float(ps_mw), qs_mvar=float(qs_mvar), pz_mw=float(pz_mw),
+                                     qz_mvar=float(qz_mvar), in_service=bool(in_service)), index)
+
+
+def create_impedance(net, from_bus, to_bus, rft_pu, xft_pu, sn_mva, rtf_pu=None, xtf_pu=None, in_service=True, name=None,
+                     index=None) -> int:
+    """pandapower.create_impedance: a series impedance in per unit of its own `sn_mva`, which may differ by direction."""
+    return _append(net, 'impedance', dict(
+        name=name, from_bus=int(from_bus), to_bus=int(to_bus), rft_pu=float(rft_pu), xft_pu=float(xft_pu),
+        rtf_pu=float(rft_pu if rtf_pu is None else rtf_pu), xtf_pu=float(xft_pu if xtf_pu is None else xtf_pu),
+        sn_mva=float(sn_mva), in_service=bool(in_service)), index)
+
+
+def create_motor(net, bus, pn_mech_mw, cos_phi, efficiency_percent=100.0, loading_percent=100.0, scaling=1.0,
+                 in_service=True, name=None, index=None) -> int:
+    """pandapower.create_motor (the columns the power flow reads)."""
+    return _append(net, 'motor', dict(name=name, bus=int(bus), pn_mech_mw=float(pn_mech_mw), cos_phi=float(cos_phi),
+                                      efficiency_percent=float(efficiency_percent), loading_percent=float(loading_percent),
+                                      scaling=float(scaling), in_service=bool(in_service)), index)
 
 
 def create_poly_cost(net, element, et, cp1_eur_per_mw, cp0_eur=0.0,

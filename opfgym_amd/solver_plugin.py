@@ -16,7 +16,8 @@ import numpy as np
 import pandas as pd
 
 from . import capi
-from .case import KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, bus_injections, generator_dispatch, net_to_case
+from .case import (KIND_IMPEDANCE, KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, _table, bus_injections, generator_dispatch,
+                   net_to_case, static_consumption)
 
 
 class LoadflowNotConverged(Exception):
@@ -149,6 +150,34 @@ class BatchedPowerFlowSolver:
             part = takes_part(df).astype(float) if len(df) else 1.0
             net['res_' + tbl] = pd.DataFrame({'p_mw': df['p_mw'].to_numpy(float) * sc * part,
                                               'q_mvar': df['q_mvar'].to_numpy(float) * sc * part}, index=df.index)
+        # element types beyond the SimBench grids: wards (constant power + constant impedance at the solved voltage), motors,
+        # series impedances (the flows at both ends from the solved voltages and the branch's own stamps)
+        static = static_consumption(net)
+        if 'ward' in static:
+            df = net['ward']
+            part = takes_part(df)
+            vw = np.array([vm[bus_pos[int(b)]] for b in df['bus']])          # (the bus's voltage whether the ward is in service or not)
+            v2 = np.where(part, vw, 0.0) ** 2
+            net['res_ward'] = pd.DataFrame({'p_mw': part * (static['ward'][0] + df['pz_mw'].to_numpy(float) * v2),
+                                            'q_mvar': part * (static['ward'][1] + df['qz_mvar'].to_numpy(float) * v2),
+                                            'vm_pu': vw}, index=df.index)
+        if 'motor' in static:
+            df = net['motor']
+            part = takes_part(df).astype(float)
+            net['res_motor'] = pd.DataFrame({'p_mw': static['motor'][0] * part, 'q_mvar': static['motor'][1] * part}, index=df.index)
+        imp = _table(net, 'impedance')
+        if imp is not None:
+            cols = {c: np.zeros(len(imp)) for c in ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw', 'ql_mvar', 'i_from_ka', 'i_to_ka')}
+            v = r['vm'] * np.exp(1j * r['va'])
+            for k in np.flatnonzero(case.br_kind == KIND_IMPEDANCE):
+                pos, f, t = int(case.br_elem[k]), int(case.f[k]), int(case.t[k])
+                i_f, i_t = case.yff[k] * v[f] + case.yft[k] * v[t], case.ytf[k] * v[f] + case.ytt[k] * v[t]
+                s_f, s_t = v[f] * np.conj(i_f) * base, v[t] * np.conj(i_t) * base
+                cols['p_from_mw'][pos], cols['q_from_mvar'][pos], cols['p_to_mw'][pos], cols['q_to_mvar'][pos] = s_f.real, s_f.imag, s_t.real, s_t.imag
+                cols['pl_mw'][pos], cols['ql_mvar'][pos] = (s_f + s_t).real, (s_f + s_t).imag
+                cols['i_from_ka'][pos] = abs(i_f) * base / (np.sqrt(3.0) * case.vn_kv[f])
+                cols['i_to_ka'][pos] = abs(i_t) * base / (np.sqrt(3.0) * case.vn_kv[t])
+            net['res_impedance'] = pd.DataFrame(cols, index=imp.index)
         gen = net['gen']
         sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns and len(gen) else 1.0
         pg, qg, vg = np.zeros(len(gen)), np.zeros(len(gen)), np.zeros(len(gen))

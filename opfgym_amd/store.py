@@ -37,6 +37,18 @@ class ColumnStore:
             self.dynamic.add(key)
         return self.ranges[key][0]
 
+    def computed(self, table, col, values):
+        """Slots of a column that the net's table does not hold as such (a quantity derived from several of its columns,
+        constant per environment): the row template carries `values`."""
+        key = (table, col)
+        if key not in self.ranges:
+            vals = np.asarray(values, dtype=float)
+            assert len(vals) == len(self.net[table]), key
+            self.ranges[key] = (self.n, len(vals))
+            self.template.append(vals.copy())
+            self.n += len(vals)
+        return self.ranges[key][0]
+
     def rows(self, table, idxs):
         pos = self.net[table].index.get_indexer(np.asarray(idxs))
         if (pos < 0).any():

@@ -66,6 +66,9 @@ class PPC:
     bus_lookup: dict = field(default_factory=dict)     # net bus index -> ppc bus
     n_net_buses: int = 0                               # ppc buses >= this are auxiliary
     calc_angles: bool = False
+    # ---- pandapower's extra branch columns BR_R_ASYM / BR_X_ASYM: what the to side sees more than the from side ------
+    r_asym: np.ndarray = None
+    x_asym: np.ndarray = None
 
     @property
     def nb(self):
@@ -232,17 +235,27 @@ def _trafo3w_as_two_winding(t3):
     return out
 
 
+def motor_pq(mt):
+    """pandapower `_get_motor_pq`: electrical power of the motors from their mechanical rating, MW / Mvar per row
+    (in_service not applied)."""
+    scale = _get(mt, 'loading_percent', 100.0) / 100.0 * _get(mt, 'scaling', 1.0)
+    p_mw = _get(mt, 'pn_mech_mw', np.nan) / _get(mt, 'efficiency_percent', 100.0) * 100.0 * scale
+    s_mva = p_mw / _get(mt, 'cos_phi', np.nan)
+    return p_mw, np.sqrt(s_mva ** 2 - p_mw ** 2)
+
+
 def refuse_unmodelled(net):
     """`pp.runpp` models every element table of the net; this restatement covers bus, line, trafo, trafo3w,
     load, sgen, storage, gen, ext_grid, shunt and switch.  Anything else that is filled in would make the
-    oracle solve another grid than pandapower does, so it is an error, not a silent omission."""
+    oracle solve another grid than pandapower does, so it is an error, not a silent omission.  (Round 6: ward, impedance,
+    motor and closed bus-bus switches with z_ohm are covered too.)"""
     def rows(name):
         df = net[name] if name in net else None
         return df if df is not None and hasattr(df, 'columns') and len(df) else None
 
     def nonzero(df, col):
         return col in df.columns and bool(np.any(_get(df, col, 0.0) != 0.0))
-    for name in ('ward', 'xward', 'impedance', 'dcline', 'motor', 'asymmetric_load', 'asymmetric_sgen', 'svc',
+    for name in ('xward', 'dcline', 'asymmetric_load', 'asymmetric_sgen', 'svc',
                  'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc'):
         if rows(name) is not None:
             raise ValueError(f'oracle: element table {name!r} is not modelled')
@@ -251,8 +264,8 @@ def refuse_unmodelled(net):
         raise ValueError('oracle: ZIP loads (load.const_z_percent / const_i_percent) are not modelled')
     sw = rows('switch')
     if sw is not None:
-        if nonzero(sw, 'z_ohm'):
-            raise ValueError('oracle: switch.z_ohm is not modelled')
+        if 'z_ohm' in sw.columns and any(z != 0.0 and str(e) != 'b' for z, e in zip(np.nan_to_num(_get(sw, 'z_ohm', 0.0)), sw['et'])):
+            raise ValueError('oracle: switch.z_ohm at a line / transformer switch is not modelled')
         if any(str(e) == 't3' for e in sw['et']):
             raise ValueError("oracle: switch.et == 't3' is not modelled")
     gn = rows('gen')
@@ -282,8 +295,9 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
     sets = _Sets(n_bus)
     sw = net['switch'] if 'switch' in net and len(net['switch']) else None
     if sw is not None:
-        for b, e, et, closed in zip(sw['bus'], sw['element'], sw['et'], sw['closed']):
-            if et == 'b' and bool(closed) and int(b) in pos_of and int(e) in pos_of:
+        sw_z = np.nan_to_num(_get(sw, 'z_ohm', 0.0))
+        for b, e, et, closed, z in zip(sw['bus'], sw['element'], sw['et'], sw['closed'], sw_z):
+            if et == 'b' and bool(closed) and int(b) in pos_of and int(e) in pos_of and not z > 0.0:     # (z_ohm > 0: a branch, below)
                 sets.join(pos_of[int(b)], pos_of[int(e)])
     roots = sorted({sets.find(i) for i in range(n_bus)})
     root_id = {r: k for k, r in enumerate(roots)}
@@ -301,11 +315,12 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
     else:
         calc_angles = bool(calculate_voltage_angles)
 
-    f, t, r, x, b, tap, shift, status, tbl, bpos, bside = [], [], [], [], [], [], [], [], [], [], []
+    f, t, r, x, b, tap, shift, status, tbl, bpos, bside, r_as, x_as = [], [], [], [], [], [], [], [], [], [], [], [], []
 
-    def add_branch(fb, tb, r_, x_, b_, tap_, shift_, on, table, pos, side=''):
+    def add_branch(fb, tb, r_, x_, b_, tap_, shift_, on, table, pos, side='', r_asym=0.0, x_asym=0.0):
         f.append(fb); t.append(tb); r.append(r_); x.append(x_); b.append(b_); tap.append(tap_)
         shift.append(shift_); status.append(1 if on else 0); tbl.append(table); bpos.append(pos); bside.append(side)
+        r_as.append(r_asym); x_as.append(x_asym)
 
     # ---- lines ---------------------------------------------------------------------------
     ln = net['line']
@@ -369,6 +384,30 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
                 add_branch(fb, tb, rr[0], xx[0], bb[0], ratio, e['shift'][k] if calc_angles else 0.0,
                            on[k] and all(bus_on[v] for v in ends.values()), 'trafo3w', k, side)
 
+    # ---- impedances (pandapower `_calc_impedance_parameters_from_dataframe`): p.u. on the element's sn_mva -> on the net's;
+    # the to-side values go into the asymmetry columns as differences ----------------------------------------------------
+    imp = net['impedance'] if 'impedance' in net and len(net['impedance']) else None
+    if imp is not None:
+        on = _flag(imp, 'in_service')
+        to_net = base_mva / _get(imp, 'sn_mva', np.nan)
+        rft, xft = _get(imp, 'rft_pu', np.nan) * to_net, _get(imp, 'xft_pu', np.nan) * to_net
+        rtf, xtf = _get(imp, 'rtf_pu', np.nan) * to_net, _get(imp, 'xtf_pu', np.nan) * to_net
+        for k in range(len(imp)):
+            fb, tb = pos_of[int(imp['from_bus'].iloc[k])], pos_of[int(imp['to_bus'].iloc[k])]
+            add_branch(int(lookup_pos[fb]), int(lookup_pos[tb]), rft[k], xft[k], 0.0, 1.0, 0.0,
+                       on[k] and bus_on[fb] and bus_on[tb], 'impedance', k, r_asym=rtf[k] - rft[k], x_asym=xtf[k] - xft[k])
+
+    # ---- closed bus-bus switches with an impedance (pandapower `_calc_switch_parameter`; runpp's switch_rx_ratio = 2):
+    # r = z_ohm * rx / sqrt(1 + rx^2), x = z_ohm / sqrt(1 + rx^2), over the base impedance of the switch's bus ---------------
+    if sw is not None:
+        rx = 2.0
+        for k, (sb, e, et, closed, z) in enumerate(zip(sw['bus'], sw['element'], sw['et'], sw['closed'], sw_z)):
+            if et == 'b' and bool(closed) and z > 0.0 and int(sb) in pos_of and int(e) in pos_of:
+                fb, tb = pos_of[int(sb)], pos_of[int(e)]
+                base_z = vn[fb] ** 2 / base_mva
+                add_branch(int(lookup_pos[fb]), int(lookup_pos[tb]), z * rx / np.sqrt(1.0 + rx * rx) / base_z,
+                           z / np.sqrt(1.0 + rx * rx) / base_z, 0.0, 1.0, 0.0, bus_on[fb] and bus_on[tb], 'switch', k)
+
     # ---- open switches at branches (pandapower `_switch_branches`) ------------------------------------
     if sw is not None:
         for et, table in (('l', 'line'), ('t', 'trafo')):
@@ -415,6 +454,24 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
                 i = bus_lookup[int(bus)]
                 pd_[i] += sign * pv[k] * sc[k]
                 qd_[i] += sign * qv[k] * sc[k]
+
+    # ---- wards: constant-power part as demand, constant-impedance part as a shunt at 1 p.u.; motors as demand
+    # (pandapower `_calc_pq_elements_and_add_on_ppc`, `_get_motor_pq`, `_calc_shunts_and_add_on_ppc`) ---------------------
+    wd = net['ward'] if 'ward' in net and len(net['ward']) else None
+    if wd is not None:
+        on = _flag(wd, 'in_service')
+        for k, bus in enumerate(wd['bus']):
+            if on[k]:
+                i = bus_lookup[int(bus)]
+                pd_[i] += float(wd['ps_mw'].iloc[k]); qd_[i] += float(wd['qs_mvar'].iloc[k])
+                gs[i] += float(wd['pz_mw'].iloc[k]); bs[i] -= float(wd['qz_mvar'].iloc[k])
+    mt = net['motor'] if 'motor' in net and len(net['motor']) else None
+    if mt is not None:
+        on = _flag(mt, 'in_service')
+        p_m, q_m = motor_pq(mt)
+        for k, bus in enumerate(mt['bus']):
+            if on[k]:
+                pd_[bus_lookup[int(bus)]] += p_m[k]; qd_[bus_lookup[int(bus)]] += q_m[k]
 
     # ---- shunts (pandapower `_calc_shunts_and_add_on_ppc`) ---------------------------------------------------
     sh_df = net['shunt'] if 'shunt' in net else None
@@ -463,7 +520,8 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
               g_bus=np.array(g_bus, dtype=np.int64), g_p=np.array(g_p, dtype=float),
               g_qmin=np.array(g_qmin, dtype=float), g_qmax=np.array(g_qmax, dtype=float),
               g_vg=np.array(g_vg, dtype=float), g_status=np.array(g_status, dtype=np.int64), g_table=g_table,
-              g_pos=np.array(g_pos, dtype=np.int64), bus_lookup=bus_lookup, n_net_buses=nb, calc_angles=calc_angles)
+              g_pos=np.array(g_pos, dtype=np.int64), bus_lookup=bus_lookup, n_net_buses=nb, calc_angles=calc_angles,
+              r_asym=np.array(r_as, dtype=float), x_asym=np.array(x_as, dtype=float))
     if not (ppc.bus_type == REF).any():
         raise ValueError('net has no in-service ext_grid (no slack bus)')
     if check_connectivity:

@@ -57,6 +57,11 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
       ideal phase shifter (tap_phase_shifter, tap_step_degree)   ideal_phase_shifter_is_a_changed_vector_group (in a loop with a plain
                                                                  transformer: the circulating flow; hv and lv side)
       storages (sign convention, scaling)                        storage_is_a_load
+      ward (constant power + constant impedance)                ward_is_a_load_and_a_shunt
+      motor (pn_mech, efficiency, loading, cos_phi)              motor_is_a_load
+      series impedance, both directions alike                    symmetric_impedance_is_a_line_without_charging (also 3 r I^2 losses)
+      series impedance, directions differing                     tests/test_beyond_simbench_elements.py (by hand: each side's own equation)
+      closed bus-bus switch with z_ohm (switch_rx_ratio = 2)     bus_bus_switch_with_impedance_is_a_short_line
       generators sharing a bus (pfsoln's split)                 tests/test_generator_dispatch.py (by hand: shares of the ranges)
       `_is_elements` zero rule of result rows                   tests/test_gpu_env.py::test_units_on_a_de_energised_island_cost_nothing
       DC start values                                            the converged solution does not depend on them; iteration counts
@@ -96,10 +101,13 @@ def branch_admittances(ppc: PPC, status=None):
     ys = stat / (ppc.r + 1j * ppc.x)
     bc = stat * ppc.b
     tap = ppc.tap * np.exp(1j * np.pi / 180.0 * ppc.shift)
-    ytt = ys + 1j * bc / 2.0
-    yff = ytt / (tap * np.conj(tap))
+    # pandapower's makeYbus (`branch_vectors`): the to side of a branch with BR_R_ASYM / BR_X_ASYM sees its own series
+    # admittance (net.impedance with rtf_pu != rft_pu)
+    ys_t = ys if ppc.r_asym is None else stat / ((ppc.r + ppc.r_asym) + 1j * (ppc.x + ppc.x_asym))
+    ytt = ys_t + 1j * bc / 2.0
+    yff = (ys + 1j * bc / 2.0) / (tap * np.conj(tap))
     yft = -ys / np.conj(tap)
-    ytf = -ys / tap
+    ytf = -ys_t / tap
     return yff, yft, ytf, ytt
 
 
@@ -440,3 +448,33 @@ def write_results(net, ppc: PPC, sol):
         net['res_' + tbl] = pd.DataFrame(
             {'p_mw': df['p_mw'].to_numpy(float) * sc * part if len(df) else [],
              'q_mvar': df['q_mvar'].to_numpy(float) * sc * part if len(df) else []}, index=df.index)
+    # ---- element types beyond the SimBench grids (pandapower results_bus.py / results_branch.py) ------------------------
+    def alive_at(df):
+        part = np.array([bus_alive.get(int(b), False) for b in df['bus']], dtype=bool)
+        return part & (df['in_service'].to_numpy(bool) if 'in_service' in df.columns else True)
+    if 'ward' in net and len(net['ward']):
+        df = net['ward']
+        part = alive_at(df)
+        vmw = np.array([vm[net['bus'].index.get_loc(int(b))] for b in df['bus']])      # (the bus's voltage, in service or not)
+        v2 = np.where(part, vmw, 0.0) ** 2
+        net['res_ward'] = pd.DataFrame({'p_mw': part * (df['ps_mw'].to_numpy(float) + df['pz_mw'].to_numpy(float) * v2),
+                                        'q_mvar': part * (df['qs_mvar'].to_numpy(float) + df['qz_mvar'].to_numpy(float) * v2),
+                                        'vm_pu': vmw}, index=df.index)
+    if 'motor' in net and len(net['motor']):
+        df = net['motor']
+        p_m, q_m = pd2ppc.motor_pq(df)
+        part = alive_at(df).astype(float)
+        net['res_motor'] = pd.DataFrame({'p_mw': p_m * part, 'q_mvar': q_m * part}, index=df.index)
+    if 'impedance' in net and len(net['impedance']):
+        df = net['impedance']
+        s_f, s_t = branch_flows(ppc, np.nan_to_num(v, nan=0.0), sol['status'])
+        cols = {c: np.zeros(len(df)) for c in ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw', 'ql_mvar', 'i_from_ka', 'i_to_ka')}
+        for k in np.flatnonzero(np.array([tb == 'impedance' for tb in ppc.br_table], dtype=bool)):
+            pos = int(ppc.br_pos[k])
+            sf, st_ = s_f[k] * ppc.base_mva, s_t[k] * ppc.base_mva
+            cols['p_from_mw'][pos], cols['q_from_mvar'][pos], cols['p_to_mw'][pos], cols['q_to_mvar'][pos] = sf.real, sf.imag, st_.real, st_.imag
+            cols['pl_mw'][pos], cols['ql_mvar'][pos] = (sf + st_).real, (sf + st_).imag
+            with np.errstate(divide='ignore', invalid='ignore'):
+                cols['i_from_ka'][pos] = abs(sf) / (np.sqrt(3.0) * abs(v[ppc.f[k]]) * ppc.base_kv[ppc.f[k]])
+                cols['i_to_ka'][pos] = abs(st_) / (np.sqrt(3.0) * abs(v[ppc.t[k]]) * ppc.base_kv[ppc.t[k]])
+        net['res_impedance'] = pd.DataFrame(cols, index=df.index)

@@ -49,7 +49,7 @@ class OracleSide:
         n_aux = case.nb - len(first)
         self.bus_map = np.array([self.ppc.bus_lookup[first[i]] if i in first else self.ppc.n_net_buses + (i - (case.nb - n_aux))
                                  for i in range(case.nb)])
-        tables = {0: 'line', 1: 'trafo', 2: 'trafo3w'}
+        tables = {0: 'line', 1: 'trafo', 2: 'trafo3w', 3: 'impedance', 4: 'switch'}
         sides = case.br_side if case.br_side is not None else np.zeros(case.nbr, int)
         self.br_map = np.array([self.ppc.branch_of(tables[int(kd)], int(e), ('hv', 'mv', 'lv')[int(sd)] if kd == 2 else '')
                                 for kd, e, sd in zip(case.br_kind, case.br_elem, sides)])
@@ -81,7 +81,8 @@ class OracleSide:
         sol = po.solve(ppc, enforce_q_lims=enforce_q_lims, tol=tol, max_it=max_it, status=status, init=init)
         v = sol['V'][self.bus_map]
         ld = po.loading_percent(ppc, self.net, sol['V'], sol['status'])
-        loading = np.array([ld[('line', 'trafo', 'trafo3w')[int(kd)]][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])   # (trafo3w: the transformer's value on each of its three windings)
+        # (trafo3w: the transformer's value on each of its three windings; impedances and switch branches: no rating, 0 %)
+        loading = np.array([ld[('line', 'trafo', 'trafo3w')[int(kd)]][int(e)] if kd < 3 else 0.0 for kd, e in zip(case.br_kind, case.br_elem)])
         s_calc = (sol['V'] * np.conj(sol['ybus'] @ np.nan_to_num(sol['V'])))[self.bus_map]
         sref = np.stack([s_calc.real[self.ref] - p[self.ref], s_calc.imag[self.ref] - q[self.ref]], axis=1)
         return dict(vm=np.abs(v), va=np.angle(v), loading=loading, s_ref=sref, converged=sol['converged'],

@@ -258,12 +258,105 @@ def storage_is_a_load():
     return a, b, lambda ra, rb: _compare_all(ra, rb)
 
 
-CASES = {f.__name__: f for f in (ideal_phase_shifter_is_a_changed_vector_group, storage_is_a_load, bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
+# ---- element types beyond the SimBench grids (round 6; VERDICT r05 "missing" #5) -----------------------------------------
+def ward_is_a_load_and_a_shunt():
+    """pandapower's ward: a constant-power part (ps_mw, qs_mvar) and a constant-impedance part (pz_mw, qz_mvar at 1 p.u. of the
+    bus — a shunt whose rated voltage is the bus's own)."""
+    a, _ = _two_winding_pair()
+    bus = int(a.bus.index[3])
+    N.create_ward(a, bus, ps_mw=1.1, qs_mvar=0.35, pz_mw=0.6, qz_mvar=-1.4)
+    N.finalize(a)
+    b, _ = _two_winding_pair()
+    N.create_load(b, bus, 1.1, 0.35)
+    N.create_shunt(b, bus, q_mvar=-1.4, p_mw=0.6)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb)
+        vm = float(ra.res_bus.vm_pu.at[bus])
+        _same(ra.res_ward.p_mw, [1.1 + 0.6 * vm ** 2], S_TOL, 'res_ward.p_mw')
+        _same(ra.res_ward.q_mvar, [0.35 - 1.4 * vm ** 2], S_TOL, 'res_ward.q_mvar')
+        _same(ra.res_ward.vm_pu, [vm], VM_TOL, 'res_ward.vm_pu')
+    return a, b, compare
+
+
+def motor_is_a_load():
+    """pandapower's motor: P = pn_mech / efficiency x loading x scaling, Q from cos_phi (inductive)."""
+    a, _ = _two_winding_pair()
+    bus = int(a.bus.index[2])
+    N.create_motor(a, bus, pn_mech_mw=2.4, cos_phi=0.86, efficiency_percent=93.0, loading_percent=70.0, scaling=1.5)
+    N.create_motor(a, bus, pn_mech_mw=9.0, cos_phi=0.8, in_service=False)
+    N.finalize(a)
+    p = 2.4 / 0.93 * 0.70 * 1.5
+    q = p * np.tan(np.arccos(0.86))
+    b, _ = _two_winding_pair()
+    N.create_load(b, bus, p, q)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb)
+        _same(ra.res_motor.p_mw, [p, 0.0], S_TOL, 'res_motor.p_mw')
+        _same(ra.res_motor.q_mvar, [q, 0.0], S_TOL, 'res_motor.q_mvar')
+    return a, b, compare
+
+
+def _line_gap_pair():
+    """The 110 / 20 kV pair with the 20 kV line cut: its far half hangs on a new bus `gap` that the case connects to bus 2."""
+    net, _ = _two_winding_pair()
+    gap = N.create_bus(net, 20.)
+    net.line.at[net.line.index[1], 'from_bus'] = gap
+    return net, int(net.bus.index[2]), gap
+
+
+def symmetric_impedance_is_a_line_without_charging():
+    """A series impedance z (p.u. of its own sn_mva) with the same value in both directions is a line of z sn_net / sn_imp
+    x vn^2 / sn_net ohm without capacitance."""
+    a, near, gap = _line_gap_pair()
+    N.create_impedance(a, near, gap, rft_pu=0.004, xft_pu=0.011, sn_mva=25.0)
+    N.finalize(a)
+    b, near, gap = _line_gap_pair()
+    z_base = 20.0 ** 2 / 25.0
+    N.create_line_from_parameters(b, near, gap, 1.0, 0.004 * z_base, 0.011 * z_base, 0.0, 1.0)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb, lines=False)
+        _same(_col(ra, 'res_line', 'loading_percent'), _col(rb, 'res_line', 'loading_percent')[:2], LD_TOL, 'line loading')
+        # (the flows of the impedance: what leaves the near bus arrives, less the losses r |I|^2, at the other)
+        r = ra.res_impedance
+        i_ka = float(r.i_from_ka.iloc[0])
+        assert abs(i_ka - float(r.i_to_ka.iloc[0])) < 1e-9
+        _same(r.pl_mw, [3 * (0.004 * z_base) * i_ka ** 2], S_TOL, 'pl_mw = 3 r I^2')
+        _same(r.ql_mvar, [3 * (0.011 * z_base) * i_ka ** 2], S_TOL, 'ql_mvar = 3 x I^2')
+        _same(_col(rb, 'res_line', 'loading_percent')[2], i_ka / 1.0 * 100.0, LD_TOL, 'i_ka of the twin line')
+    return a, b, compare
+
+
+def bus_bus_switch_with_impedance_is_a_short_line():
+    """A CLOSED bus-bus switch with z_ohm > 0 does not fuse its buses: pandapower inserts a branch of |z| = z_ohm whose r / x
+    ratio is `runpp`'s switch_rx_ratio (default 2) — r = 2 z / sqrt(5), x = z / sqrt(5)."""
+    a, near, gap = _line_gap_pair()
+    N.create_switch(a, near, gap, 'b', closed=True, z_ohm=0.08)
+    N.finalize(a)
+    b, near, gap = _line_gap_pair()
+    N.create_line_from_parameters(b, near, gap, 1.0, 0.08 * 2 / np.sqrt(5.0), 0.08 / np.sqrt(5.0), 0.0, 1.0)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb, lines=False)
+        _same(_col(ra, 'res_line', 'loading_percent'), _col(rb, 'res_line', 'loading_percent')[:2], LD_TOL, 'line loading')
+    return a, b, compare
+
+
+CASES = {f.__name__: f for f in (ward_is_a_load_and_a_shunt, motor_is_a_load, symmetric_impedance_is_a_line_without_charging,
+                                 bus_bus_switch_with_impedance_is_a_short_line,
+                                 ideal_phase_shifter_is_a_changed_vector_group, storage_is_a_load, bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
                                  parallel_two_is_two_elements, vector_group_shift_turns_the_angles_behind_it,
                                  shunt_is_a_constant_impedance_load, two_ext_grids_at_one_set_point_are_a_fused_slack,
                                  open_bus_bus_switch_is_no_switch)}
 # pairs that must compile to the SAME bus admittance matrix in the product's converter (no solve needed to compare them)
-SAME_ADMITTANCES = ('ideal_phase_shifter_is_a_changed_vector_group', 'storage_is_a_load', 'lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
+SAME_ADMITTANCES = ('ward_is_a_load_and_a_shunt', 'motor_is_a_load', 'symmetric_impedance_is_a_line_without_charging',
+                    'bus_bus_switch_with_impedance_is_a_short_line', 'ideal_phase_shifter_is_a_changed_vector_group', 'storage_is_a_load', 'lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
                     'open_bus_bus_switch_is_no_switch', 'bus_bus_switch_is_one_bus')
 
 

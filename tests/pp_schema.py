@@ -4,7 +4,7 @@ pandapower (`create_empty_network` + the `create_*` functions; `>=2.13.1,<3.0`, 
 reference) gives every element table about twice the columns the converters need, with its own dtypes:
 `uint32` bus references, `object` columns holding None / NaN / strings (`name`, `std_type`, `type`, `zone`,
 `tap_side`), boolean flags, NaN `tap_pos` for transformers without a tap changer, integer-valued floats, and a
-set of element tables that are present but EMPTY (ward, xward, impedance, dcline, motor, ...).  The column lists
+set of element tables that are present but EMPTY (xward, dcline, ... — and ward, impedance, motor where the net has none).  The column lists
 below are restated from pandapower's published `create.py` / `create_empty_network` (from memory — pandapower is
 not installed here), so they describe the SHAPE the converters must survive, nothing numeric.
 """
@@ -117,6 +117,14 @@ def dress_as_pandapower(net, seed=0):
             net[tbl]['name'] = pd.Series([f'{tbl} {i}' if i % 3 else None for i in range(len(net[tbl]))],
                                          index=net[tbl].index, dtype=object)
     for tbl, cols in EMPTY_TABLES.items():
+        if tbl in net and len(net[tbl]):              # (ward / impedance / motor rows of the net itself: pandapower's columns and dtypes on them)
+            df = net[tbl]
+            for c, d in cols:
+                if c not in df.columns:
+                    df[c] = pd.Series([None if d is object else np.nan] * len(df), index=df.index, dtype=object if d is object else 'f8')
+                elif d in ('u4', 'i8'):
+                    df[c] = df[c].astype(np.uint32 if d == 'u4' else np.int64)
+            continue
         net[tbl] = pd.DataFrame({c: pd.Series(dtype=(object if d is object else d)) for c, d in cols})
     net['std_types'] = {'line': {}, 'trafo': {}, 'trafo3w': {}}
     net['version'] = '2.13.1'
@@ -141,18 +149,13 @@ def unmodelled_variants():
         return f
     b = 1
     return [
-        ('ward', add_row('ward', bus=b, ps_mw=0.1, qs_mvar=0.05, in_service=True)),
         ('xward', add_row('xward', bus=b, ps_mw=0.1, r_ohm=0.1, x_ohm=1.0, vm_pu=1.0, in_service=True)),
-        ('impedance', add_row('impedance', from_bus=1, to_bus=2, rft_pu=0.01, xft_pu=0.05, rtf_pu=0.01, xtf_pu=0.05,
-                              sn_mva=10.0, in_service=True)),
         ('dcline', add_row('dcline', from_bus=1, to_bus=2, p_mw=1.0, vm_from_pu=1.0, vm_to_pu=1.0, in_service=True)),
-        ('motor', add_row('motor', bus=b, pn_mech_mw=0.1, cos_phi=0.9, efficiency_percent=95.0, loading_percent=80.0,
-                          scaling=1.0, in_service=True)),
         ('asymmetric_load', add_row('asymmetric_load', bus=b, p_a_mw=0.01, in_service=True)),
         ('svc', add_row('svc', bus=b, x_l_ohm=1.0, x_cvar_ohm=-10.0, set_vm_pu=1.0, in_service=True)),
         ('load.const_z_percent', set_col('load', 'const_z_percent', 30.0)),
         ('load.const_i_percent', set_col('load', 'const_i_percent', 10.0)),
-        ('switch.z_ohm', set_col('switch', 'z_ohm', 0.05)),
+        ('switch.z_ohm', lambda net: net['switch'].__setitem__('z_ohm', np.where(net['switch']['et'] == 'l', 0.05, 0.0))),   # (at LINE switches; bus-bus: modelled)
         ('switch.et', set_col('switch', 'et', 't3')),
         ('gen.slack', set_col('gen', 'slack', True)),
         ('trafo.tap_dependent_impedance', set_col('trafo', 'tap_dependent_impedance', True)),

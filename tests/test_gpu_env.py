@@ -1862,3 +1862,54 @@ def test_generators_sharing_a_bus_report_their_own_reactive_power():
     scale = qcon.autoscale_factor(d.net)
     assert np.allclose(_np(out[4]['violations'])[:, -1], viol * (scale if scale else 1.0), rtol=1e-9, atol=R_TOL)
     assert (_np(out[4]['valids'])[:, -1] == (viol == 0)).all()
+
+
+def test_env_on_a_grid_with_wards_motors_impedances_and_a_switch_impedance():
+    """Element types beyond the SimBench grids (missing #5): wards (constant power + shunt), motors, series
+    impedances (one with different values per direction) and a closed bus-bus switch with z_ohm in the net of a batched
+    environment — static parts of the grid there (nothing samples or actuates them): the reference's VoltageControl definition
+    for mv-small on that net, every row against the oracle's environment (which hands the net to the oracle's `runpp`)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import beyond_simbench
+    from opfgym_amd import envs
+    from oracle import env_oracle
+    from env_cases import reward_dict
+    kw = dict(simbench_network_name='mv-small', seed=3)
+
+    def definition():
+        d = envs.VoltageControl(batch_size=1, defer_device=True, **kw).definition
+        beyond_simbench.add_elements(d.net)
+        return d
+    B = 24
+    env = envs.VoltageControl(batch_size=B, device='cuda:0', definition=definition(), **kw)
+    assert {('ward', '_p_mw'), ('motor', '_q_mvar')} <= set(env.store.ranges)
+    h = envs.VoltageControl(batch_size=1, defer_device=True, definition=definition(), **kw)
+    d = h.host_definition()
+    orc = env_oracle.EnvOracle(
+        d['net'], d['act_keys'], d['obs_keys'], d['profiles'], d['constraints'],
+        reward_dict(d['reward_function']), env_oracle.TAILS['VoltageControl'],
+        autoscale_actions=h.autoscale_actions, diff_action_step_size=h.diff_action_step_size,
+        clipped_action_penalty=h.clipped_action_penalty, diff_objective=h.diff_objective,
+        add_mean_obs=h.add_mean_obs, pf_for_obs=h.pf_for_obs, steps_per_episode=h.steps_per_episode,
+        n_minus_one_keys=h.n_minus_one_keys, not_converged_penalty=h.not_converged_penalty,
+        data=h.train_data, state_keys=h.state_keys, sampling_params=h.sampling_params,
+        bus_wise_obs=h.bus_wise_obs, multi_stage=False, split=(h.test_steps, h.validation_steps, h.train_steps))
+    rng = np.random.default_rng(9)
+    steps = rng.choice(env.train_steps, B)
+    actions = rng.random((B, env.n_actions))
+    env.reset(options={'step': steps})
+    out = env.step(actions)
+    assert _np(out[4]['converged']).all()
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert ref['converged']
+        _check_step(env, out, dict(ref, obs_step=ref['obs']), k)
+    # (the static elements take part: without them the voltages differ by far more than the tolerance)
+    plain = envs.VoltageControl(batch_size=B, device='cuda:0', **kw)
+    plain.reset(options={'step': steps})
+    plain.step(actions)
+    n_common = _np(plain.result_table('bus', 'vm_pu')).shape[1]
+    assert np.abs(_np(plain.result_table('bus', 'vm_pu')) - _np(env.result_table('bus', 'vm_pu'))[:, :n_common]).max() > 1e-4

@@ -19,11 +19,22 @@ def _shared_bus_grid():
     return simbench_build.shared_bus_reactive_setup(net)
 
 
-@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', 'mv-small', 'hv-small', 'mv-3w', 'hv-small-shared-gen-buses'])
+def _beyond_simbench_grid():
+    # mv-small with wards, motors, series impedances (one asymmetric) and a bus-bus switch with an impedance (missing #5)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import beyond_simbench
+    return beyond_simbench.grid()[0]
+
+
+@pytest.mark.parametrize('code', ['case9', '1-LV-rural1--0-sw', 'mv-small', 'hv-small', 'mv-3w', 'hv-small-shared-gen-buses',
+                                  'mv-small-beyond-simbench'])
 def test_plugin_matches_oracle_tables(code):
     from opfgym_amd import grids, power_flow_solver
     from oracle import pf_oracle as po
-    net = grids.case9() if code == 'case9' else _shared_bus_grid() if code == 'hv-small-shared-gen-buses' else grids.get_grid(code)[0]
+    net = grids.case9() if code == 'case9' else _shared_bus_grid() if code == 'hv-small-shared-gen-buses' else \
+        _beyond_simbench_grid() if code == 'mv-small-beyond-simbench' else grids.get_grid(code)[0]
     if code == 'case9':
         net.gen['min_q_mvar'], net.gen['max_q_mvar'] = -8.0, 8.0        # make the q-limits bind
     ref = copy.deepcopy(net)
@@ -33,9 +44,16 @@ def test_plugin_matches_oracle_tables(code):
                            ('res_line', ('loading_percent',), 1e-6), ('res_trafo', ('loading_percent',), 1e-6),
                            ('res_trafo3w', ('loading_percent',), 1e-6),
                            ('res_ext_grid', ('p_mw', 'q_mvar'), 1e-6), ('res_sgen', ('p_mw', 'q_mvar'), 0),
-                           ('res_load', ('p_mw', 'q_mvar'), 0), ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6)):
+                           ('res_load', ('p_mw', 'q_mvar'), 0), ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6),
+                           ('res_ward', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6), ('res_motor', ('p_mw', 'q_mvar'), 1e-12),
+                           ('res_impedance', ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw', 'ql_mvar', 'i_from_ka',
+                                              'i_to_ka'), 1e-6)):
         if tbl == 'res_trafo3w' and not len(net['trafo3w']):
             continue
+        if tbl in ('res_ward', 'res_motor', 'res_impedance'):
+            if code != 'mv-small-beyond-simbench':
+                continue
+            assert len(ref[tbl]) >= 2
         for col in cols:
             a, b = net[tbl][col].to_numpy(float), ref[tbl][col].to_numpy(float)
             assert a.shape == b.shape

@@ -54,11 +54,12 @@ def _compare(net, tol=1e-9):
     i_f = np.abs(case.yff * v_case[case.f] + case.yft * v_case[case.t])
     i_t = np.abs(case.ytf * v_case[case.f] + case.ytt * v_case[case.t])
     mine = np.maximum(i_f * case.kf, i_t * case.kt)
-    two = case.br_kind != 2
+    two = case.br_kind < 2          # (lines and two-winding transformers; impedances and switch branches have no loading)
+    three = case.br_kind == 2
     theirs = np.array([ld['line' if kd == 0 else 'trafo'][int(e)] for kd, e in zip(case.br_kind[two], case.br_elem[two])])
     assert np.allclose(mine[two], theirs, rtol=1e-9, atol=1e-9), np.abs(mine[two] - theirs).max()
-    for pos in np.unique(case.br_elem[~two]):          # three-winding transformers: the worst of the three terminals
-        assert np.isclose(mine[~two & (case.br_elem == pos)].max(), ld['trafo3w'][int(pos)], rtol=1e-9, atol=1e-9)
+    for pos in np.unique(case.br_elem[three]):          # three-winding transformers: the worst of the three terminals
+        assert np.isclose(mine[three & (case.br_elem == pos)].max(), ld['trafo3w'][int(pos)], rtol=1e-9, atol=1e-9)
     return case, ppc
 
 
@@ -171,6 +172,25 @@ def _random_net(rng):
     t_sw = int(rng.integers(0, 2))
     end = 'hv_bus' if rng.random() < 0.5 else 'lv_bus'
     ppn.create_switch(net, int(net.trafo[end].iloc[t_sw]), int(net.trafo.index[t_sw]), 't', closed=bool(rng.random() < 0.5))
+    # element types beyond the SimBench grids (drawn last: the nets of earlier rounds keep their parameters): wards, motors,
+    # series impedances (a third of them with different values per direction), a closed bus-bus switch with an impedance
+    if rng.random() < 0.7:
+        for b in rng.choice(mv, 2, replace=False):
+            ppn.create_ward(net, int(b), float(rng.uniform(0.0, 0.4)), float(rng.uniform(-0.1, 0.2)), float(rng.uniform(0.0, 0.3)),
+                            float(rng.uniform(-0.3, 0.3)), in_service=bool(rng.random() > 0.2))
+        ppn.create_ward(net, extra, 0.05, 0.02, 0.03, -0.04)                  # (on a bus fused behind a closed switch)
+        ppn.create_motor(net, int(rng.choice(mv)), float(rng.uniform(0.05, 0.6)), float(rng.uniform(0.7, 0.95)),
+                         float(rng.uniform(85.0, 98.0)), float(rng.uniform(40.0, 110.0)), scaling=float(rng.uniform(0.5, 1.5)))
+        ppn.create_motor(net, lv[1], 0.01, 0.8, in_service=bool(rng.random() > 0.5))
+        for a_, b_ in ((mv[1], mv[5]), (hv[1], hv[3])):
+            r_, x_ = float(rng.uniform(0.002, 0.02)), float(rng.uniform(0.01, 0.08))
+            asym_ = rng.random() < 0.34
+            ppn.create_impedance(net, a_, b_, r_, x_, float(rng.choice([10.0, 40.0, 100.0])),
+                                 rtf_pu=r_ * float(rng.uniform(0.8, 1.3)) if asym_ else None,
+                                 xtf_pu=x_ * float(rng.uniform(0.8, 1.3)) if asym_ else None, in_service=bool(rng.random() > 0.15))
+        far = ppn.create_bus(net, 20.0)
+        ppn.create_load(net, far, 0.15, 0.03)
+        ppn.create_switch(net, mv[2], far, 'b', closed=True, z_ohm=float(rng.uniform(0.01, 0.5)))
     ppn.finalize(net)
     return net
 
