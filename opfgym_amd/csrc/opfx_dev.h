@@ -914,6 +914,12 @@ constexpr int POLAR_R = 4;
 // after the prologue, and the 2 304 B row per 144-bus instance was written through to HBM for every instance (20 MB of the 92 MB a
 // config-2 launch writes, EXPERIMENTS #33).  A register array wants a compile-time index: the bus rounds of phase A are unrolled
 // over the POLAR_R rounds such a grid can have (round r of a lane is bus lane + 64 r, the map of the polar shadow).
+#ifndef OPFX_POLAR_DC           // (the polar shadow also in the DC-start kernels: round 6; 0 = as before, for A/B builds)
+#define OPFX_POLAR_DC 1
+#endif
+#ifndef OPFX_PQREG_DC           // (... also in the DC-start kernels: 256 VGPRs + 124 B of scratch — developer probe, EXPERIMENTS #36)
+#define OPFX_PQREG_DC 0
+#endif
 #ifndef OPFX_PQREG
 #define OPFX_PQREG 1
 #endif
@@ -1149,11 +1155,12 @@ __device__ __forceinline__ void piv_argmin(double piv, int pbus, double* piv_out
 // THE NEWTON LOOP ITSELF (`dc_pass`, kernels instantiated with DC) whose phase A writes B' instead of the Jacobian and
 // whose phase D sets the angles — phases B / C and the dense tail's register chain are the loop's own code, not a second
 // inlined copy (round 3 had one: the wave-team kernels went to 255-256 VGPRs + 36 B of scratch, k_solve to 716 B).
-template <bool PK>
-__device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int first, int stride, int lane) {
+// PQ: the scheduled P of the lane's buses comes from registers (single-wave PQREG kernels, `pol`: rounds at compile-time positions)
+template <bool PK, bool PQ = false>
+__device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int first, int stride, int lane, const Polar* pol = nullptr) {
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
-  for (int r = first; r < P.ra; r += stride) {
+  auto row_round = [&](const int r, const bool from_regs, const double p_reg) __attribute__((always_inline)) {
     const ARound a = load_around(P, r, lane);
     const double* dc = P.lp_dc + (size_t)r * (KA + 2) * WAVE + lane;
     double bij[KA];
@@ -1161,9 +1168,9 @@ __device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int firs
     for (int k = 0; k < KA; ++k) bij[k] = dc[k * WAVE];
     const double bii = dc[KA * WAVE], cst = dc[(KA + 1) * WAVE];
     const int i = lane + WAVE * r;
-    if (i >= nb) continue;
-    const double p_sched = L.psp[i];
-    if (L.bt[i] == BT_REF) continue;
+    if (i >= nb) return;
+    const double p_sched = from_regs ? p_reg : L.psp[i];
+    if (L.bt[i] == BT_REF) return;
 #pragma unroll
     for (int k = 0; k < KA; ++k) {
       const unsigned bid = a.ent[k] >> 16;
@@ -1172,6 +1179,12 @@ __device__ __forceinline__ void dc_rows(const DevPlan& P, const Lds& L, int firs
     st_blk2<PK>(L, a.dw & 0xFFFF, Blk{bii, 0.0, 0.0, bii});
     L.rhs[i] = p_sched - cst;
     L.rq[i] = 0.0;
+  };
+  if (PQ) {
+#pragma unroll
+    for (int r = 0; r < POLAR_R; ++r) if (r < P.ra) row_round(r, true, pol->p[r]);
+  } else {
+    for (int r = first; r < P.ra; r += stride) row_round(r, false, 0.0);
   }
 }
 template <bool PK>
@@ -1228,7 +1241,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
   double piv = 1.0;
   int pbus = -1;
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
-  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV && !DC;      // scheduled P / Q in pol->p / pol->q (see Polar)
+  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV && !(DC && !OPFX_PQREG_DC);      // scheduled P / Q in pol->p / pol->q (see Polar)
   constexpr unsigned NONE = 0xFFFFu;
   const int nb = P.nb;
   // Descriptor streams: every load below is UNCONDITIONAL and sits in straight-line code, so
@@ -1269,7 +1282,7 @@ __device__ bool newton2(const DevPlan& P, const Lds& L, const Opts& o, int lane,
     if (DC && dc_pass) {
       // the DC start: B' in the blocks, P - c on the right-hand side (see dc_rows); phases B / C below solve it
       dc_overflow<PK>(P, L, 0, 1, lane);
-      dc_rows<PK>(P, L, 0, 1, lane);
+      dc_rows<PK, PQREG>(P, L, 0, 1, lane, pol);
       wave_fence();
       if (!NOMOD && n_mod > 0) { dc_mods(P, L, lane, n_mod); wave_fence(); }
     } else {
@@ -1931,14 +1944,14 @@ __device__ __forceinline__ bool solve_instance(const DevPlan& P, const Lds& L, c
 //   [vm nb | va_deg nb | loading nbr | p_ext nref | q_ext nref | q_gen nb]
 // `lane` / `stride`: the calling thread's index and the number of threads that share the work (a wavefront,
 // or the whole wave team)
-template <int V2, int SPEC = 0, bool POLAR = false, bool TEAMPQ = false>
+template <int V2, int SPEC = 0, bool POLAR = false, bool TEAMPQ = false, bool LANEPQ = POLAR>
 __device__ void compute_results(const DevPlan& P, const Lds& L, int lane, int out_br, int n_mod,
                                 const double* qg_min, const double* qg_max, double* R, bool physical,
                                 bool want_angle, int stride = WAVE, const Polar* pol = nullptr) {
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   // scheduled P / Q in pol->p / pol->q (see Polar): single-wave PQREG kernels (bus lane + 64 r) and the teams' TPQ kernels
   // (bus tid + NT k; `stride` = NT there)
-  constexpr bool PQREG = OPFX_PQREG && NOPV && V2 != 0 && (POLAR || TEAMPQ);
+  constexpr bool PQREG = OPFX_PQREG && NOPV && V2 != 0 && ((POLAR && LANEPQ) || TEAMPQ);      // (LANEPQ: the caller's PQREG — not in the DC-start kernels)
   const int nb = P.nb, nbr = P.nbr, nref = P.nref;
   double* r_vm = R;
   double* r_va = R + nb;
@@ -2845,8 +2858,8 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
   constexpr bool NOPV = (SPEC & SPEC_NO_PV) != 0, NOMOD = (SPEC & SPEC_NO_MOD) != 0;
   // (the polar shadow, see Polar: single-wave kernels at two wavefronts per SIMD without modifiers; the launch keeps grids of
   //  more than 64 POLAR_R buses off these instantiations, do_step)
-  constexpr bool POLAR = V2 != 0 && NW == 1 && !MEM && !DC && !CHORD && MINW == 2 && NOMOD;
-  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV;      // scheduled P / Q in registers (see Polar)
+  constexpr bool POLAR = V2 != 0 && NW == 1 && !MEM && !(DC && !OPFX_POLAR_DC) && !CHORD && MINW == 2 && NOMOD;
+  constexpr bool PQREG = OPFX_PQREG && POLAR && NOPV && !(DC && !OPFX_PQREG_DC);      // scheduled P / Q in registers (see Polar)
   constexpr bool TPQ = OPFX_PQREG && OPFX_TPQ && V2 != 0 && NW > 1 && NOPV && !MEM;      // ... of a team's threads (newton2_coop)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int NT = WAVE * NW;
@@ -3240,7 +3253,7 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
       // (the result bank is filled by the whole team; constraints, costs and outputs by wavefront 0)
       // (voltage angles: for the result bank, which is written from the base case only, or when an observation /
       //  constraint / objective term reads them — not for the 250 contingency cases of an N-1 step otherwise)
-      OPFX_REP(6) compute_results<V2, SPEC, POLAR, TPQ>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
+      OPFX_REP(6) compute_results<V2, SPEC, POLAR, TPQ, PQREG>(P, L, tid, out_br, n_mod, E.qg_min, E.qg_max, R, true, (c == 0 && io.results != nullptr) || E.need_angle, NT, &pol);
       blk_sync<NW>();
       // (derived rows and the constraint pass are shared by the whole team as well — with 250 contingencies per step they run
       //  251 times per instance and were 5 % of an N-1 step on wavefront 0 alone, the other three parked at the barrier)
