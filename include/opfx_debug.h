@@ -26,7 +26,7 @@ extern "C" {
 typedef struct opfx_debug_opts {
   uint32_t struct_size;      /* = sizeof(opfx_debug_opts)                                                     */
   /* ---- plan (opfx_plan_create_debug) ---------------------------------------------------------------------- */
-  int32_t plan_search;       /* 0: default (15 extra tie-breaking rules on grids of 200-800 buses); n > 0: n extra
+  int32_t plan_search;       /* 0: default (15 to 63 extra tie-breaking rules, by size, on grids of 200-800 buses); n > 0: n extra
                               * rules, on any grid; -1: the first rule only                                     */
   int32_t plan_dcap_slack;   /* > 0: pin the degree slack of the level-scheduled minimum-degree ordering       */
   int32_t plan_seed;         /* > 0: pin the tie-breaking hash seed (pins the rule like plan_dcap_slack)        */

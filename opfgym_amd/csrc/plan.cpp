@@ -1072,7 +1072,7 @@ static double plan_cost(const opfx_plan* p) {
 // The elimination order decides how many rounds and barriers an iteration takes, and on meshed grids the outcome of the
 // minimum-degree heuristic moves by 5-10 % with the way it breaks ties (306-bus HV grid: 48 to 56 rounds per wavefront
 // over 24 tie-breaking rules).  A plan is compiled once per grid and runs millions of times: for grids of the wave-team
-// kernels several rules are tried and the cheapest plan is kept (15 extra plans by default).  Radial MV / LV grids are item-bound, not
+// kernels several rules are tried and the cheapest plan is kept (15 to 63 extra plans by default, by grid size).  Radial MV / LV grids are item-bound, not
 // level-bound, and every rule gives the same round count: no search below 200 buses; above 800 (a plan takes most of a
 // second to build) only on request (opfx_debug_opts.plan_search / plan_dcap_slack / plan_seed, include/opfx_debug.h).
 extern "C" int opfx_plan_create_debug(const opfx_case* c_in, const opfx_debug_opts* dbg_in, opfx_plan** out) {
@@ -1089,7 +1089,10 @@ extern "C" int opfx_plan_create_debug(const opfx_case* c_in, const opfx_debug_op
   opfx_plan* best = nullptr;
   rc = plan_build(c, base, dbg, &best);
   if (rc != OPFX_OK) return rc;
-  const int n_search = dbg.plan_search > 0 ? dbg.plan_search : (dbg.plan_search < 0 ? 0 : 15);
+  // (default: as many extra plans as about two seconds of host time buy — 63 up to ~400 buses, 30 at 800; round 6: the 372-bus grid
+  //  of config 5 finds its 48-round plan among the first 31, 52 rounds among 15: 205.6 -> 201.0 ms)
+  const int n_default = std::max(15, std::min(63, 24000 / std::max(1, c->nb)));
+  const int n_search = dbg.plan_search > 0 ? dbg.plan_search : (dbg.plan_search < 0 ? 0 : n_default);
   if (!pinned && best->nb >= 200 && (best->nb <= 800 || dbg.plan_search > 0) && n_search > 0) {
     double best_cost = plan_cost(best);
     for (int t = 0; t < n_search; ++t) {
