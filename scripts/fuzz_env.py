@@ -98,6 +98,7 @@ def random_options(rng):
 def class_options(rng, base):
     """Constructor parameters of the benchmark classes (they change the grid the env is built on)."""
     kw = {}
+    base = base.partition('+')[0]          # (`<scenario>+beyond`: the scenario with wards, motors, impedances ... added, env_cases.product_env)
     if base not in ('nonsimbench_case9', 'constraint_sat_lv') and rng.random() < 0.5:
         kw['grid_seed'] = int(rng.integers(1, 50))      # another instance of the synthetic grid family
     if base in ('vc_mv_small', 'qm_mv_small'):

@@ -6,27 +6,31 @@ from opfgym_amd import grids, net as N
 
 
 def add_elements(net):
-    """In place on the `mv-small` stand-in (33 buses, 20 kV feeders): returns the net."""
-    mv = [int(b) for b in net.bus.index[net.bus.vn_kv == 20.0]]
-    N.create_ward(net, mv[5], ps_mw=0.12, qs_mvar=0.04, pz_mw=0.08, qz_mvar=-0.15)
-    N.create_ward(net, mv[11], ps_mw=0.05, qs_mvar=-0.01, pz_mw=0.02, qz_mvar=0.03, in_service=False)
-    N.create_ward(net, mv[17], ps_mw=0.0, qs_mvar=0.0, pz_mw=0.0, qz_mvar=-0.3)            # (a pure capacitor bank)
-    N.create_motor(net, mv[8], pn_mech_mw=0.25, cos_phi=0.87, efficiency_percent=94.0, loading_percent=80.0, scaling=1.2)
-    N.create_motor(net, mv[20], pn_mech_mw=0.4, cos_phi=0.8, in_service=False)
+    """In place on a grid with one big voltage level (the `mv-small` stand-in: 32 buses at 20 kV; `hv-small`, LV grids alike:
+    buses are picked by position within that level): returns the net."""
+    kv = float(net.bus.vn_kv.value_counts().index[0])
+    lvl = [int(b) for b in net.bus.index[net.bus.vn_kv == kv]]
+    at = lambda k: lvl[k % len(lvl)]
+    N.create_ward(net, at(5), ps_mw=0.12, qs_mvar=0.04, pz_mw=0.08, qz_mvar=-0.15)
+    N.create_ward(net, at(11), ps_mw=0.05, qs_mvar=-0.01, pz_mw=0.02, qz_mvar=0.03, in_service=False)
+    N.create_ward(net, at(17), ps_mw=0.0, qs_mvar=0.0, pz_mw=0.0, qz_mvar=-0.3)            # (a pure capacitor bank)
+    N.create_motor(net, at(8), pn_mech_mw=0.25, cos_phi=0.87, efficiency_percent=94.0, loading_percent=80.0, scaling=1.2)
+    N.create_motor(net, at(20), pn_mech_mw=0.4, cos_phi=0.8, in_service=False)
     # a tie between two feeders as a series impedance whose two directions differ, a symmetric one in parallel to a line
-    N.create_impedance(net, mv[7], mv[14], rft_pu=0.012, xft_pu=0.03, sn_mva=10.0, rtf_pu=0.015, xtf_pu=0.036)
-    ln = net.line.iloc[3]
-    N.create_impedance(net, int(ln.from_bus), int(ln.to_bus), rft_pu=0.02, xft_pu=0.05, sn_mva=5.0)
-    N.create_impedance(net, mv[3], mv[25], rft_pu=0.01, xft_pu=0.02, sn_mva=10.0, in_service=False)
+    z_scale = kv ** 2 / 400.0                          # (the per-unit values below are meant for 20 kV on the element's sn_mva)
+    N.create_impedance(net, at(7), at(14), rft_pu=0.012, xft_pu=0.03, sn_mva=10.0 * z_scale, rtf_pu=0.015, xtf_pu=0.036)
+    ln = net.line[(net.line.from_bus.isin(lvl)) & (net.line.to_bus.isin(lvl))].iloc[3]
+    N.create_impedance(net, int(ln.from_bus), int(ln.to_bus), rft_pu=0.02, xft_pu=0.05, sn_mva=5.0 * z_scale)
+    N.create_impedance(net, at(3), at(25), rft_pu=0.01, xft_pu=0.02, sn_mva=10.0 * z_scale, in_service=False)
     # a consumer behind a closed bus-bus switch with a contact resistance
-    far = N.create_bus(net, 20.0)
+    far = N.create_bus(net, kv)
     for c in net.bus.columns:
         if c not in ('name', 'vn_kv'):
-            net.bus.at[far, c] = net.bus.at[mv[9], c]
-    moved = net.load.index[net.load.bus == mv[9]]
+            net.bus.at[far, c] = net.bus.at[at(9), c]
+    moved = net.load.index[net.load.bus == at(9)]
     moved = moved[0] if len(moved) else net.load.index[4]          # (an existing load: the profiles know its index)
     net.load.at[moved, 'bus'] = far
-    N.create_switch(net, mv[9], far, 'b', closed=True, z_ohm=0.35)
+    N.create_switch(net, at(9), far, 'b', closed=True, z_ohm=0.35 * z_scale)
     return N.finalize(net)
 
 

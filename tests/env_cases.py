@@ -19,10 +19,19 @@ def golden(name):
 
 
 def product_env(name, batch_size=1, defer_device=False, **extra):
-    cls, kwargs, _, seed = SCENARIOS[name]
+    """`<scenario>+beyond`: the scenario's problem definition on its grid WITH wards, motors, series impedances and a bus-bus
+    switch with an impedance added (tests/beyond_simbench.py): static parts of the grid, the definition is otherwise the
+    scenario's."""
+    base, _, variant = name.partition('+')
+    cls, kwargs, _, seed = SCENARIOS[base]
     kw = dict(kwargs)
-    kw.update(PRODUCT_KWARGS.get(name, {}))
+    kw.update(PRODUCT_KWARGS.get(base, {}))
     kw.update(extra)
+    if variant == 'beyond' and 'definition' not in kw:
+        import beyond_simbench
+        d = getattr(product_envs, cls)(seed=seed, batch_size=1, defer_device=True, **kw).definition
+        beyond_simbench.add_elements(d.net)
+        kw['definition'] = d
     return getattr(product_envs, cls)(seed=seed, batch_size=batch_size, defer_device=defer_device, **kw)
 
 
@@ -35,7 +44,7 @@ def reward_dict(rf):
 
 def oracle_env(name, env=None):
     """EnvOracle for a scenario, built from the host-side problem definition."""
-    cls, kwargs, _, _ = SCENARIOS[name]
+    cls, kwargs, _, _ = SCENARIOS[name.partition('+')[0]]
     env = env or product_env(name, defer_device=True)
     d = env.host_definition()
     tail = env_oracle.TAILS.get(cls)
