@@ -25,7 +25,7 @@ import numpy as np
 from . import capi
 from . import constraints as constraints_mod
 from . import reward as reward_mod
-from .case import REF, static_consumption
+from .case import REF, expand_dclines, static_consumption
 from .simbench_build import define_test_train_split, get_simbench_time_observation
 from .descriptors import DescriptorCompiler, _case_all_branches_in
 from .spaces import Box, get_obs_and_state_space  # noqa: F401
@@ -146,6 +146,12 @@ class BatchedOpfEnv(DescriptorCompiler, TopologyMixin):
             self.host_objective, terms = terms[0], []
         self.objective_terms = list(terms)
         self.bus_wise_obs = bool(bus_wise_obs)
+        # (DC lines run as two generators each, as in pandapower: from here on they ARE rows at the end of the generator table —
+        #  static ones, nothing samples or actuates them — and the dcline table of the environment's copy of the net is empty)
+        if expand_dclines(net) is not net:
+            net = expand_dclines(net)
+            net['dcline'] = net['dcline'].iloc[0:0]
+            del net['_dcline_gens']
         self.net = net
         self.device_spec = device
         # opf_env.py:382 asserts on NaN actions; checking that on the host costs a device sync per

@@ -10,8 +10,8 @@ scale factors that turn per-unit branch currents into `loading_percent`.
 benchmark grids: buses, lines, two-winding transformers, loads, sgens,
 storages, gens, ext_grids, shunts, bus-bus/line/trafo switches, three-winding
 transformers (star equivalent with an auxiliary bus) — and, beyond those
-grids (round 6), wards, series impedances, motors and closed bus-bus switches
-with an impedance.  pandapower is
+grids (round 6), wards, extended wards, series impedances, motors, DC lines and
+closed bus-bus switches with an impedance.  pandapower is
 not importable here, so the element formulas are restated from its published
 documentation ("Electric model" pages of line / trafo); parity of this
 conversion against pandapower itself is NOT verified in this repository (see
@@ -24,7 +24,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 PQ, PV, REF = 1, 2, 3
-KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, KIND_IMPEDANCE, KIND_SWITCH = 0, 1, 2, 3, 4
+KIND_LINE, KIND_TRAFO, KIND_TRAFO3W, KIND_IMPEDANCE, KIND_SWITCH, KIND_XWARD = 0, 1, 2, 3, 4, 5
 # pandapower `runpp(switch_rx_ratio=2)`: a closed bus-bus switch with z_ohm > 0 is a branch of |z| = z_ohm with r / x = 2
 SWITCH_RX_RATIO = 2.0
 
@@ -144,7 +144,7 @@ def _flags(df, name, default=False):
 
 # pandapower element tables that take part in `runpp` and that this converter has no model for: a net that
 # fills one of them would be solved WITHOUT those elements — a silently different grid — so it is refused
-UNMODELLED_TABLES = ('xward', 'dcline', 'asymmetric_load', 'asymmetric_sgen',
+UNMODELLED_TABLES = ('asymmetric_load', 'asymmetric_sgen',
                      'svc', 'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc')
 
 
@@ -171,9 +171,46 @@ def pd_to_float(values):
         return np.array([np.nan if (v is None or isinstance(v, str)) else float(v) for v in values])
 
 
+def expand_dclines(net):
+    """pandapower runs a DC line as TWO GENERATORS (`_add_dcline_gens`, before `_pd2ppc`): appended to the generator table per
+    dcline row, first one at the to bus feeding in p_mw (1 - loss_percent / 100) - loss_mw at vm_to_pu within
+    [min_q_to_mvar, max_q_to_mvar], then one at the from bus taking p_mw at vm_from_pu within the from-side range.
+    Returns `net` itself when it holds no dcline row (or is expanded already), else a shallow copy — same tables, a longer
+    `gen` — marked with the number of rows added (`_dcline_gens`); the rows of the original generators keep their positions,
+    so results by generator position are those of the net's own generators first, the lines' two per row after them."""
+    dc = _table(net, 'dcline')
+    if dc is None or '_dcline_gens' in net:
+        return net
+    import copy
+    import pandas as pd
+    gen = net['gen']
+    on = _col(dc, 'in_service', True).astype(bool)
+    loss = _col(dc, 'loss_percent', 0.0) / 100.0
+    rows = []
+    for pos in range(len(dc)):
+        g = lambda c_, d=np.nan: float(_col(dc, c_, d)[pos])
+        p_from = g('p_mw')
+        p_to = p_from * (1.0 - loss[pos]) - g('loss_mw', 0.0)
+        rows.append(dict(bus=int(dc['to_bus'].iloc[pos]), p_mw=p_to, vm_pu=g('vm_to_pu'), min_q_mvar=g('min_q_to_mvar'),
+                         max_q_mvar=g('max_q_to_mvar'), scaling=1.0, in_service=bool(on[pos]), controllable=False, name=None))
+        rows.append(dict(bus=int(dc['from_bus'].iloc[pos]), p_mw=-p_from, vm_pu=g('vm_from_pu'), min_q_mvar=g('min_q_from_mvar'),
+                         max_q_mvar=g('max_q_from_mvar'), scaling=1.0, in_service=bool(on[pos]), controllable=False, name=None))
+    first = (int(gen.index.max()) + 1) if len(gen) else 0
+    add = pd.DataFrame(rows, index=range(first, first + len(rows)))
+    for c_ in gen.columns:                  # (columns of the net's own generators that a line's generators do not have)
+        if c_ not in add.columns:
+            add[c_] = False if gen[c_].dtype == bool else np.nan
+    out = copy.copy(net)
+    out['gen'] = pd.concat([gen, add[list(gen.columns) + [c_ for c_ in add.columns if c_ not in gen.columns]]]) if len(gen) else add
+    out['gen']['bus'] = out['gen']['bus'].astype(np.int64)
+    out['gen']['in_service'] = out['gen']['in_service'].astype(bool)
+    out['_dcline_gens'] = len(rows)
+    return out
+
+
 def check_supported(net) -> None:
     """Raise ValueError (naming the table / column) for net content that `pp.runpp` would model and this
-    converter does not (opf_env.py:703 hands the WHOLE net to pandapower): rows in `xward`, `dcline`, the
+    converter does not (opf_env.py:703 hands the WHOLE net to pandapower): rows in the
     asymmetric / FACTS tables; voltage-dependent (ZIP) loads; line / transformer switches with an
     impedance; switches at three-winding transformers; generators acting as slack;
     characteristic-dependent transformer impedances."""
@@ -263,6 +300,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
       * every in-service ext_grid bus is REF, every in-service gen bus PV.
     """
     check_supported(net)
+    net = expand_dclines(net)
     base = float(net['sn_mva']) if 'sn_mva' in net else 1.0
     f_hz = float(net['f_hz']) if 'f_hz' in net else 50.0
     bus_df = net['bus']
@@ -491,6 +529,23 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
                 rows.append((fb, tb, r_pi, x_pi, bc, ratio, sh, KIND_TRAFO3W, pos, k_term if w == 0 else 0.0,
                              0.0 if w == 0 else k_term, 0, w))
 
+    # --- extended wards (pandapower `_calc_xward_parameter`, `_build_gen_ppc`): the ward's two parts at the bus, and behind
+    # r_ohm + j x_ohm an internal bus that a source without active power holds at vm_pu — an auxiliary PV bus per xward
+    xw = _table(net, 'xward')
+    xward_aux = {}                                     # row -> (auxiliary bus id, vm_pu)
+    if xw is not None:
+        on = _col(xw, 'in_service', True).astype(bool)
+        for pos, idx in enumerate(xw.index):
+            b = int(xw.at[idx, 'bus'])
+            if not on[pos] or not bus_on(b):
+                continue
+            aux = -1 - len(aux_vn)
+            aux_vn.append(float(vn[b]))
+            xward_aux[pos] = (aux, float(xw.at[idx, 'vm_pu']))
+            zb = float(vn[b]) ** 2 / base
+            rows.append((b, aux, float(xw.at[idx, 'r_ohm']) / zb, float(xw.at[idx, 'x_ohm']) / zb, 0.0 + 0.0j, 1.0, 0.0,
+                         KIND_XWARD, pos, 0.0, 0.0, 0, 0))
+
     # --- which fused buses are alive: connected to a REF through branches ----
     roots = {b: uf.find(b) for b in bus_ids}
     for a_ in range(len(aux_vn)):
@@ -556,6 +611,12 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
             if on_ and int(b) in bus_lookup:
                 bus_type[bus_lookup[int(b)]] = PV
                 vm_set[bus_lookup[int(b)]] = float(vm)
+    xward_bus = {}
+    for pos, (aux, vm) in xward_aux.items():
+        if aux in root_to_case:
+            i = root_to_case[aux]
+            bus_type[i], vm_set[i] = PV, vm
+            xward_bus[pos] = i
     ref_elems = []
     for pos, (b, on_) in enumerate(zip(eg['bus'], eg_on)):
         if on_ and int(b) in bus_lookup:
@@ -579,8 +640,10 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
                 gs[i] += float(sh_df['p_mw'].iloc[pos]) * step[pos] * v_ratio / base
                 bs[i] -= float(sh_df['q_mvar'].iloc[pos]) * step[pos] * v_ratio / base
 
-    ward = _table(net, 'ward')
-    if ward is not None:                   # constant-impedance part of a ward: MW / Mvar at 1 p.u. (no voltage-level ratio)
+    for name in ('ward', 'xward'):         # constant-impedance part of a ward: MW / Mvar at 1 p.u. (no voltage-level ratio)
+        ward = _table(net, name)
+        if ward is None:
+            continue
         w_on = _col(ward, 'in_service', True).astype(bool)
         for pos, b in enumerate(ward['bus']):
             if w_on[pos] and int(b) in bus_lookup:
@@ -605,7 +668,7 @@ def net_to_case(net, calculate_voltage_angles='auto') -> Case:
         br_side=np.array([r[12] for r in rows], dtype=np.int32),
         bdc=_bdc(rows)[0], pfinj=_bdc(rows)[1],
         bus_lookup=bus_lookup, ref_elems=np.array(ref_elems, dtype=np.int32),
-        meta={'calc_angles': calc_angles})
+        meta={'calc_angles': calc_angles, 'xward_bus': xward_bus})
 
 
 def _bdc(rows):
@@ -647,6 +710,7 @@ def bus_injections(net, case: Case):
     (`p_mw·scaling`, in service only), plus the summed reactive capability of
     the generators per bus.  Returns (p, q, qg_min, qg_max); q excludes the
     voltage-controlling generators (their Q is a result)."""
+    net = expand_dclines(net)
     nb = case.nb
     p = np.zeros(nb)
     q = np.zeros(nb)
@@ -689,16 +753,17 @@ def bus_injections(net, case: Case):
 
 def static_consumption(net) -> dict:
     """Constant-power consumption of the element types that neither the reference's sampling nor its actuators touch, per
-    row of their table in MW / Mvar (zero for a row out of service): {'ward': (p, q), 'motor': (p, q)}.
+    row of their table in MW / Mvar (zero for a row out of service): {'ward': (p, q), 'xward': (p, q), 'motor': (p, q)}.
 
-      * ward (pandapower `_calc_pq_elements_and_add_on_ppc`): ps_mw, qs_mvar (the constant-impedance part is a shunt: net_to_case);
+      * ward, xward (pandapower `_calc_pq_elements_and_add_on_ppc`): ps_mw, qs_mvar (the constant-impedance part is a shunt: net_to_case);
       * motor (pandapower `_get_motor_pq`): P = pn_mech_mw / (efficiency_percent / 100) * loading_percent / 100 * scaling,
         S = P / cos_phi, Q = sqrt(S^2 - P^2)."""
     out = {}
-    ward = _table(net, 'ward')
-    if ward is not None:
-        on = _col(ward, 'in_service', True).astype(float)
-        out['ward'] = (ward['ps_mw'].to_numpy(float) * on, ward['qs_mvar'].to_numpy(float) * on)
+    for name in ('ward', 'xward'):
+        ward = _table(net, name)
+        if ward is not None:
+            on = _col(ward, 'in_service', True).astype(float)
+            out[name] = (ward['ps_mw'].to_numpy(float) * on, ward['qs_mvar'].to_numpy(float) * on)
     motor = _table(net, 'motor')
     if motor is not None:
         on = _col(motor, 'in_service', True).astype(float)
@@ -728,10 +793,12 @@ def generator_dispatch(net, case: Case) -> dict:
       * active power at a REF bus: the FIRST generator row of the bus balances it (what the solver reports as p_ext,
         the generators' own set-points already taken off), every other ext_grid there reports its ppc set-point, zero.
 
-    Returns {'gen': {...}, 'ext_grid': {...}} with arrays over the rows of the two tables: `bus` (case bus, -1 for a row
+    Returns {'gen': {...}, 'ext_grid': {...}} with arrays over the rows of the two tables (the generator rows of DC lines, `expand_dclines`,
+    after the net's own): `bus` (case bus, -1 for a row
     that takes no part in the power flow), `q_a` [Mvar], `q_b`, and for ext_grids `p_b` (1.0 / 0.0).  Q_bus is the
     solver's `q_gen[bus]` at PV buses (the limit total where `enforce_q_lims` has pinned the bus) and `q_ext` at REF buses.
     """
+    net = expand_dclines(net)
     eg, gen = net['ext_grid'], net['gen']
     members = {}                                   # case bus -> [(table, pos, qmin, qmax)] in ppc row order
     eg_on = _col(eg, 'in_service', True).astype(bool) if len(eg) else np.zeros(0, bool)

@@ -3186,8 +3186,21 @@ __global__ __launch_bounds__(WAVE * NW, MINW) void k_step(const DevPlan P, const
         // contingency cases start from the base-case solution (the reference restarts
         // pandapower from scratch for each one; the converged result is the same;
         // opfx_solve_opts::contingency_start = 1 does exactly what the reference does)
+        // A PV bus keeps the MAGNITUDE init_voltage gave it (its set-point; the Newton loop never moves |V| of a PV row) and takes
+        // only the angle: in the base case the bus may have run into a reactive limit and floated away from its set-point —
+        // started from that |V| the contingency would hold the wrong voltage, possibly meet the other limit, and end at
+        // another solution than pandapower's, which starts every power flow with all generators regulating (found by the fuzzer
+        // on grids whose generators have narrow ranges, round 6).
         const double* wv = P.warm + (size_t)blockIdx.x * 2 * nb;
-        for (int i = tid; i < nb; i += NT) { const unsigned io_ = opaque((unsigned)i); L.vr[i] = ld_at(wv, io_); L.vi[i] = ld_at(wv, (unsigned)nb + io_); }
+        for (int i = tid; i < nb; i += NT) {
+          const unsigned io_ = opaque((unsigned)i);
+          double wr = ld_at(wv, io_), wi = ld_at(wv, (unsigned)nb + io_);
+          if (!NOPV && V2 && L.bt[i] == BT_PV) {
+            const double f = sqrt((L.vr[i] * L.vr[i] + L.vi[i] * L.vi[i]) / (wr * wr + wi * wi));
+            wr *= f; wi *= f;
+          }
+          L.vr[i] = wr; L.vi[i] = wi;
+        }
       }
       // A contingency that starts from a DC power flow of its own (init = DC, contingency_start = 1: what the reference does,
       // security_constrained.py:53) — B' is the SAME matrix for every instance and every step, and the outage of branch

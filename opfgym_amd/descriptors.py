@@ -67,7 +67,7 @@ class DescriptorCompiler:
         columns, table observations, prices, per-instance voltage set-points.  Every other per-instance column is only
         written by the reset (and readable through `table_column`)."""
         hot = {(t, c) for t in ('load', 'sgen', 'storage') for c in ('p_mw', 'q_mvar')} | {('gen', 'p_mw'), ('ext_grid', 'vm_pu'), ('gen', 'vm_pu')}
-        hot |= {(t, c) for t in ('ward', 'motor') for c in ('_p_mw', '_q_mvar')}
+        hot |= {(t, c) for t in ('ward', 'xward', 'motor') for c in ('_p_mw', '_q_mvar')}
         for unit, col, _ in self.act_keys:
             hot |= {(unit, col)} | {(unit, pre + col) for pre in ('min_', 'max_', 'min_min_', 'max_max_')}
         hot |= {(unit, col) for unit, col, _ in self.obs_keys if not unit.startswith('res_')}

@@ -42,6 +42,9 @@ _TABLES = {
     'switch': ['bus', 'element', 'et', 'closed'],
     # pandapower element types beyond those of the SimBench grids (static in the batched environment: no actuator / sampling)
     'ward': ['name', 'bus', 'ps_mw', 'qs_mvar', 'pz_mw', 'qz_mvar', 'in_service'],
+    'xward': ['name', 'bus', 'ps_mw', 'qs_mvar', 'pz_mw', 'qz_mvar', 'r_ohm', 'x_ohm', 'vm_pu', 'in_service'],
+    'dcline': ['name', 'from_bus', 'to_bus', 'p_mw', 'loss_percent', 'loss_mw', 'vm_from_pu', 'vm_to_pu', 'max_p_mw',
+               'min_q_from_mvar', 'min_q_to_mvar', 'max_q_from_mvar', 'max_q_to_mvar', 'in_service'],
     'impedance': ['name', 'from_bus', 'to_bus', 'rft_pu', 'xft_pu', 'rtf_pu', 'xtf_pu', 'sn_mva', 'in_service'],
     'motor': ['name', 'bus', 'pn_mech_mw', 'cos_phi', 'efficiency_percent', 'loading_percent', 'scaling', 'in_service'],
     'poly_cost': ['element', 'et', 'cp0_eur', 'cp1_eur_per_mw',
@@ -260,6 +263,25 @@ def create_ward(net, bus, ps_mw, qs_mvar, pz_mw, qz_mvar, in_service=True, name=
     positive."""
     return _append(net, 'ward', dict(name=name, bus=int(bus), ps_mw=float(ps_mw), qs_mvar=float(qs_mvar), pz_mw=float(pz_mw),
                                      qz_mvar=float(qz_mvar), in_service=bool(in_service)), index)
+
+
+def create_xward(net, bus, ps_mw, qs_mvar, pz_mw, qz_mvar, r_ohm, x_ohm, vm_pu, in_service=True, name=None, index=None) -> int:
+    """pandapower.create_xward: a ward plus, behind r_ohm + j x_ohm, an internal voltage source at vm_pu (no active power)."""
+    return _append(net, 'xward', dict(name=name, bus=int(bus), ps_mw=float(ps_mw), qs_mvar=float(qs_mvar), pz_mw=float(pz_mw),
+                                      qz_mvar=float(qz_mvar), r_ohm=float(r_ohm), x_ohm=float(x_ohm), vm_pu=float(vm_pu),
+                                      in_service=bool(in_service)), index)
+
+
+def create_dcline(net, from_bus, to_bus, p_mw, loss_percent, loss_mw, vm_from_pu, vm_to_pu, max_p_mw=np.nan,
+                  min_q_from_mvar=np.nan, min_q_to_mvar=np.nan, max_q_from_mvar=np.nan, max_q_to_mvar=np.nan, in_service=True,
+                  name=None, index=None) -> int:
+    """pandapower.create_dcline: p_mw leaves the grid at from_bus, p_mw (1 - loss_percent / 100) - loss_mw enters it at to_bus;
+    both ends hold their bus voltage within their reactive range."""
+    return _append(net, 'dcline', dict(
+        name=name, from_bus=int(from_bus), to_bus=int(to_bus), p_mw=float(p_mw), loss_percent=float(loss_percent),
+        loss_mw=float(loss_mw), vm_from_pu=float(vm_from_pu), vm_to_pu=float(vm_to_pu), max_p_mw=float(max_p_mw),
+        min_q_from_mvar=float(min_q_from_mvar), min_q_to_mvar=float(min_q_to_mvar), max_q_from_mvar=float(max_q_from_mvar),
+        max_q_to_mvar=float(max_q_to_mvar), in_service=bool(in_service)), index)
 
 
 def create_impedance(net, from_bus, to_bus, rft_pu, xft_pu, sn_mva, rtf_pu=None, xtf_pu=None, in_service=True, name=None,

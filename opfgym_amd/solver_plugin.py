@@ -16,8 +16,8 @@ import numpy as np
 import pandas as pd
 
 from . import capi
-from .case import (KIND_IMPEDANCE, KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, _table, bus_injections, generator_dispatch,
-                   net_to_case, static_consumption)
+from .case import (KIND_IMPEDANCE, KIND_XWARD, KIND_TRAFO3W, KIND_LINE, KIND_TRAFO, REF, _table, bus_injections, expand_dclines,
+                   generator_dispatch, net_to_case, static_consumption)
 
 
 class LoadflowNotConverged(Exception):
@@ -161,6 +161,24 @@ class BatchedPowerFlowSolver:
             net['res_ward'] = pd.DataFrame({'p_mw': part * (static['ward'][0] + df['pz_mw'].to_numpy(float) * v2),
                                             'q_mvar': part * (static['ward'][1] + df['qz_mvar'].to_numpy(float) * v2),
                                             'vm_pu': vw}, index=df.index)
+        if 'xward' in static:
+            # the ward's parts plus what flows into the impedance towards the internal source; the internal bus's own voltage
+            df = net['xward']
+            part = takes_part(df)
+            vw = np.array([vm[bus_pos[int(b)]] for b in df['bus']])
+            v2 = np.where(part, vw, 0.0) ** 2
+            px = part * (static['xward'][0] + df['pz_mw'].to_numpy(float) * v2)
+            qx = part * (static['xward'][1] + df['qz_mvar'].to_numpy(float) * v2)
+            vi, ai = np.full(len(df), np.nan), np.full(len(df), np.nan)
+            v = r['vm'] * np.exp(1j * r['va'])
+            for k in np.flatnonzero(case.br_kind == KIND_XWARD):
+                pos, f, t = int(case.br_elem[k]), int(case.f[k]), int(case.t[k])
+                s_f = v[f] * np.conj(case.yff[k] * v[f] + case.yft[k] * v[t]) * base
+                px[pos] += s_f.real
+                qx[pos] += s_f.imag
+                vi[pos], ai[pos] = r['vm'][t], np.degrees(r['va'][t])
+            net['res_xward'] = pd.DataFrame({'p_mw': px, 'q_mvar': qx, 'vm_pu': vw, 'va_internal_degree': ai, 'vm_internal_pu': vi},
+                                            index=df.index)
         if 'motor' in static:
             df = net['motor']
             part = takes_part(df).astype(float)
@@ -178,7 +196,7 @@ class BatchedPowerFlowSolver:
                 cols['i_from_ka'][pos] = abs(i_f) * base / (np.sqrt(3.0) * case.vn_kv[f])
                 cols['i_to_ka'][pos] = abs(i_t) * base / (np.sqrt(3.0) * case.vn_kv[t])
             net['res_impedance'] = pd.DataFrame(cols, index=imp.index)
-        gen = net['gen']
+        gen = expand_dclines(net)['gen']          # (the net's own generators, then two per DC line: to bus, from bus)
         sc = gen['scaling'].to_numpy(float) if 'scaling' in gen.columns and len(gen) else 1.0
         pg, qg, vg = np.zeros(len(gen)), np.zeros(len(gen)), np.zeros(len(gen))
         if len(gen):
@@ -189,7 +207,17 @@ class BatchedPowerFlowSolver:
                     i = case.bus_lookup[int(b)]
                     pg[pos], vg[pos] = pset[pos], r['vm'][i]
                     qg[pos] = share['gen']['q_a'][pos] + share['gen']['q_b'][pos] * bus_q_mvar(i)
-        net['res_gen'] = pd.DataFrame({'p_mw': pg, 'q_mvar': qg, 'vm_pu': vg}, index=gen.index)
+        n_own = len(net['gen'])
+        net['res_gen'] = pd.DataFrame({'p_mw': pg[:n_own], 'q_mvar': qg[:n_own], 'vm_pu': vg[:n_own]}, index=net['gen'].index)
+        dc = _table(net, 'dcline')
+        if dc is not None:
+            # pandapower `_get_dcline_results`: what the line takes at its from end and delivers at its to end, seen as consumption
+            p_to, p_from, q_to, q_from = pg[n_own::2], pg[n_own + 1::2], qg[n_own::2], qg[n_own + 1::2]
+            ends = {side: np.array([bus_pos[int(b)] for b in dc[side + '_bus']]) for side in ('from', 'to')}
+            net['res_dcline'] = pd.DataFrame({
+                'p_from_mw': -p_from, 'q_from_mvar': -q_from, 'p_to_mw': -p_to, 'q_to_mvar': -q_to, 'pl_mw': -(p_to + p_from),
+                'vm_from_pu': vm[ends['from']], 'va_from_degree': va[ends['from']],
+                'vm_to_pu': vm[ends['to']], 'va_to_degree': va[ends['to']]}, index=dc.index)
 
 
 _default = None

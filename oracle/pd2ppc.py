@@ -247,15 +247,15 @@ def motor_pq(mt):
 def refuse_unmodelled(net):
     """`pp.runpp` models every element table of the net; this restatement covers bus, line, trafo, trafo3w,
     load, sgen, storage, gen, ext_grid, shunt and switch.  Anything else that is filled in would make the
-    oracle solve another grid than pandapower does, so it is an error, not a silent omission.  (Round 6: ward, impedance,
-    motor and closed bus-bus switches with z_ohm are covered too.)"""
+    oracle solve another grid than pandapower does, so it is an error, not a silent omission.  (Round 6: ward, xward, impedance,
+    motor, dcline and closed bus-bus switches with z_ohm are covered too.)"""
     def rows(name):
         df = net[name] if name in net else None
         return df if df is not None and hasattr(df, 'columns') and len(df) else None
 
     def nonzero(df, col):
         return col in df.columns and bool(np.any(_get(df, col, 0.0) != 0.0))
-    for name in ('xward', 'dcline', 'asymmetric_load', 'asymmetric_sgen', 'svc',
+    for name in ('asymmetric_load', 'asymmetric_sgen', 'svc',
                  'tcsc', 'ssc', 'vsc', 'b2b_vsc', 'bus_dc', 'line_dc'):
         if rows(name) is not None:
             raise ValueError(f'oracle: element table {name!r} is not modelled')
@@ -384,6 +384,22 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
                 add_branch(fb, tb, rr[0], xx[0], bb[0], ratio, e['shift'][k] if calc_angles else 0.0,
                            on[k] and all(bus_on[v] for v in ends.values()), 'trafo3w', k, side)
 
+    # ---- extended wards (pandapower `_calc_xward_parameter`): an internal bus per xward behind r_ohm + j x_ohm; the voltage
+    # source on it is a generator row without active power (below) ------------------------------------------------------------
+    xw = net['xward'] if 'xward' in net and len(net['xward']) else None
+    xw_aux = {}
+    if xw is not None:
+        on = _flag(xw, 'in_service')
+        for k in range(len(xw)):
+            at = pos_of[int(xw['bus'].iloc[k])]
+            if not (on[k] and bus_on[at]):
+                continue                                 # (pandapower keeps the bus and switches its branch off; nothing hangs on it)
+            xw_aux[k] = nb + len(aux_kv)
+            aux_kv.append(float(vn[at]))
+            base_z = vn[at] ** 2 / base_mva
+            add_branch(int(lookup_pos[at]), xw_aux[k], float(xw['r_ohm'].iloc[k]) / base_z, float(xw['x_ohm'].iloc[k]) / base_z,
+                       0.0, 1.0, 0.0, True, 'xward', k)
+
     # ---- impedances (pandapower `_calc_impedance_parameters_from_dataframe`): p.u. on the element's sn_mva -> on the net's;
     # the to-side values go into the asymmetry columns as differences ----------------------------------------------------
     imp = net['impedance'] if 'impedance' in net and len(net['impedance']) else None
@@ -457,8 +473,10 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
 
     # ---- wards: constant-power part as demand, constant-impedance part as a shunt at 1 p.u.; motors as demand
     # (pandapower `_calc_pq_elements_and_add_on_ppc`, `_get_motor_pq`, `_calc_shunts_and_add_on_ppc`) ---------------------
-    wd = net['ward'] if 'ward' in net and len(net['ward']) else None
-    if wd is not None:
+    for wname in ('ward', 'xward'):
+        wd = net[wname] if wname in net and len(net[wname]) else None
+        if wd is None:
+            continue
         on = _flag(wd, 'in_service')
         for k, bus in enumerate(wd['bus']):
             if on[k]:
@@ -511,6 +529,33 @@ def build_ppc(net, calculate_voltage_angles='auto', check_connectivity=True) -> 
             if bus_type[i] != REF:
                 bus_type[i] = PV
                 vm[i] = float(gen['vm_pu'].iloc[k])
+
+    # ---- DC lines (pandapower `_add_dcline_gens`): two generator rows per line at the end of the generator table — at the to
+    # bus what arrives (p_mw less the relative and the fixed losses) at vm_to_pu, at the from bus what is taken, as negative
+    # generation, at vm_from_pu; each within its side's reactive range.  g_pos: 2 row for the to end, 2 row + 1 for the from end
+    dc = net['dcline'] if 'dcline' in net and len(net['dcline']) else None
+    if dc is not None:
+        on = _flag(dc, 'in_service')
+        for k in range(len(dc)):
+            if not on[k]:
+                continue
+            p_from = float(dc['p_mw'].iloc[k])
+            p_to = p_from * (1.0 - _get(dc, 'loss_percent', 0.0)[k] / 100.0) - _get(dc, 'loss_mw', 0.0)[k]
+            for end, p_end, side in ((0, p_to, 'to'), (1, -p_from, 'from')):
+                i = bus_lookup[int(dc[side + '_bus'].iloc[k])]
+                qlo = _get(dc, f'min_q_{side}_mvar', np.nan)[k]
+                qhi = _get(dc, f'max_q_{side}_mvar', np.nan)[k]
+                g_bus.append(i); g_p.append(p_end); g_qmin.append(-1e9 if np.isnan(qlo) else qlo); g_qmax.append(1e9 if np.isnan(qhi) else qhi)
+                g_vg.append(float(dc[f'vm_{side}_pu'].iloc[k])); g_status.append(1); g_table.append('dcline'); g_pos.append(2 * k + end)
+                if bus_type[i] != REF:
+                    bus_type[i] = PV
+                    vm[i] = float(dc[f'vm_{side}_pu'].iloc[k])
+
+    for k, aux in xw_aux.items():                    # (after the generators, as pandapower orders its gen table)
+        g_bus.append(aux); g_p.append(0.0); g_qmin.append(-1e9); g_qmax.append(1e9)
+        g_vg.append(float(xw['vm_pu'].iloc[k])); g_status.append(1); g_table.append('xward'); g_pos.append(k)
+        bus_type[aux] = PV
+        vm[aux] = float(xw['vm_pu'].iloc[k])
 
     ppc = PPC(base_mva=base_mva, bus_type=bus_type, pd=pd_, qd=qd_, gs=gs, bs=bs, vm=vm, va=va, base_kv=base_kv,
               f=np.array(f, dtype=np.int64), t=np.array(t, dtype=np.int64), r=np.array(r, dtype=float),

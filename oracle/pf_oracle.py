@@ -58,6 +58,8 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
                                                                  transformer: the circulating flow; hv and lv side)
       storages (sign convention, scaling)                        storage_is_a_load
       ward (constant power + constant impedance)                ward_is_a_load_and_a_shunt
+      xward (ward + internal source behind an impedance)         xward_is_a_ward_and_a_voltage_source_behind_an_impedance
+      dcline (two generators, losses, reactive ranges)           dcline_is_two_generators
       motor (pn_mech, efficiency, loading, cos_phi)              motor_is_a_load
       series impedance, both directions alike                    symmetric_impedance_is_a_line_without_charging (also 3 r I^2 losses)
       series impedance, directions differing                     tests/test_beyond_simbench_elements.py (by hand: each side's own equation)
@@ -431,7 +433,7 @@ def write_results(net, ppc: PPC, sol):
         if ppc.g_table[g] == 'ext_grid':
             if live:
                 pe[pos], qe[pos] = sol['pg'][g], sol['qg'][g]
-        elif live:
+        elif live and ppc.g_table[g] == 'gen':       # (the internal sources of xwards: res_xward, below)
             pg[pos], qg[pos], vg[pos] = sol['pg'][g], sol['qg'][g], abs(v[ppc.g_bus[g]])
     net['res_ext_grid'] = pd.DataFrame({'p_mw': pe, 'q_mvar': qe}, index=eg.index)
     if len(gen):
@@ -460,6 +462,36 @@ def write_results(net, ppc: PPC, sol):
         net['res_ward'] = pd.DataFrame({'p_mw': part * (df['ps_mw'].to_numpy(float) + df['pz_mw'].to_numpy(float) * v2),
                                         'q_mvar': part * (df['qs_mvar'].to_numpy(float) + df['qz_mvar'].to_numpy(float) * v2),
                                         'vm_pu': vmw}, index=df.index)
+    if 'dcline' in net and len(net['dcline']):
+        # pandapower `_get_dcline_results`: the two generators of a line, seen from the line (consumption positive)
+        df = net['dcline']
+        cols = {c: np.zeros(len(df)) for c in ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw')}
+        for g in range(len(ppc.g_bus)):
+            if ppc.g_table[g] == 'dcline' and ppc.g_status[g] > 0 and sol['supplied'][ppc.g_bus[g]]:
+                row, end = divmod(int(ppc.g_pos[g]), 2)
+                side = 'to' if end == 0 else 'from'
+                cols[f'p_{side}_mw'][row], cols[f'q_{side}_mvar'][row] = -sol['pg'][g], -sol['qg'][g]
+        cols['pl_mw'] = cols['p_from_mw'] + cols['p_to_mw']
+        for side in ('from', 'to'):
+            at = [net['bus'].index.get_loc(int(b)) for b in df[side + '_bus']]
+            cols[f'vm_{side}_pu'], cols[f'va_{side}_degree'] = vm[at], va[at]
+        net['res_dcline'] = pd.DataFrame(cols, index=df.index)
+    if 'xward' in net and len(net['xward']):
+        df = net['xward']
+        part = alive_at(df)
+        vmw = np.array([vm[net['bus'].index.get_loc(int(b))] for b in df['bus']])
+        v2 = np.where(part, vmw, 0.0) ** 2
+        px = part * (df['ps_mw'].to_numpy(float) + df['pz_mw'].to_numpy(float) * v2)
+        qx = part * (df['qs_mvar'].to_numpy(float) + df['qz_mvar'].to_numpy(float) * v2)
+        vi, ai = np.full(len(df), np.nan), np.full(len(df), np.nan)
+        s_f, _ = branch_flows(ppc, np.nan_to_num(v, nan=0.0), sol['status'])
+        for k in np.flatnonzero(np.array([tb == 'xward' for tb in ppc.br_table], dtype=bool)):
+            pos = int(ppc.br_pos[k])
+            px[pos] += s_f[k].real * ppc.base_mva           # what flows into the impedance towards the internal source
+            qx[pos] += s_f[k].imag * ppc.base_mva
+            vi[pos], ai[pos] = abs(v[ppc.t[k]]), np.degrees(np.angle(v[ppc.t[k]]))
+        net['res_xward'] = pd.DataFrame({'p_mw': px, 'q_mvar': qx, 'vm_pu': vmw, 'va_internal_degree': ai, 'vm_internal_pu': vi},
+                                        index=df.index)
     if 'motor' in net and len(net['motor']):
         df = net['motor']
         p_m, q_m = pd2ppc.motor_pq(df)

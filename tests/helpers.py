@@ -44,16 +44,18 @@ class OracleSide:
         first = {}
         for b, i in case.bus_lookup.items():
             first.setdefault(i, b)
-        # product bus -> ppc bus; the star buses of three-winding transformers have no net index: both sides
-        # append them after the net's buses, in the order of the transformers
-        n_aux = case.nb - len(first)
-        self.bus_map = np.array([self.ppc.bus_lookup[first[i]] if i in first else self.ppc.n_net_buses + (i - (case.nb - n_aux))
-                                 for i in range(case.nb)])
-        tables = {0: 'line', 1: 'trafo', 2: 'trafo3w', 3: 'impedance', 4: 'switch'}
+        tables = {0: 'line', 1: 'trafo', 2: 'trafo3w', 3: 'impedance', 4: 'switch', 5: 'xward'}
         sides = case.br_side if case.br_side is not None else np.zeros(case.nbr, int)
         self.br_map = np.array([self.ppc.branch_of(tables[int(kd)], int(e), ('hv', 'mv', 'lv')[int(sd)] if kd == 2 else '')
                                 for kd, e, sd in zip(case.br_kind, case.br_elem, sides)])
         assert (self.br_map >= 0).all()
+        # product bus -> ppc bus; the auxiliary buses (star points of three-winding transformers, internal buses of xwards)
+        # have no net index: they are matched through the branch that ends at them (hv winding -> star, xward impedance -> source)
+        aux = {}
+        for k, (kd, sd) in enumerate(zip(case.br_kind, sides)):
+            if (kd == 2 and sd == 0) or kd == 5:
+                aux[int(case.t[k])] = int(self.ppc.t[self.br_map[k]])
+        self.bus_map = np.array([self.ppc.bus_lookup[first[i]] if i in first else aux[i] for i in range(case.nb)])
         self.ref = np.flatnonzero(case.bus_type == 3)
 
     def solve(self, p, q, outage=-1, qg_min=None, qg_max=None, enforce_q_lims=False, tol=1e-8, max_it=10, init='flat'):

@@ -280,6 +280,68 @@ def ward_is_a_load_and_a_shunt():
     return a, b, compare
 
 
+def xward_is_a_ward_and_a_voltage_source_behind_an_impedance():
+    """pandapower's extended ward: the ward's two parts at the bus plus, behind r_ohm + j x_ohm, an internal bus that a source
+    without active power holds at vm_pu — built here from a ward, an extra bus, a line without capacitance and a generator
+    with p_mw = 0."""
+    a, _ = _two_winding_pair()
+    bus = int(a.bus.index[3])
+    N.create_xward(a, bus, ps_mw=0.9, qs_mvar=0.3, pz_mw=0.5, qz_mvar=-1.1, r_ohm=0.6, x_ohm=5.0, vm_pu=1.015)
+    N.finalize(a)
+    b, _ = _two_winding_pair()
+    N.create_ward(b, bus, ps_mw=0.9, qs_mvar=0.3, pz_mw=0.5, qz_mvar=-1.1)
+    inner = N.create_bus(b, 20.)
+    N.create_line_from_parameters(b, bus, inner, 1.0, 0.6, 5.0, 0.0, 1.0)
+    N.create_gen(b, inner, 0.0, vm_pu=1.015)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        common = list(ra.bus.index)
+        _compare_all(ra, rb, buses_a=common, buses_b=common, lines=False)
+        _same(_col(ra, 'res_line', 'loading_percent'), _col(rb, 'res_line', 'loading_percent')[:2], LD_TOL, 'line loading')
+        vm = float(ra.res_bus.vm_pu.at[bus])
+        i_ka = float(rb.res_line.loading_percent.iloc[2]) / 100.0 * 1.0          # (max_i_ka = 1)
+        x = ra.res_xward.iloc[0]
+        _same([x.vm_internal_pu], [1.015], VM_TOL, 'internal |V|')
+        _same([x.vm_internal_pu, x.vm_pu], [float(rb.res_bus.vm_pu.at[inner]), vm], VM_TOL, 'voltages')
+        _angle_same([x.va_internal_degree], [float(rb.res_bus.va_degree.at[inner])], VA_TOL, 'internal angle')
+        # into the impedance: its losses (the source gives no active power) and, reactive, what the source does not deliver
+        _same([x.p_mw], [0.9 + 0.5 * vm ** 2 + 3 * 0.6 * i_ka ** 2], S_TOL, 'res_xward.p_mw')
+        _same([x.q_mvar], [0.3 - 1.1 * vm ** 2 + 3 * 5.0 * i_ka ** 2 - float(rb.res_gen.q_mvar.iloc[0])], S_TOL, 'res_xward.q_mvar')
+    return a, b, compare
+
+
+def dcline_is_two_generators():
+    """pandapower runs a DC line as two generators (`_add_dcline_gens`): at the to bus one feeding in p_mw less the relative and
+    the fixed losses at vm_to_pu, at the from bus one with -p_mw at vm_from_pu, each within its side's reactive range."""
+    def base():
+        net, _ = _two_winding_pair()
+        far = N.create_bus(net, 20.)
+        N.create_line_from_parameters(net, int(net.bus.index[3]), far, 5.0, 0.16, 0.12, 270.0, 0.36)
+        N.create_load(net, far, 3.0, 0.8)
+        return net, int(net.bus.index[2]), far
+    a, near, far = base()
+    N.create_dcline(a, near, far, p_mw=2.5, loss_percent=3.0, loss_mw=0.04, vm_from_pu=1.0, vm_to_pu=1.012,
+                    min_q_from_mvar=-2.0, max_q_from_mvar=2.0, min_q_to_mvar=-0.2, max_q_to_mvar=0.2)
+    N.create_dcline(a, far, near, p_mw=9.0, loss_percent=1.0, loss_mw=0.0, vm_from_pu=1.0, vm_to_pu=1.0, in_service=False)
+    N.finalize(a)
+    b, near, far = base()
+    N.create_gen(b, far, 2.5 * 0.97 - 0.04, vm_pu=1.012, min_q_mvar=-0.2, max_q_mvar=0.2)
+    N.create_gen(b, near, -2.5, vm_pu=1.0, min_q_mvar=-2.0, max_q_mvar=2.0)
+    N.finalize(b)
+
+    def compare(ra, rb):
+        _compare_all(ra, rb)
+        d, g = ra.res_dcline, rb.res_gen
+        _same(d.p_from_mw, [2.5, 0.0], S_TOL, 'p_from_mw')
+        _same(d.p_to_mw, [-(2.5 * 0.97 - 0.04), 0.0], S_TOL, 'p_to_mw')
+        _same(d.pl_mw, [2.5 * 0.03 + 0.04, 0.0], S_TOL, 'pl_mw')
+        _same(d.q_to_mvar, [-float(g.q_mvar.iloc[0]), 0.0], S_TOL, 'q_to_mvar')
+        _same(d.q_from_mvar, [-float(g.q_mvar.iloc[1]), 0.0], S_TOL, 'q_from_mvar')
+        _same([d.vm_to_pu.iloc[0], d.vm_from_pu.iloc[0]], [float(ra.res_bus.vm_pu.at[far]), float(ra.res_bus.vm_pu.at[near])], VM_TOL, 'end voltages')
+    return a, b, compare
+
+
 def motor_is_a_load():
     """pandapower's motor: P = pn_mech / efficiency x loading x scaling, Q from cos_phi (inductive)."""
     a, _ = _two_winding_pair()
@@ -348,14 +410,14 @@ def bus_bus_switch_with_impedance_is_a_short_line():
     return a, b, compare
 
 
-CASES = {f.__name__: f for f in (ward_is_a_load_and_a_shunt, motor_is_a_load, symmetric_impedance_is_a_line_without_charging,
+CASES = {f.__name__: f for f in (ward_is_a_load_and_a_shunt, xward_is_a_ward_and_a_voltage_source_behind_an_impedance, dcline_is_two_generators, motor_is_a_load, symmetric_impedance_is_a_line_without_charging,
                                  bus_bus_switch_with_impedance_is_a_short_line,
                                  ideal_phase_shifter_is_a_changed_vector_group, storage_is_a_load, bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
                                  parallel_two_is_two_elements, vector_group_shift_turns_the_angles_behind_it,
                                  shunt_is_a_constant_impedance_load, two_ext_grids_at_one_set_point_are_a_fused_slack,
                                  open_bus_bus_switch_is_no_switch)}
 # pairs that must compile to the SAME bus admittance matrix in the product's converter (no solve needed to compare them)
-SAME_ADMITTANCES = ('ward_is_a_load_and_a_shunt', 'motor_is_a_load', 'symmetric_impedance_is_a_line_without_charging',
+SAME_ADMITTANCES = ('ward_is_a_load_and_a_shunt', 'dcline_is_two_generators', 'motor_is_a_load', 'symmetric_impedance_is_a_line_without_charging',
                     'bus_bus_switch_with_impedance_is_a_short_line', 'ideal_phase_shifter_is_a_changed_vector_group', 'storage_is_a_load', 'lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
                     'open_bus_bus_switch_is_no_switch', 'bus_bus_switch_is_one_bus')
 

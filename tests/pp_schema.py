@@ -149,8 +149,6 @@ def unmodelled_variants():
         return f
     b = 1
     return [
-        ('xward', add_row('xward', bus=b, ps_mw=0.1, r_ohm=0.1, x_ohm=1.0, vm_pu=1.0, in_service=True)),
-        ('dcline', add_row('dcline', from_bus=1, to_bus=2, p_mw=1.0, vm_from_pu=1.0, vm_to_pu=1.0, in_service=True)),
         ('asymmetric_load', add_row('asymmetric_load', bus=b, p_a_mw=0.01, in_service=True)),
         ('svc', add_row('svc', bus=b, x_l_ohm=1.0, x_cvar_ohm=-10.0, set_vm_pu=1.0, in_service=True)),
         ('load.const_z_percent', set_col('load', 'const_z_percent', 30.0)),

@@ -70,18 +70,22 @@ def test_static_consumption_and_injections_of_the_helper_grid():
     p_m = 0.25 / 0.94 * 0.8 * 1.2
     assert np.allclose(static['motor'][0], [p_m, 0.0]) and np.allclose(static['motor'][1], [p_m * np.tan(np.arccos(0.87)), 0.0])
     case = net_to_case(net)
+    assert np.allclose(static['xward'][0], [0.06, 0.0]) and np.allclose(static['xward'][1], [0.02, 0.0])
     plain = copy.deepcopy(net)
-    for tbl in ('ward', 'motor'):
+    for tbl in ('ward', 'motor', 'xward'):
         plain[tbl] = plain[tbl].iloc[0:0]
     p1, q1 = bus_injections(net, case)[:2]
-    p0, q0 = bus_injections(plain, case)[:2]
-    assert abs((p0 - p1).sum() - (0.12 + p_m)) < 1e-12 and abs((q0 - q1).sum() - (0.04 + static['motor'][1][0])) < 1e-12
+    p0, q0 = bus_injections(plain, net_to_case(plain))[:2]
+    assert abs(p0.sum() - p1.sum() - (0.12 + 0.06 + p_m)) < 1e-12 and abs(q0.sum() - q1.sum() - (0.04 + 0.02 + static['motor'][1][0])) < 1e-12
     # the wards' constant-impedance parts are shunts at 1 p.u. of their bus
-    assert abs(case.gs.sum() * case.base_mva - 0.08) < 1e-12 and abs(case.bs.sum() * case.base_mva - (0.15 + 0.3)) < 1e-12
+    assert abs(case.gs.sum() * case.base_mva - (0.08 + 0.04)) < 1e-12 and abs(case.bs.sum() * case.base_mva - (0.15 + 0.3 + 0.05)) < 1e-12
+    # the in-service xward's internal source: one auxiliary PV bus at its set-point behind the impedance
+    (pos, aux), = case.meta['xward_bus'].items()
+    assert pos == 0 and case.bus_type[aux] == 2 and case.vm_set[aux] == 1.01 and aux not in case.bus_lookup.values()
 
 
 @pytest.mark.parametrize('label,mutate', [
-    ('xward', lambda net: net.__setitem__('xward', net['ward'].assign(r_ohm=0.1, x_ohm=1.0, vm_pu=1.0))),
+    ('svc', lambda net: net.__setitem__('svc', net['ward'].assign(x_l_ohm=1.0, x_cvar_ohm=-10.0, set_vm_pu=1.0))),
     ('z_ohm', lambda net: (N.create_switch(net, int(net.line.from_bus.iloc[0]), int(net.line.index[0]), 'l', closed=True, z_ohm=0.1), N.finalize(net))),
     ('slack', lambda net: net.gen.__setitem__('slack', True) if len(net.gen) else net.__setitem__('gen', net['gen'])),
 ])

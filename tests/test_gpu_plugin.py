@@ -46,11 +46,14 @@ def test_plugin_matches_oracle_tables(code):
                            ('res_ext_grid', ('p_mw', 'q_mvar'), 1e-6), ('res_sgen', ('p_mw', 'q_mvar'), 0),
                            ('res_load', ('p_mw', 'q_mvar'), 0), ('res_gen', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6),
                            ('res_ward', ('p_mw', 'q_mvar', 'vm_pu'), 1e-6), ('res_motor', ('p_mw', 'q_mvar'), 1e-12),
+                           ('res_xward', ('p_mw', 'q_mvar', 'vm_pu', 'va_internal_degree', 'vm_internal_pu'), 1e-6),
+                           ('res_dcline', ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw', 'vm_from_pu', 'vm_to_pu',
+                                           'va_from_degree', 'va_to_degree'), 1e-6),
                            ('res_impedance', ('p_from_mw', 'q_from_mvar', 'p_to_mw', 'q_to_mvar', 'pl_mw', 'ql_mvar', 'i_from_ka',
                                               'i_to_ka'), 1e-6)):
         if tbl == 'res_trafo3w' and not len(net['trafo3w']):
             continue
-        if tbl in ('res_ward', 'res_motor', 'res_impedance'):
+        if tbl in ('res_ward', 'res_motor', 'res_impedance', 'res_xward', 'res_dcline'):
             if code != 'mv-small-beyond-simbench':
                 continue
             assert len(ref[tbl]) >= 2

@@ -188,6 +188,14 @@ def _random_net(rng):
             ppn.create_impedance(net, a_, b_, r_, x_, float(rng.choice([10.0, 40.0, 100.0])),
                                  rtf_pu=r_ * float(rng.uniform(0.8, 1.3)) if asym_ else None,
                                  xtf_pu=x_ * float(rng.uniform(0.8, 1.3)) if asym_ else None, in_service=bool(rng.random() > 0.15))
+        for b in rng.choice(mv, 2, replace=False):         # extended wards: an internal PV bus behind an impedance each
+            ppn.create_xward(net, int(b), float(rng.uniform(0.0, 0.3)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(0.0, 0.2)),
+                             float(rng.uniform(-0.2, 0.2)), float(rng.uniform(0.1, 2.0)), float(rng.uniform(1.0, 12.0)),
+                             float(rng.uniform(0.99, 1.03)), in_service=bool(rng.random() > 0.25))
+        a_, b_ = rng.choice(mv, 2, replace=False)           # a DC line between two MV buses: two generators in the power flow
+        ppn.create_dcline(net, int(a_), int(b_), float(rng.uniform(0.1, 1.0)), float(rng.uniform(0.0, 4.0)), float(rng.uniform(0.0, 0.02)),
+                          float(rng.uniform(0.99, 1.02)), float(rng.uniform(0.99, 1.02)), min_q_from_mvar=-1.0, max_q_from_mvar=1.0,
+                          min_q_to_mvar=-1.0, max_q_to_mvar=1.0, in_service=bool(rng.random() > 0.25))
         far = ppn.create_bus(net, 20.0)
         ppn.create_load(net, far, 0.15, 0.03)
         ppn.create_switch(net, mv[2], far, 'b', closed=True, z_ohm=float(rng.uniform(0.01, 0.5)))
