@@ -27,10 +27,18 @@ def product_env(name, batch_size=1, defer_device=False, **extra):
     kw = dict(kwargs)
     kw.update(PRODUCT_KWARGS.get(base, {}))
     kw.update(extra)
-    if variant == 'beyond' and 'definition' not in kw:
-        import beyond_simbench
+    if variant in ('beyond', 'narrowq') and 'definition' not in kw:
         d = getattr(product_envs, cls)(seed=seed, batch_size=1, defer_device=True, **kw).definition
-        beyond_simbench.add_elements(d.net)
+        if variant == 'beyond':
+            import beyond_simbench
+            beyond_simbench.add_elements(d.net)
+        else:
+            # `<scenario>+narrowq`: the grid's own generators with reactive ranges narrow enough to bind in most states (the
+            # q-limit loop together with whatever the scenario actuates: taps, switches, contingencies)
+            n = len(d.net.gen)
+            assert n, name
+            d.net.gen['min_q_mvar'] = -(2.0 + 1.5 * np.arange(n))
+            d.net.gen['max_q_mvar'] = 1.0 + 2.0 * np.arange(n)[::-1]
         kw['definition'] = d
     return getattr(product_envs, cls)(seed=seed, batch_size=batch_size, defer_device=defer_device, **kw)
 
