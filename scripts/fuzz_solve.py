@@ -65,6 +65,37 @@ def random_grid(rng):
         buses = rng.choice(net['bus'].index.to_numpy(), min(3, len(net['bus'])), replace=False)
         net['shunt'] = pd.DataFrame(dict(bus=buses, p_mw=0.0, q_mvar=rng.uniform(-0.5, 0.5, len(buses)),
                                          vn_kv=net['bus']['vn_kv'].loc[buses].to_numpy(), step=1, in_service=True))
+    if rng.random() < 0.5:
+        # element types beyond the SimBench grids (round 6): wards, extended wards (an auxiliary PV bus), series impedances (some with
+        # different values per direction), DC lines (two generators), a closed bus-bus switch with an impedance, motors
+        from opfgym_amd import net as N
+        kv = float(net['bus']['vn_kv'].value_counts().index[0])
+        lvl = net['bus'].index[net['bus']['vn_kv'] == kv].to_numpy()
+        sn, zb = float(net['sn_mva']), kv ** 2 / float(net['sn_mva'])
+        pick = lambda k: [int(b) for b in rng.choice(lvl, min(k, len(lvl)), replace=False)]
+        for b in pick(2):
+            N.create_ward(net, b, sn * rng.uniform(0, 0.05), sn * rng.uniform(-0.02, 0.02), sn * rng.uniform(0, 0.05), sn * rng.uniform(-0.05, 0.05),
+                          in_service=bool(rng.random() > 0.2))
+        for b in pick(2):
+            N.create_xward(net, b, sn * rng.uniform(0, 0.03), 0.0, sn * rng.uniform(0, 0.03), sn * rng.uniform(-0.03, 0.03),
+                           zb * rng.uniform(0.005, 0.05), zb * rng.uniform(0.02, 0.3), float(rng.uniform(0.99, 1.03)), in_service=bool(rng.random() > 0.2))
+        if len(lvl) >= 4:
+            a, b, c, d = pick(4)
+            asym = rng.random() < 0.4
+            r_, x_ = float(rng.uniform(0.002, 0.03)), float(rng.uniform(0.01, 0.1))
+            N.create_impedance(net, a, b, r_, x_, sn, rtf_pu=r_ * rng.uniform(0.8, 1.25) if asym else None,
+                               xtf_pu=x_ * rng.uniform(0.8, 1.25) if asym else None)
+            N.create_dcline(net, c, d, sn * rng.uniform(0.01, 0.2), float(rng.uniform(0, 4)), 0.0, float(rng.uniform(0.99, 1.02)),
+                            float(rng.uniform(0.99, 1.02)), min_q_from_mvar=-sn, max_q_from_mvar=sn, min_q_to_mvar=-sn, max_q_to_mvar=sn)
+        far = N.create_bus(net, kv)
+        for c_ in net['bus'].columns:
+            if c_ not in ('name', 'vn_kv'):
+                net['bus'].at[far, c_] = net['bus'].at[int(lvl[0]), c_]
+        N.create_load(net, far, sn * 0.02, sn * 0.005)
+        N.create_switch(net, pick(1)[0], far, 'b', closed=True, z_ohm=zb * float(rng.uniform(0.0005, 0.01)))
+        N.create_motor(net, pick(1)[0], sn * 0.02, 0.85, 93.0, 80.0)
+        N.finalize(net)
+        desc += ' +beyond'
     return net, desc
 
 

@@ -72,7 +72,8 @@ class OracleSide:
             inv = {int(b): i for i, b in enumerate(self.bus_map)}
             n_at = np.bincount(ppc.g_bus, minlength=ppc.nb)
             for g in range(len(ppc.g_bus)):
-                if ppc.g_table[g] == 'gen' and int(ppc.g_bus[g]) in inv:
+                # (every generator row that regulates a bus: the net's generators, the two ends of DC lines, the internal sources of xwards)
+                if ppc.g_table[g] != 'ext_grid' and int(ppc.g_bus[g]) in inv:
                     i = inv[int(ppc.g_bus[g])]
                     ppc.g_qmin[g] = max(qg_min[i] * base / n_at[ppc.g_bus[g]], -1e9)
                     ppc.g_qmax[g] = min(qg_max[i] * base / n_at[ppc.g_bus[g]], 1e9)
