@@ -129,7 +129,9 @@ def class_options(rng, base):
             kw['storage_efficiency'] = 0.9
     elif base == 'sc_hv_small':
         if rng.random() < 0.3:
-            kw['simbench_network_name'] = '1-HV-urban--0-sw'     # 372 buses: the wave-team kernel, N-1
+            # 372 buses: the wave-team kernel, N-1; OPFX_FUZZ_SC_GRID=1-HV-mixed--0-sw: the 306-bus grid instead — three teams per CU on
+            # the plan with shared LDS slots, compiled for three wavefronts per SIMD, WITH contingency modifiers
+            kw['simbench_network_name'] = os.environ.get('OPFX_FUZZ_SC_GRID', '1-HV-urban--0-sw')
             kw.pop('grid_seed', None)
         if rng.random() < 0.5:
             kw['n_minus_one_lines'] = pick(rng, [(1,), (0, 2, 5), (1, 3, 7, 9)])

@@ -1946,3 +1946,32 @@ def test_warm_started_contingencies_hold_pv_buses_at_their_set_points():
             lim = np.isclose(q, orc.net.gen.min_q_mvar.to_numpy()) | np.isclose(q, orc.net.gen.max_q_mvar.to_numpy())
             pinned += int(lim.any())
     assert pinned >= B // 2                # (the narrow ranges bind: the case the test is about)
+
+
+def test_contingencies_on_the_shared_slot_plan_with_binding_generator_limits():
+    """N-1 on the 306-bus grid: three teams per CU on the plan with shared LDS slots, the kernel compiled for three wavefronts
+    per SIMD — here WITH contingency modifiers folded into its bus rounds and the q-limit loop switching generators whose
+    reactive ranges bind (`sc_hv_small+narrowq` on 1-HV-mixed--0-sw): every row against the oracle's environment."""
+    from env_cases import oracle_env, product_env
+    kw = dict(simbench_network_name='1-HV-mixed--0-sw', n_minus_one_lines=(0, 2, 5), add_res_obs=True)
+    B = 8
+    env = product_env('sc_hv_small+narrowq', batch_size=B, **kw)
+    orc = oracle_env('sc_hv_small+narrowq', product_env('sc_hv_small+narrowq', defer_device=True, **kw))
+    rng = np.random.default_rng(77)
+    steps = rng.choice(env.train_steps, B)
+    actions = rng.random((B, env.n_actions))
+    env.reset(options={'step': steps})
+    out = env.step(actions)
+    ki = env.kernel_info()                    # (what the launch ran on)
+    assert ki['shared_slots'] and ki['instances_per_cu'] == 3 and ki['waves_per_instance'] == 4, ki
+    n_ok = pinned = 0
+    for k in range(B):
+        orc.reset(int(steps[k]))
+        ref = orc.step(actions[k])
+        assert bool(_np(out[4]['converged'])[k]) == ref['converged']
+        if ref['converged']:
+            _check_step(env, out, dict(ref, obs_step=ref['obs']), k, n1=True)
+            n_ok += 1
+            q = orc.net.res_gen.q_mvar.to_numpy()
+            pinned += int((np.isclose(q, orc.net.gen.min_q_mvar.to_numpy()) | np.isclose(q, orc.net.gen.max_q_mvar.to_numpy())).any())
+    assert n_ok >= B // 2 and pinned >= 1
