@@ -48,8 +48,8 @@ class Case:
     ytt: np.ndarray
     kf: np.ndarray                # f64 [nbr] loading% = max(|If|*kf, |It|*kt)
     kt: np.ndarray
-    br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo / 2 trafo3w winding / 3 impedance / 4 bus-bus switch with z_ohm
-    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w / net.impedance / net.switch
+    br_kind: np.ndarray           # int32 [nbr]  0 line / 1 trafo / 2 trafo3w winding / 3 impedance / 4 bus-bus switch with z_ohm / 5 xward impedance
+    br_elem: np.ndarray           # int32 [nbr]  positional row in net.line / net.trafo / net.trafo3w / net.impedance / net.switch / net.xward
     br_side: np.ndarray = None    # int32 [nbr]  trafo3w: 0 hv, 1 mv, 2 lv winding of its star equivalent (else 0)
     # DC model of the branches (pypower makeBdc; for opfx_solve_opts.init = OPFX_INIT_DC)
     bdc: np.ndarray = None        # f64 [nbr]  1 / (x * ratio), 0 for a branch that couples nothing (open-ended)
