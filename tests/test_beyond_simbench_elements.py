@@ -99,3 +99,32 @@ def test_what_stays_refused(label, mutate):
         net_to_case(net)
     with pytest.raises(ValueError, match=label):
         pd2ppc.build_ppc(net)
+
+
+@pytest.mark.parametrize('enforce', [False, True])
+def test_the_table_writer_reports_the_new_elements_as_the_oracle_does(enforce):
+    """The plug-in's table writer (`solver_plugin._write_results`) fed with per-BUS results taken from the oracle's solution
+    writes the oracle's own `res_ward / res_xward / res_motor / res_impedance / res_dcline` — and `res_gen` where a DC line ends
+    on the bus of a generator (its end joins pfsoln's split of the bus's reactive power) — on the CPU, no solver involved
+    (the same helper as tests/test_generator_dispatch.py)."""
+    from test_generator_dispatch import tables_from_per_bus_results
+    from opfgym_amd import grids
+    net, _ = grids.get_grid('hv-small')
+    beyond_simbench.add_elements(net)
+    gen_bus = int(net.gen.bus.iloc[1])
+    net.gen.loc[net.gen.index[1], ['min_q_mvar', 'max_q_mvar']] = [-30.0, 40.0]
+    other = int(net.bus.index[net.bus.vn_kv == net.bus.vn_kv.at[gen_bus]][5])
+    N.create_dcline(net, other, gen_bus, p_mw=6.0, loss_percent=2.0, loss_mw=0.1, vm_from_pu=1.0, vm_to_pu=float(net.gen.vm_pu.iloc[1]),
+                    min_q_from_mvar=-5.0, max_q_from_mvar=5.0, min_q_to_mvar=-10.0, max_q_to_mvar=20.0)
+    N.finalize(net)
+    out, ref, sol = tables_from_per_bus_results(net, enforce)
+    checked = 0
+    for tbl in ('res_gen', 'res_ext_grid', 'res_ward', 'res_xward', 'res_motor', 'res_impedance', 'res_dcline'):
+        for col in ref[tbl].columns:
+            a, b = out[tbl][col].to_numpy(float), ref[tbl][col].to_numpy(float)
+            assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=1e-6, equal_nan=True), (tbl, col, a, b)
+            checked += 1
+    assert checked >= 25
+    # the line's to end and the generator share the bus's reactive power by their ranges: neither reports the bus total
+    q_gen, q_to = float(ref.res_gen.q_mvar.iloc[1]), -float(ref.res_dcline.q_to_mvar.iloc[-1])
+    assert abs(q_gen) > 1e-3 and abs(q_to) > 1e-3 and abs(q_gen - q_to) > 1e-3

@@ -45,7 +45,7 @@ def per_bus_solver_output(net, case, sol):
     ppc, base = sol['ppc'], sol['ppc'].base_mva
     v = sol['V'][side.bus_map]
     ld = po.loading_percent(ppc, net, sol['V'], sol['status'])
-    loading = np.array([ld[('line', 'trafo', 'trafo3w')[int(kd)]][int(e)] for kd, e in zip(case.br_kind, case.br_elem)])
+    loading = np.array([ld[('line', 'trafo', 'trafo3w')[int(kd)]][int(e)] if kd < 3 else 0.0 for kd, e in zip(case.br_kind, case.br_elem)])
     live = (ppc.g_status > 0) & sol['supplied'][ppc.g_bus]
     q_bus, p_first = np.zeros(ppc.nb), np.zeros(ppc.nb)
     np.add.at(q_bus, ppc.g_bus[live], sol['qg'][live])
