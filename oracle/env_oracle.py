@@ -528,7 +528,8 @@ class EnvOracle:
                     line_loading=self.net.res_line.loading_percent.to_numpy(float),
                     trafo_loading=self.net.res_trafo.loading_percent.to_numpy(float),
                     p_ext=self.net.res_ext_grid.p_mw.to_numpy(float),
-                    q_ext=self.net.res_ext_grid.q_mvar.to_numpy(float))
+                    q_ext=self.net.res_ext_grid.q_mvar.to_numpy(float),
+                    **({'q_gen': self.net.res_gen.q_mvar.to_numpy(float)} if len(self.net.gen) else {}))
 
 
 # ---------------------------------------------------------------------------

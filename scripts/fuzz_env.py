@@ -186,7 +186,8 @@ def run_one(base, kw, rng, B=8):
         outs.append(dict(obs=np_(o[0]).copy(), reward=np_(o[1]).copy(), term=np_(o[2]).copy(), trunc=np_(o[3]).copy(),
                          conv=np_(o[4]['converged']).copy(), valids=np_(o[4]['valids']).copy(),
                          viol=np_(o[4]['violations']).copy(), pen=np_(o[4]['unscaled_penalties']).copy(),
-                         cost=np_(o[4]['cost']).copy(), vm=np_(env.result_table('bus', 'vm_pu')).copy()))
+                         cost=np_(o[4]['cost']).copy(), vm=np_(env.result_table('bus', 'vm_pu')).copy(),
+                         q_gen=np_(env.result_table('gen', 'q_mvar')).copy() if len(env.net.gen) else None))
     checked = 0
     for k in range(B):
         # (the reference draws sequentially and only what the data source needs; the product has one
@@ -234,11 +235,15 @@ def run_one(base, kw, rng, B=8):
             nc = len(ref['valids'])
             assert (got['valids'][k][:nc] == ref['valids']).all(), ('valids', k, s_)
             assert np.allclose(got['viol'][k][:nc], ref['violations'], rtol=REL, atol=R_TOL), ('violations', k, s_)
-            assert np.allclose(got['pen'][k][:nc], ref['penalties'], rtol=REL, atol=R_TOL), ('penalties', k, s_)
+            # (penalty = factor * violation ** power: the relative error of a violation enters `power` times)
+            rel_pen = REL * max(1.0, float((kw.get('constraint_params') or {}).get('penalty_power', 1.0)))
+            assert np.allclose(got['pen'][k][:nc], ref['penalties'], rtol=rel_pen, atol=R_TOL), ('penalties', k, s_)
             assert np.isclose(got['cost'][k], ref['cost'], rtol=REL, atol=R_TOL), ('cost', k, s_)
             assert bool(got['term'][k]) == bool(ref['terminated']), ('terminated', k, s_)
             if not env.n_minus_one_keys:          # (after an N-1 step the tables hold the last contingency, D7)
                 assert np.allclose(got['vm'][k], ref['vm_pu'], rtol=0, atol=V_TOL, equal_nan=True), ('vm', k, s_, float(np.nanmax(np.abs(got['vm'][k] - ref['vm_pu']))))
+                if got['q_gen'] is not None and 'q_gen' in ref:      # res_gen.q_mvar per generator (pfsoln's split; the generators of DC lines last)
+                    assert np.allclose(got['q_gen'][k], ref['q_gen'], rtol=REL, atol=1e-6), ('q_gen', k, s_, float(np.abs(got['q_gen'][k] - ref['q_gen']).max()))
             checked += 1
             if ref['terminated'] or ref.get('truncated'):
                 break

@@ -211,7 +211,8 @@ def _check_rows_against_oracle(env, orc, out, obs0, steps, uniform, actions, row
     sub_info = {k: info[k][idx] for k in ('valids', 'violations', 'unscaled_penalties', 'cost', 'converged')}
     sub = (obs[idx], reward[idx], term[idx], trunc[idx], sub_info)
     tables = {} if env.n_minus_one_keys else {key: _np(env.result_table(*key)[idx]) for key in (
-        ('bus', 'vm_pu'), ('bus', 'va_degree'), ('line', 'loading_percent'), ('trafo', 'loading_percent'), ('ext_grid', 'p_mw'), ('ext_grid', 'q_mvar'))}
+        ('bus', 'vm_pu'), ('bus', 'va_degree'), ('line', 'loading_percent'), ('trafo', 'loading_percent'), ('ext_grid', 'p_mw'), ('ext_grid', 'q_mvar'))
+        + ((('gen', 'q_mvar'),) if len(env.net.gen) else ())}
     sub = (_np(sub[0]), _np(sub[1]), _np(sub[2]), _np(sub[3]), {k: _np(v) for k, v in sub_info.items()})
     obs0 = _np(obs0[idx])
 
