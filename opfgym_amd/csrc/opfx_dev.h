@@ -1811,6 +1811,12 @@ __device__ void init_voltage(const DevPlan& P, const Lds& L, int lane, const dou
       bt0 = BT_PQ_HI;
       L.qsp[i] += qg_max[i];
     }
+    // A NaN reactive injection at a PV bus: the bus's Q mismatch is no equation of the power flow, so the solve would converge
+    // around it — pypower's does not (makeSbus builds P + 1j * Q, and 1j * NaN is NaN + NaN j: the ACTIVE mismatch of the bus is NaN
+    // as well).  Reachable: voltage_control.py:123-125 takes sqrt(max_s^2 - p^2) for the reactive range of a controllable unit,
+    // NaN where p exceeds max_s by rounding, and the action's set-point with it (found by the fuzzer once such a unit sat on a
+    // regulated bus, round 6).
+    if (!NOPV && bt0 == BT_PV && L.qsp[i] != L.qsp[i]) L.psp[i] = L.qsp[i];
     L.bt[i] = (unsigned char)bt0;
   }
 }

@@ -529,7 +529,9 @@ class EnvOracle:
                     trafo_loading=self.net.res_trafo.loading_percent.to_numpy(float),
                     p_ext=self.net.res_ext_grid.p_mw.to_numpy(float),
                     q_ext=self.net.res_ext_grid.q_mvar.to_numpy(float),
-                    **({'q_gen': self.net.res_gen.q_mvar.to_numpy(float)} if len(self.net.gen) else {}))
+                    **({'q_gen': self.net.res_gen.q_mvar.to_numpy(float)} if len(self.net.gen) else {}),
+                    **({'trafo3w_loading': self.net.res_trafo3w.loading_percent.to_numpy(float)}
+                       if 'trafo3w' in self.net and len(self.net.trafo3w) and 'res_trafo3w' in self.net else {}))
 
 
 # ---------------------------------------------------------------------------

@@ -22,7 +22,7 @@ R_TOL, V_TOL = 1e-6, 1e-7      # (both Newton solvers stop at ||F||inf < 1e-8 p.
 REL = 1e-6          # relative part for rewards/penalties (penalty_power 2 and large cost coefficients amplify the 1e-8 p.u. solver tolerance)
 BASES = ['vc_mv_small', 'qm_mv_small', 'eco_hv_small', 'eco_hv_small_shared', 'maxren_lv', 'loadshed_mv_small', 'mixed_lv',
          'sc_hv_small', 'reconf_hv_small_sw', 'shunt_hv_small_sw', 'busbar_hv_small_sw', 'nonsimbench_case9', 'constraint_sat_lv', 'partial_obs_lv',
-         'custom_constraint_lv', 'multistage_lv']
+         'custom_constraint_lv', 'multistage_lv', 'vc_mv_3w']
 
 
 def pick(rng, seq):
@@ -101,7 +101,7 @@ def class_options(rng, base):
     base = base.partition('+')[0]          # (`<scenario>+beyond`: the scenario with wards, motors, impedances ... added, env_cases.product_env)
     if base not in ('nonsimbench_case9', 'constraint_sat_lv') and rng.random() < 0.5:
         kw['grid_seed'] = int(rng.integers(1, 50))      # another instance of the synthetic grid family
-    if base in ('vc_mv_small', 'qm_mv_small'):
+    if base in ('vc_mv_small', 'qm_mv_small', 'vc_mv_3w'):
         if rng.random() < 0.5:
             kw['load_scaling'] = pick(rng, [1.2, 2.0])
         if rng.random() < 0.5:

@@ -42,6 +42,8 @@ def _check_step(env, out, ref, k, n1=False):
         assert np.allclose(_np(env.result_table('ext_grid', 'q_mvar'))[k], ref['q_ext'], rtol=0, atol=R_TOL)
         if 'q_gen' in ref:                    # res_gen.q_mvar per generator: pypower pfsoln's split of the bus total (P6)
             assert np.allclose(_np(env.result_table('gen', 'q_mvar'))[k], ref['q_gen'], rtol=0, atol=R_TOL)
+        if 'trafo3w_loading' in ref and hasattr(env, 'net'):       # three-winding transformers: the worst of the three terminals
+            assert np.allclose(_np(env.result_table('trafo3w', 'loading_percent'))[k], ref['trafo3w_loading'], rtol=0, atol=R_TOL, equal_nan=True)
 
 
 @pytest.mark.parametrize('name', SINGLE_STEP)
@@ -149,7 +151,7 @@ def test_reset_kernel_teams_of_one_and_two_wavefronts(name, team, monkeypatch):
 
 @pytest.mark.parametrize('name,B', [('vc_mv_small', 48), ('qm_mv_small', 32), ('eco_hv_small', 24),
                                     ('sc_hv_small', 12), ('vc_resobs_diff', 16), ('reconf_hv_small_sw', 32),
-                                    ('mixed_lv', 32)])
+                                    ('mixed_lv', 32), ('vc_mv_3w', 16)])
 def test_env_matches_oracle_random_batch(name, B):
     env = product_env(name, batch_size=B)
     orc = oracle_env(name, product_env(name, defer_device=True))

@@ -735,3 +735,27 @@ def test_pivot_breakdown_is_located_and_a_rescue_plan_recovers_it():
     assert (got['min_pivot'] > 1e-3).all() and ((got['min_pivot_bus'] >= 0) & (got['min_pivot_bus'] < case2.nb)).all()
     held = capi.solve(capi.Context(capi.Plan(case2, elim_last=[5, 17, 60], debug=harness_debug()), 0, debug=harness_debug()), torch.tensor(p2, device=dev), torch.tensor(q2, device=dev))
     assert bool(held['converged'].all()) and np.abs(held['vm'].cpu().numpy() - got['vm']).max() < 1e-10
+
+
+@pytest.mark.parametrize('code', ['case9', 'hv-small'])
+def test_a_nan_reactive_injection_fails_the_solve_as_it_does_in_pypower(code):
+    """pypower's makeSbus builds P + 1j * Q: a NaN reactive injection makes the ACTIVE injection of its bus NaN too (1j * NaN is
+    NaN + NaN j), so the solve fails at a PQ bus and at a PV bus alike — although the Q mismatch of a PV bus is no equation of
+    the power flow; at a REF bus neither part is one, the solve converges (round 6: a NaN set-point of a controllable unit on a
+    regulated bus, from sqrt(max_s^2 - p^2) of voltage_control.py:123-125, made the kernel converge around it)."""
+    import torch
+    from opfgym_amd import capi, grids
+    from opfgym_amd.case import net_to_case
+    net, _ = (grids.case9(), None) if code == 'case9' else grids.get_grid(code)
+    case = net_to_case(net)
+    ctx = capi.Context(capi.Plan(case, debug=harness_debug()), 0, debug=harness_debug())
+    pv, pq, ref_ = (int(np.flatnonzero(case.bus_type == t)[0]) for t in (2, 1, 3))
+    p, q = random_injections(net, case, 4, 5)
+    for row, bus in ((1, pv), (2, pq), (3, ref_)):
+        q[row, bus] = np.nan
+    dev = torch.device('cuda:0')
+    out = {k: v.cpu().numpy() for k, v in capi.solve(ctx, torch.tensor(p, device=dev), torch.tensor(q, device=dev)).items()}
+    want = oracle_batch(net, case, p, q)['converged']
+    assert want.tolist() == [True, False, False, True]
+    assert out['converged'].astype(bool).tolist() == want.tolist()
+    assert np.isfinite(out['vm'][0]).all() and np.isfinite(out['vm'][3]).all()
