@@ -68,8 +68,9 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
       `_is_elements` zero rule of result rows                   tests/test_gpu_env.py::test_units_on_a_de_energised_island_cost_nothing
       DC start values                                            the converged solution does not depend on them; iteration counts
                                                                  against this oracle's own DC start only
-    Truly unreachable here (no number, no equivalent formulation through a pinned path): lines with g_us_per_km, transformer df,
-    a phase shifter given as tap_step_percent.
+      line conductance g_us_per_km (half at each end)            line_conductance_is_a_shunt_at_each_end
+      derating factors df of lines and transformers             derating_factor_scales_the_loading
+    Truly unreachable here (no number, no equivalent formulation through a pinned path): a phase shifter given as tap_step_percent.
   * the closed-form two-bus solution,
   * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
     (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to
