@@ -70,7 +70,8 @@ exists) is empty.  What pins this oracle (tests/test_oracle_pf.py, tests/test_pa
                                                                  against this oracle's own DC start only
       line conductance g_us_per_km (half at each end)            line_conductance_is_a_shunt_at_each_end
       derating factors df of lines and transformers             derating_factor_scales_the_loading
-    Truly unreachable here (no number, no equivalent formulation through a pinned path): a phase shifter given as tap_step_percent.
+      ideal phase shifter given as tap_step_percent              phase_shifter_given_in_percent_is_one_given_in_degrees (2 asin(du / 2))
+    With these, every formula of the converter is exercised by a recalled number or by an equivalence.
   * the closed-form two-bus solution,
   * published load-flow solutions of textbook systems: WSCC 9-bus (Anderson & Fouad), IEEE 14-bus
     (off-nominal taps, bus shunt, four PV buses; |V| to the three published decimals, angles to

@@ -246,6 +246,31 @@ def ideal_phase_shifter_is_a_changed_vector_group():
     return a, b, compare
 
 
+def phase_shifter_given_in_percent_is_one_given_in_degrees():
+    """An ideal phase shifter whose step is given as `tap_step_percent` (no `tap_step_degree`) turns the angle by 2 asin(du / 2),
+    du = tap_step_percent / 100 x (pos - neutral) (pandapower `_calc_tap_from_dataframe`): the same shifter given in degrees with
+    that angle per step — again in a loop with a plain transformer."""
+    def grid(**kw):
+        net, t = _two_winding_pair(shift_degree=0.0, **kw)
+        tr = dict(sn_mva=40.0, vn_hv_kv=110.0, vn_lv_kv=21.0, vk_percent=12.0, vkr_percent=0.35, pfe_kw=22.0, i0_percent=0.06, shift_degree=0.0)
+        N.create_transformer_from_parameters(net, int(net.trafo.hv_bus.iloc[0]), int(net.trafo.lv_bus.iloc[0]), **tr)
+        return N.finalize(net)
+    out = []
+    for side, pos in (('hv', 3), ('lv', -2)):
+        a = grid(tap_side=side, tap_neutral=0, tap_pos=pos, tap_step_percent=1.2, tap_phase_shifter=True)
+        angle = np.degrees(2.0 * np.arcsin(abs(0.012 * pos) / 2.0)) * np.sign(pos)
+        b = grid(tap_side=side, tap_neutral=0, tap_pos=pos, tap_step_percent=0.0, tap_step_degree=angle / pos, tap_phase_shifter=True)
+        out.append((a, b))
+    (a, b), (a2, b2) = out
+
+    def compare(ra, rb):
+        _compare_all(ra, rb)
+        ld = _col(ra, 'res_trafo', 'loading_percent')
+        assert abs(ld[0] - ld[1]) > 0.5                      # (a circulating flow: the shifter acts)
+    compare.second_pair = (a2, b2)
+    return a, b, compare
+
+
 def storage_is_a_load():
     """A storage unit enters the power flow as a load of its p_mw, q_mvar (x scaling): positive = charging = consumption."""
     a, _ = _two_winding_pair()
@@ -462,14 +487,14 @@ def bus_bus_switch_with_impedance_is_a_short_line():
     return a, b, compare
 
 
-CASES = {f.__name__: f for f in (line_conductance_is_a_shunt_at_each_end, derating_factor_scales_the_loading, ward_is_a_load_and_a_shunt, xward_is_a_ward_and_a_voltage_source_behind_an_impedance, dcline_is_two_generators, motor_is_a_load, symmetric_impedance_is_a_line_without_charging,
+CASES = {f.__name__: f for f in (phase_shifter_given_in_percent_is_one_given_in_degrees, line_conductance_is_a_shunt_at_each_end, derating_factor_scales_the_loading, ward_is_a_load_and_a_shunt, xward_is_a_ward_and_a_voltage_source_behind_an_impedance, dcline_is_two_generators, motor_is_a_load, symmetric_impedance_is_a_line_without_charging,
                                  bus_bus_switch_with_impedance_is_a_short_line,
                                  ideal_phase_shifter_is_a_changed_vector_group, storage_is_a_load, bus_bus_switch_is_one_bus, lv_side_tap_is_a_changed_lv_rating, hv_side_tap_is_a_changed_hv_rating,
                                  parallel_two_is_two_elements, vector_group_shift_turns_the_angles_behind_it,
                                  shunt_is_a_constant_impedance_load, two_ext_grids_at_one_set_point_are_a_fused_slack,
                                  open_bus_bus_switch_is_no_switch)}
 # pairs that must compile to the SAME bus admittance matrix in the product's converter (no solve needed to compare them)
-SAME_ADMITTANCES = ('line_conductance_is_a_shunt_at_each_end', 'derating_factor_scales_the_loading', 'ward_is_a_load_and_a_shunt', 'dcline_is_two_generators', 'motor_is_a_load', 'symmetric_impedance_is_a_line_without_charging',
+SAME_ADMITTANCES = ('phase_shifter_given_in_percent_is_one_given_in_degrees', 'line_conductance_is_a_shunt_at_each_end', 'derating_factor_scales_the_loading', 'ward_is_a_load_and_a_shunt', 'dcline_is_two_generators', 'motor_is_a_load', 'symmetric_impedance_is_a_line_without_charging',
                     'bus_bus_switch_with_impedance_is_a_short_line', 'ideal_phase_shifter_is_a_changed_vector_group', 'storage_is_a_load', 'lv_side_tap_is_a_changed_lv_rating', 'hv_side_tap_is_a_changed_hv_rating', 'parallel_two_is_two_elements',
                     'open_bus_bus_switch_is_no_switch', 'bus_bus_switch_is_one_bus')
 
